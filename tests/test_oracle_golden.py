@@ -1,0 +1,131 @@
+"""
+CPU tests: the oracle (oracle/*.py) against golden vectors recorded from the
+unmodified reference (tests/golden/make_golden.py).  This is what "pins" the
+oracle; the -m gpu tests then compare the HIP path with the oracle.
+"""
+import numpy as np
+import pytest
+
+from oracle import episode_info_oracle as eo
+from oracle import running_stats_oracle as rso
+
+
+def _g1_cases(g):
+    n = int(g["n_cases"][0])
+    for c in range(n):
+        p = g[f"c{c}_params"]
+        clip = None if np.isnan(p[3]) else (p[3], p[4])
+        yield c, dict(rewards=g[f"c{c}_rewards"], values=g[f"c{c}_values"],
+                      gamma=p[0], lambd=p[1], use_gae=bool(p[2]), clip=clip,
+                      ev=p[5], er=p[6]), g[f"c{c}_adv"], g[f"c{c}_rtg_np2"], g[f"c{c}_rtg_f64"]
+
+
+def test_g1_end_episode_exact(golden):
+    """end_episode: advantages bit-exact in f64; rtg bit-exact in both accumulator modes."""
+    g = golden("g1_end_episode")
+    n = 0
+    for c, k, adv, rtg_np2, rtg_f64 in _g1_cases(g):
+        a64, r64 = eo.end_episode(k["rewards"], k["values"], k["ev"], k["er"],
+                                  k["gamma"], k["lambd"], k["clip"], k["use_gae"], "float64")
+        a32, r32 = eo.end_episode(k["rewards"], k["values"], k["ev"], k["er"],
+                                  k["gamma"], k["lambd"], k["clip"], k["use_gae"], "float32")
+        np.testing.assert_array_equal(r64, rtg_f64, err_msg=f"case {c} rtg f64")
+        np.testing.assert_array_equal(r32, rtg_np2, err_msg=f"case {c} rtg np2/f32")
+        if k["use_gae"]:
+            np.testing.assert_array_equal(a64, adv, err_msg=f"case {c} adv")
+        else:
+            # non-GAE advantages inherit the rtg accumulator of the run that
+            # recorded them (NumPy 2 here -> float32 accumulation).
+            np.testing.assert_array_equal(a32, adv, err_msg=f"case {c} adv (rtg - V)")
+        n += 1
+    assert n == 288
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g2_dataset_order_and_values(golden, tag):
+    """Dense [T,E] rollout -> flattened dataset: ordering contract + adv/rtg/values."""
+    g = golden("g2_dataset")
+    pre = tag + "_"
+    rewards = g[pre + "in_rewards"]
+    values = g[pre + "in_values"]
+    boot = g[pre + "in_boot_v"]
+    end_kind = g[pre + "in_end_kind"]
+    extra = dict(obs=g[pre + "in_obs"][:-1], next_obs=g[pre + "in_obs"][1:],
+                 logp=g[pre + "in_logp"], actions=g[pre + "in_actions"])
+    d = eo.rollout_to_dataset(rewards, values, boot, boot, end_kind,
+                              rtg_accum="float32", extra=extra)
+    assert len(d["adv"]) == int(g[pre + "len"][0])
+    np.testing.assert_array_equal(d["ep_lens"], g[pre + "ep_lens"])
+    np.testing.assert_array_equal(d["obs"], g[pre + "obs"])
+    np.testing.assert_array_equal(d["next_obs"], g[pre + "next_obs"])
+    np.testing.assert_array_equal(d["actions"][:, None], g[pre + "actions"])
+    np.testing.assert_array_equal(d["logp"], g[pre + "logp"])
+    np.testing.assert_array_equal(d["values"], g[pre + "values"])
+    np.testing.assert_array_equal(d["adv"], g[pre + "adv"])
+    np.testing.assert_array_equal(d["rtg"], g[pre + "rtg"])
+    # fp64-accumulated rtg (the pinned-numpy semantic, the parity target) stays
+    # within float32 rounding of the NumPy-2 run.
+    d64 = eo.rollout_to_dataset(rewards, values, boot, boot, end_kind, rtg_accum="float64")
+    np.testing.assert_allclose(d64["rtg"], g[pre + "rtg"], rtol=2e-6, atol=2e-6)
+    # __getitem__ contract: index -> row of the flattened tensors
+    idx = int(g[pre + "item_idx"][0])
+    np.testing.assert_array_equal(d["obs"][idx], g[pre + "item_obs"])
+    assert d["adv"][idx] == g[pre + "item_adv"][0]
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g2_recalculate_advantages(golden, tag):
+    g = golden("g2_dataset")
+    pre = tag + "_"
+    rewards = g[pre + "in_rewards"]
+    boot = g[pre + "in_boot_v"]
+    end_kind = g[pre + "in_end_kind"]
+    d = eo.rollout_to_dataset(rewards, g[pre + "in_values"], boot, boot, end_kind,
+                              extra=dict(rewards=rewards))
+    ending_values = [0.0 if kind == 1 else float(boot[t1, e]) for (e, t0, t1, kind) in d["segs"]]
+    adv = eo.recalculate_advantages(d["rewards"], g[pre + "new_values"], d["ep_lens"],
+                                    ending_values)
+    np.testing.assert_array_equal(adv, g[pre + "adv_recalc"])
+
+
+def test_g3_shared_episode_layout(golden):
+    """AgentSharedEpisode stacking: [N, A, ...], episodes env-major, agents as columns."""
+    g = golden("g3_shared")
+    obs, rewards, values = g["in_obs"], g["in_rewards"], g["in_values"]
+    boot, logp, actions = g["in_boot"], g["in_logp"], g["in_actions"]
+    T, E, A = rewards.shape
+    adv = np.zeros((E * T, A), dtype=np.float32)
+    rtg = np.zeros((E * T, A), dtype=np.float32)
+    for e in range(E):
+        for a in range(A):
+            ad, rg = eo.end_episode(rewards[:, e, a], values[:, e, a], boot[e, a], boot[e, a],
+                                    0.99, 0.95, (-100.0, 100.0), True, "float32")
+            adv[e * T:(e + 1) * T, a] = ad
+            rtg[e * T:(e + 1) * T, a] = rg
+    np.testing.assert_array_equal(adv, g["adv"])
+    np.testing.assert_array_equal(rtg, g["rtg"])
+    exp_obs = np.concatenate([obs[:-1, e] for e in range(E)], axis=0)        # [E*T, A, O]
+    np.testing.assert_array_equal(exp_obs, g["obs"])
+    exp_vals = np.concatenate([values[:, e] for e in range(E)], axis=0)
+    np.testing.assert_array_equal(exp_vals, g["values"])
+    exp_lp = np.concatenate([logp[:, e] for e in range(E)], axis=0)
+    np.testing.assert_array_equal(exp_lp, g["logp"])
+    assert g["actions"].shape[:2] == (E * T, A)
+    assert int(g["len"][0]) == E * T
+
+
+def test_g4_running_mean_std(golden):
+    g = golden("g4_running_stats")
+    rs = rso.RunningMeanStd()
+    for i in range(4):
+        rs.update(g[f"s_batch{i}"])
+        exp = g[f"s_state{i}"]
+        assert np.float64(rs.mean) == exp[0]
+        assert np.float64(rs.variance) == exp[1]
+        assert rs.count == exp[2]
+    rv = rso.RunningMeanStd(shape=(6,))
+    for i in range(3):
+        rv.update(g[f"v_batch{i}"])
+        np.testing.assert_array_equal(np.asarray(rv.mean, dtype=np.float64), g[f"v_mean{i}"])
+        np.testing.assert_array_equal(np.asarray(rv.variance, dtype=np.float64), g[f"v_var{i}"])
+        assert rv.count == g[f"v_count{i}"][0]
