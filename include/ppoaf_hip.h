@@ -1,0 +1,264 @@
+/*
+ * ppoaf_hip.h -- C ABI of libppoaf_hip.so, the MI355X (gfx950) hot path that
+ * stands in for LLNL/ppo_and_friends' rollout-buffer + PPO-update arithmetic.
+ *
+ * The reference is pure Python (no FFI of its own); every entry point below
+ * replaces a chain of NumPy / PyTorch ops or a Python loop, cited per function
+ * as /root/reference-relative file:line.  The Python host (ppo_and_friends_amd/)
+ * binds these with ctypes; INTEGRATION.md shows the stub a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed from the caller (torch tensor
+ *     .data_ptr()); the caller owns the memory; nothing is allocated here except
+ *     the small per-process scratch noted on individual calls;
+ *   - the last argument is the hipStream_t to enqueue on (NULL = default
+ *     stream); calls are asynchronous on that stream and never synchronise, so
+ *     they are hipGraph-capturable;
+ *   - return 0 on success, <0 on error (PPOAF_E_*); ppoaf_last_error() returns
+ *     a thread-local message;
+ *   - shapes are checked on the host before any launch; no kernel is launched
+ *     with a shape it does not handle;
+ *   - single Python thread per rank issues the calls; the library keeps no
+ *     host threads.
+ */
+#ifndef PPOAF_HIP_H
+#define PPOAF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ppoaf_stream_t;            /* hipStream_t */
+
+#define PPOAF_OK            0
+#define PPOAF_E_INVALID    -1            /* bad argument / unsupported shape   */
+#define PPOAF_E_LAUNCH     -2            /* hipLaunch / runtime error          */
+
+#define PPOAF_ABI_VERSION   1
+
+int         ppoaf_abi_version(void);
+const char* ppoaf_last_error(void);
+/* Number of CUs of the current device (used by the host to size grids in tests). */
+int         ppoaf_device_cu_count(void);
+
+/* ------------------------------------------------------------------------ *
+ * K1  GAE advantages + rewards-to-go
+ * replaces EpisodeInfo.end_episode / compute_discounted_sums /
+ *          _compute_gae_advantages   utils/episode_info.py:223-293,419-465
+ * Numerics: delta = r + f64(fl32(gamma*V[t+1])) - V[t]; both scans accumulate
+ * in float64 (the reference's accumulator under its pinned numpy<1.24), results
+ * rounded once to float32 (PPODataset.build's float32 cast, :868-887).
+ * ending_reward is clipped to [clip_lo, clip_hi] when has_clip (:450-454) and
+ * rounded to float32 (:456-457); ending_value is NOT clipped (:410-411).
+ * use_gae == 0  ->  advantages = rtg - V (:295-301).
+ * ------------------------------------------------------------------------ */
+
+/* Dense time-major rollout buffer [T,E] (E contiguous): the build's native
+ * layout.  end_kind[t,e]: 0 = episode continues into t+1, 1 = terminal end
+ * (ending value/reward 0, ppo.py:1818-1819), 2 = bootstrapped end (ending
+ * value = boot_value[t,e], ending reward = boot_reward[t,e]; ppo.py:1932-1938).
+ * Row T-1 must be non-zero everywhere (ppo.py:1870-1871) -- when end_kind is
+ * NULL the trajectories are fixed-length: only row T-1 ends, bootstrapped, and
+ * boot_value / boot_reward are [E] arrays.  Otherwise they are [T,E] and read
+ * only where end_kind == 2. */
+int ppoaf_gae_rtg_tmajor(const float* rewards, const float* values,
+                         const float* boot_value, const float* boot_reward,
+                         const int8_t* end_kind,
+                         int32_t T, int64_t E,
+                         double gamma, double lambd,
+                         int has_clip, double clip_lo, double clip_hi,
+                         int use_gae,
+                         float* adv_out, float* rtg_out,
+                         ppoaf_stream_t stream);
+
+/* Ragged trajectory list over a flat episode-major [N] layout (the layout
+ * PPODataset.build produces, utils/episode_info.py:745-914): trajectory i
+ * covers [traj_start[i], traj_start[i] + traj_len[i]).  Used for the
+ * EpisodeInfo-level drop-in and PPODataset.recalculate_advantages (:721-743;
+ * pass rtg_out = NULL there: rtg is not recomputed by the reference). */
+int ppoaf_gae_rtg_traj(const float* rewards, const float* values,
+                       const float* ending_value, const float* ending_reward,
+                       const int64_t* traj_start, const int32_t* traj_len,
+                       int64_t n_traj,
+                       double gamma, double lambd,
+                       int has_clip, double clip_lo, double clip_hi,
+                       int use_gae,
+                       float* adv_out, float* rtg_out,
+                       ppoaf_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * K2+K3  mini-batch advantage normalisation + PPO loss, forward and backward
+ * replaces PPO._ppo_batch_train  ppo.py:2325-2333 (normalise), 2352-2438 (loss)
+ *
+ * Inputs are length-B float32 streams.  adv is the RAW advantage; when
+ * normalize_adv it is replaced by (adv-mean)/(unbiased_std+1e-8) (ppo.py:2326-2333).
+ * Outputs:
+ *   scalars[0] actor surrogate loss  mean(-min(surr1,surr2))        ppo.py:2392
+ *   scalars[1] total actor loss = [0] - w_ent*mean(H) + kl_w*kl     ppo.py:2395-2405
+ *   scalars[2] critic loss (MSE, or Huber(delta) if use_huber)      ppo.py:2416-2419
+ *   scalars[3] mean entropy                                         ppo.py:2396
+ *   scalars[4] kl = mean(old_logp - cur_logp)                       ppo.py:2358
+ *   scalars[5] advantage mean, scalars[6] advantage unbiased std
+ *   scalars[7] 1.0 if any ratio is NaN/Inf (ppo.py:2361), else 0.0
+ *   d_logp[B], d_entropy[B]  = d scalars[1] / d cur_logp, / d entropy
+ *   d_values[B]              = d scalars[2] / d values
+ * The kl_loss_weight term carries no gradient (ppo.py:2403-2405 adds a Python
+ * float).  The entropy term is skipped when entropy_weight == 0 (ppo.py:2395).
+ * The vf_clip branch of the reference raises AttributeError (ppo.py:2432) and
+ * is not reproduced.  Any gradient pointer may be NULL (forward only).
+ * ------------------------------------------------------------------------ */
+int ppoaf_ppo_loss_fwd_bwd(const float* cur_logp, const float* old_logp,
+                           const float* adv, const float* entropy,
+                           const float* values, const float* rtg,
+                           int64_t B,
+                           int normalize_adv, float surr_clip,
+                           float entropy_weight, float kl_loss_weight,
+                           int use_huber, float huber_delta,
+                           float* scalars /* [8] */,
+                           float* d_logp, float* d_entropy, float* d_values,
+                           ppoaf_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * K4  mini-batch gather
+ * replaces DataLoader(shuffle=True) + PPODataset.__getitem__ + default collate
+ *          ppo.py:2181-2184,2292-2295; utils/episode_info.py:922-952
+ * For b in [0,B): row = perm[b]; if row_map: row = row_map[row];
+ *                 dst_f[b, :] = src_f[row, :]  for every field f.
+ * row_map maps a position in the reference's flattened episode-major order to
+ * the row of the time-major [T*E] buffer (NULL = identity).  Up to
+ * PPOAF_MAX_GATHER_FIELDS fields per launch; row_bytes must be a multiple of 4.
+ * ------------------------------------------------------------------------ */
+#define PPOAF_MAX_GATHER_FIELDS 8
+typedef struct {
+    const void* src;        /* [n_rows, row_bytes] */
+    void*       dst;        /* [B, row_bytes]      */
+    int32_t     row_bytes;
+    int32_t     _pad;
+} ppoaf_gather_field_t;
+
+int ppoaf_minibatch_gather(const ppoaf_gather_field_t* fields /* host array */,
+                           int32_t n_fields,
+                           const int64_t* perm, const int32_t* row_map,
+                           int64_t n_rows, int64_t B,
+                           ppoaf_stream_t stream);
+
+/* Scatter of the freshly evaluated critic values back into the dataset
+ * (ppo.py:2340  dataset.values[batch_idxs] = values.detach()). */
+int ppoaf_scatter_rows_f32(const float* src /* [B] */, const int64_t* perm,
+                           const int32_t* row_map, int64_t n_rows, int64_t B,
+                           float* dst /* [n_rows] */, ppoaf_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * K5  running mean / variance (value, observation and reward normalisers)
+ * replaces RunningMeanStd.update/_integrate_batch_data  utils/stats.py:29-94
+ *          RunningStatNormalizer.normalize/denormalize  utils/misc.py:84-128
+ * State lives on the device: mean[W], var[W] float32, count[1] float64
+ * (initialise mean 0, var 1, count 1e-4: stats.py:25-27).
+ * ------------------------------------------------------------------------ */
+
+/* moments_out[0] = n, [1..W] = batch mean, [1+W..2W] = batch M2 = sum (x-mean)^2,
+ * all float64; data is [n, W] float32 row-major. */
+int ppoaf_batch_moments(const float* data, int64_t n, int32_t W,
+                        double* moments_out /* [1+2W] */, ppoaf_stream_t stream);
+
+/* Merge R per-rank moment records (concatenated, [R, 1+2W]; R = 1 on a single
+ * rank; more after an all-gather -- equal to the reference's allgather of the
+ * raw data, stats.py:47-50) into one batch (Chan), then integrate that batch
+ * into the running state exactly as stats.py:73-94 does. */
+int ppoaf_running_moments_integrate(const double* moments, int32_t R, int32_t W,
+                                    float* mean, float* var, double* count,
+                                    ppoaf_stream_t stream);
+
+/* out = (x - mean) / sqrt(var + eps)   misc.py:106-111 ; x is [n, W] */
+int ppoaf_normalize(const float* x, int64_t n, int32_t W,
+                    const float* mean, const float* var, float eps,
+                    float clip_lo, float clip_hi, int has_clip,
+                    float* out, ppoaf_stream_t stream);
+/* out = mean + x * sqrt(var + eps)     misc.py:124-128 */
+int ppoaf_denormalize(const float* x, int64_t n, int32_t W,
+                      const float* mean, const float* var, float eps,
+                      float* out, ppoaf_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * K6  action distributions
+ * replaces CategoricalDistribution / GaussianDistribution
+ *          networks/distributions.py:199-269, 441-694 and
+ *          PPOPolicy.get_rollout_actions / evaluate  policies/ppo_policy.py:729-794,891-952
+ * Categorical(probs) semantics of torch.distributions: probs renormalised by
+ * their sum, logits = log(clamp(probs, eps, 1-eps)) with eps = FLT_EPSILON.
+ * ------------------------------------------------------------------------ */
+
+/* Rollout: logits [n,K] -> softmax -> sample (Philox4x32-10 keyed by seed,
+ * counter = offset + row) -> log-prob of the sample.  probs_out may be NULL. */
+int ppoaf_categorical_sample(const float* logits, int64_t n, int32_t K,
+                             uint64_t seed, uint64_t offset,
+                             int64_t* action_out, float* logp_out,
+                             float* probs_out, ppoaf_stream_t stream);
+
+/* Update: logits [n,K], actions [n] -> logp[n], entropy[n] (+ probs for bwd). */
+int ppoaf_categorical_eval_fwd(const float* logits, const int64_t* actions,
+                               int64_t n, int32_t K,
+                               float* logp_out, float* entropy_out,
+                               float* probs_out, ppoaf_stream_t stream);
+/* d_logits[n,K] from d_logp[n], d_entropy[n] (either may be NULL = zeros). */
+int ppoaf_categorical_eval_bwd(const float* probs, const int64_t* actions,
+                               const float* d_logp, const float* d_entropy,
+                               int64_t n, int32_t K,
+                               float* d_logits, ppoaf_stream_t stream);
+
+/* Gaussian with tanh squashing (distributions.py:441-694):
+ *   std = max(softplus(log_std), min_std)                         :514-516
+ *   logp = sum_d clamp(N(mean,std).log_prob(x), -100, 100)
+ *          - sum_d log(clamp(1 - tanh(x)^2, 1e-6, inf))            :551-558
+ *   entropy = -logp                                               :694
+ * mean, x: [n,D]; log_std: [D]. */
+int ppoaf_gaussian_tanh_eval_fwd(const float* mean, const float* log_std,
+                                 const float* x, int64_t n, int32_t D,
+                                 float min_std,
+                                 float* logp_out, float* entropy_out,
+                                 ppoaf_stream_t stream);
+/* d_mean[n,D], d_log_std[D] (accumulated over rows; zeroed by the call) from
+ * d_logp[n] and d_entropy[n] (entropy = -logp so they fold together). */
+int ppoaf_gaussian_tanh_eval_bwd(const float* mean, const float* log_std,
+                                 const float* x, const float* d_logp,
+                                 const float* d_entropy, int64_t n, int32_t D,
+                                 float min_std,
+                                 float* d_mean, float* d_log_std,
+                                 ppoaf_stream_t stream);
+/* Rollout: raw = mean + std * N(0,1) (Philox), action = tanh(raw) rescaled to
+ * [act_lo, act_hi] (:580-609, :645-672), logp as above. */
+int ppoaf_gaussian_tanh_sample(const float* mean, const float* log_std,
+                               int64_t n, int32_t D, float min_std,
+                               float act_lo, float act_hi,
+                               uint64_t seed, uint64_t offset,
+                               float* raw_out, float* action_out,
+                               float* logp_out, ppoaf_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * K11  flat-bucket gradient clip + Adam
+ * replaces PPOPolicy.update_weights' clip_grad_norm_ + Adam.step
+ *          policies/ppo_policy.py:1037-1042,1050-1055 (Adam eps 1e-5 :336-339)
+ *          and the 1/num_procs of mpi_avg  utils/mpi_utils.py:86
+ * params/grads/exp_avg/exp_avg_sq are flat float32 buckets of n elements.
+ * grad_scale multiplies the gradient first (1/world_size after a SUM
+ * all-reduce).  max_norm <= 0 disables clipping; otherwise
+ * coef = min(1, max_norm / (||grad_scale*g||_2 + 1e-6)) as torch does.
+ * step_count is the 1-based Adam step kept on the device (int64[1],
+ * incremented by the call) so the launch is graph-replayable.
+ * norm_scratch: float64[1] device scratch owned by the caller.
+ * ------------------------------------------------------------------------ */
+int ppoaf_clip_adam_step(float* params, const float* grads,
+                         float* exp_avg, float* exp_avg_sq, int64_t n,
+                         int64_t* step_count, const float* lr /* device [1] */,
+                         float beta1, float beta2, float eps,
+                         float grad_scale, float max_norm,
+                         double* norm_scratch, float* grad_norm_out /* NULL ok */,
+                         ppoaf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPOAF_HIP_H */

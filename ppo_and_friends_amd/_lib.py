@@ -1,0 +1,132 @@
+"""
+ctypes binding of libppoaf_hip.so (include/ppoaf_hip.h).
+
+There is NO fallback: if the library is missing, cannot be loaded, or a call
+returns an error, this module raises.  The product path never computes the hot
+path anywhere else.
+
+torch is imported first so that the library's NEEDED libamdhip64.so.7 resolves
+to the HIP runtime torch already loaded (same SONAME) -- one runtime per
+process, so torch's streams and device pointers are valid in our launches.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libppoaf_hip.so")
+
+MAX_GATHER_FIELDS = 8
+
+_f32p = C.c_void_p
+_ptr = C.c_void_p
+
+
+class GatherField(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p),
+                ("row_bytes", C.c_int32), ("_pad", C.c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/ppoaf_hip.h one to one.
+SIGNATURES = {
+    "ppoaf_abi_version": (C.c_int, []),
+    "ppoaf_last_error": (C.c_char_p, []),
+    "ppoaf_device_cu_count": (C.c_int, []),
+    "ppoaf_gae_rtg_tmajor": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_int32, C.c_int64,
+                                       C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
+                                       C.c_int, _ptr, _ptr, _ptr]),
+    "ppoaf_gae_rtg_traj": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64,
+                                     C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
+                                     C.c_int, _ptr, _ptr, _ptr]),
+    "ppoaf_ppo_loss_fwd_bwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64,
+                                         C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
+                                         C.c_float, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "ppoaf_minibatch_gather": (C.c_int, [C.POINTER(GatherField), C.c_int32, _ptr, _ptr,
+                                         C.c_int64, C.c_int64, _ptr]),
+    "ppoaf_scatter_rows_f32": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int64, _ptr, _ptr]),
+    "ppoaf_batch_moments": (C.c_int, [_ptr, C.c_int64, C.c_int32, _ptr, _ptr]),
+    "ppoaf_running_moments_integrate": (C.c_int, [_ptr, C.c_int32, C.c_int32, _ptr, _ptr, _ptr, _ptr]),
+    "ppoaf_normalize": (C.c_int, [_ptr, C.c_int64, C.c_int32, _ptr, _ptr, C.c_float,
+                                  C.c_float, C.c_float, C.c_int, _ptr, _ptr]),
+    "ppoaf_denormalize": (C.c_int, [_ptr, C.c_int64, C.c_int32, _ptr, _ptr, C.c_float, _ptr, _ptr]),
+    "ppoaf_categorical_sample": (C.c_int, [_ptr, C.c_int64, C.c_int32, C.c_uint64, C.c_uint64,
+                                           _ptr, _ptr, _ptr, _ptr]),
+    "ppoaf_categorical_eval_fwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, _ptr, _ptr, _ptr, _ptr]),
+    "ppoaf_categorical_eval_bwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, C.c_int32, _ptr, _ptr]),
+    "ppoaf_gaussian_tanh_eval_fwd": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int32, C.c_float,
+                                               _ptr, _ptr, _ptr]),
+    "ppoaf_gaussian_tanh_eval_bwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64, C.c_int32,
+                                               C.c_float, _ptr, _ptr, _ptr]),
+    "ppoaf_gaussian_tanh_sample": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, C.c_float, C.c_float,
+                                             C.c_float, C.c_uint64, C.c_uint64, _ptr, _ptr, _ptr, _ptr]),
+    "ppoaf_clip_adam_step": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr, _ptr,
+                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       _ptr, _ptr, _ptr]),
+}
+
+_lib = None
+
+
+class PpoafError(RuntimeError):
+    pass
+
+
+def _check_single_hip_runtime():
+    seen = set()
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                if "libamdhip64" in line:
+                    seen.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        return
+    if len(seen) > 1:
+        raise PpoafError(f"two HIP runtimes are mapped in this process: {sorted(seen)}; "
+                         "libppoaf_hip.so must share torch's libamdhip64")
+
+
+def load():
+    """Load (once) and type the library.  Raises PpoafError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PpoafError(
+            f"{LIB_PATH} is missing: build it with `python -m ppo_and_friends_amd.csrc.build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise PpoafError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ppoaf_abi_version() != 1:
+        raise PpoafError(f"ABI version mismatch: library {lib.ppoaf_abi_version()} != 1")
+    _check_single_hip_runtime()
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ppoaf_last_error().decode("utf-8", "replace")
+        raise PpoafError(f"{what or 'libppoaf_hip'} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Requires contiguous CUDA/HIP memory."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PpoafError("libppoaf_hip needs device tensors (got a CPU tensor); no CPU fallback exists")
+    if not t.is_contiguous():
+        raise PpoafError("libppoaf_hip needs contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    """Current torch HIP stream as a hipStream_t."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,312 @@
+"""
+Tensor-level wrappers over the C ABI (include/ppoaf_hip.h).
+
+Every function validates shapes / dtypes / devices on the host BEFORE the
+launch (a kernel is never started on operands it was not written for), then
+enqueues on torch's current HIP stream.  Nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import PpoafError, check, ptr, stream
+
+
+def _req(cond, msg):
+    if not cond:
+        raise PpoafError(msg)
+
+
+def _f32(t, name):
+    _req(t.dtype == torch.float32, f"{name}: expected float32, got {t.dtype}")
+    return t
+
+
+def _clip_args(bootstrap_clip):
+    if bootstrap_clip is None:
+        return 0, 0.0, 0.0
+    return 1, float(bootstrap_clip[0]), float(bootstrap_clip[1])
+
+
+# --------------------------------------------------------------------------
+# K1
+# --------------------------------------------------------------------------
+def gae_rtg_tmajor(rewards, values, boot_value, boot_reward, end_kind=None,
+                   gamma=0.99, lambd=0.95, bootstrap_clip=(-100.0, 100.0),
+                   use_gae=True, adv_out=None, rtg_out=None):
+    """[T,E] time-major GAE + rewards-to-go (utils/episode_info.py:419-465)."""
+    _req(rewards.dim() == 2, "rewards must be [T,E]")
+    T, E = rewards.shape
+    _f32(rewards, "rewards"); _f32(values, "values")
+    _f32(boot_value, "boot_value"); _f32(boot_reward, "boot_reward")
+    _req(values.shape == (T, E), "values must be [T,E]")
+    if end_kind is None:
+        _req(boot_value.numel() == E and boot_reward.numel() == E,
+             "fixed-length form: boot_value / boot_reward must be [E]")
+    else:
+        _req(end_kind.dtype == torch.int8 and end_kind.shape == (T, E), "end_kind must be int8 [T,E]")
+        _req(boot_value.shape == (T, E) and boot_reward.shape == (T, E),
+             "dense form: boot_value / boot_reward must be [T,E]")
+    if adv_out is None:
+        adv_out = torch.empty_like(rewards)
+    if rtg_out is None:
+        rtg_out = torch.empty_like(rewards)
+    _req(adv_out.shape == (T, E) and rtg_out.shape == (T, E), "outputs must be [T,E]")
+    _f32(adv_out, "adv_out"); _f32(rtg_out, "rtg_out")
+    hc, lo, hi = _clip_args(bootstrap_clip)
+    check(_lib.load().ppoaf_gae_rtg_tmajor(
+        ptr(rewards), ptr(values), ptr(boot_value), ptr(boot_reward), ptr(end_kind),
+        T, E, float(gamma), float(lambd), hc, lo, hi, int(bool(use_gae)),
+        ptr(adv_out), ptr(rtg_out), stream()), "gae_rtg_tmajor")
+    return adv_out, rtg_out
+
+
+def gae_rtg_traj(rewards, values, ending_value, ending_reward, traj_start, traj_len,
+                 gamma=0.99, lambd=0.95, bootstrap_clip=(-100.0, 100.0), use_gae=True,
+                 adv_out=None, rtg_out=None, compute_rtg=True):
+    """Flat episode-major [N] trajectories (one wave each)."""
+    N = rewards.numel()
+    n_traj = traj_start.numel()
+    _f32(rewards, "rewards"); _f32(values, "values")
+    _f32(ending_value, "ending_value"); _f32(ending_reward, "ending_reward")
+    _req(values.numel() == N, "values must match rewards")
+    _req(traj_start.dtype == torch.int64 and traj_len.dtype == torch.int32,
+         "traj_start int64 / traj_len int32")
+    _req(traj_len.numel() == n_traj and ending_value.numel() == n_traj
+         and ending_reward.numel() == n_traj, "per-trajectory arrays must have n_traj entries")
+    if n_traj:
+        # bounds are validated on the host: a bad trajectory table must never reach the kernel
+        ends = traj_start + traj_len.to(torch.int64)
+        _req(int(traj_start.min()) >= 0 and int(ends.max()) <= N and int(traj_len.min()) >= 0,
+             "trajectory table exceeds the flat buffer")
+    if adv_out is None:
+        adv_out = torch.zeros_like(rewards)
+    if rtg_out is None and (compute_rtg or not use_gae):
+        rtg_out = torch.zeros_like(rewards)
+    hc, lo, hi = _clip_args(bootstrap_clip)
+    check(_lib.load().ppoaf_gae_rtg_traj(
+        ptr(rewards), ptr(values), ptr(ending_value), ptr(ending_reward), ptr(traj_start),
+        ptr(traj_len), n_traj, float(gamma), float(lambd), hc, lo, hi, int(bool(use_gae)),
+        ptr(adv_out), ptr(rtg_out), stream()), "gae_rtg_traj")
+    return adv_out, rtg_out
+
+
+# --------------------------------------------------------------------------
+# K2 + K3
+# --------------------------------------------------------------------------
+SC_SURR, SC_ACTOR, SC_CRITIC, SC_ENTROPY, SC_KL, SC_ADV_MEAN, SC_ADV_STD, SC_BAD = range(8)
+
+
+def ppo_loss_fwd_bwd(cur_logp, old_logp, adv, entropy, values, rtg, normalize_adv=True,
+                     surr_clip=0.2, entropy_weight=0.01, kl_loss_weight=0.0, use_huber=False,
+                     huber_delta=10.0, scalars=None, d_logp=None, d_entropy=None, d_values=None,
+                     need_grads=True):
+    B = cur_logp.numel()
+    for n, t in (("cur_logp", cur_logp), ("old_logp", old_logp), ("adv", adv),
+                 ("values", values), ("rtg", rtg)):
+        _f32(t, n)
+        _req(t.numel() == B, f"{n}: expected {B} elements, got {t.numel()}")
+    if entropy is not None:
+        _f32(entropy, "entropy")
+        _req(entropy.numel() == B, "entropy length")
+    dev = cur_logp.device
+    if scalars is None:
+        scalars = torch.empty(8, dtype=torch.float32, device=dev)
+    _req(scalars.numel() == 8 and scalars.dtype == torch.float32, "scalars must be float32[8]")
+    if need_grads:
+        d_logp = torch.empty(B, dtype=torch.float32, device=dev) if d_logp is None else d_logp
+        d_entropy = torch.empty(B, dtype=torch.float32, device=dev) if d_entropy is None else d_entropy
+        d_values = torch.empty(B, dtype=torch.float32, device=dev) if d_values is None else d_values
+        for n, t in (("d_logp", d_logp), ("d_entropy", d_entropy), ("d_values", d_values)):
+            _req(t.numel() == B and t.dtype == torch.float32, f"{n} must be float32[{B}]")
+    check(_lib.load().ppoaf_ppo_loss_fwd_bwd(
+        ptr(cur_logp), ptr(old_logp), ptr(adv), ptr(entropy), ptr(values), ptr(rtg), B,
+        int(bool(normalize_adv)), float(surr_clip), float(entropy_weight), float(kl_loss_weight),
+        int(bool(use_huber)), float(huber_delta), ptr(scalars), ptr(d_logp), ptr(d_entropy),
+        ptr(d_values), stream()), "ppo_loss_fwd_bwd")
+    return scalars, d_logp, d_entropy, d_values
+
+
+# --------------------------------------------------------------------------
+# K4
+# --------------------------------------------------------------------------
+def minibatch_gather(pairs, perm, row_map=None):
+    """pairs: list of (src [n_rows, ...], dst [B, ...]); rows picked by perm (int64 [B])."""
+    _req(1 <= len(pairs) <= _lib.MAX_GATHER_FIELDS, "1..8 fields per gather launch")
+    _req(perm.dtype == torch.int64 and perm.dim() == 1, "perm must be int64 [B]")
+    B = perm.numel()
+    if row_map is not None:
+        _req(row_map.dtype == torch.int32, "row_map must be int32")
+        n_rows = row_map.numel()
+    else:
+        n_rows = pairs[0][0].shape[0]
+    arr = (_lib.GatherField * len(pairs))()
+    for i, (src, dst) in enumerate(pairs):
+        _req(src.dtype == dst.dtype, f"field {i}: dtype mismatch")
+        rb = src[0].numel() * src.element_size() if src.shape[0] else 0
+        _req(rb > 0 and rb % 4 == 0, f"field {i}: row bytes {rb} must be a positive multiple of 4")
+        _req(dst.shape[0] == B and dst[0].numel() * dst.element_size() == rb,
+             f"field {i}: dst must be [B, same row]")
+        if row_map is None:
+            _req(src.shape[0] == n_rows, f"field {i}: row count mismatch")
+        arr[i].src = src.data_ptr()
+        arr[i].dst = dst.data_ptr()
+        arr[i].row_bytes = rb
+        ptr(src); ptr(dst)      # device / contiguity checks
+    check(_lib.load().ppoaf_minibatch_gather(arr, len(pairs), ptr(perm), ptr(row_map),
+                                             n_rows, B, stream()), "minibatch_gather")
+
+
+def scatter_rows_f32(src, perm, dst, row_map=None):
+    B = perm.numel()
+    _req(src.numel() == B and src.dtype == torch.float32 and dst.dtype == torch.float32,
+         "scatter_rows_f32: src float32[B], dst float32[n_rows]")
+    n_rows = row_map.numel() if row_map is not None else dst.numel()
+    check(_lib.load().ppoaf_scatter_rows_f32(ptr(src), ptr(perm), ptr(row_map), n_rows, B,
+                                             ptr(dst), stream()), "scatter_rows_f32")
+
+
+# --------------------------------------------------------------------------
+# K5
+# --------------------------------------------------------------------------
+def batch_moments(data, W=1, out=None):
+    _f32(data, "data")
+    n = data.numel() // W
+    _req(n * W == data.numel() and n >= 1, "data must be [n, W] with n >= 1")
+    if out is None:
+        out = torch.empty(1 + 2 * W, dtype=torch.float64, device=data.device)
+    _req(out.dtype == torch.float64 and out.numel() == 1 + 2 * W, "moments must be float64[1+2W]")
+    check(_lib.load().ppoaf_batch_moments(ptr(data), n, W, ptr(out), stream()), "batch_moments")
+    return out
+
+
+def running_moments_integrate(moments, mean, var, count):
+    W = mean.numel()
+    _req(moments.dtype == torch.float64 and moments.numel() % (1 + 2 * W) == 0,
+         "moments must be float64[R, 1+2W]")
+    R = moments.numel() // (1 + 2 * W)
+    _req(mean.dtype == torch.float32 and var.dtype == torch.float32 and var.numel() == W
+         and count.dtype == torch.float64 and count.numel() == 1, "state dtypes/shapes")
+    check(_lib.load().ppoaf_running_moments_integrate(ptr(moments), R, W, ptr(mean), ptr(var),
+                                                      ptr(count), stream()),
+          "running_moments_integrate")
+
+
+def normalize(x, mean, var, eps=1e-8, clip=None, out=None):
+    _f32(x, "x")
+    W = mean.numel()
+    _req(x.numel() % W == 0, "x must be [n, W]")
+    out = torch.empty_like(x) if out is None else out
+    hc, lo, hi = (0, 0.0, 0.0) if clip is None else (1, float(clip[0]), float(clip[1]))
+    check(_lib.load().ppoaf_normalize(ptr(x), x.numel() // W, W, ptr(mean), ptr(var), float(eps),
+                                      lo, hi, hc, ptr(out), stream()), "normalize")
+    return out
+
+
+def denormalize(x, mean, var, eps=1e-8, out=None):
+    _f32(x, "x")
+    W = mean.numel()
+    _req(x.numel() % W == 0, "x must be [n, W]")
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().ppoaf_denormalize(ptr(x), x.numel() // W, W, ptr(mean), ptr(var), float(eps),
+                                        ptr(out), stream()), "denormalize")
+    return out
+
+
+# --------------------------------------------------------------------------
+# K6
+# --------------------------------------------------------------------------
+def categorical_sample(logits, seed, offset, action_out=None, logp_out=None, probs_out=None):
+    _f32(logits, "logits")
+    _req(logits.dim() == 2, "logits must be [n,K]")
+    n, K = logits.shape
+    dev = logits.device
+    action_out = torch.empty(n, dtype=torch.int64, device=dev) if action_out is None else action_out
+    logp_out = torch.empty(n, dtype=torch.float32, device=dev) if logp_out is None else logp_out
+    _req(action_out.dtype == torch.int64 and action_out.numel() == n, "action_out int64[n]")
+    _req(logp_out.dtype == torch.float32 and logp_out.numel() == n, "logp_out float32[n]")
+    check(_lib.load().ppoaf_categorical_sample(ptr(logits), n, K, int(seed), int(offset),
+                                               ptr(action_out), ptr(logp_out), ptr(probs_out),
+                                               stream()), "categorical_sample")
+    return action_out, logp_out
+
+
+def categorical_eval_fwd(logits, actions, want_probs=True):
+    _f32(logits, "logits")
+    n, K = logits.shape
+    _req(actions.dtype == torch.int64 and actions.numel() == n, "actions must be int64[n]")
+    dev = logits.device
+    logp = torch.empty(n, dtype=torch.float32, device=dev)
+    ent = torch.empty(n, dtype=torch.float32, device=dev)
+    probs = torch.empty(n, K, dtype=torch.float32, device=dev) if want_probs else None
+    check(_lib.load().ppoaf_categorical_eval_fwd(ptr(logits), ptr(actions), n, K, ptr(logp),
+                                                 ptr(ent), ptr(probs), stream()),
+          "categorical_eval_fwd")
+    return logp, ent, probs
+
+
+def categorical_eval_bwd(probs, actions, d_logp, d_entropy):
+    n, K = probs.shape
+    d_logits = torch.empty_like(probs)
+    check(_lib.load().ppoaf_categorical_eval_bwd(ptr(probs), ptr(actions), ptr(d_logp),
+                                                 ptr(d_entropy), n, K, ptr(d_logits), stream()),
+          "categorical_eval_bwd")
+    return d_logits
+
+
+def gaussian_tanh_eval_fwd(mean, log_std, x, min_std=0.01):
+    _f32(mean, "mean"); _f32(log_std, "log_std"); _f32(x, "x")
+    n, D = mean.shape
+    _req(x.shape == (n, D) and log_std.numel() == D, "x [n,D], log_std [D]")
+    logp = torch.empty(n, dtype=torch.float32, device=mean.device)
+    ent = torch.empty(n, dtype=torch.float32, device=mean.device)
+    check(_lib.load().ppoaf_gaussian_tanh_eval_fwd(ptr(mean), ptr(log_std), ptr(x), n, D,
+                                                   float(min_std), ptr(logp), ptr(ent), stream()),
+          "gaussian_tanh_eval_fwd")
+    return logp, ent
+
+
+def gaussian_tanh_eval_bwd(mean, log_std, x, d_logp, d_entropy, min_std=0.01):
+    n, D = mean.shape
+    d_mean = torch.empty_like(mean)
+    d_log_std = torch.empty_like(log_std)
+    check(_lib.load().ppoaf_gaussian_tanh_eval_bwd(ptr(mean), ptr(log_std), ptr(x), ptr(d_logp),
+                                                   ptr(d_entropy), n, D, float(min_std),
+                                                   ptr(d_mean), ptr(d_log_std), stream()),
+          "gaussian_tanh_eval_bwd")
+    return d_mean, d_log_std
+
+
+def gaussian_tanh_sample(mean, log_std, seed, offset, min_std=0.01, act_lo=-1.0, act_hi=1.0):
+    _f32(mean, "mean"); _f32(log_std, "log_std")
+    n, D = mean.shape
+    raw = torch.empty_like(mean)
+    act = torch.empty_like(mean)
+    logp = torch.empty(n, dtype=torch.float32, device=mean.device)
+    check(_lib.load().ppoaf_gaussian_tanh_sample(ptr(mean), ptr(log_std), n, D, float(min_std),
+                                                 float(act_lo), float(act_hi), int(seed),
+                                                 int(offset), ptr(raw), ptr(act), ptr(logp),
+                                                 stream()), "gaussian_tanh_sample")
+    return raw, act, logp
+
+
+# --------------------------------------------------------------------------
+# K11
+# --------------------------------------------------------------------------
+def clip_adam_step(params, grads, exp_avg, exp_avg_sq, step_count, lr, norm_scratch,
+                   beta1=0.9, beta2=0.999, eps=1e-5, grad_scale=1.0, max_norm=0.5,
+                   grad_norm_out=None):
+    n = params.numel()
+    for nme, t in (("params", params), ("grads", grads), ("exp_avg", exp_avg),
+                   ("exp_avg_sq", exp_avg_sq)):
+        _f32(t, nme)
+        _req(t.numel() == n and t.dim() == 1, f"{nme} must be flat float32[{n}]")
+    _req(step_count.dtype == torch.int64 and step_count.numel() == 1, "step_count int64[1]")
+    _req(lr.dtype == torch.float32 and lr.numel() == 1, "lr float32[1] on the device")
+    _req(norm_scratch.dtype == torch.float64 and norm_scratch.numel() >= 1, "norm_scratch float64[>=1]")
+    check(_lib.load().ppoaf_clip_adam_step(
+        ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), n, ptr(step_count), ptr(lr),
+        float(beta1), float(beta2), float(eps), float(grad_scale),
+        float(max_norm if max_norm is not None else 0.0), ptr(norm_scratch), ptr(grad_norm_out),
+        stream()), "clip_adam_step")

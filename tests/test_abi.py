@@ -1,0 +1,69 @@
+"""
+CPU tests of the drop-in boundary: the C-ABI library builds, loads, and exports
+every symbol include/ppoaf_hip.h declares, and the ctypes table matches the
+header.  No compute call is made (there is no GPU here).
+"""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ppoaf_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(ppoaf_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        decls[m.group(1)] = n
+    return decls
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from ppo_and_friends_amd.csrc import build
+    build.build(verbose=False)
+    from ppo_and_friends_amd import _lib
+    return _lib
+
+
+def test_header_declares_the_hot_path():
+    d = _declared()
+    for name in ("ppoaf_gae_rtg_tmajor", "ppoaf_gae_rtg_traj", "ppoaf_ppo_loss_fwd_bwd",
+                 "ppoaf_minibatch_gather", "ppoaf_running_moments_integrate",
+                 "ppoaf_categorical_sample", "ppoaf_clip_adam_step"):
+        assert name in d
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    lib = built_lib.load()
+    for name in _declared():
+        assert hasattr(lib, name), f"libppoaf_hip.so lacks {name}"
+    assert lib.ppoaf_abi_version() == 1
+
+
+def test_ctypes_table_matches_header(built_lib):
+    d = _declared()
+    assert set(d) == set(built_lib.SIGNATURES), set(d) ^ set(built_lib.SIGNATURES)
+    for name, n_args in d.items():
+        assert len(built_lib.SIGNATURES[name][1]) == n_args, name
+
+
+def test_cpu_tensor_is_refused_not_computed(built_lib):
+    """The product path has no CPU fallback: host tensors raise before any launch."""
+    import torch
+    from ppo_and_friends_amd import kernels
+    x = torch.zeros(4, 4)
+    with pytest.raises(built_lib.PpoafError):
+        kernels.gae_rtg_tmajor(x, x, torch.zeros(4), torch.zeros(4))
+
+
+def test_missing_library_fails_loudly(built_lib, monkeypatch):
+    monkeypatch.setattr(built_lib, "_lib", None)
+    monkeypatch.setattr(built_lib, "LIB_PATH", "/nonexistent/libppoaf_hip.so")
+    with pytest.raises(built_lib.PpoafError):
+        built_lib.load()

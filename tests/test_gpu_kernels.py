@@ -1,0 +1,410 @@
+"""
+-m gpu parity tests: every HIP kernel, called through the C ABI
+(ppo_and_friends_amd.kernels -> ctypes -> libppoaf_hip.so), against the oracle
+on the same seeded inputs, against the committed golden fixtures, and -- at
+BASELINE sizes -- through size-independent properties.
+
+Tolerance: north_star asks for 1e-5 (fp32) on returns / advantages / losses.
+The scans accumulate in float64 on both sides, so they are held to 2 ulp of
+float32 relative (2.4e-7) + 1e-6 absolute instead.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import episode_info_oracle as eo
+from oracle import ppo_loss_oracle as lo
+from oracle import running_stats_oracle as rso
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 2.4e-7, 1e-6
+
+
+@pytest.fixture(scope="module")
+def K():
+    from ppo_and_friends_amd import kernels
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    kernels._lib.load()
+    return kernels
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+# ---------------------------------------------------------------- K1 traj
+def test_gae_traj_golden_g1(K, golden):
+    """All 288 reference end_episode cases, batched as one ragged launch per parameter set."""
+    g = golden("g1_end_episode")
+    n = int(g["n_cases"][0])
+    groups = {}
+    for c in range(n):
+        p = g[f"c{c}_params"]
+        key = (p[0], p[1], bool(p[2]), None if np.isnan(p[3]) else (p[3], p[4]))
+        groups.setdefault(key, []).append(c)
+    for (gamma, lambd, use_gae, clip), cases in groups.items():
+        rew = np.concatenate([g[f"c{c}_rewards"] for c in cases]).astype(np.float32)
+        val = np.concatenate([g[f"c{c}_values"] for c in cases]).astype(np.float32)
+        lens = np.array([len(g[f"c{c}_rewards"]) for c in cases], dtype=np.int32)
+        starts = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
+        ev = np.array([g[f"c{c}_params"][5] for c in cases], dtype=np.float32)
+        er = np.array([g[f"c{c}_params"][6] for c in cases], dtype=np.float32)
+        adv, rtg = K.gae_rtg_traj(dev(rew), dev(val), dev(ev), dev(er), dev(starts), dev(lens),
+                                  gamma, lambd, clip, use_gae)
+        adv, rtg = adv.cpu().numpy(), rtg.cpu().numpy()
+        for i, c in enumerate(cases):
+            sl = slice(starts[i], starts[i] + lens[i])
+            # rewards of the "uniform" cases are float64 in the fixture; the device
+            # buffer holds float32, so compare against the oracle on the same float32 data
+            a_ref, r_ref = eo.end_episode(rew[sl], val[sl], float(ev[i]), float(er[i]), gamma,
+                                          lambd, clip, use_gae, "float64")
+            np.testing.assert_allclose(adv[sl], a_ref.astype(np.float32), rtol=RTOL, atol=ATOL,
+                                       err_msg=f"case {c} adv")
+            np.testing.assert_allclose(rtg[sl], r_ref.astype(np.float32), rtol=RTOL, atol=ATOL,
+                                       err_msg=f"case {c} rtg")
+            if g[f"c{c}_rewards"].dtype == np.float64 and np.all(g[f"c{c}_rewards"] == 1.0):
+                # constant-1 rewards are exact in float32: compare with the reference's own output
+                if use_gae:
+                    np.testing.assert_allclose(adv[sl], g[f"c{c}_adv"].astype(np.float32),
+                                               rtol=RTOL, atol=ATOL)
+                np.testing.assert_allclose(rtg[sl], g[f"c{c}_rtg_f64"].astype(np.float32),
+                                           rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("lens", [[1], [63, 64, 65], [1, 2, 3, 500, 129, 128, 127, 1000]])
+def test_gae_traj_ragged(K, lens):
+    rng = np.random.default_rng(3)
+    lens = np.array(lens, dtype=np.int32)
+    N = int(lens.sum())
+    rew = rng.uniform(-1, 1, N).astype(np.float32)
+    val = rng.standard_normal(N).astype(np.float32)
+    starts = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
+    ev = rng.standard_normal(len(lens)).astype(np.float32)
+    er = (rng.standard_normal(len(lens)) * 80).astype(np.float32)
+    adv, rtg = K.gae_rtg_traj(dev(rew), dev(val), dev(ev), dev(er), dev(starts), dev(lens))
+    for i in range(len(lens)):
+        sl = slice(starts[i], starts[i] + lens[i])
+        a, r = eo.end_episode(rew[sl], val[sl], float(ev[i]), float(er[i]), 0.99, 0.95)
+        np.testing.assert_allclose(adv[sl].cpu().numpy(), a.astype(np.float32), rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(rtg[sl].cpu().numpy(), r.astype(np.float32), rtol=RTOL, atol=ATOL)
+
+
+def test_gae_traj_empty(K):
+    z32 = torch.zeros(0, dtype=torch.float32, device="cuda")
+    adv, rtg = K.gae_rtg_traj(z32, z32, z32, z32, torch.zeros(0, dtype=torch.int64, device="cuda"),
+                              torch.zeros(0, dtype=torch.int32, device="cuda"))
+    assert adv.numel() == 0
+
+
+# ---------------------------------------------------------------- K1 tmajor
+def _tmajor_oracle(rew, val, bv, br, ek, **kw):
+    T, E = rew.shape
+    adv = np.zeros((T, E), dtype=np.float32)
+    rtg = np.zeros((T, E), dtype=np.float32)
+    d = eo.rollout_to_dataset(rew, val, bv, br, ek, **kw)
+    adv[d["flat_t"], d["flat_e"]] = d["adv"]
+    rtg[d["flat_t"], d["flat_e"]] = d["rtg"]
+    return adv, rtg
+
+
+@pytest.mark.parametrize("T,E", [(1, 1), (5, 3), (16, 64), (17, 65), (128, 8), (128, 300), (200, 70), (33, 5000)])
+@pytest.mark.parametrize("use_gae", [True, False])
+def test_gae_tmajor_fixed_length(K, T, E, use_gae):
+    rng = np.random.default_rng(T * 1000 + E)
+    rew = rng.uniform(-1, 1, (T, E)).astype(np.float32)
+    val = rng.standard_normal((T, E)).astype(np.float32)
+    boot = (rng.standard_normal(E) * 60).astype(np.float32)
+    ek = np.zeros((T, E), dtype=np.int8); ek[-1] = 2
+    bv = np.zeros((T, E), dtype=np.float32); bv[-1] = boot
+    a_ref, r_ref = _tmajor_oracle(rew, val, bv, bv, ek, use_gae=use_gae)
+    adv, rtg = K.gae_rtg_tmajor(dev(rew), dev(val), dev(boot), dev(boot), None, use_gae=use_gae)
+    np.testing.assert_allclose(adv.cpu().numpy(), a_ref, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(rtg.cpu().numpy(), r_ref, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("T,E,p", [(12, 3, 0.15), (128, 70, 0.02), (64, 257, 0.3), (130, 9, 0.05)])
+@pytest.mark.parametrize("clip", [(-100.0, 100.0), (-0.5, 0.5), None])
+def test_gae_tmajor_with_episode_ends(K, T, E, p, clip):
+    rng = np.random.default_rng(int(p * 100) + T)
+    rew = rng.uniform(-1, 1, (T, E)).astype(np.float32)
+    val = rng.standard_normal((T, E)).astype(np.float32)
+    bv = (rng.standard_normal((T, E)) * 2).astype(np.float32)
+    br = (rng.standard_normal((T, E)) * 2).astype(np.float32)
+    u = rng.uniform(0, 1, (T, E))
+    ek = np.where(u < p, 1, np.where(u < 2 * p, 2, 0)).astype(np.int8)
+    ek[-1] = np.where(ek[-1] == 0, 2, ek[-1])
+    a_ref, r_ref = _tmajor_oracle(rew, val, bv, br, ek, bootstrap_clip=clip)
+    adv, rtg = K.gae_rtg_tmajor(dev(rew), dev(val), dev(bv), dev(br), dev(ek), bootstrap_clip=clip)
+    np.testing.assert_allclose(adv.cpu().numpy(), a_ref, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(rtg.cpu().numpy(), r_ref, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_gae_tmajor_golden_g2(K, golden, tag):
+    """The reference's own dataset (advantages / rtg in completion order) from the dense buffer."""
+    g = golden("g2_dataset")
+    pre = tag + "_"
+    rew = g[pre + "in_rewards"].astype(np.float32)
+    val = g[pre + "in_values"]
+    boot = g[pre + "in_boot_v"]
+    ek = g[pre + "in_end_kind"]
+    adv, rtg = K.gae_rtg_tmajor(dev(rew), dev(val), dev(boot), dev(boot), dev(ek))
+    d = eo.rollout_to_dataset(rew, val, boot, boot, ek)
+    ft, fe = d["flat_t"], d["flat_e"]
+    # float32 rewards on the device vs float64 rewards in the reference run: 1e-5 (north_star)
+    np.testing.assert_allclose(adv.cpu().numpy()[ft, fe], g[pre + "adv"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rtg.cpu().numpy()[ft, fe], g[pre + "rtg"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(adv.cpu().numpy()[ft, fe], d["adv"], rtol=RTOL, atol=ATOL)
+
+
+def test_gae_tmajor_full_size_properties(K):
+    """C2 size (E=4096, T=128): linearity in (rewards, bootstrap) and the closed form for constant inputs."""
+    T, E = 128, 4096
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    r1 = torch.rand(T, E, device="cuda", generator=gen) * 2 - 1
+    r2 = torch.rand(T, E, device="cuda", generator=gen) * 2 - 1
+    v1 = torch.randn(T, E, device="cuda", generator=gen)
+    v2 = torch.randn(T, E, device="cuda", generator=gen)
+    b1 = torch.randn(E, device="cuda", generator=gen)
+    b2 = torch.randn(E, device="cuda", generator=gen)
+    a1, g1 = K.gae_rtg_tmajor(r1, v1, b1, b1, None, bootstrap_clip=None)
+    a2, g2 = K.gae_rtg_tmajor(r2, v2, b2, b2, None, bootstrap_clip=None)
+    a3, g3 = K.gae_rtg_tmajor(r1 + r2, v1 + v2, b1 + b2, b1 + b2, None, bootstrap_clip=None)
+    torch.testing.assert_close(a3, a1 + a2, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(g3, g1 + g2, rtol=1e-5, atol=2e-5)
+    # constant reward 1, zero values/bootstrap: rtg_t = (1 - gamma^(T-t)) / (1 - gamma)
+    ones = torch.ones(T, E, device="cuda")
+    zeros = torch.zeros(T, E, device="cuda")
+    zb = torch.zeros(E, device="cuda")
+    a, r = K.gae_rtg_tmajor(ones, zeros, zb, zb, None)
+    k = torch.arange(T, 0, -1, device="cuda", dtype=torch.float64)
+    closed = ((1 - 0.99 ** k) / (1 - 0.99)).to(torch.float32)[:, None].expand(T, E)
+    torch.testing.assert_close(r, closed, rtol=1e-6, atol=1e-5)
+    # one env column against the oracle
+    e = 1234
+    a_ref, r_ref = eo.end_episode(r1[:, e].cpu().numpy(), v1[:, e].cpu().numpy(),
+                                  float(b1[e]), float(b1[e]), 0.99, 0.95, None)
+    np.testing.assert_allclose(a1[:, e].cpu().numpy(), a_ref.astype(np.float32), rtol=RTOL, atol=ATOL)
+
+
+# ---------------------------------------------------------------- K2+K3
+@pytest.mark.parametrize("B", [2, 63, 256, 768, 5000])
+@pytest.mark.parametrize("cfg", [dict(), dict(normalize_adv=False), dict(use_huber=True),
+                                 dict(entropy_weight=0.0), dict(kl_loss_weight=0.5, surr_clip=0.1)])
+def test_ppo_loss_matches_torch(K, B, cfg):
+    torch.manual_seed(B)
+    old_lp = -torch.rand(B) * 2
+    cur_lp = (old_lp + torch.randn(B) * 0.3).requires_grad_()
+    adv = torch.randn(B) * 3 + 1
+    ent = (torch.rand(B) * 0.7).requires_grad_()
+    val = (torch.randn(B) * 12).requires_grad_()       # |diff| crosses the Huber delta of 10
+    rtg = torch.randn(B)
+    kw = dict(normalize_adv=True, surr_clip=0.2, entropy_weight=0.01, kl_loss_weight=0.0, use_huber=False)
+    kw.update(cfg)
+    ref = lo.ppo_minibatch_losses(cur_lp, old_lp, adv, ent, val, rtg, **kw)
+    ref["actor_loss"].backward()
+    ref["critic_loss"].backward()
+    sc, dlp, dent, dval = K.ppo_loss_fwd_bwd(dev(cur_lp.detach()), dev(old_lp), dev(adv), dev(ent.detach()),
+                                             dev(val.detach()), dev(rtg), **kw)
+    sc = sc.cpu().numpy()
+    tol = dict(rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sc[K.SC_SURR], ref["surr"], **tol)
+    np.testing.assert_allclose(sc[K.SC_ACTOR], ref["actor"], **tol)
+    np.testing.assert_allclose(sc[K.SC_CRITIC], ref["critic"], **tol)
+    if kw["entropy_weight"] != 0.0:      # the reference only tallies entropy when it is weighted (ppo.py:2395-2396)
+        np.testing.assert_allclose(sc[K.SC_ENTROPY], ref["entropy"], **tol)
+    np.testing.assert_allclose(sc[K.SC_KL], ref["kl"], **tol)
+    if kw["normalize_adv"]:
+        np.testing.assert_allclose(sc[K.SC_ADV_MEAN], ref["adv_mean"], **tol)
+        np.testing.assert_allclose(sc[K.SC_ADV_STD], ref["adv_std"], **tol)
+    assert sc[K.SC_BAD] == 0.0
+    np.testing.assert_allclose(dlp.cpu().numpy(), cur_lp.grad.numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(dval.cpu().numpy(), val.grad.numpy(), rtol=1e-5, atol=1e-8)
+    exp_dent = ent.grad.numpy() if ent.grad is not None else np.zeros(B, dtype=np.float32)
+    np.testing.assert_allclose(dent.cpu().numpy(), exp_dent, rtol=1e-5, atol=1e-9)
+
+
+def test_ppo_loss_flags_nonfinite_ratio(K):
+    B = 64
+    old_lp = torch.zeros(B); cur_lp = torch.zeros(B); cur_lp[7] = 200.0      # exp -> inf
+    z = torch.zeros(B)
+    sc, *_ = K.ppo_loss_fwd_bwd(dev(cur_lp), dev(old_lp), dev(torch.randn(B)), dev(z), dev(z), dev(z))
+    assert sc[K.SC_BAD].item() == 1.0
+
+
+# ---------------------------------------------------------------- K4
+def test_minibatch_gather_all_fields(K):
+    rng = np.random.default_rng(0)
+    N, B = 1000, 256
+    obs = rng.standard_normal((N, 4)).astype(np.float32)
+    cobs = rng.standard_normal((N, 54)).astype(np.float32)
+    act = rng.integers(0, 5, (N, 1)).astype(np.int64)
+    adv = rng.standard_normal(N).astype(np.float32)
+    perm = rng.permutation(N)[:B].astype(np.int64)
+    row_map = rng.permutation(N).astype(np.int32)
+    srcs = [dev(obs), dev(cobs), dev(act), dev(adv)]
+    for rm in (None, row_map):
+        dsts = [torch.zeros(B, 4, device="cuda"), torch.zeros(B, 54, device="cuda"),
+                torch.zeros(B, 1, dtype=torch.int64, device="cuda"), torch.zeros(B, device="cuda")]
+        K.minibatch_gather(list(zip(srcs, dsts)), dev(perm), None if rm is None else dev(rm))
+        rows = perm if rm is None else rm[perm]
+        for s, d in zip((obs, cobs, act, adv), dsts):
+            np.testing.assert_array_equal(d.cpu().numpy(), s[rows])        # bit-exact
+    # scatter is the inverse on the touched rows
+    dst = torch.zeros(N, device="cuda")
+    vals = torch.arange(B, dtype=torch.float32, device="cuda")
+    K.scatter_rows_f32(vals, dev(perm), dst, dev(row_map))
+    exp = np.zeros(N, dtype=np.float32); exp[row_map[perm]] = np.arange(B)
+    np.testing.assert_array_equal(dst.cpu().numpy(), exp)
+
+
+# ---------------------------------------------------------------- K5
+def test_running_moments_golden_g4(K, golden):
+    g = golden("g4_running_stats")
+    mean = torch.zeros(1, device="cuda"); var = torch.ones(1, device="cuda")
+    count = torch.full((1,), 1e-4, dtype=torch.float64, device="cuda")
+    for i in range(4):
+        m = K.batch_moments(dev(g[f"s_batch{i}"]), 1)
+        K.running_moments_integrate(m, mean, var, count)
+        exp = g[f"s_state{i}"]
+        np.testing.assert_allclose(mean.item(), exp[0], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(var.item(), exp[1], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(count.item(), exp[2], rtol=1e-15)
+    W = 6
+    mean = torch.zeros(W, device="cuda"); var = torch.ones(W, device="cuda")
+    count = torch.full((1,), 1e-4, dtype=torch.float64, device="cuda")
+    for i in range(3):
+        m = K.batch_moments(dev(g[f"v_batch{i}"]), W)
+        K.running_moments_integrate(m, mean, var, count)
+        np.testing.assert_allclose(mean.cpu().numpy(), g[f"v_mean{i}"], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(var.cpu().numpy(), g[f"v_var{i}"], rtol=2e-6, atol=1e-7)
+
+
+def test_running_moments_multi_rank_merge_equals_concatenation(K):
+    """R per-rank records merged on the device == the reference's allgather + np.mean/np.var."""
+    rng = np.random.default_rng(9)
+    parts = [rng.standard_normal(256).astype(np.float32) * (r + 1) + r for r in range(4)]
+    recs = torch.cat([K.batch_moments(dev(p), 1) for p in parts])
+    mean = torch.zeros(1, device="cuda"); var = torch.ones(1, device="cuda")
+    count = torch.full((1,), 1e-4, dtype=torch.float64, device="cuda")
+    K.running_moments_integrate(recs, mean, var, count)
+    rs = rso.RunningMeanStd()
+    rs.update(None, gathered=parts)
+    np.testing.assert_allclose(mean.item(), float(rs.mean), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(var.item(), float(rs.variance), rtol=2e-6, atol=1e-7)
+    assert count.item() == rs.count
+
+
+def test_normalize_denormalize(K):
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((300, 5)).astype(np.float32) * 4
+    mean = rng.standard_normal(5).astype(np.float32); var = rng.uniform(0.1, 3, 5).astype(np.float32)
+    y = K.normalize(dev(x), dev(mean), dev(var)).cpu().numpy()
+    np.testing.assert_allclose(y, rso.normalize(x, mean, var), rtol=1e-6, atol=1e-6)
+    z = K.denormalize(dev(y), dev(mean), dev(var)).cpu().numpy()
+    np.testing.assert_allclose(z, x, rtol=1e-5, atol=1e-5)
+    yc = K.normalize(dev(x), dev(mean), dev(var), clip=(-1.0, 1.0)).cpu().numpy()
+    np.testing.assert_allclose(yc, np.clip(rso.normalize(x, mean, var), -1, 1), rtol=1e-6, atol=1e-6)
+
+
+# ---------------------------------------------------------------- K6
+@pytest.mark.parametrize("n,Kc", [(1, 2), (256, 2), (3072, 5), (100, 17)])
+def test_categorical_eval_fwd_bwd(K, n, Kc):
+    torch.manual_seed(n + Kc)
+    logits = (torch.randn(n, Kc) * 3).requires_grad_()
+    if n > 4:
+        with torch.no_grad():
+            logits[3, 0] = 40.0          # saturated row: probs clamp at 1 - eps / eps
+    actions = torch.randint(0, Kc, (n,))
+    logp_ref, ent_ref, probs_ref = lo.categorical_logp_entropy(logits, actions)
+    g_lp = torch.randn(n); g_ent = torch.randn(n)
+    (logp_ref * g_lp + ent_ref * g_ent).sum().backward()
+    logp, ent, probs = K.categorical_eval_fwd(dev(logits.detach()), dev(actions))
+    np.testing.assert_allclose(logp.cpu().numpy(), logp_ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ent.cpu().numpy(), ent_ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(probs.cpu().numpy(), probs_ref.detach().numpy(), rtol=1e-5, atol=1e-7)
+    dl = K.categorical_eval_bwd(probs, dev(actions), dev(g_lp), dev(g_ent))
+    np.testing.assert_allclose(dl.cpu().numpy(), logits.grad.numpy(), rtol=2e-4, atol=2e-6)
+
+
+def test_categorical_sample_distribution_and_logp(K):
+    n, Kc = 200000, 5
+    torch.manual_seed(0)
+    row = torch.randn(Kc)
+    logits = row.repeat(n, 1).cuda().contiguous()
+    a, lp = K.categorical_sample(logits, seed=123, offset=0)
+    p = torch.softmax(row, 0).numpy()
+    freq = np.bincount(a.cpu().numpy(), minlength=Kc) / n
+    np.testing.assert_allclose(freq, p, atol=5e-3)
+    np.testing.assert_allclose(lp.cpu().numpy(), np.log(p)[a.cpu().numpy()], rtol=1e-5, atol=1e-6)
+    # counter-based: same (seed, offset) -> same draws; different offset -> different draws
+    a2, _ = K.categorical_sample(logits, seed=123, offset=0)
+    a3, _ = K.categorical_sample(logits, seed=123, offset=n)
+    assert torch.equal(a, a2) and not torch.equal(a, a3)
+
+
+@pytest.mark.parametrize("n,D", [(1, 1), (256, 6), (2048, 6), (77, 3)])
+def test_gaussian_tanh_eval_fwd_bwd(K, n, D):
+    torch.manual_seed(n * 7 + D)
+    mean = torch.randn(n, D).requires_grad_()
+    log_std = (torch.randn(D) * 0.5 - 0.5).requires_grad_()
+    with torch.no_grad():
+        log_std[0] = -8.0                 # softplus < min_std: the max() floor is active
+    x = torch.randn(n, D) * 1.5
+    if n > 2:
+        x[1, 0] = 12.0                     # tanh' underflows -> clamp(1e-6)
+        x[2, 0] = 60.0 if D > 0 else 0.0   # log-prob clamp at -100 with tiny std
+    lp_ref = lo.gaussian_tanh_logp(mean, log_std, x)
+    g_lp = torch.randn(n); g_ent = torch.randn(n)
+    (lp_ref * g_lp + (-lp_ref) * g_ent).sum().backward()
+    lp, ent = K.gaussian_tanh_eval_fwd(dev(mean.detach()), dev(log_std.detach()), dev(x))
+    np.testing.assert_allclose(lp.cpu().numpy(), lp_ref.detach().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(ent.cpu().numpy(), -lp_ref.detach().numpy(), rtol=2e-5, atol=2e-5)
+    dm, dls = K.gaussian_tanh_eval_bwd(dev(mean.detach()), dev(log_std.detach()), dev(x), dev(g_lp), dev(g_ent))
+    np.testing.assert_allclose(dm.cpu().numpy(), mean.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dls.cpu().numpy(), log_std.grad.numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_gaussian_sample_moments_and_logp(K):
+    n, D = 100000, 6
+    mean = torch.linspace(-1, 1, D).repeat(n, 1).cuda().contiguous()
+    log_std = torch.full((D,), -0.5, device="cuda")
+    raw, act, lp = K.gaussian_tanh_sample(mean, log_std, seed=7, offset=0, act_lo=-2.0, act_hi=4.0)
+    sd = torch.nn.functional.softplus(torch.tensor(-0.5)).item()
+    np.testing.assert_allclose(raw.mean(0).cpu().numpy(), np.linspace(-1, 1, D), atol=0.01)
+    np.testing.assert_allclose(raw.std(0).cpu().numpy(), sd, atol=0.01)
+    ref_act = lo.gaussian_refine(raw.cpu(), -2.0, 4.0)
+    np.testing.assert_allclose(act.cpu().numpy(), ref_act.numpy(), rtol=1e-5, atol=1e-5)
+    ref_lp = lo.gaussian_tanh_logp(mean.cpu(), log_std.cpu(), raw.cpu())
+    np.testing.assert_allclose(lp.cpu().numpy(), ref_lp.numpy(), rtol=2e-5, atol=2e-5)
+
+
+# ---------------------------------------------------------------- K11
+@pytest.mark.parametrize("max_norm,grad_scale", [(0.5, 1.0), (None, 1.0), (0.5, 0.125)])
+def test_clip_adam_matches_torch(K, max_norm, grad_scale):
+    torch.manual_seed(1)
+    shapes = [(128, 4), (128,), (128, 128), (128,), (2, 128), (2,)]
+    params = [torch.randn(s) * 0.3 for s in shapes]
+    steps = 5
+    grads = [[torch.randn(s) * (3.0 if k % 2 else 0.05) for s in shapes] for k in range(steps)]
+    ref, norms = lo.clip_adam_reference(params, grads, steps, lr=3e-4, eps=1e-5,
+                                        max_norm=max_norm, grad_scale=grad_scale)
+    flat = torch.cat([p.flatten() for p in params]).cuda()
+    m = torch.zeros_like(flat); v = torch.zeros_like(flat)
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    lr = torch.full((1,), 3e-4, device="cuda")
+    scratch = torch.zeros(2, dtype=torch.float64, device="cuda")
+    gn = torch.zeros(1, device="cuda")
+    for k in range(steps):
+        g = torch.cat([x.flatten() for x in grads[k]]).cuda()
+        K.clip_adam_step(flat, g, m, v, step, lr, scratch, grad_scale=grad_scale,
+                         max_norm=max_norm, grad_norm_out=gn)
+        if max_norm is not None:
+            np.testing.assert_allclose(gn.item(), norms[k], rtol=1e-5)
+    assert step.item() == steps
+    ref_flat = torch.cat([p.flatten() for p in ref]).numpy()
+    np.testing.assert_allclose(flat.cpu().numpy(), ref_flat, rtol=1e-5, atol=1e-6)
