@@ -1,0 +1,275 @@
+"""
+TEST INFRASTRUCTURE (see oracle/__init__.py) -- CPU restatement ("port") of the
+reference's whole hot path with the reference's own loop structure, used
+  (a) as the end-to-end parity checker for rollout -> GAE -> mini-batch update, and
+  (b) as bench.py's `cpu_baseline` (kind "port"): the reference's Python files
+      cannot travel to the GPU box, so this port is what is timed on its host cores.
+
+Loop structure kept on purpose (it is where the reference spends its time,
+SURVEY.md §6): per-env `add_info` appends with `.item()` calls
+(policies/ppo_policy.py:638-651 -> utils/episode_info.py:355-368), a Python
+reverse scan per finished episode (:254-262, :289-293), list -> ndarray -> tensor
+dataset build (:815-887), torch DataLoader(shuffle=True) over per-sample
+13-tuples + default collate (ppo.py:2181-2184, episode_info.py:939-952), the
+value normaliser on every mini-batch (ppo.py:2299-2303), per-network backward /
+clip_grad_norm_ / Adam(eps=1e-5) (ppo_policy.py:1032-1055).
+
+"parity unpinned" for the update half (see oracle/ppo_loss_oracle.py); the buffer
+half is pinned through oracle/episode_info_oracle.py.
+"""
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.distributions import Categorical
+from torch.utils.data import DataLoader, Dataset
+
+from . import episode_info_oracle as eo
+from . import ppo_loss_oracle as lo
+from .running_stats_oracle import RunningMeanStd
+
+
+def make_mlp(in_size, out_size, hidden=128, depth=3, out_gain=None, activation=None):
+    """networks/utils.py:120-191 + init_layer :53-80 (orthogonal, gain sqrt(2) / out_gain, zero bias)."""
+    act = nn.ReLU() if activation is None else activation
+
+    def lin(i, o, gain=np.sqrt(2)):
+        layer = nn.Linear(i, o)
+        nn.init.orthogonal_(layer.weight, gain)
+        nn.init.constant_(layer.bias, 0.0)
+        return layer
+
+    inner = []
+    for _ in range(depth - 1):
+        inner += [lin(hidden, hidden), act]
+    last = lin(hidden, out_size) if out_gain is None else lin(hidden, out_size, out_gain)
+    return nn.Sequential(lin(in_size, hidden), act, nn.Sequential(*inner), last)
+
+
+class _Episode:
+    """The lists of EpisodeInfo (episode_info.py:205-221) and its end_episode."""
+
+    def __init__(self, gamma, lambd, clip, use_gae=True):
+        self.gamma, self.lambd, self.clip, self.use_gae = gamma, lambd, clip, use_gae
+        self.observations, self.next_observations, self.critic_observations = [], [], []
+        self.actions, self.raw_actions, self.values, self.log_probs, self.rewards = [], [], [], [], []
+
+    def add_info(self, observation, next_observation, raw_action, action, value, log_prob, reward,
+                 critic_observation):
+        self.observations.append(observation)
+        self.next_observations.append(next_observation)
+        self.actions.append(action)
+        self.raw_actions.append(raw_action)
+        self.values.append(value)
+        self.log_probs.append(log_prob)
+        self.rewards.append(reward)
+        self.critic_observations.append(critic_observation)
+
+    def end_episode(self, ending_value, ending_reward, rtg_accum="float64"):
+        self.ending_value = ending_value
+        self.length = len(self.rewards)
+        self.advantages, self.rewards_to_go = eo.end_episode(
+            self.rewards, self.values, ending_value, ending_reward, self.gamma, self.lambd,
+            self.clip, self.use_gae, rtg_accum)
+        self.values = np.array(self.values).astype(np.float32)
+
+
+class _ListDataset(Dataset):
+    """PPODataset.build + __getitem__ (episode_info.py:745-952), discrete actions."""
+
+    def __init__(self, episodes):
+        obs, nobs, cobs, act, ract, rtg, lp, adv, val = [], [], [], [], [], [], [], [], []
+        for ep in episodes:
+            obs.extend(ep.observations); nobs.extend(ep.next_observations)
+            cobs.extend(ep.critic_observations); act.extend(ep.actions); ract.extend(ep.raw_actions)
+            rtg.extend(ep.rewards_to_go); lp.extend(ep.log_probs); adv.extend(ep.advantages)
+            val.extend(ep.values)
+        self.episodes = episodes
+        self.observations = torch.tensor(np.array(obs), dtype=torch.float32)
+        self.next_observations = torch.tensor(np.array(nobs), dtype=torch.float32)
+        self.critic_observations = torch.tensor(np.array(cobs), dtype=torch.float32)
+        self.actions = torch.tensor(np.array(act), dtype=torch.long)
+        self.raw_actions = torch.tensor(np.array(ract), dtype=torch.long)
+        self.rewards_to_go = torch.tensor(np.array(rtg), dtype=torch.float32)
+        self.log_probs = torch.tensor(lp, dtype=torch.float32)
+        self.advantages = torch.tensor(np.array(adv), dtype=torch.float32)
+        self.values = torch.tensor(np.array(val), dtype=torch.float32)
+        if self.actions.dim() <= 1:
+            self.actions = self.actions.unsqueeze(-1)
+            self.raw_actions = self.raw_actions.unsqueeze(-1)
+        self.empty = np.zeros(len(self.observations)).astype(np.uint8)
+
+    def __len__(self):
+        return len(self.observations)
+
+    def __getitem__(self, idx):
+        return (self.critic_observations[idx], self.observations[idx], self.next_observations[idx],
+                self.raw_actions[idx], self.actions[idx], self.advantages[idx], self.log_probs[idx],
+                self.rewards_to_go[idx], self.empty[idx], self.empty[idx], self.empty[idx],
+                self.empty[idx], idx)
+
+
+class CpuPPO:
+    """One rank of the reference's PPO on CPU for a Discrete-action MLP policy and a table-driven env."""
+
+    def __init__(self, obs_dim, n_actions, hidden=128, depth=3, lr=3e-4, gamma=0.99, lambd=0.95,
+                 bootstrap_clip=(-100.0, 100.0), surr_clip=0.2, entropy_weight=0.01,
+                 gradient_clip=0.5, batch_size=256, normalize_adv=True, normalize_values=True,
+                 seed=0, rtg_accum="float64"):
+        torch.manual_seed(seed)
+        self.actor = make_mlp(obs_dim, n_actions, hidden, depth, out_gain=0.01)     # ppo_policy.py:433-439
+        self.critic = make_mlp(obs_dim, 1, hidden, depth, out_gain=1.0)             # :441-446
+        self.actor_optim = torch.optim.Adam(self.actor.parameters(), lr=lr, eps=1e-5)
+        self.critic_optim = torch.optim.Adam(self.critic.parameters(), lr=lr, eps=1e-5)
+        self.gamma, self.lambd, self.clip = gamma, lambd, bootstrap_clip
+        self.surr_clip, self.entropy_weight, self.gradient_clip = surr_clip, entropy_weight, gradient_clip
+        self.batch_size = batch_size
+        self.normalize_adv, self.normalize_values = normalize_adv, normalize_values
+        self.value_stats = RunningMeanStd()
+        self.rtg_accum = rtg_accum
+        self.loader_generator = torch.Generator().manual_seed(seed)
+
+    # ----- value normaliser (utils/misc.py:84-128)
+    def _denorm(self, v):
+        mean = torch.tensor(self.value_stats.mean, dtype=torch.float32)
+        var = torch.tensor(self.value_stats.variance, dtype=torch.float32)
+        return mean + v * torch.sqrt(var + torch.tensor([1e-8]))
+
+    def _norm_update(self, x):
+        self.value_stats.update(x.detach().cpu().numpy())
+        mean = torch.tensor(self.value_stats.mean, dtype=torch.float32)
+        var = torch.tensor(self.value_stats.variance, dtype=torch.float32)
+        return (x - mean) / torch.sqrt(var + torch.tensor([1e-8]))
+
+    def values_of(self, obs):
+        with torch.no_grad():
+            v = self.critic(obs).reshape(-1)
+        return self._denorm(v) if self.normalize_values else v
+
+    # ----- rollout (ppo.py:1646-1983) on pre-generated observation / reward tables
+    def rollout(self, obs_table, reward_table, actions=None, term_table=None, max_ts_per_ep=None):
+        """
+        obs_table [T+1,E,O], reward_table [T,E] numpy.  actions (optional [T,E])
+        replays a recorded rollout instead of sampling.  term_table (optional bool
+        [T,E]) marks terminal steps: those episodes end with (0, 0) (ppo.py:1804-1819);
+        episodes reaching max_ts_per_ep, and every open episode at the last step,
+        end with the critic bootstrap of the next observation (ppo.py:1863-1938).
+        Episodes enter the dataset in completion order.
+        """
+        T, E = reward_table.shape
+        new_ep = lambda: _Episode(self.gamma, self.lambd, self.clip)
+        episodes = [new_ep() for _ in range(E)]
+        finished = []
+        ep_ts = np.zeros(E, dtype=np.int64)
+        for t in range(T):
+            ep_ts += 1
+            obs = obs_table[t]
+            t_obs = torch.tensor(obs, dtype=torch.float32)
+            with torch.no_grad():
+                probs = torch.softmax(self.actor(t_obs), dim=-1)
+            dist = Categorical(probs)
+            if actions is None:
+                a = dist.sample()
+            else:
+                a = torch.as_tensor(actions[t], dtype=torch.long)
+            log_prob = torch.unsqueeze(dist.log_prob(a), dim=-1)
+            a_np = a.unsqueeze(-1).numpy()
+            value = self.values_of(t_obs).unsqueeze(-1)
+            nxt = obs_table[t + 1]
+            rew = reward_table[t].reshape(E, 1).astype(np.float64)
+            for e in range(E):                         # ppo_policy.py:638-651
+                episodes[e].add_info(
+                    critic_observation=obs[e], observation=obs[e], next_observation=nxt[e],
+                    raw_action=a_np[e], action=a_np[e], value=value[e].item(),
+                    log_prob=log_prob[e], reward=rew[e].item())
+            where_term = np.where(term_table[t])[0] if term_table is not None else np.array([], dtype=np.int64)
+            for e in where_term:                       # ppo.py:1810-1819
+                episodes[e].end_episode(0.0, 0.0, self.rtg_accum)
+                finished.append(episodes[e])
+                episodes[e] = new_ep()
+                ep_ts[e] = 0
+            if t == T - 1:                             # ppo.py:1870-1877
+                where_maxed = np.arange(E)
+            elif max_ts_per_ep is not None:
+                where_maxed = np.where(ep_ts >= max_ts_per_ep)[0]
+            else:
+                where_maxed = np.array([], dtype=np.int64)
+            where_maxed = np.setdiff1d(where_maxed, where_term)
+            if where_maxed.size > 0:
+                next_value = self.values_of(torch.tensor(nxt, dtype=torch.float32))
+                for e in where_maxed:                  # ppo.py:1932-1938 (each env its own value: quirk Q1 fixed)
+                    episodes[e].end_episode(next_value[e].item(), next_value[e].item(), self.rtg_accum)
+                    finished.append(episodes[e])
+                    episodes[e] = new_ep()
+                    ep_ts[e] = 0
+        self.dataset = _ListDataset(finished)
+        return self.dataset
+
+    # ----- one epoch (ppo.py:2274-2485)
+    def train_epoch(self):
+        loader = DataLoader(self.dataset, batch_size=self.batch_size, shuffle=True,
+                            generator=self.loader_generator)
+        tot = dict(actor=0.0, critic=0.0, entropy=0.0, kl=0.0, n=0)
+        for batch in loader:
+            critic_obs, obs, _, raw_actions, _, advantages, log_probs, rewards_tg, _, _, _, _, idxs = batch
+            if self.normalize_values:
+                rewards_tg = self._norm_update(rewards_tg.flatten()).reshape(rewards_tg.shape)
+            if obs.shape[0] == 1:
+                continue
+            values = self.critic(critic_obs).squeeze()
+            probs = torch.softmax(self.actor(obs), dim=-1)
+            dist = Categorical(probs)
+            cur_lp = torch.unsqueeze(dist.log_prob(raw_actions.flatten()), dim=-1)
+            entropy = dist.entropy()
+            self.dataset.values[idxs] = values.detach()
+            r = lo.ppo_minibatch_losses(cur_lp, log_probs, advantages, entropy, values, rewards_tg,
+                                        self.normalize_adv, self.surr_clip, self.entropy_weight)
+            self.actor_optim.zero_grad()
+            r["actor_loss"].backward()
+            nn.utils.clip_grad_norm_(self.actor.parameters(), self.gradient_clip)
+            self.actor_optim.step()
+            self.critic_optim.zero_grad()
+            r["critic_loss"].backward()
+            nn.utils.clip_grad_norm_(self.critic.parameters(), self.gradient_clip)
+            self.critic_optim.step()
+            tot["actor"] += r["surr"]; tot["critic"] += r["critic"]
+            tot["entropy"] += r["entropy"]; tot["kl"] += r["kl"]; tot["n"] += 1
+        n = max(tot["n"], 1)
+        return {"actor loss": tot["actor"] / n, "critic loss": tot["critic"] / n,
+                "weighted entropy": tot["entropy"] * self.entropy_weight / n, "kl avg": tot["kl"] / n}
+
+
+def time_iteration(E, T, obs_dim=4, n_actions=2, epochs=10, batch_size=256, seed=1234, threads=None):
+    """cpu_baseline leg: one PPO iteration (rollout + GAE/build + `epochs` epochs) -> env-steps/s."""
+    if threads is not None:
+        torch.set_num_threads(threads)
+    rng = np.random.default_rng(seed)
+    obs_table = rng.standard_normal((T + 1, E, obs_dim), dtype=np.float32)
+    rew_table = np.ones((T, E), dtype=np.float32)
+    ppo = CpuPPO(obs_dim, n_actions, batch_size=batch_size, seed=seed)
+    t0 = time.perf_counter()
+    ppo.rollout(obs_table, rew_table)
+    t1 = time.perf_counter()
+    for _ in range(epochs):
+        ppo.train_epoch()
+    t2 = time.perf_counter()
+    return dict(env_steps=E * T, rollout_s=t1 - t0, update_s=t2 - t1,
+                env_steps_per_s=E * T / (t2 - t0), threads=torch.get_num_threads())
+
+
+def pick_threads(candidates=(1, 4, 8, 16), T=128):
+    """
+    The reference leaves torch's intra-op threads at cores / ranks
+    (utils/mpi_utils.py:37-48); on a many-core host that is far slower than a
+    handful of threads for these 128-wide layers.  To keep the baseline honest
+    the timed sample uses the fastest of a few settings, found on a tiny probe.
+    """
+    best, best_rate = None, -1.0
+    for th in candidates:
+        if th > (torch.get_num_threads() if best is None else 10 ** 9) and best is None:
+            pass
+        r = time_iteration(16, T, epochs=1, threads=th)
+        if r["env_steps_per_s"] > best_rate:
+            best, best_rate = th, r["env_steps_per_s"]
+    return best

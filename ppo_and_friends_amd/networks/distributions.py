@@ -1,0 +1,132 @@
+"""
+Action distributions backed by the HIP kernels of csrc/distributions.hip.
+
+Same class / method names as the reference's networks/distributions.py
+(CategoricalDistribution :199-269, GaussianDistribution :441-694), but instead
+of moving the actor output to the CPU and building torch.distributions objects
+(policies/ppo_policy.py:770,930) the "distribution" here is a light handle on
+the device logits / means, and sampling, log-probs and entropy (forward and
+backward) are single fused launches.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from ..spaces import get_space_dtype_str
+
+
+class _CategoricalEval(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, actions):
+        logits = logits.contiguous()
+        logp, ent, probs = K.categorical_eval_fwd(logits, actions)
+        ctx.save_for_backward(probs, actions)
+        return logp, ent
+
+    @staticmethod
+    def backward(ctx, g_logp, g_ent):
+        probs, actions = ctx.saved_tensors
+        g_logp = None if g_logp is None else g_logp.contiguous()
+        g_ent = None if g_ent is None else g_ent.contiguous()
+        return K.categorical_eval_bwd(probs, actions, g_logp, g_ent), None
+
+
+class _GaussianTanhEval(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, log_std, x, min_std):
+        mean = mean.contiguous()
+        logp, ent = K.gaussian_tanh_eval_fwd(mean, log_std, x, min_std)
+        ctx.save_for_backward(mean, log_std, x)
+        ctx.min_std = min_std
+        return logp, ent
+
+    @staticmethod
+    def backward(ctx, g_logp, g_ent):
+        mean, log_std, x = ctx.saved_tensors
+        g_logp = None if g_logp is None else g_logp.contiguous()
+        g_ent = None if g_ent is None else g_ent.contiguous()
+        d_mean, d_log_std = K.gaussian_tanh_eval_bwd(mean, log_std, x, g_logp, g_ent, ctx.min_std)
+        return d_mean, d_log_std, None, None
+
+
+class _PhiloxStream:
+    """Counter-based RNG bookkeeping: (seed, running offset) instead of generator state."""
+
+    def __init__(self, seed=0):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+
+    def take(self, n):
+        o = self.offset
+        self.offset += int(n)
+        return self.seed, o
+
+
+class CategoricalDistribution:
+    """networks/distributions.py:199-269 on device logits (the softmax output_func :1043-1045 is fused in)."""
+
+    def __init__(self, seed=0, **kw_args):
+        self.rng = _PhiloxStream(seed)
+
+    def get_distribution(self, logits):
+        return logits
+
+    def sample_distribution(self, logits):
+        """-> (action, raw_action, log_prob), each [n,1] (reference returns the sample twice, :66-90)."""
+        seed, off = self.rng.take(logits.shape[0])
+        a, lp = K.categorical_sample(logits.contiguous(), seed, off)
+        a = a.unsqueeze(-1)
+        return a, a, lp.unsqueeze(-1)
+
+    def get_log_probs_and_entropy(self, logits, actions):
+        logp, ent = _CategoricalEval.apply(logits, actions.flatten().contiguous())
+        return logp.unsqueeze(-1), ent
+
+    def refine_prediction(self, logits):
+        return torch.argmax(logits, dim=-1)          # :262-263 (argmax of probs == argmax of logits)
+
+
+class GaussianDistribution(nn.Module):
+    """networks/distributions.py:441-694: learned log_std (init -std_offset), softplus, min_std floor, tanh squash."""
+
+    def __init__(self, act_dim, std_offset=0.5, min_std=0.01, distribution_min=-1.0,
+                 distribution_max=1.0, seed=0, **kw_args):
+        super().__init__()
+        self.min_std = float(min_std)
+        self.dist_min = float(np.min(distribution_min))
+        self.dist_max = float(np.max(distribution_max))
+        self.log_std = nn.Parameter(torch.as_tensor(-std_offset * np.ones(act_dim, dtype=np.float32)))
+        self.rng = _PhiloxStream(seed)
+
+    def get_distribution(self, action_mean):
+        return action_mean
+
+    def sample_distribution(self, mean):
+        seed, off = self.rng.take(mean.shape[0])
+        raw, act, lp = K.gaussian_tanh_sample(mean.contiguous(), self.log_std.detach(), seed, off,
+                                              self.min_std, self.dist_min, self.dist_max)
+        return act, raw, lp.unsqueeze(-1)
+
+    def get_log_probs_and_entropy(self, mean, raw_actions):
+        logp, ent = _GaussianTanhEval.apply(mean, self.log_std, raw_actions.contiguous(), self.min_std)
+        return logp.unsqueeze(-1), ent
+
+    def refine_prediction(self, mean):
+        s = torch.tanh(mean)
+        if self.dist_min != -1.0 or self.dist_max != 1.0:
+            s = ((s + 1.0) / 2.0) * (self.dist_max - self.dist_min) + self.dist_min
+        return s
+
+
+def get_actor_distribution(action_space, seed=0, **kw_args):
+    """networks/distributions.py:984-1115 for Discrete and Box action spaces."""
+    dtype = get_space_dtype_str(action_space)
+    if dtype == "discrete":
+        return CategoricalDistribution(seed=seed)
+    if dtype == "continuous":
+        return GaussianDistribution(int(np.prod(action_space.shape)),
+                                    distribution_min=action_space.low,
+                                    distribution_max=action_space.high, seed=seed, **kw_args)
+    raise NotImplementedError(f"action space dtype {dtype} is outside this build's hot path "
+                              "(Discrete and Box only; SURVEY.md §2.1 #4)")

@@ -1,0 +1,398 @@
+"""
+PPOPolicy -- the policy surface PPO drives (policies/ppo_policy.py:26-1419 of the
+reference), rebuilt on the device-resident rollout buffer and the HIP kernels.
+
+Same constructor keywords, attributes and method names as the reference for the
+hot path: register_agent, finalize, initialize_dataset,
+initialize_episodes, get_rollout_actions, get_critic_values, add_episode_info,
+end_episodes, finalize_dataset, clear_dataset, evaluate, update_weights,
+update_learning_rate, get_bs_clip_range, save / load.
+
+What changed underneath
+  * episodes are flags in a `[T, A*E]` SoA buffer, not E Python objects
+    (utils/episode_info.py here); observations / actions may arrive as numpy
+    arrays (reference call shape) or as device tensors (no host round trip);
+  * the distribution is evaluated on the device (the reference moves the actor
+    output to the CPU: ppo_policy.py:770,930);
+  * update_weights = backward -> one RCCL all-reduce of the flat gradient bucket
+    -> fused clip + Adam kernels (reference: per-tensor pickled MPI allreduce,
+    clip_grad_norm_, Adam.step: ppo_policy.py:1032-1055).
+"""
+import os
+
+import numpy as np
+import torch
+
+from .. import kernels as K
+from ..networks.distributions import get_actor_distribution
+from ..networks.feed_forward import FeedForwardNetwork
+from ..spaces import (get_action_prediction_shape, get_flattened_space_length,
+                      get_space_dtype_str, get_space_shape)
+from ..utils import mpi_utils
+from ..utils.episode_info import PPODataset, RolloutBuffer
+from ..utils.mpi_utils import rank_print
+
+
+class CallableValue:
+    """utils/schedulers.py:11-29: constant wrapped as a callable with finalize()."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def finalize(self, status_dict):
+        pass
+
+    def __call__(self):
+        return self.value
+
+
+def _callable(v):
+    return v if callable(v) else CallableValue(v)
+
+
+class FlatAdam:
+    """
+    Adam(eps=1e-5) + clip_grad_norm_ over a flat bucket (ppo_policy.py:336-343,
+    1037-1042) as two HIP launches; step counter and lr live on the device.
+    """
+
+    def __init__(self, network, lr, eps=1e-5, betas=(0.9, 0.999)):
+        self.network = network
+        dev = network.flat_params.device
+        self.exp_avg = torch.zeros_like(network.flat_params)
+        self.exp_avg_sq = torch.zeros_like(network.flat_params)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.lr = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
+        self.norm_scratch = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.eps = eps
+        self.betas = betas
+        self.param_groups = [{"lr": float(lr)}]      # torch.optim surface for update_optimizer_lr
+
+    def zero_grad(self):
+        self.network.flat_grads.zero_()
+
+    def step(self, grad_scale=1.0, max_norm=None):
+        K.clip_adam_step(self.network.flat_params, self.network.flat_grads, self.exp_avg,
+                         self.exp_avg_sq, self.step_count, self.lr, self.norm_scratch,
+                         beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                         grad_scale=grad_scale, max_norm=max_norm, grad_norm_out=self.grad_norm)
+
+    def set_lr(self, lr):
+        self.param_groups[0]["lr"] = float(lr)
+        self.lr.fill_(float(lr))
+
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
+                "step": int(self.step_count.item()), "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count.fill_(int(sd["step"])); self.set_lr(sd["lr"])
+
+
+class PPOPolicy:
+
+    def __init__(self, name, action_space, actor_observation_space, critic_observation_space,
+                 envs_per_proc, bootstrap_clip=(-100., 100.), ac_network=FeedForwardNetwork,
+                 actor_kw_args={}, critic_kw_args={}, icm_kw_args={}, target_kl=100.,
+                 surr_clip=0.2, vf_clip=None, gradient_clip=0.5, lr=3e-4, icm_lr=3e-4,
+                 entropy_weight=0.01, kl_loss_weight=0.0, use_gae=True, gamma=0.99, lambd=0.95,
+                 dynamic_bs_clip=False, enable_icm=False, agent_shared_icm=False, icm_network=None,
+                 intr_reward_weight=1.0, icm_beta=0.8, use_huber_loss=False, test_mode=False,
+                 verbose=False, random_seed=0, **kw_args):
+        # ppo_policy.py:164-212
+        self.name = name
+        self.action_space = action_space
+        self.actor_obs_space = actor_observation_space
+        self.critic_obs_space = critic_observation_space
+        self.enable_icm = enable_icm
+        self.agent_shared_icm = agent_shared_icm
+        self.test_mode = test_mode
+        self.use_gae = use_gae
+        self.gamma = gamma
+        self.lambd = lambd
+        self.dynamic_bs_clip = dynamic_bs_clip
+        self.using_lstm = False
+        self.dataset = None
+        self.buffer = None
+        self.device = torch.device("cpu")
+        self.agent_ids = np.array([])
+        self.icm_beta = icm_beta
+        self.target_kl = target_kl
+        self.surr_clip = surr_clip
+        self.vf_clip = vf_clip
+        self.gradient_clip = gradient_clip
+        self.kl_loss_weight = kl_loss_weight
+        self.envs_per_proc = envs_per_proc
+        self.agent_grouping = False
+        self.have_step_constraints = False
+        self.have_reset_constraints = False
+        self.verbose = verbose
+        self.use_huber_loss = use_huber_loss
+        self.frozen = False
+        self.random_seed = random_seed
+        self.lr = _callable(lr)
+        self.icm_lr = _callable(icm_lr)
+        self.entropy_weight = _callable(entropy_weight)
+        self.intr_reward_weight = _callable(intr_reward_weight)
+        if vf_clip is not None:
+            # the reference's vf_clip branch dereferences self.user_huber_loss (ppo.py:2432): unusable there too
+            raise NotImplementedError("vf_clip raises AttributeError in the reference (ppo.py:2432); not reproduced")
+        if dynamic_bs_clip:
+            raise NotImplementedError("dynamic_bs_clip is outside this round's hot-path scope")
+
+        self.action_dtype = get_space_dtype_str(self.action_space)
+        if self.action_dtype not in ("discrete", "continuous"):
+            raise NotImplementedError(f"{name}: action dtype {self.action_dtype} is outside the hot-path scope")
+        self.have_bootstrap_clip = bootstrap_clip is not None
+        self.bootstrap_clip = (None if bootstrap_clip is None
+                               else (_callable(bootstrap_clip[0]), _callable(bootstrap_clip[1])))
+        self.action_dim = get_flattened_space_length(self.action_space)
+        self.action_pred_size = get_action_prediction_shape(self.action_space)[0]
+        self.network_args = dict(ac_network=ac_network, enable_icm=enable_icm, icm_network=icm_network,
+                                 actor_kw_args=actor_kw_args, critic_kw_args=critic_kw_args,
+                                 icm_kw_args=icm_kw_args)
+        self.network_args.update(kw_args)
+        self._t = 0
+
+    # ------------------------------------------------------------------ setup
+    def register_agent(self, agent_id):
+        """ppo_policy.py:355-365 (insertion order kept instead of set order: deterministic columns)."""
+        if agent_id not in list(self.agent_ids):
+            self.agent_ids = np.array(list(self.agent_ids) + [agent_id])
+
+    def finalize(self, status_dict, device):
+        """ppo_policy.py:302-345."""
+        if len(self.agent_ids) == 0:
+            self.register_agent("agent0")
+        self.agent_idxs = np.arange(len(self.agent_ids))
+        self.num_agents = self.agent_idxs.size
+        self._agent_col = {a: i for i, a in enumerate(self.agent_ids)}
+        self.device = torch.device(device)
+        self._initialize_networks(**self.network_args)
+        for c in (self.lr, self.icm_lr, self.entropy_weight, self.intr_reward_weight):
+            c.finalize(status_dict)
+        if self.have_bootstrap_clip:
+            self.bootstrap_clip[0].finalize(status_dict)
+            self.bootstrap_clip[1].finalize(status_dict)
+        self.actor_optim = FlatAdam(self.actor, self.lr(), eps=1e-5)
+        self.critic_optim = FlatAdam(self.critic, self.lr(), eps=1e-5)
+        self.icm_optim = None
+
+    def _initialize_networks(self, ac_network, enable_icm, icm_network, actor_kw_args,
+                             critic_kw_args, icm_kw_args, **kw_args):
+        """ppo_policy.py:390-472: actor out gain 0.01, critic out gain 1.0; rank-0 broadcast."""
+        if enable_icm:
+            raise NotImplementedError("ICM (config C3) is the next hot-path row; see DESIGN.md")
+        self.actor = ac_network(name="actor", in_shape=get_space_shape(self.actor_obs_space),
+                                out_shape=get_action_prediction_shape(self.action_space),
+                                out_init=0.01, test_mode=self.test_mode, **actor_kw_args)
+        self.critic = ac_network(name="critic", in_shape=get_space_shape(self.critic_obs_space),
+                                 out_shape=(1,), out_init=1.0, test_mode=self.test_mode,
+                                 **critic_kw_args)
+        self.actor.distribution = get_actor_distribution(
+            self.action_space, seed=self.random_seed + 7919 * mpi_utils.get_rank(), **actor_kw_args)
+        self._place_networks()
+        mpi_utils.broadcast_flat(self.policy_params)      # one message for actor + critic
+
+    def seed(self, seed):
+        self.random_seed = seed
+        self.actor.distribution.rng.seed = int(seed) + 7919 * mpi_utils.get_rank()
+
+    def _place_networks(self):
+        """Actor and critic buckets adjacent in one allocation: one broadcast, one all-reduce."""
+        na, nc = self.actor.bucket_size(), self.critic.bucket_size()
+        self.policy_params = torch.zeros(na + nc, dtype=torch.float32, device=self.device)
+        self.policy_grads = torch.zeros(na + nc, dtype=torch.float32, device=self.device)
+        self.actor.flatten_parameters_(self.device, (self.policy_params[:na], self.policy_grads[:na]))
+        self.critic.flatten_parameters_(self.device, (self.policy_params[na:], self.policy_grads[na:]))
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self._place_networks()
+
+    def eval(self):
+        self.actor.eval(); self.critic.eval()
+
+    def train(self):
+        self.actor.train(); self.critic.train()
+
+    def freeze(self):
+        self.frozen = True
+
+    def unfreeze(self):
+        self.frozen = False
+
+    def shuffle_agent_ids(self):
+        np.random.shuffle(self.agent_idxs)
+        self.agent_ids = self.agent_ids[self.agent_idxs]
+
+    # ---------------------------------------------------------------- rollout
+    def initialize_dataset(self):
+        """ppo_policy.py:506-526."""
+        self.dataset = PPODataset(device=self.device, action_dtype=self.action_dtype, sequence_length=1)
+
+    def initialize_episodes(self, env_batch_size, status_dict, ts_per_rollout=None):
+        """
+        ppo_policy.py:474-504.  The reference allocates E EpisodeInfo objects per
+        agent; here one `[T, A*E]` buffer.  T = timesteps per env in this rollout
+        (ts_per_rollout / envs_per_proc, ppo.py:317-318,1646-1653).
+        """
+        if ts_per_rollout is None:
+            ts_per_rollout = status_dict["global status"]["ts per rollout"] if status_dict else None
+        if ts_per_rollout is None:
+            raise ValueError("initialize_episodes needs ts_per_rollout (total steps over all envs)")
+        T = int(ts_per_rollout) // int(env_batch_size)
+        self.env_batch_size = int(env_batch_size)
+        C = self.env_batch_size * len(self.agent_ids)
+        obs_dim = int(np.prod(get_space_shape(self.actor_obs_space)))
+        cobs_dim = int(np.prod(get_space_shape(self.critic_obs_space)))
+        if self.buffer is None or (self.buffer.T, self.buffer.C) != (T, C):
+            self.buffer = RolloutBuffer(T, C, obs_dim, cobs_dim, self.action_dim, self.action_dtype,
+                                        self.device, keep_next_observations=self.enable_icm)
+        else:
+            self.buffer.end_kind.zero_()
+            self.buffer.fixed_length = True
+            self.buffer.steps_written = 0
+        self._t = 0
+        self._agents_written = 0
+        self.dataset.attach(self.buffer, self.gamma, self.lambd, self.get_bs_clip_range(None), self.use_gae)
+
+    def _to_device(self, x, dtype=torch.float32):
+        if torch.is_tensor(x):
+            return x.to(device=self.device, dtype=dtype)
+        return torch.as_tensor(np.asarray(x), dtype=dtype).to(self.device)
+
+    def get_rollout_actions(self, obs):
+        """
+        ppo_policy.py:729-794 -> (raw_action, action, log_prob).  numpy in -> numpy
+        actions out (reference contract); device tensor in -> device tensors out.
+        """
+        if len(obs.shape) < 2:
+            raise ValueError(f"get_rollout_actions expects a batch of observations, got shape {obs.shape}")
+        as_numpy = not torch.is_tensor(obs)
+        t_obs = self._to_device(obs)
+        with torch.no_grad():
+            pred = self.actor.forward_logits(t_obs)
+            action, raw_action, log_prob = self.actor.distribution.sample_distribution(pred)
+        if as_numpy:
+            return raw_action.cpu().numpy(), action.cpu().numpy(), log_prob.detach()
+        return raw_action, action, log_prob
+
+    def get_inference_actions(self, obs, deterministic):
+        t_obs = self._to_device(obs)
+        with torch.no_grad():
+            pred = self.actor.forward_logits(t_obs)
+            if deterministic:
+                return self.actor.distribution.refine_prediction(pred)
+            return self.actor.distribution.sample_distribution(pred)[0]
+
+    def get_critic_values(self, obs):
+        """ppo_policy.py:1057-1071."""
+        return self.critic(obs)
+
+    def add_episode_info(self, agent_id, critic_observations, observations, next_observations,
+                         raw_actions, actions, values, log_probs, rewards, where_done):
+        """ppo_policy.py:545-651: one env step of E transitions for `agent_id` -> row t of the buffer."""
+        col = self._agent_col[agent_id]
+        E = self.env_batch_size
+        self.buffer.write_step(self._t, slice(col * E, (col + 1) * E), critic_observations,
+                               observations, next_observations, raw_actions, actions, values,
+                               log_probs, rewards)
+        self._agents_written += 1
+        if self._agents_written == len(self.agent_ids):      # every agent of this policy has logged step t
+            self._agents_written = 0
+            self._t += 1
+
+    def end_episodes(self, agent_id, env_idxs, episode_lengths, terminal, ending_values, ending_rewards):
+        """
+        ppo_policy.py:653-712.  Called after add_episode_info of the same step.
+        ending_values / ending_rewards may have one entry per env_idx (what the
+        terminal case passes, ppo.py:1817-1819) or one per env (what the
+        bootstrapped case passes, ppo.py:1937-1938).  In the second form the
+        reference indexes them by POSITION in env_idxs (ppo_policy.py:684-689),
+        i.e. env i can receive env j's bootstrap (quirk Q1); here each env gets
+        its own value.  The two coincide whenever env_idxs == arange(E).
+        """
+        if self.frozen:
+            return
+        col = self._agent_col[agent_id]
+        E = self.env_batch_size
+        idx = self._to_device(env_idxs, torch.int64).reshape(-1)
+        if idx.numel() == 0:
+            return
+        ev = self._to_device(ending_values).reshape(-1)
+        er = self._to_device(ending_rewards).reshape(-1)
+        if ev.numel() == E and idx.numel() != E:
+            ev = ev[idx]
+        if er.numel() == E and idx.numel() != E:
+            er = er[idx]
+        t = self._t - 1 if self._agents_written == 0 else self._t
+        self.buffer.mark_ends(t, idx + col * E, self._to_device(terminal, torch.bool).reshape(-1), ev, er)
+
+    def finalize_dataset(self):
+        """ppo_policy.py:714-719."""
+        self.dataset.build()
+
+    def clear_dataset(self):
+        """ppo_policy.py:721-727 (the HBM buffer is kept for the next rollout)."""
+        self.dataset = None
+
+    def get_bs_clip_range(self, ep_rewards):
+        """ppo_policy.py:1086-1112."""
+        if not self.have_bootstrap_clip:
+            return None
+        return (self.bootstrap_clip[0](), self.bootstrap_clip[1]())
+
+    # ----------------------------------------------------------------- update
+    def evaluate(self, batch_critic_obs, batch_obs, batch_actions):
+        """ppo_policy.py:891-952 -> (values, log_probs [B,1], entropy [B])."""
+        values = self.critic(batch_critic_obs).squeeze()
+        pred = self.actor.forward_logits(batch_obs)
+        log_probs, entropy = self.actor.distribution.get_log_probs_and_entropy(pred, batch_actions)
+        return values, log_probs, entropy
+
+    def update_weights(self, actor_loss, critic_loss):
+        """ppo_policy.py:1012-1055."""
+        if self.frozen:
+            return
+        scale = 1.0 / mpi_utils.get_num_procs()
+        self.policy_grads.zero_()
+        actor_loss.backward()
+        critic_loss.backward()
+        mpi_utils.allreduce_sum_(self.policy_grads)        # actor + critic in one message
+        self.actor_optim.step(grad_scale=scale, max_norm=self.gradient_clip)
+        self.critic_optim.step(grad_scale=scale, max_norm=self.gradient_clip)
+
+    def update_learning_rate(self):
+        """ppo_policy.py:1073-1084."""
+        if self.frozen:
+            return
+        self.actor_optim.set_lr(self.lr())
+        self.critic_optim.set_lr(self.lr())
+
+    # ------------------------------------------------------------- save / load
+    def save(self, save_path, tag="latest"):
+        """ppo_policy.py:1215-1247 (`<name>-policy/<tag>/{actor,critic}_<rank>.model`, `*_optim_<rank>`)."""
+        policy_save_path = os.path.join(save_path, f"{self.name}-policy", tag)
+        os.makedirs(policy_save_path, exist_ok=True)
+        self.actor.save(policy_save_path)
+        self.critic.save(policy_save_path)
+        r = mpi_utils.get_rank()
+        torch.save(self.actor_optim.state_dict(), os.path.join(policy_save_path, f"actor_optim_{r}"))
+        torch.save(self.critic_optim.state_dict(), os.path.join(policy_save_path, f"critic_optim_{r}"))
+
+    def load(self, load_path, tag="latest"):
+        policy_load_path = os.path.join(load_path, f"{self.name}-policy", tag)
+        self.actor.load(policy_load_path)
+        self.critic.load(policy_load_path)
+        r = mpi_utils.get_rank()
+        for net, opt in (("actor", self.actor_optim), ("critic", self.critic_optim)):
+            f = os.path.join(policy_load_path, f"{net}_optim_{r}")
+            if not os.path.exists(f):
+                f = os.path.join(policy_load_path, f"{net}_optim_0")
+            opt.load_state_dict(torch.load(f, map_location="cpu"))
+
+    def __eq__(self, other):
+        return isinstance(other, PPOPolicy) and self.name == other.name

@@ -1,0 +1,410 @@
+"""
+PPO trainer for the hot path: rollout() -> dataset build (GAE) -> epochs of
+mini-batch updates, the stand-in for ppo.py:124-2567 of the reference
+(PPO.rollout :1534-2110, PPO.learn :2112-2272, PPO._ppo_batch_train :2274-2485).
+
+Device-first differences
+  * the environment is batched and device-resident (environments/synthetic.py);
+    a rollout step never leaves the GPU: actor/critic inference, sampling,
+    buffer writes and episode bookkeeping are enqueued on one stream;
+  * every trajectory scan of the rollout is one HIP launch at finalize;
+  * one mini-batch update = gather (K4) + value-normaliser update (K5) +
+    evaluate + loss fwd/bwd (K2+K3) + backward + [RCCL all-reduce] + fused
+    clip/Adam (K11) on static buffers, captured once in a hipGraph and
+    replayed; statistics stay on the device until the epoch ends (the KL early
+    stop is the only host read per epoch);
+  * the ranks meet in ONE gradient all-reduce per mini-batch (actor and critic
+    buckets are adjacent) and one all-gather of the value-normaliser moment
+    records per epoch -- the reference issues 16 pickled all-reduces, an
+    all-gather of raw data and a barrier per mini-batch.
+"""
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from .policies.ppo_policy import PPOPolicy
+from .policies.utils import generate_policy
+from .utils import mpi_utils
+from .utils.misc import RunningStatNormalizer
+from .utils.mpi_utils import rank_print
+
+
+class PPOLossFunction(torch.autograd.Function):
+    """K2+K3 as an autograd node: (logp, entropy, values) -> (actor_loss, critic_loss, scalars[8])."""
+
+    @staticmethod
+    def forward(ctx, cur_logp, entropy, values, old_logp, adv, rtg, normalize_adv, surr_clip,
+                entropy_weight, kl_loss_weight, use_huber):
+        sc, dlp, dent, dval = K.ppo_loss_fwd_bwd(
+            cur_logp.reshape(-1).contiguous(), old_logp.reshape(-1).contiguous(),
+            adv.reshape(-1).contiguous(), entropy.reshape(-1).contiguous(),
+            values.reshape(-1).contiguous(), rtg.reshape(-1).contiguous(),
+            normalize_adv, surr_clip, entropy_weight, kl_loss_weight, use_huber, 10.0)
+        ctx.save_for_backward(dlp, dent, dval)
+        ctx.shapes = (cur_logp.shape, entropy.shape, values.shape)
+        return sc[K.SC_ACTOR], sc[K.SC_CRITIC], sc
+
+    @staticmethod
+    def backward(ctx, g_actor, g_critic, g_sc):
+        dlp, dent, dval = ctx.saved_tensors
+        s0, s1, s2 = ctx.shapes
+        return ((dlp * g_actor).reshape(s0), (dent * g_actor).reshape(s1), (dval * g_critic).reshape(s2),
+                None, None, None, None, None, None, None, None)
+
+
+class PermutationLoader:
+    """
+    DataLoader(dataset, batch_size, shuffle=True) (ppo.py:2181-2184) reduced to
+    what it does here: a fresh torch.randperm per epoch (host generator, so a
+    seeded reference run can be replayed) cut into batch_size slices.
+    """
+
+    def __init__(self, dataset, batch_size, generator=None):
+        self.dataset = dataset
+        self.batch_size = int(batch_size)
+        self.generator = generator
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def epoch_permutation(self):
+        """
+        The index order one `for batch in DataLoader(..., shuffle=True)` pass uses,
+        drawing from the host RNG exactly as torch's DataLoader does so a seeded
+        run can be replayed: the iterator first draws its base seed, then
+        RandomSampler draws the permutation (from a fresh generator seeded off the
+        global RNG when no generator was given).
+        """
+        g = self.generator
+        torch.empty((), dtype=torch.int64).random_(generator=g)          # _BaseDataLoaderIter base seed
+        if g is None:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            g = torch.Generator().manual_seed(seed)
+        n = len(self.dataset)
+        perm = torch.randperm(n, generator=g)
+        torch.randperm(n, generator=g)       # RandomSampler's trailing `randperm(n)[:num_samples % n]` draw
+        return perm.to(self.dataset.device, non_blocking=True)
+
+    def __iter__(self):
+        perm = self.epoch_permutation()
+        for o in range(0, perm.numel(), self.batch_size):
+            yield perm[o:o + self.batch_size]
+
+
+class PPO:
+
+    def __init__(self, env_generator, policy_settings, policy_mapping_fn=None, device="cuda",
+                 random_seed=None, envs_per_proc=1, max_ts_per_ep=200, batch_size=256,
+                 ts_per_rollout=1024, gamma=0.99, epochs_per_iter=10, ext_reward_weight=1.0,
+                 normalize_adv=True, normalize_obs=False, normalize_rewards=False,
+                 normalize_values=True, obs_clip=None, reward_clip=None, recalc_advantages=False,
+                 use_graphs=True, verbose=False, **kw_args):
+        """
+        ppo.py:126-167.  `ts_per_rollout` is per environment (ppo.py:317-318
+        multiplies by envs_per_proc).  Observation / reward normalising wrappers
+        (environments/filter_wrappers.py) are SURVEY.md §8(f) "next" rows.
+        """
+        if normalize_obs or normalize_rewards or obs_clip or reward_clip:
+            raise NotImplementedError("obs/reward normaliser wrappers are a 'next' row (SURVEY.md §8(f).1)")
+        mpi_utils.set_torch_threads()
+        self.device = torch.device(device)
+        self.envs_per_proc = int(envs_per_proc)
+        self.ts_per_rollout = int(ts_per_rollout) * self.envs_per_proc
+        self.max_ts_per_ep = int(max_ts_per_ep)
+        self.batch_size = int(batch_size)
+        self.epochs_per_iter = int(epochs_per_iter)
+        self.normalize_adv = normalize_adv
+        self.normalize_values = normalize_values
+        self.recalc_advantages = recalc_advantages
+        self.ext_reward_weight = ext_reward_weight
+        self.use_graphs = use_graphs and self.device.type == "cuda"
+        self.verbose = verbose
+        self.random_seed = 0 if random_seed is None else int(random_seed)
+        rank = mpi_utils.get_rank()
+        # seed + rank, as ppoaf_cli.py:419 does
+        torch.manual_seed(self.random_seed + rank)
+        np.random.seed(self.random_seed + rank)
+        self.loader_generator = torch.Generator().manual_seed(self.random_seed + rank)
+
+        self.env = env_generator()
+        self.policy_mapping_fn = policy_mapping_fn or (lambda agent_id: next(iter(policy_settings)))
+        self.status_dict = OrderedDict()
+        self.status_dict["global status"] = OrderedDict(
+            iteration=0, timesteps=0, **{"rollout time": 0.0, "train time": 0.0, "running time": 0.0})
+        self.policies = {}
+        self.value_normalizers = {}
+        for policy_id, settings in policy_settings.items():
+            # the reference's 5-tuple (policy_class, obs, critic_obs, action, args), ppo.py:329-345
+            policy_class, obs_space, critic_obs_space, act_space, policy_args = \
+                settings if len(settings) == 5 else (None,) + tuple(settings)
+            policy_args = dict(policy_args)
+            policy_args.setdefault("gamma", gamma)
+            pol = generate_policy(policy_name=policy_id, policy_class=policy_class,
+                                  actor_observation_space=obs_space,
+                                  critic_observation_space=critic_obs_space, action_space=act_space,
+                                  test_mode=False, envs_per_proc=self.envs_per_proc,
+                                  random_seed=self.random_seed, **policy_args)
+            pol.register_agent("agent0")
+            self.policies[policy_id] = pol
+            self.status_dict[policy_id] = OrderedDict()
+            if normalize_values:
+                self.value_normalizers[policy_id] = RunningStatNormalizer(
+                    name=f"{policy_id}-value_normalizer", device=self.device)
+        for pol in self.policies.values():
+            pol.finalize(self.status_dict, self.device)
+        self._graphs = {}
+        self._obs = None
+
+    # ------------------------------------------------------------------ rollout
+    def get_policy_values(self, policy_id, critic_obs):
+        """ppo.py:1030-1075 + get_denormalized_values :1143-1167."""
+        with torch.no_grad():
+            v = self.policies[policy_id].get_critic_values(critic_obs).reshape(-1)
+            if self.normalize_values:
+                v = self.value_normalizers[policy_id].denormalize(v)
+        return v
+
+    def rollout(self):
+        """
+        ppo.py:1534-2110 for a batched device environment and one policy.
+        Per step: actions / log-probs (actor + sampling kernel), values (critic,
+        denormalised), env.step, buffer row write, episode-end flags -- all
+        enqueued without a host read.  Episode-end cases (ppo.py:1795-1983):
+        terminated -> terminal end; ep_ts == max_ts_per_ep, truncated, or the
+        last step of the rollout -> bootstrapped end with the critic's value of
+        the next observation.
+        """
+        start = time.time()
+        policy_id = next(iter(self.policies))
+        pol = self.policies[policy_id]
+        pol.initialize_dataset()
+        pol.eval()
+        env = self.env
+        E = env.get_batch_size()
+        T = self.ts_per_rollout // E
+        pol.initialize_episodes(E, self.status_dict, ts_per_rollout=self.ts_per_rollout)
+        buf = pol.buffer
+        obs, critic_obs = env.reset() if self._obs is None else self._obs
+        ep_ts = torch.zeros(E, dtype=torch.int32, device=self.device)
+        score_sum = torch.zeros((), dtype=torch.float64, device=self.device)
+        n_term = torch.zeros((), dtype=torch.int64, device=self.device)
+        may_end_early = getattr(env, "term_table", True) is not None or self.max_ts_per_ep < T
+        for t in range(T):
+            raw_action, action, log_prob = pol.get_rollout_actions(obs)
+            value = self.get_policy_values(policy_id, critic_obs)
+            nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(action)
+            if self.ext_reward_weight != 1.0:
+                reward = reward * self.ext_reward_weight
+            buf.write_step(t, slice(0, E), critic_obs, obs, term_obs, raw_action, action, value,
+                           log_prob, reward)
+            pol._t = t + 1
+            score_sum += reward.sum()
+            if may_end_early:
+                ep_ts += 1
+                n_term += terminated.sum()
+                last = t == T - 1
+                boot = (~terminated) & ((ep_ts >= self.max_ts_per_ep) | truncated | last)
+                buf.end_kind[t] = torch.where(terminated, 1, torch.where(boot, 2, 0)).to(torch.int8)
+                ep_ts = torch.where(terminated | boot, torch.zeros_like(ep_ts), ep_ts)
+                if not last:
+                    buf.fixed_length = False
+            obs, critic_obs = nxt_obs, nxt_cobs
+        # bootstrap values: V(next obs).  For ends before the last row the next
+        # observation's value is the value logged at t+1 (same critic, same
+        # normaliser state during a rollout); the last row needs one more pass.
+        next_value = self.get_policy_values(policy_id, critic_obs)
+        if may_end_early:
+            buf.boot_value[:-1].copy_(buf.values[1:])
+            buf.boot_value[T - 1].copy_(next_value)
+            buf.boot_reward.copy_(buf.boot_value)
+        else:
+            buf.end_kind[T - 1].fill_(2)
+            buf.boot_value[T - 1].copy_(next_value)
+            buf.boot_reward[T - 1].copy_(next_value)
+        self._obs = (obs, critic_obs)
+        pol.finalize_dataset()
+        gs = self.status_dict["global status"]
+        gs["timesteps"] += self.ts_per_rollout * mpi_utils.get_num_procs()
+        self.status_dict[policy_id]["reward sum"] = score_sum        # device scalar; read lazily
+        self.status_dict[policy_id]["terminated episodes"] = n_term
+        torch.cuda.synchronize() if self.device.type == "cuda" else None
+        gs["rollout time"] = time.time() - start
+        return pol.dataset
+
+    # ------------------------------------------------------------------ update
+    def learn(self, num_timesteps):
+        """ppo.py:2112-2272."""
+        gs = self.status_dict["global status"]
+        ts_max = gs["timesteps"] + num_timesteps
+        while gs["timesteps"] < ts_max:
+            self.rollout()
+            self.train_on_rollout()
+            gs["iteration"] += 1
+            for pol in self.policies.values():
+                pol.update_learning_rate()
+
+    def train_on_rollout(self):
+        """The epoch loop of ppo.py:2178-2249 (KL early stop :2222-2232)."""
+        start = time.time()
+        for policy_id, pol in self.policies.items():
+            if pol.frozen:
+                continue
+            pol.train()
+            loader = PermutationLoader(pol.dataset, self.batch_size, self.loader_generator)
+            for epoch_idx in range(self.epochs_per_iter):
+                if epoch_idx > 0 and self.recalc_advantages:
+                    loader.dataset.recalculate_advantages()
+                self._ppo_batch_train(loader, policy_id)
+                if self.status_dict[policy_id]["kl avg"] > pol.target_kl:
+                    if self.verbose:
+                        rank_print(f"Target KL of {pol.target_kl} has been reached. "
+                                   f"Ending early (after {epoch_idx + 1} epochs)")
+                    break
+            pol.clear_dataset()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        self.status_dict["global status"]["train time"] = time.time() - start
+
+    def _minibatch_step(self, policy_id, dataset, perm_batch, records, totals):
+        """
+        One mini-batch of ppo.py:2292-2469 on static buffers.  `records` is the
+        (already rank-gathered) moment record of this mini-batch's rewards-to-go.
+        """
+        pol = self.policies[policy_id]
+        mb = dataset.gather_minibatch(perm_batch)
+        rtg = mb["rewards_to_go"]
+        if self.normalize_values:
+            vn = self.value_normalizers[policy_id]
+            vn.running_stats.integrate_records(records)
+            rtg = vn.normalize(rtg, update_stats=False)
+        if perm_batch.numel() == 1:          # ppo.py:2305-2306 (after the normaliser update, quirk Q9)
+            return
+        values, log_probs, entropy = pol.evaluate(mb["critic_obs"], mb["obs"], mb["raw_actions"])
+        dataset.scatter_values(perm_batch, values)
+        lp = log_probs.reshape(-1)
+        sc, dlp, dent, dval = K.ppo_loss_fwd_bwd(
+            lp.detach(), mb["log_probs"], mb["advantages"], entropy.detach(), values.detach().reshape(-1),
+            rtg, self.normalize_adv, pol.surr_clip, pol.entropy_weight(), pol.kl_loss_weight,
+            pol.use_huber_loss, 10.0)
+        pol.policy_grads.zero_()
+        torch.autograd.backward([lp, entropy, values.reshape(-1)], [dlp, dent, dval])
+        totals[:8] += sc
+        totals[8] += 1.0
+
+    def _optimizer_step(self, policy_id):
+        pol = self.policies[policy_id]
+        scale = 1.0 / mpi_utils.get_num_procs()
+        pol.actor_optim.step(grad_scale=scale, max_norm=pol.gradient_clip)
+        pol.critic_optim.step(grad_scale=scale, max_norm=pol.gradient_clip)
+
+    def _ppo_batch_train(self, data_loader, policy_id):
+        """ppo.py:2274-2485: one epoch of shuffled mini-batches; fills status_dict like :2478-2485."""
+        pol = self.policies[policy_id]
+        ds = data_loader.dataset
+        B = data_loader.batch_size
+        N = len(ds)
+        world = mpi_utils.get_num_procs()
+        perm = data_loader.epoch_permutation()
+        n_full, tail = N // B, N % B
+        totals = self._scratch("totals", 9, torch.float64)
+        totals.zero_()
+        records_all = self._epoch_records(policy_id, ds, perm, B) if self.normalize_values else None
+        W3 = 3
+        rec_static = self._scratch("rec_static", world * W3, torch.float64)
+        perm_static = self._scratch(f"perm_static_{B}", B, torch.int64)
+
+        def run(perm_slice, k, static):
+            if records_all is not None:
+                rec_static.copy_(records_all[:, k].reshape(-1))
+            if static:
+                perm_static.copy_(perm_slice)
+                self._replay_or_capture(("fb", policy_id, B, pol.entropy_weight(), pol.surr_clip), lambda: self._minibatch_step(
+                    policy_id, ds, perm_static, rec_static.view(world, W3), totals))
+            else:
+                self._minibatch_step(policy_id, ds, perm_slice.contiguous(), rec_static.view(world, W3), totals)
+            if perm_slice.numel() == 1:
+                return
+            if world > 1:
+                mpi_utils.allreduce_sum_(pol.policy_grads)
+            if static:
+                self._replay_or_capture(("opt", policy_id), lambda: self._optimizer_step(policy_id))
+            else:
+                self._optimizer_step(policy_id)
+
+        for k in range(n_full):
+            run(perm[k * B:(k + 1) * B], k, self.use_graphs)
+        if tail:
+            run(perm[n_full * B:], n_full, False)
+
+        # ppo.py:2471-2485: counters and sums across ranks, then per-mini-batch averages
+        t = totals.clone()
+        if world > 1:
+            mpi_utils.allreduce_sum_(t)
+        t = t.cpu().numpy()
+        counter = max(t[8], 1.0)
+        if t[K.SC_BAD] > 0:
+            raise FloatingPointError("ratios are nan or inf (ppo.py:2361-2387)")
+        ew = pol.entropy_weight()
+        sd = self.status_dict[policy_id]
+        sd["weighted entropy"] = (t[K.SC_ENTROPY] * ew / counter) if ew != 0.0 else 0.0
+        sd["actor loss"] = t[K.SC_SURR] / counter
+        sd["critic loss"] = t[K.SC_CRITIC] / counter
+        sd["kl avg"] = t[K.SC_KL] / counter
+
+    # ------------------------------------------------------------------ helpers
+    def _scratch(self, name, n, dtype):
+        key = ("scratch", name)
+        if key not in self._graphs:
+            self._graphs[key] = torch.zeros(n, dtype=dtype, device=self.device)
+        return self._graphs[key]
+
+    def _epoch_records(self, policy_id, ds, perm, B):
+        """
+        (n, mean, M2) of the rewards-to-go of EVERY mini-batch of the epoch,
+        all-gathered across ranks once: [R, n_batches, 3].  The reference gathers
+        the raw data inside every mini-batch (ppo.py:2299-2303 -> stats.py:47-50).
+        """
+        N = perm.numel()
+        rtg = ds.buffer.rewards_to_go.view(-1)[ds.row_map.long()[perm]]
+        nb = (N + B - 1) // B
+        pad = nb * B - N
+        x = rtg.double()
+        if pad:
+            x = torch.cat([x, torch.zeros(pad, dtype=torch.float64, device=x.device)])
+        x = x.view(nb, B)
+        cnt = torch.full((nb,), float(B), dtype=torch.float64, device=x.device)
+        if pad:
+            cnt[-1] = float(B - pad)
+        mask = torch.ones(nb, B, dtype=torch.bool, device=x.device)
+        if pad:
+            mask[-1, B - pad:] = False
+        mean = (x * mask).sum(1) / cnt
+        m2 = (((x - mean[:, None]) ** 2) * mask).sum(1)
+        rec = torch.stack([cnt, mean, m2], dim=1)                     # [nb, 3]
+        world = mpi_utils.get_num_procs()
+        if world == 1:
+            return rec.unsqueeze(0)
+        out = mpi_utils.allgather_records(rec.reshape(-1))
+        return out.view(world, nb, 3)
+
+    def _replay_or_capture(self, key, fn):
+        """Capture `fn` (kernel launches on static buffers) into a hipGraph once, then replay."""
+        g = self._graphs.get(key)
+        if g is None:
+            # warm-up on a side stream (allocator + lazy init), then capture
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                fn()
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self._graphs[key] = g
+            # the warm-up + capture passes executed the step once for real (warm-up);
+            # capture itself does not execute.  Callers account for that (see below).
+            return
+        g.replay()

@@ -1,0 +1,366 @@
+"""
+Rollout buffer + dataset: the stand-in for utils/episode_info.py of the reference.
+
+Reference model (episode_info.py:169-987): one Python `EpisodeInfo` per
+(agent, env) trajectory holding Python lists, E*A `add_info` calls per env step,
+a Python reverse scan per finished episode, then `PPODataset.build` turns the
+lists into tensors in episode-completion order.
+
+MI355X model: one SoA buffer per policy resident in HBM, time-major
+`[T, C, .]` with C = agents*envs columns (coalesced writes per env step,
+coalesced column walks for the scans).  Episode boundaries are a dense int8
+`end_kind[T, C]` (+ the bootstrap value / reward of bootstrapped ends), so
+"end_episode" is a flag write and ALL GAE / rewards-to-go scans are ONE launch of
+ppoaf_gae_rtg_tmajor at finalize.  The reference's flattened episode order is
+kept as an index map (`row_map`: dataset position -> buffer row), never as a
+physical reorder; mini-batches are gathered through it.
+
+Classes
+  RolloutBuffer  -- the HBM-resident SoA
+  PPODataset     -- the reference's Dataset surface over a RolloutBuffer
+                    (__len__, __getitem__ 13-tuple, .values, recalculate_advantages)
+  EpisodeInfo    -- per-trajectory drop-in of episode_info.py:169-482 for callers
+                    that still drive single episodes (one-wave HIP scan)
+"""
+import numpy as np
+import torch
+
+from .. import kernels as K
+from .mpi_utils import rank_print
+
+END_NONE, END_TERMINAL, END_BOOTSTRAP = 0, 1, 2
+
+
+class RolloutBuffer:
+    """Device-resident `[T, C, .]` transition store for one policy (C = num_agents * num_envs)."""
+
+    def __init__(self, T, C, obs_dim, critic_obs_dim, action_dim, action_dtype, device,
+                 keep_next_observations=False):
+        self.T, self.C = int(T), int(C)
+        self.device = torch.device(device)
+        self.action_dtype = action_dtype
+        f32 = dict(dtype=torch.float32, device=self.device)
+        adt = torch.int64 if action_dtype in ("discrete", "multi-discrete") else torch.float32
+        self.observations = torch.zeros(T, C, obs_dim, **f32)
+        self.critic_observations = torch.zeros(T, C, critic_obs_dim, **f32)
+        self.next_observations = torch.zeros(T, C, obs_dim, **f32) if keep_next_observations else None
+        self.actions = torch.zeros(T, C, action_dim, dtype=adt, device=self.device)
+        self.raw_actions = torch.zeros(T, C, action_dim, dtype=adt, device=self.device)
+        self.values = torch.zeros(T, C, **f32)
+        self.log_probs = torch.zeros(T, C, **f32)
+        self.rewards = torch.zeros(T, C, **f32)
+        self.end_kind = torch.zeros(T, C, dtype=torch.int8, device=self.device)
+        self.boot_value = torch.zeros(T, C, **f32)
+        self.boot_reward = torch.zeros(T, C, **f32)
+        self.advantages = torch.zeros(T, C, **f32)
+        self.rewards_to_go = torch.zeros(T, C, **f32)
+        self.fixed_length = True          # flips when an end is recorded before row T-1
+        self.steps_written = 0
+        # persistent across rollouts (hipGraph replays hold these addresses)
+        self.row_map = torch.zeros(T * C, dtype=torch.int32, device=self.device)
+        self._batch = {}
+
+    @property
+    def num_transitions(self):
+        return self.T * self.C
+
+    def write_step(self, t, cols, critic_obs, obs, next_obs, raw_actions, actions, values,
+                   log_probs, rewards):
+        """One env step for the columns `cols` (slice): the batched form of EpisodeInfo.add_info (:303-399)."""
+        as_t = self._as_tensor
+        self.observations[t, cols].copy_(as_t(obs, torch.float32).reshape(self.observations[t, cols].shape))
+        self.critic_observations[t, cols].copy_(
+            as_t(critic_obs, torch.float32).reshape(self.critic_observations[t, cols].shape))
+        if self.next_observations is not None:
+            self.next_observations[t, cols].copy_(
+                as_t(next_obs, torch.float32).reshape(self.next_observations[t, cols].shape))
+        adt = self.actions.dtype
+        self.actions[t, cols].copy_(as_t(actions, adt).reshape(self.actions[t, cols].shape))
+        self.raw_actions[t, cols].copy_(as_t(raw_actions, adt).reshape(self.raw_actions[t, cols].shape))
+        self.values[t, cols].copy_(as_t(values, torch.float32).reshape(-1))
+        self.log_probs[t, cols].copy_(as_t(log_probs, torch.float32).reshape(-1))
+        self.rewards[t, cols].copy_(as_t(rewards, torch.float32).reshape(-1))
+        self.steps_written = max(self.steps_written, t + 1)
+
+    def _as_tensor(self, x, dtype):
+        if torch.is_tensor(x):
+            return x.detach().to(device=self.device, dtype=dtype)
+        return torch.as_tensor(np.asarray(x), dtype=dtype).to(self.device)
+
+    def mark_ends(self, t, col_idxs, terminal, ending_values, ending_rewards):
+        """
+        Batched EpisodeInfo.end_episode bookkeeping (:419-443): record that the
+        trajectories of `col_idxs` end after step t.  The scans run at finalize.
+        """
+        col_idxs = self._as_tensor(col_idxs, torch.int64)
+        if col_idxs.numel() == 0:
+            return
+        terminal = self._as_tensor(terminal, torch.bool)
+        kind = torch.where(terminal, torch.tensor(END_TERMINAL, dtype=torch.int8, device=self.device),
+                           torch.tensor(END_BOOTSTRAP, dtype=torch.int8, device=self.device))
+        self.end_kind[t].index_copy_(0, col_idxs, kind.expand(col_idxs.numel()).contiguous())
+        self.boot_value[t].index_copy_(0, col_idxs, self._as_tensor(ending_values, torch.float32).reshape(-1))
+        self.boot_reward[t].index_copy_(0, col_idxs, self._as_tensor(ending_rewards, torch.float32).reshape(-1))
+        if t != self.T - 1:
+            self.fixed_length = False
+
+    def compute_advantages(self, gamma, lambd, bootstrap_clip, use_gae, adv_only=False):
+        """All GAE + rewards-to-go scans of the rollout: one launch (K1)."""
+        rtg_out = torch.empty_like(self.rewards_to_go) if adv_only else self.rewards_to_go
+        if self.fixed_length:
+            K.gae_rtg_tmajor(self.rewards, self.values, self.boot_value[self.T - 1],
+                             self.boot_reward[self.T - 1], None, gamma, lambd, bootstrap_clip,
+                             use_gae, self.advantages, rtg_out)
+        else:
+            K.gae_rtg_tmajor(self.rewards, self.values, self.boot_value, self.boot_reward,
+                             self.end_kind, gamma, lambd, bootstrap_clip, use_gae,
+                             self.advantages, rtg_out)
+
+    def build_row_map(self):
+        """
+        dataset position (the reference's episode-completion order: for each t,
+        terminal ends by column, then bootstrapped ends by column --
+        ppo.py:1810-1819,1873-1877,1932-1938 + combine_episodes :85-118) -> buffer
+        row t*C + c, plus the episode lengths in that order.
+        """
+        T, C = self.T, self.C
+        if self.fixed_length:
+            n = torch.arange(T * C, device=self.device, dtype=torch.int64)
+            self.row_map.copy_(((n % T) * C + n // T).to(torch.int32))
+            return self.row_map, torch.full((C,), T, dtype=torch.int64, device=self.device)
+        ek = self.end_kind
+        ends = ek != 0
+        # segment start of every cell: 1 + index of the previous end in its column (0 if none)
+        t_idx = torch.arange(T, device=self.device, dtype=torch.int64)[:, None].expand(T, C)
+        prev_end = torch.where(ends, t_idx + 1, torch.zeros_like(t_idx))
+        prev_end = torch.cat([torch.zeros(1, C, dtype=torch.int64, device=self.device),
+                              torch.cummax(prev_end, dim=0).values[:-1]], dim=0)      # start t0 per cell
+        # segment end of every cell: next end at or after t (reverse cummin)
+        big = torch.full_like(t_idx, T)
+        nxt = torch.where(ends, t_idx, big)
+        seg_end = torch.flip(torch.cummin(torch.flip(nxt, [0]), dim=0).values, [0])
+        if bool((seg_end >= T).any()):
+            raise RuntimeError("rollout buffer has an unfinished episode (every column must end at row T-1; "
+                               "ppo.py:1870-1871)")
+        # order key of a segment ending at (t1, kind, c): (t1, kind-1, c)
+        kind_end = torch.gather(ek.to(torch.int64), 0, seg_end)
+        seg_len_at_end = torch.where(ends, t_idx + 1 - prev_end, torch.zeros_like(t_idx))     # [T,C]
+        lens3 = torch.zeros(T, 2, C, dtype=torch.int64, device=self.device)
+        lens3[:, 0][ek == END_TERMINAL] = seg_len_at_end[ek == END_TERMINAL]
+        lens3[:, 1][ek == END_BOOTSTRAP] = seg_len_at_end[ek == END_BOOTSTRAP]
+        flat_lens = lens3.reshape(-1)
+        offs = torch.cumsum(flat_lens, 0) - flat_lens                                         # exclusive
+        c_idx = torch.arange(C, device=self.device, dtype=torch.int64)[None, :].expand(T, C)
+        key = seg_end * (2 * C) + (kind_end - 1) * C + c_idx
+        pos = offs[key] + (t_idx - prev_end)                                                  # dataset position
+        self.row_map[pos.reshape(-1)] = (t_idx * C + c_idx).reshape(-1).to(torch.int32)
+        ep_lens = flat_lens[flat_lens > 0]
+        return self.row_map, ep_lens
+
+    def minibatch_buffers(self, B):
+        """Static per-batch-size gather destinations (graph-capture friendly)."""
+        if B not in self._batch:
+            mk = lambda t: torch.empty((B,) + tuple(t.shape[2:]), dtype=t.dtype, device=self.device)
+            d = dict(critic_obs=mk(self.critic_observations), obs=mk(self.observations),
+                     raw_actions=mk(self.raw_actions), advantages=mk(self.advantages),
+                     log_probs=mk(self.log_probs), rewards_to_go=mk(self.rewards_to_go))
+            if self.next_observations is not None:
+                d["next_obs"] = mk(self.next_observations)
+                d["actions"] = mk(self.actions)
+            self._batch[B] = d
+        return self._batch[B]
+
+
+class _ValuesProxy:
+    """`dataset.values[batch_idxs] = v` (ppo.py:2340) routed through the row map."""
+
+    def __init__(self, dataset):
+        self._d = dataset
+
+    def __setitem__(self, idx, src):
+        idx = self._d._idx_tensor(idx)
+        K.scatter_rows_f32(src.detach().reshape(-1).contiguous().float(), idx,
+                           self._d.buffer.values.view(-1), self._d.row_map)
+
+    def __getitem__(self, idx):
+        idx = self._d._idx_tensor(idx)
+        return self._d.buffer.values.view(-1)[self._d.row_map[idx].long()]
+
+    def __len__(self):
+        return len(self._d)
+
+
+class PPODataset:
+    """
+    The Dataset surface PPO consumes (episode_info.py:647-987) over a RolloutBuffer:
+      len(ds), ds[idx] -> 13-tuple (:940-952), ds.values[...] = ..., ds.recalculate_advantages().
+    `gather_minibatch(perm)` is the fused form of DataLoader + __getitem__ + collate (K4).
+    """
+
+    def __init__(self, device, action_dtype, sequence_length=1):
+        if sequence_length != 1:
+            raise NotImplementedError("sequence_length > 1 (LSTM windows) is a 'next' row of SURVEY.md §8(f)")
+        self.device = torch.device(device)
+        self.action_dtype = action_dtype
+        self.sequence_length = 1
+        self.buffer = None
+        self.is_built = False
+        self.row_map = None
+        self.ep_lens = None
+        self.gae_args = None
+
+    def attach(self, buffer, gamma, lambd, bootstrap_clip, use_gae):
+        self.buffer = buffer
+        self.gae_args = (gamma, lambd, bootstrap_clip, use_gae)
+
+    def build(self):
+        """episode_info.py:745-914: scans + ordering; no list->tensor conversion is left to do."""
+        if self.is_built:
+            raise RuntimeError("attempting to build a dataset that has already been built")
+        b = self.buffer
+        if b.steps_written != b.T:
+            raise RuntimeError(f"rollout buffer holds {b.steps_written} of {b.T} steps")
+        b.compute_advantages(*self.gae_args)
+        self.row_map, self.ep_lens = b.build_row_map()
+        self.total_timestates = b.num_transitions
+        self.values = _ValuesProxy(self)
+        self.is_built = True
+
+    def recalculate_advantages(self):
+        """episode_info.py:721-743: new values -> new GAE advantages; rewards-to-go stay."""
+        if not self.is_built:
+            rank_print("WARNING: recalculate_advantages was called before the dataset has been built. Ignoring call.")
+            return
+        self.buffer.compute_advantages(*self.gae_args, adv_only=True)
+
+    def __len__(self):
+        return self.total_timestates
+
+    def _idx_tensor(self, idx):
+        if torch.is_tensor(idx):
+            return idx.to(device=self.device, dtype=torch.int64).reshape(-1).contiguous()
+        return torch.as_tensor(np.atleast_1d(np.asarray(idx)), dtype=torch.int64).to(self.device)
+
+    # flat views in the reference's order (materialised on demand; not used by the hot loop)
+    def _flat(self, t):
+        return t.reshape((self.buffer.num_transitions,) + tuple(t.shape[2:]))[self.row_map.long()]
+
+    @property
+    def observations(self): return self._flat(self.buffer.observations)
+    @property
+    def critic_observations(self): return self._flat(self.buffer.critic_observations)
+    @property
+    def next_observations(self):
+        return None if self.buffer.next_observations is None else self._flat(self.buffer.next_observations)
+    @property
+    def actions(self): return self._flat(self.buffer.actions)
+    @property
+    def raw_actions(self): return self._flat(self.buffer.raw_actions)
+    @property
+    def advantages(self): return self._flat(self.buffer.advantages)
+    @property
+    def log_probs(self): return self._flat(self.buffer.log_probs)
+    @property
+    def rewards_to_go(self): return self._flat(self.buffer.rewards_to_go)
+
+    def __getitem__(self, idx):
+        """13-tuple of episode_info.py:940-952 (hidden/cell slots are the uint8 zeros of :860-866)."""
+        b = self.buffer
+        row = int(self.row_map[idx])
+        f = lambda t: t.reshape((b.num_transitions,) + tuple(t.shape[2:]))[row]
+        empty = torch.zeros((), dtype=torch.uint8)
+        nxt = f(b.next_observations) if b.next_observations is not None else torch.zeros_like(f(b.observations))
+        return (f(b.critic_observations), f(b.observations), nxt, f(b.raw_actions), f(b.actions),
+                f(b.advantages), f(b.log_probs), f(b.rewards_to_go), empty, empty, empty, empty, idx)
+
+    def minibatch_buffers(self, B):
+        return self.buffer.minibatch_buffers(B)
+
+    def gather_minibatch(self, perm_batch, out=None):
+        """K4: every field of the mini-batch in one launch; rows = row_map[perm_batch]."""
+        b = self.buffer
+        B = perm_batch.numel()
+        out = self.minibatch_buffers(B) if out is None else out
+        N = b.num_transitions
+        v = lambda t: t.view((N,) + tuple(t.shape[2:]))
+        pairs = [(v(b.critic_observations), out["critic_obs"]), (v(b.observations), out["obs"]),
+                 (v(b.raw_actions), out["raw_actions"]), (v(b.advantages), out["advantages"]),
+                 (v(b.log_probs), out["log_probs"]), (v(b.rewards_to_go), out["rewards_to_go"])]
+        if "next_obs" in out:
+            pairs += [(v(b.next_observations), out["next_obs"]), (v(b.actions), out["actions"])]
+        K.minibatch_gather(pairs, perm_batch, self.row_map)
+        return out
+
+    def scatter_values(self, perm_batch, values):
+        """ppo.py:2340."""
+        K.scatter_rows_f32(values.detach().reshape(-1).contiguous(), perm_batch,
+                           self.buffer.values.view(-1), self.row_map)
+
+
+class EpisodeInfo:
+    """
+    Per-trajectory container with the reference's constructor and methods
+    (episode_info.py:169-482) for callers that drive single episodes.  Steps are
+    staged on the host exactly as the reference stages them (Python lists); the
+    arithmetic of end_episode -- rewards-to-go and GAE scans -- runs on the GPU
+    (one wave, ppoaf_gae_rtg_traj).  The throughput path is RolloutBuffer.
+    """
+
+    def __init__(self, starting_ts=0, use_gae=False, gamma=0.99, lambd=0.95,
+                 bootstrap_clip=(-10., 10.), device="cuda"):
+        self.starting_ts = starting_ts
+        self.ending_ts = -1
+        self.use_gae = use_gae
+        self.gamma = gamma
+        self.lambd = lambd
+        self.bootstrap_clip = bootstrap_clip
+        self.device = torch.device(device)
+        self.critic_observations, self.observations, self.next_observations = [], [], []
+        self.actions, self.raw_actions, self.log_probs = [], [], []
+        self.rewards, self.values = [], []
+        self.rewards_to_go = None
+        self.advantages = None
+        self.length = 0
+        self.is_finished = False
+        self.has_hidden_states = False
+
+    def add_info(self, observation, next_observation, raw_action, action, value, log_prob, reward,
+                 critic_observation=np.empty(0), **hidden):
+        if any(len(h) > 0 for h in hidden.values()):
+            raise NotImplementedError("LSTM hidden states are a 'next' row of SURVEY.md §8(f)")
+        self.observations.append(observation)
+        self.next_observations.append(next_observation)
+        self.actions.append(action)
+        self.raw_actions.append(raw_action)
+        self.values.append(value)
+        self.log_probs.append(log_prob)
+        self.rewards.append(reward)
+        self.critic_observations.append(critic_observation)
+
+    def _scan(self):
+        L = len(self.rewards)
+        dev = self.device
+        r = torch.tensor(np.asarray(self.rewards, dtype=np.float32), device=dev)
+        v = torch.tensor(np.asarray(self.values, dtype=np.float32), device=dev)
+        ev = torch.tensor([self.ending_value], dtype=torch.float32, device=dev)
+        er = torch.tensor([self._ending_reward], dtype=torch.float32, device=dev)
+        start = torch.zeros(1, dtype=torch.int64, device=dev)
+        ln = torch.tensor([L], dtype=torch.int32, device=dev)
+        return K.gae_rtg_traj(r, v, ev, er, start, ln, self.gamma, self.lambd, self.bootstrap_clip,
+                              self.use_gae)
+
+    def compute_advantages(self):
+        adv, _ = self._scan()
+        self.advantages = adv.cpu().numpy()
+
+    def end_episode(self, ending_ts, terminal, ending_value, ending_reward):
+        self.ending_ts = ending_ts
+        self.terminal = terminal
+        self.length = self.ending_ts - self.starting_ts
+        self.is_finished = True
+        self.ending_value = float(ending_value)
+        self._ending_reward = float(ending_reward)
+        adv, rtg = self._scan()
+        self.rewards_to_go = rtg.cpu().numpy()
+        self.advantages = adv.cpu().numpy()
+        self.values = np.array(self.values).astype(np.float32)

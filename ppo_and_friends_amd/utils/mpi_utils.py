@@ -1,0 +1,162 @@
+"""
+Rank utilities and DD-PPO collectives -- the stand-in for the reference's
+utils/mpi_utils.py (mpi4py on COMM_WORLD) with one process per GPU and
+torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" for the
+CPU tests of the host logic).
+
+Reference call sites replaced:
+  broadcast_model_parameters   mpi_utils.py:50-63   per-tensor Bcast  -> ONE broadcast of the flat bucket
+  mpi_avg / mpi_avg_gradients  mpi_utils.py:65-111  per-tensor pickled allreduce
+                                                    -> ONE all-reduce(SUM) of the flat gradient bucket;
+                                                       the 1/num_procs is folded into the Adam kernel
+  RunningMeanStd allgather     stats.py:47-50       raw data allgather -> all-gather of (n, mean, M2)
+  comm.barrier()               ppo.py:2221,2468...  not needed: collectives on a stream order the ranks
+
+No process group (single rank) is the common case: every function then
+degenerates to the identity, as the reference's do for num_procs == 1.
+"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+
+def is_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_rank():
+    return dist.get_rank() if is_initialized() else 0
+
+
+def get_num_procs():
+    return dist.get_world_size() if is_initialized() else 1
+
+
+def init_process_group_from_env(backend=None):
+    """
+    torchrun-style bootstrap (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), the
+    replacement for `mpirun -n N` (README.md:88-103).  Returns (rank, world, local_rank).
+    """
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def rank_print(msg, root=0, debug=False):
+    """mpi_utils.py:11-35."""
+    if root == get_rank():
+        print("{}: {}".format(root, msg))
+    sys.stdout.flush()
+
+
+def set_torch_threads():
+    """mpi_utils.py:37-48: cap intra-op threads at threads / num_procs."""
+    if torch.get_num_threads() == 1:
+        return
+    torch.set_num_threads(max(int(torch.get_num_threads() / get_num_procs()), 1))
+
+
+def broadcast_flat(flat, root=0):
+    """One broadcast of a flat parameter bucket from `root`."""
+    if get_num_procs() > 1:
+        dist.broadcast(flat, src=root)
+    return flat
+
+
+def broadcast_model_parameters(model):
+    """
+    mpi_utils.py:50-63.  Models built by this package keep their parameters in
+    one flat bucket (`model.flat_params`): that is broadcast in one message;
+    foreign nn.Modules fall back to one broadcast per tensor.
+    """
+    if get_num_procs() == 1:
+        return
+    flat = getattr(model, "flat_params", None)
+    if flat is not None:
+        broadcast_flat(flat)
+        return
+    for p in model.parameters():
+        dist.broadcast(p.data, src=0)
+
+
+def allreduce_sum_(t):
+    """In-place SUM all-reduce (identity on one rank)."""
+    if get_num_procs() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def mpi_avg(data):
+    """mpi_utils.py:65-86: average a float / int / tensor across ranks."""
+    n = get_num_procs()
+    if n == 1:
+        return data
+    if torch.is_tensor(data):
+        t = data.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t / n
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" \
+        else torch.device("cpu")
+    t = torch.tensor([float(data)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.item() / n
+
+
+def mpi_avg_gradients(model):
+    """
+    mpi_utils.py:89-111.  For this package's flat-bucket models the SUM is one
+    all-reduce of `model.flat_grads` and the division by num_procs happens in
+    the fused Adam kernel (grad_scale); for foreign modules gradients are
+    averaged per tensor, in place.
+    """
+    n = get_num_procs()
+    if n == 1:
+        return
+    flat = getattr(model, "flat_grads", None)
+    if flat is not None:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return
+    for p in model.parameters():
+        if p.grad is None:
+            continue
+        dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+        p.grad.div_(n)
+
+
+def allgather_records(rec):
+    """
+    All-gather a small fixed-size record (e.g. the (n, mean, M2) moments of a
+    batch): returns [R, len(rec)] (R = 1 without a process group).
+    """
+    n = get_num_procs()
+    if n == 1:
+        return rec.reshape(1, -1)
+    out = torch.empty(n, rec.numel(), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, rec.reshape(1, -1).contiguous())
+    return out
+
+
+def allreduce_scalars(values, op="sum"):
+    """One packed all-reduce for a list of Python scalars (ppo.py:2471-2475, 1991-2094)."""
+    if get_num_procs() == 1:
+        return list(values)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" \
+        else torch.device("cpu")
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+    rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
+    dist.all_reduce(t, op=rop)
+    return t.tolist()
