@@ -258,6 +258,90 @@ int ppoaf_clip_adam_step(float* params, const float* grads,
                          double* norm_scratch, float* grad_norm_out /* NULL ok */,
                          ppoaf_stream_t stream);
 
+
+/* ------------------------------------------------------------------------ *
+ * K12  fused PPO mini-batch update for MLP actor/critic (discrete or
+ *      tanh-Gaussian head): the whole body of one iteration of
+ *      PPO._ppo_batch_train  ppo.py:2292-2469  in three launches
+ *
+ *   ppoaf_ppo_update_fwd_bwd : grid (ceil(B/16), 2 networks).  Each workgroup
+ *        gathers its 16 rows through perm / row_map (K4), the critic side
+ *        integrates this mini-batch's value-normaliser record and normalises
+ *        rewards-to-go (K5, ppo.py:2299-2303), the actor side normalises the
+ *        advantages over the whole mini-batch (K2, :2325-2333); forward through
+ *        the MLP (hidden layers on f32 MFMA 16x16x4, exact fmaf chains),
+ *        distribution log-prob / entropy (K6), loss terms (K3), dataset.values
+ *        write-back (:2340), backward through the MLP; weight-gradient partials
+ *        go to this workgroup's slab with plain stores (no atomics: the sum
+ *        order is fixed, results are bitwise reproducible).
+ *   ppoaf_ppo_update_reduce  : slabs -> flat gradient bucket (fixed order),
+ *        per-workgroup loss partials -> running totals; optionally the squared
+ *        gradient norms (single rank).  An all-reduce of the bucket goes
+ *        between this and the next call on multi-rank runs.
+ *   ppoaf_ppo_update_adam    : [norms if not done] clip + Adam for both
+ *        networks (ppo_policy.py:1037-1055), advances the mini-batch cursor.
+ *
+ * All three read the mini-batch index from a device cursor, so one captured
+ * hipGraph of N repetitions walks N consecutive mini-batches of the epoch.
+ * Network parameters are the flat bucket of nn.Linear tensors in module order
+ * (weight [out,in] row-major then bias, each padded to 4 floats), hidden
+ * layers of equal width H (multiple of 16, <= 256), depth >= 1.
+ * ------------------------------------------------------------------------ */
+#define PPOAF_ACT_RELU        0
+#define PPOAF_ACT_LEAKY_RELU  1      /* negative slope 0.01 (nn.LeakyReLU default) */
+#define PPOAF_ACT_TANH        2
+#define PPOAF_HEAD_CATEGORICAL 0
+#define PPOAF_HEAD_GAUSSIAN    1
+#define PPOAF_UPDATE_ROWS_PER_WG 16
+
+typedef struct {
+    int32_t in_dim, hidden, depth, out_dim;   /* depth = number of hidden layers */
+    int32_t activation, _pad;
+    int64_t offset;        /* first float of this network inside the policy bucket */
+    int64_t size;          /* floats of this network's bucket (incl. padding + log_std) */
+    int64_t log_std_offset;/* actor, Gaussian head: offset of log_std [out_dim] inside the bucket, else -1 */
+} ppoaf_mlp_desc_t;
+
+typedef struct {
+    ppoaf_mlp_desc_t actor, critic;
+    /* parameters / optimiser state: one bucket, actor then critic */
+    float* params; float* grads; float* exp_avg; float* exp_avg_sq;
+    float* slabs;                 /* [n_wg, bucket_total] gradient partials               */
+    int64_t bucket_total;
+    int64_t* step_counts;         /* [2] Adam steps (actor, critic), incremented per call  */
+    const float* lr;              /* [1] device                                            */
+    double* norm_scratch;         /* [2] squared norms                                     */
+    float beta1, beta2, adam_eps, grad_scale, max_norm; int32_t head_kind;
+    /* rollout buffer (time-major rows) */
+    const float* obs; const float* critic_obs; const void* raw_actions;  /* int64 [n,1] or f32 [n,D] */
+    const float* advantages; const float* old_log_probs; const float* rewards_to_go;
+    float* values;                /* write-back target                                     */
+    const int64_t* perm; const int32_t* row_map; int64_t n_rows;
+    int64_t* cursor;              /* [1] mini-batch index within the epoch                 */
+    int64_t B;                    /* rows of this mini-batch (<= batch capacity)           */
+    int64_t batch_stride;         /* perm offset of mini-batch k = k * batch_stride        */
+    /* value normaliser: double-buffered state (slot = cursor & 1), records [n_batches, R, 3] */
+    int32_t normalize_values, n_ranks;
+    float* vn_mean; float* vn_var; double* vn_count;    /* [2] each */
+    const double* vn_records;
+    /* loss */
+    int32_t normalize_adv, use_huber;
+    float surr_clip, entropy_weight, kl_loss_weight, huber_delta, min_std, _pad2;
+    float* loss_partials;         /* [2, n_wg, 8]                                          */
+    double* totals;               /* [9] sums of the 8 loss scalars + mini-batch count     */
+} ppoaf_ppo_update_args_t;
+
+int ppoaf_ppo_update_fwd_bwd(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t stream);
+int ppoaf_ppo_update_reduce(const ppoaf_ppo_update_args_t* args, int compute_norms, ppoaf_stream_t stream);
+int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int compute_norms, ppoaf_stream_t stream);
+
+/* (n, mean, M2) float64 records of the rewards-to-go of every mini-batch of an
+ * epoch: records[k] covers perm[k*B : min((k+1)*B, n_perm)]  (ppo.py:2299-2303,
+ * utils/stats.py:52-54 batched).  One workgroup per mini-batch. */
+int ppoaf_minibatch_moments(const float* data, const int64_t* perm, const int32_t* row_map,
+                            int64_t n_perm, int64_t B, double* records /* [ceil(n/B), 3] */,
+                            ppoaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,35 @@ class GatherField(C.Structure):
                 ("row_bytes", C.c_int32), ("_pad", C.c_int32)]
 
 
+class MlpDesc(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32), ("depth", C.c_int32),
+                ("out_dim", C.c_int32), ("activation", C.c_int32), ("_pad", C.c_int32),
+                ("offset", C.c_int64), ("size", C.c_int64), ("log_std_offset", C.c_int64)]
+
+
+class PpoUpdateArgs(C.Structure):
+    """ppoaf_ppo_update_args_t (include/ppoaf_hip.h) -- field order must match the header."""
+    _fields_ = [("actor", MlpDesc), ("critic", MlpDesc),
+                ("params", C.c_void_p), ("grads", C.c_void_p), ("exp_avg", C.c_void_p),
+                ("exp_avg_sq", C.c_void_p), ("slabs", C.c_void_p), ("bucket_total", C.c_int64),
+                ("step_counts", C.c_void_p), ("lr", C.c_void_p), ("norm_scratch", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+                ("grad_scale", C.c_float), ("max_norm", C.c_float), ("head_kind", C.c_int32),
+                ("obs", C.c_void_p), ("critic_obs", C.c_void_p), ("raw_actions", C.c_void_p),
+                ("advantages", C.c_void_p), ("old_log_probs", C.c_void_p),
+                ("rewards_to_go", C.c_void_p), ("values", C.c_void_p),
+                ("perm", C.c_void_p), ("row_map", C.c_void_p), ("n_rows", C.c_int64),
+                ("cursor", C.c_void_p), ("B", C.c_int64), ("batch_stride", C.c_int64),
+                ("normalize_values", C.c_int32), ("n_ranks", C.c_int32),
+                ("vn_mean", C.c_void_p), ("vn_var", C.c_void_p), ("vn_count", C.c_void_p),
+                ("vn_records", C.c_void_p),
+                ("normalize_adv", C.c_int32), ("use_huber", C.c_int32),
+                ("surr_clip", C.c_float), ("entropy_weight", C.c_float),
+                ("kl_loss_weight", C.c_float), ("huber_delta", C.c_float),
+                ("min_std", C.c_float), ("_pad2", C.c_float),
+                ("loss_partials", C.c_void_p), ("totals", C.c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/ppoaf_hip.h one to one.
 SIGNATURES = {
     "ppoaf_abi_version": (C.c_int, []),
@@ -63,6 +92,10 @@ SIGNATURES = {
     "ppoaf_clip_adam_step": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr, _ptr,
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        _ptr, _ptr, _ptr]),
+    "ppoaf_ppo_update_fwd_bwd": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr]),
+    "ppoaf_ppo_update_reduce": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
+    "ppoaf_ppo_update_adam": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
+    "ppoaf_minibatch_moments": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int64, _ptr, _ptr]),
 }
 
 _lib = None

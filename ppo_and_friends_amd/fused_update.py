@@ -1,0 +1,272 @@
+"""
+Host driver of the fused mini-batch update kernels (K12, csrc/ppo_update.hip).
+
+One epoch of PPO._ppo_batch_train (ppo.py:2274-2485) for an MLP actor/critic:
+  begin_epoch : value-normaliser records of every mini-batch (one launch, one
+                all-gather across ranks), cursor / totals reset
+  run_epoch   : per mini-batch  fwd_bwd -> reduce -> [all-reduce] -> adam;
+                on a single rank, `graph_chunk` consecutive mini-batches are
+                captured once into a hipGraph (3 kernel nodes each, all reading
+                the device cursor) and replayed
+  end_epoch   : normaliser state back to its owner, totals to the host (the only
+                host read of the epoch: the KL early stop needs it)
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import kernels as K
+from .networks.distributions import CategoricalDistribution, GaussianDistribution
+from .networks.feed_forward import FeedForwardNetwork
+from .utils import mpi_utils
+
+
+def _activation_code(act):
+    if isinstance(act, nn.ReLU):
+        return K.ACT_RELU
+    if isinstance(act, nn.LeakyReLU) and abs(act.negative_slope - 0.01) < 1e-12:
+        return K.ACT_LEAKY_RELU
+    if isinstance(act, nn.Tanh):
+        return K.ACT_TANH
+    return None
+
+
+def _describe(net, bucket, with_log_std):
+    """MlpDesc of a FeedForwardNetwork living in `bucket`, or (None, reason)."""
+    if not isinstance(net, FeedForwardNetwork) or net.is_embedded:
+        return None, "network is not a plain FeedForwardNetwork"
+    dims = net.layer_dims()
+    if len(dims) < 2:
+        return None, "needs at least one hidden layer"
+    H = dims[0][1]
+    if any(o != H for (_, o) in dims[:-1]) or any(i != H for (i, _) in dims[1:]):
+        return None, "hidden layers must share one width"
+    if H % 16 or not (16 <= H <= 256):
+        return None, f"hidden width {H} must be a multiple of 16 in [16, 256]"
+    act = _activation_code(net.activation)
+    if act is None:
+        return None, f"activation {net.activation} is not one of ReLU / LeakyReLU(0.01) / Tanh"
+    out_dim = dims[-1][1]
+    if out_dim > 8:
+        return None, f"output width {out_dim} > 8"
+    d = _lib.MlpDesc()
+    d.in_dim, d.hidden, d.depth, d.out_dim, d.activation = dims[0][0], H, len(dims) - 1, out_dim, act
+    base = bucket.data_ptr()
+    d.offset = (net.flat_params.data_ptr() - base) // 4
+    d.size = net.flat_params.numel()
+    # the kernel assumes module order weight, bias per Linear, each padded to 4 floats
+    off = 0
+    lin = [m for m in net.sequential_net.modules() if isinstance(m, nn.Linear)]
+    for m in lin:
+        for p in (m.weight, m.bias):
+            if (p.data_ptr() - net.flat_params.data_ptr()) // 4 != off:
+                return None, "parameter layout differs from the kernel's layer table"
+            off += (p.numel() + 3) // 4 * 4
+    d.log_std_offset = -1
+    if with_log_std:
+        ls = net.distribution.log_std
+        if (ls.data_ptr() - net.flat_params.data_ptr()) // 4 != off:
+            return None, "log_std is not placed after the MLP parameters"
+        d.log_std_offset = off
+        off += (ls.numel() + 3) // 4 * 4
+    if off != d.size:
+        return None, "network holds parameters the fused kernel does not know about"
+    return d, ""
+
+
+class FusedPolicyUpdate:
+
+    graph_chunk = 32
+
+    @staticmethod
+    def unsupported_reason(pol, batch_size):
+        """'' when the fused kernels cover this policy, else why not (the torch path is used then)."""
+        if pol.using_lstm or pol.enable_icm or pol.agent_grouping:
+            return "LSTM / ICM / grouped policies are not covered by the fused MLP update"
+        dist = pol.actor.distribution
+        if isinstance(dist, CategoricalDistribution):
+            head = K.HEAD_CATEGORICAL
+        elif isinstance(dist, GaussianDistribution):
+            head = K.HEAD_GAUSSIAN
+        else:
+            return "unknown action distribution"
+        a, why = _describe(pol.actor, pol.policy_params, head == K.HEAD_GAUSSIAN)
+        if a is None:
+            return "actor: " + why
+        c, why = _describe(pol.critic, pol.policy_params, False)
+        if c is None:
+            return "critic: " + why
+        if c.out_dim != 1:
+            return "critic must have one output"
+        if a.offset != 0 or c.offset != a.size:
+            return "actor and critic buckets are not adjacent"
+        if batch_size < 2:
+            return "batch size < 2"
+        return ""
+
+    def __init__(self, ppo, policy_id):
+        self.ppo = ppo
+        self.policy_id = policy_id
+        pol = ppo.policies[policy_id]
+        self.pol = pol
+        dev = pol.device
+        self.world = mpi_utils.get_num_procs()
+        self.head = K.HEAD_GAUSSIAN if isinstance(pol.actor.distribution, GaussianDistribution) \
+            else K.HEAD_CATEGORICAL
+        self.actor_desc, _ = _describe(pol.actor, pol.policy_params, self.head == K.HEAD_GAUSSIAN)
+        self.critic_desc, _ = _describe(pol.critic, pol.policy_params, False)
+        self.B = ppo.batch_size
+        self.n_wg = (self.B + K.UPDATE_ROWS_PER_WG - 1) // K.UPDATE_ROWS_PER_WG
+        total = pol.policy_params.numel()
+        self.slabs = torch.zeros(self.n_wg, total, dtype=torch.float32, device=dev)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.vn_mean = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.vn_var = torch.ones(2, dtype=torch.float32, device=dev)
+        self.vn_count = torch.full((2,), 1e-4, dtype=torch.float64, device=dev)
+        self.loss_partials = torch.zeros(2, self.n_wg, 8, dtype=torch.float32, device=dev)
+        self.totals = torch.zeros(9, dtype=torch.float64, device=dev)
+        self.records = None
+        self.perm = None
+        self._graphs = {}
+        self._args = {}
+
+    # ------------------------------------------------------------------ args
+    def _make_args(self, B):
+        pol, ppo = self.pol, self.ppo
+        buf = pol.buffer
+        a = _lib.PpoUpdateArgs()
+        a.actor, a.critic = self.actor_desc, self.critic_desc
+        a.params = pol.policy_params.data_ptr(); a.grads = pol.policy_grads.data_ptr()
+        a.exp_avg = pol.policy_exp_avg.data_ptr(); a.exp_avg_sq = pol.policy_exp_avg_sq.data_ptr()
+        a.slabs = self.slabs.data_ptr(); a.bucket_total = pol.policy_params.numel()
+        a.step_counts = pol.policy_step_counts.data_ptr(); a.lr = pol.policy_lr.data_ptr()
+        a.norm_scratch = pol.policy_norm_scratch.data_ptr()
+        a.beta1, a.beta2, a.adam_eps = 0.9, 0.999, 1e-5
+        a.grad_scale = 1.0 / self.world
+        a.max_norm = float(pol.gradient_clip) if pol.gradient_clip is not None else 0.0
+        a.head_kind = self.head
+        a.obs = buf.observations.data_ptr(); a.critic_obs = buf.critic_observations.data_ptr()
+        a.raw_actions = buf.raw_actions.data_ptr()
+        a.advantages = buf.advantages.data_ptr(); a.old_log_probs = buf.log_probs.data_ptr()
+        a.rewards_to_go = buf.rewards_to_go.data_ptr(); a.values = buf.values.data_ptr()
+        a.perm = self.perm.data_ptr(); a.row_map = buf.row_map.data_ptr()
+        a.n_rows = buf.num_transitions
+        a.cursor = self.cursor.data_ptr()
+        a.B = B; a.batch_stride = self.B
+        a.normalize_values = int(bool(ppo.normalize_values)); a.n_ranks = self.world
+        a.vn_mean = self.vn_mean.data_ptr(); a.vn_var = self.vn_var.data_ptr()
+        a.vn_count = self.vn_count.data_ptr()
+        a.vn_records = self.records.data_ptr() if self.records is not None else None
+        a.normalize_adv = int(bool(ppo.normalize_adv)); a.use_huber = int(bool(pol.use_huber_loss))
+        a.surr_clip = float(pol.surr_clip); a.entropy_weight = float(pol.entropy_weight())
+        a.kl_loss_weight = float(pol.kl_loss_weight); a.huber_delta = 10.0
+        a.min_std = float(getattr(pol.actor.distribution, "min_std", 0.01))
+        a.loss_partials = self.loss_partials.data_ptr(); a.totals = self.totals.data_ptr()
+        return a
+
+    def _signature(self):
+        """Everything baked into captured launches; a change re-captures."""
+        pol, buf = self.pol, self.pol.buffer
+        return (buf.observations.data_ptr(), buf.num_transitions, self.perm.data_ptr(),
+                None if self.records is None else self.records.data_ptr(),
+                float(pol.entropy_weight()), float(pol.surr_clip), float(pol.kl_loss_weight),
+                bool(pol.use_huber_loss), pol.gradient_clip, bool(self.ppo.normalize_adv),
+                bool(self.ppo.normalize_values))
+
+    # ----------------------------------------------------------------- epoch
+    def begin_epoch(self, perm):
+        pol, ppo = self.pol, self.ppo
+        buf = pol.buffer
+        N = perm.numel()
+        if self.perm is None or self.perm.numel() != N:
+            self.perm = torch.empty(N, dtype=torch.int64, device=pol.device)
+            self._graphs.clear()
+        self.perm.copy_(perm)
+        nb = (N + self.B - 1) // self.B
+        if ppo.normalize_values:
+            local = K.minibatch_moments(buf.rewards_to_go.view(-1), self.perm, buf.row_map, self.B)
+            if self.world > 1:
+                allr = mpi_utils.allgather_records(local.reshape(-1)).view(self.world, nb, 3)
+                rec = allr.permute(1, 0, 2).contiguous()
+            else:
+                rec = local.view(nb, 1, 3)
+            if self.records is None or self.records.shape != rec.shape:
+                self.records = torch.empty_like(rec)
+                self._graphs.clear()
+            self.records.copy_(rec)
+            rs = ppo.value_normalizers[self.policy_id].running_stats
+            self.vn_mean[0:1].copy_(rs.mean_t); self.vn_var[0:1].copy_(rs.var_t)
+            self.vn_count[0:1].copy_(rs.count_t)
+        self.cursor.zero_()
+        self.totals.zero_()
+        sig = self._signature()
+        if self._args.get("sig") != sig:
+            self._args = {"sig": sig}
+            self._graphs.clear()
+        self.n_full, self.tail = N // self.B, N % self.B
+        self.n_done = 0
+
+    def _args_for(self, B):
+        if B not in self._args:
+            self._args[B] = self._make_args(B)
+        return self._args[B]
+
+    def _one(self, args):
+        single = self.world == 1
+        K.ppo_update_fwd_bwd(args)
+        K.ppo_update_reduce(args, compute_norms=single)
+        if not single:
+            mpi_utils.allreduce_sum_(self.pol.policy_grads)
+        K.ppo_update_adam(args, compute_norms=not single)
+
+    def _chunk(self, args, n):
+        for _ in range(n):
+            self._one(args)
+
+    def run_epoch(self):
+        args = self._args_for(self.B)
+        left = self.n_full
+        use_graph = self.ppo.use_graphs and self.world == 1
+        chunk = self.graph_chunk
+        while left > 0:
+            if use_graph and left >= chunk:
+                g = self._graphs.get(chunk)
+                if g is None:
+                    s = torch.cuda.Stream()
+                    s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        self._chunk(args, chunk)          # warm-up pass: these mini-batches are real
+                    torch.cuda.current_stream().wait_stream(s)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._chunk(args, chunk)          # capture only
+                    self._graphs[chunk] = g
+                else:
+                    g.replay()
+                left -= chunk
+                self.n_done += chunk
+            else:
+                self._one(args)
+                left -= 1
+                self.n_done += 1
+        if self.tail >= 2:
+            self._one(self._args_for(self.tail))
+            self.n_done += 1
+
+    def end_epoch(self):
+        """-> numpy totals[9] (sums of the 8 loss scalars over mini-batches, mini-batch count)."""
+        ppo = self.ppo
+        if ppo.normalize_values:
+            rs = ppo.value_normalizers[self.policy_id].running_stats
+            slot = self.n_done & 1
+            rs.mean_t.copy_(self.vn_mean[slot:slot + 1]); rs.var_t.copy_(self.vn_var[slot:slot + 1])
+            rs.count_t.copy_(self.vn_count[slot:slot + 1])
+            if self.tail == 1:
+                # ppo.py:2299-2306: a size-1 batch still updates the normaliser, then is skipped (quirk Q9)
+                rs.integrate_records(self.records[self.n_full].contiguous())
+        t = self.totals.clone()
+        if self.world > 1:
+            mpi_utils.allreduce_sum_(t)
+        return t.cpu().numpy()

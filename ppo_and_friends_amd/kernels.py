@@ -310,3 +310,42 @@ def clip_adam_step(params, grads, exp_avg, exp_avg_sq, step_count, lr, norm_scra
         float(beta1), float(beta2), float(eps), float(grad_scale),
         float(max_norm if max_norm is not None else 0.0), ptr(norm_scratch), ptr(grad_norm_out),
         stream()), "clip_adam_step")
+
+
+# --------------------------------------------------------------------------
+# K12: fused mini-batch update
+# --------------------------------------------------------------------------
+ACT_RELU, ACT_LEAKY_RELU, ACT_TANH = 0, 1, 2
+HEAD_CATEGORICAL, HEAD_GAUSSIAN = 0, 1
+UPDATE_ROWS_PER_WG = 16
+
+
+def minibatch_moments(data_flat, perm, row_map, B, out=None):
+    """[ceil(n/B), 3] float64 (n, mean, M2) records of data_flat[row_map[perm]] per mini-batch."""
+    _f32(data_flat, "data")
+    _req(perm.dtype == torch.int64 and perm.dim() == 1, "perm must be int64 [n]")
+    n = perm.numel()
+    nb = (n + B - 1) // B
+    if out is None:
+        out = torch.empty(nb, 3, dtype=torch.float64, device=data_flat.device)
+    _req(out.dtype == torch.float64 and out.numel() == nb * 3, "records must be float64 [nb,3]")
+    if row_map is not None:
+        _req(row_map.dtype == torch.int32 and row_map.numel() <= data_flat.numel() and n <= row_map.numel(),
+             "row_map must be int32 and cover perm")
+    check(_lib.load().ppoaf_minibatch_moments(ptr(data_flat), ptr(perm), ptr(row_map), n, int(B),
+                                              ptr(out), stream()), "minibatch_moments")
+    return out
+
+
+def ppo_update_fwd_bwd(args):
+    check(_lib.load().ppoaf_ppo_update_fwd_bwd(C.byref(args), stream()), "ppo_update_fwd_bwd")
+
+
+def ppo_update_reduce(args, compute_norms):
+    check(_lib.load().ppoaf_ppo_update_reduce(C.byref(args), int(compute_norms), stream()),
+          "ppo_update_reduce")
+
+
+def ppo_update_adam(args, compute_norms):
+    check(_lib.load().ppoaf_ppo_update_adam(C.byref(args), int(compute_norms), stream()),
+          "ppo_update_adam")

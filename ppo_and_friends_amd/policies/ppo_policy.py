@@ -56,14 +56,18 @@ class FlatAdam:
     1037-1042) as two HIP launches; step counter and lr live on the device.
     """
 
-    def __init__(self, network, lr, eps=1e-5, betas=(0.9, 0.999)):
+    def __init__(self, network, lr, eps=1e-5, betas=(0.9, 0.999), storage=None):
+        """storage = (exp_avg, exp_avg_sq, step_count[1], lr[1], norm_scratch[1]) views of a
+        policy-wide allocation (so the fused update kernels see actor and critic state adjacent)."""
         self.network = network
         dev = network.flat_params.device
-        self.exp_avg = torch.zeros_like(network.flat_params)
-        self.exp_avg_sq = torch.zeros_like(network.flat_params)
-        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.lr = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
-        self.norm_scratch = torch.zeros(2, dtype=torch.float64, device=dev)
+        if storage is None:
+            storage = (torch.zeros_like(network.flat_params), torch.zeros_like(network.flat_params),
+                       torch.zeros(1, dtype=torch.int64, device=dev),
+                       torch.full((1,), float(lr), dtype=torch.float32, device=dev),
+                       torch.zeros(1, dtype=torch.float64, device=dev))
+        self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.norm_scratch = storage
+        self.lr.fill_(float(lr))
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.eps = eps
         self.betas = betas
@@ -176,8 +180,19 @@ class PPOPolicy:
         if self.have_bootstrap_clip:
             self.bootstrap_clip[0].finalize(status_dict)
             self.bootstrap_clip[1].finalize(status_dict)
-        self.actor_optim = FlatAdam(self.actor, self.lr(), eps=1e-5)
-        self.critic_optim = FlatAdam(self.critic, self.lr(), eps=1e-5)
+        na = self.actor.bucket_size()
+        dev = self.device
+        self.policy_exp_avg = torch.zeros_like(self.policy_params)
+        self.policy_exp_avg_sq = torch.zeros_like(self.policy_params)
+        self.policy_step_counts = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.policy_lr = torch.full((1,), float(self.lr()), dtype=torch.float32, device=dev)
+        self.policy_norm_scratch = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.actor_optim = FlatAdam(self.actor, self.lr(), eps=1e-5, storage=(
+            self.policy_exp_avg[:na], self.policy_exp_avg_sq[:na], self.policy_step_counts[0:1],
+            self.policy_lr, self.policy_norm_scratch[0:1]))
+        self.critic_optim = FlatAdam(self.critic, self.lr(), eps=1e-5, storage=(
+            self.policy_exp_avg[na:], self.policy_exp_avg_sq[na:], self.policy_step_counts[1:2],
+            self.policy_lr, self.policy_norm_scratch[1:2]))
         self.icm_optim = None
 
     def _initialize_networks(self, ac_network, enable_icm, icm_network, actor_kw_args,

@@ -101,7 +101,7 @@ class PPO:
                  ts_per_rollout=1024, gamma=0.99, epochs_per_iter=10, ext_reward_weight=1.0,
                  normalize_adv=True, normalize_obs=False, normalize_rewards=False,
                  normalize_values=True, obs_clip=None, reward_clip=None, recalc_advantages=False,
-                 use_graphs=True, verbose=False, **kw_args):
+                 use_graphs=True, update_mode="auto", verbose=False, **kw_args):
         """
         ppo.py:126-167.  `ts_per_rollout` is per environment (ppo.py:317-318
         multiplies by envs_per_proc).  Observation / reward normalising wrappers
@@ -121,6 +121,9 @@ class PPO:
         self.recalc_advantages = recalc_advantages
         self.ext_reward_weight = ext_reward_weight
         self.use_graphs = use_graphs and self.device.type == "cuda"
+        # "fused": K12 kernels (MLP policies); "torch": torch-ROCm MLPs + K2..K11; "auto": fused when covered
+        self.update_mode = update_mode
+        self._fused = {}
         self.verbose = verbose
         self.random_seed = 0 if random_seed is None else int(random_seed)
         rank = mpi_utils.get_rank()
@@ -308,6 +311,12 @@ class PPO:
         N = len(ds)
         world = mpi_utils.get_num_procs()
         perm = data_loader.epoch_permutation()
+        fused = self._fused_updater(policy_id, B)
+        if fused is not None:
+            fused.begin_epoch(perm)
+            fused.run_epoch()
+            self._publish_epoch_stats(policy_id, fused.end_epoch())
+            return
         n_full, tail = N // B, N % B
         totals = self._scratch("totals", 9, torch.float64)
         totals.zero_()
@@ -339,11 +348,31 @@ class PPO:
         if tail:
             run(perm[n_full * B:], n_full, False)
 
-        # ppo.py:2471-2485: counters and sums across ranks, then per-mini-batch averages
         t = totals.clone()
         if world > 1:
             mpi_utils.allreduce_sum_(t)
-        t = t.cpu().numpy()
+        self._publish_epoch_stats(policy_id, t.cpu().numpy())
+
+    def _fused_updater(self, policy_id, B):
+        if self.update_mode == "torch" or self.device.type != "cuda":
+            return None
+        key = (policy_id, B)
+        if key not in self._fused:
+            from .fused_update import FusedPolicyUpdate
+            why = FusedPolicyUpdate.unsupported_reason(self.policies[policy_id], B)
+            if why:
+                if self.update_mode == "fused":
+                    raise NotImplementedError(f"update_mode='fused' but {why}")
+                if self.verbose:
+                    rank_print(f"policy {policy_id}: torch update path ({why})")
+                self._fused[key] = None
+            else:
+                self._fused[key] = FusedPolicyUpdate(self, policy_id)
+        return self._fused[key]
+
+    def _publish_epoch_stats(self, policy_id, t):
+        """ppo.py:2471-2485: counters and sums across ranks, then per-mini-batch averages."""
+        pol = self.policies[policy_id]
         counter = max(t[8], 1.0)
         if t[K.SC_BAD] > 0:
             raise FloatingPointError("ratios are nan or inf (ppo.py:2361-2387)")

@@ -15,18 +15,19 @@ from oracle import cpu_ppo_loop
 pytestmark = pytest.mark.gpu
 
 
-def _make(E, T, B, epochs, term_prob=0.0, max_ts=200, use_graphs=True, seed=3):
+def _make(E, T, B, epochs, term_prob=0.0, max_ts=200, use_graphs=True, seed=3, update_mode="auto",
+          O=4, act_space=None, policy_args=None):
     from ppo_and_friends_amd.ppo import PPO
     from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
     from ppo_and_friends_amd.spaces import Box, Discrete
     dev = torch.device("cuda", 0)
-    O, NA = 4, 2
-    env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform",
+    act_space = Discrete(2) if act_space is None else act_space
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, act_space, T, dev, reward="uniform",
                                               seed=77, term_prob=term_prob)
     sp = Box(-np.inf, np.inf, (O,), np.float32)
-    ppo = PPO(env_gen, {"p": (None, sp, sp, Discrete(NA), {})}, device=dev, random_seed=seed,
+    ppo = PPO(env_gen, {"p": (None, sp, sp, act_space, policy_args or {})}, device=dev, random_seed=seed,
               envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=epochs,
-              max_ts_per_ep=max_ts, use_graphs=use_graphs)
+              max_ts_per_ep=max_ts, use_graphs=use_graphs, update_mode=update_mode)
     return ppo
 
 
@@ -72,10 +73,12 @@ def test_rollout_and_dataset_match_cpu_port(term_prob, max_ts):
     np.testing.assert_array_equal(item[1].cpu().numpy(), ref[17][1].numpy())
 
 
-@pytest.mark.parametrize("use_graphs", [True, False])
-def test_update_epochs_match_cpu_port(use_graphs):
+@pytest.mark.parametrize("update_mode,use_graphs", [("fused", True), ("fused", False),
+                                                    ("torch", True), ("torch", False)])
+def test_update_epochs_match_cpu_port(update_mode, use_graphs):
+    """Both product update paths (fused K12 kernels; torch-ROCm MLPs + K2..K11) against the CPU port."""
     E, T, B, epochs = 16, 32, 64, 2
-    ppo = _make(E, T, B, epochs, use_graphs=use_graphs)
+    ppo = _make(E, T, B, epochs, use_graphs=use_graphs, update_mode=update_mode)
     cpu = _oracle_like(ppo, B)
     pol = ppo.policies["p"]
     ppo.rollout()
@@ -104,10 +107,11 @@ def test_update_epochs_match_cpu_port(use_graphs):
                                cpu.dataset.values.numpy(), rtol=1e-4, atol=2e-5)
 
 
-def test_tail_minibatch_and_recalc_advantages():
-    """N % B != 0 exercises the eager tail path; recalc_advantages re-runs the scan kernel."""
+@pytest.mark.parametrize("update_mode", ["fused", "torch"])
+def test_tail_minibatch_and_recalc_advantages(update_mode):
+    """N % B != 0 exercises the tail mini-batch; recalc_advantages re-runs the scan kernel."""
     E, T, B = 10, 13, 32            # N = 130 -> 4 full batches + a tail of 2
-    ppo = _make(E, T, B, 2)
+    ppo = _make(E, T, B, 2, update_mode=update_mode)
     ppo.recalc_advantages = True
     cpu = _oracle_like(ppo, B)
     pol = ppo.policies["p"]
@@ -136,3 +140,51 @@ def test_learn_runs_two_iterations_with_graph_replay():
     gs = ppo.status_dict["global status"]
     assert gs["iteration"] == 2 and gs["timesteps"] == 2 * 32 * 16
     assert np.isfinite(ppo.status_dict["p"]["actor loss"])
+
+
+def _state(ppo):
+    pol = ppo.policies["p"]
+    vs = ppo.value_normalizers["p"].running_stats
+    return (pol.policy_params.detach().cpu().numpy().copy(), dict(ppo.status_dict["p"]),
+            np.array([vs.mean, vs.variance, vs.count], dtype=np.float64),
+            pol.buffer.values.detach().cpu().numpy().copy())
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(O=18, act=("d", 5), B=48, hidden=64, depth=2, act_fn="leaky"),       # 3 workgroups, tail of 16
+    dict(O=54, act=("d", 5), B=100, hidden=256, depth=3, act_fn="relu"),      # C4 critic width, ragged last workgroup
+    dict(O=17, act=("c", 6), B=64, hidden=128, depth=3, act_fn="tanh"),       # C3 dims, tanh-Gaussian head
+    dict(O=4, act=("c", 1), B=32, hidden=32, depth=1, act_fn="relu", huber=True),
+])
+def test_fused_update_equals_torch_update(cfg):
+    """
+    The fused K12 kernels against the torch-ROCm + K2..K11 path (itself checked against the
+    oracle piecewise and end to end above) on widths / depths / activations / heads the CPU
+    port does not cover.  Same rollout, same shuffles -> same weights, losses, normaliser state.
+    """
+    import torch.nn as nn
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    from ppo_and_friends_amd.ppo import PermutationLoader
+    act_fn = {"relu": nn.ReLU, "leaky": nn.LeakyReLU, "tanh": nn.Tanh}[cfg["act_fn"]]
+    kind, n = cfg["act"]
+    space = Discrete(n) if kind == "d" else Box(-1.0, 1.0, (n,), np.float32)
+    E, T = 14, 20                      # N = 280
+    results = []
+    for mode in ("fused", "torch"):
+        kw = dict(hidden_size=cfg["hidden"], hidden_depth=cfg["depth"], activation=act_fn())
+        pargs = dict(actor_kw_args=kw, critic_kw_args=dict(kw), use_huber_loss=cfg.get("huber", False))
+        ppo = _make(E, T, cfg["B"], 2, update_mode=mode, O=cfg["O"], act_space=space, policy_args=pargs,
+                    use_graphs=False)
+        ppo.rollout()
+        pol = ppo.policies["p"]
+        loader = PermutationLoader(pol.dataset, cfg["B"], ppo.loader_generator)
+        pol.train()
+        for _ in range(2):
+            ppo._ppo_batch_train(loader, "p")
+        results.append(_state(ppo))
+    (w0, s0, v0, val0), (w1, s1, v1, val1) = results
+    for k in ("actor loss", "critic loss", "kl avg", "weighted entropy"):
+        np.testing.assert_allclose(s0[k], s1[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(w0, w1, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(v0, v1, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(val0, val1, rtol=1e-4, atol=2e-5)
