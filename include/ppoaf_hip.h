@@ -285,7 +285,8 @@ int ppoaf_clip_adam_step(float* params, const float* grads,
  * hipGraph of N repetitions walks N consecutive mini-batches of the epoch.
  * Network parameters are the flat bucket of nn.Linear tensors in module order
  * (weight [out,in] row-major then bias, each padded to 4 floats), hidden
- * layers of equal width H (multiple of 16, <= 256), depth >= 1.
+ * layers of equal width H per network; instantiated (actor, critic) widths:
+ * (32,32) (64,64) (128,128) (256,256) (128,256) (64,128); depth >= 1.
  * ------------------------------------------------------------------------ */
 #define PPOAF_ACT_RELU        0
 #define PPOAF_ACT_LEAKY_RELU  1      /* negative slope 0.01 (nn.LeakyReLU default) */
@@ -310,7 +311,7 @@ typedef struct {
     int64_t bucket_total;
     int64_t* step_counts;         /* [2] Adam steps (actor, critic), incremented per call  */
     const float* lr;              /* [1] device                                            */
-    double* norm_scratch;         /* [2] squared norms                                     */
+    double* norm_scratch;         /* [6] squared norms (2) + Adam bias corrections (4)     */
     float beta1, beta2, adam_eps, grad_scale, max_norm; int32_t head_kind;
     /* rollout buffer (time-major rows) */
     const float* obs; const float* critic_obs; const void* raw_actions;  /* int64 [n,1] or f32 [n,D] */
@@ -324,6 +325,9 @@ typedef struct {
     int32_t normalize_values, n_ranks;
     float* vn_mean; float* vn_var; double* vn_count;    /* [2] each */
     const double* vn_records;
+    /* advantage normalisation (ppo.py:2326-2333): (n, mean, M2) of the raw advantages of every
+     * mini-batch of the epoch, [n_batches, 3] from ppoaf_minibatch_moments (rank-local) */
+    const double* adv_records;
     /* loss */
     int32_t normalize_adv, use_huber;
     float surr_clip, entropy_weight, kl_loss_weight, huber_delta, min_std, _pad2;

@@ -49,7 +49,7 @@ class PpoUpdateArgs(C.Structure):
                 ("cursor", C.c_void_p), ("B", C.c_int64), ("batch_stride", C.c_int64),
                 ("normalize_values", C.c_int32), ("n_ranks", C.c_int32),
                 ("vn_mean", C.c_void_p), ("vn_var", C.c_void_p), ("vn_count", C.c_void_p),
-                ("vn_records", C.c_void_p),
+                ("vn_records", C.c_void_p), ("adv_records", C.c_void_p),
                 ("normalize_adv", C.c_int32), ("use_huber", C.c_int32),
                 ("surr_clip", C.c_float), ("entropy_weight", C.c_float),
                 ("kl_loss_weight", C.c_float), ("huber_delta", C.c_float),

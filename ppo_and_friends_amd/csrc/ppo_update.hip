@@ -14,6 +14,7 @@
 // atomics would not be) and nothing needs zeroing.
 #include "common.hpp"
 #include <cfloat>
+#include <cstdlib>
 
 namespace ppoaf {
 
@@ -43,10 +44,12 @@ struct UpdateDev {
     int64_t* cursor; long B, batch_stride;
     int normalize_values, n_ranks;
     float* vn_mean; float* vn_var; double* vn_count; const double* vn_records;
+    const double* adv_records;
     int normalize_adv, use_huber;
     float surr_clip, entropy_weight, kl_loss_weight, huber_delta, min_std;
     float* loss_partials; double* totals;
     int n_wg;
+    int debug;           // diagnostic build only (PPOAF_STAMPS): ablation switches
 };
 
 __device__ __forceinline__ float act_fwd(float z, int act) {
@@ -74,69 +77,192 @@ __device__ __forceinline__ float softplus_u(float x) { return x > 20.f ? x : log
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ppo_update_smem[];
 
-__global__ __launch_bounds__(kThreads) void ppo_update_fwd_bwd_kernel(UpdateDev u) {
+// Diagnostic build only (-DPPOAF_STAMPS): s_memtime per phase of workgroup (0, which), wave 0,
+// into a buffer nothing else reads.  The shipped library executes no stamp.
+#ifdef PPOAF_STAMPS
+__device__ unsigned long long g_ppo_update_stamps[2][16];
+#define PPOAF_STAMP(k)                                                                   \
+    do {                                                                                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                       \
+            unsigned long long t_;                                                       \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
+            g_ppo_update_stamps[0][k] = t_;                                              \
+        }                                                                                \
+    } while (0)
+#else
+#define PPOAF_STAMP(k) do {} while (0)
+#endif
+
+// ---- MFMA building blocks (v_mfma_f32_16x16x4_f32: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
+//      C/D col = lane&15, row = 4*(lane>>4)+reg).  The k order inside a 16-chunk is permuted the
+//      same way on both operands (lane slot s carries k = 4s+j at step j), which leaves the sum intact.
+
+// B fragments of one forward tile: fr[c] = W[o][16c + 4*slot .. +3], o = n0 + (lane&15); W row-major [*, H]
+#ifdef PPOAF_STAMPS
+#define PPOAF_DBG(bit) (g_dbg & (bit))
+__device__ int g_dbg_unused;
+#else
+#define PPOAF_DBG(bit) false
+#endif
+template <int HT>
+__device__ __forceinline__ void load_fwd_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT],
+                                               int g_dbg = 0) {
+    const float* w = W + (long)(n0 + (lane & 15)) * (16 * HT) + 4 * (lane >> 4);
+    if (PPOAF_DBG(1)) {
+#pragma unroll
+        for (int c = 0; c < HT; ++c) fr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < HT; ++c) fr[c] = *reinterpret_cast<const float4*>(w + 16 * c);
+}
+// B fragments of one dgrad tile: fr[c] = { W[16c+4*slot+j][n0 + (lane&15)] }_j
+template <int HT>
+__device__ __forceinline__ void load_dgrad_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT],
+                                                 int g_dbg = 0) {
+    constexpr int H = 16 * HT;
+    const float* w = W + (long)(4 * (lane >> 4)) * H + n0 + (lane & 15);
+    if (PPOAF_DBG(1)) {
+#pragma unroll
+        for (int c = 0; c < HT; ++c) fr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < HT; ++c) {
+        const float* wp = w + (long)(16 * c) * H;
+        fr[c] = make_float4(wp[0], wp[H], wp[2 * H], wp[3 * H]);
+    }
+}
+// acc[16 rows, 16 cols] = init + A[16, H] . frags ; A rows in LDS with stride HS.  Two accumulators
+// (even / odd chunks) keep the matrix pipe issuing back to back instead of waiting on its own result.
+template <int HT>
+__device__ __forceinline__ f32x4 mfma_rows_x_frags(const float* __restrict__ A, int HS, int lane,
+                                                   const float4 (&fr)[HT], float init) {
+    const float* arow = A + (lane & 15) * HS + 4 * (lane >> 4);
+    f32x4 acc0 = {init, init, init, init};
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < HT; ++c) {
+        const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * c);
+        if (c & 1) {
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, fr[c].x, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, fr[c].y, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, fr[c].z, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, fr[c].w, acc1, 0, 0, 0);
+        } else {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, fr[c].x, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, fr[c].y, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, fr[c].z, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, fr[c].w, acc0, 0, 0, 0);
+        }
+    }
+    return acc0 + acc1;
+}
+// Weight gradient of one 16-row block of outputs: dW[m0+.., i] = sum_s D[s][m0+..] * Bsrc[s][i] for
+// i < n_valid (n tiles of 16 columns), K = the 16 rows of the workgroup.  Both operands come from LDS.
+__device__ __forceinline__ void wgrad_mtile(const float* __restrict__ D, int HS, const float* __restrict__ Bsrc,
+                                            int strideB, int m0, int ntiles, int n_valid, int lane,
+                                            float* __restrict__ dstW, int ldw) {
+    float a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = D[(4 * (lane >> 4) + j) * HS + m0 + (lane & 15)];
+    const float* bcol = Bsrc + (4 * (lane >> 4)) * strideB + (lane & 15);
+    float* drow = dstW + (long)(m0 + 4 * (lane >> 4)) * ldw + (lane & 15);
+#pragma unroll 4
+    for (int nt = 0; nt < ntiles; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bcol[j * strideB + 16 * nt], acc, 0, 0, 0);
+        if (16 * nt + (lane & 15) < n_valid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) drow[(long)r * ldw + 16 * nt] = acc[r];
+        }
+    }
+}
+
+constexpr int kNW = 8;                    // waves per workgroup
+constexpr int kThreadsU = 64 * kNW;
+
+template <int HT>
+__device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, const int which, const int g) {
+    constexpr int H = 16 * HT, HS = H + 4;                 // which: 0 actor, 1 critic; g: 16-row block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x, which = blockIdx.y;          // which: 0 actor, 1 critic
     const NetDev& nd = u.net[which];
-    const int H = nd.H, HS = H + 4, in_dim = nd.in_dim, INP = ((in_dim + 3) & ~3) + 4;
-    const int depth = nd.depth, out_dim = nd.out_dim, act = nd.act;
+    const int in_dim = nd.in_dim, depth = nd.depth, out_dim = nd.out_dim, act = nd.act;
+    const int NT0 = (in_dim + 15) >> 4;                    // 16-column tiles of the input
+    const int INP = 16 * NT0 + 4;
     const float* P = u.params + nd.offset;
     float* slab = u.slabs + (long)g * u.bucket_total + nd.offset;
     const long B = u.B;
     const long mb = u.cursor[0];
     const long base = mb * u.batch_stride;
+#ifdef PPOAF_STAMPS
+    const int dbg = u.debug;
+#else
+    constexpr int dbg = 0;
+#endif
+    // Layer offsets inside the bucket, by arithmetic: indexing a table in the kernel arguments with a
+    // loop variable compiles to a vector load of kernarg memory plus a full vmcnt drain (~6k cycles).
+    const long szW0 = ((long)H * in_dim + 3) & ~3L;
+    auto offW = [&](int l) -> long { return l == 0 ? 0 : szW0 + H + (long)(l - 1) * (H * H + H); };
+    auto offB = [&](int l) -> long {
+        return l == 0 ? szW0 : offW(l) + (l < depth ? (long)H * H : (((long)out_dim * H + 3) & ~3L));
+    };
 
+    PPOAF_STAMP(0);
     // ---- LDS carve (all offsets multiples of 16 B)
     float* smem = reinterpret_cast<float*>(ppo_update_smem);
     int* sRow = reinterpret_cast<int*>(smem);                 // [16]
-    float* sMisc = smem + 16;                                 // [16]: adv mean, adv std, vn mean, vn var
-    double* sRed = reinterpret_cast<double*>(smem + 32);      // [17] doubles -> 34 floats, round to 48
-    float* sX = smem + 80;                                    // [16, INP]
+    float* sMisc = smem + 16;                                 // [16]: adv mean/std, vn mean/var
+    float* sRowF = smem + 32;                                 // [3][16]: adv, old log-prob, rewards-to-go
+    float* sActF = smem + 80;                                 // [16][8] raw actions (float or int bits)
+    float* sBias = smem + 208;                                // [(depth+1), H]
+    float* sWout = sBias + (depth + 1) * H;                   // [8, H]
+    float* sX = sWout + 8 * H;                                // [16, INP], zero padded
     float* sH = sX + kRows * INP;                             // depth x [16, HS]
     float* sD0 = sH + (long)depth * kRows * HS;               // [16, HS]
     float* sD1 = sD0 + kRows * HS;                            // [16, HS]
     float* sOut = sD1 + kRows * HS;                           // [16, 16]
     float* sDOut = sOut + kRows * kMaxOut;                    // [16, 16]
-    float* sAdv = sDOut + kRows * kMaxOut;                    // [min(B, kMaxAdvLds)] (actor only)
 
     if (g == 0 && which == 0 && tid == 0) { u.norm_scratch[0] = 0.0; u.norm_scratch[1] = 0.0; }
 
-    // ---- P0: rows of this workgroup, mini-batch statistics
+    // ---- S0: everything that does not depend on the rows is requested first: rows / statistics,
+    //      biases + output weights -> LDS, and this wave's first-layer weight fragments -> registers.
     if (tid < kRows) {
         const long s = (long)g * kRows + tid;
         int row = -1;
         if (s < B) {
-            long p = u.perm[base + s];
-            if (p >= 0 && p < u.n_rows) row = u.row_map ? u.row_map[p] : (int)p;
+            long p = (dbg & 32) ? (base + s) : u.perm[base + s];
+            if (p >= 0 && p < u.n_rows) row = (u.row_map && !(dbg & 32)) ? u.row_map[p] : (int)p;
         }
         sRow[tid] = row;
-    }
-    if (which == 0) {
-        float mean_f = 0.f, std_f = 1.f;
-        if (u.normalize_adv) {
-            double s = 0.0;
-            for (long i = tid; i < B; i += kThreads) {
-                const long p = u.perm[base + i];
-                const float a = u.adv[u.row_map ? u.row_map[p] : p];
-                if (i < kMaxAdvLds) sAdv[i] = a;
-                s += (double)a;
+        float av = 0.f, lpo = 0.f, rt = 0.f;
+        if (row >= 0 && !(dbg & 64)) {
+            if (which == 0) {
+                av = u.adv[row]; lpo = u.old_lp[row];
+                if (u.head_kind == PPOAF_HEAD_CATEGORICAL)
+                    reinterpret_cast<int*>(sActF)[tid * 8] = (int)reinterpret_cast<const int64_t*>(u.raw_actions)[row];
+                else
+                    for (int d = 0; d < out_dim; ++d)
+                        sActF[tid * 8 + d] = reinterpret_cast<const float*>(u.raw_actions)[(long)row * out_dim + d];
+            } else {
+                rt = u.rtg[row];
             }
-            const double mean = block_sum(s, sRed) / (double)B;
-            double q = 0.0;
-            for (long i = tid; i < B; i += kThreads) {
-                float a;
-                if (i < kMaxAdvLds) a = sAdv[i];
-                else { const long p = u.perm[base + i]; a = u.adv[u.row_map ? u.row_map[p] : p]; }
-                const double d = (double)a - mean;
-                q += d * d;
-            }
-            q = block_sum(q, sRed);
-            mean_f = (float)mean;
-            std_f = (float)sqrt(q / (double)(B - 1));
         }
-        if (tid == 0) { sMisc[0] = mean_f; sMisc[1] = std_f; }
-    } else {
-        if (tid == 0) {
+        sRowF[tid] = av; sRowF[16 + tid] = lpo; sRowF[32 + tid] = rt;
+    }
+    if (tid == 64) {                                        // a lane of wave 1: mini-batch statistics
+        if (which == 0) {
+            float mean_f = 0.f, std_f = 1.f;
+            if (u.normalize_adv) {                           // ppo.py:2326-2333, from the per-epoch table
+                const double* rec = u.adv_records + mb * 3;
+                mean_f = (float)rec[1];
+                std_f = (float)sqrt(rec[2] / (rec[0] - 1.0));
+            }
+            sMisc[0] = mean_f; sMisc[1] = std_f;
+        } else {
             const int slot = (int)(mb & 1);
             float m = u.vn_mean[slot], v = u.vn_var[slot];
             double cnt = u.vn_count[slot];
@@ -167,77 +293,97 @@ __global__ __launch_bounds__(kThreads) void ppo_update_fwd_bwd_kernel(UpdateDev 
             if (g == 0) { u.vn_mean[slot ^ 1] = m; u.vn_var[slot ^ 1] = v; u.vn_count[slot ^ 1] = cnt; }
         }
     }
+    for (int l = 0; l <= depth; ++l) {
+        const int n = (l == depth) ? out_dim : H;
+        const float* bb = P + offB(l);
+        for (int i = tid; i < n; i += kThreadsU) sBias[l * H + i] = bb[i];
+    }
+    for (int i = tid; i < out_dim * H; i += kThreadsU) sWout[i] = P[offW(depth) + i];
+    for (int i = tid; i < kRows * INP; i += kThreadsU) sX[i] = 0.f;
     __syncthreads();
+    PPOAF_STAMP(1);
 
-    // ---- P1: gather the input rows (K4)
+    // ---- S1: gather the input rows (K4)
     {
         const float* src = which == 0 ? u.obs : u.critic_obs;
-        for (int idx = tid; idx < kRows * in_dim; idx += kThreads) {
+        for (int idx = tid; idx < kRows * in_dim; idx += kThreadsU) {
             const int s = idx / in_dim, i = idx - s * in_dim;
             const int row = sRow[s];
-            sX[s * INP + i] = row >= 0 ? src[(long)row * in_dim + i] : 0.f;
+            if (row >= 0) sX[s * INP + i] = src[(long)row * in_dim + i];
         }
     }
+    // prefetch: fragments of the first hidden-to-hidden layer (or nothing if depth == 1)
+    float4 fr[HT];
+    const bool has_tile = wave < HT;          // waves beyond the tile count idle in MFMA phases (H < 128)
+    if (depth > 1 && has_tile) load_fwd_frags<HT>(P + offW(1), wave * 16, lane, fr, dbg);
     __syncthreads();
+    PPOAF_STAMP(2);
 
-    // ---- P2: first layer (in_dim is small: VALU)
-    {
-        const float* W = P + nd.offW[0];
-        const float* bb = P + nd.offB[0];
-        const int s = tid >> 4, og = tid & 15;
-        for (int o = og; o < H; o += 16) {
-            float acc = bb[o];
-            const float* w = W + (long)o * in_dim;
-            for (int i = 0; i < in_dim; ++i) acc = fmaf(sX[s * INP + i], w[i], acc);
-            sH[s * HS + o] = act_fwd(acc, act);
+    // ---- L0: first layer on MFMA, K = in_dim padded to a multiple of 4 (sX is zero padded)
+    if (!(dbg & 128))
+    for (int nt = wave; nt < HT; nt += kNW) {
+        const int o = nt * 16 + (lane & 15);
+        const float bv = sBias[o];
+        f32x4 acc = {bv, bv, bv, bv};
+        const float* w = P + offW(0) + (long)o * in_dim;
+        const float* arow = sX + (lane & 15) * INP;
+        for (int k0 = 0; k0 < in_dim; k0 += 16) {            // 4 MFMA steps per 16 input columns
+            float bq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + 4 * j + (lane >> 4);
+                bq[j] = k < in_dim ? w[k] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k0 + 4 * j + (lane >> 4)], bq[j], acc, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sH[(4 * (lane >> 4) + r) * HS + o] = act_fwd(acc[r], act);
     }
     __syncthreads();
+    PPOAF_STAMP(3);
 
-    // ---- P3: hidden layers on f32 MFMA: Z[16,H] = Hprev[16,H] . W^T + b
+    // ---- hidden layers forward; the next phase's fragments are requested before each barrier
     for (int l = 1; l < depth; ++l) {
-        const float* W = P + nd.offW[l];
-        const float* bb = P + nd.offB[l];
         const float* Hp = sH + (long)(l - 1) * kRows * HS;
         float* Hc = sH + (long)l * kRows * HS;
-        for (int nt = wave; nt < H / 16; nt += kThreads / 64) {
+        for (int nt = wave; nt < HT; nt += kNW) {
+            if (nt != wave) load_fwd_frags<HT>(P + offW(l), nt * 16, lane, fr, dbg);
             const int o = nt * 16 + (lane & 15);
-            const float bv = bb[o];
-            f32x4 acc = {bv, bv, bv, bv};
-            const float* arow = Hp + (lane & 15) * HS + 4 * (lane >> 4);
-            const float* wrow = W + (long)o * H + 4 * (lane >> 4);
-#pragma unroll 4
-            for (int c = 0; c < H / 16; ++c) {
-                const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * c);
-                const float4 b4 = *reinterpret_cast<const float4*>(wrow + 16 * c);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+            if (l == 1) PPOAF_STAMP(10);
+            const f32x4 acc = (dbg & 2) ? f32x4{fr[0].x + fr[HT - 1].w, 0.f, 0.f, 0.f} : mfma_rows_x_frags<HT>(Hp, HS, lane, fr, sBias[l * H + o]);
+            if (l == 1) PPOAF_STAMP(11);
+            if (nt + kNW >= HT) {                           // last tile of this wave in this layer
+                if (l + 1 < depth) load_fwd_frags<HT>(P + offW(l + 1), wave * 16, lane, fr, dbg);
+                else load_dgrad_frags<HT>(P + offW(l), wave * 16, lane, fr, dbg);   // first backward phase
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) Hc[(4 * (lane >> 4) + r) * HS + o] = act_fwd(acc[r], act);
+            if (l == 1) PPOAF_STAMP(12);
         }
         __syncthreads();
+        if (l == 1) PPOAF_STAMP(13);
     }
+    PPOAF_STAMP(4);
     const float* Hlast = sH + (long)(depth - 1) * kRows * HS;
 
-    // ---- P4: output layer (out_dim <= 16: VALU + 16-lane reductions)
-    {
-        const float* W = P + nd.offW[depth];
-        const float* bb = P + nd.offB[depth];
+    // ---- output layer (out_dim <= 8): VALU from LDS + 16-lane reductions
+    if (tid < 256) {
         const int s = tid >> 4, part = tid & 15;
         for (int k = 0; k < out_dim; ++k) {
             float acc = 0.f;
-            for (int i = part; i < H; i += 16) acc = fmaf(Hlast[s * HS + i], W[(long)k * H + i], acc);
+#pragma unroll
+            for (int i = 0; i < HT; ++i) acc = fmaf(Hlast[s * HS + part + 16 * i], sWout[k * H + part + 16 * i], acc);
             acc = group16_sum(acc);
-            if (part == 0) sOut[s * kMaxOut + k] = acc + bb[k];
+            if (part == 0) sOut[s * kMaxOut + k] = acc + sBias[depth * H + k];
         }
     }
     __syncthreads();
+    PPOAF_STAMP(5);
 
-    // ---- P5: distribution head + loss terms for this workgroup's rows (K6 + K3)
-    if (wave == 0) {
+    // ---- distribution head + loss terms for this workgroup's rows (K6 + K3)
+    if (wave == 0 && !(dbg & 8)) {
         const int s = lane;                       // lanes 0..15 hold one row each
         const int row = s < kRows ? sRow[s] : -1;
         const bool live = row >= 0;
@@ -245,92 +391,105 @@ __global__ __launch_bounds__(kThreads) void ppo_update_fwd_bwd_kernel(UpdateDev 
         float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (which == 0) {
             float logp = 0.f, ent = 0.f;
+            float av = 0.f, lpo = 0.f;
             if (live) {
-                if (u.head_kind == PPOAF_HEAD_CATEGORICAL) {
-                    float p[kMaxOut];
-                    float m = -INFINITY;
-                    for (int k = 0; k < out_dim; ++k) m = fmaxf(m, sOut[s * kMaxOut + k]);
-                    float ssum = 0.f;
-                    for (int k = 0; k < out_dim; ++k) { p[k] = expf(sOut[s * kMaxOut + k] - m); ssum += p[k]; }
-                    const float inv = 1.0f / ssum;
-                    float s2 = 0.f;
-                    for (int k = 0; k < out_dim; ++k) { p[k] *= inv; s2 += p[k]; }
-                    long a = reinterpret_cast<const int64_t*>(u.raw_actions)[row];
-                    a = a < 0 ? 0 : (a >= out_dim ? out_dim - 1 : a);
-                    for (int k = 0; k < out_dim; ++k) { const float nk = p[k] / s2; ent -= nk * logf(clamp_prob_u(nk)); }
-                    logp = logf(clamp_prob_u(p[a] / s2));
-                    // loss terms
-                    float av = u.adv[row];
-                    if (u.normalize_adv) av = (av - sMisc[0]) / (sMisc[1] + 1e-8f);
-                    const float lpo = u.old_lp[row];
-                    const float ratio = expf(logp - lpo);
-                    if (isnan(ratio) || isinf(ratio)) part[7] = 1.f;
-                    const float lo = 1.0f - u.surr_clip, hi = 1.0f + u.surr_clip;
-                    const float surr1 = ratio * av, surr2 = fminf(fmaxf(ratio, lo), hi) * av;
-                    part[0] = -fminf(surr1, surr2);
-                    part[3] = ent;
-                    part[4] = lpo - logp;
-                    float glp;
-                    if (surr1 <= surr2) glp = -av * ratio;
-                    else glp = (ratio >= lo && ratio <= hi) ? -av * ratio : 0.f;
-                    glp *= inv_B;
-                    const float gH = (u.entropy_weight != 0.0f) ? -u.entropy_weight * inv_B : 0.f;
-                    // chain: z -softmax-> p -(/sum)-> n -clamp,log-> l
-                    float gn[kMaxOut];
-                    float dot = 0.f;
-                    for (int k = 0; k < out_dim; ++k) {
-                        const float nk = p[k] / s2, ck = clamp_prob_u(nk);
+                av = sRowF[s]; lpo = sRowF[16 + s];
+                if (u.normalize_adv) av = (av - sMisc[0]) / (sMisc[1] + 1e-8f);
+            }
+            if (live && u.head_kind == PPOAF_HEAD_CATEGORICAL) {
+                float p[8];
+                float m = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k < out_dim) m = fmaxf(m, sOut[s * kMaxOut + k]);
+                float ssum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { p[k] = k < out_dim ? expf(sOut[s * kMaxOut + k] - m) : 0.f; ssum += p[k]; }
+                const float inv = 1.0f / ssum;
+                float s2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { p[k] *= inv; s2 += p[k]; }
+                int a = reinterpret_cast<const int*>(sActF)[s * 8];
+                a = a < 0 ? 0 : (a >= out_dim ? out_dim - 1 : a);
+                float nk8[8], lg8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    nk8[k] = p[k] / s2;                          // Categorical's renormalisation
+                    lg8[k] = k < out_dim ? logf(clamp_prob_u(nk8[k])) : 0.f;
+                    if (k < out_dim) ent -= nk8[k] * lg8[k];
+                    if (k == a) logp = lg8[k];
+                }
+                const float ratio = expf(logp - lpo);
+                if (isnan(ratio) || isinf(ratio)) part[7] = 1.f;
+                const float lo = 1.0f - u.surr_clip, hi = 1.0f + u.surr_clip;
+                const float surr1 = ratio * av, surr2 = fminf(fmaxf(ratio, lo), hi) * av;
+                part[0] = -fminf(surr1, surr2);
+                part[3] = ent;
+                part[4] = lpo - logp;
+                float glp;
+                if (surr1 <= surr2) glp = -av * ratio;
+                else glp = (ratio >= lo && ratio <= hi) ? -av * ratio : 0.f;
+                glp *= inv_B;
+                const float gH = (u.entropy_weight != 0.0f) ? -u.entropy_weight * inv_B : 0.f;
+                // chain: z -softmax-> p -(/sum)-> n -clamp,log-> l
+                float gn[8];
+                float dot = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float gk = 0.f;
+                    if (k < out_dim) {
+                        const float nk = nk8[k], ck = clamp_prob_u(nk);
                         const float in_range = (nk >= FLT_EPSILON && nk <= 1.0f - FLT_EPSILON) ? 1.f : 0.f;
-                        float gk = gH * (-logf(ck) - nk * in_range / ck);
+                        gk = gH * (-lg8[k] - nk * in_range / ck);
                         if (k == a) gk += glp * in_range / ck;
-                        gn[k] = gk; dot += gk * nk;
+                        dot += gk * nk;
                     }
-                    float dot2 = 0.f;
-                    for (int k = 0; k < out_dim; ++k) { gn[k] = (gn[k] - dot) / s2; dot2 += gn[k] * p[k]; }
-                    for (int k = 0; k < out_dim; ++k) sDOut[s * kMaxOut + k] = p[k] * (gn[k] - dot2);
-                } else {
-                    // tanh-Gaussian (distributions.py:441-694)
-                    const float* log_std = P + nd.log_std_off;
-                    const float* x = reinterpret_cast<const float*>(u.raw_actions) + (long)row * out_dim;
-                    float lp = 0.f, slog = 0.f;
-                    for (int d = 0; d < out_dim; ++d) {
-                        const float sd = fmaxf(softplus_u(log_std[d]), u.min_std);
-                        const float zz = x[d] - sOut[s * kMaxOut + d];
-                        float l = -(zz * zz) / (2.0f * sd * sd) - logf(sd) - 0.91893853320467274178f;
-                        l = fminf(fmaxf(l, -100.f), 100.f);
-                        lp += l;
-                        const float th = tanhf(x[d]);
-                        slog += logf(fmaxf(1.0f - th * th, 1e-6f));
-                    }
-                    logp = lp - slog; ent = -logp;
-                    float av = u.adv[row];
-                    if (u.normalize_adv) av = (av - sMisc[0]) / (sMisc[1] + 1e-8f);
-                    const float lpo = u.old_lp[row];
-                    const float ratio = expf(logp - lpo);
-                    if (isnan(ratio) || isinf(ratio)) part[7] = 1.f;
-                    const float lo = 1.0f - u.surr_clip, hi = 1.0f + u.surr_clip;
-                    const float surr1 = ratio * av, surr2 = fminf(fmaxf(ratio, lo), hi) * av;
-                    part[0] = -fminf(surr1, surr2);
-                    part[3] = ent;
-                    part[4] = lpo - logp;
-                    float glp;
-                    if (surr1 <= surr2) glp = -av * ratio;
-                    else glp = (ratio >= lo && ratio <= hi) ? -av * ratio : 0.f;
-                    glp *= inv_B;
-                    const float gH = (u.entropy_weight != 0.0f) ? -u.entropy_weight * inv_B : 0.f;
-                    const float gg = glp - gH;                         // entropy = -logp
-                    for (int d = 0; d < out_dim; ++d) {
-                        const float ls = log_std[d];
-                        const float sp = softplus_u(ls), sd = fmaxf(sp, u.min_std);
-                        const float zz = x[d] - sOut[s * kMaxOut + d];
-                        const float l = -(zz * zz) / (2.0f * sd * sd) - logf(sd) - 0.91893853320467274178f;
-                        const float pass = (l >= -100.f && l <= 100.f) ? 1.f : 0.f;
-                        sDOut[s * kMaxOut + d] = gg * pass * zz / (sd * sd);
-                        const float dmax = sp > u.min_std ? 1.f : (sp == u.min_std ? 0.5f : 0.f);
-                        const float dsp = ls > 20.f ? 1.f : 1.0f / (1.0f + expf(-ls));
-                        // per-row d logp / d log_std, parked in sOut's upper half for the reduction below
-                        sOut[s * kMaxOut + 8 + d] = gg * pass * (zz * zz / (sd * sd * sd) - 1.0f / sd) * dmax * dsp;
-                    }
+                    gn[k] = gk;
+                }
+                float dot2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { gn[k] = (gn[k] - dot) / s2; dot2 += gn[k] * p[k]; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sDOut[s * kMaxOut + k] = p[k] * (gn[k] - dot2);
+            } else if (live) {
+                // tanh-Gaussian (distributions.py:441-694)
+                const float* log_std = P + nd.log_std_off;
+                const float* x = sActF + s * 8;
+                float lp = 0.f, slog = 0.f;
+                for (int d = 0; d < out_dim; ++d) {
+                    const float sd = fmaxf(softplus_u(log_std[d]), u.min_std);
+                    const float zz = x[d] - sOut[s * kMaxOut + d];
+                    float l = -(zz * zz) / (2.0f * sd * sd) - logf(sd) - 0.91893853320467274178f;
+                    l = fminf(fmaxf(l, -100.f), 100.f);
+                    lp += l;
+                    const float th = tanhf(x[d]);
+                    slog += logf(fmaxf(1.0f - th * th, 1e-6f));
+                }
+                logp = lp - slog; ent = -logp;
+                const float ratio = expf(logp - lpo);
+                if (isnan(ratio) || isinf(ratio)) part[7] = 1.f;
+                const float lo = 1.0f - u.surr_clip, hi = 1.0f + u.surr_clip;
+                const float surr1 = ratio * av, surr2 = fminf(fmaxf(ratio, lo), hi) * av;
+                part[0] = -fminf(surr1, surr2);
+                part[3] = ent;
+                part[4] = lpo - logp;
+                float glp;
+                if (surr1 <= surr2) glp = -av * ratio;
+                else glp = (ratio >= lo && ratio <= hi) ? -av * ratio : 0.f;
+                glp *= inv_B;
+                const float gH = (u.entropy_weight != 0.0f) ? -u.entropy_weight * inv_B : 0.f;
+                const float gg = glp - gH;                         // entropy = -logp
+                for (int d = 0; d < out_dim; ++d) {
+                    const float ls = log_std[d];
+                    const float sp = softplus_u(ls), sd = fmaxf(sp, u.min_std);
+                    const float zz = x[d] - sOut[s * kMaxOut + d];
+                    const float l = -(zz * zz) / (2.0f * sd * sd) - logf(sd) - 0.91893853320467274178f;
+                    const float pass = (l >= -100.f && l <= 100.f) ? 1.f : 0.f;
+                    sDOut[s * kMaxOut + d] = gg * pass * zz / (sd * sd);
+                    if (d == 0) for (int k2 = out_dim; k2 < 8; ++k2) sDOut[s * kMaxOut + k2] = 0.f;
+                    const float dmax = sp > u.min_std ? 1.f : (sp == u.min_std ? 0.5f : 0.f);
+                    const float dsp = ls > 20.f ? 1.f : 1.0f / (1.0f + expf(-ls));
+                    // per-row d logp / d log_std, parked in sOut's upper half for the reduction below
+                    sOut[s * kMaxOut + 8 + d] = gg * pass * (zz * zz / (sd * sd * sd) - 1.0f / sd) * dmax * dsp;
                 }
             } else if (s < kRows) {
                 for (int k = 0; k < kMaxOut; ++k) sDOut[s * kMaxOut + k] = 0.f;
@@ -340,7 +499,7 @@ __global__ __launch_bounds__(kThreads) void ppo_update_fwd_bwd_kernel(UpdateDev 
         } else {
             if (live) {
                 const float v = sOut[s * kMaxOut];
-                float rt = u.rtg[row];
+                float rt = sRowF[32 + s];
                 if (u.normalize_values) rt = (rt - sMisc[2]) / sqrtf(sMisc[3] + 1e-8f);
                 const float diff = v - rt;
                 float l, dl;
@@ -351,9 +510,10 @@ __global__ __launch_bounds__(kThreads) void ppo_update_fwd_bwd_kernel(UpdateDev 
                 } else { l = diff * diff; dl = 2.0f * diff; }
                 part[2] = l;
                 sDOut[s * kMaxOut] = dl * inv_B;
+                for (int k2 = 1; k2 < 8; ++k2) sDOut[s * kMaxOut + k2] = 0.f;
                 u.values[row] = v;                                   // ppo.py:2340
             } else if (s < kRows) {
-                sDOut[s * kMaxOut] = 0.f;
+                for (int k2 = 0; k2 < 8; ++k2) sDOut[s * kMaxOut + k2] = 0.f;
             }
         }
         // per-workgroup partial sums (lanes >= 16 contribute zeros)
@@ -371,129 +531,157 @@ __global__ __launch_bounds__(kThreads) void ppo_update_fwd_bwd_kernel(UpdateDev 
         }
     }
     __syncthreads();
+    PPOAF_STAMP(6);
 
-    // ---- P6: output layer backward
-    {
-        const float* W = P + nd.offW[depth];
-        // dW_out[k][i], db_out[k]
-        for (int i = tid; i < H; i += kThreads) {
+    // ---- output layer backward (weights from LDS).  Operands are pulled into registers with
+    //      independent LDS reads first; a read-per-FMA loop is LDS-latency bound (~64 cycles each).
+    if (!(dbg & 16)) {
+        if (tid < H) {
+            const int i = tid;
+            float h[kRows];
+#pragma unroll
+            for (int s = 0; s < kRows; ++s) h[s] = Hlast[s * HS + i];
             for (int k = 0; k < out_dim; ++k) {
+                float d[kRows];
+#pragma unroll
+                for (int s = 0; s < kRows; ++s) d[s] = sDOut[s * kMaxOut + k];
                 float acc = 0.f;
 #pragma unroll
-                for (int s = 0; s < kRows; ++s) acc = fmaf(sDOut[s * kMaxOut + k], Hlast[s * HS + i], acc);
-                slab[nd.offW[depth] + (long)k * H + i] = acc;
+                for (int s = 0; s < kRows; ++s) acc = fmaf(d[s], h[s], acc);
+                slab[offW(depth) + (long)k * H + i] = acc;
             }
         }
-        if (tid < out_dim) {
+        if (tid >= 256 && tid < 256 + out_dim) {
+            const int k = tid - 256;
             float acc = 0.f;
-            for (int s = 0; s < kRows; ++s) acc += sDOut[s * kMaxOut + tid];
-            slab[nd.offB[depth] + tid] = acc;
+#pragma unroll
+            for (int s = 0; s < kRows; ++s) acc += sDOut[s * kMaxOut + k];
+            slab[offB(depth) + k] = acc;
         }
-        if (which == 0 && u.head_kind == PPOAF_HEAD_GAUSSIAN && tid >= 64 && tid < 64 + out_dim) {
-            const int d = tid - 64;
+        if (which == 0 && u.head_kind == PPOAF_HEAD_GAUSSIAN && tid >= 320 && tid < 320 + out_dim) {
+            const int d = tid - 320;
             float acc = 0.f;
+#pragma unroll
             for (int s = 0; s < kRows; ++s) acc += sOut[s * kMaxOut + 8 + d];
             slab[nd.log_std_off + d] = acc;
         }
-        // dz_last = (dOut . W_out) * act'(Hlast)
-        const int s = tid >> 4, ig = tid & 15;
-        for (int i = ig; i < H; i += 16) {
-            float acc = 0.f;
-            for (int k = 0; k < out_dim; ++k) acc = fmaf(sDOut[s * kMaxOut + k], W[(long)k * H + i], acc);
-            sD0[s * HS + i] = acc * act_bwd(Hlast[s * HS + i], act);
+        // dz_last = (dOut . W_out) * act'(Hlast): waves 4..7 (the others store dW_out above)
+        if (tid >= 256) {
+            const int t2 = tid - 256;
+            const int s = t2 >> 4, ig = t2 & 15;
+            float d[8];
+            const float4 d0 = *reinterpret_cast<const float4*>(sDOut + s * kMaxOut);
+            const float4 d1 = *reinterpret_cast<const float4*>(sDOut + s * kMaxOut + 4);
+            d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+            float hv[HT], acc[HT];
+#pragma unroll
+            for (int ii = 0; ii < HT; ++ii) { hv[ii] = Hlast[s * HS + ig + 16 * ii]; acc[ii] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < out_dim) {
+#pragma unroll
+                    for (int ii = 0; ii < HT; ++ii) acc[ii] = fmaf(d[k], sWout[k * H + ig + 16 * ii], acc[ii]);
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < HT; ++ii) sD0[s * HS + ig + 16 * ii] = acc[ii] * act_bwd(hv[ii], act);
         }
     }
     __syncthreads();
+    PPOAF_STAMP(7);
 
-    // ---- P7: hidden layers backward (wgrad + dgrad on MFMA)
+    // ---- hidden layers backward: wgrad + bias grad + dgrad; `fr` holds this wave's dgrad fragments
     float* Dc = sD0;
     float* Dn = sD1;
     for (int l = depth - 1; l >= 1; --l) {
-        const float* W = P + nd.offW[l];
         const float* Hin = sH + (long)(l - 1) * kRows * HS;
-        // wgrad: dW[o][i] = sum_s dz[s][o] * Hin[s][i]   (M = o, N = i, K = s = 16)
-        for (int mt = wave; mt < H / 16; mt += kThreads / 64) {
-            const int m0 = mt * 16;
-            float a[4];
+        // dgrad first (its operands were prefetched): dh[s][i] = sum_o dz[s][o] * W[o][i]
+        for (int nt = wave; nt < HT; nt += kNW) {
+            if (nt != wave) load_dgrad_frags<HT>(P + offW(l), nt * 16, lane, fr, dbg);
+            const f32x4 acc = (dbg & 2) ? f32x4{fr[0].x + fr[HT - 1].w, 0.f, 0.f, 0.f} : mfma_rows_x_frags<HT>(Dc, HS, lane, fr, 0.f);
+            if (nt + kNW >= HT && l - 1 >= 1) load_dgrad_frags<HT>(P + offW(l - 1), wave * 16, lane, fr, dbg);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = Dc[(4 * (lane >> 4) + j) * HS + m0 + (lane & 15)];
-            for (int nt = 0; nt < H / 16; ++nt) {
-                const int n0 = nt * 16;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float bj = Hin[(4 * (lane >> 4) + j) * HS + n0 + (lane & 15)];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bj, acc, 0, 0, 0);
-                }
-                float* dst = slab + nd.offW[l] + (long)(m0 + 4 * (lane >> 4)) * H + n0 + (lane & 15);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[(long)r * H] = acc[r];
+            for (int r = 0; r < 4; ++r) {
+                const int s = 4 * (lane >> 4) + r, i = nt * 16 + (lane & 15);
+                Dn[s * HS + i] = acc[r] * act_bwd(Hin[s * HS + i], act);
             }
         }
-        for (int o = tid; o < H; o += kThreads) {
+        // wgrad: dW[o][i] = sum_s dz[s][o] * Hin[s][i]
+        if (!(dbg & 4))
+        for (int mt = wave; mt < HT; mt += kNW)
+            wgrad_mtile(Dc, HS, Hin, HS, mt * 16, HT, H, lane, slab + offW(l), H);
+        for (int o = tid; o < H; o += kThreadsU) {
             float acc = 0.f;
 #pragma unroll
             for (int s = 0; s < kRows; ++s) acc += Dc[s * HS + o];
-            slab[nd.offB[l] + o] = acc;
-        }
-        // dgrad: dh[s][i] = sum_o dz[s][o] * W[o][i]     (M = s, N = i, K = o)
-        for (int nt = wave; nt < H / 16; nt += kThreads / 64) {
-            const int n0 = nt * 16;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float* arow = Dc + (lane & 15) * HS + 4 * (lane >> 4);
-            const float* wcol = W + (long)(4 * (lane >> 4)) * H + n0 + (lane & 15);
-#pragma unroll 2
-            for (int c = 0; c < H / 16; ++c) {
-                const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * c);
-                const float* wp = wcol + (long)(16 * c) * H;
-                const float b0 = wp[0], b1 = wp[H], b2 = wp[2 * (long)H], b3 = wp[3 * (long)H];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b3, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int s = 4 * (lane >> 4) + r, i = n0 + (lane & 15);
-                Dn[s * HS + i] = acc[r] * act_bwd(Hin[s * HS + i], act);
-            }
+            slab[offB(l) + o] = acc;
         }
         __syncthreads();
         float* t = Dc; Dc = Dn; Dn = t;
     }
+    PPOAF_STAMP(8);
 
-    // ---- P8: first layer backward (VALU)
-    {
-        for (int idx = tid; idx < H * in_dim; idx += kThreads) {
-            const int o = idx / in_dim, i = idx - o * in_dim;
-            float acc = 0.f;
+    // ---- first layer backward: dW0[o][i] = sum_s dz0[s][o] * x[s][i] on MFMA against the padded sX
+    if (!(dbg & 256))
+    for (int mt = wave; mt < HT; mt += kNW)
+        wgrad_mtile(Dc, HS, sX, INP, mt * 16, NT0, in_dim, lane, slab + offW(0), in_dim);
+    for (int o = tid; o < H; o += kThreadsU) {
+        float acc = 0.f;
 #pragma unroll
-            for (int s = 0; s < kRows; ++s) acc = fmaf(Dc[s * HS + o], sX[s * INP + i], acc);
-            slab[nd.offW[0] + idx] = acc;
-        }
-        for (int o = tid; o < H; o += kThreads) {
-            float acc = 0.f;
-#pragma unroll
-            for (int s = 0; s < kRows; ++s) acc += Dc[s * HS + o];
-            slab[nd.offB[0] + o] = acc;
-        }
+        for (int s = 0; s < kRows; ++s) acc += Dc[s * HS + o];
+        slab[offB(0) + o] = acc;
     }
+    PPOAF_STAMP(9);
 }
 
-// slabs -> gradient bucket in a fixed order; block 0 folds the loss partials into the totals and
-// advances the Adam step counters.
-__global__ __launch_bounds__(256) void ppo_update_reduce_kernel(UpdateDev u, int compute_norms) {
+// 1-D grid of 2 * n_wg workgroups.  Every workgroup of a network streams that network's whole
+// weight set, so workgroups of one network are placed on the same XCDs (blocks b and b + 8 share
+// an XCD under the observed round-robin dispatch): XCDs 0-3 take the actor, 4-7 the critic, and
+// each weight line is then fetched into an XCD's L2 once for its 4 consumers instead of once per
+// pair.  Placement only changes speed; nothing depends on it.
+template <int HTA, int HTC>
+__global__ __launch_bounds__(kThreadsU) void ppo_update_fwd_bwd_kernel(UpdateDev u) {
+    const int b = blockIdx.x;
+    const int which = (b >> 2) & 1;                        // b % 8 in {0..3} -> actor, {4..7} -> critic
+    const int g = ((b >> 3) << 2) | (b & 3);
+    if (g >= u.n_wg) return;                               // uniform per workgroup, before any barrier
+    if (which == 0) ppo_update_fwd_bwd_body<HTA>(u, 0, g);
+    else ppo_update_fwd_bwd_body<HTC>(u, 1, g);
+}
+
+// slabs -> gradient bucket in a fixed order.  The slabs were just written by other CUs, so every
+// read is a cold miss: all of them are put in flight at once -- thread (g, c) loads ONE float4 of
+// slab g, the 16-row LDS tile is then summed over g in index order (bitwise reproducible).
+// Block 0 also folds the loss partials into the totals, advances the Adam step counters and
+// publishes the bias corrections (computed once, in double, instead of per thread in the Adam kernel).
+constexpr int kRedCols = 64;      // float4 columns per block
+constexpr int kRedRows = 16;      // slabs summed per pass (= threads.y)
+
+__global__ __launch_bounds__(kRedCols * kRedRows) void ppo_update_reduce_kernel(UpdateDev u, int compute_norms) {
+    __shared__ float4 tile[kRedRows][kRedCols];
     __shared__ double red[17];
+    const int c = threadIdx.x & (kRedCols - 1), r = threadIdx.x / kRedCols;
     const long n4 = u.bucket_total >> 2;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    double q0 = 0.0, q1 = 0.0;
-    if (idx < n4) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4* sl = reinterpret_cast<const float4*>(u.slabs) + idx;
-        for (int g = 0; g < u.n_wg; ++g) {
-            const float4 v = sl[(long)g * n4];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    const long idx = (long)blockIdx.x * kRedCols + c;
+    const float4* sl = reinterpret_cast<const float4*>(u.slabs);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g0 = 0; g0 < u.n_wg; g0 += kRedRows) {
+        const int g = g0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < n4 && g < u.n_wg) v = sl[(long)g * n4 + idx];
+        tile[r][c] = v;
+        __syncthreads();
+        if (r == 0) {
+#pragma unroll
+            for (int k = 0; k < kRedRows; ++k) {
+                const float4 t = tile[k][c];
+                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            }
         }
+        __syncthreads();
+    }
+    double q0 = 0.0, q1 = 0.0;
+    if (r == 0 && idx < n4) {
         reinterpret_cast<float4*>(u.grads)[idx] = acc;
         if (compute_norms) {
             const float sc = u.grad_scale;
@@ -514,8 +702,8 @@ __global__ __launch_bounds__(256) void ppo_update_reduce_kernel(UpdateDev u, int
         float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int g = 0; g < u.n_wg; ++g) {
             const float* a = u.loss_partials + (long)g * 8;
-            const float* c = u.loss_partials + ((long)u.n_wg + g) * 8;
-            p[0] += a[0]; p[3] += a[3]; p[4] += a[4]; p[7] += a[7]; p[2] += c[2];
+            const float* cc = u.loss_partials + ((long)u.n_wg + g) * 8;
+            p[0] += a[0]; p[3] += a[3]; p[4] += a[4]; p[7] += a[7]; p[2] += cc[2];
         }
         const float n = (float)u.B;
         const float surr = p[0] / n, ent = p[3] / n, kl = p[4] / n, crit = p[2] / n;
@@ -527,7 +715,12 @@ __global__ __launch_bounds__(256) void ppo_update_reduce_kernel(UpdateDev u, int
         u.totals[5] += (double)u.loss_partials[5]; u.totals[6] += (double)u.loss_partials[6];
         u.totals[7] += p[7] > 0.f ? 1.0 : 0.0;
         u.totals[8] += 1.0;
-        u.step_counts[0] += 1; u.step_counts[1] += 1;
+        for (int w = 0; w < 2; ++w) {
+            const int64_t t = u.step_counts[w] + 1;
+            u.step_counts[w] = t;
+            u.norm_scratch[2 + 2 * w] = 1.0 - pow((double)u.beta1, (double)t);       // bias correction 1
+            u.norm_scratch[3 + 2 * w] = sqrt(1.0 - pow((double)u.beta2, (double)t)); // sqrt(bias correction 2)
+        }
     }
 }
 
@@ -560,12 +753,9 @@ __global__ __launch_bounds__(256) void ppo_update_adam_kernel(UpdateDev u) {
         float coef = 1.0f;
         if (u.max_norm > 0.f) coef = fminf(u.max_norm / (total_norm + 1e-6f), 1.0f);
         const float gs = u.grad_scale * coef;
-        const double t = (double)u.step_counts[which];
         const float lr = u.lr[0];
-        const double bc1 = 1.0 - pow((double)u.beta1, t);
-        const double bc2 = 1.0 - pow((double)u.beta2, t);
-        const float step_size = (float)((double)lr / bc1);
-        const float bc2_sqrt = (float)sqrt(bc2);
+        const float step_size = (float)((double)lr / u.norm_scratch[2 + 2 * which]);
+        const float bc2_sqrt = (float)u.norm_scratch[3 + 2 * which];
         float4 p = reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx];
         const float4 g = reinterpret_cast<const float4*>(u.grads)[idx];
         float4 m = reinterpret_cast<float4*>(u.exp_avg)[idx];
@@ -663,6 +853,7 @@ static int make_dev(const ppoaf_ppo_update_args_t* a, UpdateDev& u) {
                       a->cursor && a->vn_mean && a->vn_var && a->vn_count && a->loss_partials && a->totals,
                   "ppo_update: null pointer");
     PPOAF_REQUIRE(!a->normalize_values || (a->vn_records && a->n_ranks >= 1), "ppo_update: vn_records missing");
+    PPOAF_REQUIRE(!a->normalize_adv || a->adv_records, "ppo_update: adv_records missing");
     PPOAF_REQUIRE(((uintptr_t)a->params & 15) == 0 && ((uintptr_t)a->grads & 15) == 0 &&
                       ((uintptr_t)a->slabs & 15) == 0 && ((uintptr_t)a->exp_avg & 15) == 0 &&
                       ((uintptr_t)a->exp_avg_sq & 15) == 0,
@@ -676,11 +867,16 @@ static int make_dev(const ppoaf_ppo_update_args_t* a, UpdateDev& u) {
     u.row_map = a->row_map; u.n_rows = a->n_rows; u.cursor = a->cursor; u.B = a->B;
     u.batch_stride = a->batch_stride; u.normalize_values = a->normalize_values; u.n_ranks = a->n_ranks;
     u.vn_mean = a->vn_mean; u.vn_var = a->vn_var; u.vn_count = a->vn_count; u.vn_records = a->vn_records;
+    u.adv_records = a->adv_records;
     u.normalize_adv = a->normalize_adv; u.use_huber = a->use_huber; u.surr_clip = a->surr_clip;
     u.entropy_weight = a->entropy_weight; u.kl_loss_weight = a->kl_loss_weight;
     u.huber_delta = a->huber_delta; u.min_std = a->min_std; u.loss_partials = a->loss_partials;
     u.totals = a->totals;
     u.n_wg = (int)((a->B + kRows - 1) / kRows);
+    u.debug = 0;
+#ifdef PPOAF_STAMPS
+    if (const char* e = getenv("PPOAF_DEBUG")) u.debug = atoi(e);
+#endif
     return PPOAF_OK;
 }
 
@@ -688,13 +884,26 @@ static size_t fwd_bwd_lds_bytes(const UpdateDev& u) {
     size_t worst = 0;
     for (int w = 0; w < 2; ++w) {
         const NetDev& n = u.net[w];
-        const size_t HS = n.H + 4, INP = ((n.in_dim + 3) & ~3) + 4;
-        size_t f = 80 + kRows * INP + (size_t)n.depth * kRows * HS + 2 * kRows * HS + 2 * kRows * kMaxOut;
-        if (w == 0) f += (size_t)(u.B < kMaxAdvLds ? u.B : kMaxAdvLds);
-        f = (f + 3) / 4 * 4;
+        const size_t HS = n.H + 4, INP = 16 * ((n.in_dim + 15) / 16) + 4;
+        const size_t f = 208 + (size_t)(n.depth + 1) * n.H + 8 * (size_t)n.H + kRows * INP +
+                         (size_t)n.depth * kRows * HS + 2 * kRows * HS + 2 * kRows * kMaxOut;
         if (f * 4 > worst) worst = f * 4;
     }
-    return worst;
+    return (worst + 15) / 16 * 16;
+}
+
+template <int HTA, int HTC>
+static int launch_fwd_bwd(const UpdateDev& u, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_update_fwd_bwd_kernel<HTA, HTC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+        attr_set = true;
+    }
+    const unsigned grid = 8u * (unsigned)((u.n_wg + 3) / 4);     // groups of 4 actor + 4 critic blocks
+    hipLaunchKernelGGL((ppo_update_fwd_bwd_kernel<HTA, HTC>), dim3(grid), dim3(kThreadsU), lds, s, u);
+    return check_launch("ppo_update_fwd_bwd");
 }
 
 }  // namespace ppoaf
@@ -707,16 +916,17 @@ extern "C" int ppoaf_ppo_update_fwd_bwd(const ppoaf_ppo_update_args_t* args, ppo
     if (rc) return rc;
     const size_t lds = fwd_bwd_lds_bytes(u);
     PPOAF_REQUIRE(lds <= 160 * 1024, "ppo_update_fwd_bwd: needs %zu B of LDS (> 160 KiB)", lds);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_update_fwd_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(ppo_update_fwd_bwd_kernel, dim3(u.n_wg, 2), dim3(kThreads), lds,
-                       (hipStream_t)stream, u);
-    return check_launch("ppo_update_fwd_bwd");
+    hipStream_t s = (hipStream_t)stream;
+    // instantiated (actor width, critic width) pairs; the host falls back to the torch path otherwise
+    const int ha = u.net[0].H, hc = u.net[1].H;
+    if (ha == 32 && hc == 32) return launch_fwd_bwd<2, 2>(u, lds, s);
+    if (ha == 64 && hc == 64) return launch_fwd_bwd<4, 4>(u, lds, s);
+    if (ha == 128 && hc == 128) return launch_fwd_bwd<8, 8>(u, lds, s);
+    if (ha == 256 && hc == 256) return launch_fwd_bwd<16, 16>(u, lds, s);
+    if (ha == 128 && hc == 256) return launch_fwd_bwd<8, 16>(u, lds, s);
+    if (ha == 64 && hc == 128) return launch_fwd_bwd<4, 8>(u, lds, s);
+    set_error("ppo_update_fwd_bwd: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
+    return PPOAF_E_INVALID;
 }
 
 extern "C" int ppoaf_ppo_update_reduce(const ppoaf_ppo_update_args_t* args, int compute_norms,
@@ -725,8 +935,8 @@ extern "C" int ppoaf_ppo_update_reduce(const ppoaf_ppo_update_args_t* args, int 
     int rc = make_dev(args, u);
     if (rc) return rc;
     const long n4 = u.bucket_total >> 2;
-    hipLaunchKernelGGL(ppo_update_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, u, compute_norms);
+    hipLaunchKernelGGL(ppo_update_reduce_kernel, dim3((unsigned)((n4 + kRedCols - 1) / kRedCols)),
+                       dim3(kRedCols * kRedRows), 0, (hipStream_t)stream, u, compute_norms);
     return check_launch("ppo_update_reduce");
 }
 
@@ -745,6 +955,12 @@ extern "C" int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int co
     hipLaunchKernelGGL(ppo_update_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u);
     return check_launch("ppo_update_adam");
 }
+
+#ifdef PPOAF_STAMPS
+extern "C" int ppoaf_debug_read_stamps(unsigned long long* out /* host [32] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ppo_update_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int ppoaf_minibatch_moments(const float* data, const int64_t* perm, const int32_t* row_map,
                                        int64_t n_perm, int64_t B, double* records,

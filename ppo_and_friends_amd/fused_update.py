@@ -43,8 +43,8 @@ def _describe(net, bucket, with_log_std):
     H = dims[0][1]
     if any(o != H for (_, o) in dims[:-1]) or any(i != H for (i, _) in dims[1:]):
         return None, "hidden layers must share one width"
-    if H % 16 or not (16 <= H <= 256):
-        return None, f"hidden width {H} must be a multiple of 16 in [16, 256]"
+    if H not in (32, 64, 128, 256):
+        return None, f"hidden width {H} is not one of the instantiated widths (32, 64, 128, 256)"
     act = _activation_code(net.activation)
     if act is None:
         return None, f"activation {net.activation} is not one of ReLU / LeakyReLU(0.01) / Tanh"
@@ -102,6 +102,8 @@ class FusedPolicyUpdate:
             return "critic must have one output"
         if a.offset != 0 or c.offset != a.size:
             return "actor and critic buckets are not adjacent"
+        if (a.hidden, c.hidden) not in ((32, 32), (64, 64), (128, 128), (256, 256), (128, 256), (64, 128)):
+            return f"hidden widths (actor {a.hidden}, critic {c.hidden}) are not an instantiated pair"
         if batch_size < 2:
             return "batch size < 2"
         return ""
@@ -128,6 +130,7 @@ class FusedPolicyUpdate:
         self.loss_partials = torch.zeros(2, self.n_wg, 8, dtype=torch.float32, device=dev)
         self.totals = torch.zeros(9, dtype=torch.float64, device=dev)
         self.records = None
+        self.adv_records = None
         self.perm = None
         self._graphs = {}
         self._args = {}
@@ -159,6 +162,7 @@ class FusedPolicyUpdate:
         a.vn_mean = self.vn_mean.data_ptr(); a.vn_var = self.vn_var.data_ptr()
         a.vn_count = self.vn_count.data_ptr()
         a.vn_records = self.records.data_ptr() if self.records is not None else None
+        a.adv_records = self.adv_records.data_ptr() if self.adv_records is not None else None
         a.normalize_adv = int(bool(ppo.normalize_adv)); a.use_huber = int(bool(pol.use_huber_loss))
         a.surr_clip = float(pol.surr_clip); a.entropy_weight = float(pol.entropy_weight())
         a.kl_loss_weight = float(pol.kl_loss_weight); a.huber_delta = 10.0
@@ -171,6 +175,7 @@ class FusedPolicyUpdate:
         pol, buf = self.pol, self.pol.buffer
         return (buf.observations.data_ptr(), buf.num_transitions, self.perm.data_ptr(),
                 None if self.records is None else self.records.data_ptr(),
+                None if self.adv_records is None else self.adv_records.data_ptr(),
                 float(pol.entropy_weight()), float(pol.surr_clip), float(pol.kl_loss_weight),
                 bool(pol.use_huber_loss), pol.gradient_clip, bool(self.ppo.normalize_adv),
                 bool(self.ppo.normalize_values))
@@ -199,6 +204,11 @@ class FusedPolicyUpdate:
             rs = ppo.value_normalizers[self.policy_id].running_stats
             self.vn_mean[0:1].copy_(rs.mean_t); self.vn_var[0:1].copy_(rs.var_t)
             self.vn_count[0:1].copy_(rs.count_t)
+        if ppo.normalize_adv:
+            if self.adv_records is None or self.adv_records.shape[0] != nb:
+                self.adv_records = torch.empty(nb, 3, dtype=torch.float64, device=pol.device)
+                self._graphs.clear()
+            K.minibatch_moments(buf.advantages.view(-1), self.perm, buf.row_map, self.B, out=self.adv_records)
         self.cursor.zero_()
         self.totals.zero_()
         sig = self._signature()

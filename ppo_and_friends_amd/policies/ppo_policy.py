@@ -186,7 +186,7 @@ class PPOPolicy:
         self.policy_exp_avg_sq = torch.zeros_like(self.policy_params)
         self.policy_step_counts = torch.zeros(2, dtype=torch.int64, device=dev)
         self.policy_lr = torch.full((1,), float(self.lr()), dtype=torch.float32, device=dev)
-        self.policy_norm_scratch = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.policy_norm_scratch = torch.zeros(6, dtype=torch.float64, device=dev)   # norms + bias corrections
         self.actor_optim = FlatAdam(self.actor, self.lr(), eps=1e-5, storage=(
             self.policy_exp_avg[:na], self.policy_exp_avg_sq[:na], self.policy_step_counts[0:1],
             self.policy_lr, self.policy_norm_scratch[0:1]))

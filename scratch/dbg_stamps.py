@@ -1,0 +1,24 @@
+import sys, ctypes as C; sys.path.insert(0,'.')
+import numpy as np, torch
+from ppo_and_friends_amd import _lib
+_lib.LIB_PATH='scratch/libppoaf_hip_stamps.so'
+from ppo_and_friends_amd.ppo import PPO, PermutationLoader
+from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+from ppo_and_friends_amd.spaces import Box, Discrete
+dev=torch.device('cuda',0); E,T,O=4096,128,4
+env_gen=lambda: SyntheticFixedLengthEnv(E,O,Discrete(2),T,dev)
+sp=Box(-np.inf,np.inf,(O,),np.float32)
+ppo=PPO(env_gen,{"p":(None,sp,sp,Discrete(2),{})},device=dev,random_seed=1,envs_per_proc=E,ts_per_rollout=T,batch_size=256,epochs_per_iter=1,use_graphs=False)
+ppo.rollout(); pol=ppo.policies["p"]
+loader=PermutationLoader(pol.dataset,256,ppo.loader_generator)
+f=ppo._fused_updater("p",256); f.begin_epoch(loader.epoch_permutation())
+args=f._args_for(256)
+for _ in range(50): f._one(args)
+torch.cuda.synchronize()
+lib=_lib.load(); buf=(C.c_ulonglong*32)(); lib.ppoaf_debug_read_stamps.argtypes=[C.c_void_p]; print(lib.ppoaf_debug_read_stamps(buf))
+st=np.array(list(buf),dtype=np.int64).reshape(2,16)
+names=["P0 idx/stats","P1 gatherX","P2 layer0","P3 hidden fwd","P4 out","P5 head","P6 out bwd","P7 hidden bwd","P8 layer0 bwd"]
+for w in (0,1):
+    d=np.diff(st[w,:10]); print("net",w,"total cycles",st[w,9]-st[w,0])
+    for n,x in zip(names,d): print("   %-16s %7d"%(n,x))
+    print("   L1 fwd: pre-mfma %d, mfma %d, act+store %d, barrier %d"%(st[w,10]-st[w,3], st[w,11]-st[w,10], st[w,12]-st[w,11], st[w,13]-st[w,12]))
