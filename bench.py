@@ -95,11 +95,9 @@ def main():
         hook = getattr(ppo, "rollout_buffer_hook", None)
         if hook is None:
             return orig(self, *a, **kw)
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig(self, *a, **kw)
-        e1.record()
-        hook.append((e0, e1))
+        ev = (K.event_create(), K.event_create())      # stamped with the kernel's own begin / end
+        r = orig(self, *a, timing_events=ev, **kw)
+        hook.append(ev)
         return r
 
     ei.RolloutBuffer.compute_advantages = timed_compute
@@ -119,15 +117,16 @@ def main():
 
     env_steps = world * E * T * args.steps
     value = env_steps / dt
-    gae_ms = [a.elapsed_time(b) for a, b in gae_events]
+    gae_ms = [K.event_elapsed_ms(a, b) for a, b in gae_events]
     gae_avg_s = (sum(gae_ms) / max(len(gae_ms), 1)) * 1e-3
     gae_bytes = GAE_BYTES_PER_TRANSITION * E * T
     achieved = gae_bytes / gae_avg_s / 1e9 if gae_avg_s > 0 else 0.0
-    roofline = {"kernel": "gae_rtg_tmajor_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+    roofline = {"kernel": "gae_rtg_chunked_kernel" if E < (1 << 17) else "gae_rtg_stream_kernel", "bound": "hbm", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": None, "bytes_per_launch": gae_bytes,
                 "avg_launch_us": round(gae_avg_s * 1e6, 3), "launches": len(gae_ms),
-                "note": "config size (8.4 MB) is launch/latency-bound; see roofline_saturating"}
+                "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on the launch stream, timed region",
+                "note": "config size (8.4 MB, fits L2/MALL) is latency-bound; see roofline_saturating"}
 
     out = {"metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -150,15 +149,14 @@ def main():
         adv = torch.empty_like(r); rtg = torch.empty_like(r)
         for _ in range(2):
             K.gae_rtg_tmajor(r, v, b, b, None, adv_out=adv, rtg_out=rtg)
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         reps = 5
-        e0.record()
-        for _ in range(reps):
-            K.gae_rtg_tmajor(r, v, b, b, None, adv_out=adv, rtg_out=rtg)
-        e1.record(); torch.cuda.synchronize()
-        s = e0.elapsed_time(e1) * 1e-3 / reps
+        evs = [(K.event_create(), K.event_create()) for _ in range(reps)]
+        for ev in evs:
+            K.gae_rtg_tmajor(r, v, b, b, None, adv_out=adv, rtg_out=rtg, timing_events=ev)
+        torch.cuda.synchronize()
+        s = sum(K.event_elapsed_ms(a, c) for a, c in evs) * 1e-3 / reps
         bts = GAE_BYTES_PER_TRANSITION * T * Es
-        out["roofline_saturating"] = {"kernel": "gae_rtg_tmajor_kernel", "bound": "hbm",
+        out["roofline_saturating"] = {"kernel": "gae_rtg_stream_kernel<4, 8>", "bound": "hbm",
                                       "transitions": T * Es, "achieved": round(bts / s / 1e9, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(bts / s / 1e9 / HBM_PEAK_GBS, 4),

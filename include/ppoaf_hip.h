@@ -74,6 +74,23 @@ int ppoaf_gae_rtg_tmajor(const float* rewards, const float* values,
                          float* adv_out, float* rtg_out,
                          ppoaf_stream_t stream);
 
+/* Same launch with the kernel's own begin / end stamped into two events (hipExtLaunchKernelGGL):
+ * what bench.py uses for the roofline figure.  Events come from ppoaf_event_create(). */
+int ppoaf_gae_rtg_tmajor_timed(const float* rewards, const float* values,
+                               const float* boot_value, const float* boot_reward,
+                               const int8_t* end_kind,
+                               int32_t T, int64_t E,
+                               double gamma, double lambd,
+                               int has_clip, double clip_lo, double clip_hi,
+                               int use_gae,
+                               float* adv_out, float* rtg_out,
+                               void* start_event, void* stop_event,
+                               ppoaf_stream_t stream);
+void* ppoaf_event_create(void);
+int   ppoaf_event_destroy(void* event);
+/* waits for `stop`, then *ms = time between the two stamps */
+int   ppoaf_event_elapsed_ms(void* start_event, void* stop_event, float* ms);
+
 /* Ragged trajectory list over a flat episode-major [N] layout (the layout
  * PPODataset.build produces, utils/episode_info.py:745-914): trajectory i
  * covers [traj_start[i], traj_start[i] + traj_len[i]).  Used for the

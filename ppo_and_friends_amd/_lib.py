@@ -65,6 +65,12 @@ SIGNATURES = {
     "ppoaf_gae_rtg_tmajor": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_int32, C.c_int64,
                                        C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
                                        C.c_int, _ptr, _ptr, _ptr]),
+    "ppoaf_gae_rtg_tmajor_timed": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_int32, C.c_int64,
+                                             C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
+                                             C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "ppoaf_event_create": (C.c_void_p, []),
+    "ppoaf_event_destroy": (C.c_int, [_ptr]),
+    "ppoaf_event_elapsed_ms": (C.c_int, [_ptr, _ptr, C.POINTER(C.c_float)]),
     "ppoaf_gae_rtg_traj": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64,
                                      C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
                                      C.c_int, _ptr, _ptr, _ptr]),

@@ -12,6 +12,7 @@
 //   traj:   flat episode-major [N]; one wave per trajectory, 64 elements per
 //           step from the tail, wave-level suffix scan of the same affine maps.
 #include "common.hpp"
+#include <hip/hip_ext.h>
 
 namespace ppoaf {
 
@@ -35,50 +36,150 @@ __device__ __forceinline__ float clip_reward(float er, const GaeParams& p) {
     return er;
 }
 
-constexpr int TC = 16;     // timesteps per wave chunk (register resident)
+// ---------------------------------------------------------------------------------------------
+// tmajor, large E: streaming kernel.  A lane owns VEC adjacent env columns (16 B loads / stores
+// when VEC = 4), walks time backwards with U steps of loads in flight, state in registers.
+// Algorithmic traffic 16 B per transition (+1 B of end flags in the dense form).
+// ---------------------------------------------------------------------------------------------
+template <int VEC> struct VecF;
+template <> struct VecF<1> { using type = float; };
+template <> struct VecF<2> { using type = float2; };
+template <> struct VecF<4> { using type = float4; };
 
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void gae_rtg_tmajor_kernel(
+template <int VEC>
+__device__ __forceinline__ void vec_to_arr(const typename VecF<VEC>::type& v, float (&a)[VEC]) {
+    const float* p = reinterpret_cast<const float*>(&v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) a[k] = p[k];
+}
+
+template <int VEC, int U>
+__global__ __launch_bounds__(256) void gae_rtg_stream_kernel(
     const float* __restrict__ rewards, const float* __restrict__ values,
     const float* __restrict__ boot_value, const float* __restrict__ boot_reward,
     const int8_t* __restrict__ end_kind, int T, long E, GaeParams p,
     float* __restrict__ adv_out, float* __restrict__ rtg_out) {
-    // LDS: per (tile-chunk wave, lane): affine maps (Ma,Ba) for adv and (Mr,Br) for rtg,
-    // plus the carries that cross tiles.
-    __shared__ double sMa[WAVES][64], sBa[WAVES][64], sMr[WAVES][64], sBr[WAVES][64];
-    __shared__ double sCarryA[64], sCarryR[64];
+    using V = typename VecF<VEC>::type;
+    const long e0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    if (e0 >= E) return;
+    const bool dense = end_kind != nullptr;
+    double A[VEC], R[VEC];
+    float vnext[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { A[k] = 0.0; R[k] = 0.0; vnext[k] = 0.f; }
 
-    const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
-    const long e = (long)blockIdx.x * 64 + lane;
+    for (int t_hi = T; t_hi > 0; t_hi -= U) {
+        V rv[U], vv[U];
+        unsigned ek[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int t = t_hi - 1 - i;
+            ek[i] = 0u;
+            if (t >= 0) {
+                const long idx = (long)t * E + e0;
+                rv[i] = *reinterpret_cast<const V*>(rewards + idx);
+                vv[i] = *reinterpret_cast<const V*>(values + idx);
+                if (dense) {
+                    if (VEC == 4) ek[i] = *reinterpret_cast<const unsigned*>(end_kind + idx);
+                    else if (VEC == 2) ek[i] = *reinterpret_cast<const unsigned short*>(end_kind + idx);
+                    else ek[i] = (unsigned char)end_kind[idx];
+                } else if (t == T - 1) {
+                    ek[i] = 0x02020202u;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int t = t_hi - 1 - i;
+            if (t < 0) break;
+            const long idx = (long)t * E + e0;
+            float r[VEC], v[VEC], ao[VEC], ro[VEC];
+            vec_to_arr<VEC>(rv[i], r);
+            vec_to_arr<VEC>(vv[i], v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const unsigned kind = (ek[i] >> (8 * k)) & 0xffu;
+                float vn = vnext[k];
+                if (kind == 1u) { vn = 0.f; A[k] = 0.0; R[k] = 0.0; }
+                else if (kind == 2u) {
+                    const long b = dense ? idx + k : e0 + k;
+                    vn = boot_value[b]; A[k] = 0.0;
+                    R[k] = (double)clip_reward(boot_reward[b], p);
+                }
+                const double delta = (double)r[k] + (double)(p.gamma_f * vn) - (double)v[k];
+                A[k] = delta + p.gl * A[k];
+                R[k] = (double)r[k] + p.gamma * R[k];
+                ro[k] = (float)R[k];
+                ao[k] = p.use_gae ? (float)A[k] : (float)(R[k] - (double)v[k]);
+                vnext[k] = v[k];
+            }
+            *reinterpret_cast<V*>(adv_out + idx) = *reinterpret_cast<const V*>(ao);
+            *reinterpret_cast<V*>(rtg_out + idx) = *reinterpret_cast<const V*>(ro);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tmajor, small E (latency-bound; the 4096 x 128 configuration is 8.4 MB): the work has to be
+// spread over all CUs -- a CU pulls only a few tens of GB/s -- so a workgroup takes just 16 env
+// columns and splits TIME over its 512 lanes: lane = (time sub-chunk 0..3, env 0..15), 8 waves
+// -> 32 chunks of TC steps per tile.  Each lane folds its chunk to the affine map of the
+// recurrence (X_in -> B + M * X_in), the maps are composed (shuffles inside a wave, LDS across
+// waves), then each lane replays its chunk from the true carry with its inputs still in registers.
+// ---------------------------------------------------------------------------------------------
+constexpr int EW = 16;          // env columns per workgroup
+constexpr int TS = 64 / EW;     // time sub-chunks per wave
+constexpr int CW = 8;           // waves per workgroup
+constexpr int TC = 4;           // timesteps per lane chunk
+
+struct Affine { double Ma, Ba, Mr, Br; };   // adv: X -> Ba + Ma X ; rtg: X -> Br + Mr X
+// apply `first` (later in time), then `second` (earlier in time)
+__device__ __forceinline__ Affine then(const Affine& first, const Affine& second) {
+    Affine o;
+    o.Ba = second.Ba + second.Ma * first.Ba; o.Ma = second.Ma * first.Ma;
+    o.Br = second.Br + second.Mr * first.Br; o.Mr = second.Mr * first.Mr;
+    return o;
+}
+__device__ __forceinline__ Affine shfl_affine(const Affine& a, int src_lane) {
+    Affine o;
+    o.Ma = __shfl(a.Ma, src_lane, 64); o.Ba = __shfl(a.Ba, src_lane, 64);
+    o.Mr = __shfl(a.Mr, src_lane, 64); o.Br = __shfl(a.Br, src_lane, 64);
+    return o;
+}
+
+__global__ __launch_bounds__(64 * CW) void gae_rtg_chunked_kernel(
+    const float* __restrict__ rewards, const float* __restrict__ values,
+    const float* __restrict__ boot_value, const float* __restrict__ boot_reward,
+    const int8_t* __restrict__ end_kind, int T, long E, GaeParams p,
+    float* __restrict__ adv_out, float* __restrict__ rtg_out) {
+    __shared__ Affine sWave[CW][EW];        // per-wave aggregate map
+    __shared__ double sCarryA[EW], sCarryR[EW];
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int es = lane & (EW - 1), ts = lane / EW;
+    const long e = (long)blockIdx.x * EW + es;
     const bool live = e < E;
-    const bool dense_flags = end_kind != nullptr;
+    const bool dense = end_kind != nullptr;
+    if (threadIdx.x < EW) { sCarryA[threadIdx.x] = 0.0; sCarryR[threadIdx.x] = 0.0; }
 
-    if (w == 0) { sCarryA[lane] = 0.0; sCarryR[lane] = 0.0; }
-
-    const int tile = WAVES * TC;
-    // tiles walk backwards from the end of the rollout; tile k covers
-    // [T - (k+1)*tile, T - k*tile) clipped at 0.
+    constexpr int tile = CW * TS * TC;
     for (int t_hi = T; t_hi > 0; t_hi -= tile) {
-        // this wave's chunk: [c_lo, c_hi) ; wave 0 owns the latest chunk
-        const int c_hi = t_hi - w * TC;
+        const int c = w * TS + ts;                      // chunk 0 is the latest in time
+        const int c_hi = t_hi - c * TC;
         const int c_lo = max(c_hi - TC, 0);
-        const int n = max(c_hi - c_lo, 0);        // may be 0 for leading waves of the first tile
-
-        float r[TC], v[TC];
-        float vn_end[TC];       // ending value where the episode ends, else unused
-        float er_end[TC];
-        int8_t ek[TC];
-        float v_after = 0.f;    // V[c_hi] when the step c_hi-1 continues
+        const int n = max(c_hi - c_lo, 0);
+        float r[TC], v[TC], vn_end[TC], er_end[TC];
+        int ek[TC];
+        float v_after = 0.f;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
-            const int t = c_hi - 1 - i;           // i = 0 is the latest step of the chunk
+            const int t = c_hi - 1 - i;
             r[i] = 0.f; v[i] = 0.f; ek[i] = 0; vn_end[i] = 0.f; er_end[i] = 0.f;
             if (live && i < n) {
                 const long idx = (long)t * E + e;
                 r[i] = rewards[idx];
                 v[i] = values[idx];
-                if (dense_flags) {
+                if (dense) {
                     ek[i] = end_kind[idx];
                     if (ek[i] == 2) { vn_end[i] = boot_value[idx]; er_end[i] = boot_reward[idx]; }
                 } else if (t == T - 1) {
@@ -88,38 +189,48 @@ __global__ __launch_bounds__(64 * WAVES) void gae_rtg_tmajor_kernel(
         }
         if (live && n > 0 && c_hi < T) v_after = values[(long)c_hi * E + e];
 
-        // pass 1: affine map of the chunk  X_in -> B + M*X_in  (X_in = state at t = c_hi)
-        double Ma = 1.0, Ba = 0.0, Mr = 1.0, Br = 0.0;
+        // pass 1: this lane's chunk as an affine map of the state at t = c_hi
+        Affine m{1.0, 0.0, 1.0, 0.0};
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             if (i < n) {
                 const bool ends = ek[i] != 0;
                 const float vn = ends ? vn_end[i] : (i == 0 ? v_after : v[i - 1]);
                 const double delta = (double)r[i] + (double)(p.gamma_f * vn) - (double)v[i];
-                // A = delta + gl * (ends ? 0 : A_next)
-                Ba = delta + (ends ? 0.0 : p.gl * Ba);
-                Ma = ends ? 0.0 : p.gl * Ma;
+                m.Ba = delta + (ends ? 0.0 : p.gl * m.Ba);
+                m.Ma = ends ? 0.0 : p.gl * m.Ma;
                 const double rr = (double)r[i];
-                if (ends) { Br = rr + p.gamma * (double)clip_reward(er_end[i], p); Mr = 0.0; }
-                else      { Br = rr + p.gamma * Br; Mr = p.gamma * Mr; }
+                if (ends) { m.Br = rr + p.gamma * (double)clip_reward(er_end[i], p); m.Mr = 0.0; }
+                else      { m.Br = rr + p.gamma * m.Br; m.Mr = p.gamma * m.Mr; }
             }
         }
-        sMa[w][lane] = Ma; sBa[w][lane] = Ba; sMr[w][lane] = Mr; sBr[w][lane] = Br;
-        __syncthreads();
-
-        // carry into this wave's chunk = carry of the tile composed through the
-        // later chunks (waves 0..w-1, wave 0 latest).
-        double A = sCarryA[lane], R = sCarryR[lane];
-        for (int k = 0; k < w; ++k) {
-            A = sBa[k][lane] + sMa[k][lane] * A;
-            R = sBr[k][lane] + sMr[k][lane] * R;
+        // composition inside the wave: prefix over the later sub-chunks (ts' < ts), and the
+        // wave aggregate (all TS sub-chunks)
+        Affine prefix{1.0, 0.0, 1.0, 0.0};
+        Affine agg = m;                                  // running: chunks ts..0 applied latest-first
+        {
+            Affine run{1.0, 0.0, 1.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < TS; ++k) {
+                const Affine mk = shfl_affine(m, es + EW * k);
+                if (k == ts) prefix = run;
+                run = then(run, mk);
+            }
+            agg = run;
         }
-        // the last wave also publishes the carry for the next (earlier) tile
+        if (ts == 0) sWave[w][es] = agg;
+        __syncthreads();
+        double A = sCarryA[es], R = sCarryR[es];
+        for (int k = 0; k < w; ++k) {
+            const Affine a = sWave[k][es];
+            A = a.Ba + a.Ma * A; R = a.Br + a.Mr * R;
+        }
         double A_tile = 0.0, R_tile = 0.0;
-        if (w == WAVES - 1) { A_tile = Ba + Ma * A; R_tile = Br + Mr * R; }
+        if (w == CW - 1) { A_tile = agg.Ba + agg.Ma * A; R_tile = agg.Br + agg.Mr * R; }
+        A = prefix.Ba + prefix.Ma * A;
+        R = prefix.Br + prefix.Mr * R;
 
-        // pass 2: replay the chunk sequentially from the true carry (same op
-        // order as the reference's scalar loop within a chunk).
+        // pass 2: replay from the true carry
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             if (i < n) {
@@ -135,8 +246,8 @@ __global__ __launch_bounds__(64 * WAVES) void gae_rtg_tmajor_kernel(
                 }
             }
         }
-        __syncthreads();                 // everyone has read sM*/sB*/sCarry*
-        if (w == WAVES - 1) { sCarryA[lane] = A_tile; sCarryR[lane] = R_tile; }
+        __syncthreads();
+        if (w == CW - 1 && ts == 0) { sCarryA[es] = A_tile; sCarryR[es] = R_tile; }
         __syncthreads();
     }
 }
@@ -207,33 +318,71 @@ static GaeParams make_params(double gamma, double lambd, int has_clip, double lo
 
 using namespace ppoaf;
 
+// Kernel-exact timing: hipExtLaunchKernelGGL stamps the start / stop events with the kernel's own
+// begin / end (a plain event pair around a launch also counts the dispatch gaps, ~30 us here).
+extern "C" int ppoaf_gae_rtg_tmajor_timed(const float* rewards, const float* values,
+                                          const float* boot_value, const float* boot_reward,
+                                          const int8_t* end_kind, int32_t T, int64_t E,
+                                          double gamma, double lambd, int has_clip, double clip_lo,
+                                          double clip_hi, int use_gae, float* adv_out, float* rtg_out,
+                                          void* start_event, void* stop_event,
+                                          ppoaf_stream_t stream) {
+    PPOAF_REQUIRE(rewards && values && boot_value && boot_reward && adv_out && rtg_out,
+                  "gae_rtg_tmajor: null pointer");
+    PPOAF_REQUIRE(T >= 0 && E >= 0, "gae_rtg_tmajor: negative shape T=%d E=%ld", T, (long)E);
+    if (T == 0 || E == 0) return PPOAF_OK;
+    PPOAF_REQUIRE((E + EW - 1) / EW <= 0x7fffffffL, "gae_rtg_tmajor: E too large");
+    const GaeParams p = make_params(gamma, lambd, has_clip, clip_lo, clip_hi, use_gae);
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;
+    // Enough env columns to fill 256 CUs with several waves each -> streaming kernel (16-B lanes
+    // when rows are 16-B aligned); otherwise time is split across lanes as well (chunked kernel).
+    const bool aligned4 = (E % 4 == 0) && (((uintptr_t)rewards | (uintptr_t)values | (uintptr_t)adv_out |
+                                            (uintptr_t)rtg_out | (uintptr_t)end_kind) % 16 == 0);
+    if (E >= (1L << 20) && aligned4) {
+        const long thr = E / 4;
+        hipExtLaunchKernelGGL((gae_rtg_stream_kernel<4, 8>), dim3((unsigned)((thr + 255) / 256)), dim3(256), 0,
+                              s, e0, e1, 0, rewards, values, boot_value, boot_reward, end_kind, (int)T,
+                              (long)E, p, adv_out, rtg_out);
+    } else if (E >= (1L << 17)) {
+        hipExtLaunchKernelGGL((gae_rtg_stream_kernel<1, 8>), dim3((unsigned)((E + 255) / 256)), dim3(256), 0,
+                              s, e0, e1, 0, rewards, values, boot_value, boot_reward, end_kind, (int)T,
+                              (long)E, p, adv_out, rtg_out);
+    } else {
+        hipExtLaunchKernelGGL(gae_rtg_chunked_kernel, dim3((unsigned)((E + EW - 1) / EW)), dim3(64 * CW), 0,
+                              s, e0, e1, 0, rewards, values, boot_value, boot_reward, end_kind, (int)T,
+                              (long)E, p, adv_out, rtg_out);
+    }
+    return check_launch("gae_rtg_tmajor");
+}
+
 extern "C" int ppoaf_gae_rtg_tmajor(const float* rewards, const float* values,
                                     const float* boot_value, const float* boot_reward,
                                     const int8_t* end_kind, int32_t T, int64_t E,
                                     double gamma, double lambd, int has_clip, double clip_lo,
                                     double clip_hi, int use_gae, float* adv_out, float* rtg_out,
                                     ppoaf_stream_t stream) {
-    PPOAF_REQUIRE(rewards && values && boot_value && boot_reward && adv_out && rtg_out,
-                  "gae_rtg_tmajor: null pointer");
-    PPOAF_REQUIRE(T >= 0 && E >= 0, "gae_rtg_tmajor: negative shape T=%d E=%ld", T, (long)E);
-    if (T == 0 || E == 0) return PPOAF_OK;
-    PPOAF_REQUIRE((E + 63) / 64 <= 0x7fffffffL, "gae_rtg_tmajor: E too large");
-    const GaeParams p = make_params(gamma, lambd, has_clip, clip_lo, clip_hi, use_gae);
-    const unsigned grid = (unsigned)((E + 63) / 64);
-    hipStream_t s = (hipStream_t)stream;
-    // more waves along T when there are few env columns (latency-bound sizes),
-    // fewer when E alone fills the chip.
-    const int chunks = (T + TC - 1) / TC;
-    if (grid >= 4096 || chunks <= 1)
-        hipLaunchKernelGGL(gae_rtg_tmajor_kernel<1>, dim3(grid), dim3(64), 0, s, rewards, values,
-                           boot_value, boot_reward, end_kind, T, (long)E, p, adv_out, rtg_out);
-    else if (chunks <= 4 || grid >= 1024)
-        hipLaunchKernelGGL(gae_rtg_tmajor_kernel<4>, dim3(grid), dim3(256), 0, s, rewards, values,
-                           boot_value, boot_reward, end_kind, T, (long)E, p, adv_out, rtg_out);
-    else
-        hipLaunchKernelGGL(gae_rtg_tmajor_kernel<8>, dim3(grid), dim3(512), 0, s, rewards, values,
-                           boot_value, boot_reward, end_kind, T, (long)E, p, adv_out, rtg_out);
-    return check_launch("gae_rtg_tmajor");
+    return ppoaf_gae_rtg_tmajor_timed(rewards, values, boot_value, boot_reward, end_kind, T, E, gamma,
+                                      lambd, has_clip, clip_lo, clip_hi, use_gae, adv_out, rtg_out,
+                                      nullptr, nullptr, stream);
+}
+
+// Events for the *_timed entry points (hipEvent_t behind a void*).
+extern "C" void* ppoaf_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); return nullptr; }
+    return (void*)e;
+}
+extern "C" int ppoaf_event_destroy(void* e) {
+    return hipEventDestroy((hipEvent_t)e) == hipSuccess ? PPOAF_OK : PPOAF_E_LAUNCH;
+}
+// Blocks until `stop` has completed; returns the kernel time in ms through *ms.
+extern "C" int ppoaf_event_elapsed_ms(void* start, void* stop, float* ms) {
+    PPOAF_REQUIRE(start && stop && ms, "event_elapsed_ms: null pointer");
+    hipError_t e = hipEventSynchronize((hipEvent_t)stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    if (e != hipSuccess) { set_error("event_elapsed_ms: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+    return PPOAF_OK;
 }
 
 extern "C" int ppoaf_gae_rtg_traj(const float* rewards, const float* values,

@@ -34,8 +34,9 @@ def _clip_args(bootstrap_clip):
 # --------------------------------------------------------------------------
 def gae_rtg_tmajor(rewards, values, boot_value, boot_reward, end_kind=None,
                    gamma=0.99, lambd=0.95, bootstrap_clip=(-100.0, 100.0),
-                   use_gae=True, adv_out=None, rtg_out=None):
-    """[T,E] time-major GAE + rewards-to-go (utils/episode_info.py:419-465)."""
+                   use_gae=True, adv_out=None, rtg_out=None, timing_events=None):
+    """[T,E] time-major GAE + rewards-to-go (utils/episode_info.py:419-465).
+    timing_events = (start, stop) from event_create(): the kernel's own begin / end are stamped."""
     _req(rewards.dim() == 2, "rewards must be [T,E]")
     T, E = rewards.shape
     _f32(rewards, "rewards"); _f32(values, "values")
@@ -55,11 +56,24 @@ def gae_rtg_tmajor(rewards, values, boot_value, boot_reward, end_kind=None,
     _req(adv_out.shape == (T, E) and rtg_out.shape == (T, E), "outputs must be [T,E]")
     _f32(adv_out, "adv_out"); _f32(rtg_out, "rtg_out")
     hc, lo, hi = _clip_args(bootstrap_clip)
-    check(_lib.load().ppoaf_gae_rtg_tmajor(
+    e0, e1 = (None, None) if timing_events is None else timing_events
+    check(_lib.load().ppoaf_gae_rtg_tmajor_timed(
         ptr(rewards), ptr(values), ptr(boot_value), ptr(boot_reward), ptr(end_kind),
         T, E, float(gamma), float(lambd), hc, lo, hi, int(bool(use_gae)),
-        ptr(adv_out), ptr(rtg_out), stream()), "gae_rtg_tmajor")
+        ptr(adv_out), ptr(rtg_out), e0, e1, stream()), "gae_rtg_tmajor")
     return adv_out, rtg_out
+
+
+def event_create():
+    e = _lib.load().ppoaf_event_create()
+    _req(e is not None, "hipEventCreate failed")
+    return C.c_void_p(e)
+
+
+def event_elapsed_ms(start, stop):
+    ms = C.c_float(0.0)
+    check(_lib.load().ppoaf_event_elapsed_ms(start, stop, C.byref(ms)), "event_elapsed_ms")
+    return ms.value
 
 
 def gae_rtg_traj(rewards, values, ending_value, ending_reward, traj_start, traj_len,

@@ -104,17 +104,17 @@ class RolloutBuffer:
         if t != self.T - 1:
             self.fixed_length = False
 
-    def compute_advantages(self, gamma, lambd, bootstrap_clip, use_gae, adv_only=False):
+    def compute_advantages(self, gamma, lambd, bootstrap_clip, use_gae, adv_only=False, timing_events=None):
         """All GAE + rewards-to-go scans of the rollout: one launch (K1)."""
         rtg_out = torch.empty_like(self.rewards_to_go) if adv_only else self.rewards_to_go
         if self.fixed_length:
             K.gae_rtg_tmajor(self.rewards, self.values, self.boot_value[self.T - 1],
                              self.boot_reward[self.T - 1], None, gamma, lambd, bootstrap_clip,
-                             use_gae, self.advantages, rtg_out)
+                             use_gae, self.advantages, rtg_out, timing_events=timing_events)
         else:
             K.gae_rtg_tmajor(self.rewards, self.values, self.boot_value, self.boot_reward,
                              self.end_kind, gamma, lambd, bootstrap_clip, use_gae,
-                             self.advantages, rtg_out)
+                             self.advantages, rtg_out, timing_events=timing_events)
 
     def build_row_map(self):
         """

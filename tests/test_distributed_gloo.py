@@ -1,0 +1,120 @@
+"""
+CPU tests of the N>1 path: world_size-2 `gloo` process groups exercising the host-side
+collective layer that replaces the reference's mpi4py calls (utils/mpi_utils.py here;
+SURVEY.md §2.2(ii)): rank-0 parameter broadcast, flat-bucket gradient SUM + 1/R, the
+(n, mean, M2) moment-record exchange that replaces the raw-data allgather of
+utils/stats.py:47-50, and the packed scalar reductions.  The HIP kernels are not
+involved (no GPU here); the arithmetic the records feed is checked with the oracle.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle.running_stats_oracle import RunningMeanStd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _chan_merge(records):
+    """Numpy restatement of the record merge done by running_moments_integrate_kernel / K12."""
+    n, m, M2 = 0.0, 0.0, 0.0
+    for nb, mb, qb in records:
+        if nb <= 0:
+            continue
+        d = mb - m
+        nn = n + nb
+        m += d * (nb / nn)
+        M2 += qb + d * d * n * nb / nn
+        n = nn
+    return n, m, M2
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ppo_and_friends_amd.utils import mpi_utils
+    r, w, _ = mpi_utils.init_process_group_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and mpi_utils.get_num_procs() == world
+    res = {}
+    # 1. parameter broadcast: every rank ends with rank 0's bucket (mpi_utils.py:50-63)
+    flat = torch.full((1000,), float(rank + 1))
+    mpi_utils.broadcast_flat(flat)
+    res["bcast"] = flat.clone()
+    # 2. gradient exchange: SUM all-reduce of the flat bucket, 1/R applied by the consumer
+    g = torch.arange(8, dtype=torch.float32) * (rank + 1)
+    mpi_utils.allreduce_sum_(g)
+    res["grad_avg"] = g / world
+    # mpi_avg on scalars and tensors (mpi_utils.py:65-86)
+    res["avg_scalar"] = mpi_utils.mpi_avg(float(rank))
+    res["avg_tensor"] = mpi_utils.mpi_avg(torch.tensor([1.0, 2.0]) * (rank + 1))
+    # 3. moment records: rank-local (n, mean, M2) per mini-batch, all-gathered once per epoch
+    rng = np.random.default_rng(100 + rank)
+    nb, B = 3, 64
+    data = (rng.standard_normal((nb, B)) * (rank + 1) + rank).astype(np.float32)
+    rec = np.stack([np.full(nb, float(B)), data.mean(1, dtype=np.float64),
+                    ((data - data.mean(1, keepdims=True, dtype=np.float64)) ** 2).sum(1)], axis=1)
+    allr = mpi_utils.allgather_records(torch.tensor(rec.reshape(-1))).view(world, nb, 3)
+    res["records"] = allr.permute(1, 0, 2).contiguous()       # [nb, R, 3] as K12 reads them
+    res["data"] = torch.tensor(data)
+    # 4. packed scalar reductions (ppo.py:2471-2475, 1991-2094)
+    res["sum"] = mpi_utils.allreduce_scalars([1.0, rank, 2.5], "sum")
+    res["max"] = mpi_utils.allreduce_scalars([rank, -rank], "max")
+    res["min"] = mpi_utils.allreduce_scalars([rank, -rank], "min")
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def two_ranks():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    return [out[r] for r in range(world)]
+
+
+def test_broadcast_and_gradient_average(two_ranks):
+    r0, r1 = two_ranks
+    assert torch.equal(r0["bcast"], torch.full((1000,), 1.0)) and torch.equal(r1["bcast"], r0["bcast"])
+    exp = torch.arange(8, dtype=torch.float32) * 1.5          # (1x + 2x) / 2
+    assert torch.equal(r0["grad_avg"], exp) and torch.equal(r1["grad_avg"], exp)
+    assert r0["avg_scalar"] == 0.5 and r1["avg_scalar"] == 0.5
+    assert torch.equal(r0["avg_tensor"], torch.tensor([1.5, 3.0]))
+
+
+def test_moment_records_equal_raw_data_allgather(two_ranks):
+    """Merging the gathered records == the reference's allgather of raw data + np.mean / np.var."""
+    r0, r1 = two_ranks
+    assert torch.equal(r0["records"], r1["records"])           # every rank integrates the same records
+    recs = r0["records"].numpy()
+    ref = RunningMeanStd()
+    mine_mean, mine_var, mine_count = np.float32(0.0), np.float32(1.0), 1e-4
+    for k in range(recs.shape[0]):
+        parts = [r0["data"][k].numpy(), r1["data"][k].numpy()]
+        ref.update(None, gathered=parts)                       # stats.py:47-54 on the concatenation
+        n, m, M2 = _chan_merge(recs[k])
+        tmp = RunningMeanStd()
+        tmp.mean, tmp.variance, tmp.count = mine_mean, mine_var, mine_count
+        tmp.integrate(np.float32(m), np.float32(M2 / n), n)    # stats.py:73-94
+        mine_mean, mine_var, mine_count = tmp.mean, tmp.variance, tmp.count
+    np.testing.assert_allclose(mine_mean, ref.mean, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(mine_var, ref.variance, rtol=2e-6, atol=1e-7)
+    assert mine_count == ref.count
+
+
+def test_packed_scalar_reductions(two_ranks):
+    r0, r1 = two_ranks
+    assert r0["sum"] == [2.0, 1.0, 5.0] == r1["sum"]
+    assert r0["max"] == [1.0, 0.0] and r0["min"] == [0.0, -1.0]

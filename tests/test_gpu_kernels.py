@@ -161,6 +161,32 @@ def test_gae_tmajor_golden_g2(K, golden, tag):
     np.testing.assert_allclose(adv.cpu().numpy()[ft, fe], d["adv"], rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("T,E,dense", [(9, (1 << 17) + 3, True), (20, 1 << 17, False),
+                                        (6, 1 << 20, True), (11, (1 << 20) + 4, False), (3, (1 << 20) + 2, True)])
+def test_gae_tmajor_streaming_kernels(K, T, E, dense):
+    """Large-E launch paths (lane-per-column and 4-columns-per-lane streaming) against the C oracle."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(E % 1000 + T)
+    rew = rng.uniform(-1, 1, (T, E)).astype(np.float32)
+    val = rng.standard_normal((T, E)).astype(np.float32)
+    if dense:
+        bv = (rng.standard_normal((T, E)) * 2).astype(np.float32)
+        br = (rng.standard_normal((T, E)) * 90).astype(np.float32)
+        u = rng.uniform(0, 1, (T, E))
+        ek = np.where(u < 0.1, 1, np.where(u < 0.2, 2, 0)).astype(np.int8)
+        ek[-1] = np.where(ek[-1] == 0, 2, ek[-1])
+        adv, rtg = K.gae_rtg_tmajor(dev(rew), dev(val), dev(bv), dev(br), dev(ek))
+    else:
+        boot = (rng.standard_normal(E) * 2).astype(np.float32)
+        bv = np.zeros((T, E), dtype=np.float32); bv[-1] = boot
+        br = bv
+        ek = np.zeros((T, E), dtype=np.int8); ek[-1] = 2
+        adv, rtg = K.gae_rtg_tmajor(dev(rew), dev(val), dev(boot), dev(boot), None)
+    a_ref, r_ref = c_oracle.gae_rtg_tmajor(rew, val, bv, br, ek)
+    np.testing.assert_allclose(adv.cpu().numpy(), a_ref, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(rtg.cpu().numpy(), r_ref, rtol=RTOL, atol=ATOL)
+
+
 def test_gae_tmajor_full_size_properties(K):
     """C2 size (E=4096, T=128): linearity in (rewards, bootstrap) and the closed form for constant inputs."""
     T, E = 128, 4096

@@ -129,3 +129,28 @@ def test_g4_running_mean_std(golden):
         np.testing.assert_array_equal(np.asarray(rv.mean, dtype=np.float64), g[f"v_mean{i}"])
         np.testing.assert_array_equal(np.asarray(rv.variance, dtype=np.float64), g[f"v_var{i}"])
         assert rv.count == g[f"v_count{i}"][0]
+
+
+def test_c_oracle_matches_golden_g1(golden):
+    """oracle/gae_oracle.c (plain C) bit-exact against the reference's end_episode outputs."""
+    from oracle import c_oracle
+    g = golden("g1_end_episode")
+    for c, k, adv, rtg_np2, rtg_f64 in _g1_cases(g):
+        a, r = c_oracle.gae_rtg_episode(k["rewards"], k["values"], k["ev"], k["er"], k["gamma"],
+                                        k["lambd"], k["clip"], k["use_gae"])
+        np.testing.assert_array_equal(r, rtg_f64, err_msg=f"case {c} rtg")
+        if k["use_gae"]:
+            np.testing.assert_array_equal(a, adv, err_msg=f"case {c} adv")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_c_oracle_tmajor_matches_numpy_oracle(golden, tag):
+    from oracle import c_oracle
+    g = golden("g2_dataset")
+    pre = tag + "_"
+    rew = g[pre + "in_rewards"].astype(np.float32)
+    val, boot, ek = g[pre + "in_values"], g[pre + "in_boot_v"], g[pre + "in_end_kind"]
+    adv, rtg = c_oracle.gae_rtg_tmajor(rew, val, boot, boot, ek)
+    d = eo.rollout_to_dataset(rew, val, boot, boot, ek)
+    np.testing.assert_array_equal(adv[d["flat_t"], d["flat_e"]], d["adv"])
+    np.testing.assert_array_equal(rtg[d["flat_t"], d["flat_e"]], d["rtg"])
