@@ -34,6 +34,33 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achi
 GAE_BYTES_PER_TRANSITION = 16  # read r, V; write adv, rtg
 
 
+def pmc_traffic():
+    """
+    HBM bytes per launch of the GAE kernels from the committed PMC passes (profiles/*_gae_pmc.csv,
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; KB units).  Corrections per
+    MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide (16 B/lane) coalesced read on gfx950
+    -> doubled for the streaming kernel; the chunked kernel reads 4 B/lane in 64-B segments
+    -> taken as is; WRITE_SIZE is exact.  Counters cannot be collected inside a timed run, so
+    these are the profiled values of the same kernels at the same sizes, not of this very run.
+    """
+    import glob, re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gae_pmc.csv")))
+    if not files:
+        return {}
+    vals = {}
+    for line in open(files[-1]):
+        m = re.match(r"^(.*),(FETCH_SIZE|WRITE_SIZE),dispatches=\d+,avg=([0-9.]+)", line)
+        if m:
+            vals[(m.group(1), m.group(2))] = float(m.group(3))
+    out = {}
+    for name, mult in (("ppoaf::gae_rtg_chunked_kernel", 1.0), ("void ppoaf::gae_rtg_stream_kernel<4, 8>", 2.0)):
+        f, w = vals.get((name, "FETCH_SIZE")), vals.get((name, "WRITE_SIZE"))
+        if f is not None and w is not None:
+            out[name] = int((mult * f + w) * 1024)
+    out["_source"] = os.path.relpath(files[-1], ROOT)
+    return out
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -121,9 +148,11 @@ def main():
     gae_avg_s = (sum(gae_ms) / max(len(gae_ms), 1)) * 1e-3
     gae_bytes = GAE_BYTES_PER_TRANSITION * E * T
     achieved = gae_bytes / gae_avg_s / 1e9 if gae_avg_s > 0 else 0.0
+    pmc = pmc_traffic() if (E, T) == (4096, 128) else {}
     roofline = {"kernel": "gae_rtg_chunked_kernel" if E < (1 << 17) else "gae_rtg_stream_kernel", "bound": "hbm", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None, "bytes_per_launch": gae_bytes,
+                "traffic": pmc.get("ppoaf::gae_rtg_chunked_kernel"), "traffic_source": pmc.get("_source"),
+                "bytes_per_launch": gae_bytes,
                 "avg_launch_us": round(gae_avg_s * 1e6, 3), "launches": len(gae_ms),
                 "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on the launch stream, timed region",
                 "note": "config size (8.4 MB, fits L2/MALL) is latency-bound; see roofline_saturating"}
@@ -160,7 +189,8 @@ def main():
                                       "transitions": T * Es, "achieved": round(bts / s / 1e9, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(bts / s / 1e9 / HBM_PEAK_GBS, 4),
-                                      "avg_launch_us": round(s * 1e6, 1), "traffic": None}
+                                      "avg_launch_us": round(s * 1e6, 1),
+                                      "traffic": pmc_traffic().get("void ppoaf::gae_rtg_stream_kernel<4, 8>")}
         del r, v, b, adv, rtg
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
