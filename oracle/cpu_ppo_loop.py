@@ -240,6 +240,65 @@ class CpuPPO:
                 "weighted entropy": tot["entropy"] * self.entropy_weight / n, "kl avg": tot["kl"] / n}
 
 
+def ddppo_train_epoch(ranks):
+    """
+    One epoch of the reference's DD-PPO over R in-process "ranks" (list of CpuPPO with identical
+    weights, each with its own dataset and shuffle generator): per mini-batch every rank normalises
+    its rewards-to-go with stats updated from the data of ALL ranks (utils/stats.py:47-54), computes
+    its losses and gradients, the gradients are averaged tensor by tensor (utils/mpi_utils.py:89-111)
+    and every rank takes the same clip + Adam step (policies/ppo_policy.py:1032-1055).
+    Returns the rank-averaged epoch statistics (ppo.py:2471-2485).
+    """
+    R = len(ranks)
+    loaders = [iter(DataLoader(r.dataset, batch_size=r.batch_size, shuffle=True, generator=r.loader_generator))
+               for r in ranks]
+    tot = dict(actor=0.0, critic=0.0, entropy=0.0, kl=0.0, n=0)
+    while True:
+        batches = []
+        for it in loaders:          # every rank's loader is driven to exhaustion (each draws from its own RNG)
+            try:
+                batches.append(next(it))
+            except StopIteration:
+                pass
+        if len(batches) < R:
+            break
+        gathered = [b[7].flatten().numpy() for b in batches]          # rewards_to_go of every rank
+        outs = []
+        for r, batch in zip(ranks, batches):
+            critic_obs, obs, _, raw_actions, _, advantages, log_probs, rewards_tg, _, _, _, _, idxs = batch
+            if r.normalize_values:
+                r.value_stats.update(None, gathered=gathered)
+                mean = torch.tensor(r.value_stats.mean, dtype=torch.float32)
+                var = torch.tensor(r.value_stats.variance, dtype=torch.float32)
+                rewards_tg = (rewards_tg - mean) / torch.sqrt(var + torch.tensor([1e-8]))
+            values = r.critic(critic_obs).squeeze()
+            dist = Categorical(torch.softmax(r.actor(obs), dim=-1))
+            cur_lp = torch.unsqueeze(dist.log_prob(raw_actions.flatten()), dim=-1)
+            r.dataset.values[idxs] = values.detach()
+            o = lo.ppo_minibatch_losses(cur_lp, log_probs, advantages, dist.entropy(), values, rewards_tg,
+                                        r.normalize_adv, r.surr_clip, r.entropy_weight)
+            r.actor_optim.zero_grad(); r.critic_optim.zero_grad()
+            o["actor_loss"].backward(); o["critic_loss"].backward()
+            outs.append(o)
+        for nets in (lambda r: r.actor, lambda r: r.critic):
+            for ps in zip(*[list(nets(r).parameters()) for r in ranks]):
+                avg = sum(p.grad for p in ps) / R
+                for p in ps:
+                    p.grad = avg.clone()
+        for r in ranks:
+            nn.utils.clip_grad_norm_(r.actor.parameters(), r.gradient_clip)
+            r.actor_optim.step()
+            nn.utils.clip_grad_norm_(r.critic.parameters(), r.gradient_clip)
+            r.critic_optim.step()
+        for o in outs:
+            tot["actor"] += o["surr"]; tot["critic"] += o["critic"]
+            tot["entropy"] += o["entropy"]; tot["kl"] += o["kl"]; tot["n"] += 1
+    n = max(tot["n"], 1)
+    ew = ranks[0].entropy_weight
+    return {"actor loss": tot["actor"] / n, "critic loss": tot["critic"] / n,
+            "weighted entropy": tot["entropy"] * ew / n, "kl avg": tot["kl"] / n}
+
+
 def time_iteration(E, T, obs_dim=4, n_actions=2, epochs=10, batch_size=256, seed=1234, threads=None):
     """cpu_baseline leg: one PPO iteration (rollout + GAE/build + `epochs` epochs) -> env-steps/s."""
     if threads is not None:

@@ -70,10 +70,21 @@ def set_torch_threads():
     torch.set_num_threads(max(int(torch.get_num_threads() / get_num_procs()), 1))
 
 
+def _needs_staging(t):
+    """gloo has no device collectives in this build: device tensors go through a host copy
+    (used by the 2-ranks-on-one-GPU test of the N>1 control flow; RCCL runs take the direct path)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def broadcast_flat(flat, root=0):
     """One broadcast of a flat parameter bucket from `root`."""
     if get_num_procs() > 1:
-        dist.broadcast(flat, src=root)
+        if _needs_staging(flat):
+            h = flat.cpu()
+            dist.broadcast(h, src=root)
+            flat.copy_(h)
+        else:
+            dist.broadcast(flat, src=root)
     return flat
 
 
@@ -96,7 +107,12 @@ def broadcast_model_parameters(model):
 def allreduce_sum_(t):
     """In-place SUM all-reduce (identity on one rank)."""
     if get_num_procs() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if _needs_staging(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
@@ -145,6 +161,11 @@ def allgather_records(rec):
     n = get_num_procs()
     if n == 1:
         return rec.reshape(1, -1)
+    if _needs_staging(rec):
+        h = rec.reshape(1, -1).cpu().contiguous()
+        out = torch.empty(n, rec.numel(), dtype=rec.dtype)
+        dist.all_gather_into_tensor(out, h)
+        return out.to(rec.device)
     out = torch.empty(n, rec.numel(), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, rec.reshape(1, -1).contiguous())
     return out

@@ -1,0 +1,116 @@
+"""
+-m gpu: the N>1 DD-PPO control flow on real kernels.  Two processes share the one GPU of the box
+(collectives over gloo, staged through the host -- RCCL refuses two ranks on one device); each rank has
+its own envs / seeds, exactly as under torchrun.  Checked against the reference's DD-PPO semantics
+restated on the CPU (oracle/cpu_ppo_loop.ddppo_train_epoch): moment records of every rank feed every
+rank's value normaliser, gradients are averaged per mini-batch, all ranks stay weight-identical.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+E, T, B, O, NA, SEED = 12, 16, 32, 4, 2, 11
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _rank(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from ppo_and_friends_amd.utils import mpi_utils
+    mpi_utils.init_process_group_from_env(backend="gloo")
+    from ppo_and_friends_amd.ppo import PPO, PermutationLoader
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    dev = torch.device("cuda", 0)
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=500, rank=rank)
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    ppo = PPO(env_gen, {"p": (None, sp, sp, Discrete(NA), {})}, device=dev, random_seed=SEED,
+              envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=2, update_mode="fused")
+    pol = ppo.policies["p"]
+    w0 = pol.policy_params.detach().cpu().clone()           # after the rank-0 broadcast
+    ppo.rollout()
+    loader = PermutationLoader(pol.dataset, B, ppo.loader_generator)
+    pol.train()
+    stats = []
+    for _ in range(2):
+        ppo._ppo_batch_train(loader, "p")
+        stats.append(dict(ppo.status_dict["p"]))
+    vs = ppo.value_normalizers["p"].running_stats
+    out[rank] = dict(w0=w0, w=pol.policy_params.detach().cpu().clone(),
+                     actor_sd={k: v.detach().cpu().clone() for k, v in pol.actor.state_dict().items()},
+                     critic_sd={k: v.detach().cpu().clone() for k, v in pol.critic.state_dict().items()},
+                     obs=ppo.env.obs_table.cpu().numpy(), rew=ppo.env.reward_table.cpu().numpy(),
+                     actions=pol.buffer.actions[..., 0].cpu().numpy(),
+                     stats=[{k: float(v) for k, v in s.items() if not torch.is_tensor(v)} for s in stats],
+                     vn=np.array([vs.mean, vs.variance, vs.count], dtype=np.float64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def run2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank, args=(world, _free_port(), out), nprocs=world, join=True)
+    return [out[r] for r in range(world)]
+
+
+def test_ranks_start_and_stay_identical(run2):
+    r0, r1 = run2
+    assert torch.equal(r0["w0"], r1["w0"]), "rank-0 broadcast of the policy bucket"
+    assert torch.equal(r0["w"], r1["w"]), "synchronous DD-PPO keeps replicas identical"
+    assert r0["stats"] == r1["stats"]
+    np.testing.assert_array_equal(r0["vn"], r1["vn"])
+    assert not np.array_equal(r0["obs"], r1["obs"]), "each rank rolls out its own envs"
+
+
+def test_two_rank_update_matches_ddppo_oracle(run2):
+    from oracle import cpu_ppo_loop
+    ranks = []
+    for r, res in enumerate(run2):
+        cpu = cpu_ppo_loop.CpuPPO(O, NA, batch_size=B, seed=SEED + r)
+        # weights BEFORE training = rank 0's broadcast weights: rebuild them from w0 via rank 0's layout
+        ranks.append((cpu, res))
+    # initial weights: take them from a fresh policy bucket layout (actor then critic, padded to 4 floats)
+    w0 = run2[0]["w0"].numpy()
+
+    def load(net, keys_sd, flat, off):
+        sd = {}
+        for k, v in keys_sd.items():
+            if not k.startswith("sequential_net."):
+                continue
+            n = v.numel()
+            sd[k.replace("sequential_net.", "")] = torch.tensor(flat[off:off + n]).reshape(v.shape).clone()
+            off += (n + 3) // 4 * 4
+        net.load_state_dict(sd)
+        return off
+
+    for cpu, res in ranks:
+        off = load(cpu.actor, res["actor_sd"], w0, 0)
+        load(cpu.critic, res["critic_sd"], w0, off)
+        cpu.loader_generator = torch.Generator().manual_seed(SEED + ranks.index((cpu, res)))
+        cpu.rollout(res["obs"], res["rew"], actions=res["actions"])
+    cpus = [c for c, _ in ranks]
+    for epoch in range(2):
+        ref = cpu_ppo_loop.ddppo_train_epoch(cpus)
+        got = run2[0]["stats"][epoch]
+        for k in ("actor loss", "critic loss", "kl avg", "weighted entropy"):
+            np.testing.assert_allclose(got[k], ref[k], rtol=2e-5, atol=2e-6, err_msg=f"epoch {epoch} {k}")
+    flat_ref = np.concatenate([p.detach().reshape(-1).numpy() for p in cpus[0].actor.parameters()])
+    got_actor = np.concatenate([v.reshape(-1).numpy() for k, v in run2[0]["actor_sd"].items()])
+    np.testing.assert_allclose(got_actor, flat_ref, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(run2[0]["vn"][:2], [cpus[0].value_stats.mean, cpus[0].value_stats.variance],
+                               rtol=1e-5, atol=1e-6)
+    assert run2[0]["vn"][2] == cpus[0].value_stats.count
