@@ -356,6 +356,34 @@ int ppoaf_ppo_update_fwd_bwd(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t
 int ppoaf_ppo_update_reduce(const ppoaf_ppo_update_args_t* args, int compute_norms, ppoaf_stream_t stream);
 int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int compute_norms, ppoaf_stream_t stream);
 
+
+/* ------------------------------------------------------------------------ *
+ * K6+K7  one rollout step for all E envs of the rank in one launch
+ * replaces PPOPolicy.get_rollout_actions            policies/ppo_policy.py:729-794
+ *          PPO.get_policy_values + denormalisation  ppo.py:1030-1075, utils/misc.py:113-128
+ *          the per-env EpisodeInfo.add_info calls   policies/ppo_policy.py:638-651
+ * Actor and critic MLP forward (same tile code as the update kernel), sampling
+ * (Philox4x32-10, counter = offset + env), log-prob, value (denormalised with the
+ * running stats when normalize_values), written straight into row t of the
+ * rollout buffer.  obs / critic_obs: [E, in_dim] float32; outputs are the row-t
+ * slices of the buffer ([E,1] int64 actions for the categorical head, [E,D]
+ * float32 for the Gaussian head).  *_copy_out (optional) receive the
+ * observation rows.  Network descriptors as for K12.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    ppoaf_mlp_desc_t actor, critic;
+    const float* params;
+    const float* obs; const float* critic_obs; int64_t E;
+    int32_t head_kind; float min_std, act_lo, act_hi;
+    uint64_t seed, offset;
+    int32_t normalize_values, _pad;
+    const float* vn_mean; const float* vn_var;
+    void* raw_action_out; void* action_out; float* logp_out; float* value_out;
+    float* obs_copy_out; float* critic_obs_copy_out;
+} ppoaf_policy_step_args_t;
+
+int ppoaf_policy_step(const ppoaf_policy_step_args_t* args, ppoaf_stream_t stream);
+
 /* (n, mean, M2) float64 records of the rewards-to-go of every mini-batch of an
  * epoch: records[k] covers perm[k*B : min((k+1)*B, n_perm)]  (ppo.py:2299-2303,
  * utils/stats.py:52-54 batched).  One workgroup per mini-batch. */

@@ -57,6 +57,19 @@ class PpoUpdateArgs(C.Structure):
                 ("loss_partials", C.c_void_p), ("totals", C.c_void_p)]
 
 
+class PolicyStepArgs(C.Structure):
+    """ppoaf_policy_step_args_t (include/ppoaf_hip.h)."""
+    _fields_ = [("actor", MlpDesc), ("critic", MlpDesc), ("params", C.c_void_p),
+                ("obs", C.c_void_p), ("critic_obs", C.c_void_p), ("E", C.c_int64),
+                ("head_kind", C.c_int32), ("min_std", C.c_float), ("act_lo", C.c_float),
+                ("act_hi", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("normalize_values", C.c_int32), ("_pad", C.c_int32),
+                ("vn_mean", C.c_void_p), ("vn_var", C.c_void_p),
+                ("raw_action_out", C.c_void_p), ("action_out", C.c_void_p),
+                ("logp_out", C.c_void_p), ("value_out", C.c_void_p),
+                ("obs_copy_out", C.c_void_p), ("critic_obs_copy_out", C.c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/ppoaf_hip.h one to one.
 SIGNATURES = {
     "ppoaf_abi_version": (C.c_int, []),
@@ -101,6 +114,7 @@ SIGNATURES = {
     "ppoaf_ppo_update_fwd_bwd": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr]),
     "ppoaf_ppo_update_reduce": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
     "ppoaf_ppo_update_adam": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
+    "ppoaf_policy_step": (C.c_int, [C.POINTER(PolicyStepArgs), _ptr]),
     "ppoaf_minibatch_moments": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int64, _ptr, _ptr]),
 }
 

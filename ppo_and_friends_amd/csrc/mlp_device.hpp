@@ -1,0 +1,114 @@
+// Device building blocks shared by the fused update (ppo_update.hip) and the rollout step
+// (policy_step.hip): network descriptors, activations, f32-MFMA forward tiles.
+#pragma once
+#include "common.hpp"
+#include <cfloat>
+
+namespace ppoaf {
+
+constexpr int kRows = PPOAF_UPDATE_ROWS_PER_WG;   // 16 rows per workgroup = one MFMA M tile
+constexpr int kMaxLayers = 8;
+constexpr int kMaxOut = 16;
+constexpr int kMaxAdvLds = 4096;
+constexpr int kThreads = 256;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct NetDev {
+    int in_dim, H, depth, out_dim, act;
+    long offset, size, log_std_off;
+    long offW[kMaxLayers], offB[kMaxLayers];      // relative to this network's bucket
+};
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    if (act == PPOAF_ACT_RELU) return fmaxf(z, 0.f);
+    if (act == PPOAF_ACT_LEAKY_RELU) return z > 0.f ? z : 0.01f * z;
+    return tanhf(z);
+}
+// derivative from the POST-activation value (what autograd's backward kernels use as well)
+__device__ __forceinline__ float act_bwd(float h, int act) {
+    if (act == PPOAF_ACT_RELU) return h > 0.f ? 1.f : 0.f;
+    if (act == PPOAF_ACT_LEAKY_RELU) return h > 0.f ? 1.f : 0.01f;
+    return 1.f - h * h;
+}
+
+__device__ __forceinline__ float group16_sum(float v) {
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
+__device__ __forceinline__ float clamp_prob_u(float n) {
+    return fminf(fmaxf(n, FLT_EPSILON), 1.0f - FLT_EPSILON);
+}
+__device__ __forceinline__ float softplus_u(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// ---- MFMA building blocks (v_mfma_f32_16x16x4_f32: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
+//      C/D col = lane&15, row = 4*(lane>>4)+reg).  The k order inside a 16-chunk is permuted the
+//      same way on both operands (lane slot s carries k = 4s+j at step j), which leaves the sum intact.
+
+// B fragments of one forward tile: fr[c] = W[o][16c + 4*slot .. +3], o = n0 + (lane&15); W row-major [*, H]
+#ifdef PPOAF_STAMPS
+#define PPOAF_DBG(bit) (g_dbg & (bit))
+#else
+#define PPOAF_DBG(bit) false
+#endif
+template <int HT>
+__device__ __forceinline__ void load_fwd_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT],
+                                               int g_dbg = 0) {
+    const float* w = W + (long)(n0 + (lane & 15)) * (16 * HT) + 4 * (lane >> 4);
+    if (PPOAF_DBG(1)) {
+#pragma unroll
+        for (int c = 0; c < HT; ++c) fr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < HT; ++c) fr[c] = *reinterpret_cast<const float4*>(w + 16 * c);
+}
+// B fragments of one dgrad tile: fr[c] = { W[16c+4*slot+j][n0 + (lane&15)] }_j
+template <int HT>
+__device__ __forceinline__ void load_dgrad_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT],
+                                                 int g_dbg = 0) {
+    constexpr int H = 16 * HT;
+    const float* w = W + (long)(4 * (lane >> 4)) * H + n0 + (lane & 15);
+    if (PPOAF_DBG(1)) {
+#pragma unroll
+        for (int c = 0; c < HT; ++c) fr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < HT; ++c) {
+        const float* wp = w + (long)(16 * c) * H;
+        fr[c] = make_float4(wp[0], wp[H], wp[2 * H], wp[3 * H]);
+    }
+}
+// acc[16 rows, 16 cols] = init + A[16, H] . frags ; A rows in LDS with stride HS.  Two accumulators
+// (even / odd chunks) keep the matrix pipe issuing back to back instead of waiting on its own result.
+template <int HT>
+__device__ __forceinline__ f32x4 mfma_rows_x_frags(const float* __restrict__ A, int HS, int lane,
+                                                   const float4 (&fr)[HT], float init) {
+    const float* arow = A + (lane & 15) * HS + 4 * (lane >> 4);
+    f32x4 acc0 = {init, init, init, init};
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < HT; ++c) {
+        const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * c);
+        if (c & 1) {
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, fr[c].x, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, fr[c].y, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, fr[c].z, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, fr[c].w, acc1, 0, 0, 0);
+        } else {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, fr[c].x, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, fr[c].y, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, fr[c].z, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, fr[c].w, acc0, 0, 0, 0);
+        }
+    }
+    return acc0 + acc1;
+}
+
+// host: validate a network descriptor and fill the device view
+int fill_net(const ppoaf_mlp_desc_t& d, NetDev& n, const char* what);
+
+}  // namespace ppoaf

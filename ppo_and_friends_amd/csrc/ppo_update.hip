@@ -12,25 +12,10 @@
 // writes its weight-gradient partial to a private slab with plain coalesced stores; the slabs
 // are summed in a fixed order by the reduce kernel, so results are bitwise reproducible (float
 // atomics would not be) and nothing needs zeroing.
-#include "common.hpp"
-#include <cfloat>
+#include "mlp_device.hpp"
 #include <cstdlib>
 
 namespace ppoaf {
-
-constexpr int kRows = PPOAF_UPDATE_ROWS_PER_WG;   // 16 rows per workgroup = one MFMA M tile
-constexpr int kMaxLayers = 8;
-constexpr int kMaxOut = 16;
-constexpr int kMaxAdvLds = 4096;
-constexpr int kThreads = 256;
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct NetDev {
-    int in_dim, H, depth, out_dim, act;
-    long offset, size, log_std_off;
-    long offW[kMaxLayers], offB[kMaxLayers];      // relative to this network's bucket
-};
 
 struct UpdateDev {
     NetDev net[2];
@@ -52,29 +37,6 @@ struct UpdateDev {
     int debug;           // diagnostic build only (PPOAF_STAMPS): ablation switches
 };
 
-__device__ __forceinline__ float act_fwd(float z, int act) {
-    if (act == PPOAF_ACT_RELU) return fmaxf(z, 0.f);
-    if (act == PPOAF_ACT_LEAKY_RELU) return z > 0.f ? z : 0.01f * z;
-    return tanhf(z);
-}
-// derivative from the POST-activation value (what autograd's backward kernels use as well)
-__device__ __forceinline__ float act_bwd(float h, int act) {
-    if (act == PPOAF_ACT_RELU) return h > 0.f ? 1.f : 0.f;
-    if (act == PPOAF_ACT_LEAKY_RELU) return h > 0.f ? 1.f : 0.01f;
-    return 1.f - h * h;
-}
-
-__device__ __forceinline__ float group16_sum(float v) {
-    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-    return v;
-}
-
-__device__ __forceinline__ float clamp_prob_u(float n) {
-    return fminf(fmaxf(n, FLT_EPSILON), 1.0f - FLT_EPSILON);
-}
-__device__ __forceinline__ float softplus_u(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-
 extern __shared__ __attribute__((aligned(16))) unsigned char ppo_update_smem[];
 
 // Diagnostic build only (-DPPOAF_STAMPS): s_memtime per phase of workgroup (0, which), wave 0,
@@ -93,71 +55,6 @@ __device__ unsigned long long g_ppo_update_stamps[2][16];
 #define PPOAF_STAMP(k) do {} while (0)
 #endif
 
-// ---- MFMA building blocks (v_mfma_f32_16x16x4_f32: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
-//      C/D col = lane&15, row = 4*(lane>>4)+reg).  The k order inside a 16-chunk is permuted the
-//      same way on both operands (lane slot s carries k = 4s+j at step j), which leaves the sum intact.
-
-// B fragments of one forward tile: fr[c] = W[o][16c + 4*slot .. +3], o = n0 + (lane&15); W row-major [*, H]
-#ifdef PPOAF_STAMPS
-#define PPOAF_DBG(bit) (g_dbg & (bit))
-__device__ int g_dbg_unused;
-#else
-#define PPOAF_DBG(bit) false
-#endif
-template <int HT>
-__device__ __forceinline__ void load_fwd_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT],
-                                               int g_dbg = 0) {
-    const float* w = W + (long)(n0 + (lane & 15)) * (16 * HT) + 4 * (lane >> 4);
-    if (PPOAF_DBG(1)) {
-#pragma unroll
-        for (int c = 0; c < HT; ++c) fr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-#pragma unroll
-    for (int c = 0; c < HT; ++c) fr[c] = *reinterpret_cast<const float4*>(w + 16 * c);
-}
-// B fragments of one dgrad tile: fr[c] = { W[16c+4*slot+j][n0 + (lane&15)] }_j
-template <int HT>
-__device__ __forceinline__ void load_dgrad_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT],
-                                                 int g_dbg = 0) {
-    constexpr int H = 16 * HT;
-    const float* w = W + (long)(4 * (lane >> 4)) * H + n0 + (lane & 15);
-    if (PPOAF_DBG(1)) {
-#pragma unroll
-        for (int c = 0; c < HT; ++c) fr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-#pragma unroll
-    for (int c = 0; c < HT; ++c) {
-        const float* wp = w + (long)(16 * c) * H;
-        fr[c] = make_float4(wp[0], wp[H], wp[2 * H], wp[3 * H]);
-    }
-}
-// acc[16 rows, 16 cols] = init + A[16, H] . frags ; A rows in LDS with stride HS.  Two accumulators
-// (even / odd chunks) keep the matrix pipe issuing back to back instead of waiting on its own result.
-template <int HT>
-__device__ __forceinline__ f32x4 mfma_rows_x_frags(const float* __restrict__ A, int HS, int lane,
-                                                   const float4 (&fr)[HT], float init) {
-    const float* arow = A + (lane & 15) * HS + 4 * (lane >> 4);
-    f32x4 acc0 = {init, init, init, init};
-    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < HT; ++c) {
-        const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * c);
-        if (c & 1) {
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, fr[c].x, acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, fr[c].y, acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, fr[c].z, acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, fr[c].w, acc1, 0, 0, 0);
-        } else {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, fr[c].x, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, fr[c].y, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, fr[c].z, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, fr[c].w, acc0, 0, 0, 0);
-        }
-    }
-    return acc0 + acc1;
-}
 // Weight gradient of one 16-row block of outputs: dW[m0+.., i] = sum_s D[s][m0+..] * Bsrc[s][i] for
 // i < n_valid (n tiles of 16 columns), K = the 16 rows of the workgroup.  Both operands come from LDS.
 __device__ __forceinline__ void wgrad_mtile(const float* __restrict__ D, int HS, const float* __restrict__ Bsrc,
@@ -802,7 +699,7 @@ __global__ __launch_bounds__(256) void minibatch_moments_kernel(const float* __r
     if (threadIdx.x == 0) { records[k * 3] = (double)n; records[k * 3 + 1] = mean; records[k * 3 + 2] = q; }
 }
 
-static int fill_net(const ppoaf_mlp_desc_t& d, NetDev& n, const char* what) {
+int fill_net(const ppoaf_mlp_desc_t& d, NetDev& n, const char* what) {
     PPOAF_REQUIRE(d.hidden >= 16 && d.hidden <= 256 && d.hidden % 16 == 0,
                   "%s: hidden=%d must be a multiple of 16 in [16,256]", what, d.hidden);
     PPOAF_REQUIRE(d.depth >= 1 && d.depth + 1 <= kMaxLayers, "%s: depth=%d out of [1,%d]", what, d.depth, kMaxLayers - 1);

@@ -363,3 +363,7 @@ def ppo_update_reduce(args, compute_norms):
 def ppo_update_adam(args, compute_norms):
     check(_lib.load().ppoaf_ppo_update_adam(C.byref(args), int(compute_norms), stream()),
           "ppo_update_adam")
+
+
+def policy_step(args):
+    check(_lib.load().ppoaf_policy_step(C.byref(args), stream()), "policy_step")

@@ -295,6 +295,68 @@ class PPOPolicy:
             return raw_action.cpu().numpy(), action.cpu().numpy(), log_prob.detach()
         return raw_action, action, log_prob
 
+    def fused_step_unsupported_reason(self):
+        """'' when the K6+K7 rollout-step kernel covers this policy (same coverage as the fused update)."""
+        from ..fused_update import FusedPolicyUpdate
+        if len(self.agent_ids) != 1:
+            return "more than one agent shares this policy"
+        return FusedPolicyUpdate.unsupported_reason(self, 2)
+
+    def rollout_step(self, t, obs, critic_obs, value_normalizer=None):
+        """
+        One env step of get_rollout_actions + get_critic_values (+ denormalisation) +
+        add_episode_info's action/value/log-prob/observation writes, as ONE launch that
+        stores straight into row t of the rollout buffer.  Returns the action row (a
+        view of the buffer) for env.step; rewards / next observations are added by
+        `finish_step` once the environment has answered.
+        """
+        from .. import _lib
+        from ..fused_update import _describe
+        from ..networks.distributions import GaussianDistribution
+        buf = self.buffer
+        E = self.env_batch_size
+        a = getattr(self, "_step_args", None)
+        if a is None:
+            a = _lib.PolicyStepArgs()
+            gauss = isinstance(self.actor.distribution, GaussianDistribution)
+            a.actor, _ = _describe(self.actor, self.policy_params, gauss)
+            a.critic, _ = _describe(self.critic, self.policy_params, False)
+            a.params = self.policy_params.data_ptr()
+            a.E = E
+            a.head_kind = K.HEAD_GAUSSIAN if gauss else K.HEAD_CATEGORICAL
+            a.min_std = float(getattr(self.actor.distribution, "min_std", 0.01))
+            a.act_lo = float(getattr(self.actor.distribution, "dist_min", -1.0))
+            a.act_hi = float(getattr(self.actor.distribution, "dist_max", 1.0))
+            self._step_args = a
+        K._req(obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.numel() == E * a.actor.in_dim,
+               "rollout_step: obs must be a contiguous float32 device tensor [E, obs_dim]")
+        K._req(critic_obs.is_cuda and critic_obs.dtype == torch.float32 and critic_obs.is_contiguous()
+               and critic_obs.numel() == E * a.critic.in_dim,
+               "rollout_step: critic_obs must be a contiguous float32 device tensor [E, critic_obs_dim]")
+        a.obs = obs.data_ptr(); a.critic_obs = critic_obs.data_ptr()
+        a.seed, a.offset = self.actor.distribution.rng.take(E)
+        if value_normalizer is not None:
+            a.normalize_values = 1
+            a.vn_mean = value_normalizer.running_stats.mean_t.data_ptr()
+            a.vn_var = value_normalizer.running_stats.var_t.data_ptr()
+        else:
+            a.normalize_values = 0
+        a.raw_action_out = buf.raw_actions[t].data_ptr(); a.action_out = buf.actions[t].data_ptr()
+        a.logp_out = buf.log_probs[t].data_ptr(); a.value_out = buf.values[t].data_ptr()
+        a.obs_copy_out = buf.observations[t].data_ptr()
+        a.critic_obs_copy_out = buf.critic_observations[t].data_ptr()
+        K.policy_step(a)
+        return buf.actions[t]
+
+    def finish_step(self, t, rewards, next_obs=None):
+        """The environment's answer for step t: rewards (and next observations when ICM keeps them)."""
+        buf = self.buffer
+        buf.rewards[t].copy_(rewards.reshape(-1))
+        if buf.next_observations is not None and next_obs is not None:
+            buf.next_observations[t].copy_(next_obs.reshape(buf.next_observations[t].shape))
+        buf.steps_written = max(buf.steps_written, t + 1)
+        self._t = t + 1
+
     def get_inference_actions(self, obs, deterministic):
         t_obs = self._to_device(obs)
         with torch.no_grad():

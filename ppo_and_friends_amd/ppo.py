@@ -195,16 +195,26 @@ class PPO:
         score_sum = torch.zeros((), dtype=torch.float64, device=self.device)
         n_term = torch.zeros((), dtype=torch.int64, device=self.device)
         may_end_early = getattr(env, "term_table", True) is not None or self.max_ts_per_ep < T
+        fused_step = (self.update_mode != "torch" and self.device.type == "cuda"
+                      and pol.fused_step_unsupported_reason() == "")
+        vn = self.value_normalizers[policy_id] if self.normalize_values else None
         for t in range(T):
-            raw_action, action, log_prob = pol.get_rollout_actions(obs)
-            value = self.get_policy_values(policy_id, critic_obs)
-            nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(action)
-            if self.ext_reward_weight != 1.0:
-                reward = reward * self.ext_reward_weight
-            buf.write_step(t, slice(0, E), critic_obs, obs, term_obs, raw_action, action, value,
-                           log_prob, reward)
-            pol._t = t + 1
-            score_sum += reward.sum()
+            if fused_step:
+                # K6+K7: inference, sampling, log-probs, values and the buffer row in one launch
+                action = pol.rollout_step(t, obs.contiguous(), critic_obs.contiguous(), vn)
+                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(action)
+                if self.ext_reward_weight != 1.0:
+                    reward = reward * self.ext_reward_weight
+                pol.finish_step(t, reward, term_obs)
+            else:
+                raw_action, action, log_prob = pol.get_rollout_actions(obs)
+                value = self.get_policy_values(policy_id, critic_obs)
+                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(action)
+                if self.ext_reward_weight != 1.0:
+                    reward = reward * self.ext_reward_weight
+                buf.write_step(t, slice(0, E), critic_obs, obs, term_obs, raw_action, action, value,
+                               log_prob, reward)
+                pol._t = t + 1
             if may_end_early:
                 ep_ts += 1
                 n_term += terminated.sum()
@@ -228,6 +238,7 @@ class PPO:
             buf.boot_value[T - 1].copy_(next_value)
             buf.boot_reward[T - 1].copy_(next_value)
         self._obs = (obs, critic_obs)
+        score_sum = buf.rewards.sum(dtype=torch.float64)
         pol.finalize_dataset()
         gs = self.status_dict["global status"]
         gs["timesteps"] += self.ts_per_rollout * mpi_utils.get_num_procs()

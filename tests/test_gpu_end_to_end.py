@@ -188,3 +188,33 @@ def test_fused_update_equals_torch_update(cfg):
     np.testing.assert_allclose(w0, w1, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(v0, v1, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(val0, val1, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind,n,O,hidden", [("d", 2, 4, 128), ("d", 5, 18, 64), ("c", 6, 17, 128), ("c", 1, 3, 32)])
+def test_fused_rollout_step_equals_torch_rollout(kind, n, O, hidden):
+    """K6+K7 (one launch per env step) against the torch-ROCm forward + K6 sampling path: same Philox
+    counters -> same actions; log-probs / values / observation rows agree; then both against the oracle
+    through the dataset test above."""
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    space = Discrete(n) if kind == "d" else Box(-2.0, 3.0, (n,), np.float32)
+    kw = dict(hidden_size=hidden, hidden_depth=3 if hidden != 32 else 1)
+    pargs = dict(actor_kw_args=kw, critic_kw_args=dict(kw))
+    bufs = []
+    for mode in ("fused", "torch"):
+        ppo = _make(20, 12, 32, 1, update_mode=mode, O=O, act_space=space, policy_args=pargs)
+        ppo.rollout()
+        b = ppo.policies["p"].buffer
+        bufs.append({k: getattr(b, k).detach().cpu().numpy().copy() for k in
+                     ("observations", "critic_observations", "actions", "raw_actions", "values", "log_probs",
+                      "rewards", "advantages", "rewards_to_go")})
+    f, t = bufs
+    np.testing.assert_array_equal(f["observations"], t["observations"])
+    np.testing.assert_array_equal(f["rewards"], t["rewards"])
+    if kind == "d":
+        np.testing.assert_array_equal(f["actions"], t["actions"])
+    else:
+        np.testing.assert_allclose(f["raw_actions"], t["raw_actions"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(f["actions"], t["actions"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(f["log_probs"], t["log_probs"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(f["values"], t["values"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(f["advantages"], t["advantages"], rtol=1e-4, atol=1e-4)
