@@ -116,10 +116,12 @@ class CpuPPO:
     def __init__(self, obs_dim, n_actions, hidden=128, depth=3, lr=3e-4, gamma=0.99, lambd=0.95,
                  bootstrap_clip=(-100.0, 100.0), surr_clip=0.2, entropy_weight=0.01,
                  gradient_clip=0.5, batch_size=256, normalize_adv=True, normalize_values=True,
-                 seed=0, rtg_accum="float64"):
+                 seed=0, rtg_accum="float64", critic_obs_dim=None, critic_hidden=None):
         torch.manual_seed(seed)
+        critic_obs_dim = obs_dim if critic_obs_dim is None else critic_obs_dim
+        critic_hidden = hidden if critic_hidden is None else critic_hidden
         self.actor = make_mlp(obs_dim, n_actions, hidden, depth, out_gain=0.01)     # ppo_policy.py:433-439
-        self.critic = make_mlp(obs_dim, 1, hidden, depth, out_gain=1.0)             # :441-446
+        self.critic = make_mlp(critic_obs_dim, 1, critic_hidden, depth, out_gain=1.0)   # :441-446
         self.actor_optim = torch.optim.Adam(self.actor.parameters(), lr=lr, eps=1e-5)
         self.critic_optim = torch.optim.Adam(self.critic.parameters(), lr=lr, eps=1e-5)
         self.gamma, self.lambd, self.clip = gamma, lambd, bootstrap_clip
@@ -148,7 +150,8 @@ class CpuPPO:
         return self._denorm(v) if self.normalize_values else v
 
     # ----- rollout (ppo.py:1646-1983) on pre-generated observation / reward tables
-    def rollout(self, obs_table, reward_table, actions=None, term_table=None, max_ts_per_ep=None):
+    def rollout(self, obs_table, reward_table, actions=None, term_table=None, max_ts_per_ep=None,
+                critic_obs_table=None):
         """
         obs_table [T+1,E,O], reward_table [T,E] numpy.  actions (optional [T,E])
         replays a recorded rollout instead of sampling.  term_table (optional bool
@@ -158,6 +161,8 @@ class CpuPPO:
         Episodes enter the dataset in completion order.
         """
         T, E = reward_table.shape
+        if critic_obs_table is None:
+            critic_obs_table = obs_table          # single agent: the critic sees the actor's observation
         new_ep = lambda: _Episode(self.gamma, self.lambd, self.clip)
         episodes = [new_ep() for _ in range(E)]
         finished = []
@@ -175,12 +180,13 @@ class CpuPPO:
                 a = torch.as_tensor(actions[t], dtype=torch.long)
             log_prob = torch.unsqueeze(dist.log_prob(a), dim=-1)
             a_np = a.unsqueeze(-1).numpy()
-            value = self.values_of(t_obs).unsqueeze(-1)
+            cobs = critic_obs_table[t]
+            value = self.values_of(torch.tensor(cobs, dtype=torch.float32)).unsqueeze(-1)
             nxt = obs_table[t + 1]
             rew = reward_table[t].reshape(E, 1).astype(np.float64)
             for e in range(E):                         # ppo_policy.py:638-651
                 episodes[e].add_info(
-                    critic_observation=obs[e], observation=obs[e], next_observation=nxt[e],
+                    critic_observation=cobs[e], observation=obs[e], next_observation=nxt[e],
                     raw_action=a_np[e], action=a_np[e], value=value[e].item(),
                     log_prob=log_prob[e], reward=rew[e].item())
             where_term = np.where(term_table[t])[0] if term_table is not None else np.array([], dtype=np.int64)
@@ -197,7 +203,7 @@ class CpuPPO:
                 where_maxed = np.array([], dtype=np.int64)
             where_maxed = np.setdiff1d(where_maxed, where_term)
             if where_maxed.size > 0:
-                next_value = self.values_of(torch.tensor(nxt, dtype=torch.float32))
+                next_value = self.values_of(torch.tensor(critic_obs_table[t + 1], dtype=torch.float32))
                 for e in where_maxed:                  # ppo.py:1932-1938 (each env its own value: quirk Q1 fixed)
                     episodes[e].end_episode(next_value[e].item(), next_value[e].item(), self.rtg_accum)
                     finished.append(episodes[e])

@@ -22,29 +22,48 @@ from ..spaces import Box, Discrete
 
 
 class SyntheticFixedLengthEnv:
+    """
+    num_agents > 1 gives the multi-agent shape of the MAPPO configs: every env
+    holds A agents that share one policy; rows are agent-major columns c = a * E + e (the order the
+    reference logs agents in, ppo.py:1730-1752); critic_view = "policy" feeds the critic the
+    concatenated observations of all agents of the env (O_c = A * O), "local" the agent's own.
+    All agents of an env terminate together (the reference death-masks, ppo.py:1686-1691).
+    """
 
     def __init__(self, num_envs, obs_dim, action_space, horizon, device, reward="ones",
-                 seed=1234, rank=0, term_prob=0.0):
+                 seed=1234, rank=0, term_prob=0.0, num_agents=1, critic_view="local"):
         self.num_envs = int(num_envs)
+        self.num_agents = int(num_agents)
+        self.agent_ids = [f"agent{a}" for a in range(self.num_agents)]
         self.obs_dim = int(obs_dim)
         self.horizon = int(horizon)
         self.device = torch.device(device)
-        self.observation_space = Box(-np.inf, np.inf, (obs_dim,), np.float32)
+        A, E, O = self.num_agents, self.num_envs, self.obs_dim
+        self.critic_obs_dim = O * A if (critic_view == "policy" and A > 1) else O
+        self.observation_space = Box(-np.inf, np.inf, (O,), np.float32)
+        self.critic_observation_space = Box(-np.inf, np.inf, (self.critic_obs_dim,), np.float32)
         self.action_space = action_space
         rng = np.random.default_rng(seed + rank)                       # SURVEY.md §8(d)
-        obs = rng.standard_normal((horizon + 1, num_envs, obs_dim), dtype=np.float32)
+        obs = rng.standard_normal((horizon + 1, A * E, O), dtype=np.float32)
         self.obs_table = torch.from_numpy(obs).to(self.device)
-        if reward == "ones":
-            rew = np.ones((horizon, num_envs), dtype=np.float32)        # CartPole: +1 per step
+        if self.critic_obs_dim != O:
+            # [T+1, A, E, O] -> per env the agents' observations side by side, repeated for every agent
+            v = self.obs_table.view(horizon + 1, A, E, O).permute(0, 2, 1, 3).reshape(horizon + 1, 1, E, A * O)
+            self.critic_obs_table = v.expand(horizon + 1, A, E, A * O).reshape(horizon + 1, A * E, A * O).contiguous()
         else:
-            rew = rng.uniform(-1.0, 1.0, (horizon, num_envs)).astype(np.float32)
+            self.critic_obs_table = self.obs_table
+        if reward == "ones":
+            rew = np.ones((horizon, A * E), dtype=np.float32)           # CartPole: +1 per step
+        else:
+            rew = rng.uniform(-1.0, 1.0, (horizon, A * E)).astype(np.float32)
         self.reward_table = torch.from_numpy(rew).to(self.device)
         self.term_prob = float(term_prob)
         if term_prob > 0.0:                                             # correctness-only variant
-            self.term_table = torch.from_numpy(rng.uniform(0, 1, (horizon, num_envs)) < term_prob).to(self.device)
+            term_env = rng.uniform(0, 1, (horizon, E)) < term_prob
+            self.term_table = torch.from_numpy(np.tile(term_env, (1, A))).to(self.device)   # per column
         else:
             self.term_table = None
-        self._false = torch.zeros(num_envs, dtype=torch.bool, device=self.device)
+        self._false = torch.zeros(A * E, dtype=torch.bool, device=self.device)
         self.t = 0
 
     def get_batch_size(self):
@@ -52,8 +71,7 @@ class SyntheticFixedLengthEnv:
 
     def reset(self):
         self.t = 0
-        o = self.obs_table[0]
-        return o, o
+        return self.obs_table[0], self.critic_obs_table[0]
 
     soft_reset = reset
 
@@ -63,4 +81,4 @@ class SyntheticFixedLengthEnv:
         rew = self.reward_table[t]
         term = self._false if self.term_table is None else self.term_table[t]
         self.t += 1
-        return nxt, nxt, rew, term, self._false, nxt
+        return nxt, self.critic_obs_table[t + 1], rew, term, self._false, nxt

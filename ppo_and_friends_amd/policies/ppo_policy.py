@@ -298,8 +298,6 @@ class PPOPolicy:
     def fused_step_unsupported_reason(self):
         """'' when the K6+K7 rollout-step kernel covers this policy (same coverage as the fused update)."""
         from ..fused_update import FusedPolicyUpdate
-        if len(self.agent_ids) != 1:
-            return "more than one agent shares this policy"
         return FusedPolicyUpdate.unsupported_reason(self, 2)
 
     def rollout_step(self, t, obs, critic_obs, value_normalizer=None):
@@ -314,7 +312,7 @@ class PPOPolicy:
         from ..fused_update import _describe
         from ..networks.distributions import GaussianDistribution
         buf = self.buffer
-        E = self.env_batch_size
+        E = buf.C                       # agents x envs rows, agent-major
         a = getattr(self, "_step_args", None)
         if a is None:
             a = _lib.PolicyStepArgs()

@@ -150,7 +150,9 @@ class PPO:
                                   critic_observation_space=critic_obs_space, action_space=act_space,
                                   test_mode=False, envs_per_proc=self.envs_per_proc,
                                   random_seed=self.random_seed, **policy_args)
-            pol.register_agent("agent0")
+            for agent_id in getattr(self.env, "agent_ids", ["agent0"]):
+                if self.policy_mapping_fn(agent_id) == policy_id:
+                    pol.register_agent(agent_id)
             self.policies[policy_id] = pol
             self.status_dict[policy_id] = OrderedDict()
             if normalize_values:
@@ -186,10 +188,11 @@ class PPO:
         pol.initialize_dataset()
         pol.eval()
         env = self.env
-        E = env.get_batch_size()
-        T = self.ts_per_rollout // E
-        pol.initialize_episodes(E, self.status_dict, ts_per_rollout=self.ts_per_rollout)
+        n_envs = env.get_batch_size()
+        T = self.ts_per_rollout // n_envs
+        pol.initialize_episodes(n_envs, self.status_dict, ts_per_rollout=self.ts_per_rollout)
         buf = pol.buffer
+        E = buf.C                      # rows per step: agents x envs, agent-major (ppo.py:710-795)
         obs, critic_obs = env.reset() if self._obs is None else self._obs
         ep_ts = torch.zeros(E, dtype=torch.int32, device=self.device)
         score_sum = torch.zeros((), dtype=torch.float64, device=self.device)
@@ -241,7 +244,7 @@ class PPO:
         score_sum = buf.rewards.sum(dtype=torch.float64)
         pol.finalize_dataset()
         gs = self.status_dict["global status"]
-        gs["timesteps"] += self.ts_per_rollout * mpi_utils.get_num_procs()
+        gs["timesteps"] += self.ts_per_rollout * mpi_utils.get_num_procs()     # env steps (ppo.py:1653), not agent steps
         self.status_dict[policy_id]["reward sum"] = score_sum        # device scalar; read lazily
         self.status_dict[policy_id]["terminated episodes"] = n_term
         torch.cuda.synchronize() if self.device.type == "cuda" else None

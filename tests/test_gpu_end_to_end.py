@@ -218,3 +218,50 @@ def test_fused_rollout_step_equals_torch_rollout(kind, n, O, hidden):
     np.testing.assert_allclose(f["log_probs"], t["log_probs"], rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(f["values"], t["values"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(f["advantages"], t["advantages"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("update_mode", ["fused", "torch"])
+def test_mappo_shared_policy_three_agents(update_mode):
+    """
+    SURVEY.md §8 C4 shape: 3 agents share one policy (actor 128^3 on O=18, Discrete(5); critic 256^3
+    on the concatenated O_c=54 "policy" view); rows are agent-major, the dataset holds A*E*T
+    transitions in the reference's completion order (ppo.py:1730-1752, 1810-1819, 1932-1938).
+    """
+    from ppo_and_friends_amd.ppo import PPO, PermutationLoader
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    dev = torch.device("cuda", 0)
+    A, E, T, O, NA, B, seed = 3, 6, 10, 18, 5, 48, 4
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=21,
+                                              num_agents=A, critic_view="policy", term_prob=0.05)
+    sp, csp = Box(-np.inf, np.inf, (O,), np.float32), Box(-np.inf, np.inf, (A * O,), np.float32)
+    pargs = dict(actor_kw_args=dict(hidden_size=128), critic_kw_args=dict(hidden_size=256))
+    ppo = PPO(env_gen, {"team": (None, sp, csp, Discrete(NA), pargs)}, device=dev, random_seed=seed,
+              envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=2, update_mode=update_mode)
+    pol = ppo.policies["team"]
+    assert list(pol.agent_ids) == ["agent0", "agent1", "agent2"]
+    cpu = cpu_ppo_loop.CpuPPO(O, NA, batch_size=B, seed=seed, critic_obs_dim=A * O, critic_hidden=256)
+    strip = lambda sd: {k.replace("sequential_net.", ""): v.detach().cpu().clone() for k, v in sd.items()
+                        if k.startswith("sequential_net.")}
+    cpu.actor.load_state_dict(strip(pol.actor.state_dict()))
+    cpu.critic.load_state_dict(strip(pol.critic.state_dict()))
+    cpu.loader_generator = torch.Generator().manual_seed(seed)
+    ds = ppo.rollout()
+    env = ppo.env
+    assert len(ds) == A * E * T
+    ref = cpu.rollout(env.obs_table.cpu().numpy(), env.reward_table.cpu().numpy(),
+                      actions=pol.buffer.actions[..., 0].cpu().numpy(),
+                      term_table=env.term_table.cpu().numpy(),
+                      critic_obs_table=env.critic_obs_table.cpu().numpy())
+    tol = dict(rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(ds.critic_observations.cpu().numpy(), ref.critic_observations.numpy())
+    np.testing.assert_allclose(ds.advantages.cpu().numpy(), ref.advantages.numpy(), **tol)
+    np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), ref.rewards_to_go.numpy(), **tol)
+    loader = PermutationLoader(pol.dataset, B, ppo.loader_generator)
+    pol.train()
+    for _ in range(2):
+        ppo._ppo_batch_train(loader, "team")
+        r = cpu.train_epoch()
+        for k in ("actor loss", "critic loss", "kl avg", "weighted entropy"):
+            np.testing.assert_allclose(ppo.status_dict["team"][k], r[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(_flat_params(pol.critic), _flat_params(cpu.critic), rtol=1e-4, atol=2e-5)
