@@ -74,6 +74,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-envs", type=int, default=256)
     p.add_argument("--no-saturating", action="store_true")
+    p.add_argument("--config", default="C2", choices=["C2", "C3", "C4"],
+                   help="C2 (default, the metric's config) | C3 dims: HalfCheetah O=17, Box(6), actor 128^3 / "
+                        "critic 256^3, E=2048 (no ICM / wrappers yet) | C4 dims: SimpleSpread MAPPO, 3 agents, "
+                        "O=18, O_c=54, Discrete(5), E=1024 per rank")
     return p.parse_args()
 
 
@@ -93,11 +97,25 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     E, T, O, NA = args.envs, args.ts, 4, 2
+    A, critic_view, act_space, pargs, workload = 1, "local", Discrete(NA), {}, None
+    if args.config == "C3":
+        E, O = (2048 if args.envs == 4096 else args.envs), 17
+        act_space = Box(-1.0, 1.0, (6,), np.float32)
+        pargs = dict(actor_kw_args=dict(hidden_size=128), critic_kw_args=dict(hidden_size=256))
+        workload = (f"C3 dims (HalfCheetah-v4: O=17, Box(6) tanh-Gaussian, actor 128^3, critic 256^3), "
+                    f"envs_per_proc={E}, ts_per_rollout={T}; WITHOUT ICM and obs/reward normalisers (not built yet)")
+    elif args.config == "C4":
+        E, O, NA, A, critic_view = (1024 if args.envs == 4096 else args.envs), 18, 5, 3, "policy"
+        act_space = Discrete(NA)
+        pargs = dict(actor_kw_args=dict(hidden_size=128), critic_kw_args=dict(hidden_size=256))
+        workload = (f"C4 dims (MPE simple_spread MAPPO: 3 agents share one policy, O=18, O_c=54, Discrete(5), "
+                    f"actor 128^3, critic 256^3), envs_per_proc={E}, ts_per_rollout={T}")
 
-    env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, device, reward="ones",
-                                              seed=1234, rank=rank)
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, act_space, T, device, reward="ones" if args.config == "C2" else "uniform",
+                                              seed=1234, rank=rank, num_agents=A, critic_view=critic_view)
     obs_space = Box(-np.inf, np.inf, (O,), np.float32)
-    settings = {"cartpole": (obs_space, obs_space, Discrete(NA), {})}
+    cobs_space = Box(-np.inf, np.inf, (O * A if critic_view == "policy" else O,), np.float32)
+    settings = {"cartpole": (obs_space, cobs_space, act_space, pargs)}
     ppo = PPO(env_gen, settings, device=device, random_seed=1, envs_per_proc=E, ts_per_rollout=T,
               batch_size=args.batch_size, epochs_per_iter=args.epochs, use_graphs=not args.no_graphs)
     pol = ppo.policies["cartpole"]
@@ -146,7 +164,7 @@ def main():
     value = env_steps / dt
     gae_ms = [K.event_elapsed_ms(a, b) for a, b in gae_events]
     gae_avg_s = (sum(gae_ms) / max(len(gae_ms), 1)) * 1e-3
-    gae_bytes = GAE_BYTES_PER_TRANSITION * E * T
+    gae_bytes = GAE_BYTES_PER_TRANSITION * E * T * A
     achieved = gae_bytes / gae_avg_s / 1e9 if gae_avg_s > 0 else 0.0
     pmc = pmc_traffic() if (E, T) == (4096, 128) else {}
     roofline = {"kernel": "gae_rtg_chunked_kernel" if E < (1 << 17) else "gae_rtg_stream_kernel", "bound": "hbm", "achieved": round(achieved, 2),
@@ -161,9 +179,12 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "C2 CartPole-v1 MLP (4->128x3->2 actor, ->1 critic), "
-                                  f"envs_per_proc={E}, ts_per_rollout={T}, batch_size={args.batch_size}, "
-                                  f"epochs_per_iter={args.epochs}, fixed-length synthetic trajectories",
+           "config": {"workload": (workload + f", batch_size={args.batch_size}, epochs_per_iter={args.epochs}"
+                                   if workload else
+                                   "C2 CartPole-v1 MLP (4->128x3->2 actor, ->1 critic), "
+                                   f"envs_per_proc={E}, ts_per_rollout={T}, batch_size={args.batch_size}, "
+                                   f"epochs_per_iter={args.epochs}, fixed-length synthetic trajectories"),
+                      "agent_steps_per_iteration": world * E * T * A,
                       "global_env_steps_per_iteration": world * E * T,
                       "parallelism": f"dp{world}", "hip_graphs": not args.no_graphs,
                       "rollout_s": round(ppo.status_dict["global status"]["rollout time"], 4),
@@ -193,7 +214,7 @@ def main():
                                       "traffic": pmc_traffic().get("void ppoaf::gae_rtg_stream_kernel<4, 8>")}
         del r, v, b, adv, rtg
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "C2":
         from oracle import cpu_ppo_loop
         Ec = args.cpu_sample_envs
         import os as _os

@@ -384,6 +384,23 @@ typedef struct {
 
 int ppoaf_policy_step(const ppoaf_policy_step_args_t* args, ppoaf_stream_t stream);
 
+
+/* ------------------------------------------------------------------------ *
+ * K8  ICM forward-model loss and intrinsic reward
+ * replaces the tail of ICM.forward  networks/ppo_networks/icm.py:421-430
+ *   intr[i]  = (reward_scale / 2) * sum_d (pred[i,d] - enc2[i,d])^2
+ *   f_loss   = 0.5 * mean((pred - enc2)^2)
+ * pred, enc2: [n, D] float32; rowsum_scratch: float32[n] owned by the caller;
+ * intr_out / f_loss_out may be NULL.  bwd: d_pred = grad_f_loss * (pred-enc2)/(n*D),
+ * d_enc2 = -d_pred (NULL to skip); grad_f_loss is a device scalar.
+ * ------------------------------------------------------------------------ */
+int ppoaf_icm_forward_loss_fwd(const float* pred, const float* enc2, int64_t n, int32_t D,
+                               float reward_scale, float* rowsum_scratch, float* intr_out,
+                               float* f_loss_out, ppoaf_stream_t stream);
+int ppoaf_icm_forward_loss_bwd(const float* pred, const float* enc2, int64_t n, int32_t D,
+                               const float* grad_f_loss, float* d_pred, float* d_enc2,
+                               ppoaf_stream_t stream);
+
 /* (n, mean, M2) float64 records of the rewards-to-go of every mini-batch of an
  * epoch: records[k] covers perm[k*B : min((k+1)*B, n_perm)]  (ppo.py:2299-2303,
  * utils/stats.py:52-54 batched).  One workgroup per mini-batch. */

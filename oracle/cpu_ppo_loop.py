@@ -116,7 +116,8 @@ class CpuPPO:
     def __init__(self, obs_dim, n_actions, hidden=128, depth=3, lr=3e-4, gamma=0.99, lambd=0.95,
                  bootstrap_clip=(-100.0, 100.0), surr_clip=0.2, entropy_weight=0.01,
                  gradient_clip=0.5, batch_size=256, normalize_adv=True, normalize_values=True,
-                 seed=0, rtg_accum="float64", critic_obs_dim=None, critic_hidden=None):
+                 seed=0, rtg_accum="float64", critic_obs_dim=None, critic_hidden=None,
+                 enable_icm=False, icm_lr=3e-4, icm_beta=0.8, intr_reward_weight=1.0):
         torch.manual_seed(seed)
         critic_obs_dim = obs_dim if critic_obs_dim is None else critic_obs_dim
         critic_hidden = hidden if critic_hidden is None else critic_hidden
@@ -131,6 +132,12 @@ class CpuPPO:
         self.value_stats = RunningMeanStd()
         self.rtg_accum = rtg_accum
         self.loader_generator = torch.Generator().manual_seed(seed)
+        self.enable_icm, self.icm_beta, self.intr_reward_weight = enable_icm, icm_beta, intr_reward_weight
+        self.intrinsic_score_avg = 0.0                 # status_dict[...]["intrinsic score avg"], ppo.py:518
+        if enable_icm:                                 # ppo_policy.py:461-468, 341-343
+            from .icm_oracle import ICM
+            self.icm = ICM(obs_dim, n_actions, discrete=True)
+            self.icm_optim = torch.optim.Adam(self.icm.parameters(), lr=icm_lr, eps=1e-5)
 
     # ----- value normaliser (utils/misc.py:84-128)
     def _denorm(self, v):
@@ -161,14 +168,19 @@ class CpuPPO:
         Episodes enter the dataset in completion order.
         """
         T, E = reward_table.shape
+        nxt_all = obs_table[1:]
         if critic_obs_table is None:
             critic_obs_table = obs_table          # single agent: the critic sees the actor's observation
         new_ep = lambda: _Episode(self.gamma, self.lambd, self.clip)
         episodes = [new_ep() for _ in range(E)]
         finished = []
         ep_ts = np.zeros(E, dtype=np.int64)
+        episode_lengths = np.zeros(E, dtype=np.int64)      # reset on termination only (ppo.py:1849)
+        total_episodes, total_intr = 0.0, 0.0
+        ism = self.intrinsic_score_avg
         for t in range(T):
             ep_ts += 1
+            episode_lengths += 1
             obs = obs_table[t]
             t_obs = torch.tensor(obs, dtype=torch.float32)
             with torch.no_grad():
@@ -184,6 +196,13 @@ class CpuPPO:
             value = self.values_of(torch.tensor(cobs, dtype=torch.float32)).unsqueeze(-1)
             nxt = obs_table[t + 1]
             rew = reward_table[t].reshape(E, 1).astype(np.float64)
+            intr = np.zeros((E, 1), dtype=np.float32)
+            if self.enable_icm:                        # ppo.py:1719-1723 -> ppo_policy.py:954-1007
+                with torch.no_grad():
+                    ir, _, _ = self.icm(t_obs, torch.tensor(nxt_all[t], dtype=torch.float32), a.unsqueeze(1))
+                intr = ir.numpy().reshape(E, 1) * self.intr_reward_weight
+                rew = rew + intr                       # float64 + float32 (ppo.py:1283)
+                total_intr += float(intr.sum())
             for e in range(E):                         # ppo_policy.py:638-651
                 episodes[e].add_info(
                     critic_observation=cobs[e], observation=obs[e], next_observation=nxt[e],
@@ -195,6 +214,8 @@ class CpuPPO:
                 finished.append(episodes[e])
                 episodes[e] = new_ep()
                 ep_ts[e] = 0
+                episode_lengths[e] = 0
+                total_episodes += 1
             if t == T - 1:                             # ppo.py:1870-1877
                 where_maxed = np.arange(E)
             elif max_ts_per_ep is not None:
@@ -205,12 +226,40 @@ class CpuPPO:
             if where_maxed.size > 0:
                 next_value = self.values_of(torch.tensor(critic_obs_table[t + 1], dtype=torch.float32))
                 for e in where_maxed:                  # ppo.py:1932-1938 (each env its own value: quirk Q1 fixed)
-                    episodes[e].end_episode(next_value[e].item(), next_value[e].item(), self.rtg_accum)
+                    nr = next_value[e].item()
+                    if self.enable_icm:                # ppo.py:1926-1930 "surprise" (per env: quirk Q2 fixed)
+                        nr = float(np.float32(nr) + (intr[e, 0] - np.float32(ism)))
+                    episodes[e].end_episode(next_value[e].item(), nr, self.rtg_accum)
                     finished.append(episodes[e])
                     episodes[e] = new_ep()
                     ep_ts[e] = 0
+        if self.enable_icm:                            # ppo.py:1940-1963, 2074-2080
+            combined = float(episode_lengths.sum())
+            ts_before = max(T * E - combined, 0.0)
+            cur_total = total_episodes if total_episodes != 0 else 1.0
+            avg_ep_len = combined / E if ts_before == 0 else ts_before / cur_total
+            total_episodes += float((episode_lengths / avg_ep_len).sum())
+            self.intrinsic_score_avg = total_intr / (total_episodes / E)
         self.dataset = _ListDataset(finished)
         return self.dataset
+
+    def icm_train_epoch(self):
+        """ppo.py:2487-2567."""
+        loader = DataLoader(self.dataset, batch_size=self.batch_size, shuffle=True,
+                            generator=self.loader_generator)
+        total, n = 0.0, 0
+        for batch in loader:
+            _, obs, next_obs, _, actions, _, _, _, _, _, _, _, _ = batch
+            if len(actions.shape) < 2:
+                actions = actions.unsqueeze(1)
+            _, inv_loss, f_loss = self.icm(obs, next_obs, actions)
+            icm_loss = (1.0 - self.icm_beta) * f_loss + self.icm_beta * inv_loss
+            total += icm_loss.item()
+            self.icm_optim.zero_grad()
+            icm_loss.backward()
+            self.icm_optim.step()
+            n += 1
+        return total / max(n, 1)
 
     # ----- one epoch (ppo.py:2274-2485)
     def train_epoch(self):

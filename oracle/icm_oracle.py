@@ -1,0 +1,62 @@
+"""
+TEST INFRASTRUCTURE (see oracle/__init__.py) -- torch-CPU restatement of the reference's ICM.
+"parity unpinned": networks/ppo_networks/icm.py imports `gymnasium` (absent here) and the reference
+holds no numeric vectors for it; restated from text on torch primitives.
+
+  ObsEncoder   <- LinearObservationEncoder   networks/encoders.py:9-56
+  InverseModel <- LinearInverseModel         networks/ppo_networks/icm.py:22-114
+  ForwardModel <- LinearForwardModel         :117-211
+  ICM.forward  <- ICM.forward                :365-430
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .cpu_ppo_loop import make_mlp
+
+
+def _lin(i, o, gain=np.sqrt(2)):
+    layer = nn.Linear(i, o)
+    nn.init.orthogonal_(layer.weight, gain)
+    nn.init.constant_(layer.bias, 0.0)
+    return layer
+
+
+class ObsEncoder(nn.Module):
+    def __init__(self, obs_size, encoded_dim=128, out_init=1.0, hidden=128):
+        super().__init__()
+        self.enc_1 = _lin(obs_size, hidden); self.enc_2 = _lin(hidden, hidden)
+        self.enc_3 = _lin(hidden, hidden); self.enc_4 = _lin(hidden, encoded_dim, out_init)
+
+    def forward(self, obs):
+        x = torch.relu(self.enc_1(obs.flatten(start_dim=1)))
+        x = torch.relu(self.enc_2(x))
+        x = torch.relu(self.enc_3(x))
+        return self.enc_4(x)
+
+
+class ICM(nn.Module):
+    def __init__(self, obs_size, act_size, discrete, reward_scale=0.01, out_init=1.0, enc=128, hidden=128, depth=2):
+        super().__init__()
+        self.discrete, self.act_size, self.reward_scale = discrete, act_size, reward_scale
+        self.obs_encoder = ObsEncoder(obs_size, enc, out_init, hidden)
+        self.inv_model = nn.Module()
+        self.inv_model.sequential_net = make_mlp(2 * enc, act_size, hidden, depth, out_gain=out_init)
+        self.forward_model = nn.Module()
+        self.forward_model.sequential_net = make_mlp(enc + act_size, enc, hidden, depth, out_gain=out_init)
+
+    def forward(self, obs_1, obs_2, actions):
+        e1, e2 = self.obs_encoder(obs_1), self.obs_encoder(obs_2)
+        pred = self.inv_model.sequential_net(torch.cat((e1, e2), dim=1))
+        if self.discrete:
+            pred = F.softmax(pred, dim=-1)                                    # icm.py:84-85
+            inv_loss = nn.CrossEntropyLoss(reduction="mean")(pred, actions.squeeze(1))   # :413
+            fa = F.one_hot(actions, num_classes=self.act_size).float().flatten(start_dim=1)   # :189-191
+        else:
+            actions = actions.reshape(pred.shape)
+            inv_loss = nn.MSELoss(reduction="none")(pred, actions).mean()     # :417-419
+            fa = actions
+        obs_2_pred = self.forward_model.sequential_net(torch.cat((e1, fa), dim=1))
+        f = nn.MSELoss(reduction="none")(obs_2_pred, e2)                      # :425
+        return (self.reward_scale / 2.0) * f.sum(dim=-1), inv_loss, 0.5 * f.mean()   # :427-428

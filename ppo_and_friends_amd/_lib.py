@@ -114,6 +114,8 @@ SIGNATURES = {
     "ppoaf_ppo_update_fwd_bwd": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr]),
     "ppoaf_ppo_update_reduce": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
     "ppoaf_ppo_update_adam": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
+    "ppoaf_icm_forward_loss_fwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, C.c_float, _ptr, _ptr, _ptr, _ptr]),
+    "ppoaf_icm_forward_loss_bwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, _ptr, _ptr, _ptr, _ptr]),
     "ppoaf_policy_step": (C.c_int, [C.POINTER(PolicyStepArgs), _ptr]),
     "ppoaf_minibatch_moments": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int64, _ptr, _ptr]),
 }

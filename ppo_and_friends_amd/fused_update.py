@@ -83,8 +83,8 @@ class FusedPolicyUpdate:
     @staticmethod
     def unsupported_reason(pol, batch_size):
         """'' when the fused kernels cover this policy, else why not (the torch path is used then)."""
-        if pol.using_lstm or pol.enable_icm or pol.agent_grouping:
-            return "LSTM / ICM / grouped policies are not covered by the fused MLP update"
+        if pol.using_lstm or pol.agent_grouping:
+            return "LSTM / grouped (MAT) policies are not covered by the fused MLP update"
         dist = pol.actor.distribution
         if isinstance(dist, CategoricalDistribution):
             head = K.HEAD_CATEGORICAL

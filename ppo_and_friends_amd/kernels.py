@@ -367,3 +367,30 @@ def ppo_update_adam(args, compute_norms):
 
 def policy_step(args):
     check(_lib.load().ppoaf_policy_step(C.byref(args), stream()), "policy_step")
+
+
+# --------------------------------------------------------------------------
+# K8: ICM forward-model loss / intrinsic reward
+# --------------------------------------------------------------------------
+def icm_forward_loss_fwd(pred, enc2, reward_scale, want_loss=True):
+    _f32(pred, "pred"); _f32(enc2, "enc2")
+    _req(pred.dim() == 2 and pred.shape == enc2.shape, "pred / enc2 must both be [n, D]")
+    n, D = pred.shape
+    dev = pred.device
+    rowsum = torch.empty(n, dtype=torch.float32, device=dev)
+    intr = torch.empty(n, dtype=torch.float32, device=dev)
+    f_loss = torch.empty(1, dtype=torch.float32, device=dev) if want_loss else None
+    check(_lib.load().ppoaf_icm_forward_loss_fwd(ptr(pred), ptr(enc2), n, D, float(reward_scale),
+                                                 ptr(rowsum), ptr(intr), ptr(f_loss), stream()),
+          "icm_forward_loss_fwd")
+    return intr, f_loss
+
+
+def icm_forward_loss_bwd(pred, enc2, grad_f_loss, want_enc2_grad=True):
+    n, D = pred.shape
+    _req(grad_f_loss.dtype == torch.float32 and grad_f_loss.numel() == 1, "grad_f_loss must be a float32 scalar")
+    d_pred = torch.empty_like(pred)
+    d_enc2 = torch.empty_like(enc2) if want_enc2_grad else None
+    check(_lib.load().ppoaf_icm_forward_loss_bwd(ptr(pred), ptr(enc2), n, D, ptr(grad_f_loss.reshape(1)),
+                                                 ptr(d_pred), ptr(d_enc2), stream()), "icm_forward_loss_bwd")
+    return d_pred, d_enc2

@@ -193,13 +193,11 @@ class PPOPolicy:
         self.critic_optim = FlatAdam(self.critic, self.lr(), eps=1e-5, storage=(
             self.policy_exp_avg[na:], self.policy_exp_avg_sq[na:], self.policy_step_counts[1:2],
             self.policy_lr, self.policy_norm_scratch[1:2]))
-        self.icm_optim = None
+        self.icm_optim = FlatAdam(self.icm_model, self.icm_lr(), eps=1e-5) if self.enable_icm else None
 
     def _initialize_networks(self, ac_network, enable_icm, icm_network, actor_kw_args,
                              critic_kw_args, icm_kw_args, **kw_args):
         """ppo_policy.py:390-472: actor out gain 0.01, critic out gain 1.0; rank-0 broadcast."""
-        if enable_icm:
-            raise NotImplementedError("ICM (config C3) is the next hot-path row; see DESIGN.md")
         self.actor = ac_network(name="actor", in_shape=get_space_shape(self.actor_obs_space),
                                 out_shape=get_action_prediction_shape(self.action_space),
                                 out_init=0.01, test_mode=self.test_mode, **actor_kw_args)
@@ -210,6 +208,16 @@ class PPOPolicy:
             self.action_space, seed=self.random_seed + 7919 * mpi_utils.get_rank(), **actor_kw_args)
         self._place_networks()
         mpi_utils.broadcast_flat(self.policy_params)      # one message for actor + critic
+        if enable_icm:                                    # ppo_policy.py:461-472
+            if self.agent_shared_icm:
+                raise NotImplementedError("agent_shared_icm needs agent grouping (MAT); not built")
+            from ..networks.icm import ICM
+            icm_cls = ICM if icm_network is None else icm_network
+            self.icm_model = icm_cls(name="icm", obs_space=self.actor_obs_space,
+                                     action_space=self.action_space, test_mode=self.test_mode,
+                                     **icm_kw_args)
+            self.icm_model.to(self.device)
+            mpi_utils.broadcast_model_parameters(self.icm_model)
 
     def seed(self, seed):
         self.random_seed = seed
@@ -355,6 +363,20 @@ class PPOPolicy:
         buf.steps_written = max(buf.steps_written, t + 1)
         self._t = t + 1
 
+    def get_intrinsic_reward(self, prev_obs, obs, action):
+        """ppo_policy.py:954-1007: ICM forward without gradients -> intrinsic reward [n] (already weighted)."""
+        if len(obs.shape) < 2:
+            raise ValueError(f"get_intrinsic_reward expects a batch of observations, got shape {obs.shape}")
+        obs_1 = self._to_device(prev_obs)
+        obs_2 = self._to_device(obs)
+        adt = torch.int64 if self.action_dtype == "discrete" else torch.float32
+        act = self._to_device(action, adt)
+        if act.dim() != 2:
+            act = act.unsqueeze(1)
+        with torch.no_grad():
+            intr, _, _ = self.icm_model(obs_1, obs_2, act)
+        return intr.reshape(-1) * float(self.intr_reward_weight())
+
     def get_inference_actions(self, obs, deterministic):
         t_obs = self._to_device(obs)
         with torch.no_grad():
@@ -446,6 +468,8 @@ class PPOPolicy:
             return
         self.actor_optim.set_lr(self.lr())
         self.critic_optim.set_lr(self.lr())
+        if self.enable_icm:
+            self.icm_optim.set_lr(self.icm_lr())
 
     # ------------------------------------------------------------- save / load
     def save(self, save_path, tag="latest"):
@@ -454,6 +478,8 @@ class PPOPolicy:
         os.makedirs(policy_save_path, exist_ok=True)
         self.actor.save(policy_save_path)
         self.critic.save(policy_save_path)
+        if self.enable_icm:
+            self.icm_model.save(policy_save_path)
         r = mpi_utils.get_rank()
         torch.save(self.actor_optim.state_dict(), os.path.join(policy_save_path, f"actor_optim_{r}"))
         torch.save(self.critic_optim.state_dict(), os.path.join(policy_save_path, f"critic_optim_{r}"))
@@ -462,6 +488,8 @@ class PPOPolicy:
         policy_load_path = os.path.join(load_path, f"{self.name}-policy", tag)
         self.actor.load(policy_load_path)
         self.critic.load(policy_load_path)
+        if self.enable_icm:
+            self.icm_model.load(policy_load_path)
         r = mpi_utils.get_rank()
         for net, opt in (("actor", self.actor_optim), ("critic", self.critic_optim)):
             f = os.path.join(policy_load_path, f"{net}_optim_{r}")

@@ -201,6 +201,9 @@ class PPO:
         fused_step = (self.update_mode != "torch" and self.device.type == "cuda"
                       and pol.fused_step_unsupported_reason() == "")
         vn = self.value_normalizers[policy_id] if self.normalize_values else None
+        intr_buf = torch.zeros(T, E, dtype=torch.float32, device=self.device) if pol.enable_icm else None
+        if pol.enable_icm:
+            may_end_early = True          # bootstrap rewards carry the "surprise" term: dense end table
         for t in range(T):
             if fused_step:
                 # K6+K7: inference, sampling, log-probs, values and the buffer row in one launch
@@ -208,6 +211,9 @@ class PPO:
                 nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(action)
                 if self.ext_reward_weight != 1.0:
                     reward = reward * self.ext_reward_weight
+                if pol.enable_icm:            # ppo.py:1719-1723 -> apply_intrinsic_rewards :1219-1288
+                    intr_buf[t] = pol.get_intrinsic_reward(obs, term_obs, action)
+                    reward = reward + intr_buf[t]
                 pol.finish_step(t, reward, term_obs)
             else:
                 raw_action, action, log_prob = pol.get_rollout_actions(obs)
@@ -215,6 +221,9 @@ class PPO:
                 nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(action)
                 if self.ext_reward_weight != 1.0:
                     reward = reward * self.ext_reward_weight
+                if pol.enable_icm:
+                    intr_buf[t] = pol.get_intrinsic_reward(obs, term_obs, action)
+                    reward = reward + intr_buf[t]
                 buf.write_step(t, slice(0, E), critic_obs, obs, term_obs, raw_action, action, value,
                                log_prob, reward)
                 pol._t = t + 1
@@ -236,6 +245,11 @@ class PPO:
             buf.boot_value[:-1].copy_(buf.values[1:])
             buf.boot_value[T - 1].copy_(next_value)
             buf.boot_reward.copy_(buf.boot_value)
+            if pol.enable_icm:
+                # ppo.py:1926-1930: bootstrap reward += intrinsic reward of the step - "intrinsic score avg"
+                ism = float(self.status_dict[policy_id].get("intrinsic score avg", 0.0))
+                buf.boot_reward.add_(intr_buf - ism)
+                self._update_intrinsic_score_avg(policy_id, buf, intr_buf, n_envs, T)
         else:
             buf.end_kind[T - 1].fill_(2)
             buf.boot_value[T - 1].copy_(next_value)
@@ -250,6 +264,27 @@ class PPO:
         torch.cuda.synchronize() if self.device.type == "cuda" else None
         gs["rollout time"] = time.time() - start
         return pol.dataset
+
+    def _update_intrinsic_score_avg(self, policy_id, buf, intr_buf, n_envs, T):
+        """
+        status_dict["intrinsic score avg"] as the reference computes it (ppo.py:1849-1851,
+        1940-1963, 2074-2080): total intrinsic reward / (total_episodes / env_batch_size), with the
+        reference's fractional count for the episodes that were still running at rollout end.
+        """
+        A = buf.C // n_envs
+        term = (buf.end_kind[:, :n_envs] == 1)                          # per env (agents end together)
+        n_term = term.sum().double()
+        t_idx = torch.arange(T, device=self.device)[:, None].expand(T, n_envs)
+        last_term = torch.where(term, t_idx, torch.full_like(t_idx, -1)).max(dim=0).values
+        ep_len = (T - 1 - last_term).double()                           # steps since the last terminal
+        combined = ep_len.sum()
+        ts_before = torch.clamp(float(T * n_envs) - combined, min=0.0)
+        cur_total = torch.where(n_term == 0, torch.ones_like(n_term), n_term)
+        avg_len = torch.where(ts_before == 0, combined / n_envs, ts_before / cur_total)
+        total_eps = n_term + (ep_len / avg_len).sum()
+        tot = torch.stack([intr_buf.sum(dtype=torch.float64), total_eps])
+        mpi_utils.allreduce_sum_(tot)                                   # ppo.py:1991, 2076
+        self.status_dict[policy_id]["intrinsic score avg"] = float((tot[0] / (tot[1] / n_envs)).item())
 
     # ------------------------------------------------------------------ update
     def learn(self, num_timesteps):
@@ -275,6 +310,8 @@ class PPO:
                 if epoch_idx > 0 and self.recalc_advantages:
                     loader.dataset.recalculate_advantages()
                 self._ppo_batch_train(loader, policy_id)
+                if pol.enable_icm:
+                    self._icm_batch_train(loader, policy_id)
                 if self.status_dict[policy_id]["kl avg"] > pol.target_kl:
                     if self.verbose:
                         rank_print(f"Target KL of {pol.target_kl} has been reached. "
@@ -366,6 +403,43 @@ class PPO:
         if world > 1:
             mpi_utils.allreduce_sum_(t)
         self._publish_epoch_stats(policy_id, t.cpu().numpy())
+
+    def _icm_batch_train(self, data_loader, policy_id):
+        """
+        ppo.py:2487-2567: a second shuffled pass over the dataset that trains the ICM:
+        icm_loss = (1 - beta) * f_loss + beta * inv_loss, backward, gradient averaging, Adam (no clip).
+        """
+        pol = self.policies[policy_id]
+        ds = data_loader.dataset
+        buf = ds.buffer
+        B = data_loader.batch_size
+        perm = data_loader.epoch_permutation()
+        N = perm.numel()
+        world = mpi_utils.get_num_procs()
+        total = torch.zeros((), dtype=torch.float64, device=self.device)
+        counter = 0
+        flat = lambda t: t.view((buf.num_transitions,) + tuple(t.shape[2:]))
+        for o in range(0, N, B):
+            idx = perm[o:o + B].contiguous()
+            n = idx.numel()
+            obs = torch.empty((n,) + tuple(buf.observations.shape[2:]), dtype=torch.float32, device=self.device)
+            nxt = torch.empty_like(obs)
+            act = torch.empty((n,) + tuple(buf.actions.shape[2:]), dtype=buf.actions.dtype, device=self.device)
+            K.minibatch_gather([(flat(buf.observations), obs), (flat(buf.next_observations), nxt),
+                                (flat(buf.actions), act)], idx, buf.row_map)
+            _, inv_loss, f_loss = pol.icm_model(obs, nxt, act)
+            icm_loss = (1.0 - pol.icm_beta) * f_loss + pol.icm_beta * inv_loss
+            total += icm_loss.detach().double()
+            pol.icm_optim.zero_grad()
+            icm_loss.backward()
+            mpi_utils.allreduce_sum_(pol.icm_model.flat_grads)
+            pol.icm_optim.step(grad_scale=1.0 / world, max_norm=None)
+            counter += 1
+        t = torch.stack([total, torch.tensor(float(counter), dtype=torch.float64, device=self.device)])
+        if world > 1:
+            mpi_utils.allreduce_sum_(t)
+        t = t.cpu().numpy()
+        self.status_dict[policy_id]["icm loss"] = t[0] / max(t[1], 1.0)
 
     def _fused_updater(self, policy_id, B):
         if self.update_mode == "torch" or self.device.type != "cuda":

@@ -265,3 +265,52 @@ def test_mappo_shared_policy_three_agents(update_mode):
         for k in ("actor loss", "critic loss", "kl avg", "weighted entropy"):
             np.testing.assert_allclose(ppo.status_dict["team"][k], r[k], rtol=2e-5, atol=2e-6, err_msg=k)
     np.testing.assert_allclose(_flat_params(pol.critic), _flat_params(cpu.critic), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("update_mode", ["fused", "torch"])
+def test_icm_rollout_rewards_and_training_match_cpu_port(update_mode):
+    """
+    ICM: intrinsic rewards added per env step (K8 + torch-ROCm MLPs), the bootstrap
+    "surprise" term, and the second shuffled pass that trains the ICM -- against the CPU port.
+    """
+    from ppo_and_friends_amd.ppo import PPO, PermutationLoader
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    dev = torch.device("cuda", 0)
+    E, T, O, NA, B, seed = 12, 16, 6, 3, 32, 8
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=31, term_prob=0.04)
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    ppo = PPO(env_gen, {"p": (None, sp, sp, Discrete(NA), dict(enable_icm=True))}, device=dev,
+              random_seed=seed, envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=1,
+              update_mode=update_mode)
+    pol = ppo.policies["p"]
+    cpu = cpu_ppo_loop.CpuPPO(O, NA, batch_size=B, seed=seed, enable_icm=True)
+    strip = lambda sd: {k.replace("sequential_net.", ""): v.detach().cpu().clone() for k, v in sd.items()
+                        if k.startswith("sequential_net.")}
+    cpu.actor.load_state_dict(strip(pol.actor.state_dict()))
+    cpu.critic.load_state_dict(strip(pol.critic.state_dict()))
+    cpu.icm.load_state_dict({k: v.detach().cpu().clone() for k, v in pol.icm_model.state_dict().items()})
+    cpu.loader_generator = torch.Generator().manual_seed(seed)
+    for it in range(2):                          # the second rollout sees a non-zero "intrinsic score avg"
+        ppo._obs = None                          # restart the table-driven env, as the CPU port does
+        ds = ppo.rollout()
+        env = ppo.env
+        ref = cpu.rollout(env.obs_table.cpu().numpy(), env.reward_table.cpu().numpy(),
+                          actions=pol.buffer.actions[..., 0].cpu().numpy(),
+                          term_table=env.term_table.cpu().numpy())
+        np.testing.assert_allclose(ppo.status_dict["p"]["intrinsic score avg"], cpu.intrinsic_score_avg,
+                                   rtol=1e-4, err_msg=f"iteration {it}")
+        np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), ref.rewards_to_go.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(ds.advantages.cpu().numpy(), ref.advantages.numpy(), rtol=1e-4, atol=1e-4)
+        loader = PermutationLoader(pol.dataset, B, ppo.loader_generator)
+        pol.train()
+        ppo._ppo_batch_train(loader, "p")
+        r = cpu.train_epoch()
+        ppo._icm_batch_train(loader, "p")
+        icm_ref = cpu.icm_train_epoch()
+        for k in ("actor loss", "critic loss", "kl avg"):
+            np.testing.assert_allclose(ppo.status_dict["p"][k], r[k], rtol=5e-5, atol=5e-6, err_msg=k)
+        np.testing.assert_allclose(ppo.status_dict["p"]["icm loss"], icm_ref, rtol=2e-5)
+    w = torch.cat([p.detach().cpu().reshape(-1) for p in pol.icm_model.parameters()]).numpy()
+    w_ref = torch.cat([p.detach().reshape(-1) for p in cpu.icm.parameters()]).numpy()
+    np.testing.assert_allclose(w, w_ref, rtol=1e-4, atol=2e-5)

@@ -434,3 +434,23 @@ def test_clip_adam_matches_torch(K, max_norm, grad_scale):
     assert step.item() == steps
     ref_flat = torch.cat([p.flatten() for p in ref]).numpy()
     np.testing.assert_allclose(flat.cpu().numpy(), ref_flat, rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------- K8
+@pytest.mark.parametrize("n,D", [(1, 128), (256, 128), (2048, 128), (77, 40)])
+def test_icm_forward_loss_fwd_bwd(K, n, D):
+    """icm.py:421-430: intrinsic reward, 0.5 * mean squared error, and its gradient."""
+    torch.manual_seed(n + D)
+    pred = torch.randn(n, D, requires_grad=True)
+    enc2 = torch.randn(n, D, requires_grad=True)
+    f = torch.nn.MSELoss(reduction="none")(pred, enc2)
+    intr_ref = (0.01 / 2.0) * f.sum(dim=-1)
+    loss_ref = 0.5 * f.mean()
+    (loss_ref * 3.0).backward()
+    intr, loss = K.icm_forward_loss_fwd(dev(pred.detach()), dev(enc2.detach()), 0.01)
+    np.testing.assert_allclose(intr.cpu().numpy(), intr_ref.detach().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-5)
+    g = torch.full((1,), 3.0, device="cuda")
+    dp, de = K.icm_forward_loss_bwd(dev(pred.detach()), dev(enc2.detach()), g)
+    np.testing.assert_allclose(dp.cpu().numpy(), pred.grad.numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(de.cpu().numpy(), enc2.grad.numpy(), rtol=1e-5, atol=1e-9)
