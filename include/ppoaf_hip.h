@@ -401,6 +401,22 @@ int ppoaf_icm_forward_loss_bwd(const float* pred, const float* enc2, int64_t n, 
                                const float* grad_f_loss, float* d_pred, float* d_enc2,
                                ppoaf_stream_t stream);
 
+
+/* ------------------------------------------------------------------------ *
+ * K9  multi-agent-transformer attention core (f32 MFMA)
+ * replaces the middle of SelfAttention.forward  networks/attention.py:94-103
+ *   att = softmax(q k^T / sqrt(D) [causal mask]);  y = att v
+ * q, k, v, y, dy, dq, dk, dv: [n_seq, L, D] float32 contiguous (heads folded into
+ * n_seq), L <= 16 agents, D a multiple of 16; probs: [n_seq, L, L] (saved by fwd,
+ * consumed by bwd).  floor(16/L) sequences are packed per 16-row MFMA tile.
+ * ------------------------------------------------------------------------ */
+int ppoaf_mat_attention_fwd(const float* q, const float* k, const float* v, int64_t n_seq,
+                            int32_t L, int32_t D, int masked, float* y_out, float* probs_out,
+                            ppoaf_stream_t stream);
+int ppoaf_mat_attention_bwd(const float* q, const float* k, const float* v, const float* probs,
+                            const float* dy, int64_t n_seq, int32_t L, int32_t D,
+                            float* dq, float* dk, float* dv, ppoaf_stream_t stream);
+
 /* (n, mean, M2) float64 records of the rewards-to-go of every mini-batch of an
  * epoch: records[k] covers perm[k*B : min((k+1)*B, n_perm)]  (ppo.py:2299-2303,
  * utils/stats.py:52-54 batched).  One workgroup per mini-batch. */

@@ -116,6 +116,9 @@ SIGNATURES = {
     "ppoaf_ppo_update_adam": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
     "ppoaf_icm_forward_loss_fwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, C.c_float, _ptr, _ptr, _ptr, _ptr]),
     "ppoaf_icm_forward_loss_bwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, _ptr, _ptr, _ptr, _ptr]),
+    "ppoaf_mat_attention_fwd": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int32, C.c_int32, C.c_int, _ptr, _ptr, _ptr]),
+    "ppoaf_mat_attention_bwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64, C.c_int32, C.c_int32,
+                                          _ptr, _ptr, _ptr, _ptr]),
     "ppoaf_policy_step": (C.c_int, [C.POINTER(PolicyStepArgs), _ptr]),
     "ppoaf_minibatch_moments": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int64, _ptr, _ptr]),
 }

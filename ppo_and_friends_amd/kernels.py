@@ -394,3 +394,27 @@ def icm_forward_loss_bwd(pred, enc2, grad_f_loss, want_enc2_grad=True):
     check(_lib.load().ppoaf_icm_forward_loss_bwd(ptr(pred), ptr(enc2), n, D, ptr(grad_f_loss.reshape(1)),
                                                  ptr(d_pred), ptr(d_enc2), stream()), "icm_forward_loss_bwd")
     return d_pred, d_enc2
+
+
+# --------------------------------------------------------------------------
+# K9: MAT attention core
+# --------------------------------------------------------------------------
+def mat_attention_fwd(q, k, v, masked):
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _f32(t, n)
+        _req(t.dim() == 3 and t.shape == q.shape, f"{n} must be [n_seq, L, D]")
+    n_seq, L, D = q.shape
+    y = torch.empty_like(q)
+    probs = torch.empty(n_seq, L, L, dtype=torch.float32, device=q.device)
+    check(_lib.load().ppoaf_mat_attention_fwd(ptr(q), ptr(k), ptr(v), n_seq, L, D, int(bool(masked)),
+                                              ptr(y), ptr(probs), stream()), "mat_attention_fwd")
+    return y, probs
+
+
+def mat_attention_bwd(q, k, v, probs, dy):
+    n_seq, L, D = q.shape
+    _req(dy.shape == q.shape and probs.shape == (n_seq, L, L), "dy [n_seq,L,D], probs [n_seq,L,L]")
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    check(_lib.load().ppoaf_mat_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(probs), ptr(dy), n_seq, L, D,
+                                              ptr(dq), ptr(dk), ptr(dv), stream()), "mat_attention_bwd")
+    return dq, dk, dv

@@ -454,3 +454,53 @@ def test_icm_forward_loss_fwd_bwd(K, n, D):
     dp, de = K.icm_forward_loss_bwd(dev(pred.detach()), dev(enc2.detach()), g)
     np.testing.assert_allclose(dp.cpu().numpy(), pred.grad.numpy(), rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(de.cpu().numpy(), enc2.grad.numpy(), rtol=1e-5, atol=1e-9)
+
+
+# ---------------------------------------------------------------- K9
+def _attention_ref(q, k, v, masked):
+    """attention.py:94-103 on torch-CPU."""
+    L, D = q.shape[-2], q.shape[-1]
+    att = (q @ k.transpose(-2, -1)) * (1.0 / np.sqrt(D))
+    if masked:
+        att = att.masked_fill(torch.tril(torch.ones(L, L)) == 0, float("-inf"))
+    return torch.softmax(att, dim=-1) @ v
+
+
+@pytest.mark.parametrize("n_seq,L,D,masked", [(1, 3, 64, False), (4, 3, 64, True), (1024, 3, 64, True),
+                                              (7, 5, 32, False), (33, 16, 64, True), (10, 1, 16, False),
+                                              (257, 4, 128, True)])
+def test_mat_attention_core_fwd_bwd(K, n_seq, L, D, masked):
+    torch.manual_seed(n_seq + L + D)
+    q = torch.randn(n_seq, L, D, requires_grad=True)
+    k = torch.randn(n_seq, L, D, requires_grad=True)
+    v = torch.randn(n_seq, L, D, requires_grad=True)
+    y_ref = _attention_ref(q, k, v, masked)
+    g = torch.randn_like(y_ref)
+    (y_ref * g).sum().backward()
+    y, probs = K.mat_attention_fwd(dev(q.detach()), dev(k.detach()), dev(v.detach()), masked)
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.detach().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(probs.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)
+    dq, dk, dv = K.mat_attention_bwd(dev(q.detach()), dev(k.detach()), dev(v.detach()), probs, dev(g))
+    np.testing.assert_allclose(dq.cpu().numpy(), q.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dk.cpu().numpy(), k.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dv.cpu().numpy(), v.grad.numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_attention_blocks_match_reference_golden_g5(golden):
+    """SelfAttention / encoder / decoder blocks with the reference's seeded weights -> its recorded outputs."""
+    from ppo_and_friends_amd.networks import attention as at
+    g = golden("g5_attention")
+    x = dev(g["x"]); rep = dev(g["rep"])
+
+    def load(mod, prefix):
+        sd = {k: torch.tensor(g[prefix + k]) for k in mod.state_dict() if k != "mask" and not k.endswith(".mask")}
+        mod.load_state_dict(sd, strict=False)
+        return mod.cuda()
+
+    for tag, masked in (("u", False), ("m", True)):
+        sa = load(at.SelfAttention(64, 1, 3, masked=masked), f"sa_{tag}_")
+        np.testing.assert_allclose(sa(x, x, x).detach().cpu().numpy(), g[f"sa_{tag}_y"], rtol=1e-5, atol=1e-5)
+    enc = load(at.SelfAttentionEncodingBlock(64, 1, 3), "enc_")
+    np.testing.assert_allclose(enc(x).detach().cpu().numpy(), g["enc_y"], rtol=1e-5, atol=2e-5)
+    dec = load(at.SelfAttentionDecodingBlock(64, 1, 3), "dec_")
+    np.testing.assert_allclose(dec(x, rep).detach().cpu().numpy(), g["dec_y"], rtol=1e-5, atol=2e-5)
