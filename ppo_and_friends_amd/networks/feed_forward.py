@@ -90,6 +90,8 @@ class FlatBucketModule(nn.Module):
             p.grad = None
             p.data = flat[o:o + p.numel()].view(p.shape)
             p.grad = grads[o:o + p.numel()].view(p.shape)
+        for b in self.buffers():
+            b.data = b.data.to(device)
         self.flat_params, self.flat_grads = flat, grads
         self.num_params = n
         return self

@@ -1,0 +1,216 @@
+"""
+MATPolicy -- the Multi-Agent-Transformer policy surface (policies/mat_policy.py:24-1086 of the
+reference) on the device rollout buffer.
+
+Same hooks as the reference: agent_grouping = True, one actor_critic network and ONE optimiser
+(summed actor + critic loss, one clip over all parameters: mat_policy.py:677-699), the critic
+encodes the whole agent sequence once and the decoder samples the agents autoregressively during
+rollouts (:441-519), evaluation is teacher-forced with the shifted one-hot action block (:378-439),
+use_huber_loss defaults to True (:27-29).
+
+Layout: a dataset row is one env step of one env with its A agents side by side
+([A, .] items of PPOSharedEpisodeDataset); tensors are [rows, A, .] on the device.  The attention
+core is the f32-MFMA kernel K9; linears / LayerNorm / GELU are torch-ROCm.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as t_func
+
+from ..networks.multi_agent_transformer import MATActorCritic
+from ..spaces import get_space_shape
+from ..utils import mpi_utils
+from ..utils.episode_info import PPODataset, RolloutBuffer
+from .ppo_policy import FlatAdam, PPOPolicy
+
+
+class MATPolicy(PPOPolicy):
+
+    def __init__(self, ac_network=MATActorCritic, mat_kw_args={}, use_huber_loss=True, **kw_args):
+        super().__init__(ac_network=ac_network, mat_kw_args=mat_kw_args, use_huber_loss=use_huber_loss, **kw_args)
+        self.agent_grouping = True
+        self.expanded_actor_space = False
+        if get_space_shape(self.actor_obs_space) != get_space_shape(self.critic_obs_space):
+            # mat_policy.py:75-79: the actor then sees the critic's (wider) observation
+            self.expanded_actor_space = True
+            self.have_step_constraints = True
+            self.have_reset_constraints = True
+            self.actor_obs_space = self.critic_obs_space
+        if self.enable_icm:
+            raise NotImplementedError("ICM with MAT (agent-shared ICM) is not built")
+
+    # ------------------------------------------------------------------ setup
+    def finalize(self, status_dict, device):
+        """mat_policy.py:191-245."""
+        if len(self.agent_ids) == 0:
+            self.register_agent("agent0")
+        self._env_agent_index = {a: i for i, a in enumerate(self.agent_ids)}    # env's agent order
+        self.agent_idxs = np.arange(len(self.agent_ids))
+        self.num_agents = self.agent_idxs.size
+        self.device = torch.device(device)
+        self._initialize_networks(**self.network_args)
+        for c in (self.lr, self.icm_lr, self.entropy_weight, self.intr_reward_weight):
+            c.finalize(status_dict)
+        if self.have_bootstrap_clip:
+            self.bootstrap_clip[0].finalize(status_dict)
+            self.bootstrap_clip[1].finalize(status_dict)
+        self.actor_critic_optim = FlatAdam(self.actor_critic, self.lr(), eps=1e-5)
+        self.icm_optim = None
+        self.shuffle_agent_ids()
+
+    def _initialize_networks(self, ac_network, enable_icm, icm_network, mat_kw_args, icm_kw_args, **kw_args):
+        """mat_policy.py:88-176."""
+        if not issubclass(ac_network, MATActorCritic):
+            raise TypeError(f"ac_network for MATPolicy must be a subtype of MATActorCritic, got {ac_network}")
+        self.actor_critic = ac_network(name="actor_critic", obs_space=self.critic_obs_space,
+                                       action_space=self.action_space, num_agents=len(self.agent_ids),
+                                       test_mode=self.test_mode,
+                                       seed=self.random_seed + 7919 * mpi_utils.get_rank(), **mat_kw_args)
+        self.actor_critic.to(self.device)
+        mpi_utils.broadcast_model_parameters(self.actor_critic)
+        self.actor = self.actor_critic.actor
+        self.critic = self.actor_critic.critic
+        self.policy_params = self.actor_critic.flat_params
+        self.policy_grads = self.actor_critic.flat_grads
+
+    def agent_slot_order(self):
+        """Index of the env's agent that sits in each slot of the grouped rows (after the MAT shuffles)."""
+        return np.array([self._env_agent_index[a] for a in self.agent_ids], dtype=np.int64)
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self.actor_critic.to(self.device)
+
+    def eval(self):
+        self.actor_critic.eval()
+
+    def train(self):
+        self.actor_critic.train()
+
+    # ---------------------------------------------------------------- rollout
+    def initialize_dataset(self):
+        """mat_policy.py:179-189 (PPOSharedEpisodeDataset: rows of [A, .])."""
+        self.dataset = PPODataset(device=self.device, action_dtype=self.action_dtype, sequence_length=1)
+        self.dataset.shared = True
+
+    def initialize_episodes(self, env_batch_size, status_dict, ts_per_rollout=None):
+        if ts_per_rollout is None:
+            raise ValueError("initialize_episodes needs ts_per_rollout (total steps over all envs)")
+        T = int(ts_per_rollout) // int(env_batch_size)
+        self.env_batch_size = int(env_batch_size)
+        A = len(self.agent_ids)
+        obs_dim = int(np.prod(get_space_shape(self.actor_obs_space)))
+        cobs_dim = int(np.prod(get_space_shape(self.critic_obs_space)))
+        if self.buffer is None or (self.buffer.T, self.buffer.C) != (T, self.env_batch_size):
+            self.buffer = RolloutBuffer(T, self.env_batch_size, obs_dim, cobs_dim, self.action_dim,
+                                        self.action_dtype, self.device, keep_next_observations=False,
+                                        agents_per_row=A)
+        else:
+            self.buffer.end_kind.zero_()
+            self.buffer.fixed_length = True
+            self.buffer.steps_written = 0
+        self._t = 0
+        self.dataset.attach(self.buffer, self.gamma, self.lambd, self.get_bs_clip_range(None), self.use_gae)
+
+    def fused_step_unsupported_reason(self):
+        return "MAT policies use the torch-ROCm + K9 path"
+
+    def _get_tokened_action_block(self, batch_size):
+        """mat_policy.py:308-344."""
+        A = len(self.agent_ids)
+        if self.action_dtype == "continuous":
+            return torch.zeros((batch_size, A, self.action_pred_size), device=self.device)
+        blk = torch.zeros((batch_size, A, self.action_pred_size + 1), device=self.device)
+        blk[:, 0, 0] = 1
+        return blk
+
+    def _get_autoregressive_actions(self, encoded_obs):
+        """mat_policy.py:441-519: A decoder passes, agent i conditioned on the actions of agents < i."""
+        B, A = encoded_obs.shape[0], len(self.agent_ids)
+        block = self._get_tokened_action_block(B)
+        off = 1 if self.action_dtype == "discrete" else 0
+        adt = torch.int64 if self.action_dtype == "discrete" else torch.float32
+        out_a = torch.zeros((B, A, self.action_dim), dtype=adt, device=self.device)
+        out_raw = torch.zeros_like(out_a)
+        out_lp = torch.zeros((B, A, 1), dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            for i in range(A):
+                pred = self.actor(block, encoded_obs)[:, i, :].contiguous()
+                action, raw_action, log_prob = self.actor.distribution.sample_distribution(pred)
+                out_a[:, i, :] = action.reshape(B, self.action_dim)
+                out_raw[:, i, :] = raw_action.reshape(B, self.action_dim)
+                out_lp[:, i, :] = log_prob.reshape(B, 1)
+                if i + 1 < A:
+                    if self.action_dtype == "discrete":
+                        block[:, i + 1, off:] = t_func.one_hot(action.reshape(B), num_classes=self.action_pred_size).float()
+                    else:
+                        block[:, i + 1, off:] = action.reshape(B, -1)
+        return out_a, out_raw, out_lp
+
+    def get_rollout_actions(self, obs):
+        """
+        mat_policy.py:587-626.  Device tensors arrive grouped, [E, A, O], and grouped tensors are
+        returned ([E, A, .]); numpy arrives in the reference's [A, E, O] and is swapped like there.
+        """
+        as_numpy = not torch.is_tensor(obs)
+        t_obs = self._to_device(np.swapaxes(obs, 0, 1) if as_numpy else obs)
+        with torch.no_grad():
+            encoded_obs, _ = self.critic(t_obs)
+        actions, raw_actions, log_probs = self._get_autoregressive_actions(encoded_obs)
+        if as_numpy:
+            return (torch.swapaxes(raw_actions, 0, 1).cpu().numpy(), torch.swapaxes(actions, 0, 1).cpu().numpy(),
+                    torch.swapaxes(log_probs, 0, 1).detach())
+        return raw_actions, actions, log_probs
+
+    def get_critic_values(self, obs):
+        """mat_policy.py:660-675."""
+        _, values = self.critic(obs)
+        return values
+
+    # ----------------------------------------------------------------- update
+    def evaluate(self, batch_critic_obs, batch_obs, batch_actions):
+        """mat_policy.py:378-439,628-658 -> values [B,A,1], log_probs [B,A,1], entropy [B,A,1]."""
+        B, A = batch_critic_obs.shape[0], len(self.agent_ids)
+        block = self._get_tokened_action_block(B)
+        if self.action_dtype == "discrete":
+            acts = batch_actions.reshape(B, A)
+            block[:, 1:, 1:] = t_func.one_hot(acts, num_classes=self.action_pred_size)[:, :-1, :].float()
+        else:
+            block[:, 1:, :] = batch_actions[:, :-1, :]
+        values, pred = self.actor_critic(batch_critic_obs, block)
+        pred = pred.reshape(-1, self.action_pred_size)
+        flat_actions = batch_actions.reshape(-1, self.action_dim)
+        log_probs, entropy = self.actor.distribution.get_log_probs_and_entropy(pred, flat_actions)
+        return values, log_probs.reshape(B, A, -1), entropy.reshape(B, A, -1)
+
+    def optimizer_step(self, grad_scale):
+        self.actor_critic_optim.step(grad_scale=grad_scale, max_norm=self.gradient_clip)
+
+    def update_weights(self, actor_loss, critic_loss):
+        """mat_policy.py:677-699."""
+        if self.frozen:
+            return
+        self.policy_grads.zero_()
+        (actor_loss + critic_loss).backward()
+        mpi_utils.allreduce_sum_(self.policy_grads)
+        self.optimizer_step(1.0 / mpi_utils.get_num_procs())
+
+    def update_learning_rate(self):
+        if not self.frozen:
+            self.actor_critic_optim.set_lr(self.lr())
+
+    def save(self, save_path, tag="latest"):
+        import os
+        path = os.path.join(save_path, f"{self.name}-policy", tag)
+        os.makedirs(path, exist_ok=True)
+        self.actor_critic.save(path)                     # actor_critic_<rank>.model, as the reference
+        torch.save(self.actor_critic_optim.state_dict(),
+                   os.path.join(path, f"actor_critic_optim_{mpi_utils.get_rank()}"))
+
+    def load(self, load_path, tag="latest"):
+        import os
+        path = os.path.join(load_path, f"{self.name}-policy", tag)
+        self.actor_critic.load(path)
+        f = os.path.join(path, f"actor_critic_optim_{mpi_utils.get_rank()}")
+        if not os.path.exists(f):
+            f = os.path.join(path, "actor_critic_optim_0")
+        self.actor_critic_optim.load_state_dict(torch.load(f, map_location="cpu"))

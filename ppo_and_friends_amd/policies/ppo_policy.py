@@ -462,6 +462,11 @@ class PPOPolicy:
         self.actor_optim.step(grad_scale=scale, max_norm=self.gradient_clip)
         self.critic_optim.step(grad_scale=scale, max_norm=self.gradient_clip)
 
+    def optimizer_step(self, grad_scale):
+        """clip + Adam for both networks (the tail of update_weights, on already averaged-by-sum gradients)."""
+        self.actor_optim.step(grad_scale=grad_scale, max_norm=self.gradient_clip)
+        self.critic_optim.step(grad_scale=grad_scale, max_norm=self.gradient_clip)
+
     def update_learning_rate(self):
         """ppo_policy.py:1073-1084."""
         if self.frozen:

@@ -8,11 +8,12 @@ from .ppo_policy import PPOPolicy
 
 def generate_policy(policy_name, policy_class, actor_observation_space, critic_observation_space,
                     action_space, test_mode, envs_per_proc, **kw_args):
+    from .mat_policy import MATPolicy
     if policy_class is None:
         policy_class = PPOPolicy
-    if policy_class is not PPOPolicy:
-        raise NotImplementedError(f"policy class {policy_class} is not on this round's hot path "
-                                  "(MATPolicy: SURVEY.md §8 C5, see DESIGN.md)")
+    if policy_class not in (PPOPolicy, MATPolicy):
+        raise NotImplementedError(f"policy_class {policy_class} is of unsupported type; "
+                                  "supported: PPOPolicy, MATPolicy (policies/utils.py:45-52)")
     return policy_class(name=policy_name, action_space=action_space,
                         actor_observation_space=actor_observation_space,
                         critic_observation_space=critic_observation_space,

@@ -167,7 +167,8 @@ class PPO:
     def get_policy_values(self, policy_id, critic_obs):
         """ppo.py:1030-1075 + get_denormalized_values :1143-1167."""
         with torch.no_grad():
-            v = self.policies[policy_id].get_critic_values(critic_obs).reshape(-1)
+            v = self.policies[policy_id].get_critic_values(critic_obs)
+            v = v.reshape(v.shape[:-1]).contiguous()          # [rows] or [rows, A]
             if self.normalize_values:
                 v = self.value_normalizers[policy_id].denormalize(v)
         return v
@@ -201,6 +202,15 @@ class PPO:
         fused_step = (self.update_mode != "torch" and self.device.type == "cuda"
                       and pol.fused_step_unsupported_reason() == "")
         vn = self.value_normalizers[policy_id] if self.normalize_values else None
+        grouped = pol.agent_grouping
+        if grouped:
+            # MAT: rows are envs, agents side by side in the policy's (shuffled) slot order
+            # (ppo.py:1643-1644, 753-770): [A*E, .] agent-major env tensors -> [E, A, .]
+            pol.shuffle_agent_ids()
+            order = torch.as_tensor(pol.agent_slot_order(), device=self.device)
+            n_ag = order.numel()
+            group = lambda x: x.reshape((n_ag, n_envs) + tuple(x.shape[1:]))[order].transpose(0, 1).contiguous()
+            ungroup = lambda x: x.transpose(0, 1)[torch.argsort(order)].reshape((n_ag * n_envs,) + tuple(x.shape[2:]))
         intr_buf = torch.zeros(T, E, dtype=torch.float32, device=self.device) if pol.enable_icm else None
         if pol.enable_icm:
             may_end_early = True          # bootstrap rewards carry the "surprise" term: dense end table
@@ -215,6 +225,17 @@ class PPO:
                     intr_buf[t] = pol.get_intrinsic_reward(obs, term_obs, action)
                     reward = reward + intr_buf[t]
                 pol.finish_step(t, reward, term_obs)
+            elif grouped:
+                g_obs, g_cobs = group(obs), group(critic_obs)
+                raw_action, action, log_prob = pol.get_rollout_actions(g_cobs if pol.expanded_actor_space else g_obs)
+                value = self.get_policy_values(policy_id, g_cobs)
+                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(ungroup(action))
+                if self.ext_reward_weight != 1.0:
+                    reward = reward * self.ext_reward_weight
+                buf.write_step(t, slice(0, E), g_cobs, g_cobs if pol.expanded_actor_space else g_obs, None,
+                               raw_action, action, value, log_prob, group(reward))
+                pol._t = t + 1
+                terminated, truncated = terminated[:n_envs], truncated[:n_envs]   # agents of an env end together
             else:
                 raw_action, action, log_prob = pol.get_rollout_actions(obs)
                 value = self.get_policy_values(policy_id, critic_obs)
@@ -240,7 +261,7 @@ class PPO:
         # bootstrap values: V(next obs).  For ends before the last row the next
         # observation's value is the value logged at t+1 (same critic, same
         # normaliser state during a rollout); the last row needs one more pass.
-        next_value = self.get_policy_values(policy_id, critic_obs)
+        next_value = self.get_policy_values(policy_id, group(critic_obs) if grouped else critic_obs)
         if may_end_early:
             buf.boot_value[:-1].copy_(buf.values[1:])
             buf.boot_value[T - 1].copy_(next_value)
@@ -338,21 +359,18 @@ class PPO:
             return
         values, log_probs, entropy = pol.evaluate(mb["critic_obs"], mb["obs"], mb["raw_actions"])
         dataset.scatter_values(perm_batch, values)
-        lp = log_probs.reshape(-1)
+        lp, ent = log_probs.reshape(-1), entropy.reshape(-1)
         sc, dlp, dent, dval = K.ppo_loss_fwd_bwd(
-            lp.detach(), mb["log_probs"], mb["advantages"], entropy.detach(), values.detach().reshape(-1),
-            rtg, self.normalize_adv, pol.surr_clip, pol.entropy_weight(), pol.kl_loss_weight,
-            pol.use_huber_loss, 10.0)
+            lp.detach(), mb["log_probs"].reshape(-1), mb["advantages"].reshape(-1), ent.detach(),
+            values.detach().reshape(-1), rtg.reshape(-1), self.normalize_adv, pol.surr_clip,
+            pol.entropy_weight(), pol.kl_loss_weight, pol.use_huber_loss, 10.0)
         pol.policy_grads.zero_()
-        torch.autograd.backward([lp, entropy, values.reshape(-1)], [dlp, dent, dval])
+        torch.autograd.backward([lp, ent, values.reshape(-1)], [dlp, dent, dval])
         totals[:8] += sc
         totals[8] += 1.0
 
     def _optimizer_step(self, policy_id):
-        pol = self.policies[policy_id]
-        scale = 1.0 / mpi_utils.get_num_procs()
-        pol.actor_optim.step(grad_scale=scale, max_norm=pol.gradient_clip)
-        pol.critic_optim.step(grad_scale=scale, max_norm=pol.gradient_clip)
+        self.policies[policy_id].optimizer_step(1.0 / mpi_utils.get_num_procs())
 
     def _ppo_batch_train(self, data_loader, policy_id):
         """ppo.py:2274-2485: one epoch of shuffled mini-batches; fills status_dict like :2478-2485."""
@@ -485,7 +503,9 @@ class PPO:
         the raw data inside every mini-batch (ppo.py:2299-2303 -> stats.py:47-50).
         """
         N = perm.numel()
-        rtg = ds.buffer.rewards_to_go.view(-1)[ds.row_map.long()[perm]]
+        A = ds.buffer.A                      # grouped rows carry A values each: a mini-batch holds B*A of them
+        rtg = ds.buffer.rewards_to_go.view(ds.buffer.num_transitions, A)[ds.row_map.long()[perm]].reshape(-1)
+        N, B = N * A, B * A
         nb = (N + B - 1) // B
         pad = nb * B - N
         x = rtg.double()

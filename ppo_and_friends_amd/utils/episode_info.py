@@ -35,25 +35,32 @@ class RolloutBuffer:
     """Device-resident `[T, C, .]` transition store for one policy (C = num_agents * num_envs)."""
 
     def __init__(self, T, C, obs_dim, critic_obs_dim, action_dim, action_dtype, device,
-                 keep_next_observations=False):
-        self.T, self.C = int(T), int(C)
+                 keep_next_observations=False, agents_per_row=1):
+        """
+        agents_per_row = A > 1 is the layout of agent-grouped policies (MAT): a row is one env and
+        carries its A agents side by side -- the [N, A, .] items of PPOSharedEpisodeDataset
+        (utils/episode_info.py:584-637,1058-1084).  Scalar fields are then [T, C, A]; the scans see
+        them as T x (C*A) columns, the episode bookkeeping (end_kind, row_map) stays per env row.
+        """
+        self.T, self.C, self.A = int(T), int(C), int(agents_per_row)
         self.device = torch.device(device)
         self.action_dtype = action_dtype
         f32 = dict(dtype=torch.float32, device=self.device)
         adt = torch.int64 if action_dtype in ("discrete", "multi-discrete") else torch.float32
-        self.observations = torch.zeros(T, C, obs_dim, **f32)
-        self.critic_observations = torch.zeros(T, C, critic_obs_dim, **f32)
-        self.next_observations = torch.zeros(T, C, obs_dim, **f32) if keep_next_observations else None
-        self.actions = torch.zeros(T, C, action_dim, dtype=adt, device=self.device)
-        self.raw_actions = torch.zeros(T, C, action_dim, dtype=adt, device=self.device)
-        self.values = torch.zeros(T, C, **f32)
-        self.log_probs = torch.zeros(T, C, **f32)
-        self.rewards = torch.zeros(T, C, **f32)
+        ag = () if self.A == 1 else (self.A,)
+        self.observations = torch.zeros((T, C) + ag + (obs_dim,), **f32)
+        self.critic_observations = torch.zeros((T, C) + ag + (critic_obs_dim,), **f32)
+        self.next_observations = torch.zeros((T, C) + ag + (obs_dim,), **f32) if keep_next_observations else None
+        self.actions = torch.zeros((T, C) + ag + (action_dim,), dtype=adt, device=self.device)
+        self.raw_actions = torch.zeros((T, C) + ag + (action_dim,), dtype=adt, device=self.device)
+        self.values = torch.zeros((T, C) + ag, **f32)
+        self.log_probs = torch.zeros((T, C) + ag, **f32)
+        self.rewards = torch.zeros((T, C) + ag, **f32)
         self.end_kind = torch.zeros(T, C, dtype=torch.int8, device=self.device)
-        self.boot_value = torch.zeros(T, C, **f32)
-        self.boot_reward = torch.zeros(T, C, **f32)
-        self.advantages = torch.zeros(T, C, **f32)
-        self.rewards_to_go = torch.zeros(T, C, **f32)
+        self.boot_value = torch.zeros((T, C) + ag, **f32)
+        self.boot_reward = torch.zeros((T, C) + ag, **f32)
+        self.advantages = torch.zeros((T, C) + ag, **f32)
+        self.rewards_to_go = torch.zeros((T, C) + ag, **f32)
         self.fixed_length = True          # flips when an end is recorded before row T-1
         self.steps_written = 0
         # persistent across rollouts (hipGraph replays hold these addresses)
@@ -77,9 +84,9 @@ class RolloutBuffer:
         adt = self.actions.dtype
         self.actions[t, cols].copy_(as_t(actions, adt).reshape(self.actions[t, cols].shape))
         self.raw_actions[t, cols].copy_(as_t(raw_actions, adt).reshape(self.raw_actions[t, cols].shape))
-        self.values[t, cols].copy_(as_t(values, torch.float32).reshape(-1))
-        self.log_probs[t, cols].copy_(as_t(log_probs, torch.float32).reshape(-1))
-        self.rewards[t, cols].copy_(as_t(rewards, torch.float32).reshape(-1))
+        self.values[t, cols].copy_(as_t(values, torch.float32).reshape(self.values[t, cols].shape))
+        self.log_probs[t, cols].copy_(as_t(log_probs, torch.float32).reshape(self.log_probs[t, cols].shape))
+        self.rewards[t, cols].copy_(as_t(rewards, torch.float32).reshape(self.rewards[t, cols].shape))
         self.steps_written = max(self.steps_written, t + 1)
 
     def _as_tensor(self, x, dtype):
@@ -107,14 +114,18 @@ class RolloutBuffer:
     def compute_advantages(self, gamma, lambd, bootstrap_clip, use_gae, adv_only=False, timing_events=None):
         """All GAE + rewards-to-go scans of the rollout: one launch (K1)."""
         rtg_out = torch.empty_like(self.rewards_to_go) if adv_only else self.rewards_to_go
+        T, cols = self.T, self.C * self.A
+        v2 = lambda t: t.view(T, cols)
         if self.fixed_length:
-            K.gae_rtg_tmajor(self.rewards, self.values, self.boot_value[self.T - 1],
-                             self.boot_reward[self.T - 1], None, gamma, lambd, bootstrap_clip,
-                             use_gae, self.advantages, rtg_out, timing_events=timing_events)
+            K.gae_rtg_tmajor(v2(self.rewards), v2(self.values), self.boot_value[T - 1].reshape(-1),
+                             self.boot_reward[T - 1].reshape(-1), None, gamma, lambd, bootstrap_clip,
+                             use_gae, v2(self.advantages), v2(rtg_out), timing_events=timing_events)
         else:
-            K.gae_rtg_tmajor(self.rewards, self.values, self.boot_value, self.boot_reward,
-                             self.end_kind, gamma, lambd, bootstrap_clip, use_gae,
-                             self.advantages, rtg_out, timing_events=timing_events)
+            ek = self.end_kind if self.A == 1 else \
+                self.end_kind.unsqueeze(-1).expand(T, self.C, self.A).contiguous().view(T, cols)
+            K.gae_rtg_tmajor(v2(self.rewards), v2(self.values), v2(self.boot_value), v2(self.boot_reward),
+                             ek, gamma, lambd, bootstrap_clip, use_gae,
+                             v2(self.advantages), v2(rtg_out), timing_events=timing_events)
 
     def build_row_map(self):
         """
@@ -178,13 +189,12 @@ class _ValuesProxy:
         self._d = dataset
 
     def __setitem__(self, idx, src):
-        idx = self._d._idx_tensor(idx)
-        K.scatter_rows_f32(src.detach().reshape(-1).contiguous().float(), idx,
-                           self._d.buffer.values.view(-1), self._d.row_map)
+        self._d.scatter_values(self._d._idx_tensor(idx), src)
 
     def __getitem__(self, idx):
         idx = self._d._idx_tensor(idx)
-        return self._d.buffer.values.view(-1)[self._d.row_map[idx].long()]
+        b = self._d.buffer
+        return b.values.view((b.num_transitions,) + tuple(b.values.shape[2:]))[self._d.row_map[idx].long()]
 
     def __len__(self):
         return len(self._d)
@@ -243,6 +253,7 @@ class PPODataset:
 
     # flat views in the reference's order (materialised on demand; not used by the hot loop)
     def _flat(self, t):
+        """[T, C, ...] -> [N, ...] in the reference's dataset order (rows of grouped policies keep [A, .])."""
         return t.reshape((self.buffer.num_transitions,) + tuple(t.shape[2:]))[self.row_map.long()]
 
     @property
@@ -293,8 +304,13 @@ class PPODataset:
 
     def scatter_values(self, perm_batch, values):
         """ppo.py:2340."""
-        K.scatter_rows_f32(values.detach().reshape(-1).contiguous(), perm_batch,
-                           self.buffer.values.view(-1), self.row_map)
+        b = self.buffer
+        if b.A == 1:
+            K.scatter_rows_f32(values.detach().reshape(-1).contiguous().float(), perm_batch,
+                               b.values.view(-1), self.row_map)
+        else:   # grouped rows [A]: one row of A values per dataset position
+            rows = self.row_map[perm_batch].long()
+            b.values.view(b.num_transitions, b.A)[rows] = values.detach().reshape(-1, b.A).float()
 
 
 class EpisodeInfo:

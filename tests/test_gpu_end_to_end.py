@@ -314,3 +314,51 @@ def test_icm_rollout_rewards_and_training_match_cpu_port(update_mode):
     w = torch.cat([p.detach().cpu().reshape(-1) for p in pol.icm_model.parameters()]).numpy()
     w_ref = torch.cat([p.detach().reshape(-1) for p in cpu.icm.parameters()]).numpy()
     np.testing.assert_allclose(w, w_ref, rtol=1e-4, atol=2e-5)
+
+
+def test_mat_policy_rollout_and_update_match_cpu_port():
+    """
+    SURVEY.md §8 C5 shape: MATPolicy (3 agents, embedding 64, 1 block, 1 head, Discrete(5), critic view
+    'local').  Autoregressive rollout, shared-episode dataset ([N, A, .] rows), teacher-forced evaluation,
+    one optimiser over actor + critic, Huber value loss -- against oracle/mat_oracle.CpuMATPPO.
+    """
+    from ppo_and_friends_amd.ppo import PPO, PermutationLoader
+    from ppo_and_friends_amd.policies.mat_policy import MATPolicy
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    from oracle import mat_oracle
+    dev = torch.device("cuda", 0)
+    A, E, T, O, NA, B, seed = 3, 8, 12, 18, 5, 32, 6
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=41, num_agents=A)
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    ppo = PPO(env_gen, {"mat": (MATPolicy, sp, sp, Discrete(NA), {})}, device=dev, random_seed=seed,
+              envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=2)
+    pol = ppo.policies["mat"]
+    assert pol.agent_grouping and sum(p.numel() for p in pol.actor_critic.parameters()) == 78058
+    cpu = mat_oracle.CpuMATPPO(O, NA, A, batch_size=B, seed=seed)
+    cpu.ac.load_state_dict({k: v.detach().cpu().clone() for k, v in pol.actor_critic.state_dict().items()},
+                           strict=False)
+    cpu.loader_generator = torch.Generator().manual_seed(seed)
+    ds = ppo.rollout()
+    env, buf = ppo.env, pol.buffer
+    assert len(ds) == E * T and ds.observations.shape == (E * T, A, O)
+    order = pol.agent_slot_order()
+    obs_t = env.obs_table.view(T + 1, A, E, O)[:, order].transpose(1, 2).cpu().numpy()       # [T+1,E,A,O]
+    rew_t = env.reward_table.view(T, A, E)[:, order].transpose(1, 2).cpu().numpy()
+    ref = cpu.rollout(obs_t, rew_t, buf.actions[..., 0].cpu().numpy())
+    tol = dict(rtol=2e-5, atol=2e-5)
+    np.testing.assert_array_equal(ds.observations.cpu().numpy(), ref.obs.numpy())
+    np.testing.assert_allclose(ds.log_probs.cpu().numpy(), ref.logp.numpy(), **tol)
+    np.testing.assert_allclose(ds.values[torch.arange(E * T)].cpu().numpy(), ref.values.numpy(), **tol)
+    np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), ref.rtg.numpy(), **tol)
+    np.testing.assert_allclose(ds.advantages.cpu().numpy(), ref.adv.numpy(), **tol)
+    loader = PermutationLoader(pol.dataset, B, ppo.loader_generator)
+    pol.train()
+    for _ in range(2):
+        ppo._ppo_batch_train(loader, "mat")
+        r = cpu.train_epoch()
+        for k in ("actor loss", "critic loss", "kl avg", "weighted entropy"):
+            np.testing.assert_allclose(ppo.status_dict["mat"][k], r[k], rtol=5e-5, atol=5e-6, err_msg=k)
+    w = torch.cat([p.detach().cpu().reshape(-1) for p in pol.actor_critic.parameters()]).numpy()
+    w_ref = torch.cat([p.detach().reshape(-1) for p in cpu.ac.parameters()]).numpy()
+    np.testing.assert_allclose(w, w_ref, rtol=2e-4, atol=3e-5)

@@ -154,3 +154,22 @@ def test_c_oracle_tmajor_matches_numpy_oracle(golden, tag):
     d = eo.rollout_to_dataset(rew, val, boot, boot, ek)
     np.testing.assert_array_equal(adv[d["flat_t"], d["flat_e"]], d["adv"])
     np.testing.assert_array_equal(rtg[d["flat_t"], d["flat_e"]], d["rtg"])
+
+
+def test_attention_oracle_matches_golden_g5(golden):
+    """oracle/mat_oracle.py attention blocks, loaded with the reference's seeded weights -> its outputs."""
+    import torch
+    from oracle import mat_oracle as mo
+    g = golden("g5_attention")
+    x, rep = torch.tensor(g["x"]), torch.tensor(g["rep"])
+
+    def load(mod, prefix):
+        mod.load_state_dict({k: torch.tensor(g[prefix + k]) for k in mod.state_dict()
+                             if not k.endswith("mask")}, strict=False)
+        return mod
+
+    for tag, masked in (("u", False), ("m", True)):
+        sa = load(mo.SelfAttention(64, 1, 3, masked=masked), f"sa_{tag}_")
+        np.testing.assert_array_equal(sa(x, x, x).detach().numpy(), g[f"sa_{tag}_y"])
+    np.testing.assert_array_equal(load(mo.EncodingBlock(64, 1, 3), "enc_")(x).detach().numpy(), g["enc_y"])
+    np.testing.assert_array_equal(load(mo.DecodingBlock(64, 1, 3), "dec_")(x, rep).detach().numpy(), g["dec_y"])
