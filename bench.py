@@ -74,10 +74,11 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-envs", type=int, default=256)
     p.add_argument("--no-saturating", action="store_true")
-    p.add_argument("--config", default="C2", choices=["C2", "C3", "C4"],
+    p.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
                    help="C2 (default, the metric's config) | C3 dims: HalfCheetah O=17, Box(6), actor 128^3 / "
                         "critic 256^3, E=2048 (no ICM / wrappers yet) | C4 dims: SimpleSpread MAPPO, 3 agents, "
-                        "O=18, O_c=54, Discrete(5), E=1024 per rank")
+                        "O=18, O_c=54, Discrete(5), E=1024 per rank | C5 dims: same env, MATPolicy (embedding 64, "
+                        "1 block, 1 head, critic view local), E=1024 per rank")
     return p.parse_args()
 
 
@@ -111,11 +112,19 @@ def main():
         workload = (f"C4 dims (MPE simple_spread MAPPO: 3 agents share one policy, O=18, O_c=54, Discrete(5), "
                     f"actor 128^3, critic 256^3), envs_per_proc={E}, ts_per_rollout={T}")
 
+    policy_class = None
+    if args.config == "C5":
+        from ppo_and_friends_amd.policies.mat_policy import MATPolicy
+        E, O, NA, A, critic_view = (1024 if args.envs == 4096 else args.envs), 18, 5, 3, "local"
+        act_space, policy_class, pargs = Discrete(NA), MATPolicy, {}
+        workload = (f"C5 dims (MPE simple_spread MATPolicy: 3 agents, O=18, Discrete(5), embedding 64, 1 block, "
+                    f"1 head, attention core on f32 MFMA), envs_per_proc={E}, ts_per_rollout={T}")
+
     env_gen = lambda: SyntheticFixedLengthEnv(E, O, act_space, T, device, reward="ones" if args.config == "C2" else "uniform",
                                               seed=1234, rank=rank, num_agents=A, critic_view=critic_view)
     obs_space = Box(-np.inf, np.inf, (O,), np.float32)
     cobs_space = Box(-np.inf, np.inf, (O * A if critic_view == "policy" else O,), np.float32)
-    settings = {"cartpole": (obs_space, cobs_space, act_space, pargs)}
+    settings = {"cartpole": (policy_class, obs_space, cobs_space, act_space, pargs)}
     ppo = PPO(env_gen, settings, device=device, random_seed=1, envs_per_proc=E, ts_per_rollout=T,
               batch_size=args.batch_size, epochs_per_iter=args.epochs, use_graphs=not args.no_graphs)
     pol = ppo.policies["cartpole"]
