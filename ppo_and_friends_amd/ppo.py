@@ -62,10 +62,12 @@ class PermutationLoader:
     seeded reference run can be replayed) cut into batch_size slices.
     """
 
-    def __init__(self, dataset, batch_size, generator=None):
+    def __init__(self, dataset, batch_size, generator=None, prefetch_cache=None):
         self.dataset = dataset
         self.batch_size = int(batch_size)
         self.generator = generator
+        # {"n": N, "perm": tensor}: the NEXT draw of `generator`, made early (see prefetch())
+        self.prefetch_cache = prefetch_cache if prefetch_cache is not None else {}
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
@@ -78,15 +80,44 @@ class PermutationLoader:
         RandomSampler draws the permutation (from a fresh generator seeded off the
         global RNG when no generator was given).
         """
+        n = len(self.dataset)
+        c = self.prefetch_cache
+        if c.get("n") == n and c.get("perm") is not None:
+            perm, c["perm"] = c["perm"], None
+        else:
+            perm = self._draw(n)
+        # the staging buffer is reused by the next draw: the device copy is made (and completed) here
+        return perm.to(self.dataset.device, non_blocking=False)
+
+    def _draw(self, n):
         g = self.generator
         torch.empty((), dtype=torch.int64).random_(generator=g)          # _BaseDataLoaderIter base seed
         if g is None:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
             g = torch.Generator().manual_seed(seed)
-        n = len(self.dataset)
-        perm = torch.randperm(n, generator=g)
+        # drawn into a pinned staging buffer that is allocated once (allocating pinned memory
+        # synchronises with the device and would serialise the prefetch behind the running epoch)
+        c = self.prefetch_cache
+        buf = c.get("pinned")
+        if buf is None or buf.numel() != n:
+            buf = torch.empty(n, dtype=torch.int64, pin_memory=torch.cuda.is_available())
+            c["pinned"] = buf
+        torch.randperm(n, generator=g, out=buf)
         torch.randperm(n, generator=g)       # RandomSampler's trailing `randperm(n)[:num_samples % n]` draw
-        return perm.to(self.dataset.device, non_blocking=True)
+        return buf
+
+    def prefetch(self):
+        """
+        Draw the generator's NEXT permutation now (while the GPU is busy with the current epoch).  The
+        draw order of the generator is unchanged -- the next epoch_permutation() call, whoever makes it,
+        receives exactly this draw -- so seeded runs replay as before.  Only for a dedicated generator.
+        """
+        if self.generator is None:
+            return
+        c = self.prefetch_cache
+        n = len(self.dataset)
+        if c.get("perm") is None or c.get("n") != n:
+            c["n"], c["perm"] = n, self._draw(n)
 
     def __iter__(self):
         perm = self.epoch_permutation()
@@ -124,6 +155,7 @@ class PPO:
         # "fused": K12 kernels (MLP policies); "torch": torch-ROCm MLPs + K2..K11; "auto": fused when covered
         self.update_mode = update_mode
         self._fused = {}
+        self._perm_cache = {}
         self.verbose = verbose
         self.random_seed = 0 if random_seed is None else int(random_seed)
         rank = mpi_utils.get_rank()
@@ -326,7 +358,7 @@ class PPO:
             if pol.frozen:
                 continue
             pol.train()
-            loader = PermutationLoader(pol.dataset, self.batch_size, self.loader_generator)
+            loader = PermutationLoader(pol.dataset, self.batch_size, self.loader_generator, self._perm_cache)
             for epoch_idx in range(self.epochs_per_iter):
                 if epoch_idx > 0 and self.recalc_advantages:
                     loader.dataset.recalculate_advantages()
@@ -383,7 +415,8 @@ class PPO:
         fused = self._fused_updater(policy_id, B)
         if fused is not None:
             fused.begin_epoch(perm)
-            fused.run_epoch()
+            fused.run_epoch()                      # enqueued asynchronously
+            data_loader.prefetch()                 # next shuffle drawn on the host while the GPU works
             self._publish_epoch_stats(policy_id, fused.end_epoch())
             return
         n_full, tail = N // B, N % B

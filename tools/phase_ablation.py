@@ -14,12 +14,16 @@ ppo.rollout(); pol=ppo.policies["p"]
 loader=PermutationLoader(pol.dataset,256,ppo.loader_generator)
 f=ppo._fused_updater("p",256); f.begin_epoch(loader.epoch_permutation())
 args=f._args_for(256)
-for dbg in (0,7,7+8,7+16,7+32,7+64,7+128,7+256,7+8+16+32+64+128+256):
+for dbg in (0,1,2,3,4,7,511):
     os.environ["PPOAF_DEBUG"]=str(dbg)
-    for _ in range(20): K.ppo_update_fwd_bwd(args)
-    torch.cuda.synchronize()
-    e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(200): K.ppo_update_fwd_bwd(args)
-    e1.record(); torch.cuda.synchronize()
-    print("debug=%d  fwd_bwd kernel %.2f us/launch (back-to-back, same mini-batch)"%(dbg, e0.elapsed_time(e1)*1000/200))
+    res=[]
+    for mode in ("warm","real"):
+        fn = (lambda: K.ppo_update_fwd_bwd(args)) if mode=="warm" else (lambda: f._one(args))
+        for _ in range(20): fn()
+        torch.cuda.synchronize()
+        e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(300): fn()
+        e1.record(); torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1)*1000/300)
+    print("debug=%3d  fwd_bwd alone (same mini-batch, weights L2-warm) %.2f us | fwd_bwd+reduce+adam (weights rewritten each time) %.2f us"%(dbg,res[0],res[1]))
