@@ -129,6 +129,7 @@ class FusedPolicyUpdate:
         self.vn_count = torch.full((2,), 1e-4, dtype=torch.float64, device=dev)
         self.loss_partials = torch.zeros(2, self.n_wg, 8, dtype=torch.float32, device=dev)
         self.totals = torch.zeros(9, dtype=torch.float64, device=dev)
+        self._lib = _lib.load()
         self.records = None
         self.adv_records = None
         self.perm = None
@@ -224,12 +225,22 @@ class FusedPolicyUpdate:
         return self._args[B]
 
     def _one(self, args):
+        """One mini-batch: 3 launches (+ the gradient all-reduce on N > 1).  This is the eager path of
+        multi-rank runs, so the per-call Python overhead is kept minimal: raw ctypes handles, the
+        stream pointer looked up once per call."""
+        lib = self._lib
+        st = K.stream()
+        ref = C.byref(args)
         single = self.world == 1
-        K.ppo_update_fwd_bwd(args)
-        K.ppo_update_reduce(args, compute_norms=single)
-        if not single:
+        rc = lib.ppoaf_ppo_update_fwd_bwd(ref, st)
+        if rc == 0:
+            rc = lib.ppoaf_ppo_update_reduce(ref, 1 if single else 0, st)
+        if rc == 0 and not single:
             mpi_utils.allreduce_sum_(self.pol.policy_grads)
-        K.ppo_update_adam(args, compute_norms=not single)
+        if rc == 0:
+            rc = lib.ppoaf_ppo_update_adam(ref, 0 if single else 1, st)
+        if rc != 0:
+            _lib.check(rc, "ppo_update")
 
     def _chunk(self, args, n):
         for _ in range(n):
