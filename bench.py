@@ -76,7 +76,7 @@ def parse():
     p.add_argument("--no-saturating", action="store_true")
     p.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
                    help="C2 (default, the metric's config) | C3 dims: HalfCheetah O=17, Box(6), actor 128^3 / "
-                        "critic 256^3, E=2048 (no ICM / wrappers yet) | C4 dims: SimpleSpread MAPPO, 3 agents, "
+                        "critic 256^3, E=2048, ICM + obs/reward normalisers and clippers | C4 dims: SimpleSpread MAPPO, 3 agents, "
                         "O=18, O_c=54, Discrete(5), E=1024 per rank | C5 dims: same env, MATPolicy (embedding 64, "
                         "1 block, 1 head, critic view local), E=1024 per rank")
     return p.parse_args()
@@ -99,12 +99,14 @@ def main():
     device = torch.device("cuda", local_rank)
     E, T, O, NA = args.envs, args.ts, 4, 2
     A, critic_view, act_space, pargs, workload = 1, "local", Discrete(NA), {}, None
+    filters = dict(normalize_obs=False, normalize_rewards=False)     # C2/C4/C5 as SURVEY.md §8(d) defines them
     if args.config == "C3":
         E, O = (2048 if args.envs == 4096 else args.envs), 17
         act_space = Box(-1.0, 1.0, (6,), np.float32)
-        pargs = dict(actor_kw_args=dict(hidden_size=128), critic_kw_args=dict(hidden_size=256))
-        workload = (f"C3 dims (HalfCheetah-v4: O=17, Box(6) tanh-Gaussian, actor 128^3, critic 256^3), "
-                    f"envs_per_proc={E}, ts_per_rollout={T}; WITHOUT ICM and obs/reward normalisers (not built yet)")
+        pargs = dict(actor_kw_args=dict(hidden_size=128), critic_kw_args=dict(hidden_size=256), enable_icm=True)
+        filters = dict(normalize_obs=True, normalize_rewards=True, obs_clip=(-10.0, 10.0), reward_clip=(-10.0, 10.0))
+        workload = (f"C3 dims (HalfCheetah-v4: O=17, Box(6) tanh-Gaussian, actor 128^3, critic 256^3, ICM, "
+                    f"obs/reward normalisers + clippers), envs_per_proc={E}, ts_per_rollout={T}")
     elif args.config == "C4":
         E, O, NA, A, critic_view = (1024 if args.envs == 4096 else args.envs), 18, 5, 3, "policy"
         act_space = Discrete(NA)
@@ -126,7 +128,7 @@ def main():
     cobs_space = Box(-np.inf, np.inf, (O * A if critic_view == "policy" else O,), np.float32)
     settings = {"cartpole": (policy_class, obs_space, cobs_space, act_space, pargs)}
     ppo = PPO(env_gen, settings, device=device, random_seed=1, envs_per_proc=E, ts_per_rollout=T,
-              batch_size=args.batch_size, epochs_per_iter=args.epochs, use_graphs=not args.no_graphs)
+              batch_size=args.batch_size, epochs_per_iter=args.epochs, use_graphs=not args.no_graphs, **filters)
     pol = ppo.policies["cartpole"]
 
     def barrier():

@@ -424,6 +424,72 @@ int ppoaf_minibatch_moments(const float* data, const int64_t* perm, const int32_
                             int64_t n_perm, int64_t B, double* records /* [ceil(n/B), 3] */,
                             ppoaf_stream_t stream);
 
+/* ------------------------------------------------------------------------ *
+ * K13  environment filters: running observation / reward normalisation and clipping
+ * replaces ObservationNormalizer.step/reset        environments/filter_wrappers.py:155-268
+ *          RewardNormalizer.step                   environments/filter_wrappers.py:388-458
+ *          ObservationClipper / RewardClipper      environments/filter_wrappers.py:583-719
+ * in the wiring order of wrapper_utils.py:81-111 (normalise, then clip).
+ *
+ * One env step of G agents x n envs (rows agent-major: group g owns rows [g*n, (g+1)*n)).
+ * Two launches: `moments` reduces this rank's batch to a float64 record, the records of the
+ * R ranks are all-gathered by the caller (R = 1: pass the record itself), `apply` merges
+ * them into the running state and writes the filtered outputs.
+ *
+ * Record layout (float64, PPOAF_ENV_FILTER_RECORD_LEN(G, W_o, W_c, has_reward) values):
+ *   [0] n | obs mean[G*W_o] | obs M2[G*W_o] | critic mean[G*W_c] | critic M2[G*W_c]
+ *       | reward S1[G] | reward S2[G]
+ * Observation stats are per (agent, feature): mean/var float32, count float64 (one copy per
+ * column so no column races on it; initialise 0 / 1 / 1e-4, stats.py:25-27).
+ * Reward stats per agent are float64 (the reference's become float64 on the first update).
+ * The reference updates the reward stats n times per step, once after each env's running reward
+ * is advanced, each time with the whole half-updated vector (filter_wrappers.py:412-418); the
+ * n Chan merges equal one merge of the pooled n*n values, which is what S1/S2 carry:
+ *   S1 = sum_i (n-i)(new_i - m) + i (old_i - m),  S2 likewise with squares, m = running mean.
+ * A NULL filter pointer skips that stream.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    const float* x;        /* [G, n, W] raw */
+    float*       out;      /* [G, n, W] filtered (may alias x) */
+    float*       mean;     /* [G, W] */
+    float*       var;      /* [G, W] */
+    double*      count;    /* [G, W] */
+    int32_t      W;
+    int32_t      normalize;  /* 0: clip only (mean/var/count may be NULL) */
+    int32_t      update;     /* integrate this step into the running stats */
+    int32_t      has_clip;
+    float        clip_lo, clip_hi;
+    float        eps;        /* 1e-8 */
+} ppoaf_obs_filter_t;
+
+typedef struct {
+    const float*   reward;          /* [G, n] raw */
+    const uint8_t* done;            /* [G, n] terminated */
+    const uint8_t* done2;           /* [G, n] truncated, OR-ed with `done`; may be NULL */
+    float*         out;             /* [G, n] */
+    double*        running_reward;  /* [G, n] discounted running reward (state) */
+    double*        mean;            /* [G] */
+    double*        var;             /* [G] */
+    double*        count;           /* [G] */
+    int32_t        normalize;       /* 0: clip only (state pointers may be NULL) */
+    int32_t        update;
+    int32_t        has_clip;
+    float          clip_lo, clip_hi;
+    double         gamma;
+    double         eps;             /* 1e-8 */
+} ppoaf_reward_filter_t;
+
+#define PPOAF_ENV_FILTER_RECORD_LEN(G, W_o, W_c, has_reward) \
+    (1 + 2 * (G) * ((W_o) + (W_c) + ((has_reward) ? 1 : 0)))
+
+int ppoaf_env_filter_moments(const ppoaf_obs_filter_t* obs, const ppoaf_obs_filter_t* critic_obs,
+                             const ppoaf_reward_filter_t* reward, int32_t G, int64_t n,
+                             double* record, ppoaf_stream_t stream);
+int ppoaf_env_filter_apply(const ppoaf_obs_filter_t* obs, const ppoaf_obs_filter_t* critic_obs,
+                           const ppoaf_reward_filter_t* reward, int32_t G, int64_t n,
+                           const double* records /* [R, record_len] */, int32_t R,
+                           ppoaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

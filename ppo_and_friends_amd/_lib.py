@@ -71,6 +71,22 @@ class PolicyStepArgs(C.Structure):
 
 
 # name -> (restype, argtypes); mirrors include/ppoaf_hip.h one to one.
+class ObsFilter(C.Structure):
+    """ppoaf_obs_filter_t (include/ppoaf_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("mean", C.c_void_p), ("var", C.c_void_p),
+                ("count", C.c_void_p), ("W", C.c_int32), ("normalize", C.c_int32), ("update", C.c_int32),
+                ("has_clip", C.c_int32), ("clip_lo", C.c_float), ("clip_hi", C.c_float), ("eps", C.c_float)]
+
+
+class RewardFilter(C.Structure):
+    """ppoaf_reward_filter_t (include/ppoaf_hip.h)."""
+    _fields_ = [("reward", C.c_void_p), ("done", C.c_void_p), ("done2", C.c_void_p), ("out", C.c_void_p),
+                ("running_reward", C.c_void_p), ("mean", C.c_void_p), ("var", C.c_void_p),
+                ("count", C.c_void_p), ("normalize", C.c_int32), ("update", C.c_int32),
+                ("has_clip", C.c_int32), ("clip_lo", C.c_float), ("clip_hi", C.c_float),
+                ("gamma", C.c_double), ("eps", C.c_double)]
+
+
 SIGNATURES = {
     "ppoaf_abi_version": (C.c_int, []),
     "ppoaf_last_error": (C.c_char_p, []),
@@ -121,6 +137,10 @@ SIGNATURES = {
                                           _ptr, _ptr, _ptr, _ptr]),
     "ppoaf_policy_step": (C.c_int, [C.POINTER(PolicyStepArgs), _ptr]),
     "ppoaf_minibatch_moments": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int64, _ptr, _ptr]),
+    "ppoaf_env_filter_moments": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),
+                                           C.c_int32, C.c_int64, _ptr, _ptr]),
+    "ppoaf_env_filter_apply": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),
+                                         C.c_int32, C.c_int64, _ptr, C.c_int32, _ptr]),
 }
 
 _lib = None

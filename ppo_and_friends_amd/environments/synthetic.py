@@ -73,7 +73,12 @@ class SyntheticFixedLengthEnv:
         self.t = 0
         return self.obs_table[0], self.critic_obs_table[0]
 
-    soft_reset = reset
+    def soft_reset(self):
+        """The observation the env stopped on (ppo_env_wrappers.py:1170-1183); a hard reset before any step."""
+        if self.t == 0:
+            return self.reset()
+        t = (self.t - 1) % self.horizon + 1
+        return self.obs_table[t], self.critic_obs_table[t]
 
     def step(self, action):
         t = self.t % self.horizon

@@ -418,3 +418,101 @@ def mat_attention_bwd(q, k, v, probs, dy):
     check(_lib.load().ppoaf_mat_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(probs), ptr(dy), n_seq, L, D,
                                               ptr(dq), ptr(dk), ptr(dv), stream()), "mat_attention_bwd")
     return dq, dk, dv
+
+
+# --------------------------------------------------------------------------
+# K13: environment filters (observation / reward normalisation + clipping)
+# --------------------------------------------------------------------------
+def env_filter_record_len(G, W_o, W_c, has_reward):
+    """PPOAF_ENV_FILTER_RECORD_LEN of include/ppoaf_hip.h."""
+    return 1 + 2 * G * (W_o + W_c + (1 if has_reward else 0))
+
+
+def obs_filter(x, out, G, n, stats=None, update=True, clip=None, eps=1e-8):
+    """
+    ppoaf_obs_filter_t for x/out [G*n, W] float32; stats = (mean [G*W] f32, var [G*W] f32,
+    count [G*W] f64) or None (clip only).  The tensors must outlive the launches.
+    """
+    _req(x.is_cuda and x.is_contiguous() and out.is_contiguous() and x.dim() == 2, "obs_filter: x must be [G*n, W] on the device")
+    _f32(x, "obs_filter x"); _f32(out, "obs_filter out")
+    W = x.shape[1]
+    _req(x.shape[0] == G * n and out.shape == x.shape and W >= 1, f"obs_filter: shape {tuple(x.shape)} vs G={G} n={n}")
+    f = _lib.ObsFilter()
+    f.x, f.out, f.W = ptr(x), ptr(out), W
+    f.normalize = 0
+    if stats is not None:
+        mean, var, count = stats
+        _req(mean.dtype == torch.float32 and var.dtype == torch.float32 and count.dtype == torch.float64,
+             "obs_filter: stats dtypes (f32, f32, f64)")
+        _req(mean.numel() == G * W and var.numel() == G * W and count.numel() == G * W, "obs_filter: stats size")
+        _req(mean.is_cuda and var.is_cuda and count.is_cuda, "obs_filter: stats must be on the device")
+        f.mean, f.var, f.count = ptr(mean), ptr(var), ptr(count)
+        f.normalize = 1
+    f.update = 1 if (update and stats is not None) else 0
+    f.has_clip = 0
+    if clip is not None:
+        f.has_clip, f.clip_lo, f.clip_hi = 1, float(clip[0]), float(clip[1])
+    f.eps = float(eps)
+    return f
+
+
+def reward_filter(reward, terminated, truncated, out, G, n, state=None, update=True, clip=None,
+                  gamma=0.99, eps=1e-8):
+    """
+    ppoaf_reward_filter_t for reward/out [G*n] float32, terminated/truncated [G*n] bool;
+    state = (running_reward [G*n] f64, mean [G] f64, var [G] f64, count [G] f64) or None.
+    """
+    _req(reward.is_cuda and reward.is_contiguous() and out.is_contiguous(), "reward_filter: device contiguous")
+    _f32(reward, "reward_filter reward"); _f32(out, "reward_filter out")
+    _req(reward.numel() == G * n and out.numel() == G * n, "reward_filter: size")
+    f = _lib.RewardFilter()
+    f.reward, f.out = ptr(reward), ptr(out)
+    f.normalize = 0
+    if state is not None:
+        rr, mean, var, count = state
+        for t in (rr, mean, var, count):
+            _req(t.dtype == torch.float64 and t.is_cuda, "reward_filter: state must be float64 on the device")
+        _req(rr.numel() == G * n and mean.numel() == G and var.numel() == G and count.numel() == G,
+             "reward_filter: state size")
+        _req(terminated is not None and terminated.numel() == G * n and terminated.element_size() == 1
+             and terminated.is_contiguous(), "reward_filter: terminated must be [G*n] bool/uint8")
+        f.done = ptr(terminated)
+        if truncated is not None:
+            _req(truncated.numel() == G * n and truncated.element_size() == 1 and truncated.is_contiguous(),
+                 "reward_filter: truncated must be [G*n] bool/uint8")
+            f.done2 = ptr(truncated)
+        f.running_reward, f.mean, f.var, f.count = ptr(rr), ptr(mean), ptr(var), ptr(count)
+        f.normalize = 1
+    f.update = 1 if (update and state is not None) else 0
+    f.has_clip = 0
+    if clip is not None:
+        f.has_clip, f.clip_lo, f.clip_hi = 1, float(clip[0]), float(clip[1])
+    f.gamma, f.eps = float(gamma), float(eps)
+    return f
+
+
+def _ref(s):
+    return C.byref(s) if s is not None else None
+
+
+def env_filter_moments(obs_f, cobs_f, rew_f, G, n, record):
+    _req(record.dtype == torch.float64 and record.is_cuda and record.is_contiguous(), "env_filter_moments: record")
+    need = env_filter_record_len(G, obs_f.W if obs_f is not None else 0, cobs_f.W if cobs_f is not None else 0,
+                                 rew_f is not None)
+    _req(record.numel() >= need, f"env_filter_moments: record holds {record.numel()} < {need}")
+    check(_lib.load().ppoaf_env_filter_moments(_ref(obs_f), _ref(cobs_f), _ref(rew_f), int(G), int(n),
+                                               ptr(record), stream()), "env_filter_moments")
+    return record
+
+
+def env_filter_apply(obs_f, cobs_f, rew_f, G, n, records=None):
+    R = 0
+    if records is not None:
+        need = env_filter_record_len(G, obs_f.W if obs_f is not None else 0,
+                                     cobs_f.W if cobs_f is not None else 0, rew_f is not None)
+        _req(records.dtype == torch.float64 and records.is_cuda and records.is_contiguous(), "env_filter_apply: records")
+        _req(records.numel() % need == 0 and records.numel() >= need, "env_filter_apply: records size")
+        R = records.numel() // need
+    check(_lib.load().ppoaf_env_filter_apply(_ref(obs_f), _ref(cobs_f), _ref(rew_f), int(G), int(n),
+                                             ptr(records) if records is not None else None, R, stream()),
+          "env_filter_apply")

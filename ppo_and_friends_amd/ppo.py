@@ -25,7 +25,8 @@ import numpy as np
 import torch
 
 from . import kernels as K
-from .policies.ppo_policy import PPOPolicy
+from .environments.filter_wrappers import wrap_environment
+from .policies.ppo_policy import CallableValue, PPOPolicy
 from .policies.utils import generate_policy
 from .utils import mpi_utils
 from .utils.misc import RunningStatNormalizer
@@ -130,16 +131,15 @@ class PPO:
     def __init__(self, env_generator, policy_settings, policy_mapping_fn=None, device="cuda",
                  random_seed=None, envs_per_proc=1, max_ts_per_ep=200, batch_size=256,
                  ts_per_rollout=1024, gamma=0.99, epochs_per_iter=10, ext_reward_weight=1.0,
-                 normalize_adv=True, normalize_obs=False, normalize_rewards=False,
+                 normalize_adv=True, normalize_obs=True, normalize_rewards=True,
                  normalize_values=True, obs_clip=None, reward_clip=None, recalc_advantages=False,
-                 use_graphs=True, update_mode="auto", verbose=False, **kw_args):
+                 soft_resets=False, use_graphs=True, update_mode="auto", verbose=False, **kw_args):
         """
         ppo.py:126-167.  `ts_per_rollout` is per environment (ppo.py:317-318
-        multiplies by envs_per_proc).  Observation / reward normalising wrappers
-        (environments/filter_wrappers.py) are SURVEY.md §8(f) "next" rows.
+        multiplies by envs_per_proc).  normalize_obs / normalize_rewards / obs_clip / reward_clip
+        put the device filter stack of environments/filter_wrappers.py around `env_generator()`
+        (ppo.py:358-371 -> wrapper_utils.py:81-111); soft_resets as ppo.py:1580-1586.
         """
-        if normalize_obs or normalize_rewards or obs_clip or reward_clip:
-            raise NotImplementedError("obs/reward normaliser wrappers are a 'next' row (SURVEY.md §8(f).1)")
         mpi_utils.set_torch_threads()
         self.device = torch.device(device)
         self.envs_per_proc = int(envs_per_proc)
@@ -164,7 +164,10 @@ class PPO:
         np.random.seed(self.random_seed + rank)
         self.loader_generator = torch.Generator().manual_seed(self.random_seed + rank)
 
-        self.env = env_generator()
+        self.env = wrap_environment(env_generator, normalize_obs=normalize_obs,
+                                    normalize_rewards=normalize_rewards, obs_clip=obs_clip,
+                                    reward_clip=reward_clip, gamma=gamma, test_mode=False)
+        self.soft_resets = soft_resets if callable(soft_resets) else CallableValue(bool(soft_resets))
         self.policy_mapping_fn = policy_mapping_fn or (lambda agent_id: next(iter(policy_settings)))
         self.status_dict = OrderedDict()
         self.status_dict["global status"] = OrderedDict(
@@ -192,6 +195,9 @@ class PPO:
                     name=f"{policy_id}-value_normalizer", device=self.device)
         for pol in self.policies.values():
             pol.finalize(self.status_dict, self.device)
+        self.soft_resets.finalize(self.status_dict)
+        if callable(getattr(self.env, "finalize", None)):
+            self.env.finalize(self.status_dict)          # status-driven clip ranges (filter_wrappers.py:560-566)
         self._graphs = {}
         self._obs = None
 
@@ -226,7 +232,13 @@ class PPO:
         pol.initialize_episodes(n_envs, self.status_dict, ts_per_rollout=self.ts_per_rollout)
         buf = pol.buffer
         E = buf.C                      # rows per step: agents x envs, agent-major (ppo.py:710-795)
-        obs, critic_obs = env.reset() if self._obs is None else self._obs
+        # ppo.py:1580-1586: a hard reset per rollout unless soft_resets (then the env carries on, and
+        # a filter stack counts the carried observation once more, ppo_env_wrappers.py:149-199)
+        if self._obs is None or not self.soft_resets():
+            obs, critic_obs = env.reset()
+        else:
+            soft = getattr(env, "soft_reset", None)
+            obs, critic_obs = soft() if callable(soft) else self._obs
         ep_ts = torch.zeros(E, dtype=torch.int32, device=self.device)
         score_sum = torch.zeros((), dtype=torch.float64, device=self.device)
         n_term = torch.zeros((), dtype=torch.int64, device=self.device)

@@ -35,7 +35,7 @@ def _rank(rank, world, port, out):
     dev = torch.device("cuda", 0)
     env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=500, rank=rank)
     sp = Box(-np.inf, np.inf, (O,), np.float32)
-    ppo = PPO(env_gen, {"p": (None, sp, sp, Discrete(NA), {})}, device=dev, random_seed=SEED,
+    ppo = PPO(env_gen, {"p": (None, sp, sp, Discrete(NA), {})}, device=dev, random_seed=SEED, normalize_obs=False, normalize_rewards=False,
               envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=2, update_mode="fused")
     pol = ppo.policies["p"]
     w0 = pol.policy_params.detach().cpu().clone()           # after the rank-0 broadcast
