@@ -479,11 +479,13 @@ class PPO:
         perm = data_loader.epoch_permutation()
         N = perm.numel()
         world = mpi_utils.get_num_procs()
-        total = torch.zeros((), dtype=torch.float64, device=self.device)
+        total = self._scratch("icm_total", 1, torch.float64)
+        total.zero_()
         counter = 0
         flat = lambda t: t.view((buf.num_transitions,) + tuple(t.shape[2:]))
-        for o in range(0, N, B):
-            idx = perm[o:o + B].contiguous()
+        perm_static = self._scratch(f"icm_perm_static_{B}", B, torch.int64)
+
+        def fwd_bwd(idx):
             n = idx.numel()
             obs = torch.empty((n,) + tuple(buf.observations.shape[2:]), dtype=torch.float32, device=self.device)
             nxt = torch.empty_like(obs)
@@ -492,13 +494,26 @@ class PPO:
                                 (flat(buf.actions), act)], idx, buf.row_map)
             _, inv_loss, f_loss = pol.icm_model(obs, nxt, act)
             icm_loss = (1.0 - pol.icm_beta) * f_loss + pol.icm_beta * inv_loss
-            total += icm_loss.detach().double()
+            total.add_(icm_loss.detach().double())
             pol.icm_optim.zero_grad()
             icm_loss.backward()
-            mpi_utils.allreduce_sum_(pol.icm_model.flat_grads)
-            pol.icm_optim.step(grad_scale=1.0 / world, max_norm=None)
+
+        opt = lambda: pol.icm_optim.step(grad_scale=1.0 / world, max_norm=None)
+        for o in range(0, N, B):
+            idx = perm[o:o + B]
+            if self.use_graphs and idx.numel() == B:
+                # same two hipGraphs per mini-batch as the torch PPO path: gather + forward + backward,
+                # [gradient all-reduce], Adam
+                perm_static.copy_(idx)
+                self._replay_or_capture(("icm_fb", policy_id, B), lambda: fwd_bwd(perm_static))
+                mpi_utils.allreduce_sum_(pol.icm_model.flat_grads)
+                self._replay_or_capture(("icm_opt", policy_id), opt)
+            else:
+                fwd_bwd(idx.contiguous())
+                mpi_utils.allreduce_sum_(pol.icm_model.flat_grads)
+                opt()
             counter += 1
-        t = torch.stack([total, torch.tensor(float(counter), dtype=torch.float64, device=self.device)])
+        t = torch.cat([total, torch.tensor([float(counter)], dtype=torch.float64, device=self.device)])
         if world > 1:
             mpi_utils.allreduce_sum_(t)
         t = t.cpu().numpy()
