@@ -490,6 +490,54 @@ int ppoaf_env_filter_apply(const ppoaf_obs_filter_t* obs, const ppoaf_obs_filter
                            const double* records /* [R, record_len] */, int32_t R,
                            ppoaf_stream_t stream);
 
+/* ------------------------------------------------------------------------ *
+ * K14  fused ICM mini-batch update
+ * replaces one iteration of PPO._icm_batch_train   ppo.py:2487-2567
+ *          ICM.forward (encoder x2, inverse model, forward model, both losses)
+ *                                                  networks/ppo_networks/icm.py:375-430
+ *          LinearObservationEncoder.forward        networks/encoders.py:40-56
+ *          mpi_avg_gradients + Adam (no clipping)  ppo.py:2556-2562
+ * for the reference's default ICM topology with one width H everywhere:
+ *   encoder  O -> H -> H -> H -> H (last layer linear)
+ *   inverse  2H -> H (x depth_inv hidden layers) -> A          (softmax + CE for discrete,
+ *                                                               MSE for continuous actions)
+ *   forward  H + A_in -> H (x depth_fwd hidden layers) -> H     (A_in = classes / action dims)
+ * Parameters live in one flat bucket in module order (weight, bias per Linear, each
+ * padded to 4 floats): encoder at enc_offset, then inverse, then forward model.
+ *
+ * `fwd_bwd` enqueues three launches -- encoder forward for both observations (activations
+ * to `act_scratch`), inverse / forward model forward + losses + backward (encoding
+ * gradients to `denc_scratch`), encoder backward -- each on 2 * ceil(B/16) workgroups of
+ * 16 rows, every HxH layer on v_mfma_f32_16x16x4_f32; weight gradients go to per-workgroup
+ * slabs.  `reduce` sums the slabs in a fixed order into `grads`, folds the loss into
+ * totals[0] (icm_loss = (1-beta) f_loss + beta inv_loss) / totals[1] (count), advances
+ * the cursor and, with fused_adam, applies Adam in the same launch (the single-rank path;
+ * with more ranks the caller all-reduces `grads` and runs K11).
+ * Rows of mini-batch k are perm[k*batch_stride + 0..B) with k read from `cursor`.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t obs_dim, hidden, action_dim, fwd_action_dim, depth_inv, depth_fwd, activation, discrete;
+    int64_t enc_offset, inv_offset, fwd_offset, bucket_total;
+    const float* params; float* grads; float* exp_avg; float* exp_avg_sq;
+    float* slabs;                    /* [2*ceil(B/16), bucket_total]                           */
+    int64_t* step_count;             /* [1] Adam step counter (advanced when fused_adam)        */
+    const float* lr;                 /* [1] device scalar                                       */
+    float beta1, beta2, adam_eps, grad_scale;
+    const float* obs;                /* [n_rows, obs_dim]                                       */
+    const float* next_obs;           /* [n_rows, obs_dim]                                       */
+    const void* actions;             /* int64 [n_rows] (discrete) / float32 [n_rows, action_dim]*/
+    const int64_t* perm; const int32_t* row_map; int64_t n_rows;
+    int64_t* cursor; int64_t B, batch_stride;
+    float icm_beta; int32_t fused_adam;
+    float* act_scratch;              /* [2, 4, 16*ceil(B/16), hidden]                           */
+    float* denc_scratch;             /* [2, 2, 16*ceil(B/16), hidden]                           */
+    float* loss_partials;            /* [ceil(B/16), 2]                                         */
+    double* totals;                  /* [2]                                                     */
+} ppoaf_icm_update_args_t;
+
+int ppoaf_icm_update_fwd_bwd(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream);
+int ppoaf_icm_update_reduce(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

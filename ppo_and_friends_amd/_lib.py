@@ -71,6 +71,24 @@ class PolicyStepArgs(C.Structure):
 
 
 # name -> (restype, argtypes); mirrors include/ppoaf_hip.h one to one.
+class IcmUpdateArgs(C.Structure):
+    """ppoaf_icm_update_args_t (include/ppoaf_hip.h) -- field order must match the header."""
+    _fields_ = [("obs_dim", C.c_int32), ("hidden", C.c_int32), ("action_dim", C.c_int32),
+                ("fwd_action_dim", C.c_int32), ("depth_inv", C.c_int32), ("depth_fwd", C.c_int32),
+                ("activation", C.c_int32), ("discrete", C.c_int32),
+                ("enc_offset", C.c_int64), ("inv_offset", C.c_int64), ("fwd_offset", C.c_int64),
+                ("bucket_total", C.c_int64),
+                ("params", C.c_void_p), ("grads", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("slabs", C.c_void_p), ("step_count", C.c_void_p), ("lr", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float), ("grad_scale", C.c_float),
+                ("obs", C.c_void_p), ("next_obs", C.c_void_p), ("actions", C.c_void_p),
+                ("perm", C.c_void_p), ("row_map", C.c_void_p), ("n_rows", C.c_int64),
+                ("cursor", C.c_void_p), ("B", C.c_int64), ("batch_stride", C.c_int64),
+                ("icm_beta", C.c_float), ("fused_adam", C.c_int32),
+                ("act_scratch", C.c_void_p), ("denc_scratch", C.c_void_p), ("loss_partials", C.c_void_p),
+                ("totals", C.c_void_p)]
+
+
 class ObsFilter(C.Structure):
     """ppoaf_obs_filter_t (include/ppoaf_hip.h)."""
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("mean", C.c_void_p), ("var", C.c_void_p),
@@ -137,6 +155,8 @@ SIGNATURES = {
                                           _ptr, _ptr, _ptr, _ptr]),
     "ppoaf_policy_step": (C.c_int, [C.POINTER(PolicyStepArgs), _ptr]),
     "ppoaf_minibatch_moments": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int64, _ptr, _ptr]),
+    "ppoaf_icm_update_fwd_bwd": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
+    "ppoaf_icm_update_reduce": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
     "ppoaf_env_filter_moments": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),
                                            C.c_int32, C.c_int64, _ptr, _ptr]),
     "ppoaf_env_filter_apply": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),

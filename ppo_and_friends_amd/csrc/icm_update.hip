@@ -1,0 +1,691 @@
+// K14: fused ICM mini-batch update (see include/ppoaf_hip.h for the contract).
+// One iteration of PPO._icm_batch_train (ppo.py:2487-2567) =
+//   icm_encoder_fwd_kernel   obs / next_obs rows -> encoder (4 layers) -> activations in scratch
+//   icm_heads_kernel         inverse model | forward model: forward, loss, backward -> slabs,
+//                            gradients of the two encodings -> scratch
+//   icm_encoder_bwd_kernel   encoder backward for both observations -> slabs
+//   icm_reduce_kernel        slabs -> gradient bucket [-> Adam], loss -> totals, cursor++
+//
+// Work decomposition: as K12 -- 16 rows per workgroup (one MFMA M tile), 8 waves each owning 16
+// output columns of an H-wide layer, activations in LDS, weights streamed from L2.  The four
+// sub-networks depend on each other across rows' workgroups only through the encodings, so the
+// dependency is carried by kernel boundaries (~2 us each on gfx950) rather than grid barriers,
+// and each phase runs on 2 * B/16 workgroups: (obs, next_obs) for the encoder phases,
+// (inverse, forward model) for the heads.  float32 MFMA (v_mfma_f32_16x16x4_f32) keeps fmaf
+// chains exact, weight gradients are written to private slabs and summed in a fixed order.
+#include "mlp_device.hpp"
+
+namespace ppoaf {
+
+struct IcmDev {
+    int O, H, A, Ain, d_inv, d_fwd, act, discrete;
+    long enc_off, inv_off, fwd_off, enc_size, total;
+    const float* params; float* grads; float* exp_avg; float* exp_avg_sq; float* slabs;
+    int64_t* step_count; const float* lr;
+    float beta1, beta2, adam_eps, grad_scale;
+    const float* obs; const float* next_obs; const void* actions;
+    const int64_t* perm; const int32_t* row_map; long n_rows;
+    int64_t* cursor; long B, batch_stride, Bpad;
+    float icm_beta; int fused_adam;
+    float* actE; float* dEnc; float* loss_partials; double* totals;
+    int nT;
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char icm_smem[];
+
+// ---- fragment loads with an explicit row stride (W row-major [*, ldw], columns [0, 16*HT) of W) ----
+template <int HT, bool ALIGNED>
+__device__ __forceinline__ void load_fwd_frags_ld(const float* __restrict__ W, long ldw, int n0, int lane,
+                                                  float4 (&fr)[HT]) {
+    const float* w = W + (long)(n0 + (lane & 15)) * ldw + 4 * (lane >> 4);
+#pragma unroll
+    for (int c = 0; c < HT; ++c) {
+        if (ALIGNED) fr[c] = *reinterpret_cast<const float4*>(w + 16 * c);
+        else fr[c] = make_float4(w[16 * c], w[16 * c + 1], w[16 * c + 2], w[16 * c + 3]);
+    }
+}
+template <int HT>
+__device__ __forceinline__ void load_dgrad_frags_ld(const float* __restrict__ W, long ldw, int n0, int lane,
+                                                    float4 (&fr)[HT]) {
+    const float* w = W + (long)(4 * (lane >> 4)) * ldw + n0 + (lane & 15);
+#pragma unroll
+    for (int c = 0; c < HT; ++c) {
+        const float* wp = w + (long)(16 * c) * ldw;
+        fr[c] = make_float4(wp[0], wp[ldw], wp[2 * ldw], wp[3 * ldw]);
+    }
+}
+
+// out[s][o] = f(bias[o] + sum_k A[s][k] W[o][k]) for the H outputs; act < 0: linear
+template <int HT, bool ALIGNED>
+__device__ __forceinline__ void layer_fwd(const float* __restrict__ W, long ldw, const float* __restrict__ bias,
+                                          const float* __restrict__ A, float* __restrict__ out, int act,
+                                          int wave, int lane) {
+    constexpr int HS = 16 * HT + 4;
+    for (int nt = wave; nt < HT; nt += kNW) {
+        float4 fr[HT];
+        load_fwd_frags_ld<HT, ALIGNED>(W, ldw, nt * 16, lane, fr);
+        const int o = nt * 16 + (lane & 15);
+        const f32x4 acc = mfma_rows_x_frags<HT>(A, HS, lane, fr, bias[o]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(4 * (lane >> 4) + r) * HS + o] = act >= 0 ? act_fwd(acc[r], act) : acc[r];
+    }
+}
+
+// dh[s][i] = (sum_o D[s][o] W[o][i]) * act'(Hin[s][i]) for the H columns [0, H) of W (offset the pointer
+// for other column blocks); result to LDS (dst_lds) or to global rows (dst_glob, row stride H).
+template <int HT>
+__device__ __forceinline__ void layer_dgrad(const float* __restrict__ W, long ldw, const float* __restrict__ D,
+                                            const float* __restrict__ Hin, int act, float* __restrict__ dst_lds,
+                                            float* __restrict__ dst_glob, int wave, int lane) {
+    constexpr int H = 16 * HT, HS = H + 4;
+    for (int nt = wave; nt < HT; nt += kNW) {
+        float4 fr[HT];
+        load_dgrad_frags_ld<HT>(W, ldw, nt * 16, lane, fr);
+        const f32x4 acc = mfma_rows_x_frags<HT>(D, HS, lane, fr, 0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = 4 * (lane >> 4) + r, i = nt * 16 + (lane & 15);
+            float v = acc[r];
+            if (Hin) v *= act_bwd(Hin[s * HS + i], act);
+            if (dst_lds) dst_lds[s * HS + i] = v;
+            else dst_glob[(long)s * H + i] = v;
+        }
+    }
+}
+
+// dW[o][i] = sum_s D[s][o] Bsrc[s][i] (i < n_valid) and, when dstB, db[o] = sum_s D[s][o]
+template <int HT>
+__device__ __forceinline__ void layer_wgrad(const float* __restrict__ D, const float* __restrict__ Bsrc,
+                                            int strideB, int ntiles, int n_valid, float* __restrict__ dstW,
+                                            int ldw, float* __restrict__ dstB, int wave, int lane, int tid) {
+    constexpr int H = 16 * HT, HS = H + 4;
+    for (int mt = wave; mt < HT; mt += kNW)
+        wgrad_mtile(D, HS, Bsrc, strideB, mt * 16, ntiles, n_valid, lane, dstW, ldw);
+    if (dstB) {
+        for (int o = tid; o < H; o += kThreadsU) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < kRows; ++s) acc += D[s * HS + o];
+            dstB[o] = acc;
+        }
+    }
+}
+
+__device__ __forceinline__ void icm_rows(const IcmDev& u, int g, int tid, int* sRow) {
+    if (tid < kRows) {
+        const long s = (long)g * kRows + tid;
+        int row = -1;
+        if (s < u.B) {
+            const long p = u.perm[u.cursor[0] * u.batch_stride + s];
+            if (p >= 0 && p < u.n_rows) row = u.row_map ? u.row_map[p] : (int)p;
+        }
+        sRow[tid] = row;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder forward: blockIdx.x = 2 * g + which (0: obs, 1: next_obs)
+// ------------------------------------------------------------------------------------------------
+template <int HT>
+__global__ __launch_bounds__(kThreadsU) void icm_encoder_fwd_kernel(IcmDev u) {
+    constexpr int H = 16 * HT, HS = H + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int which = blockIdx.x & 1, g = blockIdx.x >> 1;
+    const int O = u.O, NT0 = (O + 15) >> 4, INP = 16 * NT0 + 4;
+    const float* P = u.params + u.enc_off;
+    auto encW = [&](int l) -> long { return l == 0 ? 0 : (long)H * O + H + (long)(l - 1) * (H * H + H); };
+    auto encB = [&](int l) -> long { return encW(l) + (l == 0 ? (long)H * O : (long)H * H); };
+    float* smem = reinterpret_cast<float*>(icm_smem);
+    int* sRow = reinterpret_cast<int*>(smem);
+    float* sX = smem + 16;                      // [16, INP]
+    float* sH = sX + kRows * INP;               // 4 x [16, HS]
+    if (blockIdx.x == 0 && tid == 0 && u.fused_adam) u.step_count[0] += 1;
+    icm_rows(u, g, tid, sRow);
+    for (int i = tid; i < kRows * INP; i += kThreadsU) sX[i] = 0.f;
+    __syncthreads();
+    {
+        const float* src = which == 0 ? u.obs : u.next_obs;
+        for (int idx = tid; idx < kRows * O; idx += kThreadsU) {
+            const int s = idx / O, i = idx - s * O;
+            const int row = sRow[s];
+            if (row >= 0) sX[s * INP + i] = src[(long)row * O + i];
+        }
+    }
+    __syncthreads();
+    // layer 0: K = O padded to 16 (sX zero padded), weights read with a bound check
+    for (int nt = wave; nt < HT; nt += kNW) {
+        const int o = nt * 16 + (lane & 15);
+        const float bv = P[encB(0) + o];
+        f32x4 acc = {bv, bv, bv, bv};
+        const float* w = P + encW(0) + (long)o * O;
+        const float* arow = sX + (lane & 15) * INP;
+        for (int k0 = 0; k0 < O; k0 += 16) {
+            float bq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + 4 * j + (lane >> 4);
+                bq[j] = k < O ? w[k] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k0 + 4 * j + (lane >> 4)], bq[j], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sH[(4 * (lane >> 4) + r) * HS + o] = act_fwd(acc[r], u.act);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l < 4; ++l) {
+        layer_fwd<HT, true>(P + encW(l), H, P + encB(l), sH + (long)(l - 1) * kRows * HS, sH + (long)l * kRows * HS,
+                            l < 3 ? u.act : -1, wave, lane);
+        __syncthreads();
+    }
+    // activations of all four layers -> scratch [which][l][row][H]
+    for (int idx = tid; idx < 4 * kRows * (H / 4); idx += kThreadsU) {
+        const int l = idx / (kRows * (H / 4)), rem = idx - l * (kRows * (H / 4));
+        const int s = rem / (H / 4), c4 = rem - s * (H / 4);
+        const float4 v = *reinterpret_cast<const float4*>(sH + ((long)l * kRows + s) * HS + 4 * c4);
+        *reinterpret_cast<float4*>(u.actE + (((long)(which * 4 + l) * u.Bpad) + (long)g * kRows + s) * H + 4 * c4) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// heads: blockIdx.x = 2 * g + which (0: inverse model, 1: forward model)
+// ------------------------------------------------------------------------------------------------
+constexpr int kXS = 20;      // row stride of the padded action tile [16, 16 + 4]
+
+template <int HT>
+__global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
+    constexpr int H = 16 * HT, HS = H + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int which = blockIdx.x & 1, g = blockIdx.x >> 1;
+    const int act = u.act, A = u.A, Ain = u.Ain;
+    const int depth = which == 0 ? u.d_inv : u.d_fwd;
+    const long B = u.B;
+    float* smem = reinterpret_cast<float*>(icm_smem);
+    int* sRow = reinterpret_cast<int*>(smem);                 // [16]
+    float* sAct = smem + 16;                                  // [16][8] actions (float, or int bits)
+    float* sBout = smem + 144;                                // [16]
+    float* sWout = smem + 160;                                // [8, H]
+    float* sXa = sWout + 8 * H;                               // [16, kXS]
+    float* sE1 = sXa + kRows * kXS;                           // [16, HS]
+    float* sE2 = sE1 + kRows * HS;
+    float* sH = sE2 + kRows * HS;                             // depth x [16, HS]
+    float* sD0 = sH + (long)depth * kRows * HS;
+    float* sD1 = sD0 + kRows * HS;
+    float* sOut = sD1 + kRows * HS;                           // [16, 16]
+    float* sDOut = sOut + kRows * kMaxOut;                    // [16, 16]
+    __shared__ float red[17];
+
+    icm_rows(u, g, tid, sRow);
+    for (int i = tid; i < kRows * kXS; i += kThreadsU) sXa[i] = 0.f;
+    // encodings of this tile (layer 3 of the encoder scratch)
+    for (int idx = tid; idx < 2 * kRows * (H / 4); idx += kThreadsU) {
+        const int e = idx / (kRows * (H / 4)), rem = idx - e * (kRows * (H / 4));
+        const int s = rem / (H / 4), c4 = rem - s * (H / 4);
+        const float4 v = *reinterpret_cast<const float4*>(
+            u.actE + (((long)(e * 4 + 3) * u.Bpad) + (long)g * kRows + s) * H + 4 * c4);
+        *reinterpret_cast<float4*>((e == 0 ? sE1 : sE2) + s * HS + 4 * c4) = v;
+    }
+    __syncthreads();
+    if (tid < kRows) {
+        const int row = sRow[tid];
+        if (u.discrete) {
+            int a = row >= 0 ? (int)reinterpret_cast<const int64_t*>(u.actions)[row] : 0;
+            a = a < 0 ? 0 : (a >= A ? A - 1 : a);
+            reinterpret_cast<int*>(sAct)[tid * 8] = a;
+            if (row >= 0) sXa[tid * kXS + a] = 1.0f;                              // one-hot (icm.py:198-204)
+        } else {
+            for (int d = 0; d < A; ++d) {
+                const float v = row >= 0 ? reinterpret_cast<const float*>(u.actions)[(long)row * A + d] : 0.f;
+                sAct[tid * 8 + d] = v;
+                sXa[tid * kXS + d] = v;
+            }
+        }
+    }
+
+    const long sidx = g;                                       // slab of this 16-row tile
+    if (which == 0) {
+        // =================================== inverse model ===================================
+        const float* P = u.params + u.inv_off;
+        float* slab = u.slabs + sidx * u.total + u.inv_off;
+        auto offW = [&](int l) -> long { return l == 0 ? 0 : 2L * H * H + H + (long)(l - 1) * (H * H + H); };
+        auto offB = [&](int l) -> long { return offW(l) + (l == 0 ? 2L * H * H : (l < depth ? (long)H * H : (long)A * H)); };
+        for (int i = tid; i < A * H; i += kThreadsU) sWout[i] = P[offW(depth) + i];
+        if (tid < A) sBout[tid] = P[offB(depth) + tid];
+        // layer 0 over the two K = H halves of cat(enc_1, enc_2)
+        for (int nt = wave; nt < HT; nt += kNW) {
+            float4 fa[HT], fb[HT];
+            load_fwd_frags_ld<HT, true>(P, 2 * H, nt * 16, lane, fa);
+            load_fwd_frags_ld<HT, true>(P + H, 2 * H, nt * 16, lane, fb);
+            const int o = nt * 16 + (lane & 15);
+            f32x4 acc = mfma_rows_x_frags<HT>(sE1, HS, lane, fa, P[offB(0) + o]);
+            acc += mfma_rows_x_frags<HT>(sE2, HS, lane, fb, 0.f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sH[(4 * (lane >> 4) + r) * HS + o] = act_fwd(acc[r], act);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 1; l < depth; ++l) {
+            layer_fwd<HT, true>(P + offW(l), H, P + offB(l), sH + (long)(l - 1) * kRows * HS, sH + (long)l * kRows * HS,
+                                act, wave, lane);
+            __syncthreads();
+        }
+        const float* Hlast = sH + (long)(depth - 1) * kRows * HS;
+        // output layer (A <= 8): VALU from LDS + 16-lane reductions
+        if (tid < 256) {
+            const int s = tid >> 4, part = tid & 15;
+            for (int k = 0; k < A; ++k) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < HT; ++i) acc = fmaf(Hlast[s * HS + part + 16 * i], sWout[k * H + part + 16 * i], acc);
+                acc = group16_sum(acc);
+                if (part == 0) sOut[s * kMaxOut + k] = acc + sBout[k];
+            }
+        }
+        __syncthreads();
+        // loss + d(out)
+        if (wave == 0) {
+            const int s = lane;
+            const bool live = s < kRows && sRow[s] >= 0;
+            float part = 0.f;
+            if (live && u.discrete) {
+                // icm.py:404-409: softmax output fed to CrossEntropyLoss (a second log-softmax)
+                float q[8];
+                float m = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k < A) m = fmaxf(m, sOut[s * kMaxOut + k]);
+                float ssum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { q[k] = k < A ? expf(sOut[s * kMaxOut + k] - m) : 0.f; ssum += q[k]; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) q[k] /= ssum;
+                float m2 = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k < A) m2 = fmaxf(m2, q[k]);
+                float e2[8], s2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { e2[k] = k < A ? expf(q[k] - m2) : 0.f; s2 += e2[k]; }
+                const int a = reinterpret_cast<const int*>(sAct)[s * 8];
+                float qa = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k == a) qa = q[k];
+                part = -(qa - m2 - logf(s2));
+                const float sc = u.icm_beta / (float)B;
+                float dq[8], dot = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    dq[k] = k < A ? sc * (e2[k] / s2 - (k == a ? 1.f : 0.f)) : 0.f;
+                    dot += dq[k] * q[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sDOut[s * kMaxOut + k] = q[k] * (dq[k] - dot);
+            } else if (live) {
+                // icm.py:411-413: mean squared error over B x A
+                const float sc = u.icm_beta * 2.0f / ((float)B * (float)A);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float dv = 0.f;
+                    if (k < A) {
+                        const float diff = sOut[s * kMaxOut + k] - sAct[s * 8 + k];
+                        part += diff * diff;
+                        dv = sc * diff;
+                    }
+                    sDOut[s * kMaxOut + k] = dv;
+                }
+            } else if (s < kRows) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sDOut[s * kMaxOut + k] = 0.f;
+            }
+            float v = lane < kRows ? part : 0.f;
+            v = group16_sum(v);
+            if (lane == 0) u.loss_partials[g * 2 + 0] = v;
+        }
+        __syncthreads();
+        // output layer backward
+        if (tid < H) {
+            const int i = tid;
+            float h[kRows];
+#pragma unroll
+            for (int s = 0; s < kRows; ++s) h[s] = Hlast[s * HS + i];
+            for (int k = 0; k < A; ++k) {
+                float acc = 0.f;
+#pragma unroll
+                for (int s = 0; s < kRows; ++s) acc = fmaf(sDOut[s * kMaxOut + k], h[s], acc);
+                slab[offW(depth) + (long)k * H + i] = acc;
+            }
+        }
+        if (tid >= 256 && tid < 256 + 8) {
+            const int k = tid - 256;                           // the padded bias entries get zeros
+            float acc = 0.f;
+            if (k < A)
+#pragma unroll
+                for (int s = 0; s < kRows; ++s) acc += sDOut[s * kMaxOut + k];
+            if (k < ((A + 3) & ~3)) slab[offB(depth) + k] = acc;
+        }
+        if (tid >= 256) {
+            const int t2 = tid - 256;
+            const int s = t2 >> 4, ig = t2 & 15;
+            float d[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = sDOut[s * kMaxOut + k];
+            float hv[HT], acc[HT];
+#pragma unroll
+            for (int ii = 0; ii < HT; ++ii) { hv[ii] = Hlast[s * HS + ig + 16 * ii]; acc[ii] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < A) {
+#pragma unroll
+                    for (int ii = 0; ii < HT; ++ii) acc[ii] = fmaf(d[k], sWout[k * H + ig + 16 * ii], acc[ii]);
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < HT; ++ii) sD0[s * HS + ig + 16 * ii] = acc[ii] * act_bwd(hv[ii], act);
+        }
+        __syncthreads();
+        float* Dc = sD0;
+        float* Dn = sD1;
+#pragma unroll 1
+        for (int l = depth - 1; l >= 1; --l) {
+            const float* Hin = sH + (long)(l - 1) * kRows * HS;
+            layer_dgrad<HT>(P + offW(l), H, Dc, Hin, act, Dn, nullptr, wave, lane);
+            layer_wgrad<HT>(Dc, Hin, HS, HT, H, slab + offW(l), H, slab + offB(l), wave, lane, tid);
+            __syncthreads();
+            float* t = Dc; Dc = Dn; Dn = t;
+        }
+        // layer 0: two K halves; the gradients of the encodings leave through scratch
+        layer_wgrad<HT>(Dc, sE1, HS, HT, H, slab + offW(0), 2 * H, slab + offB(0), wave, lane, tid);
+        layer_wgrad<HT>(Dc, sE2, HS, HT, H, slab + offW(0) + H, 2 * H, nullptr, wave, lane, tid);
+        float* dE = u.dEnc + ((long)(0 * 2 + 0) * u.Bpad + (long)g * kRows) * H;
+        layer_dgrad<HT>(P + offW(0), 2 * H, Dc, nullptr, act, nullptr, dE, wave, lane);
+        dE = u.dEnc + ((long)(0 * 2 + 1) * u.Bpad + (long)g * kRows) * H;
+        layer_dgrad<HT>(P + offW(0) + H, 2 * H, Dc, nullptr, act, nullptr, dE, wave, lane);
+    } else {
+        // =================================== forward model ===================================
+        const float* P = u.params + u.fwd_off;
+        float* slab = u.slabs + sidx * u.total + u.fwd_off;
+        const long ld0 = H + Ain;
+        auto offW = [&](int l) -> long { return l == 0 ? 0 : (long)H * ld0 + H + (long)(l - 1) * (H * H + H); };
+        auto offB = [&](int l) -> long { return offW(l) + (l == 0 ? (long)H * ld0 : (long)H * H); };
+        __syncthreads();                                        // sXa / sAct complete
+        for (int nt = wave; nt < HT; nt += kNW) {
+            float4 fa[HT];
+            load_fwd_frags_ld<HT, false>(P, ld0, nt * 16, lane, fa);
+            const int o = nt * 16 + (lane & 15);
+            f32x4 acc = mfma_rows_x_frags<HT>(sE1, HS, lane, fa, P[offB(0) + o]);
+            const float* wrow = P + (long)o * ld0 + H;
+            const float* arow = sXa + (lane & 15) * kXS;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * j + (lane >> 4);
+                const float bq = k < Ain ? wrow[k] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k], bq, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sH[(4 * (lane >> 4) + r) * HS + o] = act_fwd(acc[r], act);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 1; l < depth; ++l) {
+            layer_fwd<HT, true>(P + offW(l), H, P + offB(l), sH + (long)(l - 1) * kRows * HS, sH + (long)l * kRows * HS,
+                                act, wave, lane);
+            __syncthreads();
+        }
+        const float* Hlast = sH + (long)(depth - 1) * kRows * HS;
+        // output layer H -> H (linear): the prediction of enc_2, into sD0
+        layer_fwd<HT, true>(P + offW(depth), H, P + offB(depth), Hlast, sD0, -1, wave, lane);
+        __syncthreads();
+        // K8: f_loss = 0.5 mean((pred - enc_2)^2); d pred = (1 - beta) (pred - enc_2) / (B H); d enc_2 = -d pred
+        {
+            const float sc = (1.0f - u.icm_beta) / ((float)B * (float)H);
+            float part = 0.f;
+            float* dE2 = u.dEnc + ((long)(1 * 2 + 1) * u.Bpad + (long)g * kRows) * H;
+            for (int idx = tid; idx < kRows * H; idx += kThreadsU) {
+                const int s = idx / H, i = idx - s * H;
+                float dv = 0.f;
+                if (sRow[s] >= 0) {
+                    const float diff = sD0[s * HS + i] - sE2[s * HS + i];
+                    part += diff * diff;
+                    dv = sc * diff;
+                }
+                sD0[s * HS + i] = dv;
+                dE2[(long)s * H + i] = -dv;
+            }
+            part = block_sum(part, red);
+            if (tid == 0) u.loss_partials[g * 2 + 1] = 0.5f * part;
+        }
+        __syncthreads();
+        float* Dc = sD0;
+        float* Dn = sD1;
+        // output layer backward, then the hidden layers
+#pragma unroll 1
+        for (int l = depth; l >= 1; --l) {
+            const float* Hin = sH + (long)(l - 1) * kRows * HS;
+            layer_dgrad<HT>(P + offW(l), H, Dc, Hin, act, Dn, nullptr, wave, lane);
+            layer_wgrad<HT>(Dc, Hin, HS, HT, H, slab + offW(l), H, slab + offB(l), wave, lane, tid);
+            __syncthreads();
+            float* t = Dc; Dc = Dn; Dn = t;
+        }
+        layer_wgrad<HT>(Dc, sE1, HS, HT, H, slab + offW(0), (int)ld0, slab + offB(0), wave, lane, tid);
+        layer_wgrad<HT>(Dc, sXa, kXS, 1, Ain, slab + offW(0) + H, (int)ld0, nullptr, wave, lane, tid);
+        float* dE = u.dEnc + ((long)(1 * 2 + 0) * u.Bpad + (long)g * kRows) * H;
+        layer_dgrad<HT>(P + offW(0), ld0, Dc, nullptr, act, nullptr, dE, wave, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder backward: blockIdx.x = 2 * g + which (0: obs, 1: next_obs); slab index 2 * g + which
+// ------------------------------------------------------------------------------------------------
+template <int HT>
+__global__ __launch_bounds__(kThreadsU) void icm_encoder_bwd_kernel(IcmDev u) {
+    constexpr int H = 16 * HT, HS = H + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int which = blockIdx.x & 1, g = blockIdx.x >> 1;
+    const int O = u.O, NT0 = (O + 15) >> 4, INP = 16 * NT0 + 4;
+    const float* P = u.params + u.enc_off;
+    float* slab = u.slabs + (long)blockIdx.x * u.total + u.enc_off;
+    auto encW = [&](int l) -> long { return l == 0 ? 0 : (long)H * O + H + (long)(l - 1) * (H * H + H); };
+    auto encB = [&](int l) -> long { return encW(l) + (l == 0 ? (long)H * O : (long)H * H); };
+    float* smem = reinterpret_cast<float*>(icm_smem);
+    int* sRow = reinterpret_cast<int*>(smem);
+    float* sX = smem + 16;                      // [16, INP]
+    float* sH = sX + kRows * INP;               // 3 x [16, HS]
+    float* sD0 = sH + 3L * kRows * HS;
+    float* sD1 = sD0 + kRows * HS;
+    icm_rows(u, g, tid, sRow);
+    for (int i = tid; i < kRows * INP; i += kThreadsU) sX[i] = 0.f;
+    for (int idx = tid; idx < 3 * kRows * (H / 4); idx += kThreadsU) {
+        const int l = idx / (kRows * (H / 4)), rem = idx - l * (kRows * (H / 4));
+        const int s = rem / (H / 4), c4 = rem - s * (H / 4);
+        *reinterpret_cast<float4*>(sH + ((long)l * kRows + s) * HS + 4 * c4) = *reinterpret_cast<const float4*>(
+            u.actE + (((long)(which * 4 + l) * u.Bpad) + (long)g * kRows + s) * H + 4 * c4);
+    }
+    for (int idx = tid; idx < kRows * (H / 4); idx += kThreadsU) {
+        const int s = idx / (H / 4), c4 = idx - s * (H / 4);
+        const long o0 = ((long)(0 * 2 + which) * u.Bpad + (long)g * kRows + s) * H + 4 * c4;
+        const long o1 = ((long)(1 * 2 + which) * u.Bpad + (long)g * kRows + s) * H + 4 * c4;
+        const float4 a = *reinterpret_cast<const float4*>(u.dEnc + o0);
+        const float4 b = *reinterpret_cast<const float4*>(u.dEnc + o1);
+        *reinterpret_cast<float4*>(sD0 + s * HS + 4 * c4) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    __syncthreads();
+    {
+        const float* src = which == 0 ? u.obs : u.next_obs;
+        for (int idx = tid; idx < kRows * O; idx += kThreadsU) {
+            const int s = idx / O, i = idx - s * O;
+            const int row = sRow[s];
+            if (row >= 0) sX[s * INP + i] = src[(long)row * O + i];
+        }
+    }
+    float* Dc = sD0;
+    float* Dn = sD1;
+#pragma unroll 1
+    for (int l = 3; l >= 1; --l) {
+        const float* Hin = sH + (long)(l - 1) * kRows * HS;
+        layer_dgrad<HT>(P + encW(l), H, Dc, Hin, u.act, Dn, nullptr, wave, lane);
+        layer_wgrad<HT>(Dc, Hin, HS, HT, H, slab + encW(l), H, slab + encB(l), wave, lane, tid);
+        __syncthreads();
+        float* t = Dc; Dc = Dn; Dn = t;
+    }
+    layer_wgrad<HT>(Dc, sX, INP, NT0, O, slab + encW(0), O, slab + encB(0), wave, lane, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// reduce (+ Adam): the encoder region has 2 * nT slabs, the two models nT
+// ------------------------------------------------------------------------------------------------
+constexpr int kIcmRedCols = 64;
+constexpr int kIcmRedRows = 16;
+
+__global__ __launch_bounds__(kIcmRedCols * kIcmRedRows) void icm_reduce_kernel(IcmDev u) {
+    __shared__ float4 tile[kIcmRedRows][kIcmRedCols];
+    __shared__ float sBc[2];
+    const int c = threadIdx.x & (kIcmRedCols - 1), r = threadIdx.x / kIcmRedCols;
+    const long n4 = u.total >> 2;
+    const long idx = (long)blockIdx.x * kIcmRedCols + c;
+    const float4* sl = reinterpret_cast<const float4*>(u.slabs);
+    // the slab count is uniform per block only if the block does not straddle the encoder boundary;
+    // it is evaluated per column and the loop runs to the larger count with masked loads
+    const long p = idx * 4;
+    const int ns = (p >= u.enc_off && p < u.enc_off + u.enc_size) ? 2 * u.nT : u.nT;
+    if (threadIdx.x == 0 && u.fused_adam) {
+        const double t = (double)u.step_count[0];
+        sBc[0] = (float)((double)u.lr[0] / (1.0 - pow((double)u.beta1, t)));
+        sBc[1] = (float)sqrt(1.0 - pow((double)u.beta2, t));
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g0 = 0; g0 < 2 * u.nT; g0 += kIcmRedRows) {
+        const int g = g0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < n4 && g < ns) v = sl[(long)g * n4 + idx];
+        tile[r][c] = v;
+        __syncthreads();
+        if (r == 0) {
+#pragma unroll
+            for (int k = 0; k < kIcmRedRows; ++k) {
+                const float4 t = tile[k][c];
+                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            }
+        }
+        __syncthreads();
+    }
+    if (r == 0 && idx < n4) {
+        reinterpret_cast<float4*>(u.grads)[idx] = acc;
+        if (u.fused_adam) {
+            const float step_size = sBc[0], bc2_sqrt = sBc[1], gs = u.grad_scale;
+            float4 pp = reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx];
+            float4 m = reinterpret_cast<float4*>(u.exp_avg)[idx];
+            float4 v = reinterpret_cast<float4*>(u.exp_avg_sq)[idx];
+#define PPOAF_ADAM1(cc)                                                          \
+            {                                                                    \
+                const float gi = acc.cc * gs;                                    \
+                m.cc = u.beta1 * m.cc + (1.0f - u.beta1) * gi;                   \
+                v.cc = u.beta2 * v.cc + (1.0f - u.beta2) * gi * gi;              \
+                pp.cc = pp.cc - step_size * (m.cc / (sqrtf(v.cc) / bc2_sqrt + u.adam_eps)); \
+            }
+            PPOAF_ADAM1(x) PPOAF_ADAM1(y) PPOAF_ADAM1(z) PPOAF_ADAM1(w)
+#undef PPOAF_ADAM1
+            reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx] = pp;
+            reinterpret_cast<float4*>(u.exp_avg)[idx] = m;
+            reinterpret_cast<float4*>(u.exp_avg_sq)[idx] = v;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float inv = 0.f, fl = 0.f;
+        for (int g = 0; g < u.nT; ++g) { inv += u.loss_partials[g * 2]; fl += u.loss_partials[g * 2 + 1]; }
+        const float n = (float)u.B;
+        inv = u.discrete ? inv / n : inv / (n * (float)u.A);
+        fl = fl / (n * (float)u.H);
+        u.totals[0] += (double)((1.0f - u.icm_beta) * fl + u.icm_beta * inv);
+        u.totals[1] += 1.0;
+        u.cursor[0] += 1;
+    }
+}
+
+static int make_icm(const ppoaf_icm_update_args_t* a, IcmDev& u) {
+    PPOAF_REQUIRE(a, "icm_update: null args");
+    PPOAF_REQUIRE(a->hidden == 64 || a->hidden == 128, "icm_update: hidden=%d is not an instantiated width (64, 128)", a->hidden);
+    PPOAF_REQUIRE(a->obs_dim >= 1 && a->obs_dim <= 1024, "icm_update: obs_dim=%d", a->obs_dim);
+    PPOAF_REQUIRE(a->action_dim >= 1 && a->action_dim <= 8 && a->fwd_action_dim >= 1 && a->fwd_action_dim <= 8,
+                  "icm_update: action_dim=%d fwd_action_dim=%d must be in [1,8]", a->action_dim, a->fwd_action_dim);
+    PPOAF_REQUIRE(a->depth_inv >= 1 && a->depth_inv <= 3 && a->depth_fwd >= 1 && a->depth_fwd <= 3,
+                  "icm_update: hidden depths (%d, %d) out of [1,3]", a->depth_inv, a->depth_fwd);
+    PPOAF_REQUIRE(a->activation >= 0 && a->activation <= 2, "icm_update: activation=%d", a->activation);
+    PPOAF_REQUIRE(a->B >= 1 && a->batch_stride >= a->B, "icm_update: B=%ld stride=%ld", (long)a->B, (long)a->batch_stride);
+    PPOAF_REQUIRE(a->params && a->grads && a->exp_avg && a->exp_avg_sq && a->slabs && a->step_count && a->lr &&
+                      a->obs && a->next_obs && a->actions && a->perm && a->cursor && a->act_scratch &&
+                      a->denc_scratch && a->loss_partials && a->totals,
+                  "icm_update: null pointer");
+    PPOAF_REQUIRE(((uintptr_t)a->params & 15) == 0 && ((uintptr_t)a->grads & 15) == 0 && ((uintptr_t)a->slabs & 15) == 0 &&
+                      ((uintptr_t)a->exp_avg & 15) == 0 && ((uintptr_t)a->exp_avg_sq & 15) == 0 &&
+                      ((uintptr_t)a->act_scratch & 15) == 0 && ((uintptr_t)a->denc_scratch & 15) == 0,
+                  "icm_update: buckets and scratch must be 16-byte aligned");
+    const long H = a->hidden, O = a->obs_dim, A = a->action_dim, Ain = a->fwd_action_dim;
+    auto pad4 = [](long x) { return (x + 3) / 4 * 4; };
+    const long enc_size = H * O + H + 3 * (H * H + H);
+    const long inv_size = 2 * H * H + H + (long)(a->depth_inv - 1) * (H * H + H) + A * H + pad4(A);
+    const long fwd_size = H * (H + Ain) + H + (long)(a->depth_fwd - 1) * (H * H + H) + H * H + H;
+    PPOAF_REQUIRE(a->enc_offset % 4 == 0 && a->inv_offset == a->enc_offset + enc_size &&
+                      a->fwd_offset == a->inv_offset + inv_size && a->bucket_total == a->fwd_offset + fwd_size,
+                  "icm_update: bucket layout (enc %ld, inv %ld, fwd %ld, total %ld) does not match the topology "
+                  "(sizes %ld, %ld, %ld)", (long)a->enc_offset, (long)a->inv_offset, (long)a->fwd_offset,
+                  (long)a->bucket_total, enc_size, inv_size, fwd_size);
+    PPOAF_REQUIRE(a->bucket_total % 4 == 0, "icm_update: bucket_total must be a multiple of 4");
+    u.O = a->obs_dim; u.H = a->hidden; u.A = a->action_dim; u.Ain = a->fwd_action_dim;
+    u.d_inv = a->depth_inv; u.d_fwd = a->depth_fwd; u.act = a->activation; u.discrete = a->discrete != 0;
+    u.enc_off = a->enc_offset; u.inv_off = a->inv_offset; u.fwd_off = a->fwd_offset; u.enc_size = enc_size;
+    u.total = a->bucket_total;
+    u.params = a->params; u.grads = a->grads; u.exp_avg = a->exp_avg; u.exp_avg_sq = a->exp_avg_sq; u.slabs = a->slabs;
+    u.step_count = a->step_count; u.lr = a->lr; u.beta1 = a->beta1; u.beta2 = a->beta2; u.adam_eps = a->adam_eps;
+    u.grad_scale = a->grad_scale; u.obs = a->obs; u.next_obs = a->next_obs; u.actions = a->actions;
+    u.perm = a->perm; u.row_map = a->row_map; u.n_rows = a->n_rows; u.cursor = a->cursor; u.B = a->B;
+    u.batch_stride = a->batch_stride;
+    u.nT = (int)((a->B + kRows - 1) / kRows);
+    u.Bpad = (long)u.nT * kRows;
+    u.icm_beta = a->icm_beta; u.fused_adam = a->fused_adam != 0;
+    u.actE = a->act_scratch; u.dEnc = a->denc_scratch; u.loss_partials = a->loss_partials; u.totals = a->totals;
+    return PPOAF_OK;
+}
+
+template <int HT>
+static int launch_icm_fwd_bwd(const IcmDev& u, hipStream_t s) {
+    const size_t HS = 16 * HT + 4, H = 16 * HT;
+    const size_t INP = 16 * ((u.O + 15) / 16) + 4;
+    const size_t lds_enc_f = (16 + kRows * INP + 4 * kRows * HS) * 4;
+    const size_t lds_enc_b = (16 + kRows * INP + 5 * kRows * HS) * 4;
+    const int dmax = u.d_inv > u.d_fwd ? u.d_inv : u.d_fwd;
+    const size_t lds_heads = (160 + 8 * H + kRows * kXS + (4 + dmax) * kRows * HS + 2 * kRows * kMaxOut) * 4;
+    PPOAF_REQUIRE(lds_enc_b <= 64 * 1024 && lds_heads <= 64 * 1024 && lds_enc_f <= 64 * 1024,
+                  "icm_update: needs %zu / %zu B of LDS (> 64 KiB): obs_dim or depth too large for this build",
+                  lds_enc_b, lds_heads);
+    const unsigned grid = 2u * (unsigned)u.nT;
+    hipLaunchKernelGGL(icm_encoder_fwd_kernel<HT>, dim3(grid), dim3(kThreadsU), lds_enc_f, s, u);
+    int rc = check_launch("icm_encoder_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(icm_heads_kernel<HT>, dim3(grid), dim3(kThreadsU), lds_heads, s, u);
+    rc = check_launch("icm_heads");
+    if (rc) return rc;
+    hipLaunchKernelGGL(icm_encoder_bwd_kernel<HT>, dim3(grid), dim3(kThreadsU), lds_enc_b, s, u);
+    return check_launch("icm_encoder_bwd");
+}
+
+}  // namespace ppoaf
+
+using namespace ppoaf;
+
+extern "C" int ppoaf_icm_update_fwd_bwd(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream) {
+    IcmDev u;
+    const int rc = make_icm(args, u);
+    if (rc) return rc;
+    if (u.H == 64) return launch_icm_fwd_bwd<4>(u, (hipStream_t)stream);
+    return launch_icm_fwd_bwd<8>(u, (hipStream_t)stream);
+}
+
+extern "C" int ppoaf_icm_update_reduce(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream) {
+    IcmDev u;
+    const int rc = make_icm(args, u);
+    if (rc) return rc;
+    const long n4 = u.total >> 2;
+    hipLaunchKernelGGL(icm_reduce_kernel, dim3((unsigned)((n4 + kIcmRedCols - 1) / kIcmRedCols)),
+                       dim3(kIcmRedCols * kIcmRedRows), 0, (hipStream_t)stream, u);
+    return check_launch("icm_reduce");
+}

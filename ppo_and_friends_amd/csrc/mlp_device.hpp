@@ -108,6 +108,32 @@ __device__ __forceinline__ f32x4 mfma_rows_x_frags(const float* __restrict__ A, 
     return acc0 + acc1;
 }
 
+// Weight gradient of one 16-row block of outputs: dW[m0+.., i] = sum_s D[s][m0+..] * Bsrc[s][i] for
+// i < n_valid (n tiles of 16 columns), K = the 16 rows of the workgroup.  Both operands come from LDS.
+__device__ __forceinline__ void wgrad_mtile(const float* __restrict__ D, int HS, const float* __restrict__ Bsrc,
+                                            int strideB, int m0, int ntiles, int n_valid, int lane,
+                                            float* __restrict__ dstW, int ldw) {
+    float a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = D[(4 * (lane >> 4) + j) * HS + m0 + (lane & 15)];
+    const float* bcol = Bsrc + (4 * (lane >> 4)) * strideB + (lane & 15);
+    float* drow = dstW + (long)(m0 + 4 * (lane >> 4)) * ldw + (lane & 15);
+#pragma unroll 4
+    for (int nt = 0; nt < ntiles; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bcol[j * strideB + 16 * nt], acc, 0, 0, 0);
+        if (16 * nt + (lane & 15) < n_valid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) drow[(long)r * ldw + 16 * nt] = acc[r];
+        }
+    }
+}
+
+constexpr int kNW = 8;                    // waves per workgroup of the fused update kernels
+constexpr int kThreadsU = 64 * kNW;
+
 // host: validate a network descriptor and fill the device view
 int fill_net(const ppoaf_mlp_desc_t& d, NetDev& n, const char* what);
 

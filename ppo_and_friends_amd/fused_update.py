@@ -291,3 +291,178 @@ class FusedPolicyUpdate:
         if self.world > 1:
             mpi_utils.allreduce_sum_(t)
         return t.cpu().numpy()
+
+
+# ======================================================================================
+# K14: fused ICM update
+# ======================================================================================
+def _describe_icm(icm, action_dtype):
+    """IcmUpdateArgs topology fields of an ICM living in one flat bucket, or (None, reason)."""
+    from .networks.icm import ICM, LinearObservationEncoder
+    if not isinstance(icm, ICM) or not isinstance(icm.obs_encoder, LinearObservationEncoder):
+        return None, "ICM with a LinearObservationEncoder is what the fused kernels cover"
+    enc = [icm.obs_encoder.enc_1, icm.obs_encoder.enc_2, icm.obs_encoder.enc_3, icm.obs_encoder.enc_4]
+    inv = [m for m in icm.inv_model.sequential_net.modules() if isinstance(m, nn.Linear)]
+    fwd = [m for m in icm.forward_model.sequential_net.modules() if isinstance(m, nn.Linear)]
+    H, O = enc[0].out_features, enc[0].in_features
+    if H not in (64, 128):
+        return None, f"ICM width {H} is not an instantiated width (64, 128)"
+    if any((m.in_features, m.out_features) != (H, H) for m in enc[1:]):
+        return None, "encoder layers must share one width (encoded_obs_dim == encoder_hidden_size)"
+    if len(inv) < 2 or len(fwd) < 2 or len(inv) > 4 or len(fwd) > 4:
+        return None, "inverse / forward model need 1..3 hidden layers"
+    A, Ain = inv[-1].out_features, fwd[0].in_features - H
+    want_inv = [(2 * H, H)] + [(H, H)] * (len(inv) - 2) + [(H, A)]
+    want_fwd = [(H + Ain, H)] + [(H, H)] * (len(fwd) - 2) + [(H, H)]
+    if [(m.in_features, m.out_features) for m in inv] != want_inv or \
+            [(m.in_features, m.out_features) for m in fwd] != want_fwd:
+        return None, "inverse / forward model widths must equal the encoder width"
+    if not (1 <= A <= 8 and 1 <= Ain <= 8):
+        return None, f"action widths ({A}, {Ain}) must be in [1, 8]"
+    if action_dtype not in ("discrete", "continuous") or (action_dtype == "discrete" and Ain != A):
+        return None, "unsupported action space for the fused ICM update"
+    acts = {_activation_code(a) for a in (icm.activation, icm.obs_encoder.activation, icm.inv_model.activation,
+                                           icm.forward_model.activation)}
+    if len(acts) != 1 or None in acts:
+        return None, "activation is not one shared ReLU / LeakyReLU(0.01) / Tanh"
+    base = icm.flat_params.data_ptr()
+    off, marks = 0, []
+    for group in (enc, inv, fwd):
+        marks.append(off)
+        for m in group:
+            for p in (m.weight, m.bias):
+                if (p.data_ptr() - base) // 4 != off:
+                    return None, "parameter layout differs from the kernel's layer table"
+                off += (p.numel() + 3) // 4 * 4
+    if off != icm.flat_params.numel():
+        return None, "the ICM holds parameters the fused kernel does not know about"
+    return dict(obs_dim=O, hidden=H, action_dim=A, fwd_action_dim=Ain, depth_inv=len(inv) - 1,
+                depth_fwd=len(fwd) - 1, activation=acts.pop(), discrete=int(action_dtype == "discrete"),
+                enc_offset=marks[0], inv_offset=marks[1], fwd_offset=marks[2], bucket_total=off), ""
+
+
+class FusedIcmUpdate:
+    """
+    Host driver of K14 (csrc/icm_update.hip): one epoch of PPO._icm_batch_train (ppo.py:2487-2567).
+    Per mini-batch: fwd_bwd (3 launches) -> reduce [+ Adam]; with more ranks reduce -> all-reduce ->
+    K11 Adam.  On a single rank `graph_chunk` mini-batches are captured into a hipGraph and replayed
+    (all launches read the device cursor).
+    """
+
+    graph_chunk = 32
+
+    @staticmethod
+    def unsupported_reason(pol):
+        if not pol.enable_icm:
+            return "no ICM"
+        _, why = _describe_icm(pol.icm_model, pol.action_dtype)
+        return why
+
+    def __init__(self, ppo, policy_id):
+        self.ppo, self.policy_id = ppo, policy_id
+        pol = self.pol = ppo.policies[policy_id]
+        dev = pol.device
+        self.topo, _ = _describe_icm(pol.icm_model, pol.action_dtype)
+        self.world = mpi_utils.get_num_procs()
+        self.B = ppo.batch_size
+        nT = (self.B + K.UPDATE_ROWS_PER_WG - 1) // K.UPDATE_ROWS_PER_WG
+        H, total = self.topo["hidden"], self.topo["bucket_total"]
+        self.slabs = torch.zeros(2 * nT, total, dtype=torch.float32, device=dev)
+        self.act_scratch = torch.zeros(2, 4, 16 * nT, H, dtype=torch.float32, device=dev)
+        self.denc_scratch = torch.zeros(2, 2, 16 * nT, H, dtype=torch.float32, device=dev)
+        self.loss_partials = torch.zeros(nT, 2, dtype=torch.float32, device=dev)
+        self.totals = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._lib = _lib.load()
+        self.perm = None
+        self._graphs, self._args = {}, {}
+
+    def _make_args(self, B):
+        pol, buf, opt = self.pol, self.pol.buffer, self.pol.icm_optim
+        a = _lib.IcmUpdateArgs()
+        for k, v in self.topo.items():
+            setattr(a, k, v)
+        icm = pol.icm_model
+        a.params, a.grads = icm.flat_params.data_ptr(), icm.flat_grads.data_ptr()
+        a.exp_avg, a.exp_avg_sq = opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr()
+        a.slabs = self.slabs.data_ptr()
+        a.step_count, a.lr = opt.step_count.data_ptr(), opt.lr.data_ptr()
+        a.beta1, a.beta2, a.adam_eps = opt.betas[0], opt.betas[1], opt.eps
+        a.grad_scale = 1.0 / self.world
+        a.obs, a.next_obs = buf.observations.data_ptr(), buf.next_observations.data_ptr()
+        a.actions = buf.actions.data_ptr()
+        a.perm, a.row_map, a.n_rows = self.perm.data_ptr(), buf.row_map.data_ptr(), buf.num_transitions
+        a.cursor, a.B, a.batch_stride = self.cursor.data_ptr(), B, self.B
+        a.icm_beta = float(pol.icm_beta)
+        a.fused_adam = int(self.world == 1)
+        a.act_scratch, a.denc_scratch = self.act_scratch.data_ptr(), self.denc_scratch.data_ptr()
+        a.loss_partials, a.totals = self.loss_partials.data_ptr(), self.totals.data_ptr()
+        return a
+
+    def begin_epoch(self, perm):
+        pol, buf = self.pol, self.pol.buffer
+        N = perm.numel()
+        if self.perm is None or self.perm.numel() != N:
+            self.perm = torch.empty(N, dtype=torch.int64, device=pol.device)
+            self._graphs.clear()
+        self.perm.copy_(perm)
+        self.cursor.zero_()
+        self.totals.zero_()
+        sig = (buf.observations.data_ptr(), buf.next_observations.data_ptr(), buf.actions.data_ptr(),
+               buf.num_transitions, self.perm.data_ptr(), float(pol.icm_beta))
+        if self._args.get("sig") != sig:
+            self._args = {"sig": sig}
+            self._graphs.clear()
+        self.n_full, self.tail = N // self.B, N % self.B
+
+    def _args_for(self, B):
+        if B not in self._args:
+            self._args[B] = self._make_args(B)
+        return self._args[B]
+
+    def _one(self, args):
+        lib, st, ref = self._lib, K.stream(), C.byref(args)
+        rc = lib.ppoaf_icm_update_fwd_bwd(ref, st)
+        if rc == 0:
+            rc = lib.ppoaf_icm_update_reduce(ref, st)
+        if rc != 0:
+            _lib.check(rc, "icm_update")
+        if self.world > 1:
+            mpi_utils.allreduce_sum_(self.pol.icm_model.flat_grads)
+            self.pol.icm_optim.step(grad_scale=1.0 / self.world, max_norm=None)
+
+    def run_epoch(self):
+        args = self._args_for(self.B)
+        left = self.n_full
+        use_graph = self.ppo.use_graphs and self.world == 1
+        chunk = self.graph_chunk
+        while left > 0:
+            if use_graph and left >= chunk:
+                g = self._graphs.get(chunk)
+                if g is None:
+                    s = torch.cuda.Stream()
+                    s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        for _ in range(chunk):
+                            self._one(args)               # warm-up pass: these mini-batches are real
+                    torch.cuda.current_stream().wait_stream(s)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        for _ in range(chunk):
+                            self._one(args)               # capture only
+                    self._graphs[chunk] = g
+                else:
+                    g.replay()
+                left -= chunk
+            else:
+                self._one(args)
+                left -= 1
+        if self.tail:
+            self._one(self._args_for(self.tail))
+
+    def end_epoch(self):
+        """-> numpy [sum of icm_loss over mini-batches, mini-batch count] (summed over ranks)."""
+        t = self.totals.clone()
+        if self.world > 1:
+            mpi_utils.allreduce_sum_(t)
+        return t.cpu().numpy()

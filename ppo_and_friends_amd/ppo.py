@@ -479,6 +479,14 @@ class PPO:
         perm = data_loader.epoch_permutation()
         N = perm.numel()
         world = mpi_utils.get_num_procs()
+        fused = self._fused_icm_updater(policy_id)
+        if fused is not None:
+            fused.begin_epoch(perm)
+            fused.run_epoch()
+            data_loader.prefetch()
+            t = fused.end_epoch()
+            self.status_dict[policy_id]["icm loss"] = t[0] / max(t[1], 1.0)
+            return
         total = self._scratch("icm_total", 1, torch.float64)
         total.zero_()
         counter = 0
@@ -518,6 +526,18 @@ class PPO:
             mpi_utils.allreduce_sum_(t)
         t = t.cpu().numpy()
         self.status_dict[policy_id]["icm loss"] = t[0] / max(t[1], 1.0)
+
+    def _fused_icm_updater(self, policy_id):
+        if self.update_mode == "torch" or self.device.type != "cuda":
+            return None
+        key = ("icm", policy_id)
+        if key not in self._fused:
+            from .fused_update import FusedIcmUpdate
+            why = FusedIcmUpdate.unsupported_reason(self.policies[policy_id])
+            if why and self.verbose:
+                rank_print(f"policy {policy_id}: torch ICM update path ({why})")
+            self._fused[key] = None if why else FusedIcmUpdate(self, policy_id)
+        return self._fused[key]
 
     def _fused_updater(self, policy_id, B):
         if self.update_mode == "torch" or self.device.type != "cuda":

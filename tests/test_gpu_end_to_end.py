@@ -303,7 +303,7 @@ def test_icm_rollout_rewards_and_training_match_cpu_port(update_mode):
                                    rtol=1e-4, err_msg=f"iteration {it}")
         np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), ref.rewards_to_go.numpy(), rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(ds.advantages.cpu().numpy(), ref.advantages.numpy(), rtol=1e-4, atol=1e-4)
-        loader = PermutationLoader(pol.dataset, B, ppo.loader_generator)
+        loader = PermutationLoader(pol.dataset, B, ppo.loader_generator, ppo._perm_cache)   # shared prefetch cache
         pol.train()
         ppo._ppo_batch_train(loader, "p")
         r = cpu.train_epoch()
@@ -405,3 +405,65 @@ def test_filter_stack_in_the_loop(update_mode):
         refs = cpu.train_epoch()
         for k in ("actor loss", "critic loss"):
             np.testing.assert_allclose(ppo.status_dict["p"][k], refs[k], rtol=5e-5, atol=5e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("case", [
+    dict(kind="d", NA=3, O=6, H=128, E=12, T=16, B=40),                      # 4 full mini-batches + a tail of 32
+    dict(kind="c", NA=6, O=17, H=128, E=12, T=16, B=64),
+    dict(kind="d", NA=5, O=18, H=64, E=8, T=12, B=32, d_inv=3, d_fwd=1),
+    dict(kind="c", NA=2, O=3, H=64, E=16, T=64, B=16, graphs=True),          # 64 mini-batches: two graph chunks
+])
+def test_fused_icm_update_matches_oracle(case):
+    """
+    K14 (fused ICM mini-batch update: encoder x2, inverse + forward model, both losses, backward, slab
+    reduce, Adam) against the torch-CPU ICM of oracle/icm_oracle.py trained on the same mini-batches.
+    """
+    from oracle import icm_oracle
+    from ppo_and_friends_amd.ppo import PPO
+    from ppo_and_friends_amd.fused_update import FusedIcmUpdate
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    dev = torch.device("cuda", 0)
+    c = dict(d_inv=2, d_fwd=2, graphs=False); c.update(case)
+    E, T, O, NA, B, H = c["E"], c["T"], c["O"], c["NA"], c["B"], c["H"]
+    space = Discrete(NA) if c["kind"] == "d" else Box(-1.0, 1.0, (NA,), np.float32)
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, space, T, dev, reward="uniform", seed=5, term_prob=0.05)
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    icm_kw = dict(encoded_obs_dim=H, encoder_hidden_size=H, inverse_hidden_size=H, forward_hidden_size=H,
+                  inverse_hidden_depth=c["d_inv"], forward_hidden_depth=c["d_fwd"])
+    ppo = PPO(env_gen, {"p": (None, sp, sp, space, dict(enable_icm=True, icm_kw_args=icm_kw))}, device=dev,
+              random_seed=4, normalize_obs=False, normalize_rewards=False, envs_per_proc=E, ts_per_rollout=T,
+              batch_size=B, epochs_per_iter=1, use_graphs=c["graphs"])
+    pol = ppo.policies["p"]
+    assert FusedIcmUpdate.unsupported_reason(pol) == ""
+    ref = icm_oracle.ICM(O, NA, discrete=c["kind"] == "d", enc=H, hidden=H, depth=c["d_inv"])
+    if c["d_fwd"] != c["d_inv"]:
+        ref.forward_model.sequential_net = cpu_ppo_loop.make_mlp(H + NA, H, H, c["d_fwd"], out_gain=1.0)
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in pol.icm_model.state_dict().items()})
+    opt = torch.optim.Adam(ref.parameters(), lr=3e-4, eps=1e-5)
+    ppo.rollout()
+    buf = pol.buffer
+    N = E * T
+    rm = buf.row_map.cpu().long()
+    flat = lambda t: t.reshape((N,) + tuple(t.shape[2:])).cpu()[rm]
+    obs, nxt, act = flat(buf.observations), flat(buf.next_observations), flat(buf.actions)
+    fused = FusedIcmUpdate(ppo, "p")
+    g = torch.Generator().manual_seed(9)
+    for epoch in range(2):
+        perm = torch.randperm(N, generator=g)
+        fused.begin_epoch(perm.to(dev))
+        fused.run_epoch()
+        t = fused.end_epoch()
+        tot, cnt = 0.0, 0
+        for o in range(0, N, B):
+            idx = perm[o:o + B]
+            _, inv_loss, f_loss = ref(obs[idx], nxt[idx], act[idx])
+            loss = (1.0 - pol.icm_beta) * f_loss + pol.icm_beta * inv_loss
+            opt.zero_grad(); loss.backward(); opt.step()
+            tot += float(loss); cnt += 1
+        assert t[1] == cnt
+        np.testing.assert_allclose(t[0] / cnt, tot / cnt, rtol=2e-5, err_msg=f"icm loss, epoch {epoch}")
+    w = torch.cat([p.detach().cpu().reshape(-1) for p in pol.icm_model.parameters()]).numpy()
+    w_ref = torch.cat([p.detach().reshape(-1) for p in ref.parameters()]).numpy()
+    np.testing.assert_allclose(w, w_ref, rtol=1e-4, atol=2e-5)
+    assert int(pol.icm_optim.step_count.item()) == 2 * cnt
