@@ -132,7 +132,7 @@ def main():
     pol = ppo.policies["cartpole"]
 
     def barrier():
-        if world > 1:
+        if mpi_utils.distributed_path():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -167,7 +167,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dt_t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if mpi_utils.distributed_path():
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
     dt = float(dt_t.item())
 
@@ -197,7 +197,8 @@ def main():
                                    f"epochs_per_iter={args.epochs}, fixed-length synthetic trajectories"),
                       "agent_steps_per_iteration": world * E * T * A,
                       "global_env_steps_per_iteration": world * E * T,
-                      "parallelism": f"dp{world}", "hip_graphs": not args.no_graphs,
+                      "parallelism": f"dp{world}", "hip_graphs": (not args.no_graphs) and not mpi_utils.distributed_path(),
+                      "multi_rank_path": mpi_utils.distributed_path(),
                       "rollout_s": round(ppo.status_dict["global status"]["rollout time"], 4),
                       "train_s": round(ppo.status_dict["global status"]["train time"], 4)},
            "roofline": roofline}
@@ -243,7 +244,7 @@ def main():
                                          f"{os.cpu_count()} host cpus, which is slower)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if mpi_utils.is_initialized():
         dist.destroy_process_group()
 
 

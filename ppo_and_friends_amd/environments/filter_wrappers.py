@@ -160,7 +160,7 @@ class _FilterPlan:
             need = K.env_filter_record_len(G, self.W_o if of is not None else 0, self.W_c if cf is not None else 0,
                                            rf is not None)
             records = self._record[:need]
-            if mpi_utils.get_num_procs() > 1:
+            if mpi_utils.distributed_path():
                 records = mpi_utils.allgather_records(records).reshape(-1)      # stats.py:47-50
         K.env_filter_apply(of, cf, rf, G, n, records)
         return out_o, out_c, out_r

@@ -115,6 +115,7 @@ class FusedPolicyUpdate:
         self.pol = pol
         dev = pol.device
         self.world = mpi_utils.get_num_procs()
+        self.multi = mpi_utils.distributed_path()       # collectives + eager launches (N > 1, or its rehearsal)
         self.head = K.HEAD_GAUSSIAN if isinstance(pol.actor.distribution, GaussianDistribution) \
             else K.HEAD_CATEGORICAL
         self.actor_desc, _ = _describe(pol.actor, pol.policy_params, self.head == K.HEAD_GAUSSIAN)
@@ -193,7 +194,7 @@ class FusedPolicyUpdate:
         nb = (N + self.B - 1) // self.B
         if ppo.normalize_values:
             local = K.minibatch_moments(buf.rewards_to_go.view(-1), self.perm, buf.row_map, self.B)
-            if self.world > 1:
+            if self.multi:
                 allr = mpi_utils.allgather_records(local.reshape(-1)).view(self.world, nb, 3)
                 rec = allr.permute(1, 0, 2).contiguous()
             else:
@@ -231,7 +232,7 @@ class FusedPolicyUpdate:
         lib = self._lib
         st = K.stream()
         ref = C.byref(args)
-        single = self.world == 1
+        single = not self.multi
         rc = lib.ppoaf_ppo_update_fwd_bwd(ref, st)
         if rc == 0:
             rc = lib.ppoaf_ppo_update_reduce(ref, 1 if single else 0, st)
@@ -249,7 +250,7 @@ class FusedPolicyUpdate:
     def run_epoch(self):
         args = self._args_for(self.B)
         left = self.n_full
-        use_graph = self.ppo.use_graphs and self.world == 1
+        use_graph = self.ppo.use_graphs and not self.multi
         chunk = self.graph_chunk
         while left > 0:
             if use_graph and left >= chunk:
@@ -288,7 +289,7 @@ class FusedPolicyUpdate:
                 # ppo.py:2299-2306: a size-1 batch still updates the normaliser, then is skipped (quirk Q9)
                 rs.integrate_records(self.records[self.n_full].contiguous())
         t = self.totals.clone()
-        if self.world > 1:
+        if self.multi:
             mpi_utils.allreduce_sum_(t)
         return t.cpu().numpy()
 
@@ -364,6 +365,7 @@ class FusedIcmUpdate:
         dev = pol.device
         self.topo, _ = _describe_icm(pol.icm_model, pol.action_dtype)
         self.world = mpi_utils.get_num_procs()
+        self.multi = mpi_utils.distributed_path()       # collectives + eager launches (N > 1, or its rehearsal)
         self.B = ppo.batch_size
         nT = (self.B + K.UPDATE_ROWS_PER_WG - 1) // K.UPDATE_ROWS_PER_WG
         H, total = self.topo["hidden"], self.topo["bucket_total"]
@@ -394,7 +396,7 @@ class FusedIcmUpdate:
         a.perm, a.row_map, a.n_rows = self.perm.data_ptr(), buf.row_map.data_ptr(), buf.num_transitions
         a.cursor, a.B, a.batch_stride = self.cursor.data_ptr(), B, self.B
         a.icm_beta = float(pol.icm_beta)
-        a.fused_adam = int(self.world == 1)
+        a.fused_adam = int(not self.multi)
         a.act_scratch, a.denc_scratch = self.act_scratch.data_ptr(), self.denc_scratch.data_ptr()
         a.loss_partials, a.totals = self.loss_partials.data_ptr(), self.totals.data_ptr()
         return a
@@ -427,14 +429,14 @@ class FusedIcmUpdate:
             rc = lib.ppoaf_icm_update_reduce(ref, st)
         if rc != 0:
             _lib.check(rc, "icm_update")
-        if self.world > 1:
+        if self.multi:
             mpi_utils.allreduce_sum_(self.pol.icm_model.flat_grads)
             self.pol.icm_optim.step(grad_scale=1.0 / self.world, max_norm=None)
 
     def run_epoch(self):
         args = self._args_for(self.B)
         left = self.n_full
-        use_graph = self.ppo.use_graphs and self.world == 1
+        use_graph = self.ppo.use_graphs and not self.multi
         chunk = self.graph_chunk
         while left > 0:
             if use_graph and left >= chunk:
@@ -463,6 +465,6 @@ class FusedIcmUpdate:
     def end_epoch(self):
         """-> numpy [sum of icm_loss over mini-batches, mini-batch count] (summed over ranks)."""
         t = self.totals.clone()
-        if self.world > 1:
+        if self.multi:
             mpi_utils.allreduce_sum_(t)
         return t.cpu().numpy()

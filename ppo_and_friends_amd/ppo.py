@@ -450,8 +450,7 @@ class PPO:
                 self._minibatch_step(policy_id, ds, perm_slice.contiguous(), rec_static.view(world, W3), totals)
             if perm_slice.numel() == 1:
                 return
-            if world > 1:
-                mpi_utils.allreduce_sum_(pol.policy_grads)
+            mpi_utils.allreduce_sum_(pol.policy_grads)          # identity without a process group
             if static:
                 self._replay_or_capture(("opt", policy_id), lambda: self._optimizer_step(policy_id))
             else:
@@ -463,8 +462,7 @@ class PPO:
             run(perm[n_full * B:], n_full, False)
 
         t = totals.clone()
-        if world > 1:
-            mpi_utils.allreduce_sum_(t)
+        mpi_utils.allreduce_sum_(t)
         self._publish_epoch_stats(policy_id, t.cpu().numpy())
 
     def _icm_batch_train(self, data_loader, policy_id):
@@ -522,8 +520,7 @@ class PPO:
                 opt()
             counter += 1
         t = torch.cat([total, torch.tensor([float(counter)], dtype=torch.float64, device=self.device)])
-        if world > 1:
-            mpi_utils.allreduce_sum_(t)
+        mpi_utils.allreduce_sum_(t)
         t = t.cpu().numpy()
         self.status_dict[policy_id]["icm loss"] = t[0] / max(t[1], 1.0)
 
@@ -602,7 +599,7 @@ class PPO:
         m2 = (((x - mean[:, None]) ** 2) * mask).sum(1)
         rec = torch.stack([cnt, mean, m2], dim=1)                     # [nb, 3]
         world = mpi_utils.get_num_procs()
-        if world == 1:
+        if not mpi_utils.distributed_path():
             return rec.unsqueeze(0)
         out = mpi_utils.allgather_records(rec.reshape(-1))
         return out.view(world, nb, 3)

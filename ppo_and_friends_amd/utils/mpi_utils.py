@@ -34,6 +34,20 @@ def get_num_procs():
     return dist.get_world_size() if is_initialized() else 1
 
 
+def rehearsing():
+    """
+    PPOAF_REHEARSE_MULTI_RANK=1: take every N > 1 code path (process group, per-mini-batch gradient
+    all-reduce, record all-gathers, eager launches) even with ONE rank.  A one-GPU box cannot host two
+    RCCL ranks, so this is how the RCCL call sequence of the multi-GPU path is exercised there.
+    """
+    return os.environ.get("PPOAF_REHEARSE_MULTI_RANK", "0") == "1"
+
+
+def distributed_path():
+    """True when collectives have to run: more than one rank, or a rehearsal of that path."""
+    return is_initialized() and (dist.get_world_size() > 1 or rehearsing())
+
+
 def init_process_group_from_env(backend=None):
     """
     torchrun-style bootstrap (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), the
@@ -42,7 +56,7 @@ def init_process_group_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not is_initialized():
+    if (world > 1 or rehearsing()) and not is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -78,7 +92,7 @@ def _needs_staging(t):
 
 def broadcast_flat(flat, root=0):
     """One broadcast of a flat parameter bucket from `root`."""
-    if get_num_procs() > 1:
+    if distributed_path():
         if _needs_staging(flat):
             h = flat.cpu()
             dist.broadcast(h, src=root)
@@ -94,7 +108,7 @@ def broadcast_model_parameters(model):
     one flat bucket (`model.flat_params`): that is broadcast in one message;
     foreign nn.Modules fall back to one broadcast per tensor.
     """
-    if get_num_procs() == 1:
+    if not distributed_path():
         return
     flat = getattr(model, "flat_params", None)
     if flat is not None:
@@ -106,7 +120,7 @@ def broadcast_model_parameters(model):
 
 def allreduce_sum_(t):
     """In-place SUM all-reduce (identity on one rank)."""
-    if get_num_procs() > 1:
+    if distributed_path():
         if _needs_staging(t):
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -119,7 +133,7 @@ def allreduce_sum_(t):
 def mpi_avg(data):
     """mpi_utils.py:65-86: average a float / int / tensor across ranks."""
     n = get_num_procs()
-    if n == 1:
+    if not distributed_path():
         return data
     if torch.is_tensor(data):
         t = data.clone()
@@ -140,7 +154,7 @@ def mpi_avg_gradients(model):
     averaged per tensor, in place.
     """
     n = get_num_procs()
-    if n == 1:
+    if not distributed_path():
         return
     flat = getattr(model, "flat_grads", None)
     if flat is not None:
@@ -159,7 +173,7 @@ def allgather_records(rec):
     batch): returns [R, len(rec)] (R = 1 without a process group).
     """
     n = get_num_procs()
-    if n == 1:
+    if not distributed_path():
         return rec.reshape(1, -1)
     if _needs_staging(rec):
         h = rec.reshape(1, -1).cpu().contiguous()
@@ -173,7 +187,7 @@ def allgather_records(rec):
 
 def allreduce_scalars(values, op="sum"):
     """One packed all-reduce for a list of Python scalars (ppo.py:2471-2475, 1991-2094)."""
-    if get_num_procs() == 1:
+    if not distributed_path():
         return list(values)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" \
         else torch.device("cpu")

@@ -49,7 +49,7 @@ class RunningMeanStd:
     def update(self, data, gather_stats=True):
         """stats.py:29-60."""
         rec = self.batch_record(data)
-        if gather_stats and mpi_utils.get_num_procs() > 1:
+        if gather_stats and mpi_utils.distributed_path():
             rec = mpi_utils.allgather_records(rec)
         self.integrate_records(rec)
 
