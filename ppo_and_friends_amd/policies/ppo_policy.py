@@ -198,6 +198,8 @@ class PPOPolicy:
     def _initialize_networks(self, ac_network, enable_icm, icm_network, actor_kw_args,
                              critic_kw_args, icm_kw_args, **kw_args):
         """ppo_policy.py:390-472: actor out gain 0.01, critic out gain 1.0; rank-0 broadcast."""
+        from ..networks.lstm import PPOLSTMNetwork
+        self.using_lstm = isinstance(ac_network, type) and issubclass(ac_network, PPOLSTMNetwork)   # ppo_policy.py:420-422
         self.actor = ac_network(name="actor", in_shape=get_space_shape(self.actor_obs_space),
                                 out_shape=get_action_prediction_shape(self.action_space),
                                 out_init=0.01, test_mode=self.test_mode, **actor_kw_args)
@@ -254,7 +256,13 @@ class PPOPolicy:
     # ---------------------------------------------------------------- rollout
     def initialize_dataset(self):
         """ppo_policy.py:506-526."""
-        self.dataset = PPODataset(device=self.device, action_dtype=self.action_dtype, sequence_length=1)
+        sequence_length = 1
+        if self.using_lstm:
+            self.actor.reset_hidden_state(batch_size=1, device=self.device)
+            self.critic.reset_hidden_state(batch_size=1, device=self.device)
+            sequence_length = self.actor.sequence_length
+        self.dataset = PPODataset(device=self.device, action_dtype=self.action_dtype,
+                                  sequence_length=sequence_length)
 
     def initialize_episodes(self, env_batch_size, status_dict, ts_per_rollout=None):
         """
@@ -272,8 +280,12 @@ class PPOPolicy:
         obs_dim = int(np.prod(get_space_shape(self.actor_obs_space)))
         cobs_dim = int(np.prod(get_space_shape(self.critic_obs_space)))
         if self.buffer is None or (self.buffer.T, self.buffer.C) != (T, C):
+            lstm_spec = None
+            if self.using_lstm:
+                lstm_spec = ((self.actor.num_lstm_layers, self.actor.lstm_hidden_size),
+                             (self.critic.num_lstm_layers, self.critic.lstm_hidden_size))
             self.buffer = RolloutBuffer(T, C, obs_dim, cobs_dim, self.action_dim, self.action_dtype,
-                                        self.device, keep_next_observations=self.enable_icm)
+                                        self.device, keep_next_observations=self.enable_icm, lstm_spec=lstm_spec)
         else:
             self.buffer.end_kind.zero_()
             self.buffer.fixed_length = True
@@ -302,6 +314,34 @@ class PPOPolicy:
         if as_numpy:
             return raw_action.cpu().numpy(), action.cpu().numpy(), log_prob.detach()
         return raw_action, action, log_prob
+
+    # ---- LSTM hidden states (ppo_policy.py:593-627, ppo.py:2312-2319,2450-2466)
+    def store_hidden_states(self, t, terminated):
+        """
+        Row t of the buffer receives the networks' (hidden, cell) AFTER this step's forward passes,
+        zeroed for the envs that terminated at this step.  The networks' own state is NOT reset
+        (the reference never resets it inside a rollout).
+        """
+        keep = (~terminated).to(torch.float32).view(-1, 1, 1)
+        h = self.buffer.hidden
+        for name, net in (("actor", self.actor), ("critic", self.critic)):
+            hid, cell = net.hidden_state                       # [layers, C, H]
+            h[name + "_hidden"][t].copy_(hid.transpose(0, 1) * keep)
+            h[name + "_cell"][t].copy_(cell.transpose(0, 1) * keep)
+
+    def load_hidden_states(self, mb):
+        """ppo.py:2312-2319: the mini-batch's stored states become the networks' initial states."""
+        self.actor.hidden_state = (mb["actor_hidden"].transpose(0, 1).contiguous(),
+                                   mb["actor_cell"].transpose(0, 1).contiguous())
+        self.critic.hidden_state = (mb["critic_hidden"].transpose(0, 1).contiguous(),
+                                    mb["critic_cell"].transpose(0, 1).contiguous())
+
+    def write_back_hidden_states(self, dataset, batch_idxs):
+        """ppo.py:2450-2466: the states the networks ended the window with replace the stored ones."""
+        dataset.actor_hidden[batch_idxs] = self.actor.hidden_state[0].detach().transpose(0, 1)
+        dataset.critic_hidden[batch_idxs] = self.critic.hidden_state[0].detach().transpose(0, 1)
+        dataset.actor_cell[batch_idxs] = self.actor.hidden_state[1].detach().transpose(0, 1)
+        dataset.critic_cell[batch_idxs] = self.critic.hidden_state[1].detach().transpose(0, 1)
 
     def fused_step_unsupported_reason(self):
         """'' when the K6+K7 rollout-step kernel covers this policy (same coverage as the fused update)."""

@@ -292,11 +292,23 @@ class PPO:
                 buf.write_step(t, slice(0, E), critic_obs, obs, term_obs, raw_action, action, value,
                                log_prob, reward)
                 pol._t = t + 1
+                if pol.using_lstm:
+                    pol.store_hidden_states(t, terminated)
             if may_end_early:
                 ep_ts += 1
                 n_term += terminated.sum()
                 last = t == T - 1
                 boot = (~terminated) & ((ep_ts >= self.max_ts_per_ep) | truncated | last)
+                if pol.using_lstm and not last:
+                    # ppo.py:1863-1881: whenever an episode is cut (max length / truncation) the reference
+                    # evaluates the critic on the NEXT observation for the whole batch, which also steps the
+                    # stateful LSTM critic once more.  Branch-free here: the extra step is computed every
+                    # time and kept only if the reference would have taken it.
+                    cut = (((ep_ts == self.max_ts_per_ep) & ~terminated).any() | truncated.any())   # ep_ts of terminated envs is 0 by then (:1851)
+                    h_old = tuple(x.clone() for x in pol.critic.hidden_state)
+                    v_next = self.get_policy_values(policy_id, nxt_cobs)
+                    pol.critic.hidden_state = tuple(torch.where(cut, n, o) for n, o in zip(pol.critic.hidden_state, h_old))
+                    buf.boot_value[t].copy_(v_next)
                 buf.end_kind[t] = torch.where(terminated, 1, torch.where(boot, 2, 0)).to(torch.int8)
                 ep_ts = torch.where(terminated | boot, torch.zeros_like(ep_ts), ep_ts)
                 if not last:
@@ -307,7 +319,8 @@ class PPO:
         # normaliser state during a rollout); the last row needs one more pass.
         next_value = self.get_policy_values(policy_id, group(critic_obs) if grouped else critic_obs)
         if may_end_early:
-            buf.boot_value[:-1].copy_(buf.values[1:])
+            if not pol.using_lstm:           # stateless critics: V(next obs) is the value logged at t + 1
+                buf.boot_value[:-1].copy_(buf.values[1:])
             buf.boot_value[T - 1].copy_(next_value)
             buf.boot_reward.copy_(buf.boot_value)
             if pol.enable_icm:
@@ -393,7 +406,12 @@ class PPO:
         (already rank-gathered) moment record of this mini-batch's rewards-to-go.
         """
         pol = self.policies[policy_id]
-        mb = dataset.gather_minibatch(perm_batch)
+        windows = dataset.sequence_length > 1
+        mb = dataset.gather_sequences(perm_batch) if windows else dataset.gather_minibatch(perm_batch)
+        if pol.using_lstm and not windows:
+            N = dataset.buffer.num_transitions
+            rows = dataset.row_map[perm_batch].long()
+            mb = dict(mb, **{k: t.view((N,) + tuple(t.shape[2:]))[rows] for k, t in dataset.buffer.hidden.items()})
         rtg = mb["rewards_to_go"]
         if self.normalize_values:
             vn = self.value_normalizers[policy_id]
@@ -401,8 +419,13 @@ class PPO:
             rtg = vn.normalize(rtg, update_stats=False)
         if perm_batch.numel() == 1:          # ppo.py:2305-2306 (after the normaliser update, quirk Q9)
             return
+        if pol.using_lstm:
+            pol.load_hidden_states(mb)                              # ppo.py:2312-2319
         values, log_probs, entropy = pol.evaluate(mb["critic_obs"], mb["obs"], mb["raw_actions"])
-        dataset.scatter_values(perm_batch, values)
+        last = dataset.last_positions(perm_batch)
+        dataset.scatter_values(last, values)
+        if pol.using_lstm:
+            pol.write_back_hidden_states(dataset, last)             # ppo.py:2450-2466
         lp, ent = log_probs.reshape(-1), entropy.reshape(-1)
         sc, dlp, dent, dval = K.ppo_loss_fwd_bwd(
             lp.detach(), mb["log_probs"].reshape(-1), mb["advantages"].reshape(-1), ent.detach(),
@@ -456,8 +479,9 @@ class PPO:
             else:
                 self._optimizer_step(policy_id)
 
+        graphs = self.use_graphs and not pol.using_lstm      # the stateful LSTM modules are run eagerly
         for k in range(n_full):
-            run(perm[k * B:(k + 1) * B], k, self.use_graphs)
+            run(perm[k * B:(k + 1) * B], k, graphs)
         if tail:
             run(perm[n_full * B:], n_full, False)
 
@@ -581,7 +605,7 @@ class PPO:
         """
         N = perm.numel()
         A = ds.buffer.A                      # grouped rows carry A values each: a mini-batch holds B*A of them
-        rtg = ds.buffer.rewards_to_go.view(ds.buffer.num_transitions, A)[ds.row_map.long()[perm]].reshape(-1)
+        rtg = ds.buffer.rewards_to_go.view(ds.buffer.num_transitions, A)[ds.row_map.long()[ds.last_positions(perm)]].reshape(-1)
         N, B = N * A, B * A
         nb = (N + B - 1) // B
         pad = nb * B - N

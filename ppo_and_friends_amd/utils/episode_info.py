@@ -35,7 +35,7 @@ class RolloutBuffer:
     """Device-resident `[T, C, .]` transition store for one policy (C = num_agents * num_envs)."""
 
     def __init__(self, T, C, obs_dim, critic_obs_dim, action_dim, action_dtype, device,
-                 keep_next_observations=False, agents_per_row=1):
+                 keep_next_observations=False, agents_per_row=1, lstm_spec=None):
         """
         agents_per_row = A > 1 is the layout of agent-grouped policies (MAT): a row is one env and
         carries its A agents side by side -- the [N, A, .] items of PPOSharedEpisodeDataset
@@ -61,6 +61,13 @@ class RolloutBuffer:
         self.boot_reward = torch.zeros((T, C) + ag, **f32)
         self.advantages = torch.zeros((T, C) + ag, **f32)
         self.rewards_to_go = torch.zeros((T, C) + ag, **f32)
+        # LSTM policies: the (hidden, cell) pair of actor and critic AFTER each step, zeroed where the
+        # env terminated (ppo_policy.py:598-627); lstm_spec = ((layers, H) actor, (layers, H) critic)
+        self.hidden = None
+        if lstm_spec is not None:
+            (la, ha), (lc, hc) = lstm_spec
+            self.hidden = dict(actor_hidden=torch.zeros(T, C, la, ha, **f32), actor_cell=torch.zeros(T, C, la, ha, **f32),
+                               critic_hidden=torch.zeros(T, C, lc, hc, **f32), critic_cell=torch.zeros(T, C, lc, hc, **f32))
         self.fixed_length = True          # flips when an end is recorded before row T-1
         self.steps_written = 0
         # persistent across rollouts (hipGraph replays hold these addresses)
@@ -200,6 +207,23 @@ class _ValuesProxy:
         return len(self._d)
 
 
+class _HiddenProxy:
+    """`dataset.actor_hidden[batch_idxs] = h` / `[...]` (ppo.py:2462-2466) routed through the row map."""
+
+    def __init__(self, dataset, key):
+        self._d, self._k = dataset, key
+
+    def _flat(self):
+        t = self._d.buffer.hidden[self._k]
+        return t.view((self._d.buffer.num_transitions,) + tuple(t.shape[2:]))
+
+    def __setitem__(self, idx, src):
+        self._flat()[self._d.row_map[self._d._idx_tensor(idx)].long()] = src.detach().to(torch.float32)
+
+    def __getitem__(self, idx):
+        return self._flat()[self._d.row_map[self._d._idx_tensor(idx)].long()]
+
+
 class PPODataset:
     """
     The Dataset surface PPO consumes (episode_info.py:647-987) over a RolloutBuffer:
@@ -208,11 +232,18 @@ class PPODataset:
     """
 
     def __init__(self, device, action_dtype, sequence_length=1):
-        if sequence_length != 1:
-            raise NotImplementedError("sequence_length > 1 (LSTM windows) is a 'next' row of SURVEY.md §8(f)")
+        """
+        sequence_length S > 1 (LSTM policies, episode_info.py:686-720): item i is the WINDOW of dataset
+        positions [i, i+S-1]; its observations are that window (zeroed after a terminal transition inside
+        it, :775-809,976-987), every other field -- and the index handed back -- belongs to the window's
+        LAST position; len = N - (S - 1) (:916-920).  Windows run across episode boundaries exactly as the
+        reference's flat concatenation does.
+        """
         self.device = torch.device(device)
         self.action_dtype = action_dtype
-        self.sequence_length = 1
+        self.sequence_length = int(sequence_length)
+        if self.sequence_length < 1:
+            raise ValueError("sequence_length must be >= 1")
         self.buffer = None
         self.is_built = False
         self.row_map = None
@@ -234,6 +265,12 @@ class PPODataset:
         self.row_map, self.ep_lens = b.build_row_map()
         self.total_timestates = b.num_transitions
         self.values = _ValuesProxy(self)
+        if self.sequence_length > 1:
+            # terminal flag of every dataset position (last transition of a terminated episode)
+            self.terminal_positions = (b.end_kind.view(-1)[self.row_map.long()] == END_TERMINAL)
+        if b.hidden is not None:
+            for k in ("actor_hidden", "critic_hidden", "actor_cell", "critic_cell"):
+                setattr(self, k, _HiddenProxy(self, k))
         self.is_built = True
 
     def recalculate_advantages(self):
@@ -244,7 +281,44 @@ class PPODataset:
         self.buffer.compute_advantages(*self.gae_args, adv_only=True)
 
     def __len__(self):
-        return self.total_timestates
+        return self.total_timestates - (self.sequence_length - 1)
+
+    def last_positions(self, idx):
+        """Dataset position the non-observation fields of item `idx` come from (episode_info.py:960-962)."""
+        return idx + (self.sequence_length - 1)
+
+    def window_rows(self, idx):
+        """-> (buffer rows [B, S], zero mask [B, S]) of the observation windows of items `idx` [B]."""
+        S = self.sequence_length
+        pos = idx.reshape(-1, 1) + torch.arange(S, device=self.device, dtype=torch.int64)
+        rows = self.row_map[pos].long()
+        term = self.terminal_positions[pos].to(torch.int64)
+        mask = (torch.cumsum(term, dim=1) - term) > 0          # True strictly after a terminal transition
+        return rows, mask
+
+    def gather_sequences(self, perm_batch):
+        """
+        The S > 1 form of gather_minibatch (torch-ROCm indexing; the LSTM forward that consumes it is
+        MIOpen): observation windows [B, S, .] (actor observations zeroed after a terminal, critic
+        observations as they are -- episode_info.py:976-987), everything else at the last position.
+        """
+        b = self.buffer
+        N = b.num_transitions
+        v = lambda t: t.view((N,) + tuple(t.shape[2:]))
+        rows, mask = self.window_rows(perm_batch)
+        last = rows[:, -1]
+        obs = v(b.observations)[rows]
+        obs = obs.masked_fill(mask.unsqueeze(-1), 0.0)
+        out = dict(obs=obs, critic_obs=v(b.critic_observations)[rows], raw_actions=v(b.raw_actions)[last],
+                   advantages=v(b.advantages)[last], log_probs=v(b.log_probs)[last],
+                   rewards_to_go=v(b.rewards_to_go)[last])
+        if b.next_observations is not None:
+            out["next_obs"] = v(b.next_observations)[rows].masked_fill(mask.unsqueeze(-1), 0.0)
+            out["actions"] = v(b.actions)[last]
+        if b.hidden is not None:
+            for k, t in b.hidden.items():
+                out[k] = v(t)[last]
+        return out
 
     def _idx_tensor(self, idx):
         if torch.is_tensor(idx):
@@ -275,8 +349,22 @@ class PPODataset:
     def rewards_to_go(self): return self._flat(self.buffer.rewards_to_go)
 
     def __getitem__(self, idx):
-        """13-tuple of episode_info.py:940-952 (hidden/cell slots are the uint8 zeros of :860-866)."""
+        """13-tuple of episode_info.py:940-987 (hidden/cell slots are the uint8 zeros of :860-866 without an LSTM)."""
         b = self.buffer
+        if self.sequence_length > 1 or b.hidden is not None:
+            i = torch.as_tensor([int(idx)], dtype=torch.int64, device=self.device)
+            if self.sequence_length > 1:
+                g = self.gather_sequences(i)
+            else:
+                g = self.gather_minibatch(i, out={})
+                N = b.num_transitions
+                for k, t in b.hidden.items():
+                    g[k] = t.view((N,) + tuple(t.shape[2:]))[self.row_map[i].long()]
+            nxt = g["next_obs"][0] if "next_obs" in g else torch.zeros_like(g["obs"][0])
+            act = g["actions"][0] if "actions" in g else self._flat(b.actions)[int(idx) + self.sequence_length - 1]
+            return (g["critic_obs"][0], g["obs"][0], nxt, g["raw_actions"][0], act, g["advantages"][0],
+                    g["log_probs"][0], g["rewards_to_go"][0], g["actor_hidden"][0], g["critic_hidden"][0],
+                    g["actor_cell"][0], g["critic_cell"][0], int(idx) + self.sequence_length - 1)
         row = int(self.row_map[idx])
         f = lambda t: t.reshape((b.num_transitions,) + tuple(t.shape[2:]))[row]
         empty = torch.zeros((), dtype=torch.uint8)
@@ -291,6 +379,10 @@ class PPODataset:
         """K4: every field of the mini-batch in one launch; rows = row_map[perm_batch]."""
         b = self.buffer
         B = perm_batch.numel()
+        if out is not None and len(out) == 0:       # fresh destinations (the __getitem__ path)
+            mk = lambda t: torch.empty((B,) + tuple(t.shape[2:]), dtype=t.dtype, device=self.device)
+            out.update(critic_obs=mk(b.critic_observations), obs=mk(b.observations), raw_actions=mk(b.raw_actions),
+                       advantages=mk(b.advantages), log_probs=mk(b.log_probs), rewards_to_go=mk(b.rewards_to_go))
         out = self.minibatch_buffers(B) if out is None else out
         N = b.num_transitions
         v = lambda t: t.view((N,) + tuple(t.shape[2:]))

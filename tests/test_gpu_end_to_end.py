@@ -467,3 +467,60 @@ def test_fused_icm_update_matches_oracle(case):
     w_ref = torch.cat([p.detach().reshape(-1) for p in ref.parameters()]).numpy()
     np.testing.assert_allclose(w, w_ref, rtol=1e-4, atol=2e-5)
     assert int(pol.icm_optim.step_count.item()) == 2 * cnt
+
+
+@pytest.mark.parametrize("S,max_ts,term_prob", [(4, 7, 0.05), (1, 200, 0.0), (5, 200, 0.08)])
+def test_lstm_policy_rollout_windows_and_update_match_cpu_port(S, max_ts, term_prob):
+    """
+    SURVEY.md §8(f).3 / a20: LSTM actor + critic (torch-ROCm nn.LSTM), hidden states logged per step,
+    sequence-window dataset with terminal masks, hidden-state hand-over and write-back in the update --
+    against oracle/lstm_oracle.CpuLSTMPPO (the reference's list-based flow on torch-CPU).
+    """
+    from oracle import lstm_oracle
+    from ppo_and_friends_amd.ppo import PPO, PermutationLoader
+    from ppo_and_friends_amd.networks.lstm import LSTMNetwork
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    dev = torch.device("cuda", 0)
+    E, T, O, NA, B, seed, H = 6, 20, 5, 3, 16, 2, 32
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=13, term_prob=term_prob)
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    net_kw = dict(sequence_length=S, lstm_hidden_size=H, ff_hidden_size=H)
+    ppo = PPO(env_gen, {"p": (None, sp, sp, Discrete(NA), dict(ac_network=LSTMNetwork, actor_kw_args=net_kw,
+                                                             critic_kw_args=net_kw))},
+              device=dev, random_seed=seed, normalize_obs=False, normalize_rewards=False, envs_per_proc=E,
+              ts_per_rollout=T, batch_size=B, epochs_per_iter=1, max_ts_per_ep=max_ts)
+    pol = ppo.policies["p"]
+    assert pol.using_lstm
+    cpu = lstm_oracle.CpuLSTMPPO(O, NA, sequence_length=S, lstm_hidden=H, ff_hidden=H, batch_size=B, seed=seed)
+    cpu.actor.load_state_dict({k: v.detach().cpu().clone() for k, v in pol.actor.state_dict().items()})
+    cpu.critic.load_state_dict({k: v.detach().cpu().clone() for k, v in pol.critic.state_dict().items()})
+    cpu.loader_generator = torch.Generator().manual_seed(seed)
+    for it in range(2):
+        ds = ppo.rollout()
+        env = ppo.env
+        term = None if env.term_table is None else env.term_table.cpu().numpy()
+        ref = cpu.rollout(env.obs_table.cpu().numpy(), env.reward_table.cpu().numpy(),
+                          pol.buffer.actions[..., 0].cpu().numpy(), term, max_ts_per_ep=max_ts)
+        assert len(ds) == len(ref) == E * T - (S - 1)
+        tol = dict(rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(ds.log_probs.cpu().numpy(), ref.log_probs.numpy().reshape(-1), **tol)
+        np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), ref.rewards_to_go.numpy(), **tol)
+        np.testing.assert_allclose(ds.advantages.cpu().numpy(), ref.advantages.numpy(), **tol)
+        np.testing.assert_allclose(ds.actor_hidden[torch.arange(E * T)].cpu().numpy(), ref.actor_hidden.numpy(), **tol)
+        np.testing.assert_allclose(ds.critic_cell[torch.arange(E * T)].cpu().numpy(), ref.critic_cell.numpy(), **tol)
+        for i in (0, 7, len(ds) - 1):                        # 13-tuple items: windows, masks, last-position fields
+            got, want = ds[i], ref[i]
+            np.testing.assert_allclose(got[0].cpu().numpy(), want[0].numpy(), **tol)     # critic obs window
+            np.testing.assert_allclose(got[1].cpu().numpy(), want[1].numpy(), **tol)     # masked obs window
+            assert got[12] == want[10]
+        loader = PermutationLoader(pol.dataset, B, ppo.loader_generator, ppo._perm_cache)
+        pol.train()
+        ppo._ppo_batch_train(loader, "p")
+        r = cpu.train_epoch()
+        for k in ("actor loss", "critic loss", "kl avg"):
+            np.testing.assert_allclose(ppo.status_dict["p"][k], r[k], rtol=1e-4, atol=1e-5, err_msg=f"{k} it={it}")
+        np.testing.assert_allclose(ds.actor_hidden[torch.arange(E * T)].cpu().numpy(), ref.actor_hidden.numpy(),
+                                   rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(_flat_params(pol.actor), _flat_params(cpu.actor), rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(_flat_params(pol.critic), _flat_params(cpu.critic), rtol=2e-4, atol=5e-5)
