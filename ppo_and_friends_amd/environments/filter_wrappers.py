@@ -26,6 +26,7 @@ import torch
 
 from .. import kernels as K
 from ..utils import mpi_utils
+from ..utils.reference_io import dump_running_stats, load_running_stats
 
 
 class IdentityWrapper:
@@ -170,6 +171,11 @@ class _FilterPlan:
         self._raw_obs = (obs, cobs)
         self.natural_reward = reward            # info["natural reward"], filter_wrappers.py:426-437
         obs, cobs, reward = self._run(obs, cobs, reward, terminated, truncated)
+        if self.filters_obs and term_obs is not None:
+            # the "next observation" the reference logs (ppo.py:1725-1745): the FILTERED next observation,
+            # except for terminated envs, whose info["terminal observation"] was written below the filters
+            # (ppo_env_wrappers.py:1128-1137) and stays raw
+            term_obs = torch.where(terminated.reshape(-1, 1), term_obs.reshape(obs.shape), obs)
         return obs, cobs, reward, terminated, truncated, term_obs
 
     def reset(self):
@@ -267,7 +273,7 @@ class ObservationNormalizer(_DeviceFilter):
             for stem, st in (("ActorRunningObsStats", self.actor_running_stats),
                              ("CriticRunningObsStats", self.critic_running_stats)):
                 with open(os.path.join(path, f"{stem}_{r}.pickle"), "wb") as fh:
-                    pickle.dump(st, fh)
+                    dump_running_stats(st, fh)
         super().save_info(path)
 
     def load_info(self, path):
@@ -276,7 +282,7 @@ class ObservationNormalizer(_DeviceFilter):
             p._setup()
         for stem, key, W in (("ActorRunningObsStats", "stats", p.W_o), ("CriticRunningObsStats", "critic_stats", p.W_c)):
             with open(_rank_file(path, stem, self.test_mode), "rb") as fh:
-                _stats_from_host(pickle.load(fh), p.G, W, *self._cfg[key], self._agent_ids())
+                _stats_from_host(load_running_stats(fh), p.G, W, *self._cfg[key], self._agent_ids())
         super().load_info(path)
 
 
@@ -311,7 +317,7 @@ class RewardNormalizer(_DeviceFilter):
     def save_info(self, path):
         if not self.test_mode:
             with open(os.path.join(path, f"RunningRewardsStats_{mpi_utils.get_rank()}.pickle"), "wb") as fh:
-                pickle.dump(self.running_stats, fh)
+                dump_running_stats(self.running_stats, fh)
         super().save_info(path)
 
     def load_info(self, path):
@@ -319,7 +325,7 @@ class RewardNormalizer(_DeviceFilter):
         if not p._ready:
             p._setup()
         with open(_rank_file(path, "RunningRewardsStats", self.test_mode), "rb") as fh:
-            d = pickle.load(fh)
+            d = load_running_stats(fh)
         _, mean, var, count = self._cfg["state"]
         for i, a in enumerate(getattr(p.raw, "agent_ids", ["agent0"])):
             if a in d:

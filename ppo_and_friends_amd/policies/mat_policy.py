@@ -213,4 +213,4 @@ class MATPolicy(PPOPolicy):
         f = os.path.join(path, f"actor_critic_optim_{mpi_utils.get_rank()}")
         if not os.path.exists(f):
             f = os.path.join(path, "actor_critic_optim_0")
-        self.actor_critic_optim.load_state_dict(torch.load(f, map_location="cpu"))
+        self.actor_critic_optim.load_state_dict(torch.load(f, map_location="cpu", weights_only=False))

@@ -87,11 +87,18 @@ class FlatAdam:
         self.lr.fill_(float(lr))
 
     def state_dict(self):
-        return {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
-                "step": int(self.step_count.item()), "lr": self.param_groups[0]["lr"]}
+        """torch.optim.Adam.state_dict() layout (what the reference torch.saves, ppo_policy.py:1239-1247)."""
+        from ..utils.reference_io import adam_state_dict
+        return adam_state_dict(self.network, self.exp_avg, self.exp_avg_sq, int(self.step_count.item()),
+                               self.param_groups[0]["lr"], self.betas, self.eps)
 
     def load_state_dict(self, sd):
-        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if "param_groups" in sd:
+            from ..utils.reference_io import load_adam_state_dict
+            step, lr = load_adam_state_dict(sd, self.network, self.exp_avg, self.exp_avg_sq)
+            self.step_count.fill_(step); self.set_lr(lr)
+            return
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])      # this package's old layout
         self.step_count.fill_(int(sd["step"])); self.set_lr(sd["lr"])
 
 
@@ -528,6 +535,8 @@ class PPOPolicy:
         r = mpi_utils.get_rank()
         torch.save(self.actor_optim.state_dict(), os.path.join(policy_save_path, f"actor_optim_{r}"))
         torch.save(self.critic_optim.state_dict(), os.path.join(policy_save_path, f"critic_optim_{r}"))
+        if self.enable_icm:
+            torch.save(self.icm_optim.state_dict(), os.path.join(policy_save_path, f"icm_optim_{r}"))
 
     def load(self, load_path, tag="latest"):
         policy_load_path = os.path.join(load_path, f"{self.name}-policy", tag)
@@ -536,11 +545,16 @@ class PPOPolicy:
         if self.enable_icm:
             self.icm_model.load(policy_load_path)
         r = mpi_utils.get_rank()
-        for net, opt in (("actor", self.actor_optim), ("critic", self.critic_optim)):
+        opts = [("actor", self.actor_optim), ("critic", self.critic_optim)]
+        if self.enable_icm:
+            opts.append(("icm", self.icm_optim))
+        for net, opt in opts:
             f = os.path.join(policy_load_path, f"{net}_optim_{r}")
             if not os.path.exists(f):
                 f = os.path.join(policy_load_path, f"{net}_optim_0")
-            opt.load_state_dict(torch.load(f, map_location="cpu"))
+            if net == "icm" and not os.path.exists(f):
+                continue                                   # checkpoints written before the ICM optimiser was saved
+            opt.load_state_dict(torch.load(f, map_location="cpu", weights_only=False))
 
     def __eq__(self, other):
         return isinstance(other, PPOPolicy) and self.name == other.name

@@ -18,6 +18,8 @@ Device-first differences
     records per epoch -- the reference issues 16 pickled all-reduces, an
     all-gather of raw data and a barrier per mini-batch.
 """
+import os
+import pickle
 import time
 from collections import OrderedDict
 
@@ -133,7 +135,9 @@ class PPO:
                  ts_per_rollout=1024, gamma=0.99, epochs_per_iter=10, ext_reward_weight=1.0,
                  normalize_adv=True, normalize_obs=True, normalize_rewards=True,
                  normalize_values=True, obs_clip=None, reward_clip=None, recalc_advantages=False,
-                 soft_resets=False, use_graphs=True, update_mode="auto", verbose=False, **kw_args):
+                 soft_resets=False, state_path="./saved_state", load_state=False, checkpoint_every=100,
+                 save_train_scores=False, save_avg_ep_len=False, save_running_time=False, save_bs_info=False,
+                 save_state=True, use_graphs=True, update_mode="auto", verbose=False, **kw_args):
         """
         ppo.py:126-167.  `ts_per_rollout` is per environment (ppo.py:317-318
         multiplies by envs_per_proc).  normalize_obs / normalize_rewards / obs_clip / reward_clip
@@ -169,9 +173,19 @@ class PPO:
                                     reward_clip=reward_clip, gamma=gamma, test_mode=False)
         self.soft_resets = soft_resets if callable(soft_resets) else CallableValue(bool(soft_resets))
         self.policy_mapping_fn = policy_mapping_fn or (lambda agent_id: next(iter(policy_settings)))
-        self.status_dict = OrderedDict()
-        self.status_dict["global status"] = OrderedDict(
-            iteration=0, timesteps=0, **{"rollout time": 0.0, "train time": 0.0, "running time": 0.0})
+        max_int = int(np.iinfo(np.int32).max)
+        self.status_dict = OrderedDict()                     # keys and initial values of ppo.py:455-518
+        self.status_dict["global status"] = OrderedDict([
+            ("iteration", 0), ("rollout time", 0.0), ("train time", 0.0), ("running time", 0.0), ("timesteps", 0),
+            ("total episodes", 0), ("longest episode", 0), ("shortest episode", max_int), ("average episode", 0)])
+        self.state_path = state_path
+        self.env_info_path = os.path.join(state_path, "env_info")
+        self.curve_path = os.path.join(state_path, "curves")
+        self.checkpoint_every = int(checkpoint_every)
+        self.save_state = bool(save_state)                   # False: learn() writes nothing (tests, benchmarks)
+        self.save_train_scores, self.save_avg_ep_len = save_train_scores, save_avg_ep_len
+        self.save_running_time, self.save_bs_info = save_running_time, save_bs_info
+        self.normalize_obs = bool(normalize_obs)
         self.policies = {}
         self.value_normalizers = {}
         for policy_id, settings in policy_settings.items():
@@ -189,7 +203,15 @@ class PPO:
                 if self.policy_mapping_fn(agent_id) == policy_id:
                     pol.register_agent(agent_id)
             self.policies[policy_id] = pol
-            self.status_dict[policy_id] = OrderedDict()
+            self.status_dict[policy_id] = OrderedDict([
+                ("score avg", 0), ("natural score avg", 0), ("top score", -max_int), ("weighted entropy", 0),
+                ("actor loss", 0), ("critic loss", 0), ("kl avg", 0), ("natural reward range", (max_int, -max_int)),
+                ("top natural reward", -max_int), ("reward range", (max_int, -max_int)),
+                ("bootstrap range", (max_int, -max_int)), ("bootstrap avg", "N/A"), ("obs range", (max_int, -max_int)),
+                ("frozen", False)])
+            if dict(policy_args).get("enable_icm", False):
+                self.status_dict[policy_id].update({"icm loss": 0, "intrinsic score avg": 0,
+                                                    "intr reward range": (max_int, -max_int)})
             if normalize_values:
                 self.value_normalizers[policy_id] = RunningStatNormalizer(
                     name=f"{policy_id}-value_normalizer", device=self.device)
@@ -200,6 +222,11 @@ class PPO:
             self.env.finalize(self.status_dict)          # status-driven clip ranges (filter_wrappers.py:560-566)
         self._graphs = {}
         self._obs = None
+        if load_state and os.path.exists(os.path.join(state_path, "state_0.pickle")):      # ppo.py:521-545
+            saved = self.load(state_path, "latest")
+            for k in self.status_dict:
+                if k in saved:
+                    self.status_dict[k].update(saved[k])
 
     # ------------------------------------------------------------------ rollout
     def get_policy_values(self, policy_id, critic_obs):
@@ -240,8 +267,6 @@ class PPO:
             soft = getattr(env, "soft_reset", None)
             obs, critic_obs = soft() if callable(soft) else self._obs
         ep_ts = torch.zeros(E, dtype=torch.int32, device=self.device)
-        score_sum = torch.zeros((), dtype=torch.float64, device=self.device)
-        n_term = torch.zeros((), dtype=torch.int64, device=self.device)
         may_end_early = getattr(env, "term_table", True) is not None or self.max_ts_per_ep < T
         fused_step = (self.update_mode != "torch" and self.device.type == "cuda"
                       and pol.fused_step_unsupported_reason() == "")
@@ -258,15 +283,18 @@ class PPO:
         intr_buf = torch.zeros(T, E, dtype=torch.float32, device=self.device) if pol.enable_icm else None
         if pol.enable_icm:
             may_end_early = True          # bootstrap rewards carry the "surprise" term: dense end table
+        nat_buf = self._scratch(f"nat_buf_{T}_{env.num_agents if hasattr(env, 'num_agents') else 1}_{n_envs}",
+                                T * (E if not grouped else E * pol.num_agents), torch.float32).view(T, -1)
         for t in range(T):
             if fused_step:
                 # K6+K7: inference, sampling, log-probs, values and the buffer row in one launch
                 action = pol.rollout_step(t, obs.contiguous(), critic_obs.contiguous(), vn)
                 nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(action)
+                nat_buf[t].copy_(self._natural_reward(env, reward))
                 if self.ext_reward_weight != 1.0:
                     reward = reward * self.ext_reward_weight
                 if pol.enable_icm:            # ppo.py:1719-1723 -> apply_intrinsic_rewards :1219-1288
-                    intr_buf[t] = pol.get_intrinsic_reward(obs, term_obs, action)
+                    intr_buf[t] = pol.get_intrinsic_reward(obs, nxt_obs, action)   # ppo.py:1719-1723: the post-step observation
                     reward = reward + intr_buf[t]
                 pol.finish_step(t, reward, term_obs)
             elif grouped:
@@ -274,6 +302,7 @@ class PPO:
                 raw_action, action, log_prob = pol.get_rollout_actions(g_cobs if pol.expanded_actor_space else g_obs)
                 value = self.get_policy_values(policy_id, g_cobs)
                 nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(ungroup(action))
+                nat_buf[t].copy_(self._natural_reward(env, reward))
                 if self.ext_reward_weight != 1.0:
                     reward = reward * self.ext_reward_weight
                 buf.write_step(t, slice(0, E), g_cobs, g_cobs if pol.expanded_actor_space else g_obs, None,
@@ -284,10 +313,11 @@ class PPO:
                 raw_action, action, log_prob = pol.get_rollout_actions(obs)
                 value = self.get_policy_values(policy_id, critic_obs)
                 nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(action)
+                nat_buf[t].copy_(self._natural_reward(env, reward))
                 if self.ext_reward_weight != 1.0:
                     reward = reward * self.ext_reward_weight
                 if pol.enable_icm:
-                    intr_buf[t] = pol.get_intrinsic_reward(obs, term_obs, action)
+                    intr_buf[t] = pol.get_intrinsic_reward(obs, nxt_obs, action)   # ppo.py:1719-1723: the post-step observation
                     reward = reward + intr_buf[t]
                 buf.write_step(t, slice(0, E), critic_obs, obs, term_obs, raw_action, action, value,
                                log_prob, reward)
@@ -296,7 +326,6 @@ class PPO:
                     pol.store_hidden_states(t, terminated)
             if may_end_early:
                 ep_ts += 1
-                n_term += terminated.sum()
                 last = t == T - 1
                 boot = (~terminated) & ((ep_ts >= self.max_ts_per_ep) | truncated | last)
                 if pol.using_lstm and not last:
@@ -327,54 +356,169 @@ class PPO:
                 # ppo.py:1926-1930: bootstrap reward += intrinsic reward of the step - "intrinsic score avg"
                 ism = float(self.status_dict[policy_id].get("intrinsic score avg", 0.0))
                 buf.boot_reward.add_(intr_buf - ism)
-                self._update_intrinsic_score_avg(policy_id, buf, intr_buf, n_envs, T)
         else:
             buf.end_kind[T - 1].fill_(2)
             buf.boot_value[T - 1].copy_(next_value)
             buf.boot_reward[T - 1].copy_(next_value)
         self._obs = (obs, critic_obs)
-        score_sum = buf.rewards.sum(dtype=torch.float64)
         pol.finalize_dataset()
+        self._publish_rollout_statistics(policy_id, buf, nat_buf, intr_buf, n_envs, T, obs, grouped)
         gs = self.status_dict["global status"]
         gs["timesteps"] += self.ts_per_rollout * mpi_utils.get_num_procs()     # env steps (ppo.py:1653), not agent steps
-        self.status_dict[policy_id]["reward sum"] = score_sum        # device scalar; read lazily
-        self.status_dict[policy_id]["terminated episodes"] = n_term
         torch.cuda.synchronize() if self.device.type == "cuda" else None
         gs["rollout time"] = time.time() - start
         return pol.dataset
 
-    def _update_intrinsic_score_avg(self, policy_id, buf, intr_buf, n_envs, T):
-        """
-        status_dict["intrinsic score avg"] as the reference computes it (ppo.py:1849-1851,
-        1940-1963, 2074-2080): total intrinsic reward / (total_episodes / env_batch_size), with the
-        reference's fractional count for the episodes that were still running at rollout end.
-        """
-        A = buf.C // n_envs
-        term = (buf.end_kind[:, :n_envs] == 1)                          # per env (agents end together)
-        n_term = term.sum().double()
-        t_idx = torch.arange(T, device=self.device)[:, None].expand(T, n_envs)
-        last_term = torch.where(term, t_idx, torch.full_like(t_idx, -1)).max(dim=0).values
-        ep_len = (T - 1 - last_term).double()                           # steps since the last terminal
-        combined = ep_len.sum()
-        ts_before = torch.clamp(float(T * n_envs) - combined, min=0.0)
-        cur_total = torch.where(n_term == 0, torch.ones_like(n_term), n_term)
-        avg_len = torch.where(ts_before == 0, combined / n_envs, ts_before / cur_total)
-        total_eps = n_term + (ep_len / avg_len).sum()
-        tot = torch.stack([intr_buf.sum(dtype=torch.float64), total_eps])
-        mpi_utils.allreduce_sum_(tot)                                   # ppo.py:1991, 2076
-        self.status_dict[policy_id]["intrinsic score avg"] = float((tot[0] / (tot[1] / n_envs)).item())
+    @staticmethod
+    def _natural_reward(env, reward):
+        """info["natural reward"] of the filter wrappers, else the env's own reward (ppo.py:1689-1693)."""
+        nat = getattr(env, "natural_reward", None)
+        return reward if nat is None else nat
+
+    def _publish_rollout_statistics(self, policy_id, buf, nat_buf, intr_buf, n_envs, T, last_obs, grouped):
+        """ppo.py:1978-2099 (see utils/rollout_stats.py) -> status_dict."""
+        from .utils.rollout_stats import rollout_statistics
+        pol = self.policies[policy_id]
+        A = nat_buf.shape[1] // n_envs
+        per_env = (lambda x: x.reshape(T, n_envs, A).sum(2)) if grouped else (lambda x: x.reshape(T, A, n_envs).sum(1))
+        nat_env = nat_buf.view(T, A, n_envs).sum(1)                      # the env hands agent-major columns
+        ek = buf.end_kind[:, :n_envs]
+        mm = lambda x: torch.aminmax(x)
+        o_lo, o_hi = mm(last_obs)
+        if T > 1:
+            b_lo, b_hi = mm(buf.observations[1:])
+            o_lo, o_hi = torch.minimum(o_lo, b_lo), torch.maximum(o_hi, b_hi)
+        st = rollout_statistics(per_env(buf.rewards), nat_env, ek == 1, ek == 2, buf.boot_reward, A, mm(buf.rewards),
+                                mm(nat_buf), (o_lo, o_hi), self.ts_per_rollout / self.envs_per_proc,
+                                None if intr_buf is None else per_env(intr_buf),
+                                None if intr_buf is None else mm(intr_buf))
+        sd, gs = self.status_dict[policy_id], self.status_dict["global status"]
+        if not self.normalize_obs:                                       # ppo.py:2010-2017: a running range
+            st["obs range"] = (min(sd["obs range"][0], st["obs range"][0]), max(sd["obs range"][1], st["obs range"][1]))
+        sd["top natural reward"] = max(sd["top natural reward"], st["natural reward range"][1])
+        for k in ("score avg", "natural score avg", "top score", "obs range", "reward range", "natural reward range",
+                  "bootstrap range", "bootstrap avg", "intrinsic score avg", "intr reward range"):
+            if k in st:
+                sd[k] = st[k]
+        sd["frozen"] = pol.frozen
+        gs["total episodes"] += st["total episodes"]
+        for k in ("longest episode", "shortest episode", "average episode"):
+            gs[k] = st[k]
 
     # ------------------------------------------------------------------ update
     def learn(self, num_timesteps):
         """ppo.py:2112-2272."""
         gs = self.status_dict["global status"]
         ts_max = gs["timesteps"] + num_timesteps
+        best = {policy_id: -np.inf for policy_id in self.policies}
+        iter_start = iter_stop = time.time()
         while gs["timesteps"] < ts_max:
+            pre_rollout_timesteps = gs["timesteps"]
             self.rollout()
+            for policy_id in self.policies:                       # ppo.py:2144-2150
+                score = self.status_dict[policy_id]["natural score avg"]
+                if score >= best[policy_id]:
+                    best[policy_id] = score
+                    self.save(tag=f"{policy_id}_best")
+            gs["running time"] += (iter_stop - iter_start) + gs["rollout time"]
+            iter_start = time.time()
+            if self.verbose:
+                self.print_status()
+            self.save()
+            if gs["iteration"] % self.checkpoint_every == 0:
+                self.save(tag=str(gs["iteration"]))
+            self._save_curves(pre_rollout_timesteps)
             self.train_on_rollout()
             gs["iteration"] += 1
-            for pol in self.policies.values():
+            for policy_id, pol in self.policies.items():
                 pol.update_learning_rate()
+                self.status_dict[policy_id]["lr"] = pol.lr()
+            if sum(pol.lr() for pol in self.policies.values()) <= 0.0:
+                rank_print("Learning rate has bottomed out. Terminating early")
+                break
+            iter_stop = time.time()
+
+    def print_status(self):
+        """ppo.py:1383-1404."""
+        rank_print("\n--------------------------------------------------------")
+        rank_print("Status Report:")
+        for section, d in self.status_dict.items():
+            rank_print("  {}:".format(section))
+            for key, val in d.items():
+                rank_print("    {}: {}".format(key, val))
+        rank_print("--------------------------------------------------------")
+
+    # ------------------------------------------------------------ state on disk
+    def save(self, tag="latest"):
+        """
+        ppo.py:2569-2618: rank 0 writes `<state>/<policy>-policy/<tag>/...` (networks, optimisers),
+        `<state>/env_info/<tag>/...` (filter and value-normaliser statistics) and `<state>/state_0.pickle`
+        (the status dict), in the reference's file names and payload formats (utils/reference_io.py).
+        """
+        if not self.save_state:
+            return
+        if mpi_utils.get_rank() == 0:
+            info = os.path.join(self.env_info_path, tag)
+            os.makedirs(info, exist_ok=True)
+            if callable(getattr(self.env, "save_info", None)):
+                self.env.save_info(info)
+            for pol in self.policies.values():
+                pol.save(self.state_path, tag)
+            for vn in self.value_normalizers.values():
+                vn.save_info(info)
+            with open(os.path.join(self.state_path, "state_0.pickle"), "wb") as fh:
+                pickle.dump(self.status_dict, fh, protocol=pickle.HIGHEST_PROTOCOL)
+        if mpi_utils.distributed_path():
+            torch.distributed.barrier()
+
+    def load_status(self, state_path):
+        with open(os.path.join(state_path, "state_0.pickle"), "rb") as fh:
+            return pickle.load(fh)
+
+    def load_policy(self, policy_id, state_path, tag="latest"):
+        self.policies[policy_id].load(state_path, tag)
+        if policy_id in self.value_normalizers:
+            try:
+                self.value_normalizers[policy_id].load_info(os.path.join(state_path, "env_info", tag))
+            except OSError:
+                pass
+
+    def load(self, state_path, tag="latest"):
+        """ppo.py:2704-2721."""
+        for policy_id in self.policies:
+            self.load_policy(policy_id, state_path, tag)
+        info = os.path.join(state_path, "env_info", tag)
+        if callable(getattr(self.env, "load_info", None)) and os.path.isdir(info):
+            try:
+                self.env.load_info(info)
+            except OSError:
+                pass
+        return self.load_status(state_path)
+
+    def _save_curves(self, timestep):
+        """ppo.py:2723-2851: `<timestep> <value>` rows appended to the files `ppoaf plot` reads."""
+        if not self.save_state or mpi_utils.get_rank() != 0:
+            return
+        gs = self.status_dict["global status"]
+
+        def put(sub, name, value):
+            d = os.path.join(self.curve_path, sub)
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, name), "ab") as fh:
+                np.savetxt(fh, np.array([[timestep, value]], dtype=np.float64))
+
+        for policy_id in self.policies:
+            sd = self.status_dict[policy_id]
+            if self.save_train_scores:
+                put("scores", f"{policy_id}_scores.npy", sd["natural score avg"])
+            if self.save_bs_info:
+                put("bs_min", f"{policy_id}_bs_min.npy", sd["bootstrap range"][0])
+                put("bs_max", f"{policy_id}_bs_max.npy", sd["bootstrap range"][1])
+                put("bs_avg", f"{policy_id}_bs_avg.npy", sd["bootstrap avg"])
+        if self.save_avg_ep_len:
+            put("episode_length", "average_episode.npy", gs["average episode"])
+        if self.save_running_time:
+            put("runtime", "running_time.npy", gs["running time"])
 
     def train_on_rollout(self):
         """The epoch loop of ppo.py:2178-2249 (KL early stop :2222-2232)."""

@@ -10,6 +10,7 @@ import torch
 
 from .. import kernels as K
 from . import mpi_utils
+from .reference_io import dump_running_stats, load_running_stats
 from .stats import RunningMeanStd
 
 
@@ -38,7 +39,7 @@ class RunningStatNormalizer:
             return
         f = os.path.join(path, "{}_stats_{}.pickle".format(self.name, mpi_utils.get_rank()))
         with open(f, "wb") as fh:
-            pickle.dump(self.running_stats.state_dict(), fh)
+            dump_running_stats(self.running_stats.state_dict(), fh)     # a reference RunningMeanStd object
 
     def load_info(self, path):
         """misc.py:147-172 incl. the rank-0 fallback when restarting with more ranks."""
@@ -47,4 +48,4 @@ class RunningStatNormalizer:
         if not os.path.exists(f):
             f = os.path.join(path, "{}_stats_0.pickle".format(self.name))
         with open(f, "rb") as fh:
-            self.running_stats.load_state_dict(pickle.load(fh))
+            self.running_stats.load_state_dict(load_running_stats(fh))

@@ -136,6 +136,7 @@ def test_tail_minibatch_and_recalc_advantages(update_mode):
 
 def test_learn_runs_two_iterations_with_graph_replay():
     ppo = _make(32, 16, 64, 2)
+    ppo.save_state = False
     ppo.learn(2 * 32 * 16)
     gs = ppo.status_dict["global status"]
     assert gs["iteration"] == 2 and gs["timesteps"] == 2 * 32 * 16
@@ -524,3 +525,83 @@ def test_lstm_policy_rollout_windows_and_update_match_cpu_port(S, max_ts, term_p
                                    rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(_flat_params(pol.actor), _flat_params(cpu.actor), rtol=2e-4, atol=5e-5)
     np.testing.assert_allclose(_flat_params(pol.critic), _flat_params(cpu.critic), rtol=2e-4, atol=5e-5)
+
+
+def test_learn_writes_the_reference_state_layout_and_resumes(tmp_path):
+    """
+    SURVEY.md §8(f).2/4: learn() saves `latest`, `<policy>_best`, numbered tags, env_info statistics,
+    state_0.pickle and the curve files in the reference's layout (ppo.py:2144-2161, 2569-2618, 2723-2851);
+    a new PPO with load_state=True continues from them.
+    """
+    import os
+    from ppo_and_friends_amd.ppo import PPO
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    dev = torch.device("cuda", 0)
+    E, T, O, NA, B = 8, 16, 5, 3, 32
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+
+    def make(load):
+        env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=3, term_prob=0.05)
+        return PPO(env_gen, {"p": (None, sp, sp, Discrete(NA), dict(enable_icm=True))}, device=dev, random_seed=1,
+                   obs_clip=(-5.0, 5.0), reward_clip=(-5.0, 5.0), envs_per_proc=E, ts_per_rollout=T, batch_size=B,
+                   epochs_per_iter=1, state_path=str(tmp_path), load_state=load, save_train_scores=True,
+                   save_avg_ep_len=True, save_running_time=True, save_bs_info=True, checkpoint_every=1)
+
+    ppo = make(False)
+    ppo.learn(2 * E * T)
+    root = str(tmp_path)
+    for tag in ("latest", "p_best", "0", "1"):
+        d = os.path.join(root, "p-policy", tag)
+        for f in ("actor_0.model", "critic_0.model", "icm_0.model", "actor_optim_0", "critic_optim_0", "icm_optim_0"):
+            assert os.path.exists(os.path.join(d, f)), (tag, f)
+        for f in ("ActorRunningObsStats_0.pickle", "CriticRunningObsStats_0.pickle", "RunningRewardsStats_0.pickle",
+                  "p-value_normalizer_stats_0.pickle"):
+            assert os.path.exists(os.path.join(root, "env_info", tag, f)), (tag, f)
+    assert os.path.exists(os.path.join(root, "state_0.pickle"))
+    curve = np.loadtxt(os.path.join(root, "curves", "scores", "p_scores.npy"))
+    assert curve.shape == (2, 2) and curve[0, 0] == 0 and curve[1, 0] == E * T
+    for sub, f in (("episode_length", "average_episode.npy"), ("runtime", "running_time.npy"), ("bs_avg", "p_bs_avg.npy")):
+        assert os.path.exists(os.path.join(root, "curves", sub, f))
+    # reference-side readers: torch.load of a state_dict with its module keys; Adam.load_state_dict
+    sd = torch.load(os.path.join(root, "p-policy", "latest", "actor_0.model"))
+    assert list(sd.keys())[0] == "sequential_net.0.weight"
+    ref_actor = cpu_ppo_loop.make_mlp(O, NA, out_gain=0.01)
+    torch.optim.Adam(ref_actor.parameters(), eps=1e-5).load_state_dict(
+        torch.load(os.path.join(root, "p-policy", "latest", "actor_optim_0"), weights_only=False))
+    # `latest` is written after the rollout and before the update of the same iteration (ppo.py:2153):
+    # take a final snapshot so the resumed object can be compared with the live one
+    ppo.save()
+    resumed = make(True)
+    a, b = ppo.policies["p"], resumed.policies["p"]
+    assert torch.equal(a.policy_params, b.policy_params) and torch.equal(a.icm_model.flat_params, b.icm_model.flat_params)
+    assert torch.equal(a.policy_exp_avg, b.policy_exp_avg) and torch.equal(a.icm_optim.exp_avg_sq, b.icm_optim.exp_avg_sq)
+    assert int(a.icm_optim.step_count.item()) == int(b.icm_optim.step_count.item()) > 0
+    va, vb = ppo.value_normalizers["p"].running_stats, resumed.value_normalizers["p"].running_stats
+    assert np.array_equal(va.mean, vb.mean) and va.count == vb.count
+    assert resumed.status_dict["global status"]["timesteps"] == 2 * E * T
+    assert resumed.status_dict["global status"]["iteration"] == 2
+    ra, rb = ppo.env.running_stats["agent0"], resumed.env.running_stats["agent0"]     # RewardNormalizer under the clipper (attribute forwarding)
+    assert ra == rb
+
+
+def test_rollout_statistics_in_status_dict():
+    """The statistics block of the rollout on a live buffer, against the literal loop of the oracle."""
+    from oracle.rollout_stats_oracle import rollout_statistics_loop
+    E, T = 10, 24
+    ppo = _make(E, T, 32, 1, term_prob=0.06, max_ts=9)
+    ppo.rollout()
+    buf, env = ppo.policies["p"].buffer, ppo.env
+    ek = buf.end_kind.cpu().numpy()
+    r = buf.rewards.double().cpu().numpy()
+    obs_after = np.concatenate([buf.observations[1:].cpu().numpy(), ppo._obs[0].cpu().numpy()[None]], axis=0)
+    want = rollout_statistics_loop(r, env.reward_table.double().cpu().numpy(), np.zeros_like(r),
+                                   obs_after.min(axis=(1, 2)), obs_after.max(axis=(1, 2)), ek == 1, ek == 2,
+                                   buf.boot_reward.double().cpu().numpy())
+    sd, gs = ppo.status_dict["p"], ppo.status_dict["global status"]
+    for k in ("score avg", "natural score avg", "top score", "reward range", "natural reward range", "obs range",
+              "bootstrap range", "bootstrap avg"):
+        np.testing.assert_allclose(sd[k], want[k], rtol=1e-6, atol=1e-6, err_msg=k)
+    for k in ("total episodes", "longest episode", "shortest episode", "average episode"):
+        np.testing.assert_allclose(gs[k], want[k], rtol=1e-9, err_msg=k)
+    assert gs["timesteps"] == E * T

@@ -52,7 +52,9 @@ def test_filter_stack_matches_oracle(A, E, O, critic_view, obs_clip, reward_clip
         np.testing.assert_allclose(_np(obs), o_obs, rtol=1e-5, atol=1e-5, err_msg=f"obs t={t}")
         np.testing.assert_allclose(_np(cobs), o_cobs, rtol=1e-5, atol=1e-5, err_msg=f"critic obs t={t}")
         np.testing.assert_allclose(_np(rew), o_rew, rtol=1e-6, atol=1e-6, err_msg=f"reward t={t}")
-        assert torch.equal(tobs, r_tobs)                       # terminal observation stays raw
+        # logged next observation: filtered, except the raw terminal observation of terminated envs
+        want_t = np.where(_np(r_term)[:, None], _np(r_tobs), o_obs)
+        np.testing.assert_allclose(_np(tobs), want_t, rtol=1e-5, atol=1e-5)
         assert torch.equal(env.natural_reward, r_rew)
     # running state after T steps
     w = env

@@ -52,7 +52,7 @@ def _rank(rank, world, port, out):
                      critic_sd={k: v.detach().cpu().clone() for k, v in pol.critic.state_dict().items()},
                      obs=ppo.env.obs_table.cpu().numpy(), rew=ppo.env.reward_table.cpu().numpy(),
                      actions=pol.buffer.actions[..., 0].cpu().numpy(),
-                     stats=[{k: float(v) for k, v in s.items() if not torch.is_tensor(v)} for s in stats],
+                     stats=[{k: float(v) for k, v in s.items() if isinstance(v, (int, float)) and not isinstance(v, bool)} for s in stats],
                      vn=np.array([vs.mean, vs.variance, vs.count], dtype=np.float64))
     dist.barrier()
     dist.destroy_process_group()
