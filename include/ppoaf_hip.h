@@ -538,6 +538,43 @@ typedef struct {
 int ppoaf_icm_update_fwd_bwd(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream);
 int ppoaf_icm_update_reduce(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream);
 
+/* ------------------------------------------------------------------------ *
+ * K15  fused multi-agent-transformer mini-batch update
+ * replaces one iteration of PPO._ppo_batch_train for a MATPolicy  ppo.py:2292-2469
+ *          MATPolicy.evaluate (token block, teacher forcing)      policies/mat_policy.py:378-439,628-658
+ *          MATActorCritic.forward / MATCritic / MATActor          networks/actor_critic/multi_agent_transformer.py:22-373
+ *          SelfAttention / Encoding / Decoding blocks             networks/attention.py:13-257
+ *          the loss, backward and (through K11) the one clip + Adam over the shared bucket  mat_policy.py:677-699
+ * for the default topology: embedding 64, one block, one head, GELU, Discrete actions (<= 8),
+ * obs_dim <= 64, num_agents <= 16.  `offsets` are the 63 parameter tensors of MATActorCritic in
+ * module order (each padded to 4 floats) relative to `params`.  Dataset rows are envs carrying
+ * num_agents tokens: critic_obs [n_rows, A, O], raw_actions int64 [n_rows, A], advantages /
+ * old_log_probs / rewards_to_go / values [n_rows, A].  adv_records / vn_records are (n, mean, M2)
+ * float64 per mini-batch over its B*A values ([n_batches, 3] and [n_batches, n_ranks, 3]).
+ * `fwd_bwd` = one launch on ceil(B / floor(16/A)) workgroups writing slabs [that many, bucket_total];
+ * `reduce` sums them into `grads`, folds the 8 loss scalars + count into totals[9] and advances
+ * the cursor; the caller then all-reduces `grads` (N > 1) and runs ppoaf_clip_adam_step.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t obs_dim, num_agents, num_actions, embedding;
+    int64_t offsets[64];
+    int64_t bucket_total;
+    const float* params; float* grads; float* slabs;
+    const float* critic_obs; const int64_t* raw_actions;
+    const float* advantages; const float* old_log_probs; const float* rewards_to_go; float* values;
+    const int64_t* perm; const int32_t* row_map; int64_t n_rows;
+    int64_t* cursor; int64_t B, batch_stride;
+    int32_t normalize_values, n_ranks, normalize_adv, use_huber;
+    float* vn_mean; float* vn_var; double* vn_count;     /* [2] double-buffered by mini-batch parity, as K12 */
+    const double* vn_records; const double* adv_records;
+    float surr_clip, entropy_weight, kl_loss_weight, huber_delta;
+    float* loss_partials;            /* [n_workgroups, 8] */
+    double* totals;                  /* [9] */
+} ppoaf_mat_update_args_t;
+
+int ppoaf_mat_update_fwd_bwd(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream);
+int ppoaf_mat_update_reduce(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,25 @@ class IcmUpdateArgs(C.Structure):
                 ("totals", C.c_void_p)]
 
 
+class MatUpdateArgs(C.Structure):
+    """ppoaf_mat_update_args_t (include/ppoaf_hip.h) -- field order must match the header."""
+    _fields_ = [("obs_dim", C.c_int32), ("num_agents", C.c_int32), ("num_actions", C.c_int32), ("embedding", C.c_int32),
+                ("offsets", C.c_int64 * 64), ("bucket_total", C.c_int64),
+                ("params", C.c_void_p), ("grads", C.c_void_p), ("slabs", C.c_void_p),
+                ("critic_obs", C.c_void_p), ("raw_actions", C.c_void_p),
+                ("advantages", C.c_void_p), ("old_log_probs", C.c_void_p), ("rewards_to_go", C.c_void_p),
+                ("values", C.c_void_p),
+                ("perm", C.c_void_p), ("row_map", C.c_void_p), ("n_rows", C.c_int64),
+                ("cursor", C.c_void_p), ("B", C.c_int64), ("batch_stride", C.c_int64),
+                ("normalize_values", C.c_int32), ("n_ranks", C.c_int32), ("normalize_adv", C.c_int32),
+                ("use_huber", C.c_int32),
+                ("vn_mean", C.c_void_p), ("vn_var", C.c_void_p), ("vn_count", C.c_void_p),
+                ("vn_records", C.c_void_p), ("adv_records", C.c_void_p),
+                ("surr_clip", C.c_float), ("entropy_weight", C.c_float), ("kl_loss_weight", C.c_float),
+                ("huber_delta", C.c_float),
+                ("loss_partials", C.c_void_p), ("totals", C.c_void_p)]
+
+
 class ObsFilter(C.Structure):
     """ppoaf_obs_filter_t (include/ppoaf_hip.h)."""
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("mean", C.c_void_p), ("var", C.c_void_p),
@@ -157,6 +176,8 @@ SIGNATURES = {
     "ppoaf_minibatch_moments": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int64, _ptr, _ptr]),
     "ppoaf_icm_update_fwd_bwd": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
     "ppoaf_icm_update_reduce": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
+    "ppoaf_mat_update_fwd_bwd": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
+    "ppoaf_mat_update_reduce": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
     "ppoaf_env_filter_moments": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),
                                            C.c_int32, C.c_int64, _ptr, _ptr]),
     "ppoaf_env_filter_apply": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),

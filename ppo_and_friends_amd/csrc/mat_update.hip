@@ -1,0 +1,913 @@
+// K15: fused multi-agent-transformer mini-batch update (see include/ppoaf_hip.h for the contract).
+// One iteration of PPO._ppo_batch_train for a MATPolicy (ppo.py:2292-2469 with
+// mat_policy.py:378-439,628-699; networks multi_agent_transformer.py:22-373, attention.py:13-257) =
+//   mat_update_fwd_bwd_kernel   gather + token block + critic (encoder) forward + actor (decoder)
+//                               forward + categorical head / PPO loss / value loss + the whole
+//                               backward -> weight-gradient slab of this workgroup
+//   mat_update_reduce_kernel    slabs -> gradient bucket (fixed order), loss partials -> totals, cursor++
+//   then K11 (global-norm clip + Adam over the one actor_critic bucket; mat_policy.py:677-699)
+//
+// Work decomposition: attention couples only the L agents of one env, so floor(16/L) sequences
+// (15 token rows for L = 3) form a self-contained 16-row tile: one workgroup of 4 waves owns a
+// tile end to end.  Every 64x64 linear is 4 output tiles of v_mfma_f32_16x16x4_f32 (one per wave),
+// the 3x3 attention blocks are packed block-diagonally into one 16x16 MFMA tile exactly as K9 does,
+// LayerNorm / GELU / residuals are 16-lane-per-row VALU passes, and everything the backward needs
+// (normalised activations, pre-GELU values, q/k/v, probabilities) stays in LDS: ~147 KB of the 160 KB.
+// A mini-batch of 256 envs is 52 workgroups; the ~80 dependent phases are barrier + LDS latency
+// bound, not MFMA bound -- the point is that they replace ~270 separate kernel launches.
+#include "mlp_device.hpp"
+
+namespace ppoaf {
+
+constexpr int kMD = 64;            // embedding width
+constexpr int kMHS = kMD + 4;      // LDS row stride of a [16, 64] tile
+constexpr int kMNW = 4;            // waves per workgroup
+constexpr int kMT = 64 * kMNW;
+constexpr int kMXS = 20;           // row stride of the action-token tile [16, 16 + 4]
+constexpr int kMTile = kRows * kMHS;
+
+// parameter tensors of MATActorCritic in module order (== bucket order); offsets in floats
+enum MatP {
+    A_ENC_W, A_LN_G, A_LN_B, A_LN1_G, A_LN1_B, A_LN2_G, A_LN2_B, A_LN3_G, A_LN3_B,
+    A_K1_W, A_K1_B, A_Q1_W, A_Q1_B, A_V1_W, A_V1_B, A_P1_W, A_P1_B,
+    A_K2_W, A_K2_B, A_Q2_W, A_Q2_B, A_V2_W, A_V2_B, A_P2_W, A_P2_B,
+    A_M1_W, A_M1_B, A_M2_W, A_M2_B, A_H1_W, A_H1_B, A_HLN_G, A_HLN_B, A_H2_W, A_H2_B,
+    C_OLN_G, C_OLN_B, C_ENC_W, C_ENC_B, C_LN_G, C_LN_B, C_LN1_G, C_LN1_B, C_LN2_G, C_LN2_B,
+    C_K_W, C_K_B, C_Q_W, C_Q_B, C_V_W, C_V_B, C_P_W, C_P_B,
+    C_M1_W, C_M1_B, C_M2_W, C_M2_B, C_H1_W, C_H1_B, C_HLN_G, C_HLN_B, C_H2_W, C_H2_B,
+    MAT_NUM_PARAMS
+};
+static_assert(MAT_NUM_PARAMS == 63, "offset table layout");
+
+struct MatDev {
+    long off[64];
+    int O, L, NA, Ain, per_tile, nT;
+    long total;
+    const float* params; float* grads; float* slabs;
+    const float* obs; const int64_t* actions; const float* adv; const float* old_lp; const float* rtg; float* values;
+    const int64_t* perm; const int32_t* row_map; long n_rows;
+    int64_t* cursor; long B, batch_stride;
+    int normalize_values, n_ranks, normalize_adv, use_huber;
+    float* vn_mean; float* vn_var; double* vn_count; const double* vn_records; const double* adv_records;
+    float surr_clip, entropy_weight, kl_loss_weight, huber_delta;
+    float* loss_partials; double* totals;
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char mat_smem[];
+
+// ------------------------------------------------------------------------------------------------
+// element-wise passes over a [16, 64] tile: thread = (row = tid >> 4, lane16 = tid & 15), 4 columns each
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_d(float z) {
+    const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+    const float pdf = expf(-0.5f * z * z) * 0.39894228040143267794f;
+    return cdf + z * pdf;
+}
+
+// out = gelu(Z)
+__device__ __forceinline__ void tile_gelu(const float* __restrict__ Z, float* __restrict__ out, int tid) {
+    const int row = tid >> 4, l = tid & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[row * kMHS + l + 16 * j] = gelu_f(Z[row * kMHS + l + 16 * j]);
+}
+// D *= gelu'(Z)
+__device__ __forceinline__ void tile_gelu_bwd(float* __restrict__ D, const float* __restrict__ Z, int tid) {
+    const int row = tid >> 4, l = tid & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) D[row * kMHS + l + 16 * j] *= gelu_d(Z[row * kMHS + l + 16 * j]);
+}
+// out = A + B
+__device__ __forceinline__ void tile_add(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ out, int tid) {
+    const int row = tid >> 4, l = tid & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[row * kMHS + l + 16 * j] = A[row * kMHS + l + 16 * j] + B[row * kMHS + l + 16 * j];
+}
+// Y = Xhat * g + b   (LayerNorm output re-materialised for the backward)
+__device__ __forceinline__ void tile_affine(const float* __restrict__ Xhat, const float* __restrict__ g,
+                                            const float* __restrict__ b, float* __restrict__ Y, int tid) {
+    const int row = tid >> 4, l = tid & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = l + 16 * j; Y[row * kMHS + c] = Xhat[row * kMHS + c] * g[c] + b[c]; }
+}
+
+// LayerNorm over W <= 64 columns (tile stride `ld`): Xhat, rstd[16], Y = Xhat * g + b.  X may alias Y.
+__device__ __forceinline__ void tile_ln_fwd(const float* X, int ld, int W, const float* __restrict__ g,
+                                            const float* __restrict__ b, float* __restrict__ Xhat,
+                                            float* __restrict__ rstd, float* Y, int tid) {
+    const int row = tid >> 4, l = tid & 15;
+    float x[4], s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = l + 16 * j; x[j] = c < W ? X[row * ld + c] : 0.f; s += x[j]; }
+    const float mean = group16_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = l + 16 * j; x[j] = c < W ? x[j] - mean : 0.f; q += x[j] * x[j]; }
+    const float rs = 1.0f / sqrtf(group16_sum(q) / (float)W + 1e-5f);
+    if (l == 0) rstd[row] = rs;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = l + 16 * j;
+        if (c < W) {
+            const float xh = x[j] * rs;
+            Xhat[row * ld + c] = xh;
+            Y[row * ld + c] = xh * g[c] + b[c];
+        }
+    }
+}
+// LayerNorm backward: DX = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)); d gamma / d beta column sums -> slab.
+// DX must not alias DY (the column sums read DY while the rows are being written).  DX == nullptr: no input gradient.
+__device__ __forceinline__ void tile_ln_bwd(const float* __restrict__ DY, int ld, int W, const float* __restrict__ Xhat,
+                                            const float* __restrict__ rstd, const float* __restrict__ g,
+                                            float* __restrict__ DX, float* __restrict__ slab_g, float* __restrict__ slab_b,
+                                            int tid) {
+    const int row = tid >> 4, l = tid & 15;
+    if (DX) {
+        float dxh[4], xh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = l + 16 * j;
+            xh[j] = c < W ? Xhat[row * ld + c] : 0.f;
+            dxh[j] = c < W ? DY[row * ld + c] * g[c] : 0.f;
+            s1 += dxh[j]; s2 += dxh[j] * xh[j];
+        }
+        const float m1 = group16_sum(s1) / (float)W, m2 = group16_sum(s2) / (float)W, rs = rstd[row];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int c = l + 16 * j; if (c < W) DX[row * ld + c] = (dxh[j] - m1 - xh[j] * m2) * rs; }
+    }
+    if (tid < 64) {
+        if (tid < W) {
+            float a = 0.f;
+#pragma unroll
+            for (int s = 0; s < kRows; ++s) a = fmaf(DY[s * ld + tid], Xhat[s * ld + tid], a);
+            slab_g[tid] = a;
+        }
+    } else if (tid < 128) {
+        const int c = tid - 64;
+        if (c < W) {
+            float a = 0.f;
+#pragma unroll
+            for (int s = 0; s < kRows; ++s) a += DY[s * ld + c];
+            slab_b[c] = a;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// linears on [16, 64] tiles (one output tile of 16 columns per wave)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lin_fwd(const float* __restrict__ W, const float* __restrict__ bias,
+                                        const float* __restrict__ A, float* __restrict__ out, int wave, int lane) {
+    layer_fwd<4, true, kMNW>(W, kMD, bias, A, out, -1, wave, lane);
+}
+__device__ __forceinline__ void lin_wgrad(const float* __restrict__ Dt, const float* __restrict__ In,
+                                          float* __restrict__ dW, float* __restrict__ dB, int wave, int lane, int tid) {
+    layer_wgrad<4, kMNW>(Dt, In, kMHS, 4, kMD, dW, kMD, dB, wave, lane, tid);
+}
+// out (+)= Dt . W   (out must not alias Dt)
+template <bool ACCUM>
+__device__ __forceinline__ void lin_dgrad(const float* __restrict__ W, const float* __restrict__ Dt,
+                                          float* __restrict__ out, int wave, int lane) {
+    float4 fr[4];
+    load_dgrad_frags_ld<4>(W, kMD, wave * 16, lane, fr);
+    const f32x4 acc = mfma_rows_x_frags<4>(Dt, kMHS, lane, fr, 0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int idx = (4 * (lane >> 4) + r) * kMHS + wave * 16 + (lane & 15);
+        out[idx] = ACCUM ? out[idx] + acc[r] : acc[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention core on LDS tiles (K9's block-diagonal packing).  Q, K, V, Y, dY ... are [16, 64] tiles.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 att_xyT(const float* __restrict__ X, const float* __restrict__ Y, int lane) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* xr = X + (lane & 15) * kMHS + 4 * (lane >> 4);
+    const float* yr = Y + (lane & 15) * kMHS + 4 * (lane >> 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + 16 * c);
+        const float4 b = *reinterpret_cast<const float4*>(yr + 16 * c);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// out[:, 16 nt ..] = A[16,16] . Z[:, 16 nt ..]; A from the 17-stride tile T, as is or transposed
+__device__ __forceinline__ void att_a_times(const float* __restrict__ T, bool transposed, const float* __restrict__ Z,
+                                            float* __restrict__ out, int nt, int lane) {
+    const int i = lane & 15, slot = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kk = 4 * slot + j;
+        const float a = transposed ? T[kk * 17 + i] : T[i * 17 + kk];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Z[kk * kMHS + 16 * nt + i], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(4 * slot + r) * kMHS + 16 * nt + i] = acc[r];
+}
+// forward: probabilities -> sP (kept for the backward), Y = P V.  Two barriers inside, none after.
+__device__ __forceinline__ void att_fwd(const float* Q, const float* K, const float* V, float* Y, float* sP,
+                                        int L, int n_rows, bool masked, int wave, int lane) {
+    if (wave == 0) {
+        const f32x4 s = att_xyT(Q, K, lane);
+        const int col = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * (lane >> 4) + r;
+            bool ok = row < n_rows && col < n_rows && (row / L) == (col / L);
+            if (masked) ok = ok && (col % L) <= (row % L);
+            const float x = ok ? s[r] * 0.125f : -INFINITY;             // 1 / sqrt(64)
+            float m = x;
+            m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
+            m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 1, 64));
+            const float e = ok ? expf(x - m) : 0.f;
+            const float den = group16_sum(e);
+            sP[row * 17 + col] = den > 0.f ? e / den : 0.f;
+        }
+    }
+    __syncthreads();
+    att_a_times(sP, false, V, Y, wave, lane);
+}
+// backward from dY: dQ, dK, dV (three distinct output tiles); sS is a 17-stride scratch tile
+__device__ __forceinline__ void att_bwd(const float* Q, const float* K, const float* V, const float* sP, const float* dY,
+                                        float* dQ, float* dK, float* dV, float* sS, int wave, int lane) {
+    if (wave == 0) {
+        const f32x4 dp = att_xyT(dY, V, lane);
+        const int col = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * (lane >> 4) + r;
+            const float p = sP[row * 17 + col];
+            const float dot = group16_sum(dp[r] * p);
+            sS[row * 17 + col] = p * (dp[r] - dot) * 0.125f;
+        }
+    }
+    __syncthreads();
+    att_a_times(sP, true, dY, dV, wave, lane);      // dV = P^T dY
+    att_a_times(sS, false, K, dQ, wave, lane);      // dQ = dS K
+    att_a_times(sS, true, Q, dK, wave, lane);       // dK = dS^T Q
+}
+
+// ------------------------------------------------------------------------------------------------
+// narrow first layers (observation encoder K = O, action encoder K = Ain): weights [64, K] row-major
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void narrow_fwd(const float* __restrict__ W, int Kdim, const float* __restrict__ bias,
+                                           const float* __restrict__ X, int ldx, float* __restrict__ out, int wave, int lane) {
+    const int o = wave * 16 + (lane & 15);
+    const float bv = bias ? bias[o] : 0.f;
+    f32x4 acc = {bv, bv, bv, bv};
+    const float* w = W + (long)o * Kdim;
+    const float* arow = X + (lane & 15) * ldx;
+    for (int k0 = 0; k0 < Kdim; k0 += 16) {
+        float bq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int k = k0 + 4 * j + (lane >> 4); bq[j] = k < Kdim ? w[k] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k0 + 4 * j + (lane >> 4)], bq[j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(4 * (lane >> 4) + r) * kMHS + o] = acc[r];
+}
+// dX[16, Kdim] = D[16,64] . W[64, Kdim]  (tile stride ldx; columns >= Kdim untouched)
+__device__ __forceinline__ void narrow_dgrad(const float* __restrict__ W, int Kdim, const float* __restrict__ Dt,
+                                             float* __restrict__ dX, int ldx, int wave, int lane) {
+    for (int nt = wave; nt * 16 < Kdim; nt += kMNW) {
+        const int i = nt * 16 + (lane & 15);
+        float4 fr[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* wp = W + (long)(16 * c + 4 * (lane >> 4)) * Kdim + i;
+            fr[c] = i < Kdim ? make_float4(wp[0], wp[Kdim], wp[2 * Kdim], wp[3 * Kdim]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const f32x4 acc = mfma_rows_x_frags<4>(Dt, kMHS, lane, fr, 0.f);
+        if (i < Kdim) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dX[(4 * (lane >> 4) + r) * ldx + i] = acc[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// narrow output layers (64 -> n_out <= 8) on the VALU
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void head_out_fwd(const float* __restrict__ W, const float* __restrict__ bias, int n_out,
+                                             const float* __restrict__ Hh, float* __restrict__ sOut, int tid) {
+    const int s = tid >> 4, part = tid & 15;
+    for (int k = 0; k < n_out; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = fmaf(Hh[s * kMHS + part + 16 * i], W[k * kMD + part + 16 * i], acc);
+        acc = group16_sum(acc);
+        if (part == 0) sOut[s * 8 + k] = acc + bias[k];
+    }
+}
+// dW[k][i], db[k] -> slab; dH[s][i] = sum_k dOut[s][k] W[k][i]
+__device__ __forceinline__ void head_out_bwd(const float* __restrict__ W, int n_out, const float* __restrict__ Hh,
+                                             const float* __restrict__ sDOut, float* __restrict__ dH,
+                                             float* __restrict__ slabW, float* __restrict__ slabB, int tid) {
+    if (tid < kMD) {
+        float h[kRows];
+#pragma unroll
+        for (int s = 0; s < kRows; ++s) h[s] = Hh[s * kMHS + tid];
+        for (int k = 0; k < n_out; ++k) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < kRows; ++s) acc = fmaf(sDOut[s * 8 + k], h[s], acc);
+            slabW[k * kMD + tid] = acc;
+        }
+    } else if (tid < kMD + 8) {
+        const int k = tid - kMD;
+        float acc = 0.f;
+        if (k < n_out)
+#pragma unroll
+            for (int s = 0; s < kRows; ++s) acc += sDOut[s * 8 + k];
+        if (k < ((n_out + 3) & ~3)) slabB[k] = acc;
+    }
+    const int s = tid >> 4, part = tid & 15;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < n_out; ++k) {
+        const float d = sDOut[s * 8 + k];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(d, W[k * kMD + part + 16 * i], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dH[s * kMHS + part + 16 * i] = acc[i];
+}
+
+#define MAT_SYNC() __syncthreads()
+
+__global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const int O = u.O, L = u.L, NA = u.NA, Ain = u.Ain;
+    const int NT0 = (O + 15) >> 4, OS = 16 * NT0 + 4;
+    const float* P = u.params;
+    float* slab = u.slabs + (long)g * u.total;
+    const long mb = u.cursor[0];
+    const long seq0 = (long)g * u.per_tile;
+    const long rem = u.B - seq0;
+    const int n_seq = (int)(rem < u.per_tile ? (rem < 0 ? 0 : rem) : u.per_tile);
+    const int n_rows = n_seq * L;
+    const float inv_n = 1.0f / (float)(u.B * L);
+
+    // ---- LDS carve
+    float* sm = reinterpret_cast<float*>(mat_smem);
+    int* sRow = reinterpret_cast<int*>(sm);                 // [16] buffer row of the token's env (-1: padding)
+    int* sAct = reinterpret_cast<int*>(sm) + 16;            // [16] action of the token
+    float* sMisc = sm + 32;                                 // [8] adv mean/std, vn mean/var
+    float* sRowF = sm + 48;                                 // [3][16] adv, old log-prob, rewards-to-go
+    float* sRstd = sm + 96;                                 // [10][16]
+    float* sOutC = sm + 256;                                // [16][8] critic output (col 0)
+    float* sOutA = sOutC + 128;                             // [16][8] logits
+    float* sDOutC = sOutA + 128;
+    float* sDOutA = sDOutC + 128;
+    float* sP0 = sDOutA + 128;                              // 3 probability tiles + 1 dS scratch, [16][17] each
+    float* sP1 = sP0 + 272;
+    float* sP2 = sP1 + 272;
+    float* sS = sP2 + 272;
+    float* sXA = sS + 272;                                  // [16][kMXS] action tokens
+    float* sXO = sXA + kRows * kMXS;                        // [16][OS] xhat of the observation LayerNorm
+    float* sYO = sXO + kRows * OS;                          // [16][OS] its output (input of the encoder linear)
+    float* T = sYO + kRows * OS;                            // [16][68] tiles from here on
+    auto tile = [&](int k) -> float* { return T + (long)k * kMTile; };
+    // saved for the backward
+    float *cZ1 = tile(0), *cN0 = tile(1), *cQ = tile(2), *cK = tile(3), *cV = tile(4), *cY = tile(5), *cN1 = tile(6),
+          *cZM = tile(7), *cN2 = tile(8), *cENC = tile(9), *cZH = tile(10), *cNH = tile(11);
+    float *aZ = tile(12), *aN0 = tile(13), *aQ1 = tile(14), *aK1 = tile(15), *aV1 = tile(16), *aY1 = tile(17),
+          *aN1 = tile(18), *aK2 = tile(19), *aV2 = tile(20), *aQ2 = tile(21), *aY2 = tile(22), *aN2 = tile(23),
+          *aZM = tile(24), *aN3 = tile(25), *aZH = tile(26), *aNH = tile(27);
+    float *S0 = tile(28), *S1 = tile(29), *S2 = tile(30), *S3 = tile(31), *S4 = tile(32), *DENC = tile(33);
+    auto rstd = [&](int k) -> float* { return sRstd + 16 * k; };
+    auto W = [&](int k) -> const float* { return P + u.off[k]; };
+    auto G = [&](int k) -> float* { return slab + u.off[k]; };
+
+    // ---- rows, per-token scalars, mini-batch statistics
+    if (tid < kRows) {
+        int row = -1, act = 0;
+        float av = 0.f, lpo = 0.f, rt = 0.f;
+        if (tid < n_rows) {
+            const int s = tid / L, a = tid - s * L;
+            const long p = u.perm[mb * u.batch_stride + seq0 + s];
+            if (p >= 0 && p < u.n_rows) {
+                row = u.row_map ? u.row_map[p] : (int)p;
+                const long tok = (long)row * L + a;
+                act = (int)u.actions[tok];
+                act = act < 0 ? 0 : (act >= NA ? NA - 1 : act);
+                av = u.adv[tok]; lpo = u.old_lp[tok]; rt = u.rtg[tok];
+            }
+        }
+        sRow[tid] = row; sAct[tid] = act;
+        sRowF[tid] = av; sRowF[16 + tid] = lpo; sRowF[32 + tid] = rt;
+    }
+    if (tid == 64) {
+        float mean_f = 0.f, std_f = 1.f;
+        if (u.normalize_adv) {
+            const double* rec = u.adv_records + mb * 3;
+            mean_f = (float)rec[1];
+            std_f = (float)sqrt(rec[2] / (rec[0] - 1.0));
+        }
+        sMisc[0] = mean_f; sMisc[1] = std_f;
+    }
+    if (tid == 128) {
+        // value normaliser: Chan merge of the rank records of this mini-batch + the reference's integrate
+        // (utils/stats.py:73-94), as in K12
+        const int slot = (int)(mb & 1);
+        float m = u.vn_mean[slot], v = u.vn_var[slot];
+        double cnt = u.vn_count[slot];
+        if (u.normalize_values) {
+            double n = 0.0, bm = 0.0, M2 = 0.0;
+            for (int r = 0; r < u.n_ranks; ++r) {
+                const double* rec = u.vn_records + (mb * u.n_ranks + r) * 3;
+                const double nb = rec[0];
+                if (nb <= 0.0) continue;
+                const double d = rec[1] - bm, nn = n + nb;
+                bm += d * (nb / nn);
+                M2 += rec[2] + d * d * n * nb / nn;
+                n = nn;
+            }
+            if (n > 0.0) {
+                const float batch_mean = (float)bm, batch_var = (float)(M2 / n);
+                const float delta = batch_mean - m;
+                const double new_count = cnt + n;
+                const float new_mean = (float)((double)m + (double)delta * (n / new_count));
+                const double m_2 = (double)v * cnt + (double)batch_var * n + (double)(delta * delta) * cnt * n / (cnt + n);
+                m = new_mean; v = (float)(m_2 / (cnt + n)); cnt = new_count;
+            }
+        }
+        sMisc[2] = m; sMisc[3] = v;
+        if (g == 0) { u.vn_mean[slot ^ 1] = m; u.vn_var[slot ^ 1] = v; u.vn_count[slot ^ 1] = cnt; }
+    }
+    for (int i = tid; i < kRows * OS; i += kMT) { sXO[i] = 0.f; sYO[i] = 0.f; }
+    for (int i = tid; i < kRows * kMXS; i += kMT) sXA[i] = 0.f;
+    MAT_SYNC();
+    // observations of the tile's tokens; the shifted one-hot token block (mat_policy.py:308-344,378-416)
+    for (int idx = tid; idx < n_rows * O; idx += kMT) {
+        const int s = idx / O, i = idx - s * O;
+        const int row = sRow[s];
+        if (row >= 0) sYO[s * OS + i] = u.obs[((long)row * L + (s % L)) * O + i];
+    }
+    if (tid < n_rows && sRow[tid] >= 0) {
+        const int a = tid % L;
+        if (a == 0) sXA[tid * kMXS] = 1.0f;
+        else sXA[tid * kMXS + 1 + sAct[tid - 1]] = 1.0f;
+    }
+    MAT_SYNC();
+
+    // =========================================== critic (encoder) forward ===========================================
+    tile_ln_fwd(sYO, OS, O, W(C_OLN_G), W(C_OLN_B), sXO, rstd(0), sYO, tid);                 // obs_encoder.0
+    MAT_SYNC();
+    narrow_fwd(W(C_ENC_W), O, W(C_ENC_B), sYO, OS, cZ1, wave, lane);                          // obs_encoder.1
+    MAT_SYNC();
+    tile_gelu(cZ1, S0, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S0, kMHS, kMD, W(C_LN_G), W(C_LN_B), cN0, rstd(1), S1, tid);                  // critic.ln -> H0 in S1
+    MAT_SYNC();
+    lin_fwd(W(C_Q_W), W(C_Q_B), S1, cQ, wave, lane);
+    lin_fwd(W(C_K_W), W(C_K_B), S1, cK, wave, lane);
+    lin_fwd(W(C_V_W), W(C_V_B), S1, cV, wave, lane);
+    MAT_SYNC();
+    att_fwd(cQ, cK, cV, cY, sP0, L, n_rows, false, wave, lane);
+    MAT_SYNC();
+    lin_fwd(W(C_P_W), W(C_P_B), cY, S2, wave, lane);
+    MAT_SYNC();
+    tile_add(S1, S2, S2, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S2, kMHS, kMD, W(C_LN1_G), W(C_LN1_B), cN1, rstd(2), S0, tid);                // H1 in S0
+    MAT_SYNC();
+    lin_fwd(W(C_M1_W), W(C_M1_B), S0, cZM, wave, lane);
+    MAT_SYNC();
+    tile_gelu(cZM, S2, tid);
+    MAT_SYNC();
+    lin_fwd(W(C_M2_W), W(C_M2_B), S2, S3, wave, lane);
+    MAT_SYNC();
+    tile_add(S0, S3, S3, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S3, kMHS, kMD, W(C_LN2_G), W(C_LN2_B), cN2, rstd(3), cENC, tid);              // rep_enc
+    MAT_SYNC();
+    lin_fwd(W(C_H1_W), W(C_H1_B), cENC, cZH, wave, lane);
+    MAT_SYNC();
+    tile_gelu(cZH, S0, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S0, kMHS, kMD, W(C_HLN_G), W(C_HLN_B), cNH, rstd(4), S1, tid);
+    MAT_SYNC();
+    head_out_fwd(W(C_H2_W), W(C_H2_B), 1, S1, sOutC, tid);
+
+    // =========================================== actor (decoder) forward ===========================================
+    narrow_fwd(W(A_ENC_W), Ain, nullptr, sXA, kMXS, aZ, wave, lane);                          // action_encoder.0 (no bias)
+    MAT_SYNC();
+    tile_gelu(aZ, S0, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S0, kMHS, kMD, W(A_LN_G), W(A_LN_B), aN0, rstd(5), S1, tid);                  // x0 in S1
+    MAT_SYNC();
+    lin_fwd(W(A_K1_W), W(A_K1_B), S1, aK1, wave, lane);
+    lin_fwd(W(A_Q1_W), W(A_Q1_B), S1, aQ1, wave, lane);
+    lin_fwd(W(A_V1_W), W(A_V1_B), S1, aV1, wave, lane);
+    MAT_SYNC();
+    att_fwd(aQ1, aK1, aV1, aY1, sP1, L, n_rows, true, wave, lane);
+    MAT_SYNC();
+    lin_fwd(W(A_P1_W), W(A_P1_B), aY1, S2, wave, lane);
+    MAT_SYNC();
+    tile_add(S1, S2, S2, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S2, kMHS, kMD, W(A_LN1_G), W(A_LN1_B), aN1, rstd(6), S0, tid);                // x1 in S0
+    MAT_SYNC();
+    lin_fwd(W(A_K2_W), W(A_K2_B), S0, aK2, wave, lane);                                       // key = value = x1
+    lin_fwd(W(A_V2_W), W(A_V2_B), S0, aV2, wave, lane);
+    lin_fwd(W(A_Q2_W), W(A_Q2_B), cENC, aQ2, wave, lane);                                     // query = rep_enc
+    MAT_SYNC();
+    att_fwd(aQ2, aK2, aV2, aY2, sP2, L, n_rows, true, wave, lane);
+    MAT_SYNC();
+    lin_fwd(W(A_P2_W), W(A_P2_B), aY2, S2, wave, lane);
+    MAT_SYNC();
+    tile_add(cENC, S2, S2, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S2, kMHS, kMD, W(A_LN2_G), W(A_LN2_B), aN2, rstd(7), S1, tid);                // x2 in S1
+    MAT_SYNC();
+    lin_fwd(W(A_M1_W), W(A_M1_B), S1, aZM, wave, lane);
+    MAT_SYNC();
+    tile_gelu(aZM, S2, tid);
+    MAT_SYNC();
+    lin_fwd(W(A_M2_W), W(A_M2_B), S2, S3, wave, lane);
+    MAT_SYNC();
+    tile_add(S1, S3, S3, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S3, kMHS, kMD, W(A_LN3_G), W(A_LN3_B), aN3, rstd(8), S0, tid);                // x3 in S0
+    MAT_SYNC();
+    lin_fwd(W(A_H1_W), W(A_H1_B), S0, aZH, wave, lane);
+    MAT_SYNC();
+    tile_gelu(aZH, S2, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S2, kMHS, kMD, W(A_HLN_G), W(A_HLN_B), aNH, rstd(9), S1, tid);                // head LayerNorm output in S1
+    MAT_SYNC();
+    head_out_fwd(W(A_H2_W), W(A_H2_B), NA, S1, sOutA, tid);
+    MAT_SYNC();
+
+    // =========================================== heads: distribution + losses (K6 + K3) =============================
+    if (wave == 0) {
+        const int s = lane;
+        const bool live = s < n_rows && sRow[s] >= 0;
+        float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (live) {
+            float av = sRowF[s];
+            const float lpo = sRowF[16 + s];
+            if (u.normalize_adv) av = (av - sMisc[0]) / (sMisc[1] + 1e-8f);
+            float p[8];
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (k < NA) m = fmaxf(m, sOutA[s * 8 + k]);
+            float ssum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { p[k] = k < NA ? expf(sOutA[s * 8 + k] - m) : 0.f; ssum += p[k]; }
+            const float inv = 1.0f / ssum;
+            float s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { p[k] *= inv; s2 += p[k]; }
+            const int a = sAct[s];
+            float nk8[8], lg8[8], logp = 0.f, ent = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                nk8[k] = p[k] / s2;
+                lg8[k] = k < NA ? logf(clamp_prob_u(nk8[k])) : 0.f;
+                if (k < NA) ent -= nk8[k] * lg8[k];
+                if (k == a) logp = lg8[k];
+            }
+            const float ratio = expf(logp - lpo);
+            if (isnan(ratio) || isinf(ratio)) part[7] = 1.f;
+            const float lo = 1.0f - u.surr_clip, hi = 1.0f + u.surr_clip;
+            const float surr1 = ratio * av, surr2 = fminf(fmaxf(ratio, lo), hi) * av;
+            part[0] = -fminf(surr1, surr2);
+            part[3] = ent;
+            part[4] = lpo - logp;
+            float glp;
+            if (surr1 <= surr2) glp = -av * ratio;
+            else glp = (ratio >= lo && ratio <= hi) ? -av * ratio : 0.f;
+            glp *= inv_n;
+            const float gH = (u.entropy_weight != 0.0f) ? -u.entropy_weight * inv_n : 0.f;
+            float gn[8], dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float gk = 0.f;
+                if (k < NA) {
+                    const float nk = nk8[k], ck = clamp_prob_u(nk);
+                    const float in_range = (nk >= FLT_EPSILON && nk <= 1.0f - FLT_EPSILON) ? 1.f : 0.f;
+                    gk = gH * (-lg8[k] - nk * in_range / ck);
+                    if (k == a) gk += glp * in_range / ck;
+                    dot += gk * nk;
+                }
+                gn[k] = gk;
+            }
+            float dot2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { gn[k] = (gn[k] - dot) / s2; dot2 += gn[k] * p[k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sDOutA[s * 8 + k] = p[k] * (gn[k] - dot2);
+            // value loss
+            const float v = sOutC[s * 8];
+            float rt = sRowF[32 + s];
+            if (u.normalize_values) rt = (rt - sMisc[2]) / sqrtf(sMisc[3] + 1e-8f);
+            const float diff = v - rt;
+            float l, dl;
+            if (u.use_huber) {
+                const float ad = fabsf(diff);
+                if (ad < u.huber_delta) { l = 0.5f * diff * diff; dl = diff; }
+                else { l = u.huber_delta * (ad - 0.5f * u.huber_delta); dl = diff > 0.f ? u.huber_delta : -u.huber_delta; }
+            } else { l = diff * diff; dl = 2.0f * diff; }
+            part[2] = l;
+            sDOutC[s * 8] = dl * inv_n;
+            u.values[(long)sRow[s] * L + (s % L)] = v;                                          // ppo.py:2340
+        } else if (s < kRows) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { sDOutA[s * 8 + k] = 0.f; sDOutC[s * 8 + k] = 0.f; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = (lane < kRows) ? part[k] : 0.f;
+            part[k] = group16_sum(v);
+        }
+        if (lane == 0) {
+            if (g == 0) { part[5] = sMisc[0]; part[6] = sMisc[1]; }
+            float* lp = u.loss_partials + (long)g * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) lp[k] = part[k];
+        }
+    }
+    MAT_SYNC();
+
+    // =========================================== actor backward ===========================================
+    // S1 still holds the head LayerNorm output
+    head_out_bwd(W(A_H2_W), NA, S1, sDOutA, S2, G(A_H2_W), G(A_H2_B), tid);                   // d head-LN out -> S2
+    MAT_SYNC();
+    tile_ln_bwd(S2, kMHS, kMD, aNH, rstd(9), W(A_HLN_G), S3, G(A_HLN_G), G(A_HLN_B), tid);     // -> d gelu out in S3
+    MAT_SYNC();
+    tile_gelu_bwd(S3, aZH, tid);                                                              // d aZH
+    tile_affine(aN3, W(A_LN3_G), W(A_LN3_B), S0, tid);                                        // x3
+    MAT_SYNC();
+    lin_wgrad(S3, S0, G(A_H1_W), G(A_H1_B), wave, lane, tid);
+    lin_dgrad<false>(W(A_H1_W), S3, S2, wave, lane);                                          // d x3 -> S2
+    MAT_SYNC();
+    tile_ln_bwd(S2, kMHS, kMD, aN3, rstd(8), W(A_LN3_G), S4, G(A_LN3_G), G(A_LN3_B), tid);     // d r3 -> S4 (= d x2 residual = d mlp out)
+    tile_gelu(aZM, S0, tid);                                                                  // mlp hidden activation
+    MAT_SYNC();
+    lin_wgrad(S4, S0, G(A_M2_W), G(A_M2_B), wave, lane, tid);
+    lin_dgrad<false>(W(A_M2_W), S4, S3, wave, lane);
+    MAT_SYNC();
+    tile_gelu_bwd(S3, aZM, tid);                                                              // d aZM
+    tile_affine(aN2, W(A_LN2_G), W(A_LN2_B), S0, tid);                                        // x2
+    MAT_SYNC();
+    lin_wgrad(S3, S0, G(A_M1_W), G(A_M1_B), wave, lane, tid);
+    lin_dgrad<true>(W(A_M1_W), S3, S4, wave, lane);                                           // d x2 total in S4
+    MAT_SYNC();
+    tile_ln_bwd(S4, kMHS, kMD, aN2, rstd(7), W(A_LN2_G), DENC, G(A_LN2_G), G(A_LN2_B), tid);   // d r2 -> DENC (rep_enc share) = d proj2 out
+    MAT_SYNC();
+    lin_wgrad(DENC, aY2, G(A_P2_W), G(A_P2_B), wave, lane, tid);
+    lin_dgrad<false>(W(A_P2_W), DENC, S2, wave, lane);                                        // d Y2 -> S2
+    MAT_SYNC();
+    att_bwd(aQ2, aK2, aV2, sP2, S2, S0, S3, S4, sS, wave, lane);                              // dQ2 -> S0, dK2 -> S3, dV2 -> S4
+    MAT_SYNC();
+    lin_wgrad(S0, cENC, G(A_Q2_W), G(A_Q2_B), wave, lane, tid);
+    lin_dgrad<true>(W(A_Q2_W), S0, DENC, wave, lane);                                         // rep_enc gradient from the query path
+    tile_affine(aN1, W(A_LN1_G), W(A_LN1_B), S1, tid);                                        // x1
+    MAT_SYNC();
+    lin_wgrad(S3, S1, G(A_K2_W), G(A_K2_B), wave, lane, tid);
+    lin_wgrad(S4, S1, G(A_V2_W), G(A_V2_B), wave, lane, tid);
+    lin_dgrad<false>(W(A_K2_W), S3, S2, wave, lane);
+    MAT_SYNC();
+    lin_dgrad<true>(W(A_V2_W), S4, S2, wave, lane);                                           // d x1 -> S2
+    MAT_SYNC();
+    tile_ln_bwd(S2, kMHS, kMD, aN1, rstd(6), W(A_LN1_G), S0, G(A_LN1_G), G(A_LN1_B), tid);     // d r1 -> S0 (= d x0 residual = d proj1 out)
+    MAT_SYNC();
+    lin_wgrad(S0, aY1, G(A_P1_W), G(A_P1_B), wave, lane, tid);
+    lin_dgrad<false>(W(A_P1_W), S0, S2, wave, lane);                                          // d Y1 -> S2
+    MAT_SYNC();
+    att_bwd(aQ1, aK1, aV1, sP1, S2, S1, S3, S4, sS, wave, lane);                              // dQ1 -> S1, dK1 -> S3, dV1 -> S4
+    MAT_SYNC();                                                                               // dY (S2) fully consumed
+    tile_affine(aN0, W(A_LN_G), W(A_LN_B), S2, tid);                                          // x0
+    MAT_SYNC();
+    lin_wgrad(S1, S2, G(A_Q1_W), G(A_Q1_B), wave, lane, tid);
+    lin_wgrad(S3, S2, G(A_K1_W), G(A_K1_B), wave, lane, tid);
+    lin_wgrad(S4, S2, G(A_V1_W), G(A_V1_B), wave, lane, tid);
+    lin_dgrad<true>(W(A_Q1_W), S1, S0, wave, lane);
+    MAT_SYNC();
+    lin_dgrad<true>(W(A_K1_W), S3, S0, wave, lane);
+    MAT_SYNC();
+    lin_dgrad<true>(W(A_V1_W), S4, S0, wave, lane);                                           // d x0 total in S0
+    MAT_SYNC();
+    tile_ln_bwd(S0, kMHS, kMD, aN0, rstd(5), W(A_LN_G), S1, G(A_LN_G), G(A_LN_B), tid);        // d gelu out -> S1
+    MAT_SYNC();
+    tile_gelu_bwd(S1, aZ, tid);
+    MAT_SYNC();
+    layer_wgrad<4, kMNW>(S1, sXA, kMXS, 1, Ain, G(A_ENC_W), Ain, nullptr, wave, lane, tid);
+
+    // =========================================== critic backward ===========================================
+    tile_affine(cNH, W(C_HLN_G), W(C_HLN_B), S0, tid);                                        // head LayerNorm output
+    MAT_SYNC();
+    head_out_bwd(W(C_H2_W), 1, S0, sDOutC, S2, G(C_H2_W), G(C_H2_B), tid);
+    MAT_SYNC();
+    tile_ln_bwd(S2, kMHS, kMD, cNH, rstd(4), W(C_HLN_G), S3, G(C_HLN_G), G(C_HLN_B), tid);
+    MAT_SYNC();
+    tile_gelu_bwd(S3, cZH, tid);
+    MAT_SYNC();
+    lin_wgrad(S3, cENC, G(C_H1_W), G(C_H1_B), wave, lane, tid);
+    lin_dgrad<true>(W(C_H1_W), S3, DENC, wave, lane);                                         // total d rep_enc
+    MAT_SYNC();
+    tile_ln_bwd(DENC, kMHS, kMD, cN2, rstd(3), W(C_LN2_G), S4, G(C_LN2_G), G(C_LN2_B), tid);   // d r2 -> S4
+    tile_gelu(cZM, S0, tid);
+    MAT_SYNC();
+    lin_wgrad(S4, S0, G(C_M2_W), G(C_M2_B), wave, lane, tid);
+    lin_dgrad<false>(W(C_M2_W), S4, S3, wave, lane);
+    MAT_SYNC();
+    tile_gelu_bwd(S3, cZM, tid);
+    tile_affine(cN1, W(C_LN1_G), W(C_LN1_B), S0, tid);                                        // H1
+    MAT_SYNC();
+    lin_wgrad(S3, S0, G(C_M1_W), G(C_M1_B), wave, lane, tid);
+    lin_dgrad<true>(W(C_M1_W), S3, S4, wave, lane);                                           // d H1 total
+    MAT_SYNC();
+    tile_ln_bwd(S4, kMHS, kMD, cN1, rstd(2), W(C_LN1_G), S0, G(C_LN1_G), G(C_LN1_B), tid);     // d r1 -> S0
+    MAT_SYNC();
+    lin_wgrad(S0, cY, G(C_P_W), G(C_P_B), wave, lane, tid);
+    lin_dgrad<false>(W(C_P_W), S0, S2, wave, lane);                                           // d Y
+    MAT_SYNC();
+    att_bwd(cQ, cK, cV, sP0, S2, S1, S3, S4, sS, wave, lane);                                 // dQ -> S1, dK -> S3, dV -> S4
+    MAT_SYNC();
+    tile_affine(cN0, W(C_LN_G), W(C_LN_B), S2, tid);                                          // H0
+    MAT_SYNC();
+    lin_wgrad(S1, S2, G(C_Q_W), G(C_Q_B), wave, lane, tid);
+    lin_wgrad(S3, S2, G(C_K_W), G(C_K_B), wave, lane, tid);
+    lin_wgrad(S4, S2, G(C_V_W), G(C_V_B), wave, lane, tid);
+    lin_dgrad<true>(W(C_Q_W), S1, S0, wave, lane);
+    MAT_SYNC();
+    lin_dgrad<true>(W(C_K_W), S3, S0, wave, lane);
+    MAT_SYNC();
+    lin_dgrad<true>(W(C_V_W), S4, S0, wave, lane);                                            // d H0 total
+    MAT_SYNC();
+    tile_ln_bwd(S0, kMHS, kMD, cN0, rstd(1), W(C_LN_G), S1, G(C_LN_G), G(C_LN_B), tid);
+    MAT_SYNC();
+    tile_gelu_bwd(S1, cZ1, tid);
+    MAT_SYNC();
+    layer_wgrad<4, kMNW>(S1, sYO, OS, NT0, O, G(C_ENC_W), O, G(C_ENC_B), wave, lane, tid);
+    narrow_dgrad(W(C_ENC_W), O, S1, S2, kMHS, wave, lane);                                     // d (obs LayerNorm output) in S2[:, :O]
+    MAT_SYNC();
+    // observation LayerNorm: only its affine parameters receive gradient
+    if (tid < 64) {
+        if (tid < O) {
+            float a = 0.f;
+#pragma unroll
+            for (int s = 0; s < kRows; ++s) a = fmaf(S2[s * kMHS + tid], sXO[s * OS + tid], a);
+            G(C_OLN_G)[tid] = a;
+        }
+    } else if (tid < 128) {
+        const int c = tid - 64;
+        if (c < O) {
+            float a = 0.f;
+#pragma unroll
+            for (int s = 0; s < kRows; ++s) a += S2[s * kMHS + c];
+            G(C_OLN_B)[c] = a;
+        }
+    }
+}
+
+// slabs -> gradient bucket in a fixed order; block 0 folds the loss partials and advances the cursor
+constexpr int kMatRedCols = 64, kMatRedRows = 16;
+__global__ __launch_bounds__(kMatRedCols * kMatRedRows) void mat_update_reduce_kernel(MatDev u) {
+    __shared__ float4 tile[kMatRedRows][kMatRedCols];
+    const int c = threadIdx.x & (kMatRedCols - 1), r = threadIdx.x / kMatRedCols;
+    const long n4 = u.total >> 2;
+    const long idx = (long)blockIdx.x * kMatRedCols + c;
+    const float4* sl = reinterpret_cast<const float4*>(u.slabs);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g0 = 0; g0 < u.nT; g0 += kMatRedRows) {
+        const int g = g0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < n4 && g < u.nT) v = sl[(long)g * n4 + idx];
+        tile[r][c] = v;
+        __syncthreads();
+        if (r == 0) {
+#pragma unroll
+            for (int k = 0; k < kMatRedRows; ++k) {
+                const float4 t = tile[k][c];
+                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            }
+        }
+        __syncthreads();
+    }
+    if (r == 0 && idx < n4) reinterpret_cast<float4*>(u.grads)[idx] = acc;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < u.nT; ++g) {
+            const float* a = u.loss_partials + (long)g * 8;
+            p[0] += a[0]; p[2] += a[2]; p[3] += a[3]; p[4] += a[4]; p[7] += a[7];
+        }
+        const float n = (float)(u.B * u.L);
+        const float surr = p[0] / n, ent = p[3] / n, kl = p[4] / n, crit = p[2] / n;
+        float total = surr;
+        if (u.entropy_weight != 0.0f) total -= u.entropy_weight * ent;
+        if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
+        u.totals[0] += (double)surr; u.totals[1] += (double)total; u.totals[2] += (double)crit;
+        u.totals[3] += (double)ent; u.totals[4] += (double)kl;
+        u.totals[5] += (double)u.loss_partials[5]; u.totals[6] += (double)u.loss_partials[6];
+        u.totals[7] += p[7] > 0.f ? 1.0 : 0.0;
+        u.totals[8] += 1.0;
+        u.cursor[0] += 1;
+    }
+}
+
+static size_t mat_lds_bytes(int O) {
+    const size_t OS = 16 * ((O + 15) / 16) + 4;
+    return (256 + 4 * 128 + 4 * 272 + kRows * kMXS + 2 * kRows * OS + 34 * (size_t)kMTile) * 4;
+}
+
+static int make_mat(const ppoaf_mat_update_args_t* a, MatDev& u) {
+    PPOAF_REQUIRE(a, "mat_update: null args");
+    PPOAF_REQUIRE(a->embedding == kMD, "mat_update: embedding=%d (the fused kernel is built for 64)", a->embedding);
+    PPOAF_REQUIRE(a->num_agents >= 1 && a->num_agents <= 16, "mat_update: num_agents=%d out of [1,16]", a->num_agents);
+    PPOAF_REQUIRE(a->obs_dim >= 1 && a->obs_dim <= 64, "mat_update: obs_dim=%d out of [1,64]", a->obs_dim);
+    PPOAF_REQUIRE(a->num_actions >= 1 && a->num_actions <= 8, "mat_update: num_actions=%d out of [1,8]", a->num_actions);
+    PPOAF_REQUIRE(a->B >= 1 && a->batch_stride >= a->B, "mat_update: B=%ld stride=%ld", (long)a->B, (long)a->batch_stride);
+    PPOAF_REQUIRE(a->params && a->grads && a->slabs && a->critic_obs && a->raw_actions && a->advantages &&
+                      a->old_log_probs && a->rewards_to_go && a->values && a->perm && a->cursor && a->vn_mean &&
+                      a->vn_var && a->vn_count && a->loss_partials && a->totals,
+                  "mat_update: null pointer");
+    PPOAF_REQUIRE(!a->normalize_values || (a->vn_records && a->n_ranks >= 1), "mat_update: vn_records missing");
+    PPOAF_REQUIRE(!a->normalize_adv || a->adv_records, "mat_update: adv_records missing");
+    PPOAF_REQUIRE(a->bucket_total % 4 == 0 && ((uintptr_t)a->params & 15) == 0 && ((uintptr_t)a->grads & 15) == 0 &&
+                      ((uintptr_t)a->slabs & 15) == 0, "mat_update: buckets must be 16-byte aligned");
+    // the offset table must describe MATActorCritic's module order with every tensor padded to 4 floats
+    const long D = kMD, O = a->obs_dim, NA = a->num_actions, Ain = NA + 1;
+    auto pad4 = [](long x) { return (x + 3) / 4 * 4; };
+    long want[MAT_NUM_PARAMS];
+    {
+        long sizes[MAT_NUM_PARAMS];
+        int k = 0;
+        sizes[k++] = D * Ain;
+        for (int i = 0; i < 8; ++i) sizes[k++] = D;                       // a.ln, ln1, ln2, ln3 (g, b)
+        for (int i = 0; i < 8; ++i) { sizes[k++] = D * D; sizes[k++] = D; }   // attn1 k,q,v,proj; attn2 k,q,v,proj
+        for (int i = 0; i < 2; ++i) { sizes[k++] = D * D; sizes[k++] = D; }   // mlp.0, mlp.2
+        sizes[k++] = D * D; sizes[k++] = D; sizes[k++] = D; sizes[k++] = D; sizes[k++] = NA * D; sizes[k++] = NA;   // head
+        sizes[k++] = O; sizes[k++] = O; sizes[k++] = D * O; sizes[k++] = D;   // obs_encoder
+        for (int i = 0; i < 6; ++i) sizes[k++] = D;                       // c.ln, ln1, ln2
+        for (int i = 0; i < 4; ++i) { sizes[k++] = D * D; sizes[k++] = D; }   // attn k,q,v,proj
+        for (int i = 0; i < 2; ++i) { sizes[k++] = D * D; sizes[k++] = D; }   // mlp
+        sizes[k++] = D * D; sizes[k++] = D; sizes[k++] = D; sizes[k++] = D; sizes[k++] = D; sizes[k++] = 1;         // head
+        PPOAF_REQUIRE(k == MAT_NUM_PARAMS, "mat_update: internal size table (%d)", k);
+        long off = 0;
+        for (int i = 0; i < MAT_NUM_PARAMS; ++i) { want[i] = off; off += pad4(sizes[i]); }
+        PPOAF_REQUIRE(off == a->bucket_total, "mat_update: bucket_total=%ld, the topology needs %ld", (long)a->bucket_total, off);
+    }
+    for (int i = 0; i < MAT_NUM_PARAMS; ++i) {
+        PPOAF_REQUIRE(a->offsets[i] == want[i], "mat_update: parameter %d sits at %ld, expected %ld", i,
+                      (long)a->offsets[i], want[i]);
+        u.off[i] = a->offsets[i];
+    }
+    u.off[63] = 0;
+    u.O = a->obs_dim; u.L = a->num_agents; u.NA = a->num_actions; u.Ain = (int)Ain;
+    u.per_tile = 16 / u.L;
+    u.nT = (int)((a->B + u.per_tile - 1) / u.per_tile);
+    u.total = a->bucket_total;
+    u.params = a->params; u.grads = a->grads; u.slabs = a->slabs;
+    u.obs = a->critic_obs; u.actions = a->raw_actions; u.adv = a->advantages; u.old_lp = a->old_log_probs;
+    u.rtg = a->rewards_to_go; u.values = a->values; u.perm = a->perm; u.row_map = a->row_map; u.n_rows = a->n_rows;
+    u.cursor = a->cursor; u.B = a->B; u.batch_stride = a->batch_stride;
+    u.normalize_values = a->normalize_values; u.n_ranks = a->n_ranks; u.normalize_adv = a->normalize_adv;
+    u.use_huber = a->use_huber; u.vn_mean = a->vn_mean; u.vn_var = a->vn_var; u.vn_count = a->vn_count;
+    u.vn_records = a->vn_records; u.adv_records = a->adv_records;
+    u.surr_clip = a->surr_clip; u.entropy_weight = a->entropy_weight; u.kl_loss_weight = a->kl_loss_weight;
+    u.huber_delta = a->huber_delta; u.loss_partials = a->loss_partials; u.totals = a->totals;
+    return PPOAF_OK;
+}
+
+}  // namespace ppoaf
+
+using namespace ppoaf;
+
+extern "C" int ppoaf_mat_update_fwd_bwd(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream) {
+    MatDev u;
+    const int rc = make_mat(args, u);
+    if (rc) return rc;
+    const size_t lds = mat_lds_bytes(u.O);
+    PPOAF_REQUIRE(lds <= 160 * 1024, "mat_update: needs %zu B of LDS (> 160 KiB)", lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mat_update_fwd_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mat_update_fwd_bwd_kernel, dim3((unsigned)u.nT), dim3(kMT), lds, (hipStream_t)stream, u);
+    return check_launch("mat_update_fwd_bwd");
+}
+
+extern "C" int ppoaf_mat_update_reduce(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream) {
+    MatDev u;
+    const int rc = make_mat(args, u);
+    if (rc) return rc;
+    const long n4 = u.total >> 2;
+    hipLaunchKernelGGL(mat_update_reduce_kernel, dim3((unsigned)((n4 + kMatRedCols - 1) / kMatRedCols)),
+                       dim3(kMatRedCols * kMatRedRows), 0, (hipStream_t)stream, u);
+    return check_launch("mat_update_reduce");
+}

@@ -134,6 +134,84 @@ __device__ __forceinline__ void wgrad_mtile(const float* __restrict__ D, int HS,
 constexpr int kNW = 8;                    // waves per workgroup of the fused update kernels
 constexpr int kThreadsU = 64 * kNW;
 
+// ---- fragment loads with an explicit row stride (W row-major [*, ldw], columns [0, 16*HT) of W) ----
+template <int HT, bool ALIGNED>
+__device__ __forceinline__ void load_fwd_frags_ld(const float* __restrict__ W, long ldw, int n0, int lane,
+                                                  float4 (&fr)[HT]) {
+    const float* w = W + (long)(n0 + (lane & 15)) * ldw + 4 * (lane >> 4);
+#pragma unroll
+    for (int c = 0; c < HT; ++c) {
+        if (ALIGNED) fr[c] = *reinterpret_cast<const float4*>(w + 16 * c);
+        else fr[c] = make_float4(w[16 * c], w[16 * c + 1], w[16 * c + 2], w[16 * c + 3]);
+    }
+}
+template <int HT>
+__device__ __forceinline__ void load_dgrad_frags_ld(const float* __restrict__ W, long ldw, int n0, int lane,
+                                                    float4 (&fr)[HT]) {
+    const float* w = W + (long)(4 * (lane >> 4)) * ldw + n0 + (lane & 15);
+#pragma unroll
+    for (int c = 0; c < HT; ++c) {
+        const float* wp = w + (long)(16 * c) * ldw;
+        fr[c] = make_float4(wp[0], wp[ldw], wp[2 * ldw], wp[3 * ldw]);
+    }
+}
+
+// out[s][o] = f(bias[o] + sum_k A[s][k] W[o][k]) for the H outputs; act < 0: linear
+template <int HT, bool ALIGNED, int NW = 8>
+__device__ __forceinline__ void layer_fwd(const float* __restrict__ W, long ldw, const float* __restrict__ bias,
+                                          const float* __restrict__ A, float* __restrict__ out, int act,
+                                          int wave, int lane) {
+    constexpr int HS = 16 * HT + 4;
+    for (int nt = wave; nt < HT; nt += NW) {
+        float4 fr[HT];
+        load_fwd_frags_ld<HT, ALIGNED>(W, ldw, nt * 16, lane, fr);
+        const int o = nt * 16 + (lane & 15);
+        const f32x4 acc = mfma_rows_x_frags<HT>(A, HS, lane, fr, bias[o]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(4 * (lane >> 4) + r) * HS + o] = act >= 0 ? act_fwd(acc[r], act) : acc[r];
+    }
+}
+
+// dh[s][i] = (sum_o D[s][o] W[o][i]) * act'(Hin[s][i]) for the H columns [0, H) of W (offset the pointer
+// for other column blocks); result to LDS (dst_lds) or to global rows (dst_glob, row stride H).
+template <int HT, int NW = 8>
+__device__ __forceinline__ void layer_dgrad(const float* __restrict__ W, long ldw, const float* __restrict__ D,
+                                            const float* __restrict__ Hin, int act, float* __restrict__ dst_lds,
+                                            float* __restrict__ dst_glob, int wave, int lane) {
+    constexpr int H = 16 * HT, HS = H + 4;
+    for (int nt = wave; nt < HT; nt += NW) {
+        float4 fr[HT];
+        load_dgrad_frags_ld<HT>(W, ldw, nt * 16, lane, fr);
+        const f32x4 acc = mfma_rows_x_frags<HT>(D, HS, lane, fr, 0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = 4 * (lane >> 4) + r, i = nt * 16 + (lane & 15);
+            float v = acc[r];
+            if (Hin) v *= act_bwd(Hin[s * HS + i], act);
+            if (dst_lds) dst_lds[s * HS + i] = v;
+            else dst_glob[(long)s * H + i] = v;
+        }
+    }
+}
+
+// dW[o][i] = sum_s D[s][o] Bsrc[s][i] (i < n_valid) and, when dstB, db[o] = sum_s D[s][o]
+template <int HT, int NW = 8>
+__device__ __forceinline__ void layer_wgrad(const float* __restrict__ D, const float* __restrict__ Bsrc,
+                                            int strideB, int ntiles, int n_valid, float* __restrict__ dstW,
+                                            int ldw, float* __restrict__ dstB, int wave, int lane, int tid) {
+    constexpr int H = 16 * HT, HS = H + 4;
+    for (int mt = wave; mt < HT; mt += NW)
+        wgrad_mtile(D, HS, Bsrc, strideB, mt * 16, ntiles, n_valid, lane, dstW, ldw);
+    if (dstB) {
+        for (int o = tid; o < H; o += 64 * NW) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < kRows; ++s) acc += D[s * HS + o];
+            dstB[o] = acc;
+        }
+    }
+}
+
 // host: validate a network descriptor and fill the device view
 int fill_net(const ppoaf_mlp_desc_t& d, NetDev& n, const char* what);
 

@@ -468,3 +468,174 @@ class FusedIcmUpdate:
         if self.multi:
             mpi_utils.allreduce_sum_(t)
         return t.cpu().numpy()
+
+
+# ======================================================================================
+# K15: fused multi-agent-transformer update
+# ======================================================================================
+_MAT_PARAM_NAMES = (
+    ["actor.action_encoder.0.weight", "actor.ln.weight", "actor.ln.bias"]
+    + [f"actor.blocks.0.ln{i}.{p}" for i in (1, 2, 3) for p in ("weight", "bias")]
+    + [f"actor.blocks.0.attn{i}.{n}.{p}" for i in (1, 2) for n in ("key_net", "query_net", "value_net", "proj")
+       for p in ("weight", "bias")]
+    + [f"actor.blocks.0.mlp.{i}.{p}" for i in (0, 2) for p in ("weight", "bias")]
+    + [f"actor.head.{i}.{p}" for i in (0, 2, 3) for p in ("weight", "bias")]
+    + [f"critic.obs_encoder.{i}.{p}" for i in (0, 1) for p in ("weight", "bias")]
+    + ["critic.ln.weight", "critic.ln.bias"]
+    + [f"critic.blocks.0.ln{i}.{p}" for i in (1, 2) for p in ("weight", "bias")]
+    + [f"critic.blocks.0.attn.{n}.{p}" for n in ("key_net", "query_net", "value_net", "proj") for p in ("weight", "bias")]
+    + [f"critic.blocks.0.mlp.{i}.{p}" for i in (0, 2) for p in ("weight", "bias")]
+    + [f"critic.head.{i}.{p}" for i in (0, 2, 3) for p in ("weight", "bias")])
+
+
+def _describe_mat(pol):
+    """Topology + offset table of a MATPolicy's actor_critic for K15, or (None, reason)."""
+    from .networks.multi_agent_transformer import MATActorCritic
+    ac = getattr(pol, "actor_critic", None)
+    if not isinstance(ac, MATActorCritic):
+        return None, "not a MATActorCritic"
+    if pol.action_dtype != "discrete":
+        return None, "the fused MAT update covers Discrete actions"
+    D = ac.actor.embedding_size
+    if D != 64 or ac.critic.embedding_size != 64:
+        return None, f"embedding {D} (the fused kernel is built for 64)"
+    if len(ac.actor.blocks) != 1 or len(ac.critic.blocks) != 1:
+        return None, "more than one block"
+    atts = [ac.actor.blocks[0].attn1, ac.actor.blocks[0].attn2, ac.critic.blocks[0].attn]
+    if any(a.num_heads != 1 for a in atts):
+        return None, "more than one attention head"
+    gelus = [m for m in ac.modules() if isinstance(m, nn.GELU)]
+    others = [m for m in ac.modules() if isinstance(m, (nn.ReLU, nn.Tanh, nn.LeakyReLU, nn.Sigmoid, nn.ELU))]
+    if others or any(getattr(m, "approximate", "none") != "none" for m in gelus):
+        return None, "activations other than exact GELU"
+    named = list(ac.named_parameters())
+    if [n for n, _ in named] != _MAT_PARAM_NAMES:
+        return None, "parameter list differs from the default MATActorCritic"
+    NA, O, A = ac.actor.action_pred_size, ac.critic.in_size, ac.actor.num_agents
+    if not (1 <= NA <= 8 and 1 <= O <= 32 and 1 <= A <= 16):
+        return None, f"sizes (actions {NA}, obs {O}, agents {A}) outside the fused kernel's limits (8, 32, 16)"
+    if ac.actor.action_encoder[0].in_features != NA + 1 or ac.actor.action_encoder[0].bias is not None:
+        return None, "action encoder is not the Discrete (start token + one-hot, no bias) form"
+    base = ac.flat_params.data_ptr()
+    offs, off = [], 0
+    for _, p in named:
+        if (p.data_ptr() - base) // 4 != off:
+            return None, "parameter layout differs from the kernel's table"
+        offs.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    if off != ac.flat_params.numel():
+        return None, "bucket holds parameters the fused kernel does not know about"
+    return dict(obs_dim=O, num_agents=A, num_actions=NA, embedding=64, offsets=offs, bucket_total=off), ""
+
+
+class FusedMatUpdate(FusedPolicyUpdate):
+    """
+    Host driver of K15 (csrc/mat_update.hip).  Same epoch protocol as FusedPolicyUpdate: records of
+    every mini-batch up front, then per mini-batch fwd_bwd -> reduce -> [all-reduce] -> K11 clip + Adam,
+    `graph_chunk` mini-batches per hipGraph on a single rank.
+    """
+
+    @staticmethod
+    def unsupported_reason(pol, batch_size):
+        if not pol.agent_grouping:
+            return "not an agent-grouped policy"
+        _, why = _describe_mat(pol)
+        if not why and batch_size < 2:
+            return "batch size < 2"
+        return why
+
+    def __init__(self, ppo, policy_id):
+        self.ppo, self.policy_id = ppo, policy_id
+        pol = self.pol = ppo.policies[policy_id]
+        dev = pol.device
+        self.topo, _ = _describe_mat(pol)
+        self.world = mpi_utils.get_num_procs()
+        self.multi = mpi_utils.distributed_path()
+        self.B = ppo.batch_size
+        self.per_tile = 16 // self.topo["num_agents"]
+        self.n_wg = (self.B + self.per_tile - 1) // self.per_tile
+        total = self.topo["bucket_total"]
+        self.slabs = torch.zeros(self.n_wg, total, dtype=torch.float32, device=dev)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.vn_mean = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.vn_var = torch.ones(2, dtype=torch.float32, device=dev)
+        self.vn_count = torch.full((2,), 1e-4, dtype=torch.float64, device=dev)
+        self.loss_partials = torch.zeros(self.n_wg, 8, dtype=torch.float32, device=dev)
+        self.totals = torch.zeros(9, dtype=torch.float64, device=dev)
+        self._lib = _lib.load()
+        self.records = self.adv_records = self.perm = None
+        self._graphs, self._args = {}, {}
+
+    def _make_args(self, B):
+        pol, ppo, buf = self.pol, self.ppo, self.pol.buffer
+        a = _lib.MatUpdateArgs()
+        t = self.topo
+        a.obs_dim, a.num_agents, a.num_actions, a.embedding = t["obs_dim"], t["num_agents"], t["num_actions"], 64
+        for i, o in enumerate(t["offsets"]):
+            a.offsets[i] = o
+        a.bucket_total = t["bucket_total"]
+        ac = pol.actor_critic
+        a.params, a.grads, a.slabs = ac.flat_params.data_ptr(), ac.flat_grads.data_ptr(), self.slabs.data_ptr()
+        a.critic_obs, a.raw_actions = buf.critic_observations.data_ptr(), buf.raw_actions.data_ptr()
+        a.advantages, a.old_log_probs = buf.advantages.data_ptr(), buf.log_probs.data_ptr()
+        a.rewards_to_go, a.values = buf.rewards_to_go.data_ptr(), buf.values.data_ptr()
+        a.perm, a.row_map, a.n_rows = self.perm.data_ptr(), buf.row_map.data_ptr(), buf.num_transitions
+        a.cursor, a.B, a.batch_stride = self.cursor.data_ptr(), B, self.B
+        a.normalize_values, a.n_ranks = int(bool(ppo.normalize_values)), self.world
+        a.normalize_adv, a.use_huber = int(bool(ppo.normalize_adv)), int(bool(pol.use_huber_loss))
+        a.vn_mean, a.vn_var, a.vn_count = self.vn_mean.data_ptr(), self.vn_var.data_ptr(), self.vn_count.data_ptr()
+        a.vn_records = self.records.data_ptr() if self.records is not None else None
+        a.adv_records = self.adv_records.data_ptr() if self.adv_records is not None else None
+        a.surr_clip, a.entropy_weight = float(pol.surr_clip), float(pol.entropy_weight())
+        a.kl_loss_weight, a.huber_delta = float(pol.kl_loss_weight), 10.0
+        a.loss_partials, a.totals = self.loss_partials.data_ptr(), self.totals.data_ptr()
+        return a
+
+    def begin_epoch(self, perm):
+        pol, ppo, buf = self.pol, self.ppo, self.pol.buffer
+        ds = pol.dataset
+        N = perm.numel()
+        if self.perm is None or self.perm.numel() != N:
+            self.perm = torch.empty(N, dtype=torch.int64, device=pol.device)
+            self._graphs.clear()
+        self.perm.copy_(perm)
+        nb = (N + self.B - 1) // self.B
+
+        def keep(name, rec):
+            cur = getattr(self, name)
+            if cur is None or cur.shape != rec.shape:
+                setattr(self, name, torch.empty_like(rec))
+                self._graphs.clear()
+            getattr(self, name).copy_(rec)
+
+        if ppo.normalize_values:
+            rec = ppo._epoch_records(self.policy_id, ds, self.perm, self.B)             # [R, nb, 3]
+            keep("records", rec.permute(1, 0, 2).contiguous())
+            rs = ppo.value_normalizers[self.policy_id].running_stats
+            self.vn_mean[0:1].copy_(rs.mean_t); self.vn_var[0:1].copy_(rs.var_t); self.vn_count[0:1].copy_(rs.count_t)
+        if ppo.normalize_adv:
+            keep("adv_records", ppo._epoch_records(self.policy_id, ds, self.perm, self.B, field="advantages",
+                                                   gather=False)[0].contiguous())
+        self.cursor.zero_()
+        self.totals.zero_()
+        sig = (buf.critic_observations.data_ptr(), buf.num_transitions, self.perm.data_ptr(),
+               None if self.records is None else self.records.data_ptr(),
+               None if self.adv_records is None else self.adv_records.data_ptr(),
+               float(pol.entropy_weight()), float(pol.surr_clip), float(pol.kl_loss_weight),
+               bool(pol.use_huber_loss), pol.gradient_clip, bool(ppo.normalize_adv), bool(ppo.normalize_values))
+        if self._args.get("sig") != sig:
+            self._args = {"sig": sig}
+            self._graphs.clear()
+        self.n_full, self.tail = N // self.B, N % self.B
+        self.n_done = 0
+
+    def _one(self, args):
+        lib, st, ref = self._lib, K.stream(), C.byref(args)
+        rc = lib.ppoaf_mat_update_fwd_bwd(ref, st)
+        if rc == 0:
+            rc = lib.ppoaf_mat_update_reduce(ref, st)
+        if rc != 0:
+            _lib.check(rc, "mat_update")
+        if self.multi:
+            mpi_utils.allreduce_sum_(self.pol.policy_grads)
+        self.pol.optimizer_step(1.0 / self.world)

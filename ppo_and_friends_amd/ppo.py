@@ -709,7 +709,9 @@ class PPO:
             return None
         key = (policy_id, B)
         if key not in self._fused:
-            from .fused_update import FusedPolicyUpdate
+            from .fused_update import FusedMatUpdate, FusedPolicyUpdate
+            if self.policies[policy_id].agent_grouping:
+                FusedPolicyUpdate = FusedMatUpdate                      # K15 instead of K12
             why = FusedPolicyUpdate.unsupported_reason(self.policies[policy_id], B)
             if why:
                 if self.update_mode == "fused":
@@ -741,7 +743,7 @@ class PPO:
             self._graphs[key] = torch.zeros(n, dtype=dtype, device=self.device)
         return self._graphs[key]
 
-    def _epoch_records(self, policy_id, ds, perm, B):
+    def _epoch_records(self, policy_id, ds, perm, B, field="rewards_to_go", gather=True):
         """
         (n, mean, M2) of the rewards-to-go of EVERY mini-batch of the epoch,
         all-gathered across ranks once: [R, n_batches, 3].  The reference gathers
@@ -749,7 +751,7 @@ class PPO:
         """
         N = perm.numel()
         A = ds.buffer.A                      # grouped rows carry A values each: a mini-batch holds B*A of them
-        rtg = ds.buffer.rewards_to_go.view(ds.buffer.num_transitions, A)[ds.row_map.long()[ds.last_positions(perm)]].reshape(-1)
+        rtg = getattr(ds.buffer, field).view(ds.buffer.num_transitions, A)[ds.row_map.long()[ds.last_positions(perm)]].reshape(-1)
         N, B = N * A, B * A
         nb = (N + B - 1) // B
         pad = nb * B - N
@@ -767,7 +769,7 @@ class PPO:
         m2 = (((x - mean[:, None]) ** 2) * mask).sum(1)
         rec = torch.stack([cnt, mean, m2], dim=1)                     # [nb, 3]
         world = mpi_utils.get_num_procs()
-        if not mpi_utils.distributed_path():
+        if not gather or not mpi_utils.distributed_path():
             return rec.unsqueeze(0)
         out = mpi_utils.allgather_records(rec.reshape(-1))
         return out.view(world, nb, 3)

@@ -318,8 +318,11 @@ def test_icm_rollout_rewards_and_training_match_cpu_port(update_mode):
     np.testing.assert_allclose(w, w_ref, rtol=1e-4, atol=2e-5)
 
 
-def test_mat_policy_rollout_and_update_match_cpu_port():
+@pytest.mark.parametrize("update_mode,B", [("fused", 32), ("torch", 32), ("fused", 20)])
+def test_mat_policy_rollout_and_update_match_cpu_port(update_mode, B):
     """
+    Both update paths (K15 fused kernel; torch-ROCm modules + K9) -- B = 20 leaves a tail mini-batch and
+    a partly filled 16-row tile.
     SURVEY.md §8 C5 shape: MATPolicy (3 agents, embedding 64, 1 block, 1 head, Discrete(5), critic view
     'local').  Autoregressive rollout, shared-episode dataset ([N, A, .] rows), teacher-forced evaluation,
     one optimiser over actor + critic, Huber value loss -- against oracle/mat_oracle.CpuMATPPO.
@@ -330,13 +333,14 @@ def test_mat_policy_rollout_and_update_match_cpu_port():
     from ppo_and_friends_amd.spaces import Box, Discrete
     from oracle import mat_oracle
     dev = torch.device("cuda", 0)
-    A, E, T, O, NA, B, seed = 3, 8, 12, 18, 5, 32, 6
+    A, E, T, O, NA, seed = 3, 8, 12, 18, 5, 6
     env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=41, num_agents=A)
     sp = Box(-np.inf, np.inf, (O,), np.float32)
     ppo = PPO(env_gen, {"mat": (MATPolicy, sp, sp, Discrete(NA), {})}, device=dev, random_seed=seed, normalize_obs=False, normalize_rewards=False,
-              envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=2)
+              envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=2, update_mode=update_mode)
     pol = ppo.policies["mat"]
     assert pol.agent_grouping and sum(p.numel() for p in pol.actor_critic.parameters()) == 78058
+    assert (ppo._fused_updater("mat", B) is not None) == (update_mode == "fused")
     cpu = mat_oracle.CpuMATPPO(O, NA, A, batch_size=B, seed=seed)
     cpu.ac.load_state_dict({k: v.detach().cpu().clone() for k, v in pol.actor_critic.state_dict().items()},
                            strict=False)
