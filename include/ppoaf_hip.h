@@ -575,6 +575,30 @@ typedef struct {
 int ppoaf_mat_update_fwd_bwd(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream);
 int ppoaf_mat_update_reduce(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream);
 
+/* ------------------------------------------------------------------------ *
+ * K16  one rollout step of a MATPolicy for all E envs of the rank in one launch
+ * replaces MATPolicy.get_rollout_actions / _get_autoregressive_actions  policies/mat_policy.py:441-519,587-626
+ *          MATPolicy.get_critic_values + denormalisation               mat_policy.py:660-675, utils/misc.py:124-128
+ *          the per-env add_info calls                                   policies/ppo_policy.py:638-651
+ * critic_obs: [E, A, obs_dim] (agents of an env side by side, in the policy's slot order); the
+ * encoder runs once, the decoder A times (agent i's sampled action is agent i+1's token).
+ * Outputs are the step's row of the rollout buffer: actions int64 [E, A], log-probs and
+ * (denormalised) values [E, A]; *_copy_out receive the observation rows (actor_obs [E, A,
+ * actor_obs_dim], or critic_obs again when NULL).  offsets / limits as K15.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t obs_dim, num_agents, num_actions, embedding, actor_obs_dim, normalize_values;
+    int64_t offsets[64];
+    const float* params;
+    const float* critic_obs; const float* actor_obs; int64_t E;
+    uint64_t seed, offset;
+    const float* vn_mean; const float* vn_var;
+    int64_t* action_out; int64_t* raw_action_out; float* logp_out; float* value_out;
+    float* critic_obs_copy_out; float* obs_copy_out;
+} ppoaf_mat_step_args_t;
+
+int ppoaf_mat_policy_step(const ppoaf_mat_step_args_t* args, ppoaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

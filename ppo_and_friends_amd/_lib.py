@@ -108,6 +108,18 @@ class MatUpdateArgs(C.Structure):
                 ("loss_partials", C.c_void_p), ("totals", C.c_void_p)]
 
 
+class MatStepArgs(C.Structure):
+    """ppoaf_mat_step_args_t (include/ppoaf_hip.h)."""
+    _fields_ = [("obs_dim", C.c_int32), ("num_agents", C.c_int32), ("num_actions", C.c_int32), ("embedding", C.c_int32),
+                ("actor_obs_dim", C.c_int32), ("normalize_values", C.c_int32),
+                ("offsets", C.c_int64 * 64), ("params", C.c_void_p),
+                ("critic_obs", C.c_void_p), ("actor_obs", C.c_void_p), ("E", C.c_int64),
+                ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("vn_mean", C.c_void_p), ("vn_var", C.c_void_p),
+                ("action_out", C.c_void_p), ("raw_action_out", C.c_void_p), ("logp_out", C.c_void_p),
+                ("value_out", C.c_void_p), ("critic_obs_copy_out", C.c_void_p), ("obs_copy_out", C.c_void_p)]
+
+
 class ObsFilter(C.Structure):
     """ppoaf_obs_filter_t (include/ppoaf_hip.h)."""
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("mean", C.c_void_p), ("var", C.c_void_p),
@@ -178,6 +190,7 @@ SIGNATURES = {
     "ppoaf_icm_update_reduce": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
     "ppoaf_mat_update_fwd_bwd": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
     "ppoaf_mat_update_reduce": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
+    "ppoaf_mat_policy_step": (C.c_int, [C.POINTER(MatStepArgs), _ptr]),
     "ppoaf_env_filter_moments": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),
                                            C.c_int32, C.c_int64, _ptr, _ptr]),
     "ppoaf_env_filter_apply": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),

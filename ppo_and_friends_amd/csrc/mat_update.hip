@@ -342,49 +342,180 @@ __device__ __forceinline__ void head_out_bwd(const float* __restrict__ W, int n_
 
 #define MAT_SYNC() __syncthreads()
 
+// LDS carve shared by the update kernel (K15) and the rollout step kernel (K16)
+struct MatCtx {
+    const float* P; const long* off;
+    int O, L, NA, Ain, OS, n_rows;
+    int* sRow; int* sAct; float* sMisc; float* sRowF; float* sRstd;
+    float *sOutC, *sOutA, *sDOutC, *sDOutA, *sP0, *sP1, *sP2, *sS, *sXA, *sXO, *sYO, *T;
+    __device__ __forceinline__ float* tile(int k) const { return T + (long)k * kMTile; }
+    __device__ __forceinline__ float* rstd(int k) const { return sRstd + 16 * k; }
+    __device__ __forceinline__ const float* W(int k) const { return P + off[k]; }
+    __device__ __forceinline__ void carve(float* sm, int O_) {
+        O = O_; OS = 16 * ((O_ + 15) >> 4) + 4;
+        sRow = reinterpret_cast<int*>(sm);                 // [16] buffer row of the token's env (-1: padding)
+        sAct = reinterpret_cast<int*>(sm) + 16;            // [16] action of the token
+        sMisc = sm + 32;                                   // [8] adv mean/std, vn mean/var
+        sRowF = sm + 48;                                   // [3][16] adv, old log-prob, rewards-to-go
+        sRstd = sm + 96;                                   // [10][16]
+        sOutC = sm + 256;                                  // [16][8] critic output (col 0)
+        sOutA = sOutC + 128;                               // [16][8] logits
+        sDOutC = sOutA + 128;
+        sDOutA = sDOutC + 128;
+        sP0 = sDOutA + 128;                                // 3 probability tiles + 1 dS scratch, [16][17] each
+        sP1 = sP0 + 272;
+        sP2 = sP1 + 272;
+        sS = sP2 + 272;
+        sXA = sS + 272;                                    // [16][kMXS] action tokens
+        sXO = sXA + kRows * kMXS;                          // [16][OS] xhat of the observation LayerNorm
+        sYO = sXO + kRows * OS;                            // [16][OS] its output (input of the encoder linear)
+        T = sYO + kRows * OS;                              // [16][68] tiles from here on
+    }
+};
+// tile indices: saved activations of the critic (0-11) and the actor (12-27), scratch (28-33)
+enum { cZ1_ = 0, cN0_, cQ_, cK_, cV_, cY_, cN1_, cZM_, cN2_, cENC_, cZH_, cNH_,
+       aZ_, aN0_, aQ1_, aK1_, aV1_, aY1_, aN1_, aK2_, aV2_, aQ2_, aY2_, aN2_, aZM_, aN3_, aZH_, aNH_,
+       S0_, S1_, S2_, S3_, S4_, DENC_, MAT_NUM_TILES };
+
+#define MAT_TILES(c)                                                                                              \
+    float *cZ1 = c.tile(cZ1_), *cN0 = c.tile(cN0_), *cQ = c.tile(cQ_), *cK = c.tile(cK_), *cV = c.tile(cV_),       \
+          *cY = c.tile(cY_), *cN1 = c.tile(cN1_), *cZM = c.tile(cZM_), *cN2 = c.tile(cN2_), *cENC = c.tile(cENC_), \
+          *cZH = c.tile(cZH_), *cNH = c.tile(cNH_);                                                               \
+    float *aZ = c.tile(aZ_), *aN0 = c.tile(aN0_), *aQ1 = c.tile(aQ1_), *aK1 = c.tile(aK1_), *aV1 = c.tile(aV1_),   \
+          *aY1 = c.tile(aY1_), *aN1 = c.tile(aN1_), *aK2 = c.tile(aK2_), *aV2 = c.tile(aV2_), *aQ2 = c.tile(aQ2_), \
+          *aY2 = c.tile(aY2_), *aN2 = c.tile(aN2_), *aZM = c.tile(aZM_), *aN3 = c.tile(aN3_), *aZH = c.tile(aZH_), \
+          *aNH = c.tile(aNH_);                                                                                    \
+    float *S0 = c.tile(S0_), *S1 = c.tile(S1_), *S2 = c.tile(S2_), *S3 = c.tile(S3_), *S4 = c.tile(S4_),           \
+          *DENC = c.tile(DENC_);                                                                                  \
+    (void)cZ1; (void)cN0; (void)cQ; (void)cK; (void)cV; (void)cY; (void)cN1; (void)cZM; (void)cN2; (void)cENC;     \
+    (void)cZH; (void)cNH; (void)aZ; (void)aN0; (void)aQ1; (void)aK1; (void)aV1; (void)aY1; (void)aN1; (void)aK2;   \
+    (void)aV2; (void)aQ2; (void)aY2; (void)aN2; (void)aZM; (void)aN3; (void)aZH; (void)aNH; (void)S0; (void)S1;   \
+    (void)S2; (void)S3; (void)S4; (void)DENC;                                                                     \
+    float *sXA = c.sXA, *sXO = c.sXO, *sYO = c.sYO, *sP0 = c.sP0, *sP1 = c.sP1, *sP2 = c.sP2, *sS = c.sS,          \
+          *sOutC = c.sOutC, *sOutA = c.sOutA;                                                                     \
+    (void)sXA; (void)sXO; (void)sYO; (void)sP0; (void)sP1; (void)sP2; (void)sS; (void)sOutC; (void)sOutA;          \
+    const int O = c.O, L = c.L, NA = c.NA, Ain = c.Ain, OS = c.OS, n_rows = c.n_rows;                              \
+    (void)O; (void)L; (void)NA; (void)Ain; (void)OS; (void)n_rows;                                                \
+    auto W = [&](int k) -> const float* { return c.W(k); };                                                       \
+    auto rstd = [&](int k) -> float* { return c.rstd(k); }
+
+// critic (encoder): observations in sYO -> rep_enc in cENC, value in sOutC[:, 0]; ends WITHOUT a barrier
+__device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, int wave, int lane) {
+    MAT_TILES(c);
+    tile_ln_fwd(sYO, OS, O, W(C_OLN_G), W(C_OLN_B), sXO, rstd(0), sYO, tid);                 // obs_encoder.0
+    MAT_SYNC();
+    narrow_fwd(W(C_ENC_W), O, W(C_ENC_B), sYO, OS, cZ1, wave, lane);                          // obs_encoder.1
+    MAT_SYNC();
+    tile_gelu(cZ1, S0, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S0, kMHS, kMD, W(C_LN_G), W(C_LN_B), cN0, rstd(1), S1, tid);                  // critic.ln -> H0 in S1
+    MAT_SYNC();
+    lin_fwd(W(C_Q_W), W(C_Q_B), S1, cQ, wave, lane);
+    lin_fwd(W(C_K_W), W(C_K_B), S1, cK, wave, lane);
+    lin_fwd(W(C_V_W), W(C_V_B), S1, cV, wave, lane);
+    MAT_SYNC();
+    att_fwd(cQ, cK, cV, cY, sP0, L, n_rows, false, wave, lane);
+    MAT_SYNC();
+    lin_fwd(W(C_P_W), W(C_P_B), cY, S2, wave, lane);
+    MAT_SYNC();
+    tile_add(S1, S2, S2, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S2, kMHS, kMD, W(C_LN1_G), W(C_LN1_B), cN1, rstd(2), S0, tid);                // H1 in S0
+    MAT_SYNC();
+    lin_fwd(W(C_M1_W), W(C_M1_B), S0, cZM, wave, lane);
+    MAT_SYNC();
+    tile_gelu(cZM, S2, tid);
+    MAT_SYNC();
+    lin_fwd(W(C_M2_W), W(C_M2_B), S2, S3, wave, lane);
+    MAT_SYNC();
+    tile_add(S0, S3, S3, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S3, kMHS, kMD, W(C_LN2_G), W(C_LN2_B), cN2, rstd(3), cENC, tid);              // rep_enc
+    MAT_SYNC();
+    lin_fwd(W(C_H1_W), W(C_H1_B), cENC, cZH, wave, lane);
+    MAT_SYNC();
+    tile_gelu(cZH, S0, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S0, kMHS, kMD, W(C_HLN_G), W(C_HLN_B), cNH, rstd(4), S1, tid);
+    MAT_SYNC();
+    head_out_fwd(W(C_H2_W), W(C_H2_B), 1, S1, sOutC, tid);
+
+}
+
+// actor (decoder): token block in sXA + rep_enc in cENC -> logits in sOutA; starts and ends with the tiles settled
+__device__ __forceinline__ void mat_decoder_forward(const MatCtx& c, int tid, int wave, int lane) {
+    MAT_TILES(c);
+    narrow_fwd(W(A_ENC_W), Ain, nullptr, sXA, kMXS, aZ, wave, lane);                          // action_encoder.0 (no bias)
+    MAT_SYNC();
+    tile_gelu(aZ, S0, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S0, kMHS, kMD, W(A_LN_G), W(A_LN_B), aN0, rstd(5), S1, tid);                  // x0 in S1
+    MAT_SYNC();
+    lin_fwd(W(A_K1_W), W(A_K1_B), S1, aK1, wave, lane);
+    lin_fwd(W(A_Q1_W), W(A_Q1_B), S1, aQ1, wave, lane);
+    lin_fwd(W(A_V1_W), W(A_V1_B), S1, aV1, wave, lane);
+    MAT_SYNC();
+    att_fwd(aQ1, aK1, aV1, aY1, sP1, L, n_rows, true, wave, lane);
+    MAT_SYNC();
+    lin_fwd(W(A_P1_W), W(A_P1_B), aY1, S2, wave, lane);
+    MAT_SYNC();
+    tile_add(S1, S2, S2, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S2, kMHS, kMD, W(A_LN1_G), W(A_LN1_B), aN1, rstd(6), S0, tid);                // x1 in S0
+    MAT_SYNC();
+    lin_fwd(W(A_K2_W), W(A_K2_B), S0, aK2, wave, lane);                                       // key = value = x1
+    lin_fwd(W(A_V2_W), W(A_V2_B), S0, aV2, wave, lane);
+    lin_fwd(W(A_Q2_W), W(A_Q2_B), cENC, aQ2, wave, lane);                                     // query = rep_enc
+    MAT_SYNC();
+    att_fwd(aQ2, aK2, aV2, aY2, sP2, L, n_rows, true, wave, lane);
+    MAT_SYNC();
+    lin_fwd(W(A_P2_W), W(A_P2_B), aY2, S2, wave, lane);
+    MAT_SYNC();
+    tile_add(cENC, S2, S2, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S2, kMHS, kMD, W(A_LN2_G), W(A_LN2_B), aN2, rstd(7), S1, tid);                // x2 in S1
+    MAT_SYNC();
+    lin_fwd(W(A_M1_W), W(A_M1_B), S1, aZM, wave, lane);
+    MAT_SYNC();
+    tile_gelu(aZM, S2, tid);
+    MAT_SYNC();
+    lin_fwd(W(A_M2_W), W(A_M2_B), S2, S3, wave, lane);
+    MAT_SYNC();
+    tile_add(S1, S3, S3, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S3, kMHS, kMD, W(A_LN3_G), W(A_LN3_B), aN3, rstd(8), S0, tid);                // x3 in S0
+    MAT_SYNC();
+    lin_fwd(W(A_H1_W), W(A_H1_B), S0, aZH, wave, lane);
+    MAT_SYNC();
+    tile_gelu(aZH, S2, tid);
+    MAT_SYNC();
+    tile_ln_fwd(S2, kMHS, kMD, W(A_HLN_G), W(A_HLN_B), aNH, rstd(9), S1, tid);                // head LayerNorm output in S1
+    MAT_SYNC();
+    head_out_fwd(W(A_H2_W), W(A_H2_B), NA, S1, sOutA, tid);
+    MAT_SYNC();
+
+}
+
+
 __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x;
-    const int O = u.O, L = u.L, NA = u.NA, Ain = u.Ain;
-    const int NT0 = (O + 15) >> 4, OS = 16 * NT0 + 4;
+    const int NT0 = (u.O + 15) >> 4;
     const float* P = u.params;
     float* slab = u.slabs + (long)g * u.total;
     const long mb = u.cursor[0];
     const long seq0 = (long)g * u.per_tile;
     const long rem = u.B - seq0;
     const int n_seq = (int)(rem < u.per_tile ? (rem < 0 ? 0 : rem) : u.per_tile);
-    const int n_rows = n_seq * L;
-    const float inv_n = 1.0f / (float)(u.B * L);
+    const float inv_n = 1.0f / (float)(u.B * u.L);
 
     // ---- LDS carve
-    float* sm = reinterpret_cast<float*>(mat_smem);
-    int* sRow = reinterpret_cast<int*>(sm);                 // [16] buffer row of the token's env (-1: padding)
-    int* sAct = reinterpret_cast<int*>(sm) + 16;            // [16] action of the token
-    float* sMisc = sm + 32;                                 // [8] adv mean/std, vn mean/var
-    float* sRowF = sm + 48;                                 // [3][16] adv, old log-prob, rewards-to-go
-    float* sRstd = sm + 96;                                 // [10][16]
-    float* sOutC = sm + 256;                                // [16][8] critic output (col 0)
-    float* sOutA = sOutC + 128;                             // [16][8] logits
-    float* sDOutC = sOutA + 128;
-    float* sDOutA = sDOutC + 128;
-    float* sP0 = sDOutA + 128;                              // 3 probability tiles + 1 dS scratch, [16][17] each
-    float* sP1 = sP0 + 272;
-    float* sP2 = sP1 + 272;
-    float* sS = sP2 + 272;
-    float* sXA = sS + 272;                                  // [16][kMXS] action tokens
-    float* sXO = sXA + kRows * kMXS;                        // [16][OS] xhat of the observation LayerNorm
-    float* sYO = sXO + kRows * OS;                          // [16][OS] its output (input of the encoder linear)
-    float* T = sYO + kRows * OS;                            // [16][68] tiles from here on
-    auto tile = [&](int k) -> float* { return T + (long)k * kMTile; };
-    // saved for the backward
-    float *cZ1 = tile(0), *cN0 = tile(1), *cQ = tile(2), *cK = tile(3), *cV = tile(4), *cY = tile(5), *cN1 = tile(6),
-          *cZM = tile(7), *cN2 = tile(8), *cENC = tile(9), *cZH = tile(10), *cNH = tile(11);
-    float *aZ = tile(12), *aN0 = tile(13), *aQ1 = tile(14), *aK1 = tile(15), *aV1 = tile(16), *aY1 = tile(17),
-          *aN1 = tile(18), *aK2 = tile(19), *aV2 = tile(20), *aQ2 = tile(21), *aY2 = tile(22), *aN2 = tile(23),
-          *aZM = tile(24), *aN3 = tile(25), *aZH = tile(26), *aNH = tile(27);
-    float *S0 = tile(28), *S1 = tile(29), *S2 = tile(30), *S3 = tile(31), *S4 = tile(32), *DENC = tile(33);
-    auto rstd = [&](int k) -> float* { return sRstd + 16 * k; };
-    auto W = [&](int k) -> const float* { return P + u.off[k]; };
+    MatCtx c;
+    c.P = P; c.off = u.off; c.L = u.L; c.NA = u.NA; c.Ain = u.Ain; c.n_rows = n_seq * u.L;
+    c.carve(reinterpret_cast<float*>(mat_smem), u.O);
+    MAT_TILES(c);
+    int* sRow = c.sRow; int* sAct = c.sAct; float* sMisc = c.sMisc; float* sRowF = c.sRowF;
+    float* sDOutC = c.sDOutC; float* sDOutA = c.sDOutA;
     auto G = [&](int k) -> float* { return slab + u.off[k]; };
 
     // ---- rows, per-token scalars, mini-batch statistics
@@ -459,94 +590,8 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     }
     MAT_SYNC();
 
-    // =========================================== critic (encoder) forward ===========================================
-    tile_ln_fwd(sYO, OS, O, W(C_OLN_G), W(C_OLN_B), sXO, rstd(0), sYO, tid);                 // obs_encoder.0
-    MAT_SYNC();
-    narrow_fwd(W(C_ENC_W), O, W(C_ENC_B), sYO, OS, cZ1, wave, lane);                          // obs_encoder.1
-    MAT_SYNC();
-    tile_gelu(cZ1, S0, tid);
-    MAT_SYNC();
-    tile_ln_fwd(S0, kMHS, kMD, W(C_LN_G), W(C_LN_B), cN0, rstd(1), S1, tid);                  // critic.ln -> H0 in S1
-    MAT_SYNC();
-    lin_fwd(W(C_Q_W), W(C_Q_B), S1, cQ, wave, lane);
-    lin_fwd(W(C_K_W), W(C_K_B), S1, cK, wave, lane);
-    lin_fwd(W(C_V_W), W(C_V_B), S1, cV, wave, lane);
-    MAT_SYNC();
-    att_fwd(cQ, cK, cV, cY, sP0, L, n_rows, false, wave, lane);
-    MAT_SYNC();
-    lin_fwd(W(C_P_W), W(C_P_B), cY, S2, wave, lane);
-    MAT_SYNC();
-    tile_add(S1, S2, S2, tid);
-    MAT_SYNC();
-    tile_ln_fwd(S2, kMHS, kMD, W(C_LN1_G), W(C_LN1_B), cN1, rstd(2), S0, tid);                // H1 in S0
-    MAT_SYNC();
-    lin_fwd(W(C_M1_W), W(C_M1_B), S0, cZM, wave, lane);
-    MAT_SYNC();
-    tile_gelu(cZM, S2, tid);
-    MAT_SYNC();
-    lin_fwd(W(C_M2_W), W(C_M2_B), S2, S3, wave, lane);
-    MAT_SYNC();
-    tile_add(S0, S3, S3, tid);
-    MAT_SYNC();
-    tile_ln_fwd(S3, kMHS, kMD, W(C_LN2_G), W(C_LN2_B), cN2, rstd(3), cENC, tid);              // rep_enc
-    MAT_SYNC();
-    lin_fwd(W(C_H1_W), W(C_H1_B), cENC, cZH, wave, lane);
-    MAT_SYNC();
-    tile_gelu(cZH, S0, tid);
-    MAT_SYNC();
-    tile_ln_fwd(S0, kMHS, kMD, W(C_HLN_G), W(C_HLN_B), cNH, rstd(4), S1, tid);
-    MAT_SYNC();
-    head_out_fwd(W(C_H2_W), W(C_H2_B), 1, S1, sOutC, tid);
-
-    // =========================================== actor (decoder) forward ===========================================
-    narrow_fwd(W(A_ENC_W), Ain, nullptr, sXA, kMXS, aZ, wave, lane);                          // action_encoder.0 (no bias)
-    MAT_SYNC();
-    tile_gelu(aZ, S0, tid);
-    MAT_SYNC();
-    tile_ln_fwd(S0, kMHS, kMD, W(A_LN_G), W(A_LN_B), aN0, rstd(5), S1, tid);                  // x0 in S1
-    MAT_SYNC();
-    lin_fwd(W(A_K1_W), W(A_K1_B), S1, aK1, wave, lane);
-    lin_fwd(W(A_Q1_W), W(A_Q1_B), S1, aQ1, wave, lane);
-    lin_fwd(W(A_V1_W), W(A_V1_B), S1, aV1, wave, lane);
-    MAT_SYNC();
-    att_fwd(aQ1, aK1, aV1, aY1, sP1, L, n_rows, true, wave, lane);
-    MAT_SYNC();
-    lin_fwd(W(A_P1_W), W(A_P1_B), aY1, S2, wave, lane);
-    MAT_SYNC();
-    tile_add(S1, S2, S2, tid);
-    MAT_SYNC();
-    tile_ln_fwd(S2, kMHS, kMD, W(A_LN1_G), W(A_LN1_B), aN1, rstd(6), S0, tid);                // x1 in S0
-    MAT_SYNC();
-    lin_fwd(W(A_K2_W), W(A_K2_B), S0, aK2, wave, lane);                                       // key = value = x1
-    lin_fwd(W(A_V2_W), W(A_V2_B), S0, aV2, wave, lane);
-    lin_fwd(W(A_Q2_W), W(A_Q2_B), cENC, aQ2, wave, lane);                                     // query = rep_enc
-    MAT_SYNC();
-    att_fwd(aQ2, aK2, aV2, aY2, sP2, L, n_rows, true, wave, lane);
-    MAT_SYNC();
-    lin_fwd(W(A_P2_W), W(A_P2_B), aY2, S2, wave, lane);
-    MAT_SYNC();
-    tile_add(cENC, S2, S2, tid);
-    MAT_SYNC();
-    tile_ln_fwd(S2, kMHS, kMD, W(A_LN2_G), W(A_LN2_B), aN2, rstd(7), S1, tid);                // x2 in S1
-    MAT_SYNC();
-    lin_fwd(W(A_M1_W), W(A_M1_B), S1, aZM, wave, lane);
-    MAT_SYNC();
-    tile_gelu(aZM, S2, tid);
-    MAT_SYNC();
-    lin_fwd(W(A_M2_W), W(A_M2_B), S2, S3, wave, lane);
-    MAT_SYNC();
-    tile_add(S1, S3, S3, tid);
-    MAT_SYNC();
-    tile_ln_fwd(S3, kMHS, kMD, W(A_LN3_G), W(A_LN3_B), aN3, rstd(8), S0, tid);                // x3 in S0
-    MAT_SYNC();
-    lin_fwd(W(A_H1_W), W(A_H1_B), S0, aZH, wave, lane);
-    MAT_SYNC();
-    tile_gelu(aZH, S2, tid);
-    MAT_SYNC();
-    tile_ln_fwd(S2, kMHS, kMD, W(A_HLN_G), W(A_HLN_B), aNH, rstd(9), S1, tid);                // head LayerNorm output in S1
-    MAT_SYNC();
-    head_out_fwd(W(A_H2_W), W(A_H2_B), NA, S1, sOutA, tid);
-    MAT_SYNC();
+    mat_encoder_forward(c, tid, wave, lane);
+    mat_decoder_forward(c, tid, wave, lane);
 
     // =========================================== heads: distribution + losses (K6 + K3) =============================
     if (wave == 0) {
@@ -772,6 +817,94 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K16: one rollout step of a MATPolicy for all envs of the rank (mat_policy.py:441-519,587-626,660-675):
+// encoder forward (values), then L autoregressive decoder passes -- agent i's action is sampled
+// (Philox4x32-10, counter = offset + env * L + i) from the logits of pass i and becomes agent i+1's
+// token -- and the step's row of the rollout buffer is written in place.
+// ------------------------------------------------------------------------------------------------
+struct MatStepDev {
+    long off[64];
+    int O, L, NA, Ain, per_tile, Oa;
+    const float* params;
+    const float* obs; const float* actor_obs; long E;
+    unsigned long long seed, offset;
+    int normalize_values; const float* vn_mean; const float* vn_var;
+    int64_t* action_out; int64_t* raw_action_out; float* logp_out; float* value_out;
+    float* critic_obs_out; float* obs_out;
+};
+
+__global__ __launch_bounds__(kMT) void mat_policy_step_kernel(MatStepDev u) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long seq0 = (long)blockIdx.x * u.per_tile;
+    const long rem = u.E - seq0;
+    const int n_seq = (int)(rem < u.per_tile ? (rem < 0 ? 0 : rem) : u.per_tile);
+    MatCtx c;
+    c.P = u.params; c.off = u.off; c.L = u.L; c.NA = u.NA; c.Ain = u.Ain; c.n_rows = n_seq * u.L;
+    c.carve(reinterpret_cast<float*>(mat_smem), u.O);
+    MAT_TILES(c);
+    int* sAct = c.sAct;
+    for (int i = tid; i < kRows * OS; i += kMT) { sXO[i] = 0.f; sYO[i] = 0.f; }
+    for (int i = tid; i < kRows * kMXS; i += kMT) sXA[i] = 0.f;
+    MAT_SYNC();
+    const long tok0 = seq0 * L;                                  // first token (env-major, agents inside)
+    for (int idx = tid; idx < n_rows * O; idx += kMT) {
+        const int s = idx / O, i = idx - s * O;
+        const float v = u.obs[(tok0 + s) * O + i];
+        sYO[s * OS + i] = v;
+        if (u.critic_obs_out) u.critic_obs_out[(tok0 + s) * O + i] = v;
+    }
+    if (u.obs_out) {
+        const float* src = u.actor_obs ? u.actor_obs : u.obs;
+        for (long idx = tid; idx < (long)n_rows * u.Oa; idx += kMT) u.obs_out[tok0 * u.Oa + idx] = src[tok0 * u.Oa + idx];
+    }
+    if (tid < n_rows && tid % L == 0) sXA[tid * kMXS] = 1.0f;     // start token of agent 0 (mat_policy.py:325-333)
+    MAT_SYNC();
+    mat_encoder_forward(c, tid, wave, lane);
+    MAT_SYNC();
+    if (tid < n_rows) {
+        float v = sOutC[tid * 8];
+        if (u.normalize_values) v = u.vn_mean[0] + v * sqrtf(u.vn_var[0] + 1e-8f);     // misc.py:124-128
+        u.value_out[tok0 + tid] = v;
+    }
+    for (int i = 0; i < L; ++i) {
+        mat_decoder_forward(c, tid, wave, lane);                  // ends with a barrier
+        if (tid < n_rows && tid % L == i) {
+            float p[8];
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (k < NA) m = fmaxf(m, sOutA[tid * 8 + k]);
+            float ssum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { p[k] = k < NA ? expf(sOutA[tid * 8 + k] - m) : 0.f; ssum += p[k]; }
+            const float inv = 1.0f / ssum;
+            float s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { p[k] *= inv; s2 += p[k]; }
+            const Philox4 rnd = philox4x32_10(u.seed, u.offset + (unsigned long long)(tok0 + tid), 0u);
+            const float uu = u32_to_unit(rnd.x) * s2;             // inverse CDF over the probability mass
+            int a = NA - 1;
+            float cum = 0.f, pa = 0.f;
+            bool found = false;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < NA && !found) {
+                    cum += p[k];
+                    if (uu < cum) { a = k; found = true; }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (k == a) pa = p[k];
+            sAct[tid] = a;
+            u.action_out[tok0 + tid] = a;
+            if (u.raw_action_out) u.raw_action_out[tok0 + tid] = a;
+            u.logp_out[tok0 + tid] = logf(clamp_prob_u(pa / s2));
+            if (i + 1 < L) sXA[(tid + 1) * kMXS + 1 + a] = 1.0f;  // agent i+1 sees agent i's action
+        }
+        MAT_SYNC();
+    }
+}
+
 // slabs -> gradient bucket in a fixed order; block 0 folds the loss partials and advances the cursor
 constexpr int kMatRedCols = 64, kMatRedRows = 16;
 __global__ __launch_bounds__(kMatRedCols * kMatRedRows) void mat_update_reduce_kernel(MatDev u) {
@@ -910,4 +1043,38 @@ extern "C" int ppoaf_mat_update_reduce(const ppoaf_mat_update_args_t* args, ppoa
     hipLaunchKernelGGL(mat_update_reduce_kernel, dim3((unsigned)((n4 + kMatRedCols - 1) / kMatRedCols)),
                        dim3(kMatRedCols * kMatRedRows), 0, (hipStream_t)stream, u);
     return check_launch("mat_update_reduce");
+}
+
+extern "C" int ppoaf_mat_policy_step(const ppoaf_mat_step_args_t* a, ppoaf_stream_t stream) {
+    PPOAF_REQUIRE(a, "mat_policy_step: null args");
+    PPOAF_REQUIRE(a->embedding == kMD, "mat_policy_step: embedding=%d (built for 64)", a->embedding);
+    PPOAF_REQUIRE(a->num_agents >= 1 && a->num_agents <= 16 && a->obs_dim >= 1 && a->obs_dim <= 64 &&
+                      a->num_actions >= 1 && a->num_actions <= 8 && a->actor_obs_dim >= 1,
+                  "mat_policy_step: sizes (agents %d, obs %d, actions %d)", a->num_agents, a->obs_dim, a->num_actions);
+    PPOAF_REQUIRE(a->E >= 1, "mat_policy_step: E=%ld", (long)a->E);
+    PPOAF_REQUIRE(a->params && a->critic_obs && a->action_out && a->logp_out && a->value_out, "mat_policy_step: null pointer");
+    PPOAF_REQUIRE(!a->normalize_values || (a->vn_mean && a->vn_var), "mat_policy_step: value normaliser statistics missing");
+    PPOAF_REQUIRE(((uintptr_t)a->params & 15) == 0, "mat_policy_step: params must be 16-byte aligned");
+    MatStepDev u;
+    for (int i = 0; i < 64; ++i) u.off[i] = a->offsets[i];
+    u.O = a->obs_dim; u.L = a->num_agents; u.NA = a->num_actions; u.Ain = a->num_actions + 1;
+    u.per_tile = 16 / u.L; u.Oa = a->actor_obs_dim;
+    u.params = a->params; u.obs = a->critic_obs; u.actor_obs = a->actor_obs; u.E = a->E;
+    u.seed = a->seed; u.offset = a->offset;
+    u.normalize_values = a->normalize_values; u.vn_mean = a->vn_mean; u.vn_var = a->vn_var;
+    u.action_out = a->action_out; u.raw_action_out = a->raw_action_out; u.logp_out = a->logp_out;
+    u.value_out = a->value_out; u.critic_obs_out = a->critic_obs_copy_out; u.obs_out = a->obs_copy_out;
+    const size_t lds = mat_lds_bytes(u.O);
+    PPOAF_REQUIRE(lds <= 160 * 1024, "mat_policy_step: needs %zu B of LDS (> 160 KiB)", lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mat_policy_step_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+        attr_set = true;
+    }
+    const long n_wg = (a->E + u.per_tile - 1) / u.per_tile;
+    PPOAF_REQUIRE(n_wg <= 0x7fffffffL, "mat_policy_step: too many envs");
+    hipLaunchKernelGGL(mat_policy_step_kernel, dim3((unsigned)n_wg), dim3(kMT), lds, (hipStream_t)stream, u);
+    return check_launch("mat_policy_step");
 }

@@ -112,7 +112,57 @@ class MATPolicy(PPOPolicy):
         self.dataset.attach(self.buffer, self.gamma, self.lambd, self.get_bs_clip_range(None), self.use_gae)
 
     def fused_step_unsupported_reason(self):
-        return "MAT policies use the torch-ROCm + K9 path"
+        """'' when the K16 rollout-step kernel covers this policy (same coverage as the fused update K15)."""
+        from ..fused_update import _describe_mat
+        return _describe_mat(self)[1]
+
+    def rollout_step(self, t, critic_obs, actor_obs, value_normalizer=None):
+        """
+        One env step of get_rollout_actions (encoder + A autoregressive decoder passes + sampling) and
+        get_critic_values (+ denormalisation) as ONE launch (K16) that stores straight into row t of the
+        rollout buffer.  critic_obs / actor_obs: grouped device tensors [E, A, .].  Returns the action row
+        (a view of the buffer, [E, A, 1]) for env.step; rewards are added by `finish_step`.
+        """
+        from .. import _lib
+        from .. import kernels as K
+        from ..fused_update import _describe_mat
+        import ctypes as C
+        buf = self.buffer
+        E, A = buf.C, buf.A
+        a = getattr(self, "_step_args", None)
+        if a is None:
+            topo, why = _describe_mat(self)
+            if topo is None:
+                raise _lib.PpoafError(f"mat rollout_step: {why}")
+            a = _lib.MatStepArgs()
+            a.obs_dim, a.num_agents, a.num_actions, a.embedding = topo["obs_dim"], topo["num_agents"], topo["num_actions"], 64
+            for i, o in enumerate(topo["offsets"]):
+                a.offsets[i] = o
+            a.params = self.actor_critic.flat_params.data_ptr()
+            a.E = E
+            a.actor_obs_dim = int(buf.observations.shape[-1])
+            self._step_args = a
+        if critic_obs.shape != (E, A, a.obs_dim) or not critic_obs.is_cuda:
+            raise _lib.PpoafError(f"mat rollout_step: critic_obs must be a device tensor [{E}, {A}, {a.obs_dim}]")
+        critic_obs = critic_obs.contiguous()
+        actor_obs = actor_obs.contiguous()
+        a.critic_obs, a.actor_obs = critic_obs.data_ptr(), actor_obs.data_ptr()
+        a.seed, a.offset = self.actor.distribution.rng.take(E * A)
+        a.normalize_values = int(value_normalizer is not None)
+        if value_normalizer is not None:
+            a.vn_mean = value_normalizer.running_stats.mean_t.data_ptr()
+            a.vn_var = value_normalizer.running_stats.var_t.data_ptr()
+        a.action_out, a.raw_action_out = buf.actions[t].data_ptr(), buf.raw_actions[t].data_ptr()
+        a.logp_out, a.value_out = buf.log_probs[t].data_ptr(), buf.values[t].data_ptr()
+        a.critic_obs_copy_out, a.obs_copy_out = buf.critic_observations[t].data_ptr(), buf.observations[t].data_ptr()
+        _lib.check(_lib.load().ppoaf_mat_policy_step(C.byref(a), K.stream()), "mat_policy_step")
+        return buf.actions[t]
+
+    def finish_step(self, t, rewards, next_obs=None):
+        buf = self.buffer
+        buf.rewards[t].copy_(rewards.reshape(buf.rewards[t].shape))
+        buf.steps_written = max(buf.steps_written, t + 1)
+        self._t = t + 1
 
     def _get_tokened_action_block(self, batch_size):
         """mat_policy.py:308-344."""

@@ -286,7 +286,17 @@ class PPO:
         nat_buf = self._scratch(f"nat_buf_{T}_{env.num_agents if hasattr(env, 'num_agents') else 1}_{n_envs}",
                                 T * (E if not grouped else E * pol.num_agents), torch.float32).view(T, -1)
         for t in range(T):
-            if fused_step:
+            if fused_step and grouped:
+                # K16: encoder + autoregressive decoder passes + sampling + values + the buffer row in one launch
+                g_obs, g_cobs = group(obs), group(critic_obs)
+                action = pol.rollout_step(t, g_cobs, g_cobs if pol.expanded_actor_space else g_obs, vn)
+                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(ungroup(action))
+                nat_buf[t].copy_(self._natural_reward(env, reward))
+                if self.ext_reward_weight != 1.0:
+                    reward = reward * self.ext_reward_weight
+                pol.finish_step(t, group(reward))
+                terminated, truncated = terminated[:n_envs], truncated[:n_envs]   # agents of an env end together
+            elif fused_step:
                 # K6+K7: inference, sampling, log-probs, values and the buffer row in one launch
                 action = pol.rollout_step(t, obs.contiguous(), critic_obs.contiguous(), vn)
                 nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(action)
