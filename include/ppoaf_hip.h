@@ -531,7 +531,7 @@ typedef struct {
     float icm_beta; int32_t fused_adam;
     float* act_scratch;              /* [2, 4, 16*ceil(B/16), hidden]                           */
     float* denc_scratch;             /* [2, 2, 16*ceil(B/16), hidden]                           */
-    float* loss_partials;            /* [ceil(B/16), 2]                                         */
+    float* loss_partials;            /* [ceil(B/16) + 1, 2] (last row: this step's Adam constants)*/
     double* totals;                  /* [2]                                                     */
 } ppoaf_icm_update_args_t;
 

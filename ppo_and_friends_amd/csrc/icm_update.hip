@@ -61,7 +61,14 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_fwd_kernel(IcmDev u) {
     int* sRow = reinterpret_cast<int*>(smem);
     float* sX = smem + 16;                      // [16, INP]
     float* sH = sX + kRows * INP;               // 4 x [16, HS]
-    if (blockIdx.x == 0 && tid == 0 && u.fused_adam) u.step_count[0] += 1;
+    if (blockIdx.x == 0 && tid == 0 && u.fused_adam) {
+        // Adam step counter and the two bias-correction constants of this mini-batch, computed once (in
+        // double, as torch.optim.Adam does) and parked behind the loss partials for the reduce kernel
+        const int64_t t = u.step_count[0] + 1;
+        u.step_count[0] = t;
+        u.loss_partials[2 * u.nT] = (float)((double)u.lr[0] / (1.0 - pow((double)u.beta1, (double)t)));
+        u.loss_partials[2 * u.nT + 1] = (float)sqrt(1.0 - pow((double)u.beta2, (double)t));
+    }
     icm_rows(u, g, tid, sRow);
     for (int i = tid; i < kRows * INP; i += kThreadsU) sX[i] = 0.f;
     __syncthreads();
@@ -455,71 +462,60 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_bwd_kernel(IcmDev u) {
 // ------------------------------------------------------------------------------------------------
 // reduce (+ Adam): the encoder region has 2 * nT slabs, the two models nT
 // ------------------------------------------------------------------------------------------------
-constexpr int kIcmRedCols = 64;
-constexpr int kIcmRedRows = 16;
+constexpr int kIcmRedThreads = 256;
 
-__global__ __launch_bounds__(kIcmRedCols * kIcmRedRows) void icm_reduce_kernel(IcmDev u) {
-    __shared__ float4 tile[kIcmRedRows][kIcmRedCols];
-    __shared__ float sBc[2];
-    const int c = threadIdx.x & (kIcmRedCols - 1), r = threadIdx.x / kIcmRedCols;
+__global__ __launch_bounds__(kIcmRedThreads) void icm_reduce_kernel(IcmDev u) {
+    if (blockIdx.x == gridDim.x - 1) {                       // bookkeeping workgroup: loss -> totals, cursor++
+        if (threadIdx.x >= 64) return;
+        const int lane = threadIdx.x;
+        float inv = 0.f, fl = 0.f;
+        for (int g = lane; g < u.nT; g += 64) { inv += u.loss_partials[g * 2]; fl += u.loss_partials[g * 2 + 1]; }
+        inv = wave_sum(inv); fl = wave_sum(fl);
+        if (lane == 0) {
+            const float n = (float)u.B;
+            inv = u.discrete ? inv / n : inv / (n * (float)u.A);
+            fl = fl / (n * (float)u.H);
+            u.totals[0] += (double)((1.0f - u.icm_beta) * fl + u.icm_beta * inv);
+            u.totals[1] += 1.0;
+            u.cursor[0] += 1;
+        }
+        return;
+    }
     const long n4 = u.total >> 2;
-    const long idx = (long)blockIdx.x * kIcmRedCols + c;
+    const long idx = (long)blockIdx.x * kIcmRedThreads + threadIdx.x;
+    if (idx >= n4) return;
     const float4* sl = reinterpret_cast<const float4*>(u.slabs);
-    // the slab count is uniform per block only if the block does not straddle the encoder boundary;
-    // it is evaluated per column and the loop runs to the larger count with masked loads
+    // the encoder region holds 2 * nT slabs (one per observation stream and tile), the two models nT
     const long p = idx * 4;
     const int ns = (p >= u.enc_off && p < u.enc_off + u.enc_size) ? 2 * u.nT : u.nT;
-    if (threadIdx.x == 0 && u.fused_adam) {
-        const double t = (double)u.step_count[0];
-        sBc[0] = (float)((double)u.lr[0] / (1.0 - pow((double)u.beta1, t)));
-        sBc[1] = (float)sqrt(1.0 - pow((double)u.beta2, t));
-    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int g0 = 0; g0 < 2 * u.nT; g0 += kIcmRedRows) {
-        const int g = g0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < n4 && g < ns) v = sl[(long)g * n4 + idx];
-        tile[r][c] = v;
-        __syncthreads();
-        if (r == 0) {
+    for (int g0 = 0; g0 < ns; g0 += 8) {
+        float4 v[8];
 #pragma unroll
-            for (int k = 0; k < kIcmRedRows; ++k) {
-                const float4 t = tile[k][c];
-                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-            }
-        }
-        __syncthreads();
+        for (int k = 0; k < 8; ++k)
+            v[k] = (g0 + k < ns) ? sl[(long)(g0 + k) * n4 + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
     }
-    if (r == 0 && idx < n4) {
-        reinterpret_cast<float4*>(u.grads)[idx] = acc;
-        if (u.fused_adam) {
-            const float step_size = sBc[0], bc2_sqrt = sBc[1], gs = u.grad_scale;
-            float4 pp = reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx];
-            float4 m = reinterpret_cast<float4*>(u.exp_avg)[idx];
-            float4 v = reinterpret_cast<float4*>(u.exp_avg_sq)[idx];
+    reinterpret_cast<float4*>(u.grads)[idx] = acc;
+    if (u.fused_adam) {
+        const float step_size = u.loss_partials[2 * u.nT], bc2_sqrt = u.loss_partials[2 * u.nT + 1];
+        const float gs = u.grad_scale;
+        float4 pp = reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx];
+        float4 m = reinterpret_cast<float4*>(u.exp_avg)[idx];
+        float4 v = reinterpret_cast<float4*>(u.exp_avg_sq)[idx];
 #define PPOAF_ADAM1(cc)                                                          \
-            {                                                                    \
-                const float gi = acc.cc * gs;                                    \
-                m.cc = u.beta1 * m.cc + (1.0f - u.beta1) * gi;                   \
-                v.cc = u.beta2 * v.cc + (1.0f - u.beta2) * gi * gi;              \
-                pp.cc = pp.cc - step_size * (m.cc / (sqrtf(v.cc) / bc2_sqrt + u.adam_eps)); \
-            }
-            PPOAF_ADAM1(x) PPOAF_ADAM1(y) PPOAF_ADAM1(z) PPOAF_ADAM1(w)
-#undef PPOAF_ADAM1
-            reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx] = pp;
-            reinterpret_cast<float4*>(u.exp_avg)[idx] = m;
-            reinterpret_cast<float4*>(u.exp_avg_sq)[idx] = v;
+        {                                                                        \
+            const float gi = acc.cc * gs;                                        \
+            m.cc = u.beta1 * m.cc + (1.0f - u.beta1) * gi;                       \
+            v.cc = u.beta2 * v.cc + (1.0f - u.beta2) * gi * gi;                  \
+            pp.cc = pp.cc - step_size * (m.cc / (sqrtf(v.cc) / bc2_sqrt + u.adam_eps)); \
         }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float inv = 0.f, fl = 0.f;
-        for (int g = 0; g < u.nT; ++g) { inv += u.loss_partials[g * 2]; fl += u.loss_partials[g * 2 + 1]; }
-        const float n = (float)u.B;
-        inv = u.discrete ? inv / n : inv / (n * (float)u.A);
-        fl = fl / (n * (float)u.H);
-        u.totals[0] += (double)((1.0f - u.icm_beta) * fl + u.icm_beta * inv);
-        u.totals[1] += 1.0;
-        u.cursor[0] += 1;
+        PPOAF_ADAM1(x) PPOAF_ADAM1(y) PPOAF_ADAM1(z) PPOAF_ADAM1(w)
+#undef PPOAF_ADAM1
+        reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx] = pp;
+        reinterpret_cast<float4*>(u.exp_avg)[idx] = m;
+        reinterpret_cast<float4*>(u.exp_avg_sq)[idx] = v;
     }
 }
 
@@ -607,7 +603,7 @@ extern "C" int ppoaf_icm_update_reduce(const ppoaf_icm_update_args_t* args, ppoa
     const int rc = make_icm(args, u);
     if (rc) return rc;
     const long n4 = u.total >> 2;
-    hipLaunchKernelGGL(icm_reduce_kernel, dim3((unsigned)((n4 + kIcmRedCols - 1) / kIcmRedCols)),
-                       dim3(kIcmRedCols * kIcmRedRows), 0, (hipStream_t)stream, u);
+    hipLaunchKernelGGL(icm_reduce_kernel, dim3((unsigned)((n4 + kIcmRedThreads - 1) / kIcmRedThreads) + 1u),
+                       dim3(kIcmRedThreads), 0, (hipStream_t)stream, u);
     return check_launch("icm_reduce");
 }

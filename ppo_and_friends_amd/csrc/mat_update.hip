@@ -905,49 +905,48 @@ __global__ __launch_bounds__(kMT) void mat_policy_step_kernel(MatStepDev u) {
     }
 }
 
-// slabs -> gradient bucket in a fixed order; block 0 folds the loss partials and advances the cursor
-constexpr int kMatRedCols = 64, kMatRedRows = 16;
-__global__ __launch_bounds__(kMatRedCols * kMatRedRows) void mat_update_reduce_kernel(MatDev u) {
-    __shared__ float4 tile[kMatRedRows][kMatRedCols];
-    const int c = threadIdx.x & (kMatRedCols - 1), r = threadIdx.x / kMatRedCols;
+// slabs -> gradient bucket in a fixed order (each thread owns a float4 column, 8 slab loads in flight at a
+// time, no LDS staging); the last workgroup folds the loss partials and advances the cursor
+constexpr int kMatRedThreads = 256;
+__global__ __launch_bounds__(kMatRedThreads) void mat_update_reduce_kernel(MatDev u) {
+    if (blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x >= 64) return;
+        const int lane = threadIdx.x;
+        float p0 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p7 = 0.f;
+        for (int g = lane; g < u.nT; g += 64) {
+            const float* a = u.loss_partials + (long)g * 8;
+            p0 += a[0]; p2 += a[2]; p3 += a[3]; p4 += a[4]; p7 += a[7];
+        }
+        p0 = wave_sum(p0); p2 = wave_sum(p2); p3 = wave_sum(p3); p4 = wave_sum(p4); p7 = wave_sum(p7);
+        if (lane == 0) {
+            const float n = (float)(u.B * u.L);
+            const float surr = p0 / n, ent = p3 / n, kl = p4 / n, crit = p2 / n;
+            float total = surr;
+            if (u.entropy_weight != 0.0f) total -= u.entropy_weight * ent;
+            if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
+            u.totals[0] += (double)surr; u.totals[1] += (double)total; u.totals[2] += (double)crit;
+            u.totals[3] += (double)ent; u.totals[4] += (double)kl;
+            u.totals[5] += (double)u.loss_partials[5]; u.totals[6] += (double)u.loss_partials[6];
+            u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
+            u.totals[8] += 1.0;
+            u.cursor[0] += 1;
+        }
+        return;
+    }
     const long n4 = u.total >> 2;
-    const long idx = (long)blockIdx.x * kMatRedCols + c;
+    const long idx = (long)blockIdx.x * kMatRedThreads + threadIdx.x;
+    if (idx >= n4) return;
     const float4* sl = reinterpret_cast<const float4*>(u.slabs);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int g0 = 0; g0 < u.nT; g0 += kMatRedRows) {
-        const int g = g0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < n4 && g < u.nT) v = sl[(long)g * n4 + idx];
-        tile[r][c] = v;
-        __syncthreads();
-        if (r == 0) {
+    for (int g0 = 0; g0 < u.nT; g0 += 8) {
+        float4 v[8];
 #pragma unroll
-            for (int k = 0; k < kMatRedRows; ++k) {
-                const float4 t = tile[k][c];
-                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-            }
-        }
-        __syncthreads();
+        for (int k = 0; k < 8; ++k)
+            v[k] = (g0 + k < u.nT) ? sl[(long)(g0 + k) * n4 + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
     }
-    if (r == 0 && idx < n4) reinterpret_cast<float4*>(u.grads)[idx] = acc;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int g = 0; g < u.nT; ++g) {
-            const float* a = u.loss_partials + (long)g * 8;
-            p[0] += a[0]; p[2] += a[2]; p[3] += a[3]; p[4] += a[4]; p[7] += a[7];
-        }
-        const float n = (float)(u.B * u.L);
-        const float surr = p[0] / n, ent = p[3] / n, kl = p[4] / n, crit = p[2] / n;
-        float total = surr;
-        if (u.entropy_weight != 0.0f) total -= u.entropy_weight * ent;
-        if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
-        u.totals[0] += (double)surr; u.totals[1] += (double)total; u.totals[2] += (double)crit;
-        u.totals[3] += (double)ent; u.totals[4] += (double)kl;
-        u.totals[5] += (double)u.loss_partials[5]; u.totals[6] += (double)u.loss_partials[6];
-        u.totals[7] += p[7] > 0.f ? 1.0 : 0.0;
-        u.totals[8] += 1.0;
-        u.cursor[0] += 1;
-    }
+    reinterpret_cast<float4*>(u.grads)[idx] = acc;
 }
 
 static size_t mat_lds_bytes(int O) {
@@ -1040,8 +1039,8 @@ extern "C" int ppoaf_mat_update_reduce(const ppoaf_mat_update_args_t* args, ppoa
     const int rc = make_mat(args, u);
     if (rc) return rc;
     const long n4 = u.total >> 2;
-    hipLaunchKernelGGL(mat_update_reduce_kernel, dim3((unsigned)((n4 + kMatRedCols - 1) / kMatRedCols)),
-                       dim3(kMatRedCols * kMatRedRows), 0, (hipStream_t)stream, u);
+    hipLaunchKernelGGL(mat_update_reduce_kernel, dim3((unsigned)((n4 + kMatRedThreads - 1) / kMatRedThreads) + 1u),
+                       dim3(kMatRedThreads), 0, (hipStream_t)stream, u);
     return check_launch("mat_update_reduce");
 }
 

@@ -529,38 +529,34 @@ __global__ __launch_bounds__(kThreadsU) void ppo_update_fwd_bwd_kernel(UpdateDev
 }
 
 // slabs -> gradient bucket in a fixed order.  The slabs were just written by other CUs, so every
-// read is a cold miss: all of them are put in flight at once -- thread (g, c) loads ONE float4 of
-// slab g, the 16-row LDS tile is then summed over g in index order (bitwise reproducible).
-// Block 0 also folds the loss partials into the totals, advances the Adam step counters and
-// publishes the bias corrections (computed once, in double, instead of per thread in the Adam kernel).
-constexpr int kRedCols = 64;      // float4 columns per block
-constexpr int kRedRows = 16;      // slabs summed per pass (= threads.y)
+// read is a cold miss: each thread owns one float4 column and puts the loads of 8 slabs in flight
+// at a time, then adds them in slab order (bitwise reproducible, no LDS round trip, no barrier
+// before the result is stored).  Block 0 also folds the loss partials into the totals, advances the
+// Adam step counters and publishes the bias corrections (computed once, in double, instead of per
+// thread in the Adam kernel).
+constexpr int kRedThreads = 256;
 
-__global__ __launch_bounds__(kRedCols * kRedRows) void ppo_update_reduce_kernel(UpdateDev u, int compute_norms) {
-    __shared__ float4 tile[kRedRows][kRedCols];
+__device__ __forceinline__ void ppo_update_bookkeeping(const UpdateDev& u);
+
+__global__ __launch_bounds__(kRedThreads) void ppo_update_reduce_kernel(UpdateDev u, int compute_norms) {
     __shared__ double red[17];
-    const int c = threadIdx.x & (kRedCols - 1), r = threadIdx.x / kRedCols;
+    if (blockIdx.x == gridDim.x - 1) { ppo_update_bookkeeping(u); return; }      // uniform per workgroup
     const long n4 = u.bucket_total >> 2;
-    const long idx = (long)blockIdx.x * kRedCols + c;
+    const long idx = (long)blockIdx.x * kRedThreads + threadIdx.x;
     const float4* sl = reinterpret_cast<const float4*>(u.slabs);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int g0 = 0; g0 < u.n_wg; g0 += kRedRows) {
-        const int g = g0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < n4 && g < u.n_wg) v = sl[(long)g * n4 + idx];
-        tile[r][c] = v;
-        __syncthreads();
-        if (r == 0) {
+    if (idx < n4) {
+        for (int g0 = 0; g0 < u.n_wg; g0 += 8) {
+            float4 v[8];
 #pragma unroll
-            for (int k = 0; k < kRedRows; ++k) {
-                const float4 t = tile[k][c];
-                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-            }
+            for (int k = 0; k < 8; ++k)
+                v[k] = (g0 + k < u.n_wg) ? sl[(long)(g0 + k) * n4 + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
         }
-        __syncthreads();
     }
     double q0 = 0.0, q1 = 0.0;
-    if (r == 0 && idx < n4) {
+    if (idx < n4) {
         reinterpret_cast<float4*>(u.grads)[idx] = acc;
         if (compute_norms) {
             const float sc = u.grad_scale;
@@ -577,29 +573,39 @@ __global__ __launch_bounds__(kRedCols * kRedRows) void ppo_update_reduce_kernel(
             if (q1 != 0.0) atomicAdd(&u.norm_scratch[1], q1);
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int g = 0; g < u.n_wg; ++g) {
-            const float* a = u.loss_partials + (long)g * 8;
-            const float* cc = u.loss_partials + ((long)u.n_wg + g) * 8;
-            p[0] += a[0]; p[3] += a[3]; p[4] += a[4]; p[7] += a[7]; p[2] += cc[2];
-        }
+}
+
+// The per-mini-batch bookkeeping runs in its own (last) workgroup so that it overlaps the slab
+// reads instead of extending workgroup 0: loss partials summed by one wave (lane = workgroup of the
+// fwd_bwd kernel), totals, Adam step counters and bias corrections.
+__device__ __forceinline__ void ppo_update_bookkeeping(const UpdateDev& u) {
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    float p0 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p7 = 0.f;
+    for (int g = lane; g < u.n_wg; g += 64) {
+        const float* a = u.loss_partials + (long)g * 8;
+        const float* cc = u.loss_partials + ((long)u.n_wg + g) * 8;
+        p0 += a[0]; p3 += a[3]; p4 += a[4]; p7 += a[7]; p2 += cc[2];
+    }
+    p0 = wave_sum(p0); p2 = wave_sum(p2); p3 = wave_sum(p3); p4 = wave_sum(p4); p7 = wave_sum(p7);
+    if (lane == 0) {
         const float n = (float)u.B;
-        const float surr = p[0] / n, ent = p[3] / n, kl = p[4] / n, crit = p[2] / n;
+        const float surr = p0 / n, ent = p3 / n, kl = p4 / n, crit = p2 / n;
         float total = surr;
         if (u.entropy_weight != 0.0f) total -= u.entropy_weight * ent;
         if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
         u.totals[0] += (double)surr; u.totals[1] += (double)total; u.totals[2] += (double)crit;
         u.totals[3] += (double)ent; u.totals[4] += (double)kl;
         u.totals[5] += (double)u.loss_partials[5]; u.totals[6] += (double)u.loss_partials[6];
-        u.totals[7] += p[7] > 0.f ? 1.0 : 0.0;
+        u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
         u.totals[8] += 1.0;
-        for (int w = 0; w < 2; ++w) {
-            const int64_t t = u.step_counts[w] + 1;
-            u.step_counts[w] = t;
-            u.norm_scratch[2 + 2 * w] = 1.0 - pow((double)u.beta1, (double)t);       // bias correction 1
-            u.norm_scratch[3 + 2 * w] = sqrt(1.0 - pow((double)u.beta2, (double)t)); // sqrt(bias correction 2)
-        }
+    }
+    if (lane < 2) {                                       // one lane per network: step counter + bias corrections
+        const int w = lane;
+        const int64_t t = u.step_counts[w] + 1;
+        u.step_counts[w] = t;
+        u.norm_scratch[2 + 2 * w] = 1.0 - pow((double)u.beta1, (double)t);       // bias correction 1
+        u.norm_scratch[3 + 2 * w] = sqrt(1.0 - pow((double)u.beta2, (double)t)); // sqrt(bias correction 2)
     }
 }
 
@@ -814,8 +820,8 @@ extern "C" int ppoaf_ppo_update_reduce(const ppoaf_ppo_update_args_t* args, int 
     int rc = make_dev(args, u);
     if (rc) return rc;
     const long n4 = u.bucket_total >> 2;
-    hipLaunchKernelGGL(ppo_update_reduce_kernel, dim3((unsigned)((n4 + kRedCols - 1) / kRedCols)),
-                       dim3(kRedCols * kRedRows), 0, (hipStream_t)stream, u, compute_norms);
+    hipLaunchKernelGGL(ppo_update_reduce_kernel, dim3((unsigned)((n4 + kRedThreads - 1) / kRedThreads) + 1u),
+                       dim3(kRedThreads), 0, (hipStream_t)stream, u, compute_norms);
     return check_launch("ppo_update_reduce");
 }
 

@@ -372,7 +372,7 @@ class FusedIcmUpdate:
         self.slabs = torch.zeros(2 * nT, total, dtype=torch.float32, device=dev)
         self.act_scratch = torch.zeros(2, 4, 16 * nT, H, dtype=torch.float32, device=dev)
         self.denc_scratch = torch.zeros(2, 2, 16 * nT, H, dtype=torch.float32, device=dev)
-        self.loss_partials = torch.zeros(nT, 2, dtype=torch.float32, device=dev)
+        self.loss_partials = torch.zeros(nT + 1, 2, dtype=torch.float32, device=dev)    # + the step's Adam constants
         self.totals = torch.zeros(2, dtype=torch.float64, device=dev)
         self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
         self._lib = _lib.load()
