@@ -274,6 +274,15 @@ int ppoaf_clip_adam_step(float* params, const float* grads,
                          float grad_scale, float max_norm,
                          double* norm_scratch, float* grad_norm_out /* NULL ok */,
                          ppoaf_stream_t stream);
+/* The Adam half alone: norm_scratch[0] already holds ||grad_scale * grads||^2 and step_count has
+ * been advanced for this step (a producer kernel did both, e.g. K15's reduce with fuse_norm). */
+int ppoaf_adam_step_prenormed(float* params, const float* grads,
+                              float* exp_avg, float* exp_avg_sq, int64_t n,
+                              const int64_t* step_count, const float* lr /* device [1] */,
+                              float beta1, float beta2, float eps,
+                              float grad_scale, float max_norm,
+                              const double* norm_scratch, float* grad_norm_out /* NULL ok */,
+                              ppoaf_stream_t stream);
 
 
 /* ------------------------------------------------------------------------ *
@@ -570,6 +579,10 @@ typedef struct {
     float surr_clip, entropy_weight, kl_loss_weight, huber_delta;
     float* loss_partials;            /* [n_workgroups, 8] */
     double* totals;                  /* [9] */
+    /* single-rank fusion of K11's norm pass: with fuse_norm the reduce launch also accumulates
+     * ||grads||^2 into norm_scratch[0] (zeroed by fwd_bwd) and advances step_count, so the caller
+     * follows with ppoaf_adam_step_prenormed instead of ppoaf_clip_adam_step */
+    double* norm_scratch; int64_t* step_count; int32_t fuse_norm, _pad;
 } ppoaf_mat_update_args_t;
 
 int ppoaf_mat_update_fwd_bwd(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream);

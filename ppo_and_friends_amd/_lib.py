@@ -105,7 +105,8 @@ class MatUpdateArgs(C.Structure):
                 ("vn_records", C.c_void_p), ("adv_records", C.c_void_p),
                 ("surr_clip", C.c_float), ("entropy_weight", C.c_float), ("kl_loss_weight", C.c_float),
                 ("huber_delta", C.c_float),
-                ("loss_partials", C.c_void_p), ("totals", C.c_void_p)]
+                ("loss_partials", C.c_void_p), ("totals", C.c_void_p),
+                ("norm_scratch", C.c_void_p), ("step_count", C.c_void_p), ("fuse_norm", C.c_int32), ("_pad", C.c_int32)]
 
 
 class MatStepArgs(C.Structure):
@@ -188,6 +189,8 @@ SIGNATURES = {
     "ppoaf_minibatch_moments": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int64, _ptr, _ptr]),
     "ppoaf_icm_update_fwd_bwd": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
     "ppoaf_icm_update_reduce": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
+    "ppoaf_adam_step_prenormed": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr, _ptr, C.c_float, C.c_float,
+                                            C.c_float, C.c_float, C.c_float, _ptr, _ptr, _ptr]),
     "ppoaf_mat_update_fwd_bwd": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
     "ppoaf_mat_update_reduce": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
     "ppoaf_mat_policy_step": (C.c_int, [C.POINTER(MatStepArgs), _ptr]),

@@ -100,3 +100,19 @@ extern "C" int ppoaf_clip_adam_step(float* params, const float* grads, float* ex
                        exp_avg, exp_avg_sq, (long)n, step_count, lr, a, norm_scratch, grad_norm_out);
     return check_launch("clip_adam_step/adam");
 }
+
+extern "C" int ppoaf_adam_step_prenormed(float* params, const float* grads, float* exp_avg,
+                                         float* exp_avg_sq, int64_t n, const int64_t* step_count,
+                                         const float* lr, float beta1, float beta2, float eps,
+                                         float grad_scale, float max_norm, const double* norm_scratch,
+                                         float* grad_norm_out, ppoaf_stream_t stream) {
+    PPOAF_REQUIRE(n >= 1, "adam_step_prenormed: n must be >= 1");
+    PPOAF_REQUIRE(params && grads && exp_avg && exp_avg_sq && step_count && lr && norm_scratch,
+                  "adam_step_prenormed: null pointer");
+    AdamParams a{beta1, beta2, eps, grad_scale, max_norm};
+    long blocks2 = (n + 255) / 256;
+    if (blocks2 > 2048) blocks2 = 2048;
+    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks2), dim3(256), 0, (hipStream_t)stream, params,
+                       grads, exp_avg, exp_avg_sq, (long)n, step_count, lr, a, norm_scratch, grad_norm_out);
+    return check_launch("adam_step_prenormed");
+}

@@ -51,6 +51,7 @@ struct MatDev {
     float* vn_mean; float* vn_var; double* vn_count; const double* vn_records; const double* adv_records;
     float surr_clip, entropy_weight, kl_loss_weight, huber_delta;
     float* loss_partials; double* totals;
+    double* norm_scratch; int64_t* step_count; int fuse_norm;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char mat_smem[];
@@ -518,6 +519,7 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     float* sDOutC = c.sDOutC; float* sDOutA = c.sDOutA;
     auto G = [&](int k) -> float* { return slab + u.off[k]; };
 
+    if (u.fuse_norm && g == 0 && tid == 192) u.norm_scratch[0] = 0.0;          // accumulated by the reduce launch
     // ---- rows, per-token scalars, mini-batch statistics
     if (tid < kRows) {
         int row = -1, act = 0;
@@ -930,14 +932,16 @@ __global__ __launch_bounds__(kMatRedThreads) void mat_update_reduce_kernel(MatDe
             u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
             u.totals[8] += 1.0;
             u.cursor[0] += 1;
+            if (u.fuse_norm) u.step_count[0] += 1;
         }
         return;
     }
+    __shared__ double red[17];
     const long n4 = u.total >> 2;
     const long idx = (long)blockIdx.x * kMatRedThreads + threadIdx.x;
-    if (idx >= n4) return;
     const float4* sl = reinterpret_cast<const float4*>(u.slabs);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < n4)
     for (int g0 = 0; g0 < u.nT; g0 += 8) {
         float4 v[8];
 #pragma unroll
@@ -946,7 +950,12 @@ __global__ __launch_bounds__(kMatRedThreads) void mat_update_reduce_kernel(MatDe
 #pragma unroll
         for (int k = 0; k < 8; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
     }
-    reinterpret_cast<float4*>(u.grads)[idx] = acc;
+    if (idx < n4) reinterpret_cast<float4*>(u.grads)[idx] = acc;
+    if (u.fuse_norm) {                                        // uniform per launch: every thread reaches the barriers
+        double q = (double)acc.x * acc.x + (double)acc.y * acc.y + (double)acc.z * acc.z + (double)acc.w * acc.w;
+        q = block_sum(q, red);
+        if (threadIdx.x == 0 && q != 0.0) atomicAdd(&u.norm_scratch[0], q);
+    }
 }
 
 static size_t mat_lds_bytes(int O) {
@@ -1010,6 +1019,8 @@ static int make_mat(const ppoaf_mat_update_args_t* a, MatDev& u) {
     u.vn_records = a->vn_records; u.adv_records = a->adv_records;
     u.surr_clip = a->surr_clip; u.entropy_weight = a->entropy_weight; u.kl_loss_weight = a->kl_loss_weight;
     u.huber_delta = a->huber_delta; u.loss_partials = a->loss_partials; u.totals = a->totals;
+    PPOAF_REQUIRE(!a->fuse_norm || (a->norm_scratch && a->step_count), "mat_update: fuse_norm needs norm_scratch and step_count");
+    u.norm_scratch = a->norm_scratch; u.step_count = a->step_count; u.fuse_norm = a->fuse_norm != 0;
     return PPOAF_OK;
 }
 

@@ -589,6 +589,9 @@ class FusedMatUpdate(FusedPolicyUpdate):
         a.surr_clip, a.entropy_weight = float(pol.surr_clip), float(pol.entropy_weight())
         a.kl_loss_weight, a.huber_delta = float(pol.kl_loss_weight), 10.0
         a.loss_partials, a.totals = self.loss_partials.data_ptr(), self.totals.data_ptr()
+        opt = pol.actor_critic_optim
+        a.norm_scratch, a.step_count = opt.norm_scratch.data_ptr(), opt.step_count.data_ptr()
+        a.fuse_norm = int(not self.multi)          # one rank: the reduce launch also yields ||g||^2 and the step count
         return a
 
     def begin_epoch(self, perm):
@@ -638,4 +641,13 @@ class FusedMatUpdate(FusedPolicyUpdate):
             _lib.check(rc, "mat_update")
         if self.multi:
             mpi_utils.allreduce_sum_(self.pol.policy_grads)
-        self.pol.optimizer_step(1.0 / self.world)
+            self.pol.optimizer_step(1.0 / self.world)
+            return
+        opt, ac = self.pol.actor_critic_optim, self.pol.actor_critic
+        clip = self.pol.gradient_clip
+        rc = lib.ppoaf_adam_step_prenormed(
+            ac.flat_params.data_ptr(), ac.flat_grads.data_ptr(), opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr(),
+            ac.flat_params.numel(), opt.step_count.data_ptr(), opt.lr.data_ptr(), opt.betas[0], opt.betas[1], opt.eps,
+            1.0, float(clip) if clip is not None else 0.0, opt.norm_scratch.data_ptr(), opt.grad_norm.data_ptr(), st)
+        if rc != 0:
+            _lib.check(rc, "adam_step_prenormed")
