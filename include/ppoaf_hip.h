@@ -546,6 +546,14 @@ typedef struct {
 
 int ppoaf_icm_update_fwd_bwd(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream);
 int ppoaf_icm_update_reduce(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream);
+/* Rollout-time intrinsic reward of a whole env batch (PPOPolicy.get_intrinsic_reward,
+ * policies/ppo_policy.py:954-1007 -> ICM.forward icm.py:375-430 without the inverse model):
+ * intr_out[i] = scale * sum_d (forward_model(enc(obs_i), action_i) - enc(next_obs_i))_d^2 with
+ * scale = intr_reward_weight * reward_scale / 2.  Uses the same args struct: obs / next_obs /
+ * actions hold the B = batch rows directly (perm NULL, fused_adam 0); params, topology and
+ * act_scratch as for the update; two launches (encoder for both observations, forward model). */
+int ppoaf_icm_intrinsic_reward(const ppoaf_icm_update_args_t* args, float scale, float* intr_out,
+                               ppoaf_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * K15  fused multi-agent-transformer mini-batch update

@@ -189,6 +189,7 @@ SIGNATURES = {
     "ppoaf_minibatch_moments": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int64, _ptr, _ptr]),
     "ppoaf_icm_update_fwd_bwd": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
     "ppoaf_icm_update_reduce": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
+    "ppoaf_icm_intrinsic_reward": (C.c_int, [C.POINTER(IcmUpdateArgs), C.c_float, _ptr, _ptr]),
     "ppoaf_adam_step_prenormed": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr, _ptr, C.c_float, C.c_float,
                                             C.c_float, C.c_float, C.c_float, _ptr, _ptr, _ptr]),
     "ppoaf_mat_update_fwd_bwd": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),

@@ -38,8 +38,12 @@ __device__ __forceinline__ void icm_rows(const IcmDev& u, int g, int tid, int* s
         const long s = (long)g * kRows + tid;
         int row = -1;
         if (s < u.B) {
-            const long p = u.perm[u.cursor[0] * u.batch_stride + s];
-            if (p >= 0 && p < u.n_rows) row = u.row_map ? u.row_map[p] : (int)p;
+            if (u.perm) {
+                const long p = u.perm[u.cursor[0] * u.batch_stride + s];
+                if (p >= 0 && p < u.n_rows) row = u.row_map ? u.row_map[p] : (int)p;
+            } else {
+                row = (int)s;                         // rollout-time reward: the batch is the env batch itself
+            }
         }
         sRow[tid] = row;
     }
@@ -403,6 +407,88 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// rollout-time intrinsic reward (ppo_policy.py:954-1007 -> icm.py:375-430 without the inverse model):
+// forward model on the encodings left in scratch by icm_encoder_fwd_kernel;
+// intr[row] = weight * (reward_scale / 2) * sum_d (pred - enc_2)^2.  One workgroup per 16 rows.
+// ------------------------------------------------------------------------------------------------
+template <int HT>
+__global__ __launch_bounds__(kThreadsU) void icm_reward_kernel(IcmDev u, float scale, float* __restrict__ intr_out) {
+    constexpr int H = 16 * HT, HS = H + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const int act = u.act, A = u.A, Ain = u.Ain, depth = u.d_fwd;
+    float* smem = reinterpret_cast<float*>(icm_smem);
+    float* sXa = smem;                                        // [16, kXS]
+    float* sE1 = sXa + kRows * kXS;                           // [16, HS]
+    float* sE2 = sE1 + kRows * HS;
+    float* sH = sE2 + kRows * HS;                             // 2 x [16, HS] ping-pong
+    for (int i = tid; i < kRows * kXS; i += kThreadsU) sXa[i] = 0.f;
+    for (int idx = tid; idx < 2 * kRows * (H / 4); idx += kThreadsU) {
+        const int e = idx / (kRows * (H / 4)), rem = idx - e * (kRows * (H / 4));
+        const int s = rem / (H / 4), c4 = rem - s * (H / 4);
+        const float4 v = *reinterpret_cast<const float4*>(
+            u.actE + (((long)(e * 4 + 3) * u.Bpad) + (long)g * kRows + s) * H + 4 * c4);
+        *reinterpret_cast<float4*>((e == 0 ? sE1 : sE2) + s * HS + 4 * c4) = v;
+    }
+    __syncthreads();
+    if (tid < kRows) {
+        const long row = (long)g * kRows + tid;
+        if (row < u.B) {
+            if (u.discrete) {
+                int a = (int)reinterpret_cast<const int64_t*>(u.actions)[row];
+                a = a < 0 ? 0 : (a >= A ? A - 1 : a);
+                sXa[tid * kXS + a] = 1.0f;
+            } else {
+                for (int d = 0; d < A; ++d) sXa[tid * kXS + d] = reinterpret_cast<const float*>(u.actions)[row * A + d];
+            }
+        }
+    }
+    __syncthreads();
+    const float* P = u.params + u.fwd_off;
+    const long ld0 = H + Ain;
+    auto offW = [&](int l) -> long { return l == 0 ? 0 : (long)H * ld0 + H + (long)(l - 1) * (H * H + H); };
+    auto offB = [&](int l) -> long { return offW(l) + (l == 0 ? (long)H * ld0 : (long)H * H); };
+    for (int nt = wave; nt < HT; nt += kNW) {
+        float4 fa[HT];
+        load_fwd_frags_ld<HT, false>(P, ld0, nt * 16, lane, fa);
+        const int o = nt * 16 + (lane & 15);
+        f32x4 acc = mfma_rows_x_frags<HT>(sE1, HS, lane, fa, P[offB(0) + o]);
+        const float* wrow = P + (long)o * ld0 + H;
+        const float* arow = sXa + (lane & 15) * kXS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * j + (lane >> 4);
+            const float bq = k < Ain ? wrow[k] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k], bq, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sH[(4 * (lane >> 4) + r) * HS + o] = act_fwd(acc[r], act);
+    }
+    __syncthreads();
+    float* cur = sH;
+    float* nxt = sH + kRows * HS;
+#pragma unroll 1
+    for (int l = 1; l <= depth; ++l) {                        // hidden layers, then the linear output layer
+        layer_fwd<HT, true>(P + offW(l), H, P + offB(l), cur, nxt, l < depth ? act : -1, wave, lane);
+        __syncthreads();
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    // row sums of (pred - enc_2)^2: 16 lanes per row
+    if (tid < 256) {
+        const int s = tid >> 4, part = tid & 15;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < HT; ++i) {
+            const float d = cur[s * HS + part + 16 * i] - sE2[s * HS + part + 16 * i];
+            acc = fmaf(d, d, acc);
+        }
+        acc = group16_sum(acc);
+        const long row = (long)g * kRows + s;
+        if (part == 0 && row < u.B) intr_out[row] = scale * acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // encoder backward: blockIdx.x = 2 * g + which (0: obs, 1: next_obs); slab index 2 * g + which
 // ------------------------------------------------------------------------------------------------
 template <int HT>
@@ -519,7 +605,7 @@ __global__ __launch_bounds__(kIcmRedThreads) void icm_reduce_kernel(IcmDev u) {
     }
 }
 
-static int make_icm(const ppoaf_icm_update_args_t* a, IcmDev& u) {
+static int make_icm(const ppoaf_icm_update_args_t* a, IcmDev& u, bool training = true) {
     PPOAF_REQUIRE(a, "icm_update: null args");
     PPOAF_REQUIRE(a->hidden == 64 || a->hidden == 128, "icm_update: hidden=%d is not an instantiated width (64, 128)", a->hidden);
     PPOAF_REQUIRE(a->obs_dim >= 1 && a->obs_dim <= 1024, "icm_update: obs_dim=%d", a->obs_dim);
@@ -529,14 +615,18 @@ static int make_icm(const ppoaf_icm_update_args_t* a, IcmDev& u) {
                   "icm_update: hidden depths (%d, %d) out of [1,3]", a->depth_inv, a->depth_fwd);
     PPOAF_REQUIRE(a->activation >= 0 && a->activation <= 2, "icm_update: activation=%d", a->activation);
     PPOAF_REQUIRE(a->B >= 1 && a->batch_stride >= a->B, "icm_update: B=%ld stride=%ld", (long)a->B, (long)a->batch_stride);
-    PPOAF_REQUIRE(a->params && a->grads && a->exp_avg && a->exp_avg_sq && a->slabs && a->step_count && a->lr &&
-                      a->obs && a->next_obs && a->actions && a->perm && a->cursor && a->act_scratch &&
-                      a->denc_scratch && a->loss_partials && a->totals,
-                  "icm_update: null pointer");
-    PPOAF_REQUIRE(((uintptr_t)a->params & 15) == 0 && ((uintptr_t)a->grads & 15) == 0 && ((uintptr_t)a->slabs & 15) == 0 &&
-                      ((uintptr_t)a->exp_avg & 15) == 0 && ((uintptr_t)a->exp_avg_sq & 15) == 0 &&
-                      ((uintptr_t)a->act_scratch & 15) == 0 && ((uintptr_t)a->denc_scratch & 15) == 0,
+    PPOAF_REQUIRE(a->params && a->obs && a->next_obs && a->actions && a->act_scratch, "icm_update: null pointer");
+    PPOAF_REQUIRE(((uintptr_t)a->params & 15) == 0 && ((uintptr_t)a->act_scratch & 15) == 0,
                   "icm_update: buckets and scratch must be 16-byte aligned");
+    if (training) {
+        PPOAF_REQUIRE(a->grads && a->exp_avg && a->exp_avg_sq && a->slabs && a->step_count && a->lr && a->perm &&
+                          a->cursor && a->denc_scratch && a->loss_partials && a->totals,
+                      "icm_update: null pointer");
+        PPOAF_REQUIRE(((uintptr_t)a->grads & 15) == 0 && ((uintptr_t)a->slabs & 15) == 0 &&
+                          ((uintptr_t)a->exp_avg & 15) == 0 && ((uintptr_t)a->exp_avg_sq & 15) == 0 &&
+                          ((uintptr_t)a->denc_scratch & 15) == 0,
+                      "icm_update: buckets and scratch must be 16-byte aligned");
+    }
     const long H = a->hidden, O = a->obs_dim, A = a->action_dim, Ain = a->fwd_action_dim;
     auto pad4 = [](long x) { return (x + 3) / 4 * 4; };
     const long enc_size = H * O + H + 3 * (H * H + H);
@@ -606,4 +696,30 @@ extern "C" int ppoaf_icm_update_reduce(const ppoaf_icm_update_args_t* args, ppoa
     hipLaunchKernelGGL(icm_reduce_kernel, dim3((unsigned)((n4 + kIcmRedThreads - 1) / kIcmRedThreads) + 1u),
                        dim3(kIcmRedThreads), 0, (hipStream_t)stream, u);
     return check_launch("icm_reduce");
+}
+
+template <int HT>
+static int launch_icm_reward(const IcmDev& u, float scale, float* intr_out, hipStream_t s) {
+    const size_t HS = 16 * HT + 4;
+    const size_t INP = 16 * ((u.O + 15) / 16) + 4;
+    const size_t lds_enc_f = (16 + kRows * INP + 4 * kRows * HS) * 4;
+    const size_t lds_rew = (kRows * kXS + 4 * kRows * HS) * 4;
+    PPOAF_REQUIRE(lds_enc_f <= 64 * 1024, "icm_intrinsic_reward: obs_dim too large for this build");
+    hipLaunchKernelGGL(icm_encoder_fwd_kernel<HT>, dim3(2u * (unsigned)u.nT), dim3(kThreadsU), lds_enc_f, s, u);
+    int rc = check_launch("icm_intrinsic_reward/encoder");
+    if (rc) return rc;
+    hipLaunchKernelGGL(icm_reward_kernel<HT>, dim3((unsigned)u.nT), dim3(kThreadsU), lds_rew, s, u, scale, intr_out);
+    return check_launch("icm_intrinsic_reward");
+}
+
+extern "C" int ppoaf_icm_intrinsic_reward(const ppoaf_icm_update_args_t* args, float scale, float* intr_out,
+                                          ppoaf_stream_t stream) {
+    IcmDev u;
+    const int rc = make_icm(args, u, false);
+    if (rc) return rc;
+    PPOAF_REQUIRE(intr_out, "icm_intrinsic_reward: null output");
+    PPOAF_REQUIRE(args->perm == nullptr && args->fused_adam == 0,
+                  "icm_intrinsic_reward: rows are the batch itself (perm must be NULL, fused_adam 0)");
+    if (u.H == 64) return launch_icm_reward<4>(u, scale, intr_out, (hipStream_t)stream);
+    return launch_icm_reward<8>(u, scale, intr_out, (hipStream_t)stream);
 }

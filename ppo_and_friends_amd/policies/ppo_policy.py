@@ -420,9 +420,44 @@ class PPOPolicy:
         act = self._to_device(action, adt)
         if act.dim() != 2:
             act = act.unsqueeze(1)
+        if obs_1.is_cuda and getattr(self, "fused_icm_reward", True):
+            fused = self._fused_intrinsic_reward(obs_1, obs_2, act)
+            if fused is not None:
+                return fused
         with torch.no_grad():
             intr, _, _ = self.icm_model(obs_1, obs_2, act)
         return intr.reshape(-1) * float(self.intr_reward_weight())
+
+    def _fused_intrinsic_reward(self, obs_1, obs_2, act):
+        """K14's encoder + forward-model kernels on the env batch (two launches); None when not covered."""
+        import ctypes as C
+        from .. import _lib
+        from .. import kernels as K
+        st = getattr(self, "_icm_reward_state", None)
+        n = obs_1.shape[0]
+        if st is None or st["n"] != n:
+            from ..fused_update import _describe_icm
+            topo, why = _describe_icm(self.icm_model, self.action_dtype)
+            if topo is None:
+                self.fused_icm_reward = False
+                return None
+            a = _lib.IcmUpdateArgs()
+            for k, v in topo.items():
+                setattr(a, k, v)
+            nT = (n + 15) // 16
+            scratch = torch.zeros(2, 4, 16 * nT, topo["hidden"], dtype=torch.float32, device=self.device)
+            a.params = self.icm_model.flat_params.data_ptr()
+            a.act_scratch = scratch.data_ptr()
+            a.B, a.batch_stride, a.n_rows, a.fused_adam = n, n, n, 0
+            st = self._icm_reward_state = dict(n=n, args=a, scratch=scratch)
+        a = st["args"]
+        obs_1, obs_2, act = obs_1.reshape(n, -1).contiguous(), obs_2.reshape(n, -1).contiguous(), act.contiguous()
+        a.obs, a.next_obs, a.actions = obs_1.data_ptr(), obs_2.data_ptr(), act.data_ptr()
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        scale = float(self.intr_reward_weight()) * float(self.icm_model.reward_scale) / 2.0
+        _lib.check(_lib.load().ppoaf_icm_intrinsic_reward(C.byref(a), scale, out.data_ptr(), K.stream()),
+                   "icm_intrinsic_reward")
+        return out
 
     def get_inference_actions(self, obs, deterministic):
         t_obs = self._to_device(obs)

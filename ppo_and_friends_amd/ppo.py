@@ -217,6 +217,7 @@ class PPO:
                     name=f"{policy_id}-value_normalizer", device=self.device)
         for pol in self.policies.values():
             pol.finalize(self.status_dict, self.device)
+            pol.fused_icm_reward = update_mode != "torch"       # K14's kernels for the rollout-time intrinsic reward
         self.soft_resets.finalize(self.status_dict)
         if callable(getattr(self.env, "finalize", None)):
             self.env.finalize(self.status_dict)          # status-driven clip ranges (filter_wrappers.py:560-566)
