@@ -100,6 +100,19 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
 
     if (g == 0 && which == 0 && tid == 0) { u.norm_scratch[0] = 0.0; u.norm_scratch[1] = 0.0; }
 
+    // Deep prefetch (three hidden layers, one output tile per wave): the weights depend on nothing, so the
+    // fragments of BOTH hidden-to-hidden layers are requested before anything else; as each set is consumed
+    // its registers are refilled with the dgrad fragments of the backward pass (W2 first, then W1).  Every
+    // weight load is then in flight for at least two phases -- including the cold first touch after the
+    // Adam kernel rewrote the bucket -- instead of one barrier.
+    const bool has_tile = wave < HT;          // waves beyond the tile count idle in MFMA phases (H < 128)
+    const bool deep = depth == 3 && HT <= kNW && !dbg;
+    float4 fr[HT], fr2[HT];
+    if (deep && has_tile) {
+        load_fwd_frags<HT>(P + offW(1), wave * 16, lane, fr);
+        load_fwd_frags<HT>(P + offW(2), wave * 16, lane, fr2);
+    }
+
     // The weights were rewritten by the Adam kernel a moment ago, so this XCD's L2 does not hold them:
     // the first touch of every 128-B line of the network is requested here, before anything else, so
     // the misses overlap the index / gather / first-layer phases instead of stalling the hidden layers.
@@ -191,9 +204,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
         }
     }
     // prefetch: fragments of the first hidden-to-hidden layer (or nothing if depth == 1)
-    float4 fr[HT];
-    const bool has_tile = wave < HT;          // waves beyond the tile count idle in MFMA phases (H < 128)
-    if (depth > 1 && has_tile) load_fwd_frags<HT>(P + offW(1), wave * 16, lane, fr, dbg);
+    if (!deep && depth > 1 && has_tile) load_fwd_frags<HT>(P + offW(1), wave * 16, lane, fr, dbg);
     __syncthreads();
     PPOAF_STAMP(2);
 
@@ -227,14 +238,25 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
         const float* Hp = sH + (long)(l - 1) * kRows * HS;
         float* Hc = sH + (long)l * kRows * HS;
         for (int nt = wave; nt < HT; nt += kNW) {
-            if (nt != wave) load_fwd_frags<HT>(P + offW(l), nt * 16, lane, fr, dbg);
             const int o = nt * 16 + (lane & 15);
+            f32x4 acc;
+            if (deep) {
+                if (l == 1) {
+                    acc = mfma_rows_x_frags<HT>(Hp, HS, lane, fr, sBias[l * H + o]);
+                    load_dgrad_frags<HT>(P + offW(2), wave * 16, lane, fr);      // first backward phase, two phases early
+                } else {
+                    acc = mfma_rows_x_frags<HT>(Hp, HS, lane, fr2, sBias[l * H + o]);
+                    load_dgrad_frags<HT>(P + offW(1), wave * 16, lane, fr2);     // second backward phase
+                }
+            } else {
+            if (nt != wave) load_fwd_frags<HT>(P + offW(l), nt * 16, lane, fr, dbg);
             if (l == 1) PPOAF_STAMP(10);
-            const f32x4 acc = (dbg & 2) ? f32x4{fr[0].x + fr[HT - 1].w, 0.f, 0.f, 0.f} : mfma_rows_x_frags<HT>(Hp, HS, lane, fr, sBias[l * H + o]);
+            acc = (dbg & 2) ? f32x4{fr[0].x + fr[HT - 1].w, 0.f, 0.f, 0.f} : mfma_rows_x_frags<HT>(Hp, HS, lane, fr, sBias[l * H + o]);
             if (l == 1) PPOAF_STAMP(11);
             if (nt + kNW >= HT) {                           // last tile of this wave in this layer
                 if (l + 1 < depth) load_fwd_frags<HT>(P + offW(l + 1), wave * 16, lane, fr, dbg);
                 else load_dgrad_frags<HT>(P + offW(l), wave * 16, lane, fr, dbg);   // first backward phase
+            }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) Hc[(4 * (lane >> 4) + r) * HS + o] = act_fwd(acc[r], act);
@@ -475,9 +497,14 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
         const float* Hin = sH + (long)(l - 1) * kRows * HS;
         // dgrad first (its operands were prefetched): dh[s][i] = sum_o dz[s][o] * W[o][i]
         for (int nt = wave; nt < HT; nt += kNW) {
+            f32x4 acc;
+            if (deep) {
+                acc = l == 2 ? mfma_rows_x_frags<HT>(Dc, HS, lane, fr, 0.f) : mfma_rows_x_frags<HT>(Dc, HS, lane, fr2, 0.f);
+            } else {
             if (nt != wave) load_dgrad_frags<HT>(P + offW(l), nt * 16, lane, fr, dbg);
-            const f32x4 acc = (dbg & 2) ? f32x4{fr[0].x + fr[HT - 1].w, 0.f, 0.f, 0.f} : mfma_rows_x_frags<HT>(Dc, HS, lane, fr, 0.f);
+            acc = (dbg & 2) ? f32x4{fr[0].x + fr[HT - 1].w, 0.f, 0.f, 0.f} : mfma_rows_x_frags<HT>(Dc, HS, lane, fr, 0.f);
             if (nt + kNW >= HT && l - 1 >= 1) load_dgrad_frags<HT>(P + offW(l - 1), wave * 16, lane, fr, dbg);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int s = 4 * (lane >> 4) + r, i = nt * 16 + (lane & 15);
