@@ -112,6 +112,14 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
         load_fwd_frags<HT>(P + offW(1), wave * 16, lane, fr);
         load_fwd_frags<HT>(P + offW(2), wave * 16, lane, fr2);
     }
+    // first layer with at most 16 inputs: its 4 weight values per lane are requested here as well
+    const bool l0_pre = in_dim <= 16 && HT <= kNW && has_tile && !dbg;
+    float l0w[4] = {0.f, 0.f, 0.f, 0.f};
+    if (l0_pre) {
+        const float* w = P + offW(0) + (long)(wave * 16 + (lane & 15)) * in_dim;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int k = 4 * j + (lane >> 4); if (k < in_dim) l0w[j] = w[k]; }
+    }
 
     // The weights were rewritten by the Adam kernel a moment ago, so this XCD's L2 does not hold them:
     // the first touch of every 128-B line of the network is requested here, before anything else, so
@@ -221,7 +229,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = k0 + 4 * j + (lane >> 4);
-                bq[j] = k < in_dim ? w[k] : 0.f;
+                bq[j] = l0_pre ? l0w[j] : (k < in_dim ? w[k] : 0.f);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)

@@ -156,7 +156,7 @@ class FusedPolicyUpdate:
         a.raw_actions = buf.raw_actions.data_ptr()
         a.advantages = buf.advantages.data_ptr(); a.old_log_probs = buf.log_probs.data_ptr()
         a.rewards_to_go = buf.rewards_to_go.data_ptr(); a.values = buf.values.data_ptr()
-        a.perm = self.perm.data_ptr(); a.row_map = buf.row_map.data_ptr()
+        a.perm = self.rows.data_ptr(); a.row_map = None      # rows = row_map[perm], resolved once per epoch
         a.n_rows = buf.num_transitions
         a.cursor = self.cursor.data_ptr()
         a.B = B; a.batch_stride = self.B
@@ -175,7 +175,7 @@ class FusedPolicyUpdate:
     def _signature(self):
         """Everything baked into captured launches; a change re-captures."""
         pol, buf = self.pol, self.pol.buffer
-        return (buf.observations.data_ptr(), buf.num_transitions, self.perm.data_ptr(),
+        return (buf.observations.data_ptr(), buf.num_transitions, self.rows.data_ptr(),
                 None if self.records is None else self.records.data_ptr(),
                 None if self.adv_records is None else self.adv_records.data_ptr(),
                 float(pol.entropy_weight()), float(pol.surr_clip), float(pol.kl_loss_weight),
@@ -191,6 +191,12 @@ class FusedPolicyUpdate:
             self.perm = torch.empty(N, dtype=torch.int64, device=pol.device)
             self._graphs.clear()
         self.perm.copy_(perm)
+        # one dependent load less per mini-batch: the kernels read the buffer row directly
+        if getattr(self, "rows", None) is None or self.rows.numel() != N:
+            self.rows = torch.empty(N, dtype=torch.int64, device=pol.device)
+            self._graphs.clear()
+        torch.index_select(buf.row_map, 0, self.perm, out=self._rows32(N))
+        self.rows.copy_(self._rows32(N))
         nb = (N + self.B - 1) // self.B
         if ppo.normalize_values:
             local = K.minibatch_moments(buf.rewards_to_go.view(-1), self.perm, buf.row_map, self.B)
@@ -219,6 +225,12 @@ class FusedPolicyUpdate:
             self._graphs.clear()
         self.n_full, self.tail = N // self.B, N % self.B
         self.n_done = 0
+
+    def _rows32(self, N):
+        t = getattr(self, "_rows_i32", None)
+        if t is None or t.numel() != N:
+            t = self._rows_i32 = torch.empty(N, dtype=torch.int32, device=self.pol.device)
+        return t
 
     def _args_for(self, B):
         if B not in self._args:
@@ -251,7 +263,7 @@ class FusedPolicyUpdate:
         args = self._args_for(self.B)
         left = self.n_full
         use_graph = self.ppo.use_graphs and not self.multi
-        chunk = self.graph_chunk
+        chunk = self.graph_chunk if self.n_full < 8 * self.graph_chunk else 4 * self.graph_chunk   # long epochs: fewer, longer graphs
         while left > 0:
             if use_graph and left >= chunk:
                 g = self._graphs.get(chunk)
@@ -437,7 +449,7 @@ class FusedIcmUpdate:
         args = self._args_for(self.B)
         left = self.n_full
         use_graph = self.ppo.use_graphs and not self.multi
-        chunk = self.graph_chunk
+        chunk = self.graph_chunk if self.n_full < 8 * self.graph_chunk else 4 * self.graph_chunk   # long epochs: fewer, longer graphs
         while left > 0:
             if use_graph and left >= chunk:
                 g = self._graphs.get(chunk)
