@@ -356,9 +356,19 @@ typedef struct {
     const double* adv_records;
     /* loss */
     int32_t normalize_adv, use_huber;
-    float surr_clip, entropy_weight, kl_loss_weight, huber_delta, min_std, _pad2;
+    float surr_clip, entropy_weight, kl_loss_weight, huber_delta, min_std;
+    /* 1: obs / critic_obs / raw_actions / advantages / old_log_probs / rewards_to_go are per-epoch
+     * tables already in shuffled order (entry i belongs to perm[i]), so a mini-batch reads
+     * [k * batch_stride, +B) directly -- no index -> data dependent load; `values` is still
+     * written through perm / row_map.  0: they are the rollout buffer's rows. */
+    int32_t inputs_in_batch_order;
     float* loss_partials;         /* [2, n_wg, 8]                                          */
     double* totals;               /* [9] sums of the 8 loss scalars + mini-batch count     */
+    /* mini-batch index = *cursor + mb_offset; the Adam launch adds cursor_advance to *cursor.
+     * Eager use: (0, 1).  A captured chain of n mini-batches bakes mb_offset = 0..n-1 into its nodes
+     * and advances the cursor once, by n, in the last one: the cursor word is then rewritten once per
+     * chain instead of once per mini-batch, so all but the first read of it hit the reader's L2. */
+    int64_t mb_offset, cursor_advance;
 } ppoaf_ppo_update_args_t;
 
 int ppoaf_ppo_update_fwd_bwd(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t stream);

@@ -53,8 +53,9 @@ class PpoUpdateArgs(C.Structure):
                 ("normalize_adv", C.c_int32), ("use_huber", C.c_int32),
                 ("surr_clip", C.c_float), ("entropy_weight", C.c_float),
                 ("kl_loss_weight", C.c_float), ("huber_delta", C.c_float),
-                ("min_std", C.c_float), ("_pad2", C.c_float),
-                ("loss_partials", C.c_void_p), ("totals", C.c_void_p)]
+                ("min_std", C.c_float), ("inputs_in_batch_order", C.c_int32),
+                ("loss_partials", C.c_void_p), ("totals", C.c_void_p),
+                ("mb_offset", C.c_int64), ("cursor_advance", C.c_int64)]
 
 
 class PolicyStepArgs(C.Structure):

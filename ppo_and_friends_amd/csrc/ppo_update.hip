@@ -26,11 +26,11 @@ struct UpdateDev {
     const float* obs; const float* critic_obs; const void* raw_actions;
     const float* adv; const float* old_lp; const float* rtg; float* values;
     const int64_t* perm; const int32_t* row_map; long n_rows;
-    int64_t* cursor; long B, batch_stride;
+    int64_t* cursor; long B, batch_stride, mb_offset, cursor_advance;
     int normalize_values, n_ranks;
     float* vn_mean; float* vn_var; double* vn_count; const double* vn_records;
     const double* adv_records;
-    int normalize_adv, use_huber;
+    int normalize_adv, use_huber, pregathered;
     float surr_clip, entropy_weight, kl_loss_weight, huber_delta, min_std;
     float* loss_partials; double* totals;
     int n_wg;
@@ -67,7 +67,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
     const float* P = u.params + nd.offset;
     float* slab = u.slabs + (long)g * u.bucket_total + nd.offset;
     const long B = u.B;
-    const long mb = u.cursor[0];
+    const long mb = u.cursor[0] + u.mb_offset;
     const long base = mb * u.batch_stride;
 #ifdef PPOAF_STAMPS
     const int dbg = u.debug;
@@ -125,33 +125,55 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
     // the first touch of every 128-B line of the network is requested here, before anything else, so
     // the misses overlap the index / gather / first-layer phases instead of stalling the hidden layers.
     float l2_touch = 0.f;
-    for (long i = (long)tid * 32; i < nd.size; i += (long)kThreadsU * 32) l2_touch += P[i];
+    if (!deep) for (long i = (long)tid * 32; i < nd.size; i += (long)kThreadsU * 32) l2_touch += P[i];
 
-    // ---- S0: everything that does not depend on the rows is requested first: rows / statistics,
-    //      biases + output weights -> LDS, and this wave's first-layer weight fragments -> registers.
+    // biases and output-layer weights: requested into registers now, stored to LDS after the row loads
+    // below have been issued too -- one wait covers all of them (a store in between would serialise
+    // the cold misses: this bucket was rewritten by the Adam kernel a moment ago)
+    constexpr int kCopyRegs = 4;                          // (depth + 1) * H and out_dim * H are <= 4 * threads
+    float bias_reg[kCopyRegs], wout_reg[kCopyRegs];
+    const int n_bias = (depth + 1) * H, n_wout = out_dim * H;
+    const bool copy_fits = n_bias <= kCopyRegs * kThreadsU && n_wout <= kCopyRegs * kThreadsU;
+    if (copy_fits) {
+#pragma unroll
+        for (int r = 0; r < kCopyRegs; ++r) {
+            const int i = tid + r * kThreadsU;
+            bias_reg[r] = 0.f; wout_reg[r] = 0.f;
+            if (i < n_bias) { const int l = i / H, j = i - l * H; if (l < depth || j < out_dim) bias_reg[r] = P[offB(l) + j]; }
+            if (i < n_wout) wout_reg[r] = P[offW(depth) + i];
+        }
+    }
+
     if (tid < kRows) {
         const long s = (long)g * kRows + tid;
         int row = -1;
+        long di = -1;                                      // where this row's inputs are read from
         if (s < B) {
             long p = (dbg & 32) ? (base + s) : u.perm[base + s];
             if (p >= 0 && p < u.n_rows) row = (u.row_map && !(dbg & 32)) ? u.row_map[p] : (int)p;
+            // per-epoch tables in shuffled order: the address depends on the cursor only, so these loads
+            // go out together with the perm load instead of after it
+            di = u.pregathered ? base + s : row;
         }
-        sRow[tid] = row;
         float av = 0.f, lpo = 0.f, rt = 0.f;
-        if (row >= 0 && !(dbg & 64)) {
+        if (di >= 0 && !(dbg & 64)) {
             if (which == 0) {
-                av = u.adv[row]; lpo = u.old_lp[row];
+                av = u.adv[di]; lpo = u.old_lp[di];
                 if (u.head_kind == PPOAF_HEAD_CATEGORICAL)
-                    reinterpret_cast<int*>(sActF)[tid * 8] = (int)reinterpret_cast<const int64_t*>(u.raw_actions)[row];
+                    reinterpret_cast<int*>(sActF)[tid * 8] = (int)reinterpret_cast<const int64_t*>(u.raw_actions)[di];
                 else
                     for (int d = 0; d < out_dim; ++d)
-                        sActF[tid * 8 + d] = reinterpret_cast<const float*>(u.raw_actions)[(long)row * out_dim + d];
+                        sActF[tid * 8 + d] = reinterpret_cast<const float*>(u.raw_actions)[(long)di * out_dim + d];
             } else {
-                rt = u.rtg[row];
+                rt = u.rtg[di];
             }
         }
+        sRow[tid] = row;
         sRowF[tid] = av; sRowF[16 + tid] = lpo; sRowF[32 + tid] = rt;
     }
+
+    // ---- S0: everything that does not depend on the rows is requested first: rows / statistics,
+    //      biases + output weights -> LDS, and this wave's first-layer weight fragments -> registers.
     if (tid == 64) {                                        // a lane of wave 1: mini-batch statistics
         if (which == 0) {
             float mean_f = 0.f, std_f = 1.f;
@@ -192,12 +214,21 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
             if (g == 0) { u.vn_mean[slot ^ 1] = m; u.vn_var[slot ^ 1] = v; u.vn_count[slot ^ 1] = cnt; }
         }
     }
-    for (int l = 0; l <= depth; ++l) {
-        const int n = (l == depth) ? out_dim : H;
-        const float* bb = P + offB(l);
-        for (int i = tid; i < n; i += kThreadsU) sBias[l * H + i] = bb[i];
+    if (copy_fits) {
+#pragma unroll
+        for (int r = 0; r < kCopyRegs; ++r) {
+            const int i = tid + r * kThreadsU;
+            if (i < n_bias) sBias[i] = bias_reg[r];
+            if (i < n_wout) sWout[i] = wout_reg[r];
+        }
+    } else {
+        for (int l = 0; l <= depth; ++l) {
+            const int n = (l == depth) ? out_dim : H;
+            const float* bb = P + offB(l);
+            for (int i = tid; i < n; i += kThreadsU) sBias[l * H + i] = bb[i];
+        }
+        for (int i = tid; i < out_dim * H; i += kThreadsU) sWout[i] = P[offW(depth) + i];
     }
-    for (int i = tid; i < out_dim * H; i += kThreadsU) sWout[i] = P[offW(depth) + i];
     for (int i = tid; i < kRows * INP; i += kThreadsU) sX[i] = 0.f;
     __syncthreads();
     PPOAF_STAMP(1);
@@ -208,7 +239,8 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
         for (int idx = tid; idx < kRows * in_dim; idx += kThreadsU) {
             const int s = idx / in_dim, i = idx - s * in_dim;
             const int row = sRow[s];
-            if (row >= 0) sX[s * INP + i] = src[(long)row * in_dim + i];
+            const long di = u.pregathered ? base + (long)g * kRows + s : row;
+            if (row >= 0) sX[s * INP + i] = src[di * in_dim + i];
         }
     }
     // prefetch: fragments of the first hidden-to-hidden layer (or nothing if depth == 1)
@@ -693,7 +725,7 @@ __global__ __launch_bounds__(256) void ppo_update_adam_kernel(UpdateDev u) {
         reinterpret_cast<float4*>(u.exp_avg)[idx] = m;
         reinterpret_cast<float4*>(u.exp_avg_sq)[idx] = v;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) u.cursor[0] += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && u.cursor_advance) u.cursor[0] += u.cursor_advance;
 }
 
 // (n, mean, M2) of every mini-batch's rewards-to-go: one workgroup per mini-batch
@@ -785,12 +817,13 @@ static int make_dev(const ppoaf_ppo_update_args_t* a, UpdateDev& u) {
     u.obs = a->obs; u.critic_obs = a->critic_obs; u.raw_actions = a->raw_actions; u.adv = a->advantages;
     u.old_lp = a->old_log_probs; u.rtg = a->rewards_to_go; u.values = a->values; u.perm = a->perm;
     u.row_map = a->row_map; u.n_rows = a->n_rows; u.cursor = a->cursor; u.B = a->B;
-    u.batch_stride = a->batch_stride; u.normalize_values = a->normalize_values; u.n_ranks = a->n_ranks;
+    u.batch_stride = a->batch_stride; u.mb_offset = a->mb_offset; u.cursor_advance = a->cursor_advance;
+    u.normalize_values = a->normalize_values; u.n_ranks = a->n_ranks;
     u.vn_mean = a->vn_mean; u.vn_var = a->vn_var; u.vn_count = a->vn_count; u.vn_records = a->vn_records;
     u.adv_records = a->adv_records;
     u.normalize_adv = a->normalize_adv; u.use_huber = a->use_huber; u.surr_clip = a->surr_clip;
     u.entropy_weight = a->entropy_weight; u.kl_loss_weight = a->kl_loss_weight;
-    u.huber_delta = a->huber_delta; u.min_std = a->min_std; u.loss_partials = a->loss_partials;
+    u.huber_delta = a->huber_delta; u.min_std = a->min_std; u.pregathered = a->inputs_in_batch_order != 0; u.loss_partials = a->loss_partials;
     u.totals = a->totals;
     u.n_wg = (int)((a->B + kRows - 1) / kRows);
     u.debug = 0;

@@ -152,10 +152,13 @@ class FusedPolicyUpdate:
         a.grad_scale = 1.0 / self.world
         a.max_norm = float(pol.gradient_clip) if pol.gradient_clip is not None else 0.0
         a.head_kind = self.head
-        a.obs = buf.observations.data_ptr(); a.critic_obs = buf.critic_observations.data_ptr()
-        a.raw_actions = buf.raw_actions.data_ptr()
-        a.advantages = buf.advantages.data_ptr(); a.old_log_probs = buf.log_probs.data_ptr()
-        a.rewards_to_go = buf.rewards_to_go.data_ptr(); a.values = buf.values.data_ptr()
+        # inputs come from the per-epoch tables in shuffled order (begin_epoch): no index -> data dependent load
+        t = self.tables
+        a.obs = t["obs"].data_ptr(); a.critic_obs = t["critic_obs"].data_ptr()
+        a.raw_actions = t["raw_actions"].data_ptr()
+        a.advantages = t["advantages"].data_ptr(); a.old_log_probs = t["log_probs"].data_ptr()
+        a.rewards_to_go = t["rewards_to_go"].data_ptr(); a.values = buf.values.data_ptr()
+        a.inputs_in_batch_order = 1
         a.perm = self.rows.data_ptr(); a.row_map = None      # rows = row_map[perm], resolved once per epoch
         a.n_rows = buf.num_transitions
         a.cursor = self.cursor.data_ptr()
@@ -170,12 +173,13 @@ class FusedPolicyUpdate:
         a.kl_loss_weight = float(pol.kl_loss_weight); a.huber_delta = 10.0
         a.min_std = float(getattr(pol.actor.distribution, "min_std", 0.01))
         a.loss_partials = self.loss_partials.data_ptr(); a.totals = self.totals.data_ptr()
+        a.mb_offset, a.cursor_advance = 0, 1
         return a
 
     def _signature(self):
         """Everything baked into captured launches; a change re-captures."""
         pol, buf = self.pol, self.pol.buffer
-        return (buf.observations.data_ptr(), buf.num_transitions, self.rows.data_ptr(),
+        return (buf.observations.data_ptr(), buf.num_transitions, self.rows.data_ptr(), self.tables["obs"].data_ptr(),
                 None if self.records is None else self.records.data_ptr(),
                 None if self.adv_records is None else self.adv_records.data_ptr(),
                 float(pol.entropy_weight()), float(pol.surr_clip), float(pol.kl_loss_weight),
@@ -197,6 +201,7 @@ class FusedPolicyUpdate:
             self._graphs.clear()
         torch.index_select(buf.row_map, 0, self.perm, out=self._rows32(N))
         self.rows.copy_(self._rows32(N))
+        self._gather_epoch_tables(N)
         nb = (N + self.B - 1) // self.B
         if ppo.normalize_values:
             local = K.minibatch_moments(buf.rewards_to_go.view(-1), self.perm, buf.row_map, self.B)
@@ -225,6 +230,20 @@ class FusedPolicyUpdate:
             self._graphs.clear()
         self.n_full, self.tail = N // self.B, N % self.B
         self.n_done = 0
+
+    def _gather_epoch_tables(self, N):
+        """K4 over the whole epoch: every input field of the update in shuffled order (one launch)."""
+        buf = self.pol.buffer
+        flat = lambda x: x.view((buf.num_transitions,) + tuple(x.shape[2:]))
+        fields = dict(obs=buf.observations, critic_obs=buf.critic_observations, raw_actions=buf.raw_actions,
+                      advantages=buf.advantages, log_probs=buf.log_probs, rewards_to_go=buf.rewards_to_go)
+        t = getattr(self, "tables", None)
+        if t is None or t["advantages"].shape[0] != N:
+            t = self.tables = {k: torch.empty((N,) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)
+                               for k, v in fields.items()}
+            self._graphs.clear()
+            self._args = {}
+        K.minibatch_gather([(flat(v), t[k]) for k, v in fields.items()], self.perm, buf.row_map)
 
     def _rows32(self, N):
         t = getattr(self, "_rows_i32", None)
@@ -256,8 +275,14 @@ class FusedPolicyUpdate:
             _lib.check(rc, "ppo_update")
 
     def _chunk(self, args, n):
-        for _ in range(n):
-            self._one(args)
+        """n consecutive mini-batches with their index baked in: one cursor update for the whole chain."""
+        try:
+            for j in range(n):
+                args.mb_offset = j
+                args.cursor_advance = n if j == n - 1 else 0
+                self._one(args)
+        finally:
+            args.mb_offset, args.cursor_advance = 0, 1
 
     def run_epoch(self):
         args = self._args_for(self.B)

@@ -8,7 +8,7 @@ from ppo_and_friends_amd.spaces import Box, Discrete
 dev=torch.device('cuda',0); E,T,O=4096,128,4
 env_gen=lambda: SyntheticFixedLengthEnv(E,O,Discrete(2),T,dev)
 sp=Box(-np.inf,np.inf,(O,),np.float32)
-ppo=PPO(env_gen,{"p":(None,sp,sp,Discrete(2),{})},device=dev,random_seed=1,envs_per_proc=E,ts_per_rollout=T,batch_size=256,epochs_per_iter=1,use_graphs=False)
+ppo=PPO(env_gen,{"p":(None,sp,sp,Discrete(2),{})},device=dev,random_seed=1,normalize_obs=False,normalize_rewards=False,envs_per_proc=E,ts_per_rollout=T,batch_size=256,epochs_per_iter=1,use_graphs=False)
 ppo.rollout(); pol=ppo.policies["p"]
 loader=PermutationLoader(pol.dataset,256,ppo.loader_generator)
 f=ppo._fused_updater("p",256); f.begin_epoch(loader.epoch_permutation())
