@@ -131,6 +131,35 @@ __device__ __forceinline__ void wgrad_mtile(const float* __restrict__ D, int HS,
     }
 }
 
+// The same for a full [*, 16 * NT] gradient block with a compile-time tile count: all B operands are read
+// from LDS up front and the NT accumulation chains (4 dependent MFMAs each) are issued interleaved, so the
+// matrix pipe is never waiting on an LDS read or on its own previous result.
+template <int NT>
+__device__ __forceinline__ void wgrad_mtile_full(const float* __restrict__ D, int HS, const float* __restrict__ Bsrc,
+                                                 int strideB, int m0, int lane, float* __restrict__ dstW, int ldw) {
+    float a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = D[(4 * (lane >> 4) + j) * HS + m0 + (lane & 15)];
+    const float* bcol = Bsrc + (4 * (lane >> 4)) * strideB + (lane & 15);
+    float b[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[nt][j] = bcol[j * strideB + 16 * nt];
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[nt][j], acc[nt], 0, 0, 0);
+    float* drow = dstW + (long)(m0 + 4 * (lane >> 4)) * ldw + (lane & 15);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) drow[(long)r * ldw + 16 * nt] = acc[nt][r];
+}
+
 constexpr int kNW = 8;                    // waves per workgroup of the fused update kernels
 constexpr int kThreadsU = 64 * kNW;
 

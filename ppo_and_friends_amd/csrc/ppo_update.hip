@@ -336,60 +336,67 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
                 av = sRowF[s]; lpo = sRowF[16 + s];
                 if (u.normalize_adv) av = (av - sMisc[0]) / (sMisc[1] + 1e-8f);
             }
-            if (live && u.head_kind == PPOAF_HEAD_CATEGORICAL) {
-                float p[8];
-                float m = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) if (k < out_dim) m = fmaxf(m, sOut[s * kMaxOut + k]);
-                float ssum = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { p[k] = k < out_dim ? expf(sOut[s * kMaxOut + k] - m) : 0.f; ssum += p[k]; }
-                const float inv = 1.0f / ssum;
-                float s2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { p[k] *= inv; s2 += p[k]; }
-                int a = reinterpret_cast<const int*>(sActF)[s * 8];
-                a = a < 0 ? 0 : (a >= out_dim ? out_dim - 1 : a);
-                float nk8[8], lg8[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    nk8[k] = p[k] / s2;                          // Categorical's renormalisation
-                    lg8[k] = k < out_dim ? logf(clamp_prob_u(nk8[k])) : 0.f;
-                    if (k < out_dim) ent -= nk8[k] * lg8[k];
-                    if (k == a) logp = lg8[k];
+            if (u.head_kind == PPOAF_HEAD_CATEGORICAL) {
+                // lane-parallel: 4 lanes per row, lane (s4, q) owns classes q and q + 4; the class
+                // reductions are two xor-shuffles inside the 4-lane group, so the transcendental chain
+                // is 2 values long instead of 8.  Row results are handed to lane s4 at the end.
+                const int s4 = lane >> 2, q = lane & 3;
+                const bool live4 = sRow[s4] >= 0;
+                float av4 = 0.f, lpo4 = 0.f;
+                if (live4) {
+                    av4 = sRowF[s4]; lpo4 = sRowF[16 + s4];
+                    if (u.normalize_adv) av4 = (av4 - sMisc[0]) / (sMisc[1] + 1e-8f);
                 }
-                const float ratio = expf(logp - lpo);
-                if (isnan(ratio) || isinf(ratio)) part[7] = 1.f;
+                auto rsum = [](float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); return v; };
+                auto rmax = [](float v) { v = fmaxf(v, __shfl_xor(v, 1, 64)); return fmaxf(v, __shfl_xor(v, 2, 64)); };
+                const int k0 = q, k1 = q + 4;
+                const bool v0 = k0 < out_dim, v1 = k1 < out_dim;
+                const float z0 = v0 ? sOut[s4 * kMaxOut + k0] : -INFINITY, z1 = v1 ? sOut[s4 * kMaxOut + k1] : -INFINITY;
+                const float m = rmax(fmaxf(z0, z1));
+                float p0 = v0 ? expf(z0 - m) : 0.f, p1 = v1 ? expf(z1 - m) : 0.f;
+                const float inv = 1.0f / rsum(p0 + p1);
+                p0 *= inv; p1 *= inv;
+                const float s2 = rsum(p0 + p1);
+                int a = reinterpret_cast<const int*>(sActF)[s4 * 8];
+                a = a < 0 ? 0 : (a >= out_dim ? out_dim - 1 : a);
+                const float n0 = p0 / s2, n1 = p1 / s2;                          // Categorical's renormalisation
+                const float l0 = v0 ? logf(clamp_prob_u(n0)) : 0.f, l1 = v1 ? logf(clamp_prob_u(n1)) : 0.f;
+                const float ent4 = -rsum((v0 ? n0 * l0 : 0.f) + (v1 ? n1 * l1 : 0.f));
+                const float logp4 = rsum((k0 == a ? l0 : 0.f) + (k1 == a ? l1 : 0.f));
+                const float ratio = expf(logp4 - lpo4);
+                const float bad4 = (isnan(ratio) || isinf(ratio)) ? 1.f : 0.f;
                 const float lo = 1.0f - u.surr_clip, hi = 1.0f + u.surr_clip;
-                const float surr1 = ratio * av, surr2 = fminf(fmaxf(ratio, lo), hi) * av;
-                part[0] = -fminf(surr1, surr2);
-                part[3] = ent;
-                part[4] = lpo - logp;
+                const float surr1 = ratio * av4, surr2 = fminf(fmaxf(ratio, lo), hi) * av4;
                 float glp;
-                if (surr1 <= surr2) glp = -av * ratio;
-                else glp = (ratio >= lo && ratio <= hi) ? -av * ratio : 0.f;
+                if (surr1 <= surr2) glp = -av4 * ratio;
+                else glp = (ratio >= lo && ratio <= hi) ? -av4 * ratio : 0.f;
                 glp *= inv_B;
                 const float gH = (u.entropy_weight != 0.0f) ? -u.entropy_weight * inv_B : 0.f;
                 // chain: z -softmax-> p -(/sum)-> n -clamp,log-> l
-                float gn[8];
-                float dot = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float gk = 0.f;
-                    if (k < out_dim) {
-                        const float nk = nk8[k], ck = clamp_prob_u(nk);
-                        const float in_range = (nk >= FLT_EPSILON && nk <= 1.0f - FLT_EPSILON) ? 1.f : 0.f;
-                        gk = gH * (-lg8[k] - nk * in_range / ck);
-                        if (k == a) gk += glp * in_range / ck;
-                        dot += gk * nk;
-                    }
-                    gn[k] = gk;
+                auto gk_of = [&](bool valid, int k, float nk, float lg) {
+                    if (!valid) return 0.f;
+                    const float ck = clamp_prob_u(nk);
+                    const float in_range = (nk >= FLT_EPSILON && nk <= 1.0f - FLT_EPSILON) ? 1.f : 0.f;
+                    float gk = gH * (-lg - nk * in_range / ck);
+                    if (k == a) gk += glp * in_range / ck;
+                    return gk;
+                };
+                float g0 = gk_of(v0, k0, n0, l0), g1 = gk_of(v1, k1, n1, l1);
+                const float dot = rsum(g0 * n0 + g1 * n1);
+                g0 = (g0 - dot) / s2; g1 = (g1 - dot) / s2;
+                const float dot2 = rsum(g0 * p0 + g1 * p1);
+                if (live4) {
+                    if (k0 < 8) sDOut[s4 * kMaxOut + k0] = p0 * (g0 - dot2);
+                    sDOut[s4 * kMaxOut + k1] = p1 * (g1 - dot2);
+                } else {
+                    sDOut[s4 * kMaxOut + k0] = 0.f; sDOut[s4 * kMaxOut + k1] = 0.f;
+                    if (q == 0) for (int k2 = 8; k2 < kMaxOut; ++k2) sDOut[s4 * kMaxOut + k2] = 0.f;
                 }
-                float dot2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { gn[k] = (gn[k] - dot) / s2; dot2 += gn[k] * p[k]; }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) sDOut[s * kMaxOut + k] = p[k] * (gn[k] - dot2);
+                // row results -> lane s (= row s) for the partial sums below
+                const int src = (lane & 15) * 4;
+                const float r_surr = __shfl(-fminf(surr1, surr2), src, 64), r_ent = __shfl(ent4, src, 64);
+                const float r_kl = __shfl(lpo4 - logp4, src, 64), r_bad = __shfl(bad4, src, 64);
+                if (live) { part[0] = r_surr; part[3] = r_ent; part[4] = r_kl; part[7] = r_bad; }
             } else if (live) {
                 // tanh-Gaussian (distributions.py:441-694)
                 const float* log_std = P + nd.log_std_off;
@@ -553,8 +560,10 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
         }
         // wgrad: dW[o][i] = sum_s dz[s][o] * Hin[s][i]
         if (!(dbg & 4))
-        for (int mt = wave; mt < HT; mt += kNW)
-            wgrad_mtile(Dc, HS, Hin, HS, mt * 16, HT, H, lane, slab + offW(l), H);
+        for (int mt = wave; mt < HT; mt += kNW) {
+            if (HT <= 8) wgrad_mtile_full<(HT <= 8 ? HT : 1)>(Dc, HS, Hin, HS, mt * 16, lane, slab + offW(l), H);
+            else wgrad_mtile(Dc, HS, Hin, HS, mt * 16, HT, H, lane, slab + offW(l), H);
+        }
         for (int o = tid; o < H; o += kThreadsU) {
             float acc = 0.f;
 #pragma unroll
