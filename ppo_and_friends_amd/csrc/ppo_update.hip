@@ -42,10 +42,13 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ppo_update_smem[];
 // Diagnostic build only (-DPPOAF_STAMPS): s_memtime per phase of workgroup (0, which), wave 0,
 // into a buffer nothing else reads.  The shipped library executes no stamp.
 #ifdef PPOAF_STAMPS
+#ifndef PPOAF_STAMP_BLOCK
+#define PPOAF_STAMP_BLOCK 0        /* 0..3: an actor workgroup, 4..7: a critic workgroup */
+#endif
 __device__ unsigned long long g_ppo_update_stamps[2][16];
 #define PPOAF_STAMP(k)                                                                   \
     do {                                                                                 \
-        if (blockIdx.x == 0 && threadIdx.x == 0) {                                       \
+        if (blockIdx.x == PPOAF_STAMP_BLOCK && threadIdx.x == 0) {                       \
             unsigned long long t_;                                                       \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
             g_ppo_update_stamps[0][k] = t_;                                              \

@@ -5,10 +5,12 @@ _lib.LIB_PATH='tools/libppoaf_hip_stamps.so'
 from ppo_and_friends_amd.ppo import PPO, PermutationLoader
 from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
 from ppo_and_friends_amd.spaces import Box, Discrete
+import os
 dev=torch.device('cuda',0); E,T,O=4096,128,4
+CH=int(os.environ.get('CRITIC_H','128'))
 env_gen=lambda: SyntheticFixedLengthEnv(E,O,Discrete(2),T,dev)
 sp=Box(-np.inf,np.inf,(O,),np.float32)
-ppo=PPO(env_gen,{"p":(None,sp,sp,Discrete(2),{})},device=dev,random_seed=1,normalize_obs=False,normalize_rewards=False,envs_per_proc=E,ts_per_rollout=T,batch_size=256,epochs_per_iter=1,use_graphs=False)
+ppo=PPO(env_gen,{"p":(None,sp,sp,Discrete(2),dict(critic_kw_args=dict(hidden_size=CH)))},device=dev,random_seed=1,normalize_obs=False,normalize_rewards=False,envs_per_proc=E,ts_per_rollout=T,batch_size=256,epochs_per_iter=1,use_graphs=False)
 ppo.rollout(); pol=ppo.policies["p"]
 loader=PermutationLoader(pol.dataset,256,ppo.loader_generator)
 f=ppo._fused_updater("p",256); f.begin_epoch(loader.epoch_permutation())
