@@ -552,6 +552,9 @@ typedef struct {
     float* denc_scratch;             /* [2, 2, 16*ceil(B/16), hidden]                           */
     float* loss_partials;            /* [ceil(B/16) + 1, 2] (last row: this step's Adam constants)*/
     double* totals;                  /* [2]                                                     */
+    /* 1: obs / next_obs / actions are per-epoch tables already in shuffled order (entry i belongs to
+     * perm[i]); mini-batch k reads [k * batch_stride, +B) directly, perm / row_map are not consulted */
+    int32_t inputs_in_batch_order, _pad;
 } ppoaf_icm_update_args_t;
 
 int ppoaf_icm_update_fwd_bwd(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream);

@@ -87,7 +87,7 @@ class IcmUpdateArgs(C.Structure):
                 ("cursor", C.c_void_p), ("B", C.c_int64), ("batch_stride", C.c_int64),
                 ("icm_beta", C.c_float), ("fused_adam", C.c_int32),
                 ("act_scratch", C.c_void_p), ("denc_scratch", C.c_void_p), ("loss_partials", C.c_void_p),
-                ("totals", C.c_void_p)]
+                ("totals", C.c_void_p), ("inputs_in_batch_order", C.c_int32), ("_pad", C.c_int32)]
 
 
 class MatUpdateArgs(C.Structure):

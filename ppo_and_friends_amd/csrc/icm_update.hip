@@ -26,7 +26,7 @@ struct IcmDev {
     const float* obs; const float* next_obs; const void* actions;
     const int64_t* perm; const int32_t* row_map; long n_rows;
     int64_t* cursor; long B, batch_stride, Bpad;
-    float icm_beta; int fused_adam;
+    float icm_beta; int fused_adam, pregathered;
     float* actE; float* dEnc; float* loss_partials; double* totals;
     int nT;
 };
@@ -38,7 +38,9 @@ __device__ __forceinline__ void icm_rows(const IcmDev& u, int g, int tid, int* s
         const long s = (long)g * kRows + tid;
         int row = -1;
         if (s < u.B) {
-            if (u.perm) {
+            if (u.pregathered) {
+                row = (int)(u.cursor[0] * u.batch_stride + s);   // tables in shuffled order: no index chain
+            } else if (u.perm) {
                 const long p = u.perm[u.cursor[0] * u.batch_stride + s];
                 if (p >= 0 && p < u.n_rows) row = u.row_map ? u.row_map[p] : (int)p;
             } else {
@@ -619,8 +621,8 @@ static int make_icm(const ppoaf_icm_update_args_t* a, IcmDev& u, bool training =
     PPOAF_REQUIRE(((uintptr_t)a->params & 15) == 0 && ((uintptr_t)a->act_scratch & 15) == 0,
                   "icm_update: buckets and scratch must be 16-byte aligned");
     if (training) {
-        PPOAF_REQUIRE(a->grads && a->exp_avg && a->exp_avg_sq && a->slabs && a->step_count && a->lr && a->perm &&
-                          a->cursor && a->denc_scratch && a->loss_partials && a->totals,
+        PPOAF_REQUIRE(a->grads && a->exp_avg && a->exp_avg_sq && a->slabs && a->step_count && a->lr &&
+                          (a->perm || a->inputs_in_batch_order) && a->cursor && a->denc_scratch && a->loss_partials && a->totals,
                       "icm_update: null pointer");
         PPOAF_REQUIRE(((uintptr_t)a->grads & 15) == 0 && ((uintptr_t)a->slabs & 15) == 0 &&
                           ((uintptr_t)a->exp_avg & 15) == 0 && ((uintptr_t)a->exp_avg_sq & 15) == 0 &&
@@ -649,7 +651,7 @@ static int make_icm(const ppoaf_icm_update_args_t* a, IcmDev& u, bool training =
     u.batch_stride = a->batch_stride;
     u.nT = (int)((a->B + kRows - 1) / kRows);
     u.Bpad = (long)u.nT * kRows;
-    u.icm_beta = a->icm_beta; u.fused_adam = a->fused_adam != 0;
+    u.icm_beta = a->icm_beta; u.fused_adam = a->fused_adam != 0; u.pregathered = a->inputs_in_batch_order != 0;
     u.actE = a->act_scratch; u.dEnc = a->denc_scratch; u.loss_partials = a->loss_partials; u.totals = a->totals;
     return PPOAF_OK;
 }

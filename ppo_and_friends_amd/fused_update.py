@@ -428,8 +428,9 @@ class FusedIcmUpdate:
         a.step_count, a.lr = opt.step_count.data_ptr(), opt.lr.data_ptr()
         a.beta1, a.beta2, a.adam_eps = opt.betas[0], opt.betas[1], opt.eps
         a.grad_scale = 1.0 / self.world
-        a.obs, a.next_obs = buf.observations.data_ptr(), buf.next_observations.data_ptr()
-        a.actions = buf.actions.data_ptr()
+        t = self.tables                        # per-epoch inputs in shuffled order (begin_epoch)
+        a.obs, a.next_obs, a.actions = t["obs"].data_ptr(), t["next_obs"].data_ptr(), t["actions"].data_ptr()
+        a.inputs_in_batch_order = 1
         a.perm, a.row_map, a.n_rows = self.perm.data_ptr(), buf.row_map.data_ptr(), buf.num_transitions
         a.cursor, a.B, a.batch_stride = self.cursor.data_ptr(), B, self.B
         a.icm_beta = float(pol.icm_beta)
@@ -445,9 +446,18 @@ class FusedIcmUpdate:
             self.perm = torch.empty(N, dtype=torch.int64, device=pol.device)
             self._graphs.clear()
         self.perm.copy_(perm)
+        flat = lambda x: x.view((buf.num_transitions,) + tuple(x.shape[2:]))
+        fields = dict(obs=buf.observations, next_obs=buf.next_observations, actions=buf.actions)
+        t = getattr(self, "tables", None)
+        if t is None or t["obs"].shape[0] != N:
+            t = self.tables = {k: torch.empty((N,) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)
+                               for k, v in fields.items()}
+            self._graphs.clear()
+            self._args = {}
+        K.minibatch_gather([(flat(v), t[k]) for k, v in fields.items()], self.perm, buf.row_map)   # one launch per epoch
         self.cursor.zero_()
         self.totals.zero_()
-        sig = (buf.observations.data_ptr(), buf.next_observations.data_ptr(), buf.actions.data_ptr(),
+        sig = (t["obs"].data_ptr(), buf.observations.data_ptr(), buf.next_observations.data_ptr(), buf.actions.data_ptr(),
                buf.num_transitions, self.perm.data_ptr(), float(pol.icm_beta))
         if self._args.get("sig") != sig:
             self._args = {"sig": sig}
