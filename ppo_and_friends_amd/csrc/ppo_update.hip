@@ -293,9 +293,9 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
                 }
             } else {
             if (nt != wave) load_fwd_frags<HT>(P + offW(l), nt * 16, lane, fr, dbg);
-            if (l == 1) PPOAF_STAMP(10);
+            
             acc = (dbg & 2) ? f32x4{fr[0].x + fr[HT - 1].w, 0.f, 0.f, 0.f} : mfma_rows_x_frags<HT>(Hp, HS, lane, fr, sBias[l * H + o]);
-            if (l == 1) PPOAF_STAMP(11);
+            
             if (nt + kNW >= HT) {                           // last tile of this wave in this layer
                 if (l + 1 < depth) load_fwd_frags<HT>(P + offW(l + 1), wave * 16, lane, fr, dbg);
                 else load_dgrad_frags<HT>(P + offW(l), wave * 16, lane, fr, dbg);   // first backward phase
@@ -303,10 +303,10 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) Hc[(4 * (lane >> 4) + r) * HS + o] = act_fwd(acc[r], act);
-            if (l == 1) PPOAF_STAMP(12);
+            
         }
         __syncthreads();
-        if (l == 1) PPOAF_STAMP(13);
+        
     }
     PPOAF_STAMP(4);
     const float* Hlast = sH + (long)(depth - 1) * kRows * HS;
@@ -561,19 +561,23 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
                 Dn[s * HS + i] = acc[r] * act_bwd(Hin[s * HS + i], act);
             }
         }
+        if (l == depth - 1) PPOAF_STAMP(10);
         // wgrad: dW[o][i] = sum_s dz[s][o] * Hin[s][i]
         if (!(dbg & 4))
         for (int mt = wave; mt < HT; mt += kNW) {
             if (HT <= 8) wgrad_mtile_full<(HT <= 8 ? HT : 1)>(Dc, HS, Hin, HS, mt * 16, lane, slab + offW(l), H);
             else wgrad_mtile(Dc, HS, Hin, HS, mt * 16, HT, H, lane, slab + offW(l), H);
         }
+        if (l == depth - 1) PPOAF_STAMP(11);
         for (int o = tid; o < H; o += kThreadsU) {
             float acc = 0.f;
 #pragma unroll
             for (int s = 0; s < kRows; ++s) acc += Dc[s * HS + o];
             slab[offB(l) + o] = acc;
         }
+        if (l == depth - 1) PPOAF_STAMP(12);
         __syncthreads();
+        if (l == depth - 1) PPOAF_STAMP(13);
         float* t = Dc; Dc = Dn; Dn = t;
     }
     PPOAF_STAMP(8);

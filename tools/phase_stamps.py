@@ -23,4 +23,4 @@ names=["P0 idx/stats","P1 gatherX","P2 layer0","P3 hidden fwd","P4 out","P5 head
 for w in (0,1):
     d=np.diff(st[w,:10]); print("net",w,"total cycles",st[w,9]-st[w,0])
     for n,x in zip(names,d): print("   %-16s %7d"%(n,x))
-    print("   L1 fwd: pre-mfma %d, mfma %d, act+store %d, barrier %d"%(st[w,10]-st[w,3], st[w,11]-st[w,10], st[w,12]-st[w,11], st[w,13]-st[w,12]))
+    print("   first bwd layer: dgrad %d, wgrad %d, bias sums %d, barrier %d"%(st[w,10]-st[w,7], st[w,11]-st[w,10], st[w,12]-st[w,11], st[w,13]-st[w,12]))
