@@ -117,20 +117,6 @@ __device__ __forceinline__ void wgrad_mtile(const float* __restrict__ D, int HS,
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[j] = D[(4 * (lane >> 4) + j) * HS + m0 + (lane & 15)];
     const float* bcol = Bsrc + (4 * (lane >> 4)) * strideB + (lane & 15);
-    if ((ldw & 3) == 0 && n_valid == 16 * ntiles) {
-        // full, 16-byte aligned rows: the tile is accumulated TRANSPOSED (operands swapped), so a lane ends up
-        // with 4 consecutive input columns of one output row and writes them with ONE 16-byte store
-        float* drow = dstW + (long)(m0 + (lane & 15)) * ldw + 4 * (lane >> 4);
-#pragma unroll 4
-        for (int nt = 0; nt < ntiles; ++nt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bcol[j * strideB + 16 * nt], a[j], acc, 0, 0, 0);
-            *reinterpret_cast<float4*>(drow + 16 * nt) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        }
-        return;
-    }
     float* drow = dstW + (long)(m0 + 4 * (lane >> 4)) * ldw + (lane & 15);
 #pragma unroll 4
     for (int nt = 0; nt < ntiles; ++nt) {
@@ -166,12 +152,12 @@ __device__ __forceinline__ void wgrad_mtile_full(const float* __restrict__ D, in
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][j], a[j], acc[nt], 0, 0, 0);
-    // transposed accumulation (operands swapped): one 16-byte store per tile and lane (ldw % 4 == 0)
-    float* drow = dstW + (long)(m0 + (lane & 15)) * ldw + 4 * (lane >> 4);
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[nt][j], acc[nt], 0, 0, 0);
+    float* drow = dstW + (long)(m0 + 4 * (lane >> 4)) * ldw + (lane & 15);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-        *reinterpret_cast<float4*>(drow + 16 * nt) = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) drow[(long)r * ldw + 16 * nt] = acc[nt][r];
 }
 
 constexpr int kNW = 8;                    // waves per workgroup of the fused update kernels
