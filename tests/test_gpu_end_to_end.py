@@ -609,3 +609,32 @@ def test_rollout_statistics_in_status_dict():
     for k in ("total episodes", "longest episode", "shortest episode", "average episode"):
         np.testing.assert_allclose(gs[k], want[k], rtol=1e-9, err_msg=k)
     assert gs["timesteps"] == E * T
+
+
+def test_cartpole_learns_like_the_reference_gate():
+    """
+    The reference's only quantitative gate (test/tests/train/test_gymnasium.py:3-49: CartPole reaches a score
+    of 200 within 70 000 timesteps) on the batched device CartPole, with the runner's settings
+    (baselines/gymnasium/cart_pole.py: LeakyReLU, lr 2e-3, batch 256, max_ts_per_ep 32, obs / reward
+    normalisers and +-10 clips).  Exercises truncation + termination ends, bootstrapped cuts, the filter stack,
+    the fused rollout step and update, and the statistics block in one run.
+    """
+    import torch.nn as nn
+    from ppo_and_friends_amd.ppo import PPO
+    from ppo_and_friends_amd.environments.cartpole import BatchedCartPoleEnv
+    from ppo_and_friends_amd.spaces import Discrete
+    dev = torch.device("cuda", 0)
+    E = 16
+    env_gen = lambda: BatchedCartPoleEnv(E, dev, seed=0)
+    probe = env_gen()
+    act = dict(activation=nn.LeakyReLU())
+    ppo = PPO(env_gen, {"p": (None, probe.observation_space, probe.observation_space, Discrete(2),
+                              dict(lr=2e-3, actor_kw_args=act, critic_kw_args=dict(act)))},
+              device=dev, random_seed=2, envs_per_proc=E, ts_per_rollout=256, max_ts_per_ep=32, batch_size=256,
+              obs_clip=(-10.0, 10.0), reward_clip=(-10.0, 10.0), normalize_obs=True, normalize_rewards=True,
+              save_state=False)
+    best = 0.0
+    while ppo.status_dict["global status"]["timesteps"] < 70000 and best < 195.0:
+        ppo.learn(E * 256)
+        best = max(best, ppo.status_dict["p"]["natural score avg"])
+    assert best >= 195.0, f"best natural score avg {best:.1f} after {ppo.status_dict['global status']['timesteps']} steps"
