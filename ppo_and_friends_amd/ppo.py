@@ -542,9 +542,10 @@ class PPO:
             for epoch_idx in range(self.epochs_per_iter):
                 if epoch_idx > 0 and self.recalc_advantages:
                     loader.dataset.recalculate_advantages()
-                self._ppo_batch_train(loader, policy_id)
-                if pol.enable_icm:
-                    self._icm_batch_train(loader, policy_id)
+                if not self._ppo_icm_epoch_overlapped(loader, policy_id):
+                    self._ppo_batch_train(loader, policy_id)
+                    if pol.enable_icm:
+                        self._icm_batch_train(loader, policy_id)
                 if self.status_dict[policy_id]["kl avg"] > pol.target_kl:
                     if self.verbose:
                         rank_print(f"Target KL of {pol.target_kl} has been reached. "
@@ -554,6 +555,41 @@ class PPO:
         if self.device.type == "cuda":
             torch.cuda.synchronize()
         self.status_dict["global status"]["train time"] = time.time() - start
+
+    def _ppo_icm_epoch_overlapped(self, loader, policy_id):
+        """
+        One PPO epoch and the ICM epoch that follows it (ppo.py:2208-2216) on two HIP streams at once.
+        Within an epoch pair the two passes are independent: the PPO pass reads / writes the actor-critic
+        bucket, `values` and the value normaliser; the ICM pass reads observations / actions and writes the
+        ICM bucket.  Both are latency-bound chains on ~32 workgroups each, so running them side by side
+        nearly halves the pair's wall time; shuffles are drawn in the reference's order, results are
+        identical.  Single rank + both fused updaters only (collectives stay on one stream).
+        """
+        pol = self.policies[policy_id]
+        if not pol.enable_icm or not getattr(self, "overlap_icm", True) or mpi_utils.distributed_path() \
+                or self.device.type != "cuda":
+            return False
+        fused = self._fused_updater(policy_id, loader.batch_size)
+        fused_icm = self._fused_icm_updater(policy_id)
+        if fused is None or fused_icm is None:
+            return False
+        fused.begin_epoch(loader.epoch_permutation())
+        fused_icm.begin_epoch(loader.epoch_permutation())
+        main = torch.cuda.current_stream()
+        if "side_streams" not in self._graphs:
+            self._graphs["side_streams"] = (torch.cuda.Stream(), torch.cuda.Stream())
+        sa, sb = self._graphs["side_streams"]
+        sa.wait_stream(main); sb.wait_stream(main)
+        with torch.cuda.stream(sa):
+            fused.run_epoch()
+        with torch.cuda.stream(sb):
+            fused_icm.run_epoch()
+        main.wait_stream(sa); main.wait_stream(sb)
+        loader.prefetch()
+        self._publish_epoch_stats(policy_id, fused.end_epoch())
+        t = fused_icm.end_epoch()
+        self.status_dict[policy_id]["icm loss"] = t[0] / max(t[1], 1.0)
+        return True
 
     def _minibatch_step(self, policy_id, dataset, perm_batch, records, totals):
         """

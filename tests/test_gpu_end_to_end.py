@@ -638,3 +638,28 @@ def test_cartpole_learns_like_the_reference_gate():
         ppo.learn(E * 256)
         best = max(best, ppo.status_dict["p"]["natural score avg"])
     assert best >= 195.0, f"best natural score avg {best:.1f} after {ppo.status_dict['global status']['timesteps']} steps"
+
+
+def test_overlapped_ppo_and_icm_epochs_equal_the_sequential_order():
+    """PPO + ICM epochs on two streams (ppo.py:_ppo_icm_epoch_overlapped) vs one after the other: bitwise equal."""
+    from ppo_and_friends_amd.ppo import PPO
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box
+    dev = torch.device("cuda", 0)
+    E, T, O, B = 32, 64, 17, 64
+    space = Box(-1.0, 1.0, (6,), np.float32)
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+
+    def run(overlap):
+        env_gen = lambda: SyntheticFixedLengthEnv(E, O, space, T, dev, reward="uniform", seed=3, term_prob=0.02)
+        ppo = PPO(env_gen, {"p": (None, sp, sp, space, dict(enable_icm=True))}, device=dev, random_seed=5,
+                  envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=3, save_state=False)
+        ppo.overlap_icm = overlap
+        ppo.learn(2 * E * T)
+        pol = ppo.policies["p"]
+        return (pol.policy_params.clone(), pol.icm_model.flat_params.clone(), dict(ppo.status_dict["p"]))
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in ("actor loss", "critic loss", "kl avg", "icm loss", "intrinsic score avg"):
+        assert a[2][k] == b[2][k], k
