@@ -12,7 +12,7 @@ Import recipe: a scratch directory on sys.path holding
 The scratch directory lives under /tmp and is removed afterwards.
 
 Importable with that recipe: utils.episode_info, utils.stats, utils.mpi_utils,
-networks.attention, networks.utils.  Everything routed through `gymnasium`
+networks.attention, networks.utils (fixtures g1-g6).  Everything routed through `gymnasium`
 (distributions, policies, ppo.py) is NOT importable here and is restated from
 text in oracle/ (pinned by torch primitives; see DESIGN.md "Oracle").
 
@@ -321,14 +321,50 @@ def gen_g5(at, out):
     out["rep"] = rep.numpy()
 
 
+def gen_g6(nu, out):
+    """
+    G6: networks/utils.py -- create_sequential_network (:120-191: module tree, activation placement,
+    out_init) and init_layer / init_net_parameters (:53-111: orthogonal weights with a gain, constant bias):
+    parameter names + values and the forward output on a fixed input for the layer shapes of the configs.
+    """
+    import torch.nn as nn
+    torch.manual_seed(4321)
+    cases = [("c2_actor", 4, 2, 128, 3, 0.01, nn.ReLU()), ("c2_critic", 4, 1, 128, 3, 1.0, nn.ReLU()),
+             ("leaky", 6, 3, 32, 2, None, nn.LeakyReLU()), ("tanh_d1", 5, 4, 16, 1, 0.5, nn.Tanh()),
+             ("no_hidden", 7, 3, 0, 0, 1.0, nn.ReLU()), ("list_sizes", 9, 2, [24, 16, 8], 99, None, nn.ReLU())]
+    out["n_cases"] = np.array([len(cases)])
+    for i, (tag, n_in, n_out, hs, hd, out_init, act) in enumerate(cases):
+        net = nu.create_sequential_network(in_size=n_in, out_size=n_out, hidden_size=hs, hidden_depth=hd,
+                                           activation=act, out_init=out_init)
+        x = torch.randn(11, n_in)
+        names = []
+        for n, p in net.named_parameters():
+            out[f"c{i}_p_{n}"] = p.detach().numpy()
+            names.append(n)
+        out[f"c{i}_names"] = np.array(names)
+        out[f"c{i}_x"] = x.numpy()
+        out[f"c{i}_y"] = net(x).detach().numpy()
+        out[f"c{i}_cfg"] = np.array([tag, str(n_in), str(n_out), repr(hs), str(hd), repr(out_init), type(act).__name__])
+    lstm = nu.init_net_parameters(nn.LSTM(5, 8, 1))
+    for n, p in lstm.named_parameters():
+        out[f"lstm_{n}"] = p.detach().numpy()
+    lin = nu.init_layer(nn.Linear(6, 6), gain=0.3, bias_const=0.25)
+    out["lin_w"], out["lin_b"] = lin.weight.detach().numpy(), lin.bias.detach().numpy()
+
+
 def main():
+    only = set(sys.argv[1:])                      # e.g. `make_golden.py g6_network_utils`: just that fixture
     scratch, ei, st, at = _import_reference()
+    from ppo_and_friends.networks import utils as nu
     try:
         for name, fn, mod in (("g1_end_episode", gen_g1, ei),
                               ("g2_dataset", gen_g2, ei),
                               ("g3_shared", gen_g3, ei),
                               ("g4_running_stats", gen_g4, st),
-                              ("g5_attention", gen_g5, at)):
+                              ("g5_attention", gen_g5, at),
+                              ("g6_network_utils", gen_g6, nu)):
+            if only and name not in only:
+                continue
             out = {}
             fn(mod, out)
             path = os.path.join(HERE, name + ".npz")
