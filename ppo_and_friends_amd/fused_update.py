@@ -274,6 +274,29 @@ class FusedPolicyUpdate:
         if rc != 0:
             _lib.check(rc, "ppo_update")
 
+    def _eager_multi_rank(self, args, n):
+        """
+        n mini-batches of the N > 1 path: fwd_bwd, reduce, the gradient all-reduce (RCCL), norm + Adam.
+        Everything is bound to locals once -- this loop is what the host executes 2048 times per epoch
+        while the GPUs wait on each other, so no attribute lookups, wrappers or environment reads inside.
+        """
+        import torch.distributed as dist
+        lib, ref, st = self._lib, C.byref(args), K.stream()
+        fwd, red, adam = lib.ppoaf_ppo_update_fwd_bwd, lib.ppoaf_ppo_update_reduce, lib.ppoaf_ppo_update_adam
+        grads = self.pol.policy_grads
+        if mpi_utils._needs_staging(grads):                  # gloo (tests): through a host copy
+            allreduce = lambda: mpi_utils.allreduce_sum_(grads)
+        else:
+            # (calling the c10d process group object directly, pg.allreduce([t]).wait(), measured 40 % slower)
+            allreduce = lambda: dist.all_reduce(grads)
+        for _ in range(n):
+            rc = fwd(ref, st) or red(ref, 0, st)
+            if rc == 0:
+                allreduce()
+                rc = adam(ref, 1, st)
+            if rc != 0:
+                _lib.check(rc, "ppo_update")
+
     def _chunk(self, args, n):
         """n consecutive mini-batches with their index baked in: one cursor update for the whole chain."""
         try:
@@ -306,6 +329,10 @@ class FusedPolicyUpdate:
                     g.replay()
                 left -= chunk
                 self.n_done += chunk
+            elif self.multi and type(self)._one is FusedPolicyUpdate._one:
+                self._eager_multi_rank(args, left)
+                self.n_done += left
+                left = 0
             else:
                 self._one(args)
                 left -= 1

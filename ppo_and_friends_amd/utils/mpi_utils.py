@@ -66,6 +66,14 @@ def init_process_group_from_env(backend=None):
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local_rank)
+            try:
+                # the per-mini-batch gradient all-reduce is a 270 KB, latency-bound message on the critical
+                # path: its RCCL kernels go to a high-priority stream
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                kw["pg_options"] = opts
+            except Exception:
+                pass
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local_rank
 
