@@ -249,6 +249,8 @@ class PPO:
         last step of the rollout -> bootstrapped end with the critic's value of
         the next observation.
         """
+        if len(self.policies) > 1:
+            return self._rollout_multi_policy()
         start = time.time()
         policy_id = next(iter(self.policies))
         pol = self.policies[policy_id]
@@ -379,6 +381,103 @@ class PPO:
         torch.cuda.synchronize() if self.device.type == "cuda" else None
         gs["rollout time"] = time.time() - start
         return pol.dataset
+
+    def _rollout_multi_policy(self):
+        """
+        ppo.py:1534-2110 with several policies (`policy_mapping_fn` partitions the env's agents, ppo.py:329-345,
+        710-858): every policy acts on its own agents' rows of the agent-major env tensors and logs into its own
+        rollout buffer; the env is stepped once with the combined actions; episode ends are shared (the agents of an
+        env end together).  Covers feed-forward PPOPolicy instances whose agents share observation / action shapes
+        (independent or team-wise PPO); grouped (MAT), LSTM and ICM policies are single-policy features here.
+        """
+        start = time.time()
+        env = self.env
+        n_envs = env.get_batch_size()
+        T = self.ts_per_rollout // n_envs
+        agent_ids = list(env.agent_ids)
+        A = len(agent_ids)
+        ctxs = []
+        for policy_id, pol in self.policies.items():
+            if pol.agent_grouping or pol.using_lstm or pol.enable_icm:
+                raise NotImplementedError("several policies in one run: feed-forward PPOPolicy without ICM only")
+            pol.initialize_dataset()
+            pol.eval()
+            pol.initialize_episodes(n_envs, self.status_dict, ts_per_rollout=self.ts_per_rollout)
+            idx = torch.as_tensor(sorted(agent_ids.index(a) for a in pol.agent_ids), device=self.device)
+            fused = (self.update_mode != "torch" and self.device.type == "cuda"
+                     and pol.fused_step_unsupported_reason() == "")
+            ctxs.append(dict(id=policy_id, pol=pol, buf=pol.buffer, idx=idx, n=int(idx.numel()), fused=fused,
+                             vn=self.value_normalizers[policy_id] if self.normalize_values else None,
+                             nat=torch.zeros(T, int(idx.numel()) * n_envs, dtype=torch.float32, device=self.device)))
+        if sorted(int(i) for c in ctxs for i in c["idx"]) != list(range(A)):
+            raise ValueError("policy_mapping_fn must assign every agent of the env to exactly one policy")
+        if self._obs is None or not self.soft_resets():
+            obs, critic_obs = env.reset()
+        else:
+            soft = getattr(env, "soft_reset", None)
+            obs, critic_obs = soft() if callable(soft) else self._obs
+        rows = lambda x, c: x.reshape((A, n_envs) + tuple(x.shape[1:]))[c["idx"]].reshape((c["n"] * n_envs,) + tuple(x.shape[1:]))
+        ep_ts = torch.zeros(n_envs, dtype=torch.int32, device=self.device)
+        may_end_early = getattr(env, "term_table", True) is not None or self.max_ts_per_ep < T
+        actions = None
+        for t in range(T):
+            for c in ctxs:
+                pol, o, co = c["pol"], rows(obs, c).contiguous(), rows(critic_obs, c).contiguous()
+                if c["fused"]:
+                    a = pol.rollout_step(t, o, co, c["vn"])
+                else:
+                    raw, a, lp = pol.get_rollout_actions(o)
+                    c["pending"] = (co, o, raw, a, self.get_policy_values(c["id"], co), lp)
+                if actions is None:
+                    actions = torch.zeros((A, n_envs) + tuple(a.shape[1:]), dtype=a.dtype, device=self.device)
+                actions[c["idx"]] = a.reshape((c["n"], n_envs) + tuple(a.shape[1:]))
+            nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(actions.reshape((A * n_envs,) + tuple(actions.shape[2:])))
+            nat = self._natural_reward(env, reward)
+            if self.ext_reward_weight != 1.0:
+                reward = reward * self.ext_reward_weight
+            for c in ctxs:
+                c["nat"][t].copy_(rows(nat, c))
+                r = rows(reward, c)
+                if c["fused"]:
+                    c["pol"].finish_step(t, r, None)
+                else:
+                    co, o, raw, a, v, lp = c.pop("pending")
+                    c["buf"].write_step(t, slice(0, c["buf"].C), co, o, None, raw, a, v, lp, r)
+                    c["pol"]._t = t + 1
+            if may_end_early:
+                term_e, trunc_e = terminated[:n_envs], truncated[:n_envs]          # agents of an env end together
+                ep_ts += 1
+                last = t == T - 1
+                boot = (~term_e) & ((ep_ts >= self.max_ts_per_ep) | trunc_e | last)
+                kind = torch.where(term_e, 1, torch.where(boot, 2, 0)).to(torch.int8)
+                for c in ctxs:
+                    c["buf"].end_kind[t] = kind.repeat(c["n"])
+                    if not last:
+                        c["buf"].fixed_length = False
+                ep_ts = torch.where(term_e | boot, torch.zeros_like(ep_ts), ep_ts)
+            obs, critic_obs = nxt_obs, nxt_cobs
+        self._obs = (obs, critic_obs)
+        gs = self.status_dict["global status"]
+        episodes_before = gs["total episodes"]
+        for c in ctxs:
+            buf = c["buf"]
+            next_value = self.get_policy_values(c["id"], rows(critic_obs, c).contiguous())
+            if may_end_early:
+                buf.boot_value[:-1].copy_(buf.values[1:])
+                buf.boot_value[T - 1].copy_(next_value)
+                buf.boot_reward.copy_(buf.boot_value)
+            else:
+                buf.end_kind[T - 1].fill_(2)
+                buf.boot_value[T - 1].copy_(next_value)
+                buf.boot_reward[T - 1].copy_(next_value)
+            c["pol"].finalize_dataset()
+            self._publish_rollout_statistics(c["id"], buf, c["nat"], None, n_envs, T, rows(obs, c), False)
+        # every policy's statistics pass added the (shared, per-env) episode count: keep it once (ppo.py:2089)
+        gs["total episodes"] = episodes_before + (gs["total episodes"] - episodes_before) / len(ctxs)
+        gs["timesteps"] += self.ts_per_rollout * mpi_utils.get_num_procs()
+        torch.cuda.synchronize() if self.device.type == "cuda" else None
+        gs["rollout time"] = time.time() - start
+        return {c["id"]: c["pol"].dataset for c in ctxs}
 
     @staticmethod
     def _natural_reward(env, reward):

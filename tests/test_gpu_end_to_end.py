@@ -663,3 +663,62 @@ def test_overlapped_ppo_and_icm_epochs_equal_the_sequential_order():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     for k in ("actor loss", "critic loss", "kl avg", "icm loss", "intrinsic score avg"):
         assert a[2][k] == b[2][k], k
+
+
+@pytest.mark.parametrize("update_mode", ["fused", "torch"])
+def test_two_policies_in_one_run_match_two_cpu_ports(update_mode):
+    """
+    `policy_mapping_fn` with two policies (independent PPO, ppo.py:329-345,710-858): each policy sees only its
+    agent's rows of the env, logs into its own buffer and is updated from its own dataset; the loaders draw
+    from the one shuffle generator in the reference's order (policy by policy).  Against one CPU port per
+    policy on that agent's observation / reward tables.
+    """
+    from ppo_and_friends_amd.ppo import PPO
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    dev = torch.device("cuda", 0)
+    A, E, T, O, NA, B, seed = 2, 12, 20, 5, 3, 32, 4
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=21, term_prob=0.04,
+                                              num_agents=A)
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    settings = {"p0": (None, sp, sp, Discrete(NA), {}), "p1": (None, sp, sp, Discrete(NA), dict(lr=1e-3))}
+    ppo = PPO(env_gen, settings, policy_mapping_fn=lambda agent_id: "p0" if agent_id == "agent0" else "p1",
+              device=dev, random_seed=seed, normalize_obs=False, normalize_rewards=False, envs_per_proc=E,
+              ts_per_rollout=T, batch_size=B, epochs_per_iter=2, update_mode=update_mode, save_state=False)
+    assert [list(p.agent_ids) for p in ppo.policies.values()] == [["agent0"], ["agent1"]]
+    gen = torch.Generator().manual_seed(seed)                    # ONE shuffle stream for both policies
+    cpus = {}
+    strip = lambda sd: {k.replace("sequential_net.", ""): v.detach().cpu().clone() for k, v in sd.items()
+                        if k.startswith("sequential_net.")}
+    for pid, lr in (("p0", 3e-4), ("p1", 1e-3)):
+        cpu = cpu_ppo_loop.CpuPPO(O, NA, batch_size=B, seed=seed, lr=lr)
+        cpu.actor.load_state_dict(strip(ppo.policies[pid].actor.state_dict()))
+        cpu.critic.load_state_dict(strip(ppo.policies[pid].critic.state_dict()))
+        cpu.loader_generator = gen
+        cpus[pid] = cpu
+    datasets = ppo.rollout()
+    env = ppo.env
+    obs_t = env.obs_table.view(T + 1, A, E, O).cpu().numpy()
+    rew_t = env.reward_table.view(T, A, E).cpu().numpy()
+    term_t = env.term_table.view(T, A, E).cpu().numpy()
+    tol = dict(rtol=1e-5, atol=1e-5)
+    for a, pid in enumerate(("p0", "p1")):
+        ds, pol = datasets[pid], ppo.policies[pid]
+        ref = cpus[pid].rollout(obs_t[:, a], rew_t[:, a], actions=pol.buffer.actions[..., 0].cpu().numpy(),
+                                term_table=term_t[:, a], max_ts_per_ep=200)
+        assert len(ds) == len(ref) == E * T
+        np.testing.assert_array_equal(ds.observations.cpu().numpy(), ref.observations.numpy())
+        np.testing.assert_allclose(ds.log_probs.cpu().numpy(), ref.log_probs.numpy(), **tol)
+        np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), ref.rewards_to_go.numpy(), **tol)
+        np.testing.assert_allclose(ds.advantages.cpu().numpy(), ref.advantages.numpy(), **tol)
+    assert ppo.status_dict["global status"]["timesteps"] == E * T
+    assert ppo.status_dict["global status"]["total episodes"] > 0
+    ppo.train_on_rollout()                                       # p0: 2 epochs, then p1: 2 epochs
+    for pid in ("p0", "p1"):
+        for _ in range(2):
+            r = cpus[pid].train_epoch()
+        sd = ppo.status_dict[pid]
+        for k in ("actor loss", "critic loss", "kl avg"):
+            np.testing.assert_allclose(sd[k], r[k], rtol=5e-5, atol=5e-6, err_msg=f"{pid} {k}")
+        np.testing.assert_allclose(_flat_params(ppo.policies[pid].actor), _flat_params(cpus[pid].actor), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(_flat_params(ppo.policies[pid].critic), _flat_params(cpus[pid].critic), rtol=1e-4, atol=2e-5)
