@@ -540,9 +540,14 @@ class PPO:
             self._save_curves(pre_rollout_timesteps)
             self.train_on_rollout()
             gs["iteration"] += 1
-            for policy_id, pol in self.policies.items():
+            for policy_id, pol in self.policies.items():        # ppo.py:1406-1426
                 pol.update_learning_rate()
-                self.status_dict[policy_id]["lr"] = pol.lr()
+                sd = self.status_dict[policy_id]
+                sd["lr"] = pol.lr()
+                sd["entropy weight"] = pol.entropy_weight()
+                if pol.enable_icm:
+                    sd["icm lr"] = pol.icm_lr()
+                    sd["intr reward weight"] = pol.intr_reward_weight()
             if sum(pol.lr() for pol in self.policies.values()) <= 0.0:
                 rank_print("Learning rate has bottomed out. Terminating early")
                 break
