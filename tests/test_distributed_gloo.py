@@ -71,6 +71,22 @@ def _worker(rank, world, port, out):
     res["sum"] = mpi_utils.allreduce_scalars([1.0, rank, 2.5], "sum")
     res["max"] = mpi_utils.allreduce_scalars([rank, -rank], "max")
     res["min"] = mpi_utils.allreduce_scalars([rank, -rank], "min")
+    # 5. the rollout statistics block across ranks (ppo.py:1978-2099: SUM / MAX / MIN allreduces)
+    from ppo_and_friends_amd.utils.rollout_stats import rollout_statistics
+    rs = np.random.default_rng(7 + rank)
+    T, E = 12, 5
+    term = rs.uniform(0, 1, (T, E)) < 0.15
+    boot = np.zeros((T, E), bool); boot[-1] = ~term[-1]
+    arr = dict(r=rs.uniform(-1, 1, (T, E)), nat=rs.uniform(-2, 2, (T, E)), nr=rs.uniform(-3, 3, (T, E)),
+               term=term, boot=boot, omin=rs.uniform(-5, -1, T), omax=rs.uniform(1, 5, T))
+    tt = torch.as_tensor
+    res["stats"] = rollout_statistics(tt(arr["r"]), tt(arr["nat"]), tt(term), tt(boot), tt(arr["nr"]), 1,
+                                      (tt(arr["r"].min()), tt(arr["r"].max())), (tt(arr["nat"].min()), tt(arr["nat"].max())),
+                                      (tt(arr["omin"].min()), tt(arr["omax"].max())), T)
+    res["stats_in"] = arr
+    # 6. the environment-filter record exchange (one all-gather per env step instead of raw data)
+    rec = torch.arange(7, dtype=torch.float64) + 10 * rank
+    res["filter_records"] = mpi_utils.allgather_records(rec)
     out[rank] = res
     dist.barrier()
     dist.destroy_process_group()
@@ -118,3 +134,28 @@ def test_packed_scalar_reductions(two_ranks):
     r0, r1 = two_ranks
     assert r0["sum"] == [2.0, 1.0, 5.0] == r1["sum"]
     assert r0["max"] == [1.0, 0.0] and r0["min"] == [0.0, -1.0]
+
+
+def test_rollout_statistics_across_ranks(two_ranks):
+    """Per-rank literal loops (oracle) combined the way the reference's allreduces do == the 2-rank result."""
+    from oracle.rollout_stats_oracle import rollout_statistics_loop
+    r0, r1 = two_ranks
+    per = []
+    for r in (r0, r1):
+        a = r["stats_in"]
+        per.append(rollout_statistics_loop(a["r"], a["nat"], np.zeros_like(a["r"]), a["omin"], a["omax"], a["term"],
+                                           a["boot"], a["nr"]))
+    eps = per[0]["total episodes"] + per[1]["total episodes"]
+    got = r0["stats"]
+    assert got == r1["stats"]
+    np.testing.assert_allclose(got["total episodes"], eps, rtol=1e-12)
+    np.testing.assert_allclose(got["score avg"], (per[0]["score avg"] * per[0]["total episodes"] +
+                                                  per[1]["score avg"] * per[1]["total episodes"]) / eps, rtol=1e-12)
+    np.testing.assert_allclose(got["top score"], max(p["top score"] for p in per), rtol=1e-12)
+    np.testing.assert_allclose(got["reward range"], (min(p["reward range"][0] for p in per),
+                                                     max(p["reward range"][1] for p in per)), rtol=1e-12)
+    np.testing.assert_allclose(got["longest episode"], max(p["longest episode"] for p in per))
+    np.testing.assert_allclose(got["shortest episode"], min(p["shortest episode"] for p in per))
+    np.testing.assert_allclose(got["average episode"], (per[0]["average episode"] + per[1]["average episode"]) / 2)
+    assert torch.equal(r0["filter_records"], torch.stack([torch.arange(7, dtype=torch.float64),
+                                                          torch.arange(7, dtype=torch.float64) + 10]))
