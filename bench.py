@@ -186,6 +186,12 @@ def main():
                 "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on the launch stream, timed region",
                 "note": "config size (8.4 MB, fits L2/MALL) is latency-bound; see roofline_saturating"}
 
+    # which per-mini-batch gradient exchange the update loops actually used (N > 1 or its rehearsal)
+    fused = [f for f in getattr(ppo, "_fused", {}).values() if f is not None]
+    peer = bool(fused) and all(getattr(f, "xchg", None) is not None for f in fused)
+    exchange = None if not mpi_utils.distributed_path() else \
+        ("K17 peer mappings (xGMI), in-graph" if peer else "RCCL all-reduce, eager loop")
+
     out = {"metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
@@ -197,8 +203,9 @@ def main():
                                    f"epochs_per_iter={args.epochs}, fixed-length synthetic trajectories"),
                       "agent_steps_per_iteration": world * E * T * A,
                       "global_env_steps_per_iteration": world * E * T,
-                      "parallelism": f"dp{world}", "hip_graphs": (not args.no_graphs) and not mpi_utils.distributed_path(),
+                      "parallelism": f"dp{world}", "hip_graphs": (not args.no_graphs) and (not mpi_utils.distributed_path() or peer),
                       "multi_rank_path": mpi_utils.distributed_path(),
+                      "gradient_exchange": exchange,
                       "rollout_s": round(ppo.status_dict["global status"]["rollout time"], 4),
                       "train_s": round(ppo.status_dict["global status"]["train time"], 4)},
            "roofline": roofline}

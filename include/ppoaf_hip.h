@@ -633,6 +633,36 @@ typedef struct {
 
 int ppoaf_mat_policy_step(const ppoaf_mat_step_args_t* args, ppoaf_stream_t stream);
 
+/* ------------------------------------------------------------------------ *
+ * K17  gradient exchange between the ranks of one node over peer mappings (xGMI)
+ * replaces, inside the per-mini-batch update chain, the comm.Allreduce of
+ *          mpi_avg_gradients                       utils/mpi_utils.py:65-86  (called from ppo.py:2443-2448,
+ *          2557-2558 once per mini-batch; the division by num_procs stays in the optimiser's grad_scale)
+ * One process per GPU.  Every rank creates an exchange for its flat gradient bucket, exports an opaque
+ * blob (IPC handle of its exchange slots + flag words), the host all-gathers the blobs in rank order over
+ * any control plane (torch.distributed, MPI, a file) and every rank connects.  After a host barrier,
+ * ppoaf_peer_exchange_allreduce is ONE kernel launch with fixed arguments (hipGraph-capturable):
+ *   dst[i] = sum over ranks r = 0..n-1, in that order, of src_r[i]          (bitwise identical on every rank)
+ *   norm_out[0] = sum_{i <  split} (norm_scale * dst[i])^2,  norm_out[1] = the same for i >= split
+ *                 (double, added in a fixed order; NULL to skip; split_floats = bucket size for one segment)
+ * dst may alias src.  All ranks must issue the same sequence of exchanges.  A rank waits at most
+ * wait_seconds for its peers inside the kernel; on expiry the launch drains, dst is undefined and the error
+ * word (status out[1]) holds the sequence number that timed out -- it never hangs.
+ * ppoaf_peer_exchange_status: out[0] = exchanges completed, out[1] = 0 or the sequence number of a timed-out
+ * wait, out[2] = 1 uncached / 2 fine-grained exchange memory, out[3] = n_ranks (synchronises the device).
+ * ------------------------------------------------------------------------ */
+#define PPOAF_PEER_EXCHANGE_MAX_RANKS 16
+#define PPOAF_PEER_EXCHANGE_BLOB_BYTES 128
+typedef struct ppoaf_peer_exchange ppoaf_peer_exchange_t;
+
+int ppoaf_peer_exchange_create(int rank, int n_ranks, int64_t bucket_floats, ppoaf_peer_exchange_t** out);
+int ppoaf_peer_exchange_export(ppoaf_peer_exchange_t* x, void* blob /* host, PPOAF_PEER_EXCHANGE_BLOB_BYTES */);
+int ppoaf_peer_exchange_connect(ppoaf_peer_exchange_t* x, const void* all_blobs /* host, n_ranks blobs in rank order */);
+int ppoaf_peer_exchange_allreduce(ppoaf_peer_exchange_t* x, const float* src, float* dst, int64_t split_floats,
+                                  float norm_scale, double* norm_out, double wait_seconds, ppoaf_stream_t stream);
+int ppoaf_peer_exchange_status(ppoaf_peer_exchange_t* x, int64_t* out /* host [4] */);
+int ppoaf_peer_exchange_destroy(ppoaf_peer_exchange_t* x);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,6 +196,12 @@ SIGNATURES = {
     "ppoaf_mat_update_fwd_bwd": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
     "ppoaf_mat_update_reduce": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
     "ppoaf_mat_policy_step": (C.c_int, [C.POINTER(MatStepArgs), _ptr]),
+    "ppoaf_peer_exchange_create": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
+    "ppoaf_peer_exchange_export": (C.c_int, [_ptr, _ptr]),
+    "ppoaf_peer_exchange_connect": (C.c_int, [_ptr, C.c_char_p]),
+    "ppoaf_peer_exchange_allreduce": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_float, _ptr, C.c_double, _ptr]),
+    "ppoaf_peer_exchange_status": (C.c_int, [_ptr, C.POINTER(C.c_int64)]),
+    "ppoaf_peer_exchange_destroy": (C.c_int, [_ptr]),
     "ppoaf_env_filter_moments": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),
                                            C.c_int32, C.c_int64, _ptr, _ptr]),
     "ppoaf_env_filter_apply": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),

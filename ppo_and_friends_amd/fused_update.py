@@ -20,7 +20,7 @@ from . import _lib
 from . import kernels as K
 from .networks.distributions import CategoricalDistribution, GaussianDistribution
 from .networks.feed_forward import FeedForwardNetwork
-from .utils import mpi_utils
+from .utils import mpi_utils, peer_exchange
 
 
 def _activation_code(act):
@@ -136,6 +136,9 @@ class FusedPolicyUpdate:
         self.perm = None
         self._graphs = {}
         self._args = {}
+        # N > 1: the per-mini-batch gradient exchange.  K17 over peer mappings when every rank can (same
+        # host, IPC + self-test passed: collective decision), else the RCCL all-reduce in an eager loop.
+        self.xchg, self.xchg_reason = (peer_exchange.open_exchange(total, dev) if self.multi else (None, "single rank"))
 
     # ------------------------------------------------------------------ args
     def _make_args(self, B):
@@ -267,10 +270,17 @@ class FusedPolicyUpdate:
         rc = lib.ppoaf_ppo_update_fwd_bwd(ref, st)
         if rc == 0:
             rc = lib.ppoaf_ppo_update_reduce(ref, 1 if single else 0, st)
-        if rc == 0 and not single:
-            mpi_utils.allreduce_sum_(self.pol.policy_grads)
-        if rc == 0:
-            rc = lib.ppoaf_ppo_update_adam(ref, 0 if single else 1, st)
+        if rc == 0 and self.xchg is not None:
+            # K17: summed gradients + both clip norms in one launch, then Adam without a norm pass
+            g = self.pol.policy_grads
+            self.xchg.allreduce(g, g, split_floats=self.actor_desc.size, norm_scale=args.grad_scale,
+                                norm_out=self.pol.policy_norm_scratch, stream=st)
+            rc = lib.ppoaf_ppo_update_adam(ref, 0, st)
+        else:
+            if rc == 0 and not single:
+                mpi_utils.allreduce_sum_(self.pol.policy_grads)
+            if rc == 0:
+                rc = lib.ppoaf_ppo_update_adam(ref, 0 if single else 1, st)
         if rc != 0:
             _lib.check(rc, "ppo_update")
 
@@ -310,7 +320,7 @@ class FusedPolicyUpdate:
     def run_epoch(self):
         args = self._args_for(self.B)
         left = self.n_full
-        use_graph = self.ppo.use_graphs and not self.multi
+        use_graph = self.ppo.use_graphs and (not self.multi or self.xchg is not None)   # RCCL calls are not captured
         chunk = self.graph_chunk if self.n_full < 8 * self.graph_chunk else 4 * self.graph_chunk   # long epochs: fewer, longer graphs
         while left > 0:
             if use_graph and left >= chunk:
@@ -329,7 +339,7 @@ class FusedPolicyUpdate:
                     g.replay()
                 left -= chunk
                 self.n_done += chunk
-            elif self.multi and type(self)._one is FusedPolicyUpdate._one:
+            elif self.multi and self.xchg is None and type(self)._one is FusedPolicyUpdate._one:
                 self._eager_multi_rank(args, left)
                 self.n_done += left
                 left = 0
@@ -355,7 +365,10 @@ class FusedPolicyUpdate:
         t = self.totals.clone()
         if self.multi:
             mpi_utils.allreduce_sum_(t)
-        return t.cpu().numpy()
+        out = t.cpu().numpy()
+        if self.xchg is not None:
+            self.xchg.check()                # a wait that ran out of time invalidates the epoch: raise, never continue
+        return out
 
 
 # ======================================================================================

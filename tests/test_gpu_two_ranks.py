@@ -23,9 +23,10 @@ def _free_port():
     return p
 
 
-def _rank(rank, world, port, out):
+def _rank(rank, world, port, out, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
-                      WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      PPOAF_GRAD_EXCHANGE=mode)
     import torch.distributed as dist
     from ppo_and_friends_amd.utils import mpi_utils
     mpi_utils.init_process_group_from_env(backend="gloo")
@@ -47,7 +48,9 @@ def _rank(rank, world, port, out):
         ppo._ppo_batch_train(loader, "p")
         stats.append(dict(ppo.status_dict["p"]))
     vs = ppo.value_normalizers["p"].running_stats
+    fused = [f for f in getattr(ppo, "_fused", {}).values() if f is not None]
     out[rank] = dict(w0=w0, w=pol.policy_params.detach().cpu().clone(),
+                     peer_exchange=[getattr(f, "xchg", None) is not None for f in fused],
                      actor_sd={k: v.detach().cpu().clone() for k, v in pol.actor.state_dict().items()},
                      critic_sd={k: v.detach().cpu().clone() for k, v in pol.critic.state_dict().items()},
                      obs=ppo.env.obs_table.cpu().numpy(), rew=ppo.env.reward_table.cpu().numpy(),
@@ -58,13 +61,18 @@ def _rank(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module")
-def run2():
+# "peer": K17 exchange over IPC mappings inside hipGraph-replayed chains; "rccl": the eager loop with the
+# process group's all-reduce (gloo here, staged through the host)
+@pytest.fixture(scope="module", params=["peer", "rccl"])
+def run2(request):
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_rank, args=(world, _free_port(), out), nprocs=world, join=True)
-    return [out[r] for r in range(world)]
+    mp.spawn(_rank, args=(world, _free_port(), out, request.param), nprocs=world, join=True)
+    res = [out[r] for r in range(world)]
+    for r in res:
+        assert r["peer_exchange"] == [request.param == "peer"], r["peer_exchange"]
+    return res
 
 
 def test_ranks_start_and_stay_identical(run2):
