@@ -644,7 +644,8 @@ int ppoaf_mat_policy_step(const ppoaf_mat_step_args_t* args, ppoaf_stream_t stre
  * ppoaf_peer_exchange_allreduce is ONE kernel launch with fixed arguments (hipGraph-capturable):
  *   dst[i] = sum over ranks r = 0..n-1, in that order, of src_r[i]          (bitwise identical on every rank)
  *   norm_out[0] = sum_{i <  split} (norm_scale * dst[i])^2,  norm_out[1] = the same for i >= split
- *                 (double, added in a fixed order; NULL to skip; split_floats = bucket size for one segment)
+ *                 (double, added in a fixed order; NULL to skip; split_floats >= bucket size: one segment and
+ *                 only norm_out[0] is written)
  * dst may alias src.  All ranks must issue the same sequence of exchanges.  A rank waits at most
  * wait_seconds for its peers inside the kernel; on expiry the launch drains, dst is undefined and the error
  * word (status out[1]) holds the sequence number that timed out -- it never hangs.

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kXchgThreads) void peer_allreduce_kernel(XchgDev x,
             n0 += __hip_atomic_load(&x.norm_partials[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             n1 += __hip_atomic_load(&x.norm_partials[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (norm_out) { norm_out[0] = n0; norm_out[1] = n1; }
+        if (norm_out) { norm_out[0] = n0; if (split4 < x.n4) norm_out[1] = n1; }     // one segment: one word
         __hip_atomic_store(&x.words[2], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&x.words[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -455,6 +455,8 @@ class FusedIcmUpdate:
         self._lib = _lib.load()
         self.perm = None
         self._graphs, self._args = {}, {}
+        self.xchg, self.xchg_reason = (peer_exchange.open_exchange(pol.icm_model.flat_grads.numel(), dev)
+                                       if self.multi else (None, "single rank"))
 
     def _make_args(self, B):
         pol, buf, opt = self.pol, self.pol.buffer, self.pol.icm_optim
@@ -517,13 +519,17 @@ class FusedIcmUpdate:
         if rc != 0:
             _lib.check(rc, "icm_update")
         if self.multi:
-            mpi_utils.allreduce_sum_(self.pol.icm_model.flat_grads)
+            g = self.pol.icm_model.flat_grads
+            if self.xchg is not None:
+                self.xchg.allreduce(g, g, stream=st)                                  # K17, in-graph
+            else:
+                mpi_utils.allreduce_sum_(g)
             self.pol.icm_optim.step(grad_scale=1.0 / self.world, max_norm=None)
 
     def run_epoch(self):
         args = self._args_for(self.B)
         left = self.n_full
-        use_graph = self.ppo.use_graphs and not self.multi
+        use_graph = self.ppo.use_graphs and (not self.multi or self.xchg is not None)   # RCCL calls are not captured
         chunk = self.graph_chunk if self.n_full < 8 * self.graph_chunk else 4 * self.graph_chunk   # long epochs: fewer, longer graphs
         while left > 0:
             if use_graph and left >= chunk:
@@ -554,7 +560,10 @@ class FusedIcmUpdate:
         t = self.totals.clone()
         if self.multi:
             mpi_utils.allreduce_sum_(t)
-        return t.cpu().numpy()
+        out = t.cpu().numpy()
+        if self.xchg is not None:
+            self.xchg.check()
+        return out
 
 
 # ======================================================================================
@@ -652,6 +661,7 @@ class FusedMatUpdate(FusedPolicyUpdate):
         self._lib = _lib.load()
         self.records = self.adv_records = self.perm = None
         self._graphs, self._args = {}, {}
+        self.xchg, self.xchg_reason = (peer_exchange.open_exchange(total, dev) if self.multi else (None, "single rank"))
 
     def _make_args(self, B):
         pol, ppo, buf = self.pol, self.ppo, self.pol.buffer
@@ -678,7 +688,9 @@ class FusedMatUpdate(FusedPolicyUpdate):
         a.loss_partials, a.totals = self.loss_partials.data_ptr(), self.totals.data_ptr()
         opt = pol.actor_critic_optim
         a.norm_scratch, a.step_count = opt.norm_scratch.data_ptr(), opt.step_count.data_ptr()
-        a.fuse_norm = int(not self.multi)          # one rank: the reduce launch also yields ||g||^2 and the step count
+        # the reduce launch also advances the step count and yields the local ||g||^2 (replaced by K17's norm of the
+        # summed gradient when ranks exchange); only the RCCL path runs the separate K11 norm pass
+        a.fuse_norm = int(not self.multi or self.xchg is not None)
         return a
 
     def begin_epoch(self, perm):
@@ -726,15 +738,17 @@ class FusedMatUpdate(FusedPolicyUpdate):
             rc = lib.ppoaf_mat_update_reduce(ref, st)
         if rc != 0:
             _lib.check(rc, "mat_update")
-        if self.multi:
+        if self.multi and self.xchg is None:
             mpi_utils.allreduce_sum_(self.pol.policy_grads)
             self.pol.optimizer_step(1.0 / self.world)
             return
         opt, ac = self.pol.actor_critic_optim, self.pol.actor_critic
         clip = self.pol.gradient_clip
+        if self.xchg is not None:
+            self.xchg.allreduce(ac.flat_grads, ac.flat_grads, norm_scale=1.0 / self.world, norm_out=opt.norm_scratch, stream=st)
         rc = lib.ppoaf_adam_step_prenormed(
             ac.flat_params.data_ptr(), ac.flat_grads.data_ptr(), opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr(),
             ac.flat_params.numel(), opt.step_count.data_ptr(), opt.lr.data_ptr(), opt.betas[0], opt.betas[1], opt.eps,
-            1.0, float(clip) if clip is not None else 0.0, opt.norm_scratch.data_ptr(), opt.grad_norm.data_ptr(), st)
+            1.0 / self.world, float(clip) if clip is not None else 0.0, opt.norm_scratch.data_ptr(), opt.grad_norm.data_ptr(), st)
         if rc != 0:
             _lib.check(rc, "adam_step_prenormed")

@@ -171,8 +171,8 @@ def open_exchange(n_floats, device):
     device = torch.device(device)
     world = mpi_utils.get_num_procs()
     hosts = _all_gather_bytes(socket.gethostname().encode())
-    if not _vote(device.type == "cuda" and world <= MAX_RANKS and len(set(hosts)) == 1):
-        return refuse(f"needs CUDA devices of one host and at most {MAX_RANKS} ranks")
+    if not _vote(device.type == "cuda" and world <= MAX_RANKS and len(set(hosts)) == 1 and n_floats % 4 == 0):
+        return refuse(f"needs CUDA devices of one host, at most {MAX_RANKS} ranks and a bucket of a multiple of 4 floats")
     x, err = None, ""
     try:
         x = PeerExchange(n_floats, device)
