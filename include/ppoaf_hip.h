@@ -662,6 +662,16 @@ int ppoaf_peer_exchange_connect(ppoaf_peer_exchange_t* x, const void* all_blobs 
 int ppoaf_peer_exchange_allreduce(ppoaf_peer_exchange_t* x, const float* src, float* dst, int64_t split_floats,
                                   float norm_scale, double* norm_out, double wait_seconds, ppoaf_stream_t stream);
 int ppoaf_peer_exchange_status(ppoaf_peer_exchange_t* x, int64_t* out /* host [4] */);
+/* K12 + K17 in one launch: ppoaf_ppo_update_reduce (slabs -> gradient, bookkeeping) whose column sums go from
+ * registers into the exchange slot, followed by the cross-rank sum into args->grads; the two clip norms
+ * (scaled by args->grad_scale) are left as per-workgroup partials inside the exchange object and are added, in
+ * a fixed order, by ppoaf_ppo_update_adam_exchanged -- the Adam launch that must follow on the same stream
+ * (ppoaf_ppo_update_adam with the norms taken from the exchange instead of args->norm_scratch).
+ * The exchange must have been created for args->bucket_total floats (at most 256 * 1024 of them). */
+int ppoaf_ppo_update_reduce_exchange(const ppoaf_ppo_update_args_t* args, ppoaf_peer_exchange_t* x,
+                                     double wait_seconds, ppoaf_stream_t stream);
+int ppoaf_ppo_update_adam_exchanged(const ppoaf_ppo_update_args_t* args, ppoaf_peer_exchange_t* x,
+                                    ppoaf_stream_t stream);
 int ppoaf_peer_exchange_destroy(ppoaf_peer_exchange_t* x);
 
 #ifdef __cplusplus

@@ -12,14 +12,14 @@
 //   phase 2  the workgroups poll the LOCAL flag words until every peer has published this sequence number,
 //   phase 3  every workgroup reads its slice from all the peers' slots (loads of up to 8 peers in flight) and
 //            adds them in rank order -- every rank computes the bitwise identical sum, so replicas stay
-//            identical -- writes the summed bucket and per-workgroup squared-norm partials; the last
-//            workgroup to finish adds the partials in workgroup order (deterministic clip coefficient on
-//            every rank) and advances the sequence word.
+//            identical -- writes the summed bucket and per-workgroup squared-norm partials, which are added
+//            in workgroup order (deterministic clip coefficient on every rank) by the last workgroup to
+//            finish, or by the consuming kernel (K12's Adam launch).
 //
 // Two slots suffice with one flag per exchange: a rank rewrites slot s&1 at exchange s+2 only after it has
 // passed the wait of exchange s+1, and a peer publishes s+1 only after its exchange-s launch has completed.
 // Every wait is bounded (wall-clock budget): on expiry the error word is set and the launch drains.
-#include "common.hpp"
+#include "peer_exchange_device.hpp"
 
 #include <unistd.h>
 #include <cstring>
@@ -27,102 +27,30 @@
 
 namespace ppoaf {
 
-constexpr int kMaxPeers = PPOAF_PEER_EXCHANGE_MAX_RANKS;
-constexpr int kXchgThreads = 256;
-constexpr int kXchgMaxGrid = 64;
-constexpr size_t kHeaderBytes = 256;                // flag words of one rank; slots start after it
-
-struct XchgDev {
-    int rank, n_ranks;
-    long n4;                                        // float4 elements of one slot
-    long long* words;                               // local: [0] sequence, [1] arrive count, [2] finish count, [3] error
-    long long* my_flags;                            // this rank's flag words (polled locally)
-    long long* peer_flags[kMaxPeers];               // rank p's flag words (remote store target)
-    const float4* peer_slots[kMaxPeers];            // rank p's two slots
-    float4* my_slots;
-    double* norm_partials;                          // [kXchgMaxGrid][2]
-};
-
 __global__ __launch_bounds__(kXchgThreads) void peer_allreduce_kernel(XchgDev x, const float4* src, float4* dst,
                                                                      long split4, float norm_scale,
                                                                      double* norm_out, long long wait_ticks) {
     __shared__ double red[17];
     __shared__ int s_last;
     const int tid = threadIdx.x;
-    const long long seq = x.words[0] + 1;           // advanced by the last workgroup of the previous launch
+    const long long seq = xchg_sequence(x);
     const long slot = (long)(seq & 1) * x.n4;
     const long stride = (long)gridDim.x * kXchgThreads;
-    // ---- phase 1: publish
     float4* mine = x.my_slots + slot;
     for (long i = (long)blockIdx.x * kXchgThreads + tid; i < x.n4; i += stride) mine[i] = src[i];
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(&x.words[1]), 1ull);
-        if (prev == (unsigned long long)gridDim.x - 1ull) {
-            __hip_atomic_store(&x.words[1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
-            for (int p = 0; p < x.n_ranks; ++p)
-                if (p != x.rank)
-                    __hip_atomic_store(&x.peer_flags[p][x.rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-    // ---- phase 2: wait for every peer's sequence number
-    if (tid < x.n_ranks && tid != x.rank) {
-        const long long t0 = (long long)wall_clock64();
-        while (__hip_atomic_load(&x.my_flags[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-            __builtin_amdgcn_s_sleep(2);
-            if ((long long)wall_clock64() - t0 > wait_ticks) {
-                __hip_atomic_store(&x.words[3], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);        // system scope: drop any cached peer lines
-    // ---- phase 3: sum in rank order
+    xchg_publish(x, seq, gridDim.x);
+    xchg_wait(x, seq, wait_ticks);
     double q0 = 0.0, q1 = 0.0;
     for (long i = (long)blockIdx.x * kXchgThreads + tid; i < x.n4; i += stride) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int p0 = 0; p0 < x.n_ranks; p0 += 8) {
-            float4 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int p = p0 + k;
-                if (p >= x.n_ranks) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                else if (p == x.rank) v[k] = src[i];
-                else v[k] = x.peer_slots[p][slot + i];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (p0 + k < x.n_ranks) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
-        }
+        const float4 acc = xchg_sum(x, slot, i, src[i]);
         dst[i] = acc;
-        const float sc = norm_scale;
-        const double q = (double)(acc.x * sc) * (acc.x * sc) + (double)(acc.y * sc) * (acc.y * sc) +
-                         (double)(acc.z * sc) * (acc.z * sc) + (double)(acc.w * sc) * (acc.w * sc);
+        const double q = xchg_sq(acc, norm_scale);
         if (i < split4) q0 += q; else q1 += q;
     }
-    q0 = block_sum(q0, red);
-    q1 = block_sum(q1, red);
-    if (tid == 0) {
-        x.norm_partials[2 * blockIdx.x] = q0;
-        x.norm_partials[2 * blockIdx.x + 1] = q1;
-        __threadfence();
-        const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(&x.words[2]), 1ull);
-        s_last = prev == (unsigned long long)gridDim.x - 1ull;
-    }
-    __syncthreads();
-    if (s_last && tid == 0) {
-        __threadfence();
-        double n0 = 0.0, n1 = 0.0;
-        for (unsigned b = 0; b < gridDim.x; ++b) {
-            n0 += __hip_atomic_load(&x.norm_partials[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            n1 += __hip_atomic_load(&x.norm_partials[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (norm_out) { norm_out[0] = n0; if (split4 < x.n4) norm_out[1] = n1; }     // one segment: one word
-        __hip_atomic_store(&x.words[2], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&x.words[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (norm_out) {                                  // uniform over the launch
+        q0 = block_sum(q0, red);
+        q1 = block_sum(q1, red);
+        xchg_finish(x, blockIdx.x, gridDim.x, q0, q1, split4 < x.n4, norm_out, &s_last);
     }
 }
 
@@ -139,15 +67,6 @@ static_assert(sizeof(ExportBlob) == PPOAF_PEER_EXCHANGE_BLOB_BYTES, "blob layout
 }  // namespace ppoaf
 
 using namespace ppoaf;
-
-struct ppoaf_peer_exchange {
-    XchgDev dev;
-    void* base = nullptr;                           // exported allocation: header + 2 slots
-    size_t bytes = 0;
-    void* opened[kMaxPeers] = {};
-    bool connected = false;
-    int memory_kind = 0;                            // 1 uncached, 2 fine-grained
-};
 
 #define PPOAF_HIP_TRY(expr, what)                                                      \
     do {                                                                               \
@@ -168,7 +87,7 @@ extern "C" int ppoaf_peer_exchange_create(int rank, int n_ranks, int64_t bucket_
     ppoaf_peer_exchange* x = new (std::nothrow) ppoaf_peer_exchange();
     PPOAF_REQUIRE(x, "peer_exchange_create: out of host memory");
     x->dev.rank = rank; x->dev.n_ranks = n_ranks; x->dev.n4 = bucket_floats / 4;
-    x->bytes = kHeaderBytes + 2 * (size_t)bucket_floats * sizeof(float);
+    x->bytes = kXchgHeaderBytes + 2 * (size_t)bucket_floats * sizeof(float);
     hipError_t e = hipExtMallocWithFlags(&x->base, x->bytes, hipDeviceMallocUncached);
     x->memory_kind = 1;
     if (e != hipSuccess) {
@@ -197,7 +116,7 @@ extern "C" int ppoaf_peer_exchange_create(int rank, int n_ranks, int64_t bucket_
     x->dev.words = static_cast<long long*>(local);
     x->dev.norm_partials = reinterpret_cast<double*>(x->dev.words + 4);
     x->dev.my_flags = static_cast<long long*>(x->base);
-    x->dev.my_slots = reinterpret_cast<float4*>(static_cast<char*>(x->base) + kHeaderBytes);
+    x->dev.my_slots = reinterpret_cast<float4*>(static_cast<char*>(x->base) + kXchgHeaderBytes);
     for (int p = 0; p < kMaxPeers; ++p) { x->dev.peer_flags[p] = nullptr; x->dev.peer_slots[p] = nullptr; }
     x->dev.peer_flags[rank] = x->dev.my_flags;
     x->dev.peer_slots[rank] = x->dev.my_slots;
@@ -233,7 +152,7 @@ extern "C" int ppoaf_peer_exchange_connect(ppoaf_peer_exchange_t* x, const void*
                       "peer_exchange_connect: hipIpcOpenMemHandle");
         x->opened[p] = ptr;
         x->dev.peer_flags[p] = static_cast<long long*>(ptr);
-        x->dev.peer_slots[p] = reinterpret_cast<const float4*>(static_cast<char*>(ptr) + kHeaderBytes);
+        x->dev.peer_slots[p] = reinterpret_cast<const float4*>(static_cast<char*>(ptr) + kXchgHeaderBytes);
     }
     x->connected = true;
     return PPOAF_OK;

@@ -1,0 +1,154 @@
+// K17 device side: the three phases of the peer-mapped gradient exchange (see peer_exchange.hip for the
+// protocol).  Shared by the stand-alone exchange kernel and by kernels that fuse the exchange into the
+// launch that produces the gradient (ppo_update.hip: slab reduce + exchange in one launch).
+#pragma once
+
+#include "common.hpp"
+
+namespace ppoaf {
+
+constexpr int kMaxPeers = PPOAF_PEER_EXCHANGE_MAX_RANKS;
+constexpr int kXchgThreads = 256;
+constexpr int kXchgMaxGrid = 256;               // every workgroup of an exchange launch must be resident (256 CUs)
+constexpr size_t kXchgHeaderBytes = 256;            // flag words of one rank; slots start after it
+
+struct XchgDev {
+    int rank, n_ranks;
+    long n4;                                        // float4 elements of one slot
+    long long* words;                               // local: [0] sequence, [1] arrive count, [2] finish count, [3] error
+    long long* my_flags;                            // this rank's flag words (polled locally)
+    long long* peer_flags[kMaxPeers];               // rank p's flag words (remote store target)
+    const float4* peer_slots[kMaxPeers];            // rank p's two slots
+    float4* my_slots;
+    double* norm_partials;                          // [kXchgMaxGrid][2]
+};
+
+// Sequence number of the exchange this launch performs.  Uniform over the launch: the word is advanced by the
+// last workgroup to ARRIVE in xchg_publish, i.e. after every workgroup of this launch has read it, and the
+// next launch is ordered behind this one by the stream.
+__device__ __forceinline__ long long xchg_sequence(const XchgDev& x) { return x.words[0] + 1; }
+
+// Phase 1 tail: the caller's threads have stored their part of this rank's slot.  Fence it to system scope;
+// the last of `n_groups` workgroups to arrive publishes the sequence number to every peer.  Only thread 0
+// waits for the arrival counter; the pollers of xchg_wait sit in another wave and start immediately.
+__device__ __forceinline__ void xchg_publish(const XchgDev& x, long long seq, unsigned n_groups) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(&x.words[1]), 1ull);
+        if (prev == (unsigned long long)n_groups - 1ull) {
+            __hip_atomic_store(&x.words[1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&x.words[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            for (int p = 0; p < x.n_ranks; ++p)
+                if (p != x.rank)
+                    __hip_atomic_store(&x.peer_flags[p][x.rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// Phase 2: poll the local flag words until every peer has published `seq`, at most wait_ticks of the
+// 100 MHz wall clock; on expiry the error word is set and the caller continues (the launch must drain).
+// Lane p of the SECOND wave polls peer p (blockDim.x >= 128).
+__device__ __forceinline__ void xchg_wait(const XchgDev& x, long long seq, long long wait_ticks) {
+    const int p = (int)threadIdx.x - 64;
+    if (p >= 0 && p < x.n_ranks && p != x.rank) {
+        const long long t0 = (long long)wall_clock64();
+        while (__hip_atomic_load(&x.my_flags[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((long long)wall_clock64() - t0 > wait_ticks) {
+                __hip_atomic_store(&x.words[3], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);        // system scope: drop any cached peer lines
+}
+
+// Phase 3 core: element i of the rank-ordered sum; `own` is this rank's contribution (already in registers).
+__device__ __forceinline__ float4 xchg_sum(const XchgDev& x, long slot, long i, const float4& own) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p0 = 0; p0 < x.n_ranks; p0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = p0 + k;
+            if (p >= x.n_ranks) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            else if (p == x.rank) v[k] = own;
+            else v[k] = x.peer_slots[p][slot + i];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (p0 + k < x.n_ranks) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+    }
+    return acc;
+}
+
+__device__ __forceinline__ double xchg_sq(const float4& a, float sc) {
+    return (double)(a.x * sc) * (a.x * sc) + (double)(a.y * sc) * (a.y * sc) +
+           (double)(a.z * sc) * (a.z * sc) + (double)(a.w * sc) * (a.w * sc);
+}
+
+// Fixed-order sum of the per-workgroup partials by one wave (all 64 lanes call it): 64 partials are loaded in
+// parallel, then the lanes are walked in order -- the same sum on every rank, without a chain of dependent loads.
+__device__ __forceinline__ double xchg_lane_value(double v, unsigned lane /* uniform */) {
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, (int)lane);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), (int)lane);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void xchg_ordered_norms(const double* partials, unsigned n_groups, double& n0, double& n1) {
+    const unsigned lane = threadIdx.x & 63;
+    n0 = 0.0; n1 = 0.0;
+    for (unsigned b0 = 0; b0 < n_groups; b0 += 64) {
+        const unsigned b = b0 + lane;
+        double p0 = 0.0, p1 = 0.0;
+        if (b < n_groups) {
+            p0 = __hip_atomic_load(&partials[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p1 = __hip_atomic_load(&partials[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned cnt = (n_groups - b0) < 64u ? (n_groups - b0) : 64u;
+        for (unsigned l = 0; l < cnt; ++l) { n0 += xchg_lane_value(p0, l); n1 += xchg_lane_value(p1, l); }
+    }
+}
+
+// Phase 3 tail when the norms are wanted by the end of THIS launch: per-workgroup squared-norm partials (q0, q1
+// already summed over the workgroup, `group` in [0, n_groups)); the last workgroup to finish adds them in
+// workgroup order and writes the norms.  `red_last` is one int of LDS.  (A consumer kernel can instead call
+// xchg_ordered_norms on the partials itself and save this launch the counter round trip.)
+__device__ __forceinline__ void xchg_finish(const XchgDev& x, unsigned group, unsigned n_groups,
+                                            double q0, double q1, bool two_segments, double* norm_out,
+                                            int* red_last) {
+    if (threadIdx.x == 0) {
+        x.norm_partials[2 * group] = q0;
+        x.norm_partials[2 * group + 1] = q1;
+        __threadfence();
+        const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(&x.words[2]), 1ull);
+        *red_last = prev == (unsigned long long)n_groups - 1ull;
+    }
+    __syncthreads();
+    if (*red_last && threadIdx.x < 64) {
+        __threadfence();
+        double n0, n1;
+        xchg_ordered_norms(x.norm_partials, n_groups, n0, n1);
+        if (threadIdx.x == 0) {
+            norm_out[0] = n0;
+            if (two_segments) norm_out[1] = n1;
+            __hip_atomic_store(&x.words[2], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// The host object behind ppoaf_peer_exchange_t (opaque in the C ABI).
+}  // namespace ppoaf
+
+struct ppoaf_peer_exchange {
+    ppoaf::XchgDev dev;
+    void* base = nullptr;                           // exported allocation: header + 2 slots
+    size_t bytes = 0;
+    void* opened[ppoaf::kMaxPeers] = {};
+    bool connected = false;
+    int memory_kind = 0;                            // 1 uncached, 2 fine-grained
+};

@@ -13,6 +13,7 @@
 // are summed in a fixed order by the reduce kernel, so results are bitwise reproducible (float
 // atomics would not be) and nothing needs zeroing.
 #include "mlp_device.hpp"
+#include "peer_exchange_device.hpp"
 #include <cstdlib>
 
 namespace ppoaf {
@@ -658,6 +659,48 @@ __global__ __launch_bounds__(kRedThreads) void ppo_update_reduce_kernel(UpdateDe
     }
 }
 
+// N > 1 with the K17 peer exchange: the slab reduce and the exchange in ONE launch.  The workgroup's float4
+// column sums go straight from registers into this rank's exchange slot (no copy through the gradient
+// bucket), the ranks' sums are added in rank order, and the bucket receives the cross-rank gradient together
+// with both clip norms (fixed-order, identical on every rank) -- the Adam launch follows without a norm pass.
+// Grid as the plain reduce: one column per thread, all workgroups resident (<= kXchgMaxGrid), bookkeeping last.
+__global__ __launch_bounds__(kRedThreads) void ppo_update_reduce_exchange_kernel(UpdateDev u, XchgDev x,
+                                                                                long long wait_ticks) {
+    __shared__ double red[17];
+    if (blockIdx.x == gridDim.x - 1) { ppo_update_bookkeeping(u); return; }      // uniform per workgroup
+    const unsigned n_groups = gridDim.x - 1;
+    const long n4 = u.bucket_total >> 2;
+    const long idx = (long)blockIdx.x * kRedThreads + threadIdx.x;
+    const float4* sl = reinterpret_cast<const float4*>(u.slabs);
+    const long long seq = xchg_sequence(x);
+    const long slot = (long)(seq & 1) * x.n4;
+    float4 own = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < n4) {
+        for (int g0 = 0; g0 < u.n_wg; g0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                v[k] = (g0 + k < u.n_wg) ? sl[(long)(g0 + k) * n4 + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { own.x += v[k].x; own.y += v[k].y; own.z += v[k].z; own.w += v[k].w; }
+        }
+        x.my_slots[slot + idx] = own;
+    }
+    xchg_publish(x, seq, n_groups);
+    xchg_wait(x, seq, wait_ticks);
+    double q0 = 0.0, q1 = 0.0;
+    if (idx < n4) {
+        const float4 acc = xchg_sum(x, slot, idx, own);
+        reinterpret_cast<float4*>(u.grads)[idx] = acc;
+        const double q = xchg_sq(acc, u.grad_scale);
+        if (idx * 4 < u.net[0].size) q0 = q; else q1 = q;
+    }
+    // partials only: the Adam launch that follows adds them in workgroup order itself (ppo_update_adam_kernel)
+    q0 = block_sum(q0, red);
+    q1 = block_sum(q1, red);
+    if (threadIdx.x == 0) { x.norm_partials[2 * blockIdx.x] = q0; x.norm_partials[2 * blockIdx.x + 1] = q1; }
+}
+
 // The per-mini-batch bookkeeping runs in its own (last) workgroup so that it overlaps the slab
 // reads instead of extending workgroup 0: loss partials summed by one wave (lane = workgroup of the
 // fwd_bwd kernel), totals, Adam step counters and bias corrections.
@@ -712,12 +755,17 @@ __global__ __launch_bounds__(256) void ppo_update_sqnorm_kernel(UpdateDev u) {
     }
 }
 
-__global__ __launch_bounds__(256) void ppo_update_adam_kernel(UpdateDev u) {
+// norm_partials != nullptr: the squared norms arrive as per-workgroup partials of the fused reduce + exchange
+// launch (n_norm_groups pairs); every wave adds them in workgroup order -- identical on all ranks.
+__global__ __launch_bounds__(256) void ppo_update_adam_kernel(UpdateDev u, const double* norm_partials,
+                                                              unsigned n_norm_groups) {
     const long n4 = u.bucket_total >> 2;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    double sq0 = 0.0, sq1 = 0.0;
+    if (norm_partials) xchg_ordered_norms(norm_partials, n_norm_groups, sq0, sq1);   // uniform branch, whole waves
     if (idx < n4) {
         const int which = (idx * 4 < u.net[0].size) ? 0 : 1;
-        const float total_norm = (float)sqrt(u.norm_scratch[which]);
+        const float total_norm = (float)sqrt(norm_partials ? (which ? sq1 : sq0) : u.norm_scratch[which]);
         float coef = 1.0f;
         if (u.max_norm > 0.f) coef = fminf(u.max_norm / (total_norm + 1e-6f), 1.0f);
         const float gs = u.grad_scale * coef;
@@ -909,6 +957,26 @@ extern "C" int ppoaf_ppo_update_reduce(const ppoaf_ppo_update_args_t* args, int 
     return check_launch("ppo_update_reduce");
 }
 
+extern "C" int ppoaf_ppo_update_reduce_exchange(const ppoaf_ppo_update_args_t* args, ppoaf_peer_exchange_t* xchg,
+                                                double wait_seconds, ppoaf_stream_t stream) {
+    UpdateDev u;
+    int rc = make_dev(args, u);
+    if (rc) return rc;
+    PPOAF_REQUIRE(xchg && xchg->connected, "ppo_update_reduce_exchange: exchange missing or not connected");
+    const long n4 = u.bucket_total >> 2;
+    PPOAF_REQUIRE(xchg->dev.n4 == n4, "ppo_update_reduce_exchange: exchange made for %ld float4, bucket has %ld",
+                  xchg->dev.n4, n4);
+    PPOAF_REQUIRE(xchg->dev.n_ranks == u.n_ranks || !u.normalize_values, "ppo_update_reduce_exchange: %d ranks in the exchange, %d in args",
+                  xchg->dev.n_ranks, u.n_ranks);
+    const long groups = (n4 + kRedThreads - 1) / kRedThreads;
+    PPOAF_REQUIRE(groups <= kXchgMaxGrid, "ppo_update_reduce_exchange: bucket of %ld floats needs %ld workgroups (at most %d: "
+                  "use ppoaf_ppo_update_reduce + ppoaf_peer_exchange_allreduce)", (long)u.bucket_total, groups, kXchgMaxGrid);
+    PPOAF_REQUIRE(wait_seconds > 0.0 && wait_seconds <= 600.0, "ppo_update_reduce_exchange: wait_seconds=%g", wait_seconds);
+    hipLaunchKernelGGL(ppo_update_reduce_exchange_kernel, dim3((unsigned)groups + 1u), dim3(kRedThreads), 0,
+                       (hipStream_t)stream, u, xchg->dev, (long long)(wait_seconds * 1.0e8));
+    return check_launch("ppo_update_reduce_exchange");
+}
+
 extern "C" int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int compute_norms,
                                      ppoaf_stream_t stream) {
     UpdateDev u;
@@ -921,8 +989,25 @@ extern "C" int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int co
         rc = check_launch("ppo_update_adam/sqnorm");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(ppo_update_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u);
+    hipLaunchKernelGGL(ppo_update_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u,
+                       (const double*)nullptr, 0u);
     return check_launch("ppo_update_adam");
+}
+
+extern "C" int ppoaf_ppo_update_adam_exchanged(const ppoaf_ppo_update_args_t* args, ppoaf_peer_exchange_t* xchg,
+                                               ppoaf_stream_t stream) {
+    UpdateDev u;
+    int rc = make_dev(args, u);
+    if (rc) return rc;
+    PPOAF_REQUIRE(xchg && xchg->connected, "ppo_update_adam_exchanged: exchange missing or not connected");
+    const long n4 = u.bucket_total >> 2;
+    PPOAF_REQUIRE(xchg->dev.n4 == n4, "ppo_update_adam_exchanged: exchange made for %ld float4, bucket has %ld",
+                  xchg->dev.n4, n4);
+    const unsigned groups = (unsigned)((n4 + kRedThreads - 1) / kRedThreads);     // as ppoaf_ppo_update_reduce_exchange
+    PPOAF_REQUIRE(groups <= (unsigned)kXchgMaxGrid, "ppo_update_adam_exchanged: bucket too large for the fused exchange");
+    hipLaunchKernelGGL(ppo_update_adam_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u,
+                       (const double*)xchg->dev.norm_partials, groups);
+    return check_launch("ppo_update_adam_exchanged");
 }
 
 #ifdef PPOAF_STAMPS

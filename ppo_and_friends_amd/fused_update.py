@@ -268,6 +268,13 @@ class FusedPolicyUpdate:
         ref = C.byref(args)
         single = not self.multi
         rc = lib.ppoaf_ppo_update_fwd_bwd(ref, st)
+        if rc == 0 and self.xchg is not None and self.pol.policy_grads.numel() <= 256 * 1024:
+            # slab reduce + K17 exchange in one launch (sums travel from registers to the exchange slot)
+            rc = lib.ppoaf_ppo_update_reduce_exchange(ref, self.xchg.handle, self.xchg.wait_seconds, st) \
+                or lib.ppoaf_ppo_update_adam_exchanged(ref, self.xchg.handle, st)
+            if rc != 0:
+                _lib.check(rc, "ppo_update")
+            return
         if rc == 0:
             rc = lib.ppoaf_ppo_update_reduce(ref, 1 if single else 0, st)
         if rc == 0 and self.xchg is not None:

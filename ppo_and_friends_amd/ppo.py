@@ -20,6 +20,7 @@ Device-first differences
 """
 import os
 import pickle
+import sys
 import time
 from collections import OrderedDict
 
@@ -656,9 +657,49 @@ class PPO:
                                    f"Ending early (after {epoch_idx + 1} epochs)")
                     break
             pol.clear_dataset()
+        self._guard_replicas()
         if self.device.type == "cuda":
             torch.cuda.synchronize()
         self.status_dict["global status"]["train time"] = time.time() - start
+
+    def _replicated_state(self):
+        """Every tensor that synchronous DD-PPO keeps bitwise identical on all ranks: parameter buckets + Adam moments."""
+        out = []
+        for pol in self.policies.values():
+            if getattr(pol, "agent_grouping", False) and hasattr(pol, "actor_critic"):
+                opt = pol.actor_critic_optim
+                out += [pol.actor_critic.flat_params, opt.exp_avg, opt.exp_avg_sq]
+            elif hasattr(pol, "policy_exp_avg"):
+                out += [pol.policy_params, pol.policy_exp_avg, pol.policy_exp_avg_sq]
+            if pol.enable_icm and hasattr(pol.icm_model, "flat_params"):
+                out += [pol.icm_model.flat_params, pol.icm_optim.exp_avg, pol.icm_optim.exp_avg_sq]
+        return out
+
+    def _guard_replicas(self):
+        """
+        Safety net of the K17 peer exchange (N > 1 only; one 8-byte all-gather per iteration).  The exchange
+        is self-tested at start-up and sums in a fixed order, so replicas stay bitwise identical; should they
+        ever differ (a peer mapping misbehaving in a way the self-test did not show), say so loudly, restore
+        rank 0's state everywhere and continue on the RCCL all-reduce path.  Returns True if all was well.
+        """
+        active = [f for f in getattr(self, "_fused", {}).values() if f is not None and getattr(f, "xchg", None) is not None]
+        if not active or mpi_utils.get_num_procs() == 1:
+            return True
+        state = self._replicated_state()
+        if mpi_utils.replicas_agree(state):
+            return True
+        print(f"[ppo_and_friends_amd] rank {mpi_utils.get_rank()}: replicas diverged under the peer gradient exchange; "
+              "restoring rank 0's weights and optimiser state and switching to the RCCL all-reduce path",
+              file=sys.stderr, flush=True)
+        for t in state:
+            mpi_utils.broadcast_flat(t)
+        for f in active:
+            f.xchg.close()
+            f.xchg, f.xchg_reason = None, "disabled: replicas diverged"
+            f._graphs.clear()
+            f._args = {}
+        self.status_dict["global status"]["peer exchange disabled"] = True
+        return False
 
     def _ppo_icm_epoch_overlapped(self, loader, policy_id):
         """

@@ -193,6 +193,28 @@ def allgather_records(rec):
     return out
 
 
+def bucket_checksum(tensors):
+    """
+    Order-sensitive int64 checksum of the BIT PATTERNS of float32 tensors (wrapping arithmetic, exact and
+    deterministic): replicas that are bitwise identical -- what synchronous DD-PPO maintains -- agree on it.
+    """
+    acc = None
+    for t in tensors:
+        bits = t.detach().reshape(-1).view(torch.int32).to(torch.int64)
+        w = torch.arange(1, bits.numel() + 1, dtype=torch.int64, device=bits.device) % 65521 + 1
+        c = (bits * w).sum()
+        acc = c if acc is None else acc * 1000003 + c
+    return acc.reshape(1)
+
+
+def replicas_agree(tensors):
+    """True when every rank holds the same checksum of `tensors` (one tiny all-gather)."""
+    if not distributed_path() or get_num_procs() == 1:
+        return True
+    allc = allgather_records(bucket_checksum(tensors))
+    return bool((allc == allc[0]).all().item())
+
+
 def allreduce_scalars(values, op="sum"):
     """One packed all-reduce for a list of Python scalars (ppo.py:2471-2475, 1991-2094)."""
     if not distributed_path():

@@ -159,3 +159,30 @@ def test_rollout_statistics_across_ranks(two_ranks):
     np.testing.assert_allclose(got["average episode"], (per[0]["average episode"] + per[1]["average episode"]) / 2)
     assert torch.equal(r0["filter_records"], torch.stack([torch.arange(7, dtype=torch.float64),
                                                           torch.arange(7, dtype=torch.float64) + 10]))
+
+
+def _checksum_rank(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from ppo_and_friends_amd.utils import mpi_utils
+    mpi_utils.init_process_group_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(1000, generator=g), torch.randn(77, generator=g)
+    same = mpi_utils.replicas_agree([a, b])
+    if rank == 1:
+        a[400] = torch.nextafter(a[400], torch.tensor(10.0))        # one ulp on one rank
+    differ = mpi_utils.replicas_agree([a, b])
+    swapped = mpi_utils.bucket_checksum([b, a]).item() != mpi_utils.bucket_checksum([a, b]).item()
+    out[rank] = (same, differ, swapped)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_checksum_sees_one_ulp():
+    """utils.mpi_utils.replicas_agree: the guard behind the K17 peer exchange (ppo.PPO._guard_replicas)."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_checksum_rank, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in range(2):
+        assert out[r] == (True, False, True)

@@ -137,11 +137,11 @@ def _rank_kind(rank, world, port, out, mode, kind):
     from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
     from ppo_and_friends_amd.spaces import Box, Discrete
     dev = torch.device("cuda", 0)
-    if kind == "icm":
+    if kind in ("icm", "guard"):
         E_, T_, O_, NA_, B_ = 16, 64, 6, 3, 16                 # 64 mini-batches per epoch: two graph chunks
         env_gen = lambda: SyntheticFixedLengthEnv(E_, O_, Discrete(NA_), T_, dev, reward="uniform", seed=77, rank=rank)
         sp = Box(-np.inf, np.inf, (O_,), np.float32)
-        settings = {"p": (None, sp, sp, Discrete(NA_), dict(enable_icm=True))}
+        settings = {"p": (None, sp, sp, Discrete(NA_), dict(enable_icm=kind == "icm"))}
     else:
         from ppo_and_friends_amd.policies.mat_policy import MATPolicy
         E_, T_, O_, NA_, B_, A_ = 16, 40, 18, 5, 16, 3           # 40 mini-batches: one graph chunk + eager rest
@@ -158,7 +158,18 @@ def _rank_kind(rank, world, port, out, mode, kind):
     res = dict(peer_exchange=[getattr(f, "xchg", None) is not None for f in fused],
                stats={k: float(v) for k, v in ppo.status_dict["p"].items()
                       if isinstance(v, (int, float)) and not isinstance(v, bool)})
-    if kind == "icm":
+    if kind == "guard":
+        # replicas agree after a normal iteration; then rank 1 is corrupted behind the framework's back
+        res["agree_before"] = ppo._guard_replicas()
+        if rank == 1:
+            pol.policy_params[7] += 1e-3
+        res["agree_after_corruption"] = ppo._guard_replicas()        # restores rank 0's state, leaves the peer path
+        res["w_healed"] = pol.policy_params.detach().cpu().clone()
+        res["peer_exchange_after"] = [getattr(f, "xchg", None) is not None for f in fused]
+        ppo.rollout()
+        ppo.train_on_rollout()                                       # continues on the all-reduce path
+        res["w"] = pol.policy_params.detach().cpu().clone()
+    elif kind == "icm":
         res["w"] = pol.policy_params.detach().cpu().clone()
         res["w_icm"] = pol.icm_model.flat_params.detach().cpu().clone()
     else:
@@ -187,3 +198,15 @@ def test_peer_exchange_equals_allreduce_path(kind):
         torch.testing.assert_close(a["w_icm"], b["w_icm"], rtol=1e-5, atol=1e-6)
     for k in a["stats"]:
         np.testing.assert_allclose(a["stats"][k], b["stats"][k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_diverged_replicas_are_detected_and_healed():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank_kind, args=(2, _free_port(), out, "peer", "guard"), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    for r in (r0, r1):
+        assert r["peer_exchange"] == [True] and r["agree_before"] is True
+        assert r["agree_after_corruption"] is False and r["peer_exchange_after"] == [False]
+    assert torch.equal(r0["w_healed"], r1["w_healed"])
+    assert torch.equal(r0["w"], r1["w"]) and not torch.equal(r0["w"], r0["w_healed"])
