@@ -32,17 +32,22 @@ __device__ __forceinline__ long long xchg_sequence(const XchgDev& x) { return x.
 // the last of `n_groups` workgroups to arrive publishes the sequence number to every peer.  Only thread 0
 // waits for the arrival counter; the pollers of xchg_wait sit in another wave and start immediately.
 __device__ __forceinline__ void xchg_publish(const XchgDev& x, long long seq, unsigned n_groups) {
-    __threadfence_system();
+    // Every wave waits until its own slot stores are acknowledged (they have then left the CU and reached the
+    // L2 / the uncached memory behind it), the barrier collects the waves, and ONE system-scope release fence
+    // by the publishing thread writes back whatever this XCD's L2 still holds.  A system fence in every wave
+    // costs 4.5 us more per launch (measured) and adds nothing: the waves of a workgroup share the XCD.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+        __threadfence_system();
         const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(&x.words[1]), 1ull);
         if (prev == (unsigned long long)n_groups - 1ull) {
             __hip_atomic_store(&x.words[1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&x.words[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
-            for (int p = 0; p < x.n_ranks; ++p)
+            __threadfence_system();                 // one release fence, then relaxed posted stores: a release
+            for (int p = 0; p < x.n_ranks; ++p)     // store per peer would repeat the L2 write-back per peer
                 if (p != x.rank)
-                    __hip_atomic_store(&x.peer_flags[p][x.rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&x.peer_flags[p][x.rank], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
