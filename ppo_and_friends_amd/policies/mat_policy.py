@@ -264,3 +264,20 @@ class MATPolicy(PPOPolicy):
         if not os.path.exists(f):
             f = os.path.join(path, "actor_critic_optim_0")
         self.actor_critic_optim.load_state_dict(torch.load(f, map_location="cpu", weights_only=False))
+
+    def direct_load(self, policy_load_path):
+        """mat_policy.py (direct_load): the actor_critic network only, from the directory itself."""
+        self.actor_critic.load(policy_load_path)
+
+    def apply_step_constraints(self, obs, critic_obs, reward, terminated, truncated, info):
+        """
+        mat_policy.py:808-853: with a non-local critic view the actor must see the critic's observation
+        (`obs[agent] = critic_obs[agent]`).  This build makes that substitution where the observation is
+        consumed -- the rollout hands the critic's observation to K16 / get_rollout_actions for the actor
+        when `expanded_actor_space` is set (ppo.py rollout) -- so the env tuple passes through unchanged.
+        """
+        return obs, critic_obs, reward, terminated, truncated, info
+
+    def apply_reset_constraints(self, obs, critic_obs):
+        """mat_policy.py:855-878: see apply_step_constraints."""
+        return obs, critic_obs

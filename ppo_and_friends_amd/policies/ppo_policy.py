@@ -591,5 +591,26 @@ class PPOPolicy:
                 continue                                   # checkpoints written before the ICM optimiser was saved
             opt.load_state_dict(torch.load(f, map_location="cpu", weights_only=False))
 
+    def direct_load(self, policy_load_path):
+        """ppo_policy.py:1287-1300: networks only, from the directory itself (no `<name>-policy/<tag>` below it)."""
+        self.actor.load(policy_load_path)
+        self.critic.load(policy_load_path)
+        if self.enable_icm:
+            self.icm_model.load(policy_load_path)
+
+    # ------------------------------------------------------------- hooks
+    def apply_step_constraints(self, *args):
+        """ppo_policy.py:1114-1135: identity; policies that must alter what the environment returns override it
+        (args = obs, critic_obs, reward, terminated, truncated, info as PPO.apply_policy_step_constraints passes them)."""
+        return args
+
+    def apply_reset_constraints(self, *args):
+        """ppo_policy.py:1137-1151: identity (args = obs, critic_obs)."""
+        return args
+
+    def get_agent_shared_intrinsic_rewards(self, *args):
+        """ppo_policy.py:1009-1010: only agent-grouped policies can share an ICM."""
+        raise NotImplementedError
+
     def __eq__(self, other):
         return isinstance(other, PPOPolicy) and self.name == other.name

@@ -219,6 +219,9 @@ class PPO:
         for pol in self.policies.values():
             pol.finalize(self.status_dict, self.device)
             pol.fused_icm_reward = update_mode != "torch"       # K14's kernels for the rollout-time intrinsic reward
+        # ppo.py:325-354: policies may post-process what the environment returns
+        self.have_policy_step_constraints = any(p.have_step_constraints for p in self.policies.values())
+        self.have_policy_reset_constraints = any(p.have_reset_constraints for p in self.policies.values())
         self.soft_resets.finalize(self.status_dict)
         if callable(getattr(self.env, "finalize", None)):
             self.env.finalize(self.status_dict)          # status-driven clip ranges (filter_wrappers.py:560-566)
@@ -266,7 +269,7 @@ class PPO:
         # ppo.py:1580-1586: a hard reset per rollout unless soft_resets (then the env carries on, and
         # a filter stack counts the carried observation once more, ppo_env_wrappers.py:149-199)
         if self._obs is None or not self.soft_resets():
-            obs, critic_obs = env.reset()
+            obs, critic_obs = self.apply_policy_reset_constraints(*env.reset())
         else:
             soft = getattr(env, "soft_reset", None)
             obs, critic_obs = soft() if callable(soft) else self._obs
@@ -294,7 +297,7 @@ class PPO:
                 # K16: encoder + autoregressive decoder passes + sampling + values + the buffer row in one launch
                 g_obs, g_cobs = group(obs), group(critic_obs)
                 action = pol.rollout_step(t, g_cobs, g_cobs if pol.expanded_actor_space else g_obs, vn)
-                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(ungroup(action))
+                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(ungroup(action)))
                 nat_buf[t].copy_(self._natural_reward(env, reward))
                 if self.ext_reward_weight != 1.0:
                     reward = reward * self.ext_reward_weight
@@ -303,7 +306,7 @@ class PPO:
             elif fused_step:
                 # K6+K7: inference, sampling, log-probs, values and the buffer row in one launch
                 action = pol.rollout_step(t, obs.contiguous(), critic_obs.contiguous(), vn)
-                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(action)
+                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(action))
                 nat_buf[t].copy_(self._natural_reward(env, reward))
                 if self.ext_reward_weight != 1.0:
                     reward = reward * self.ext_reward_weight
@@ -315,7 +318,7 @@ class PPO:
                 g_obs, g_cobs = group(obs), group(critic_obs)
                 raw_action, action, log_prob = pol.get_rollout_actions(g_cobs if pol.expanded_actor_space else g_obs)
                 value = self.get_policy_values(policy_id, g_cobs)
-                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(ungroup(action))
+                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(ungroup(action)))
                 nat_buf[t].copy_(self._natural_reward(env, reward))
                 if self.ext_reward_weight != 1.0:
                     reward = reward * self.ext_reward_weight
@@ -326,7 +329,7 @@ class PPO:
             else:
                 raw_action, action, log_prob = pol.get_rollout_actions(obs)
                 value = self.get_policy_values(policy_id, critic_obs)
-                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(action)
+                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(action))
                 nat_buf[t].copy_(self._natural_reward(env, reward))
                 if self.ext_reward_weight != 1.0:
                     reward = reward * self.ext_reward_weight
@@ -413,7 +416,7 @@ class PPO:
         if sorted(int(i) for c in ctxs for i in c["idx"]) != list(range(A)):
             raise ValueError("policy_mapping_fn must assign every agent of the env to exactly one policy")
         if self._obs is None or not self.soft_resets():
-            obs, critic_obs = env.reset()
+            obs, critic_obs = self.apply_policy_reset_constraints(*env.reset())
         else:
             soft = getattr(env, "soft_reset", None)
             obs, critic_obs = soft() if callable(soft) else self._obs
@@ -432,7 +435,7 @@ class PPO:
                 if actions is None:
                     actions = torch.zeros((A, n_envs) + tuple(a.shape[1:]), dtype=a.dtype, device=self.device)
                 actions[c["idx"]] = a.reshape((c["n"], n_envs) + tuple(a.shape[1:]))
-            nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = env.step(actions.reshape((A * n_envs,) + tuple(actions.shape[2:])))
+            nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(actions.reshape((A * n_envs,) + tuple(actions.shape[2:]))))
             nat = self._natural_reward(env, reward)
             if self.ext_reward_weight != 1.0:
                 reward = reward * self.ext_reward_weight
@@ -586,6 +589,39 @@ class PPO:
                 pickle.dump(self.status_dict, fh, protocol=pickle.HIGHEST_PROTOCOL)
         if mpi_utils.distributed_path():
             torch.distributed.barrier()
+
+    def apply_policy_reset_constraints(self, obs, critic_obs):
+        """ppo.py:1468-1491.  In this build the environment hands over batched device tensors
+        ([agents x envs, .], agent-major) instead of per-agent dicts; the hooks receive those."""
+        if self.have_policy_reset_constraints:
+            for pol in self.policies.values():
+                obs, critic_obs = pol.apply_reset_constraints(obs, critic_obs)
+        return obs, critic_obs
+
+    def apply_policy_step_constraints(self, obs, critic_obs, reward, terminated, truncated, info):
+        """ppo.py:1493-1532; `info` is this build's terminal-observation tensor (the only info field the path reads)."""
+        if self.have_policy_step_constraints:
+            for pol in self.policies.values():
+                obs, critic_obs, reward, terminated, truncated, info = pol.apply_step_constraints(
+                    obs, critic_obs, reward, terminated, truncated, info)
+        return obs, critic_obs, reward, terminated, truncated, info
+
+    def direct_load_policy(self, policy_id, policy_path):
+        """ppo.py:2664-2686: weights straight from `<state>/<name>-policy/<tag>`, value normaliser from that tag."""
+        self.policies[policy_id].direct_load(policy_path)
+        tag = os.path.basename(os.path.dirname(os.path.join(os.path.abspath(policy_path), "")))
+        if self.normalize_values and policy_id in self.value_normalizers:
+            for t in (tag, "latest"):
+                try:
+                    self.value_normalizers[policy_id].load_info(os.path.join(self.env_info_path, t))
+                    break
+                except OSError:
+                    continue
+
+    def load_policies(self, state_path, tag):
+        """ppo.py:2688-2701."""
+        for policy_id in self.policies:
+            self.load_policy(policy_id, state_path, tag)
 
     def load_status(self, state_path):
         with open(os.path.join(state_path, "state_0.pickle"), "rb") as fh:
