@@ -37,9 +37,12 @@ class ObsEncoder(nn.Module):
 
 
 class ICM(nn.Module):
-    def __init__(self, obs_size, act_size, discrete, reward_scale=0.01, out_init=1.0, enc=128, hidden=128, depth=2):
+    def __init__(self, obs_size, act_size, discrete, reward_scale=0.01, out_init=1.0, enc=128, hidden=128, depth=2,
+                 nvec=None):
+        """nvec: the MultiDiscrete class counts of an agent-shared ICM (act_size = sum(nvec)); icm.py:322-324."""
         super().__init__()
         self.discrete, self.act_size, self.reward_scale = discrete, act_size, reward_scale
+        self.nvec = None if nvec is None else [int(n) for n in nvec]
         self.obs_encoder = ObsEncoder(obs_size, enc, out_init, hidden)
         self.inv_model = nn.Module()
         self.inv_model.sequential_net = make_mlp(2 * enc, act_size, hidden, depth, out_gain=out_init)
@@ -49,7 +52,18 @@ class ICM(nn.Module):
     def forward(self, obs_1, obs_2, actions):
         e1, e2 = self.obs_encoder(obs_1), self.obs_encoder(obs_2)
         pred = self.inv_model.sequential_net(torch.cat((e1, e2), dim=1))
-        if self.discrete:
+        if self.nvec is not None:                                             # "multi-discrete"
+            pred = F.softmax(pred, dim=-1)                                    # icm.py:76-77: one softmax over the row
+            inv_loss, start = 0, 0
+            for idx, dim in enumerate(self.nvec):                             # :400-412
+                inv_loss = inv_loss + nn.CrossEntropyLoss(reduction="mean")(pred[:, start:start + dim], actions[:, idx:idx + 1].flatten())
+                start += dim
+            hots, start = [], 0
+            for dim in self.nvec:                                             # :198-211 (slices action COLUMNS by class offsets)
+                hots.append(F.one_hot(actions[:, start:start + dim], num_classes=dim).float().flatten(start_dim=1))
+                start += dim
+            fa = torch.cat(hots, dim=1)
+        elif self.discrete:
             pred = F.softmax(pred, dim=-1)                                    # icm.py:84-85
             inv_loss = nn.CrossEntropyLoss(reduction="mean")(pred, actions.squeeze(1))   # :413
             fa = F.one_hot(actions, num_classes=self.act_size).float().flatten(start_dim=1)   # :189-191

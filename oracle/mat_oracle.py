@@ -124,8 +124,9 @@ class MATActorCritic(nn.Module):
 class _SharedDataset(Dataset):
     """PPOSharedEpisodeDataset items: [A, .] per index (episode_info.py:1058-1084)."""
 
-    def __init__(self, obs, actions, adv, logp, rtg, values):
+    def __init__(self, obs, actions, adv, logp, rtg, values, next_obs=None):
         self.obs, self.actions, self.adv, self.logp, self.rtg, self.values = obs, actions, adv, logp, rtg, values
+        self.next_obs = next_obs
 
     def __len__(self):
         return self.obs.shape[0]
@@ -138,9 +139,20 @@ class CpuMATPPO:
     """One rank of the reference's MAT training on CPU (discrete actions, critic view 'local')."""
 
     def __init__(self, obs_dim, n_actions, A, lr=3e-4, gamma=0.99, lambd=0.95, bootstrap_clip=(-100.0, 100.0),
-                 surr_clip=0.2, entropy_weight=0.01, gradient_clip=0.5, batch_size=256, seed=0):
+                 surr_clip=0.2, entropy_weight=0.01, gradient_clip=0.5, batch_size=256, seed=0,
+                 enable_icm=False, agent_shared_icm=False, icm_lr=3e-4, icm_beta=0.8, intr_reward_weight=1.0):
         torch.manual_seed(seed)
         self.A, self.n_actions = A, n_actions
+        self.enable_icm, self.agent_shared_icm = enable_icm, agent_shared_icm
+        self.icm_beta, self.intr_reward_weight = icm_beta, intr_reward_weight
+        self.intrinsic_score_avg = 0.0
+        if enable_icm:                                    # mat_policy.py:132-176, 224-227
+            from .icm_oracle import ICM
+            if agent_shared_icm:                          # spaces spanning the group: obs A*O, MultiDiscrete([n] * A)
+                self.icm = ICM(obs_dim * A, n_actions * A, discrete=True, nvec=[n_actions] * A)
+            else:
+                self.icm = ICM(obs_dim, n_actions, discrete=True)
+            self.icm_optim = torch.optim.Adam(self.icm.parameters(), lr=icm_lr, eps=1e-5)
         self.ac = MATActorCritic(obs_dim, n_actions, A)
         self.optim = torch.optim.Adam(self.ac.parameters(), lr=lr, eps=1e-5)       # mat_policy.py:221-222
         self.gamma, self.lambd, self.clip = gamma, lambd, bootstrap_clip
@@ -171,13 +183,39 @@ class CpuMATPPO:
         ent = dist.entropy().reshape(B, self.A, 1)
         return values, logp, ent
 
-    def rollout(self, obs_table, reward_table, actions):
+    def intrinsic_rewards(self, obs, nxt, actions, slot_order):
+        """
+        ppo.py:1219-1288 for one step: obs / nxt [E,A,O], actions [E,A] in the policy's slot order ->
+        float32 [E,A].  Shared form (mat_policy.py:1012-1090): the rows are built in the ORIGINAL agent
+        order (icm_agent_ids) -- original agent k sits in slot argsort(slot_order)[k] -- and every agent of
+        an env receives the env's one value.
+        """
+        E, A = actions.shape
+        o, n, a = (torch.tensor(x) for x in (obs, nxt, actions))
+        with torch.no_grad():
+            if self.agent_shared_icm:
+                inv = torch.as_tensor(np.argsort(slot_order))
+                ir, _, _ = self.icm(o[:, inv].reshape(E, -1).float(), n[:, inv].reshape(E, -1).float(), a[:, inv].long())
+                ir = ir.reshape(E, 1).repeat(1, A)
+            else:
+                ir, _, _ = self.icm(o.reshape(E * A, -1).float(), n.reshape(E * A, -1).float(), a.reshape(E * A, 1).long())
+                ir = ir.reshape(E, A)
+        return ir.numpy() * np.float32(self.intr_reward_weight)
+
+    def rollout(self, obs_table, reward_table, actions, slot_order=None):
         """
         obs_table [T+1,E,A,O], reward_table [T,E,A], actions [T,E,A] (recorded).  Fixed-length: every env's
         shared episode closes at the last step with the critic bootstrap; dataset rows are env-major
-        (episode_info.py:584-637), each row [A, .].
+        (episode_info.py:584-637), each row [A, .].  slot_order[j] = original index of the agent in slot j
+        (needed by the agent-shared ICM only).
         """
         T, E, A = reward_table.shape
+        intr = None
+        if self.enable_icm:
+            slot_order = np.arange(A) if slot_order is None else np.asarray(slot_order)
+            intr = np.stack([self.intrinsic_rewards(obs_table[t], obs_table[t + 1], actions[t], slot_order)
+                             for t in range(T)])                              # [T,E,A]
+            reward_table = reward_table.astype(np.float64) + intr             # ppo.py:1283 (float64 + float32)
         with torch.no_grad():
             vals, logps = [], []
             for t in range(T):
@@ -191,14 +229,49 @@ class CpuMATPPO:
         adv = np.zeros((E * T, A), dtype=np.float32); rtg = np.zeros((E * T, A), dtype=np.float32)
         for e in range(E):
             for a in range(A):
+                nr = float(next_value[e, a])
+                if self.enable_icm:                      # ppo.py:1926-1930 "surprise" (per env: quirk Q2 fixed)
+                    nr = float(np.float32(nr) + (intr[T - 1, e, a] - np.float32(self.intrinsic_score_avg)))
                 ad, rg = eo.end_episode(reward_table[:, e, a], vals[:, e, a], float(next_value[e, a]),
-                                        float(next_value[e, a]), self.gamma, self.lambd, self.clip, True)
+                                        nr, self.gamma, self.lambd, self.clip, True)
                 adv[e * T:(e + 1) * T, a] = ad; rtg[e * T:(e + 1) * T, a] = rg
         flat = lambda x: np.concatenate([x[:, e] for e in range(E)], axis=0)
         self.dataset = _SharedDataset(torch.tensor(flat(obs_table[:-1])), torch.tensor(flat(actions)).long(),
                                       torch.tensor(adv), torch.tensor(flat(logps)), torch.tensor(rtg),
-                                      torch.tensor(flat(vals)))
+                                      torch.tensor(flat(vals)),
+                                      torch.tensor(flat(obs_table[1:])) if self.enable_icm else None)
+        if self.enable_icm:
+            # ppo.py:1940-1963, 2074-2080 with no terminations: every env contributes exactly one (maxed) episode,
+            # total_episodes / env_batch_size = 1, and the per-policy score sums the agents' rewards
+            self.intrinsic_score_avg = float(intr.sum())
         return self.dataset
+
+    def icm_train_epoch(self, agent_idxs=None):
+        """
+        ppo.py:2487-2567 on the shared dataset.  agent_idxs = the policy's (in-place shuffled) index vector,
+        applied as `x[:, agent_idxs]` before the agents are laid side by side (case 2); without agent sharing
+        every (row, agent) pair is one sample (case 3).
+        """
+        ds = self.dataset
+        loader = DataLoader(ds, batch_size=self.batch_size, shuffle=True, generator=self.loader_generator)
+        total, n = 0.0, 0
+        for obs, act, _, _, _, idx in loader:
+            obs, nxt = obs.float(), ds.next_obs[idx].float()
+            B = obs.shape[0]
+            if self.agent_shared_icm:
+                ai = torch.as_tensor(np.asarray(agent_idxs))
+                obs, nxt = obs[:, ai].reshape(B, -1), nxt[:, ai].reshape(B, -1)
+                act = act.reshape(B, self.A, 1)[:, ai].reshape(B, -1)
+            else:
+                obs, nxt, act = obs.reshape(B * self.A, -1), nxt.reshape(B * self.A, -1), act.reshape(B * self.A, -1)
+            _, inv_loss, f_loss = self.icm(obs, nxt, act)
+            icm_loss = (1.0 - self.icm_beta) * f_loss + self.icm_beta * inv_loss
+            total += icm_loss.item()
+            self.icm_optim.zero_grad()
+            icm_loss.backward()
+            self.icm_optim.step()
+            n += 1
+        return total / max(n, 1)
 
     def train_epoch(self):
         """ppo.py:2274-2485 with MATPolicy.evaluate / update_weights (one optimiser, summed loss)."""

@@ -440,6 +440,8 @@ class FusedIcmUpdate:
     def unsupported_reason(pol):
         if not pol.enable_icm:
             return "no ICM"
+        if pol.agent_grouping:
+            return "agent-grouped policy: the ICM rows are regrouped per mini-batch (ppo.py:2509-2545), torch path"
         _, why = _describe_icm(pol.icm_model, pol.action_dtype)
         return why
 

@@ -51,7 +51,8 @@ class LinearInverseModel(nn.Module):
 
     def forward(self, enc_obs_1, enc_obs_2):
         out = self.sequential_net(torch.cat((enc_obs_1, enc_obs_2), dim=1))
-        if self.action_dtype == "discrete":
+        if self.action_dtype in ("discrete", "multi-discrete"):
+            # icm.py:76-77: ONE softmax over the whole output row, also when it holds several dims' classes
             out = t_functional.softmax(out, dim=-1)
         return out
 
@@ -60,10 +61,11 @@ class LinearForwardModel(nn.Module):
     """icm.py:117-211: (enc_1, action [one-hot for discrete]) -> predicted enc_2."""
 
     def __init__(self, in_size, out_size, out_init, hidden_size, hidden_depth, action_dtype, n_classes,
-                 activation=None, **kw_args):
+                 activation=None, action_nvec=None, **kw_args):
         super().__init__()
         self.action_dtype = action_dtype
         self.n_classes = n_classes
+        self.action_nvec = None if action_nvec is None else [int(n) for n in action_nvec]
         self.activation = nn.ReLU() if activation is None else activation
         self.sequential_net = create_sequential_network(in_size, out_size, hidden_size, hidden_depth,
                                                         self.activation, out_init)
@@ -71,6 +73,16 @@ class LinearForwardModel(nn.Module):
     def forward(self, enc_obs_1, actions):
         if self.action_dtype == "discrete":
             actions = t_functional.one_hot(actions, num_classes=self.n_classes).float().flatten(start_dim=1)
+        elif self.action_dtype == "multi-discrete":
+            # icm.py:198-211 literally: the loop slices the action COLUMNS by class offsets
+            # (start:stop walks nvec), so with nvec = [n] * A the first slices take all the columns and the
+            # rest are empty -- for equal class counts that equals one_hot(actions, n) flattened
+            one_hots, start = [], 0
+            for dim in self.action_nvec:
+                stop = start + dim
+                one_hots.append(t_functional.one_hot(actions[:, start:stop], num_classes=dim).float().flatten(start_dim=1))
+                start = stop
+            actions = torch.cat(one_hots, dim=1)
         return self.sequential_net(torch.cat((enc_obs_1, actions), dim=1))
 
 
@@ -103,8 +115,10 @@ class ICM(PPONetwork):
         super().__init__(in_shape=get_space_shape(obs_space), out_shape=(1,), **kw_args)
         self.reward_scale = reward_scale
         self.action_dtype = get_space_dtype_str(action_space)
-        if self.action_dtype not in ("discrete", "continuous"):
+        if self.action_dtype not in ("discrete", "multi-discrete", "continuous"):
             raise NotImplementedError(f"ICM for {self.action_dtype} actions is outside the hot-path scope")
+        self.obs_space, self.action_space = obs_space, action_space
+        self.action_nvec = [int(n) for n in action_space.nvec] if hasattr(action_space, "nvec") else None
         act_size = get_action_prediction_shape(action_space)[0]
         self.activation = nn.ReLU() if activation is None else activation
         self.ce_loss = nn.CrossEntropyLoss(reduction="mean")
@@ -118,7 +132,7 @@ class ICM(PPONetwork):
                                             inverse_hidden_depth, self.action_dtype, activation=self.activation)
         self.forward_model = LinearForwardModel(encoded_obs_dim + act_size, encoded_obs_dim, out_init,
                                                 forward_hidden_size, forward_hidden_depth, self.action_dtype,
-                                                act_size, activation=self.activation)
+                                                act_size, activation=self.activation, action_nvec=self.action_nvec)
 
     def forward(self, obs_1, obs_2, actions):
         enc_obs_1 = self.obs_encoder(obs_1)
@@ -128,6 +142,15 @@ class ICM(PPONetwork):
             # the reference feeds its softmax output to CrossEntropyLoss (a second log-softmax): kept
             actions = actions.reshape(actions.shape[0], -1)[:, 0]
             inv_loss = self.ce_loss(action_pred, actions)
+            fwd_actions = actions
+        elif self.action_dtype == "multi-discrete":
+            # icm.py:400-412: one cross entropy per action dim on its slice of the (jointly soft-maxed) row, summed
+            actions = actions.reshape(actions.shape[0], -1)
+            inv_loss, start = 0, 0
+            for idx, dim in enumerate(self.action_nvec):
+                stop = start + dim
+                inv_loss = inv_loss + self.ce_loss(action_pred[:, start:stop], actions[:, idx])
+                start = stop
             fwd_actions = actions
         else:
             fwd_actions = actions.reshape(action_pred.shape)

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as t_func
 
 from ..networks.multi_agent_transformer import MATActorCritic
-from ..spaces import get_space_shape
+from ..spaces import get_agent_shared_space, get_space_shape
 from ..utils import mpi_utils
 from ..utils.episode_info import PPODataset, RolloutBuffer
 from .ppo_policy import FlatAdam, PPOPolicy
@@ -35,8 +35,6 @@ class MATPolicy(PPOPolicy):
             self.have_step_constraints = True
             self.have_reset_constraints = True
             self.actor_obs_space = self.critic_obs_space
-        if self.enable_icm:
-            raise NotImplementedError("ICM with MAT (agent-shared ICM) is not built")
 
     # ------------------------------------------------------------------ setup
     def finalize(self, status_dict, device):
@@ -54,7 +52,7 @@ class MATPolicy(PPOPolicy):
             self.bootstrap_clip[0].finalize(status_dict)
             self.bootstrap_clip[1].finalize(status_dict)
         self.actor_critic_optim = FlatAdam(self.actor_critic, self.lr(), eps=1e-5)
-        self.icm_optim = None
+        self.icm_optim = FlatAdam(self.icm_model, self.icm_lr(), eps=1e-5) if self.enable_icm else None   # mat_policy.py:224-227
         self.shuffle_agent_ids()
 
     def _initialize_networks(self, ac_network, enable_icm, icm_network, mat_kw_args, icm_kw_args, **kw_args):
@@ -71,6 +69,26 @@ class MATPolicy(PPOPolicy):
         self.critic = self.actor_critic.critic
         self.policy_params = self.actor_critic.flat_params
         self.policy_grads = self.actor_critic.flat_grads
+        if enable_icm:
+            # mat_policy.py:132-176.  Two forms: one ICM over each agent's own (observation, action) -- rows are
+            # then (env, agent) pairs -- or, with agent_shared_icm, one ICM over the concatenation of the
+            # group's observations / actions in the ORIGINAL agent order (icm_agent_ids), one reward per env.
+            from ..networks.icm import ICM
+            self.icm_agent_ids = None
+            icm_obs_space, icm_action_space = self.actor_obs_space, self.action_space
+            if self.agent_shared_icm:
+                if self.expanded_actor_space:
+                    raise ValueError("agent_shared_icm can only be enabled with the multi-agent transformer "
+                                     "if critic view is set to local (mat_policy.py:146-152)")
+                n = len(self.agent_ids)
+                icm_obs_space = get_agent_shared_space(self.actor_obs_space, n)
+                icm_action_space = get_agent_shared_space(self.action_space, n)
+                self.icm_agent_ids = np.array(self.agent_ids).copy()
+            icm_cls = ICM if icm_network is None else icm_network
+            self.icm_model = icm_cls(name="icm", obs_space=icm_obs_space, action_space=icm_action_space,
+                                     test_mode=self.test_mode, **icm_kw_args)
+            self.icm_model.to(self.device)
+            mpi_utils.broadcast_model_parameters(self.icm_model)
 
     def agent_slot_order(self):
         """Index of the env's agent that sits in each slot of the grouped rows (after the MAT shuffles)."""
@@ -102,7 +120,7 @@ class MATPolicy(PPOPolicy):
         cobs_dim = int(np.prod(get_space_shape(self.critic_obs_space)))
         if self.buffer is None or (self.buffer.T, self.buffer.C) != (T, self.env_batch_size):
             self.buffer = RolloutBuffer(T, self.env_batch_size, obs_dim, cobs_dim, self.action_dim,
-                                        self.action_dtype, self.device, keep_next_observations=False,
+                                        self.action_dtype, self.device, keep_next_observations=self.enable_icm,
                                         agents_per_row=A)
         else:
             self.buffer.end_kind.zero_()
@@ -161,6 +179,8 @@ class MATPolicy(PPOPolicy):
     def finish_step(self, t, rewards, next_obs=None):
         buf = self.buffer
         buf.rewards[t].copy_(rewards.reshape(buf.rewards[t].shape))
+        if buf.next_observations is not None and next_obs is not None:
+            buf.next_observations[t].copy_(next_obs.reshape(buf.next_observations[t].shape))
         buf.steps_written = max(buf.steps_written, t + 1)
         self._t = t + 1
 
@@ -247,6 +267,8 @@ class MATPolicy(PPOPolicy):
     def update_learning_rate(self):
         if not self.frozen:
             self.actor_critic_optim.set_lr(self.lr())
+            if self.enable_icm:                          # mat_policy.py:895-896
+                self.icm_optim.set_lr(self.icm_lr())
 
     def save(self, save_path, tag="latest"):
         import os
@@ -255,6 +277,9 @@ class MATPolicy(PPOPolicy):
         self.actor_critic.save(path)                     # actor_critic_<rank>.model, as the reference
         torch.save(self.actor_critic_optim.state_dict(),
                    os.path.join(path, f"actor_critic_optim_{mpi_utils.get_rank()}"))
+        if self.enable_icm:                              # mat_policy.py:1105-1111
+            self.icm_model.save(path)
+            torch.save(self.icm_optim.state_dict(), os.path.join(path, f"icm_optim_{mpi_utils.get_rank()}"))
 
     def load(self, load_path, tag="latest"):
         import os
@@ -264,10 +289,39 @@ class MATPolicy(PPOPolicy):
         if not os.path.exists(f):
             f = os.path.join(path, "actor_critic_optim_0")
         self.actor_critic_optim.load_state_dict(torch.load(f, map_location="cpu", weights_only=False))
+        if self.enable_icm:
+            self.icm_model.load(path)
+            f = os.path.join(path, f"icm_optim_{mpi_utils.get_rank()}")
+            if not os.path.exists(f):
+                f = os.path.join(path, "icm_optim_0")
+            if os.path.exists(f):
+                self.icm_optim.load_state_dict(torch.load(f, map_location="cpu", weights_only=False))
 
     def direct_load(self, policy_load_path):
-        """mat_policy.py (direct_load): the actor_critic network only, from the directory itself."""
+        """mat_policy.py (direct_load): the networks only, from the directory itself."""
         self.actor_critic.load(policy_load_path)
+        if self.enable_icm:
+            self.icm_model.load(policy_load_path)
+
+    def get_agent_shared_intrinsic_rewards(self, prev_obs, obs, actions):
+        """
+        mat_policy.py:1012-1090.  The reference takes dicts keyed by agent id and stacks them in
+        icm_agent_ids order; here the environment's agent-major batches [A*E, .] (rows of agent a at
+        a*E..(a+1)*E, the env's = the original agent order) are regrouped to [E, A*.]: one ICM row and one
+        reward per env, already weighted.  Returns float32 [E].
+        """
+        A = len(self.agent_ids)
+        obs_1 = self._to_device(prev_obs)
+        if obs_1.dim() < 2:
+            raise ValueError(f"get_agent_shared_intrinsic_rewards expects a batch of observations, got {obs_1.shape}")
+        E = obs_1.shape[0] // A
+        join = lambda x: x.reshape(A, E, -1).transpose(0, 1).reshape(E, -1)
+        obs_1, obs_2 = join(obs_1), join(self._to_device(obs))
+        adt = torch.int64 if self.action_dtype in ("discrete", "multi-discrete") else torch.float32
+        act = join(self._to_device(actions, adt))
+        with torch.no_grad():
+            intr, _, _ = self.icm_model(obs_1, obs_2, act)
+        return intr.reshape(-1) * float(self.intr_reward_weight())
 
     def apply_step_constraints(self, obs, critic_obs, reward, terminated, truncated, info):
         """

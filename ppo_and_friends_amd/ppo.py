@@ -287,7 +287,18 @@ class PPO:
             n_ag = order.numel()
             group = lambda x: x.reshape((n_ag, n_envs) + tuple(x.shape[1:]))[order].transpose(0, 1).contiguous()
             ungroup = lambda x: x.transpose(0, 1)[torch.argsort(order)].reshape((n_ag * n_envs,) + tuple(x.shape[2:]))
-        intr_buf = torch.zeros(T, E, dtype=torch.float32, device=self.device) if pol.enable_icm else None
+        # per-step intrinsic rewards in the buffer's own layout ([T, E*A] rows of agents side by side when grouped)
+        intr_buf = torch.zeros(T, E * (pol.num_agents if grouped else 1), dtype=torch.float32,
+                               device=self.device) if pol.enable_icm else None
+
+        def grouped_intrinsic(prev_obs, prev_cobs, nxt_obs, nxt_cobs, act_env):
+            """ppo.py:1219-1288 for an agent-grouped policy: agent-major [A*E] intrinsic rewards (one shared value
+            per env repeated for its agents, or one per (agent, env) row); observations = the actor's view."""
+            o1, o2 = (prev_cobs, nxt_cobs) if pol.expanded_actor_space else (prev_obs, nxt_obs)
+            if pol.agent_shared_icm:
+                return pol.get_agent_shared_intrinsic_rewards(o1, o2, act_env).repeat(n_ag)
+            return pol.get_intrinsic_reward(o1, o2, act_env)
+
         if pol.enable_icm:
             may_end_early = True          # bootstrap rewards carry the "surprise" term: dense end table
         nat_buf = self._scratch(f"nat_buf_{T}_{env.num_agents if hasattr(env, 'num_agents') else 1}_{n_envs}",
@@ -297,11 +308,16 @@ class PPO:
                 # K16: encoder + autoregressive decoder passes + sampling + values + the buffer row in one launch
                 g_obs, g_cobs = group(obs), group(critic_obs)
                 action = pol.rollout_step(t, g_cobs, g_cobs if pol.expanded_actor_space else g_obs, vn)
-                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(ungroup(action)))
+                act_env = ungroup(action)
+                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(act_env))
                 nat_buf[t].copy_(self._natural_reward(env, reward))
                 if self.ext_reward_weight != 1.0:
                     reward = reward * self.ext_reward_weight
-                pol.finish_step(t, group(reward))
+                if pol.enable_icm:
+                    intr = grouped_intrinsic(obs, critic_obs, nxt_obs, nxt_cobs, act_env)
+                    intr_buf[t] = group(intr).reshape(-1)
+                    reward = reward + intr
+                pol.finish_step(t, group(reward), group(nxt_cobs if pol.expanded_actor_space else term_obs) if pol.enable_icm else None)
                 terminated, truncated = terminated[:n_envs], truncated[:n_envs]   # agents of an env end together
             elif fused_step:
                 # K6+K7: inference, sampling, log-probs, values and the buffer row in one launch
@@ -318,11 +334,17 @@ class PPO:
                 g_obs, g_cobs = group(obs), group(critic_obs)
                 raw_action, action, log_prob = pol.get_rollout_actions(g_cobs if pol.expanded_actor_space else g_obs)
                 value = self.get_policy_values(policy_id, g_cobs)
-                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(ungroup(action)))
+                act_env = ungroup(action)
+                nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(act_env))
                 nat_buf[t].copy_(self._natural_reward(env, reward))
                 if self.ext_reward_weight != 1.0:
                     reward = reward * self.ext_reward_weight
-                buf.write_step(t, slice(0, E), g_cobs, g_cobs if pol.expanded_actor_space else g_obs, None,
+                if pol.enable_icm:
+                    intr = grouped_intrinsic(obs, critic_obs, nxt_obs, nxt_cobs, act_env)
+                    intr_buf[t] = group(intr).reshape(-1)
+                    reward = reward + intr
+                buf.write_step(t, slice(0, E), g_cobs, g_cobs if pol.expanded_actor_space else g_obs,
+                               group(nxt_cobs if pol.expanded_actor_space else term_obs) if pol.enable_icm else None,
                                raw_action, action, value, log_prob, group(reward))
                 pol._t = t + 1
                 terminated, truncated = terminated[:n_envs], truncated[:n_envs]   # agents of an env end together
@@ -372,7 +394,7 @@ class PPO:
             if pol.enable_icm:
                 # ppo.py:1926-1930: bootstrap reward += intrinsic reward of the step - "intrinsic score avg"
                 ism = float(self.status_dict[policy_id].get("intrinsic score avg", 0.0))
-                buf.boot_reward.add_(intr_buf - ism)
+                buf.boot_reward.add_((intr_buf - ism).view_as(buf.boot_reward))
         else:
             buf.end_kind[T - 1].fill_(2)
             buf.boot_value[T - 1].copy_(next_value)
@@ -886,6 +908,9 @@ class PPO:
         counter = 0
         flat = lambda t: t.view((buf.num_transitions,) + tuple(t.shape[2:]))
         perm_static = self._scratch(f"icm_perm_static_{B}", B, torch.int64)
+        if pol.agent_shared_icm:             # a device copy refreshed per epoch: the captured launches read it
+            agent_order = self._scratch(f"icm_agent_order_{policy_id}", len(pol.agent_idxs), torch.int64)
+            agent_order.copy_(torch.as_tensor(np.asarray(pol.agent_idxs), dtype=torch.int64))
 
         def fwd_bwd(idx):
             n = idx.numel()
@@ -894,6 +919,14 @@ class PPO:
             act = torch.empty((n,) + tuple(buf.actions.shape[2:]), dtype=buf.actions.dtype, device=self.device)
             K.minibatch_gather([(flat(buf.observations), obs), (flat(buf.next_observations), nxt),
                                 (flat(buf.actions), act)], idx, buf.row_map)
+            if pol.agent_shared_icm:
+                # ppo.py:2520-2538 (case 2): agents re-ordered by the policy's agent_idxs, then side by side in one
+                # row.  (agent_idxs is the in-place shuffled index vector of shuffle_agent_ids, as in the reference.)
+                obs, nxt, act = (x.reshape(n, buf.A, -1).index_select(1, agent_order).reshape(n, -1) for x in (obs, nxt, act))
+            elif pol.agent_grouping:
+                # ppo.py:2540-2545 (case 3): every (row, agent) pair is one ICM sample
+                rows = n * buf.A
+                obs, nxt, act = obs.reshape(rows, -1), nxt.reshape(rows, -1), act.reshape(rows, -1)
             _, inv_loss, f_loss = pol.icm_model(obs, nxt, act)
             icm_loss = (1.0 - pol.icm_beta) * f_loss + pol.icm_beta * inv_loss
             total.add_(icm_loss.detach().double())

@@ -33,12 +33,48 @@ class Discrete:
         return [seed]
 
 
+class MultiDiscrete:
+    """gymnasium.spaces.MultiDiscrete attributes used on this path: nvec, start, shape, dtype."""
+
+    def __init__(self, nvec, dtype=np.int64, start=None):
+        self.nvec = np.asarray(nvec, dtype=np.int64)
+        self.start = np.zeros_like(self.nvec) if start is None else np.asarray(start, dtype=np.int64)
+        self.shape = tuple(self.nvec.shape)
+        self.dtype = np.dtype(dtype)
+
+    def seed(self, seed=None):
+        return [seed]
+
+
+def is_multi_discrete(space):
+    return hasattr(space, "nvec")
+
+
+def get_agent_shared_space(space, num_agents):
+    """
+    utils/misc.py:349-396: the space spanning all agents of a group (agent-shared ICM): Box -> the
+    flattened concatenation, Discrete -> MultiDiscrete([n] * A), MultiDiscrete -> tiled nvec.
+    """
+    if is_multi_discrete(space):
+        return MultiDiscrete(np.tile(space.nvec, num_agents), dtype=space.dtype,
+                             start=np.tile(getattr(space, "start", np.zeros_like(space.nvec)), num_agents))
+    if is_discrete(space):
+        return MultiDiscrete([int(space.n)] * num_agents, dtype=space.dtype)
+    if np.issubdtype(space.dtype, np.floating):
+        low = np.tile(np.asarray(space.low, dtype=space.dtype).reshape(-1), num_agents)
+        high = np.tile(np.asarray(space.high, dtype=space.dtype).reshape(-1), num_agents)
+        return Box(low, high, low.shape, space.dtype)
+    raise NotImplementedError(f"get_agent_shared_space: unsupported space {type(space)}")
+
+
 def is_discrete(space):
     return hasattr(space, "n") and not hasattr(space, "nvec") and np.issubdtype(space.dtype, np.integer)
 
 
 def get_space_dtype_str(space):
-    """utils/misc.py:17-46 for the two space kinds on this path."""
+    """utils/misc.py:17-46 for the space kinds on this path."""
+    if is_multi_discrete(space):
+        return "multi-discrete"
     if is_discrete(space):
         return "discrete"
     if np.issubdtype(space.dtype, np.floating):
@@ -56,5 +92,7 @@ def get_flattened_space_length(space):
 
 
 def get_action_prediction_shape(space):
-    """utils/misc.py:295-346: Discrete -> (n,), Box -> its shape."""
+    """utils/misc.py:295-346: Discrete -> (n,), MultiDiscrete -> (sum(nvec),), Box -> its shape."""
+    if is_multi_discrete(space):
+        return (int(np.sum(space.nvec)),)
     return (space.n,) if is_discrete(space) else tuple(space.shape)

@@ -370,6 +370,72 @@ def test_mat_policy_rollout_and_update_match_cpu_port(update_mode, B):
     np.testing.assert_allclose(w, w_ref, rtol=2e-4, atol=3e-5)
 
 
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("update_mode", ["fused", "torch"])
+def test_mat_policy_with_icm_matches_cpu_port(update_mode, shared, tmp_path):
+    """
+    MATPolicy + ICM (mat_policy.py:132-176, 1012-1090; ppo.py:1219-1288, 2509-2545): per-agent ICM rows
+    ((env, agent) pairs), or agent_shared_icm -- one ICM over the group's concatenated observations / actions
+    in the original agent order, MultiDiscrete([n] * A) actions, one reward per env for all its agents.
+    Two iterations (the second after the policy has re-shuffled its agent ids and with a non-zero
+    "intrinsic score avg") against oracle/mat_oracle.CpuMATPPO.
+    """
+    from ppo_and_friends_amd.ppo import PPO, PermutationLoader
+    from ppo_and_friends_amd.policies.mat_policy import MATPolicy
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    from oracle import mat_oracle
+    dev = torch.device("cuda", 0)
+    A, E, T, O, NA, B, seed = 3, 8, 12, 18, 5, 16, 6
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=41, num_agents=A)
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    ppo = PPO(env_gen, {"mat": (MATPolicy, sp, sp, Discrete(NA), dict(enable_icm=True, agent_shared_icm=shared))},
+              device=dev, random_seed=seed, normalize_obs=False, normalize_rewards=False, envs_per_proc=E,
+              ts_per_rollout=T, batch_size=B, epochs_per_iter=1, update_mode=update_mode)
+    pol = ppo.policies["mat"]
+    assert pol.icm_model.action_dtype == ("multi-discrete" if shared else "discrete")
+    cpu = mat_oracle.CpuMATPPO(O, NA, A, batch_size=B, seed=seed, enable_icm=True, agent_shared_icm=shared)
+    cpu.ac.load_state_dict({k: v.detach().cpu().clone() for k, v in pol.actor_critic.state_dict().items()}, strict=False)
+    cpu.icm.load_state_dict({k: v.detach().cpu().clone() for k, v in pol.icm_model.state_dict().items()})
+    cpu.loader_generator = torch.Generator().manual_seed(seed)
+    tol = dict(rtol=3e-5, atol=3e-5)
+    for it in range(2):
+        ds = ppo.rollout()
+        env, buf = ppo.env, pol.buffer
+        order = pol.agent_slot_order()
+        obs_t = env.obs_table.view(T + 1, A, E, O)[:, order].transpose(1, 2).cpu().numpy()       # [T+1,E,A,O]
+        rew_t = env.reward_table.view(T, A, E)[:, order].transpose(1, 2).cpu().numpy()
+        ism_before = cpu.intrinsic_score_avg
+        ref = cpu.rollout(obs_t, rew_t, buf.actions[..., 0].cpu().numpy(), slot_order=order)
+        np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), ref.rtg.numpy(), **tol)
+        np.testing.assert_allclose(ds.advantages.cpu().numpy(), ref.adv.numpy(), **tol)
+        np.testing.assert_array_equal(ds.next_observations.cpu().numpy(), ref.next_obs.numpy())
+        np.testing.assert_allclose(ppo.status_dict["mat"]["intrinsic score avg"], cpu.intrinsic_score_avg, rtol=1e-4)
+        assert it == 0 or ism_before != 0.0
+        loader = PermutationLoader(pol.dataset, B, ppo.loader_generator)
+        pol.train()
+        ppo._ppo_batch_train(loader, "mat")
+        r = cpu.train_epoch()
+        for k in ("actor loss", "critic loss", "kl avg"):
+            np.testing.assert_allclose(ppo.status_dict["mat"][k], r[k], rtol=5e-5, atol=5e-6, err_msg=k)
+        ppo._icm_batch_train(loader, "mat")
+        icm_loss = cpu.icm_train_epoch(agent_idxs=pol.agent_idxs)
+        np.testing.assert_allclose(ppo.status_dict["mat"]["icm loss"], icm_loss, rtol=5e-5)
+        pol.clear_dataset()
+    w = torch.cat([p.detach().cpu().reshape(-1) for p in pol.icm_model.parameters()]).numpy()
+    w_ref = torch.cat([p.detach().reshape(-1) for p in cpu.icm.parameters()]).numpy()
+    np.testing.assert_allclose(w, w_ref, rtol=2e-4, atol=3e-5)
+    # checkpoint files of the reference (mat_policy.py:898-990): actor_critic + icm networks and optimisers
+    import os
+    pol.save(str(tmp_path))
+    d = os.path.join(str(tmp_path), "mat-policy", "latest")
+    assert sorted(os.listdir(d)) == ["actor_critic_0.model", "actor_critic_optim_0", "icm_0.model", "icm_optim_0"]
+    keep = pol.icm_model.flat_params.clone(), pol.icm_optim.exp_avg.clone()
+    pol.icm_model.flat_params.zero_(); pol.icm_optim.exp_avg.zero_()
+    pol.load(str(tmp_path))
+    assert torch.equal(pol.icm_model.flat_params, keep[0]) and torch.equal(pol.icm_optim.exp_avg, keep[1])
+
+
 @pytest.mark.parametrize("update_mode", ["fused", "torch"])
 def test_filter_stack_in_the_loop(update_mode):
     """
