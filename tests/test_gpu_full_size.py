@@ -20,6 +20,14 @@ def _c_config(name, **kw):
         space, pargs, pc = Box(-1.0, 1.0, (6,), np.float32), dict(actor_kw_args=dict(hidden_size=128),
                                                                   critic_kw_args=dict(hidden_size=256), enable_icm=True), None
         extra = dict(normalize_obs=True, normalize_rewards=True, obs_clip=(-10.0, 10.0), reward_clip=(-10.0, 10.0))
+    elif name == "C2":
+        E, T, O, A, cv = 4096, 128, 4, 1, "local"
+        space, pargs, pc = Discrete(2), {}, None
+        extra = dict(normalize_obs=False, normalize_rewards=False)
+    elif name == "C4":
+        E, T, O, A, cv = 1024, 128, 18, 3, "policy"
+        space, pargs, pc = Discrete(5), dict(actor_kw_args=dict(hidden_size=128), critic_kw_args=dict(hidden_size=256)), None
+        extra = dict(normalize_obs=False, normalize_rewards=False)
     elif name == "C5":
         from ppo_and_friends_amd.policies.mat_policy import MATPolicy
         E, T, O, A, cv = 1024, 128, 18, 3, "local"
@@ -27,8 +35,9 @@ def _c_config(name, **kw):
         extra = dict(normalize_obs=False, normalize_rewards=False)
     env_gen = lambda: SyntheticFixedLengthEnv(E, O, space, T, dev, reward="uniform", seed=1234, num_agents=A, critic_view=cv)
     sp = Box(-np.inf, np.inf, (O,), np.float32)
+    csp = Box(-np.inf, np.inf, (O * A if cv == "policy" else O,), np.float32)
     extra.update(kw)
-    return PPO(env_gen, {"p": (pc, sp, sp, space, pargs)}, device=dev, random_seed=1, envs_per_proc=E, ts_per_rollout=T,
+    return PPO(env_gen, {"p": (pc, sp, csp, space, pargs)}, device=dev, random_seed=1, envs_per_proc=E, ts_per_rollout=T,
                batch_size=256, epochs_per_iter=1, save_state=False, **extra), E, T, A
 
 
@@ -97,3 +106,28 @@ def test_c5_mat_update_full_size_properties():
         crit.append(sd["critic loss"])
     assert crit[2] < crit[0]
     assert int(pol.actor_critic_optim.step_count.item()) == 3 * (E * T // 256)
+
+
+@pytest.mark.parametrize("name", ["C2", "C4"])
+def test_k12_full_size_graph_replay_equals_eager_launches(name):
+    """
+    K12 at the metric's own size (C2: 2048 mini-batches per epoch; C4: MAPPO shape, 3 agents, 256-wide critic):
+    the hipGraph-replayed chain and the eager launches are two execution modes of the same kernels -- bitwise
+    equal weights, optimiser state and statistics; every mini-batch counted once; value normaliser saw every row.
+    """
+    outs = []
+    for graphs in (True, False):
+        ppo, E, T, A = _c_config(name, use_graphs=graphs)
+        ppo.rollout()
+        pol = ppo.policies["p"]
+        ppo.train_on_rollout()
+        n_mb = E * T * A // 256
+        assert int(pol.policy_step_counts[0].item()) == int(pol.policy_step_counts[1].item()) == n_mb
+        vs = ppo.value_normalizers["p"].running_stats
+        assert abs(vs.count - (E * T * A + 1e-4)) < 1e-3
+        sd = ppo.status_dict["p"]
+        assert all(np.isfinite(sd[k]) for k in ("actor loss", "critic loss", "kl avg", "weighted entropy"))
+        outs.append((pol.policy_params.clone(), pol.policy_exp_avg_sq.clone(),
+                     [sd[k] for k in ("actor loss", "critic loss", "kl avg", "weighted entropy")], vs.mean.copy()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2] and np.array_equal(outs[0][3], outs[1][3])
