@@ -674,6 +674,30 @@ int ppoaf_ppo_update_adam_exchanged(const ppoaf_ppo_update_args_t* args, ppoaf_p
                                     ppoaf_stream_t stream);
 int ppoaf_peer_exchange_destroy(ppoaf_peer_exchange_t* x);
 
+/* ------------------------------------------------------------------------ *
+ * Rank collectives (one communicator per process, one process per GPU; RCCL bound at run time)
+ * replaces broadcast_model_parameters   utils/mpi_utils.py:50-63    -> ppoaf_bcast_f32 (flat bucket, once)
+ *          mpi_avg / mpi_avg_gradients  utils/mpi_utils.py:65-111   -> ppoaf_allreduce_avg_f32 (sum, then / world)
+ *          the raw-data allgather of RunningMeanStd.update  utils/stats.py:47-50
+ *                                                                   -> ppoaf_allgather_moments of (n, mean, M2) records
+ * Rank 0 creates the id (ppoaf_comm_unique_id), the host distributes its PPOAF_COMM_UNIQUE_ID_BYTES bytes
+ * (MPI_Bcast / a file / torch.distributed), every rank calls ppoaf_comm_init (collective).  All calls are
+ * asynchronous on `stream` and in place; out of ppoaf_allgather_moments is [world, n_doubles].  They return
+ * PPOAF_E_INVALID with a message when no librccl can be bound.  The per-mini-batch gradient exchange inside
+ * the update loop has the lower-latency K17 path above; ppo_and_friends_amd's own Python host uses
+ * torch.distributed (the same RCCL) for these collectives.
+ * ------------------------------------------------------------------------ */
+#define PPOAF_COMM_UNIQUE_ID_BYTES 128
+typedef struct ppoaf_comm ppoaf_comm_t;
+
+int ppoaf_comm_unique_id(void* out /* host, PPOAF_COMM_UNIQUE_ID_BYTES */);
+int ppoaf_comm_init(int rank, int world, const void* unique_id, ppoaf_comm_t** out);
+int ppoaf_allreduce_avg_f32(ppoaf_comm_t* comm, float* buf, int64_t n, ppoaf_stream_t stream);
+int ppoaf_bcast_f32(ppoaf_comm_t* comm, float* buf, int64_t n, int root, ppoaf_stream_t stream);
+int ppoaf_allgather_moments(ppoaf_comm_t* comm, const double* record, int64_t n_doubles, double* out,
+                            ppoaf_stream_t stream);
+int ppoaf_comm_destroy(ppoaf_comm_t* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,6 +202,12 @@ SIGNATURES = {
     "ppoaf_peer_exchange_allreduce": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_float, _ptr, C.c_double, _ptr]),
     "ppoaf_peer_exchange_status": (C.c_int, [_ptr, C.POINTER(C.c_int64)]),
     "ppoaf_peer_exchange_destroy": (C.c_int, [_ptr]),
+    "ppoaf_comm_unique_id": (C.c_int, [_ptr]),
+    "ppoaf_comm_init": (C.c_int, [C.c_int, C.c_int, _ptr, C.POINTER(C.c_void_p)]),
+    "ppoaf_allreduce_avg_f32": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr]),
+    "ppoaf_bcast_f32": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int, _ptr]),
+    "ppoaf_allgather_moments": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr, _ptr]),
+    "ppoaf_comm_destroy": (C.c_int, [_ptr]),
     "ppoaf_ppo_update_reduce_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr]),
     "ppoaf_ppo_update_adam_exchanged": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, _ptr]),
     "ppoaf_env_filter_moments": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),

@@ -504,3 +504,32 @@ def test_attention_blocks_match_reference_golden_g5(golden):
     np.testing.assert_allclose(enc(x).detach().cpu().numpy(), g["enc_y"], rtol=1e-5, atol=2e-5)
     dec = load(at.SelfAttentionDecodingBlock(64, 1, 3), "dec_")
     np.testing.assert_allclose(dec(x, rep).detach().cpu().numpy(), g["dec_y"], rtol=1e-5, atol=2e-5)
+
+
+def test_c_abi_collectives_single_rank(K):
+    """
+    ppoaf_comm_* / allreduce_avg / bcast / allgather_moments (utils/mpi_utils.py:50-111,
+    utils/stats.py:47-50) with a one-rank communicator -- what a one-GPU box can host: RCCL is bound at run
+    time, the calls run on the caller's stream and are the identity for world = 1, as the reference's
+    collectives are for num_procs == 1.
+    """
+    import ctypes as C
+    from ppo_and_friends_amd import _lib
+    lib = _lib.load()
+    uid = C.create_string_buffer(128)
+    _lib.check(lib.ppoaf_comm_unique_id(uid), "comm_unique_id")
+    comm = C.c_void_p()
+    _lib.check(lib.ppoaf_comm_init(0, 1, uid, C.byref(comm)), "comm_init")
+    st = K.stream()
+    x = torch.randn(1000, device="cuda")
+    want = x.clone()
+    _lib.check(lib.ppoaf_allreduce_avg_f32(comm, x.data_ptr(), x.numel(), st), "allreduce_avg_f32")
+    _lib.check(lib.ppoaf_bcast_f32(comm, x.data_ptr(), x.numel(), 0, st), "bcast_f32")
+    rec = torch.tensor([256.0, 0.25, 17.5], dtype=torch.float64, device="cuda")
+    out = torch.zeros(1, 3, dtype=torch.float64, device="cuda")
+    _lib.check(lib.ppoaf_allgather_moments(comm, rec.data_ptr(), 3, out.data_ptr(), st), "allgather_moments")
+    torch.cuda.synchronize()
+    assert torch.equal(x, want) and torch.equal(out[0], rec)
+    assert lib.ppoaf_bcast_f32(comm, x.data_ptr(), x.numel(), 3, st) != 0          # root outside the communicator
+    assert b"root" in lib.ppoaf_last_error()
+    _lib.check(lib.ppoaf_comm_destroy(comm), "comm_destroy")
