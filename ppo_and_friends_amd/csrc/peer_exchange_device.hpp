@@ -95,28 +95,20 @@ __device__ __forceinline__ double xchg_sq(const float4& a, float sc) {
            (double)(a.z * sc) * (a.z * sc) + (double)(a.w * sc) * (a.w * sc);
 }
 
-// Fixed-order sum of the per-workgroup partials by one wave (all 64 lanes call it): 64 partials are loaded in
-// parallel, then the lanes are walked in order -- the same sum on every rank, without a chain of dependent loads.
-__device__ __forceinline__ double xchg_lane_value(double v, unsigned lane /* uniform */) {
-    const unsigned long long b = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, (int)lane);
-    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), (int)lane);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-
+// Fixed-association sum of the per-workgroup partials by one wave (all 64 lanes call it): the partials are loaded
+// in parallel, one (or a few) per lane, and folded by a butterfly -- the same sum on every rank, without a chain of
+// dependent loads.
+// (wave_sum: xor-butterfly over the 64 lanes -- the same additions in the same association on every rank and in
+// every run, IEEE addition being commutative, so all lanes of all ranks hold the bitwise identical total.)
 __device__ __forceinline__ void xchg_ordered_norms(const double* partials, unsigned n_groups, double& n0, double& n1) {
     const unsigned lane = threadIdx.x & 63;
-    n0 = 0.0; n1 = 0.0;
-    for (unsigned b0 = 0; b0 < n_groups; b0 += 64) {
-        const unsigned b = b0 + lane;
-        double p0 = 0.0, p1 = 0.0;
-        if (b < n_groups) {
-            p0 = __hip_atomic_load(&partials[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            p1 = __hip_atomic_load(&partials[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const unsigned cnt = (n_groups - b0) < 64u ? (n_groups - b0) : 64u;
-        for (unsigned l = 0; l < cnt; ++l) { n0 += xchg_lane_value(p0, l); n1 += xchg_lane_value(p1, l); }
+    double p0 = 0.0, p1 = 0.0;
+    for (unsigned b = lane; b < n_groups; b += 64) {           // lane-strided, ascending: fixed per-lane order
+        p0 += __hip_atomic_load(&partials[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p1 += __hip_atomic_load(&partials[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    n0 = wave_sum(p0);
+    n1 = wave_sum(p1);
 }
 
 // Phase 3 tail when the norms are wanted by the end of THIS launch: per-workgroup squared-norm partials (q0, q1

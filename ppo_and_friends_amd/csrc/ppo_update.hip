@@ -761,9 +761,19 @@ __global__ __launch_bounds__(256) void ppo_update_adam_kernel(UpdateDev u, const
                                                               unsigned n_norm_groups) {
     const long n4 = u.bucket_total >> 2;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = idx < n4;
+    // the column's loads go out first; the norm partials (another cold round trip, then an ordered sum) are
+    // fetched while they are in flight
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), g = p, m = p, v = p;
+    if (live) {
+        p = reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx];
+        g = reinterpret_cast<const float4*>(u.grads)[idx];
+        m = reinterpret_cast<float4*>(u.exp_avg)[idx];
+        v = reinterpret_cast<float4*>(u.exp_avg_sq)[idx];
+    }
     double sq0 = 0.0, sq1 = 0.0;
     if (norm_partials) xchg_ordered_norms(norm_partials, n_norm_groups, sq0, sq1);   // uniform branch, whole waves
-    if (idx < n4) {
+    if (live) {
         const int which = (idx * 4 < u.net[0].size) ? 0 : 1;
         const float total_norm = (float)sqrt(norm_partials ? (which ? sq1 : sq0) : u.norm_scratch[which]);
         float coef = 1.0f;
@@ -772,10 +782,6 @@ __global__ __launch_bounds__(256) void ppo_update_adam_kernel(UpdateDev u, const
         const float lr = u.lr[0];
         const float step_size = (float)((double)lr / u.norm_scratch[2 + 2 * which]);
         const float bc2_sqrt = (float)u.norm_scratch[3 + 2 * which];
-        float4 p = reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx];
-        const float4 g = reinterpret_cast<const float4*>(u.grads)[idx];
-        float4 m = reinterpret_cast<float4*>(u.exp_avg)[idx];
-        float4 v = reinterpret_cast<float4*>(u.exp_avg_sq)[idx];
 #define PPOAF_ADAM1(c)                                                   \
         {                                                                \
             const float gi = g.c * gs;                                   \
