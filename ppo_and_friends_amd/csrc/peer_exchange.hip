@@ -5,19 +5,22 @@
 // pure latency.  One launch per exchange, no library call and no host round trip -- the launch has fixed
 // arguments and can be captured in a hipGraph together with the update kernels:
 //
-//   phase 1  every workgroup copies its slice of the local gradient into this rank's exchange slot
-//            (uncached device memory exported to the peers by IPC; two slots, alternating by sequence
-//            number) and fences it to system scope; the last workgroup to arrive stores the sequence
-//            number into every peer's flag word (posted remote stores),
-//   phase 2  the workgroups poll the LOCAL flag words until every peer has published this sequence number,
-//   phase 3  every workgroup reads its slice from all the peers' slots (loads of up to 8 peers in flight) and
-//            adds them in rank order -- every rank computes the bitwise identical sum, so replicas stay
-//            identical -- writes the summed bucket and per-workgroup squared-norm partials, which are added
-//            in workgroup order (deterministic clip coefficient on every rank) by the last workgroup to
-//            finish, or by the consuming kernel (K12's Adam launch).
+//   phase 1  workgroup g copies its elements of the local gradient into this rank's exchange slot (uncached
+//            device memory exported to the peers by IPC; two slots, alternating by sequence number), fences
+//            them to system scope and stores its sequence number into every peer's flag word for
+//            (group g, this rank) -- posted remote stores,
+//   phase 2  it polls its LOCAL flag words until group g of every peer has published this sequence number,
+//   phase 3  it reads its elements from all the peers' slots (loads of up to 8 peers in flight) and adds them in
+//            rank order -- every rank computes the bitwise identical sum, so replicas stay identical -- writes
+//            the summed bucket and its squared-norm partial; the partials are folded in a fixed association
+//            (deterministic clip coefficient on every rank) by the last workgroup to finish, or by the
+//            consuming kernel (K12's Adam launch).
 //
-// Two slots suffice with one flag per exchange: a rank rewrites slot s&1 at exchange s+2 only after it has
-// passed the wait of exchange s+1, and a peer publishes s+1 only after its exchange-s launch has completed.
+// Group g of every rank owns the same elements, so a workgroup depends only on its peers' group g: there is no
+// rank-wide arrival counter (each would cost a ~1.5 us memory-side atomic round trip) and no single publisher.
+// Two slots suffice with one flag per (group, exchange): a group rewrites its part of slot s&1 at exchange s+2
+// only after it has passed its wait of exchange s+1, and the peer's group publishes s+1 only after its
+// exchange-s launch -- hence its reads of that part -- has completed.
 // Every wait is bounded (wall-clock budget): on expiry the error word is set and the launch drains.
 #include "peer_exchange_device.hpp"
 
@@ -33,26 +36,32 @@ __global__ __launch_bounds__(kXchgThreads) void peer_allreduce_kernel(XchgDev x,
     __shared__ double red[17];
     __shared__ int s_last;
     const int tid = threadIdx.x;
-    const long long seq = xchg_sequence(x);
+    const unsigned g = blockIdx.x;                   // group g owns elements g*256 + tid + k*grid*256, on every rank
+    const long long seq = xchg_sequence(x, g);
     const long slot = (long)(seq & 1) * x.n4;
     const long stride = (long)gridDim.x * kXchgThreads;
     float4* mine = x.my_slots + slot;
-    for (long i = (long)blockIdx.x * kXchgThreads + tid; i < x.n4; i += stride) mine[i] = src[i];
-    xchg_publish(x, seq, gridDim.x);
-    xchg_wait(x, seq, wait_ticks);
+    for (long i = (long)g * kXchgThreads + tid; i < x.n4; i += stride) mine[i] = src[i];
+    xchg_publish(x, seq, g);
+    xchg_wait(x, seq, g, wait_ticks);
     double q0 = 0.0, q1 = 0.0;
-    for (long i = (long)blockIdx.x * kXchgThreads + tid; i < x.n4; i += stride) {
+    for (long i = (long)g * kXchgThreads + tid; i < x.n4; i += stride) {
         const float4 acc = xchg_sum(x, slot, i, src[i]);
         dst[i] = acc;
         const double q = xchg_sq(acc, norm_scale);
         if (i < split4) q0 += q; else q1 += q;
     }
+    xchg_advance(x, seq, g);
     if (norm_out) {                                  // uniform over the launch
         q0 = block_sum(q0, red);
         q1 = block_sum(q1, red);
-        xchg_finish(x, blockIdx.x, gridDim.x, q0, q1, split4 < x.n4, norm_out, &s_last);
+        xchg_finish(x, g, gridDim.x, q0, q1, split4 < x.n4, norm_out, &s_last);
     }
 }
+
+}  // namespace ppoaf
+
+namespace ppoaf {
 
 struct ExportBlob {                                 // PPOAF_PEER_EXCHANGE_BLOB_BYTES
     hipIpcMemHandle_t handle;                       // 64 bytes
@@ -101,7 +110,7 @@ extern "C" int ppoaf_peer_exchange_create(int rank, int n_ranks, int64_t bucket_
         return PPOAF_E_LAUNCH;
     }
     void* local = nullptr;
-    const size_t local_bytes = 4 * sizeof(long long) + 2 * kXchgMaxGrid * sizeof(double);
+    const size_t local_bytes = (4 + kXchgMaxGrid) * sizeof(long long) + 2 * kXchgMaxGrid * sizeof(double);
     e = hipMalloc(&local, local_bytes);
     if (e == hipSuccess) e = hipMemset(local, 0, local_bytes);
     if (e == hipSuccess) e = hipMemset(x->base, 0, x->bytes);
@@ -114,7 +123,8 @@ extern "C" int ppoaf_peer_exchange_create(int rank, int n_ranks, int64_t bucket_
         return PPOAF_E_LAUNCH;
     }
     x->dev.words = static_cast<long long*>(local);
-    x->dev.norm_partials = reinterpret_cast<double*>(x->dev.words + 4);
+    x->dev.group_seq = x->dev.words + 4;
+    x->dev.norm_partials = reinterpret_cast<double*>(x->dev.group_seq + kXchgMaxGrid);
     x->dev.my_flags = static_cast<long long*>(x->base);
     x->dev.my_slots = reinterpret_cast<float4*>(static_cast<char*>(x->base) + kXchgHeaderBytes);
     for (int p = 0; p < kMaxPeers; ++p) { x->dev.peer_flags[p] = nullptr; x->dev.peer_slots[p] = nullptr; }
@@ -168,7 +178,7 @@ extern "C" int ppoaf_peer_exchange_allreduce(ppoaf_peer_exchange_t* x, const flo
                   (long)split_floats);
     PPOAF_REQUIRE(wait_seconds > 0.0 && wait_seconds <= 600.0, "peer_exchange_allreduce: wait_seconds=%g", wait_seconds);
     long blocks = (x->dev.n4 + kXchgThreads - 1) / kXchgThreads;
-    if (blocks > kXchgMaxGrid) blocks = kXchgMaxGrid;    // all workgroups resident: the waits cannot starve a publisher
+    if (blocks > kXchgMaxGrid) blocks = kXchgMaxGrid;    // one flag word per group; every launch of this object uses this grid
     const long long ticks = (long long)(wait_seconds * 1.0e8);     // wall_clock64: 100 MHz
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3((unsigned)blocks), dim3(kXchgThreads), 0, (hipStream_t)stream,
                        x->dev, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst),

@@ -10,56 +10,55 @@ namespace ppoaf {
 constexpr int kMaxPeers = PPOAF_PEER_EXCHANGE_MAX_RANKS;
 constexpr int kXchgThreads = 256;
 constexpr int kXchgMaxGrid = 256;               // every workgroup of an exchange launch must be resident (256 CUs)
-constexpr size_t kXchgHeaderBytes = 256;            // flag words of one rank; slots start after it
+constexpr size_t kXchgHeaderBytes = (size_t)kXchgMaxGrid * kMaxPeers * 8;   // flag words of one rank [group][peer]; slots follow
 
 struct XchgDev {
     int rank, n_ranks;
     long n4;                                        // float4 elements of one slot
-    long long* words;                               // local: [0] sequence, [1] arrive count, [2] finish count, [3] error
-    long long* my_flags;                            // this rank's flag words (polled locally)
+    long long* words;                               // local: [0] exchanges completed, [2] finish count, [3] error
+    long long* group_seq;                           // local [kXchgMaxGrid]: sequence number each workgroup has completed
+    long long* my_flags;                            // this rank's flag words [group][peer] (polled locally)
     long long* peer_flags[kMaxPeers];               // rank p's flag words (remote store target)
     const float4* peer_slots[kMaxPeers];            // rank p's two slots
     float4* my_slots;
     double* norm_partials;                          // [kXchgMaxGrid][2]
 };
 
-// Sequence number of the exchange this launch performs.  Uniform over the launch: the word is advanced by the
-// last workgroup to ARRIVE in xchg_publish, i.e. after every workgroup of this launch has read it, and the
-// next launch is ordered behind this one by the stream.
-__device__ __forceinline__ long long xchg_sequence(const XchgDev& x) { return x.words[0] + 1; }
+// The exchange is organised per WORKGROUP: group g of every rank owns the same elements of the bucket, publishes
+// its own flag and waits only for group g of its peers -- no workgroup of a rank waits for another one of the
+// same rank, so there is no arrival counter (a memory-side atomic round trip of ~1.5 us) on the path.
+// Every launch of an exchange object must use the same number of groups and the same element -> group map.
 
-// Phase 1 tail: the caller's threads have stored their part of this rank's slot.  Fence it to system scope;
-// the last of `n_groups` workgroups to arrive publishes the sequence number to every peer.  Only thread 0
-// waits for the arrival counter; the pollers of xchg_wait sit in another wave and start immediately.
-__device__ __forceinline__ void xchg_publish(const XchgDev& x, long long seq, unsigned n_groups) {
-    // Every wave waits until its own slot stores are acknowledged (they have then left the CU and reached the
-    // L2 / the uncached memory behind it), the barrier collects the waves, and ONE system-scope release fence
-    // by the publishing thread writes back whatever this XCD's L2 still holds.  A system fence in every wave
-    // costs 4.5 us more per launch (measured) and adds nothing: the waves of a workgroup share the XCD.
+// Sequence number of the exchange group g performs in this launch (it advances its own word at the end; the
+// next launch is ordered behind this one by the stream).
+__device__ __forceinline__ long long xchg_sequence(const XchgDev& x, unsigned g) { return x.group_seq[g] + 1; }
+
+// Phase 1 tail: the workgroup's threads have stored its elements of this rank's slot.  Every wave waits until
+// its own stores are acknowledged (they have then left the CU and reached the L2 / the uncached memory behind
+// it), the barrier collects the waves, and ONE system-scope release fence by the publishing thread writes back
+// whatever this XCD's L2 still holds (a system fence in every wave costs 4.5 us more per launch, measured, and
+// adds nothing: the waves of a workgroup share the XCD).  Then relaxed posted stores of the sequence number
+// into every peer's flag word for (group g, this rank) -- a release store per peer would repeat the write-back.
+__device__ __forceinline__ void xchg_publish(const XchgDev& x, long long seq, unsigned g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence_system();
-        const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(&x.words[1]), 1ull);
-        if (prev == (unsigned long long)n_groups - 1ull) {
-            __hip_atomic_store(&x.words[1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&x.words[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();                 // one release fence, then relaxed posted stores: a release
-            for (int p = 0; p < x.n_ranks; ++p)     // store per peer would repeat the L2 write-back per peer
-                if (p != x.rank)
-                    __hip_atomic_store(&x.peer_flags[p][x.rank], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        for (int p = 0; p < x.n_ranks; ++p)
+            if (p != x.rank)
+                __hip_atomic_store(&x.peer_flags[p][g * kMaxPeers + x.rank], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-// Phase 2: poll the local flag words until every peer has published `seq`, at most wait_ticks of the
-// 100 MHz wall clock; on expiry the error word is set and the caller continues (the launch must drain).
-// Lane p of the SECOND wave polls peer p (blockDim.x >= 128).
-__device__ __forceinline__ void xchg_wait(const XchgDev& x, long long seq, long long wait_ticks) {
+// Phase 2: poll the local flag words of group g until every peer's group g has published `seq`, at most
+// wait_ticks of the 100 MHz wall clock; on expiry the error word is set and the caller continues (the launch
+// must drain).  Lane p of the SECOND wave polls peer p (blockDim.x >= 128), so polling starts while thread 0
+// is still publishing.
+__device__ __forceinline__ void xchg_wait(const XchgDev& x, long long seq, unsigned g, long long wait_ticks) {
     const int p = (int)threadIdx.x - 64;
     if (p >= 0 && p < x.n_ranks && p != x.rank) {
         const long long t0 = (long long)wall_clock64();
-        while (__hip_atomic_load(&x.my_flags[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        while (__hip_atomic_load(&x.my_flags[g * kMaxPeers + p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
             __builtin_amdgcn_s_sleep(1);
             if ((long long)wall_clock64() - t0 > wait_ticks) {
                 __hip_atomic_store(&x.words[3], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -69,6 +68,14 @@ __device__ __forceinline__ void xchg_wait(const XchgDev& x, long long seq, long 
     }
     __syncthreads();
     __atomic_thread_fence(__ATOMIC_ACQUIRE);        // system scope: drop any cached peer lines
+}
+
+// End of the workgroup's exchange: its sequence word moves on (group 0 also keeps the completed count).
+__device__ __forceinline__ void xchg_advance(const XchgDev& x, long long seq, unsigned g) {
+    if (threadIdx.x == 0) {
+        x.group_seq[g] = seq;
+        if (g == 0) x.words[0] = seq;
+    }
 }
 
 // Phase 3 core: element i of the rank-ordered sum; `own` is this rank's contribution (already in registers).

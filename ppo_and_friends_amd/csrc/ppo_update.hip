@@ -668,11 +668,10 @@ __global__ __launch_bounds__(kRedThreads) void ppo_update_reduce_exchange_kernel
                                                                                 long long wait_ticks) {
     __shared__ double red[17];
     if (blockIdx.x == gridDim.x - 1) { ppo_update_bookkeeping(u); return; }      // uniform per workgroup
-    const unsigned n_groups = gridDim.x - 1;
     const long n4 = u.bucket_total >> 2;
     const long idx = (long)blockIdx.x * kRedThreads + threadIdx.x;
     const float4* sl = reinterpret_cast<const float4*>(u.slabs);
-    const long long seq = xchg_sequence(x);
+    const long long seq = xchg_sequence(x, blockIdx.x);
     const long slot = (long)(seq & 1) * x.n4;
     float4 own = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx < n4) {
@@ -686,8 +685,8 @@ __global__ __launch_bounds__(kRedThreads) void ppo_update_reduce_exchange_kernel
         }
         x.my_slots[slot + idx] = own;
     }
-    xchg_publish(x, seq, n_groups);
-    xchg_wait(x, seq, wait_ticks);
+    xchg_publish(x, seq, blockIdx.x);
+    xchg_wait(x, seq, blockIdx.x, wait_ticks);
     double q0 = 0.0, q1 = 0.0;
     if (idx < n4) {
         const float4 acc = xchg_sum(x, slot, idx, own);
@@ -699,6 +698,7 @@ __global__ __launch_bounds__(kRedThreads) void ppo_update_reduce_exchange_kernel
     q0 = block_sum(q0, red);
     q1 = block_sum(q1, red);
     if (threadIdx.x == 0) { x.norm_partials[2 * blockIdx.x] = q0; x.norm_partials[2 * blockIdx.x + 1] = q1; }
+    xchg_advance(x, seq, blockIdx.x);
 }
 
 // The per-mini-batch bookkeeping runs in its own (last) workgroup so that it overlaps the slab
