@@ -191,6 +191,8 @@ def main():
     peer = bool(fused) and all(getattr(f, "xchg", None) is not None for f in fused)
     exchange = None if not mpi_utils.distributed_path() else \
         ("K17 peer mappings (xGMI), in-graph" if peer else "RCCL all-reduce, eager loop")
+    if exchange is not None and fused:                       # why that path (self-test verdict / fallback reason)
+        exchange += f" [{getattr(fused[0], 'xchg_reason', '')}]"
 
     out = {"metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
