@@ -87,3 +87,58 @@ class SyntheticFixedLengthEnv:
         term = self._false if self.term_table is None else self.term_table[t]
         self.t += 1
         return nxt, self.critic_obs_table[t + 1], rew, term, self._false, nxt
+
+
+class SyntheticMixedAgentsEnv:
+    """
+    Agents with DIFFERENT observation / action spaces in one env (the shape of the reference's
+    multi-policy baselines, e.g. baselines/pettingzoo/mpe_simple_adversary.py: an adversary and a
+    team of good agents): every quantity is a dict keyed by agent id, as the reference's multi-agent
+    wrappers hand them over (environments/ppo_env_wrappers.py:1075-1156), each entry a device tensor
+    over the E envs of the rank.  agent_specs: [(agent_id, obs_dim, action_space), ...].  All agents
+    of an env terminate together.
+    """
+
+    def __init__(self, num_envs, agent_specs, horizon, device, reward="uniform", seed=1234, rank=0, term_prob=0.0):
+        self.num_envs, self.horizon, self.device = int(num_envs), int(horizon), torch.device(device)
+        self.agent_ids = [a for a, _, _ in agent_specs]
+        self.num_agents = len(self.agent_ids)
+        E = self.num_envs
+        rng = np.random.default_rng(seed + rank)
+        self.observation_space, self.critic_observation_space, self.action_space = {}, {}, {}
+        self.obs_table, self.reward_table = {}, {}
+        for agent_id, obs_dim, action_space in agent_specs:
+            sp = Box(-np.inf, np.inf, (int(obs_dim),), np.float32)
+            self.observation_space[agent_id] = self.critic_observation_space[agent_id] = sp
+            self.action_space[agent_id] = action_space
+            self.obs_table[agent_id] = torch.from_numpy(
+                rng.standard_normal((horizon + 1, E, int(obs_dim)), dtype=np.float32)).to(self.device)
+            rew = np.ones((horizon, E), dtype=np.float32) if reward == "ones" else \
+                rng.uniform(-1.0, 1.0, (horizon, E)).astype(np.float32)
+            self.reward_table[agent_id] = torch.from_numpy(rew).to(self.device)
+        self.term_table = None
+        if term_prob > 0.0:
+            self.term_table = torch.from_numpy(rng.uniform(0, 1, (horizon, E)) < term_prob).to(self.device)
+        self._false = torch.zeros(E, dtype=torch.bool, device=self.device)
+        self.t = 0
+
+    def get_batch_size(self):
+        return self.num_envs
+
+    def _obs(self, t):
+        o = {a: tab[t] for a, tab in self.obs_table.items()}
+        return o, o
+
+    def reset(self):
+        self.t = 0
+        return self._obs(0)
+
+    def step(self, action):
+        assert set(action.keys()) == set(self.agent_ids)
+        t = self.t % self.horizon
+        obs, cobs = self._obs(t + 1)
+        rew = {a: tab[t] for a, tab in self.reward_table.items()}
+        term = self._false if self.term_table is None else self.term_table[t]
+        self.t += 1
+        done = {a: term for a in self.agent_ids}
+        return obs, cobs, rew, done, {a: self._false for a in self.agent_ids}, obs

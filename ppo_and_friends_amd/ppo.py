@@ -89,9 +89,18 @@ class PermutationLoader:
         if c.get("n") == n and c.get("perm") is not None:
             perm, c["perm"] = c["perm"], None
         else:
+            self._discard_prefetch()
             perm = self._draw(n)
         # the staging buffer is reused by the next draw: the device copy is made (and completed) here
         return perm.to(self.dataset.device, non_blocking=False)
+
+    def _discard_prefetch(self):
+        """A permutation drawn ahead for another dataset size (the next policy's dataset differs): put the
+        generator back where the reference's would be, so the stream of draws stays the reference's."""
+        c = self.prefetch_cache
+        if c.get("perm") is not None and c.get("state_before") is not None and self.generator is not None:
+            self.generator.set_state(c["state_before"])
+        c["perm"], c["state_before"] = None, None
 
     def _draw(self, n):
         g = self.generator
@@ -121,6 +130,8 @@ class PermutationLoader:
         c = self.prefetch_cache
         n = len(self.dataset)
         if c.get("perm") is None or c.get("n") != n:
+            self._discard_prefetch()
+            c["state_before"] = self.generator.get_state()
             c["n"], c["perm"] = n, self._draw(n)
 
     def __iter__(self):
@@ -413,8 +424,11 @@ class PPO:
         ppo.py:1534-2110 with several policies (`policy_mapping_fn` partitions the env's agents, ppo.py:329-345,
         710-858): every policy acts on its own agents' rows of the agent-major env tensors and logs into its own
         rollout buffer; the env is stepped once with the combined actions; episode ends are shared (the agents of an
-        env end together).  Covers feed-forward PPOPolicy instances whose agents share observation / action shapes
-        (independent or team-wise PPO); grouped (MAT), LSTM and ICM policies are single-policy features here.
+        env end together).  Covers feed-forward PPOPolicy instances (independent or team-wise PPO).  The env hands over
+        either agent-major tensors [A*E, .] (all agents share shapes) or, as the reference's multi-agent wrappers do,
+        dicts keyed by agent id (agents of different policies may then differ in observation / action space; the
+        agents of ONE policy share them, as in the reference).  Grouped (MAT), LSTM and ICM policies are
+        single-policy features here.
         """
         start = time.time()
         env = self.env
@@ -433,6 +447,7 @@ class PPO:
             fused = (self.update_mode != "torch" and self.device.type == "cuda"
                      and pol.fused_step_unsupported_reason() == "")
             ctxs.append(dict(id=policy_id, pol=pol, buf=pol.buffer, idx=idx, n=int(idx.numel()), fused=fused,
+                             agents=[agent_ids[int(i)] for i in idx],          # the policy's agents in env order
                              vn=self.value_normalizers[policy_id] if self.normalize_values else None,
                              nat=torch.zeros(T, int(idx.numel()) * n_envs, dtype=torch.float32, device=self.device)))
         if sorted(int(i) for c in ctxs for i in c["idx"]) != list(range(A)):
@@ -442,7 +457,15 @@ class PPO:
         else:
             soft = getattr(env, "soft_reset", None)
             obs, critic_obs = soft() if callable(soft) else self._obs
-        rows = lambda x, c: x.reshape((A, n_envs) + tuple(x.shape[1:]))[c["idx"]].reshape((c["n"] * n_envs,) + tuple(x.shape[1:]))
+        dict_env = isinstance(obs, dict)
+
+        def rows(x, c):
+            """The policy's rows of an env quantity, agent-major: [n * E, .]."""
+            if isinstance(x, dict):
+                return torch.cat([x[a] for a in c["agents"]], 0)
+            return x.reshape((A, n_envs) + tuple(x.shape[1:]))[c["idx"]].reshape((c["n"] * n_envs,) + tuple(x.shape[1:]))
+
+        per_env = lambda x: (x[agent_ids[0]] if isinstance(x, dict) else x[:n_envs])   # agents of an env end together
         ep_ts = torch.zeros(n_envs, dtype=torch.int32, device=self.device)
         may_end_early = getattr(env, "term_table", True) is not None or self.max_ts_per_ep < T
         actions = None
@@ -454,16 +477,26 @@ class PPO:
                 else:
                     raw, a, lp = pol.get_rollout_actions(o)
                     c["pending"] = (co, o, raw, a, self.get_policy_values(c["id"], co), lp)
+                if dict_env:
+                    if actions is None:
+                        actions = {}
+                    per_agent = a.reshape((c["n"], n_envs) + tuple(a.shape[1:]))
+                    for i, agent_id in enumerate(c["agents"]):
+                        actions[agent_id] = per_agent[i]
+                    continue
                 if actions is None:
                     actions = torch.zeros((A, n_envs) + tuple(a.shape[1:]), dtype=a.dtype, device=self.device)
                 actions[c["idx"]] = a.reshape((c["n"], n_envs) + tuple(a.shape[1:]))
-            nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(actions.reshape((A * n_envs,) + tuple(actions.shape[2:]))))
+            env_action = actions if dict_env else actions.reshape((A * n_envs,) + tuple(actions.shape[2:]))
+            nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(env_action))
             nat = self._natural_reward(env, reward)
-            if self.ext_reward_weight != 1.0:
+            if self.ext_reward_weight != 1.0 and not dict_env:
                 reward = reward * self.ext_reward_weight
             for c in ctxs:
                 c["nat"][t].copy_(rows(nat, c))
                 r = rows(reward, c)
+                if self.ext_reward_weight != 1.0 and dict_env:
+                    r = r * self.ext_reward_weight
                 if c["fused"]:
                     c["pol"].finish_step(t, r, None)
                 else:
@@ -471,7 +504,7 @@ class PPO:
                     c["buf"].write_step(t, slice(0, c["buf"].C), co, o, None, raw, a, v, lp, r)
                     c["pol"]._t = t + 1
             if may_end_early:
-                term_e, trunc_e = terminated[:n_envs], truncated[:n_envs]          # agents of an env end together
+                term_e, trunc_e = per_env(terminated), per_env(truncated)
                 ep_ts += 1
                 last = t == T - 1
                 boot = (~term_e) & ((ep_ts >= self.max_ts_per_ep) | trunc_e | last)
