@@ -650,13 +650,15 @@ int ppoaf_mat_policy_step(const ppoaf_mat_step_args_t* args, ppoaf_stream_t stre
  * wait_seconds for its peers inside the kernel; on expiry the launch drains, dst is undefined and the error
  * word (status out[1]) holds the sequence number that timed out -- it never hangs.
  * ppoaf_peer_exchange_status: out[0] = exchanges completed, out[1] = 0 or the sequence number of a timed-out
- * wait, out[2] = 1 uncached / 2 fine-grained exchange memory, out[3] = n_ranks (synchronises the device).
+ * wait, out[2] = 1 uncached / 2 fine-grained / 3 coarse-grained exchange memory, out[3] = n_ranks (synchronises the device).
  * ------------------------------------------------------------------------ */
 #define PPOAF_PEER_EXCHANGE_MAX_RANKS 16
 #define PPOAF_PEER_EXCHANGE_BLOB_BYTES 128
 typedef struct ppoaf_peer_exchange ppoaf_peer_exchange_t;
 
-int ppoaf_peer_exchange_create(int rank, int n_ranks, int64_t bucket_floats, ppoaf_peer_exchange_t** out);
+/* memory_kind of the exchange slots: 0 auto (uncached, else fine-grained), 1 uncached, 2 fine-grained, 3 coarse-grained */
+int ppoaf_peer_exchange_create(int rank, int n_ranks, int64_t bucket_floats, int memory_kind,
+                               ppoaf_peer_exchange_t** out);
 int ppoaf_peer_exchange_export(ppoaf_peer_exchange_t* x, void* blob /* host, PPOAF_PEER_EXCHANGE_BLOB_BYTES */);
 int ppoaf_peer_exchange_connect(ppoaf_peer_exchange_t* x, const void* all_blobs /* host, n_ranks blobs in rank order */);
 int ppoaf_peer_exchange_allreduce(ppoaf_peer_exchange_t* x, const float* src, float* dst, int64_t split_floats,

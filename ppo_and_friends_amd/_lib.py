@@ -196,7 +196,7 @@ SIGNATURES = {
     "ppoaf_mat_update_fwd_bwd": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
     "ppoaf_mat_update_reduce": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
     "ppoaf_mat_policy_step": (C.c_int, [C.POINTER(MatStepArgs), _ptr]),
-    "ppoaf_peer_exchange_create": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
+    "ppoaf_peer_exchange_create": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
     "ppoaf_peer_exchange_export": (C.c_int, [_ptr, _ptr]),
     "ppoaf_peer_exchange_connect": (C.c_int, [_ptr, C.c_char_p]),
     "ppoaf_peer_exchange_allreduce": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_float, _ptr, C.c_double, _ptr]),

@@ -86,26 +86,39 @@ using namespace ppoaf;
         }                                                                              \
     } while (0)
 
-extern "C" int ppoaf_peer_exchange_create(int rank, int n_ranks, int64_t bucket_floats,
+extern "C" int ppoaf_peer_exchange_create(int rank, int n_ranks, int64_t bucket_floats, int memory_kind,
                                           ppoaf_peer_exchange_t** out) {
     PPOAF_REQUIRE(out, "peer_exchange_create: null out");
     PPOAF_REQUIRE(n_ranks >= 1 && n_ranks <= kMaxPeers && rank >= 0 && rank < n_ranks,
                   "peer_exchange_create: rank %d of %d (at most %d ranks)", rank, n_ranks, kMaxPeers);
     PPOAF_REQUIRE(bucket_floats > 0 && bucket_floats % 4 == 0, "peer_exchange_create: bucket of %ld floats (multiple of 4)",
                   (long)bucket_floats);
+    PPOAF_REQUIRE(memory_kind >= 0 && memory_kind <= 3, "peer_exchange_create: memory_kind=%d (0 auto, 1 uncached, 2 fine-grained, 3 coarse)",
+                  memory_kind);
     ppoaf_peer_exchange* x = new (std::nothrow) ppoaf_peer_exchange();
     PPOAF_REQUIRE(x, "peer_exchange_create: out of host memory");
     x->dev.rank = rank; x->dev.n_ranks = n_ranks; x->dev.n4 = bucket_floats / 4;
     x->bytes = kXchgHeaderBytes + 2 * (size_t)bucket_floats * sizeof(float);
-    hipError_t e = hipExtMallocWithFlags(&x->base, x->bytes, hipDeviceMallocUncached);
-    x->memory_kind = 1;
-    if (e != hipSuccess) {
+    // exchange memory: 1 uncached (default: remote reads / writes never meet a cached copy), 2 fine-grained,
+    // 3 ordinary coarse-grained device memory (relies on the system-scope fences of the kernel alone);
+    // 0 = uncached, or fine-grained if that allocation is refused
+    hipError_t e = hipErrorInvalidValue;
+    if (memory_kind == 0 || memory_kind == 1) {
+        e = hipExtMallocWithFlags(&x->base, x->bytes, hipDeviceMallocUncached);
+        x->memory_kind = 1;
+    }
+    if ((memory_kind == 0 && e != hipSuccess) || memory_kind == 2) {
         (void)hipGetLastError();
         e = hipExtMallocWithFlags(&x->base, x->bytes, hipDeviceMallocFinegrained);
         x->memory_kind = 2;
     }
+    if (memory_kind == 3) {
+        e = hipMalloc(&x->base, x->bytes);
+        x->memory_kind = 3;
+    }
     if (e != hipSuccess) {
-        set_error("peer_exchange_create: hipExtMallocWithFlags: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        set_error("peer_exchange_create: exchange memory (kind %d): %s", memory_kind, hipGetErrorString(e));
         delete x;
         return PPOAF_E_LAUNCH;
     }

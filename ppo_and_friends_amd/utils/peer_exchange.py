@@ -50,15 +50,15 @@ class PeerExchange:
 
     wait_seconds = 20.0          # in-kernel budget for a peer to show up (ranks are aligned by the epoch's collectives)
 
-    def __init__(self, n_floats, device):
+    def __init__(self, n_floats, device, memory_kind=0):
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.rank, self.world = mpi_utils.get_rank(), mpi_utils.get_num_procs()
         self.n_floats = int(n_floats)
         self.handle = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.ppoaf_peer_exchange_create(self.rank, self.world, self.n_floats, C.byref(self.handle)),
-                       "peer_exchange_create")
+            _lib.check(self.lib.ppoaf_peer_exchange_create(self.rank, self.world, self.n_floats, int(memory_kind),
+                                                           C.byref(self.handle)), "peer_exchange_create")
 
     def export(self):
         blob = C.create_string_buffer(BLOB_BYTES)
@@ -173,31 +173,43 @@ def open_exchange(n_floats, device):
     hosts = _all_gather_bytes(socket.gethostname().encode())
     if not _vote(device.type == "cuda" and world <= MAX_RANKS and len(set(hosts)) == 1 and n_floats % 4 == 0):
         return refuse(f"needs CUDA devices of one host, at most {MAX_RANKS} ranks and a bucket of a multiple of 4 floats")
-    x, err = None, ""
-    try:
-        x = PeerExchange(n_floats, device)
-        blob = x.export()
-    except Exception as exc:                                   # noqa: BLE001 -- any failure means "fall back", by vote
-        blob, err = b"\0" * BLOB_BYTES, f"{type(exc).__name__}: {exc}"
-    blobs = _all_gather_bytes(blob)
-    if not _vote(x is not None and not err):
-        if x is not None:
+    # exchange memory kinds in order of preference (PPOAF_PEER_MEMORY pins one): the first kind with which every
+    # rank creates, exports, connects and passes the self-test is used
+    names = {1: "uncached", 2: "fine-grained", 3: "coarse-grained"}
+    forced = os.environ.get("PPOAF_PEER_MEMORY", "").strip().lower()
+    kinds = [k for k, v in names.items() if v == forced] or [1, 2, 3]
+    reasons = []
+    for kind in kinds:
+        x, err = None, ""
+        try:
+            x = PeerExchange(n_floats, device, memory_kind=kind)
+            blob = x.export()
+        except Exception as exc:                               # noqa: BLE001 -- any failure means "next option", by vote
+            blob, err = b"\0" * BLOB_BYTES, f"{type(exc).__name__}: {exc}"
+        blobs = _all_gather_bytes(blob)
+        if not _vote(x is not None and not err):
+            if x is not None:
+                x.close()
+            reasons.append(f"{names[kind]}: create/export failed on a rank" + (f" ({err})" if err else ""))
+            continue
+        try:
+            x.connect(blobs)
+        except Exception as exc:                               # noqa: BLE001
+            err = f"{type(exc).__name__}: {exc}"
+        if not _vote(not err):
             x.close()
-        return refuse("create/export failed on a rank" + (f" ({err})" if err else ""))
-    try:
-        x.connect(blobs)
-    except Exception as exc:                                   # noqa: BLE001
-        err = f"{type(exc).__name__}: {exc}"
-    if not _vote(not err):
+            reasons.append(f"{names[kind]}: connect failed on a rank" + (f" ({err})" if err else ""))
+            continue
+        if mpi_utils.is_initialized() and world > 1:
+            dist.barrier()                                     # every rank's flag words are zeroed and mapped
+        try:
+            good = x.self_test()
+        except Exception as exc:                               # noqa: BLE001
+            good, err = False, f"{type(exc).__name__}: {exc}"
+        if _vote(good):
+            return x, f"peer mappings ({names[kind]} slots), self-test passed"
         x.close()
-        return refuse("connect failed on a rank" + (f" ({err})" if err else ""))
-    if mpi_utils.is_initialized() and world > 1:
-        dist.barrier()                                         # every rank's flag words are zeroed and mapped
-    try:
-        good = x.self_test()
-    except Exception as exc:                                   # noqa: BLE001
-        good, err = False, f"{type(exc).__name__}: {exc}"
-    if not _vote(good):
-        x.close()
-        return refuse("self-test against the gathered sum failed on a rank" + (f" ({err})" if err else ""))
-    return x, "peer mappings, self-test passed"
+        if mpi_utils.is_initialized() and world > 1:
+            dist.barrier()                                     # nobody still reads a slot that is about to be freed
+        reasons.append(f"{names[kind]}: self-test against the gathered sum failed on a rank" + (f" ({err})" if err else ""))
+    return refuse("; ".join(reasons))

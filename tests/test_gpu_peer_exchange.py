@@ -38,9 +38,10 @@ def _want(step, world, dev):
     return acc
 
 
-def _rank(rank, world, port, out):
+def _rank(rank, world, port, out, memory):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PPOAF_GRAD_EXCHANGE="peer")
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PPOAF_GRAD_EXCHANGE="peer",
+                      PPOAF_PEER_MEMORY=memory)
     import torch.distributed as dist
     from ppo_and_friends_amd.utils import mpi_utils, peer_exchange
     mpi_utils.init_process_group_from_env(backend="gloo")
@@ -123,18 +124,25 @@ def _rank(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module")
-def run3():
+# the three kinds of exchange memory open_exchange tries in turn on a node (uncached first)
+MEMORY = {"uncached": 1, "fine-grained": 2, "coarse-grained": 3}
+
+
+@pytest.fixture(scope="module", params=list(MEMORY))
+def run3(request):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_rank, args=(WORLD, _free_port(), out), nprocs=WORLD, join=True)
-    return [out[r] for r in range(WORLD)]
+    mp.spawn(_rank, args=(WORLD, _free_port(), out, request.param), nprocs=WORLD, join=True)
+    res = [out[r] for r in range(WORLD)]
+    for r in res:
+        assert r["memory_kind"] == MEMORY[request.param] and request.param in r["why"], (r["memory_kind"], r["why"])
+    return res
 
 
 def test_exchange_opens_and_self_test_passes(run3):
     for r in run3:
         assert r["opened"], r["why"]
-        assert r["memory_kind"] in (1, 2)
+        assert r["memory_kind"] in (1, 2, 3)
 
 
 def test_sum_is_rank_ordered_and_bit_exact(run3):
