@@ -95,6 +95,8 @@ def main():
 
     rank, world, local_rank = mpi_utils.init_process_group_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("PPOAF_SHARE_DEVICE", "0") == "1":
+        local_rank = 0          # rehearsal on a one-GPU box (with PPOAF_BACKEND=gloo): all ranks on device 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     E, T, O, NA = args.envs, args.ts, 4, 2
@@ -166,10 +168,7 @@ def main():
         iteration(True)
     barrier()
     dt = time.perf_counter() - t0
-    dt_t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if mpi_utils.distributed_path():
-        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-    dt = float(dt_t.item())
+    dt = float(mpi_utils.allreduce_scalars([dt], op="max")[0])        # MAX over ranks
 
     env_steps = world * E * T * args.steps
     value = env_steps / dt

@@ -58,7 +58,7 @@ def init_process_group_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or rehearsing()) and not is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("PPOAF_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -210,3 +210,33 @@ def test_diverged_replicas_are_detected_and_healed():
         assert r["agree_after_corruption"] is False and r["peer_exchange_after"] == [False]
     assert torch.equal(r0["w_healed"], r1["w_healed"])
     assert torch.equal(r0["w"], r1["w"]) and not torch.equal(r0["w"], r0["w_healed"])
+
+
+def test_bench_contract_under_the_drivers_two_rank_launch():
+    """
+    The driver's N > 1 command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- rehearsed with N = 2 on the one GPU of
+    the box (PPOAF_BACKEND=gloo: RCCL refuses two ranks on a device; PPOAF_SHARE_DEVICE=1: both ranks on device 0).
+    One JSON line from rank 0, whole-job value, weak scaling, the K17 exchange inside graph-replayed chains.
+    """
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PPOAF_BACKEND="gloo", PPOAF_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PPOAF_GRAD_EXCHANGE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--epochs", "1", "--no-cpu-baseline", "--no-saturating"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["metric"] == "env_steps_per_sec" and out["value"] > 0 and out["higher_is_better"] is True
+    cfg = out["config"]
+    assert cfg["parallelism"] == "dp2" and cfg["global_env_steps_per_iteration"] == 2 * 4096 * 128
+    assert cfg["multi_rank_path"] is True and cfg["hip_graphs"] is True and cfg["gradient_exchange"].startswith("K17")
+    assert abs(out["value"] - 2 * 4096 * 128 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-3
+    assert "roofline" in out and out["roofline"]["bound"] == "hbm"
