@@ -98,6 +98,8 @@ def gae_rtg_traj(rewards, values, ending_value, ending_reward, traj_start, traj_
         adv_out = torch.zeros_like(rewards)
     if rtg_out is None and (compute_rtg or not use_gae):
         rtg_out = torch.zeros_like(rewards)
+    if N == 0:                       # only zero-length trajectories: nothing to scan (and no storage to point at)
+        return adv_out, rtg_out
     hc, lo, hi = _clip_args(bootstrap_clip)
     check(_lib.load().ppoaf_gae_rtg_traj(
         ptr(rewards), ptr(values), ptr(ending_value), ptr(ending_reward), ptr(traj_start),

@@ -533,3 +533,60 @@ def test_c_abi_collectives_single_rank(K):
     assert lib.ppoaf_bcast_f32(comm, x.data_ptr(), x.numel(), 3, st) != 0          # root outside the communicator
     assert b"root" in lib.ppoaf_last_error()
     _lib.check(lib.ppoaf_comm_destroy(comm), "comm_destroy")
+
+
+# ---------------------------------------------------------------- K1 fuzz
+def test_gae_kernels_fuzz_against_the_oracle(K):
+    """
+    Randomised shapes and episode structures (hypothesis, derandomised): the dense time-major form -- any T, E,
+    density of terminal / bootstrapped ends, clip range, (gamma, lambda), GAE or rtg - V -- and the ragged
+    trajectory form incl. zero-length trajectories, both against oracle/episode_info_oracle.py.
+    """
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    params = st.sampled_from([(0.99, 0.95), (1.0, 1.0), (0.9, 0.0), (0.5, 0.99)])
+    clips = st.sampled_from([(-100.0, 100.0), (-0.25, 0.75), None])
+
+    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(T=st.integers(1, 300), E=st.integers(1, 150), p_term=st.floats(0.0, 0.4), p_boot=st.floats(0.0, 0.4),
+           gl=params, clip=clips, use_gae=st.booleans(), seed=st.integers(0, 10_000))
+    def dense(T, E, p_term, p_boot, gl, clip, use_gae, seed):
+        rng = np.random.default_rng(seed)
+        rew = rng.uniform(-1, 1, (T, E)).astype(np.float32)
+        val = rng.standard_normal((T, E)).astype(np.float32)
+        bv = (rng.standard_normal((T, E)) * 2).astype(np.float32)
+        br = (rng.standard_normal((T, E)) * 3).astype(np.float32)
+        u = rng.uniform(0, 1, (T, E))
+        ek = np.where(u < p_term, 1, np.where(u < p_term + p_boot, 2, 0)).astype(np.int8)
+        ek[-1] = np.where(ek[-1] == 0, 2, ek[-1])
+        kw = dict(gamma=gl[0], lambd=gl[1], bootstrap_clip=clip, use_gae=use_gae)
+        a_ref, r_ref = _tmajor_oracle(rew, val, bv, br, ek, **kw)
+        adv, rtg = K.gae_rtg_tmajor(dev(rew), dev(val), dev(bv), dev(br), dev(ek), **kw)
+        np.testing.assert_allclose(adv.cpu().numpy(), a_ref, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(rtg.cpu().numpy(), r_ref, rtol=RTOL, atol=ATOL)
+
+    @settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(lens=st.lists(st.integers(0, 260), min_size=1, max_size=12), gl=params, clip=clips, use_gae=st.booleans(),
+           seed=st.integers(0, 10_000))
+    def ragged(lens, gl, clip, use_gae, seed):
+        rng = np.random.default_rng(seed)
+        lens = np.array(lens, dtype=np.int32)
+        N = int(lens.sum())
+        rew = rng.uniform(-1, 1, N).astype(np.float32)
+        val = rng.standard_normal(N).astype(np.float32)
+        starts = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
+        ev = rng.standard_normal(len(lens)).astype(np.float32)
+        er = (rng.standard_normal(len(lens)) * 3).astype(np.float32)
+        kw = dict(gamma=gl[0], lambd=gl[1], bootstrap_clip=clip, use_gae=use_gae)
+        adv, rtg = K.gae_rtg_traj(dev(rew), dev(val), dev(ev), dev(er), dev(starts), dev(lens), **kw)
+        adv, rtg = adv.cpu().numpy(), rtg.cpu().numpy()
+        for i in range(len(lens)):
+            if lens[i] == 0:
+                continue
+            sl = slice(starts[i], starts[i] + lens[i])
+            a, r = eo.end_episode(rew[sl], val[sl], float(ev[i]), float(er[i]), gl[0], gl[1], clip, use_gae)
+            np.testing.assert_allclose(adv[sl], a.astype(np.float32), rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(rtg[sl], r.astype(np.float32), rtol=RTOL, atol=ATOL)
+
+    dense()
+    ragged()
