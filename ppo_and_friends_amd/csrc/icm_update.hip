@@ -656,6 +656,21 @@ static int make_icm(const ppoaf_icm_update_args_t* a, IcmDev& u, bool training =
     return PPOAF_OK;
 }
 
+// gfx950 has 160 KB of LDS per CU; launches above the 64 KB default need the attribute set once per kernel
+static int allow_large_lds(const void* kernel, size_t bytes, bool& done, const char* what) {
+    if (bytes <= 64 * 1024 || done) return PPOAF_OK;
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, kernel);          // static __shared__ counts against the same 160 KB
+    if (e != hipSuccess) { set_error("%s: hipFuncGetAttributes: %s", what, hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+    const size_t room = 160 * 1024 - fa.sharedSizeBytes;
+    PPOAF_REQUIRE(bytes <= room, "%s: needs %zu B of dynamic LDS, %zu available beside %zu B of static LDS", what, bytes,
+                  room, (size_t)fa.sharedSizeBytes);
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)room);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+    done = true;
+    return PPOAF_OK;
+}
+
 template <int HT>
 static int launch_icm_fwd_bwd(const IcmDev& u, hipStream_t s) {
     const size_t HS = 16 * HT + 4, H = 16 * HT;
@@ -664,12 +679,17 @@ static int launch_icm_fwd_bwd(const IcmDev& u, hipStream_t s) {
     const size_t lds_enc_b = (16 + kRows * INP + 5 * kRows * HS) * 4;
     const int dmax = u.d_inv > u.d_fwd ? u.d_inv : u.d_fwd;
     const size_t lds_heads = (160 + 8 * H + kRows * kXS + (4 + dmax) * kRows * HS + 2 * kRows * kMaxOut) * 4;
-    PPOAF_REQUIRE(lds_enc_b <= 64 * 1024 && lds_heads <= 64 * 1024 && lds_enc_f <= 64 * 1024,
-                  "icm_update: needs %zu / %zu B of LDS (> 64 KiB): obs_dim or depth too large for this build",
+    PPOAF_REQUIRE(lds_enc_b <= 160 * 1024 && lds_heads <= 160 * 1024 && lds_enc_f <= 160 * 1024,
+                  "icm_update: needs %zu / %zu B of LDS (> 160 KiB): obs_dim or depth too large",
                   lds_enc_b, lds_heads);
+    static bool big_f = false, big_h = false, big_b = false;
+    int rc = allow_large_lds(reinterpret_cast<const void*>(icm_encoder_fwd_kernel<HT>), lds_enc_f, big_f, "icm_encoder_fwd");
+    if (!rc) rc = allow_large_lds(reinterpret_cast<const void*>(icm_heads_kernel<HT>), lds_heads, big_h, "icm_heads");
+    if (!rc) rc = allow_large_lds(reinterpret_cast<const void*>(icm_encoder_bwd_kernel<HT>), lds_enc_b, big_b, "icm_encoder_bwd");
+    if (rc) return rc;
     const unsigned grid = 2u * (unsigned)u.nT;
     hipLaunchKernelGGL(icm_encoder_fwd_kernel<HT>, dim3(grid), dim3(kThreadsU), lds_enc_f, s, u);
-    int rc = check_launch("icm_encoder_fwd");
+    rc = check_launch("icm_encoder_fwd");
     if (rc) return rc;
     hipLaunchKernelGGL(icm_heads_kernel<HT>, dim3(grid), dim3(kThreadsU), lds_heads, s, u);
     rc = check_launch("icm_heads");
@@ -706,9 +726,13 @@ static int launch_icm_reward(const IcmDev& u, float scale, float* intr_out, hipS
     const size_t INP = 16 * ((u.O + 15) / 16) + 4;
     const size_t lds_enc_f = (16 + kRows * INP + 4 * kRows * HS) * 4;
     const size_t lds_rew = (kRows * kXS + 4 * kRows * HS) * 4;
-    PPOAF_REQUIRE(lds_enc_f <= 64 * 1024, "icm_intrinsic_reward: obs_dim too large for this build");
+    PPOAF_REQUIRE(lds_enc_f <= 160 * 1024 && lds_rew <= 160 * 1024, "icm_intrinsic_reward: obs_dim too large");
+    static bool big_f = false, big_r = false;
+    int rc = allow_large_lds(reinterpret_cast<const void*>(icm_encoder_fwd_kernel<HT>), lds_enc_f, big_f, "icm_encoder_fwd");
+    if (!rc) rc = allow_large_lds(reinterpret_cast<const void*>(icm_reward_kernel<HT>), lds_rew, big_r, "icm_reward");
+    if (rc) return rc;
     hipLaunchKernelGGL(icm_encoder_fwd_kernel<HT>, dim3(2u * (unsigned)u.nT), dim3(kThreadsU), lds_enc_f, s, u);
-    int rc = check_launch("icm_intrinsic_reward/encoder");
+    rc = check_launch("icm_intrinsic_reward/encoder");
     if (rc) return rc;
     hipLaunchKernelGGL(icm_reward_kernel<HT>, dim3((unsigned)u.nT), dim3(kThreadsU), lds_rew, s, u, scale, intr_out);
     return check_launch("icm_intrinsic_reward");

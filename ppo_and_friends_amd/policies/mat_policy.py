@@ -116,6 +116,9 @@ class MATPolicy(PPOPolicy):
         T = int(ts_per_rollout) // int(env_batch_size)
         self.env_batch_size = int(env_batch_size)
         A = len(self.agent_ids)
+        if A < 2:
+            raise NotImplementedError("MATPolicy groups the agents of an env into one sequence: it needs at least two "
+                                      "agents (a single agent is an ordinary PPOPolicy)")
         obs_dim = int(np.prod(get_space_shape(self.actor_obs_space)))
         cobs_dim = int(np.prod(get_space_shape(self.critic_obs_space)))
         if self.buffer is None or (self.buffer.T, self.buffer.C) != (T, self.env_batch_size):

@@ -975,3 +975,90 @@ def test_two_policies_with_different_spaces_match_two_cpu_ports(update_mode):
             np.testing.assert_allclose(sd[k], r[k], rtol=5e-5, atol=5e-6, err_msg=f"{pid} {k}")
         np.testing.assert_allclose(_flat_params(ppo.policies[pid].actor), _flat_params(cpus[pid].actor), rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(_flat_params(ppo.policies[pid].critic), _flat_params(cpus[pid].critic), rtol=1e-4, atol=2e-5)
+
+
+def test_fused_mat_and_icm_paths_fuzz_against_the_torch_paths():
+    """
+    Randomised shapes (hypothesis, derandomised) for the other two fused chains, each against this package's
+    torch-ROCm path on the same rollout and shuffles (those paths are the ones checked against the oracles):
+    K15 / K16 (MATPolicy: 2-5 agents, observation 1-32, 2-8 actions, batch sizes that are not multiples of the
+    sequences per tile, epoch tails) and K14 (ICM: discrete / continuous, widths 64 / 128, depths 1-3).
+    """
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from ppo_and_friends_amd.ppo import PPO, PermutationLoader
+    from ppo_and_friends_amd.policies.mat_policy import MATPolicy
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    dev = torch.device("cuda", 0)
+
+    @settings(max_examples=16, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(A=st.integers(2, 5), O=st.integers(1, 32), NA=st.integers(2, 8), E=st.integers(1, 9), T=st.integers(2, 14),
+           B=st.integers(2, 40), seed=st.integers(0, 50))
+    def mat(A, O, NA, E, T, B, seed):
+        def make(mode):
+            env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=41, num_agents=A)
+            sp = Box(-np.inf, np.inf, (O,), np.float32)
+            return PPO(env_gen, {"mat": (MATPolicy, sp, sp, Discrete(NA), {})}, device=dev, random_seed=seed, normalize_obs=False,
+                       normalize_rewards=False, envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=1,
+                       update_mode=mode, use_graphs=False)
+        # K16: the rollout kernel's log-probs / values against the torch modules, teacher-forced on its own actions
+        ppo = make("fused")
+        pol = ppo.policies["mat"]
+        assert pol.fused_step_unsupported_reason() == ""
+        ppo.rollout()
+        buf = pol.buffer
+        flat = lambda x: x.reshape((T * E,) + tuple(x.shape[2:]))
+        with torch.no_grad():
+            v, lp, _ = pol.evaluate(flat(buf.critic_observations), flat(buf.observations), flat(buf.raw_actions))
+        np.testing.assert_allclose(flat(buf.log_probs).cpu().numpy(), lp.reshape(T * E, A).cpu().numpy(), rtol=3e-5, atol=3e-5)
+        vn = ppo.value_normalizers["mat"]
+        np.testing.assert_allclose(flat(buf.values).cpu().numpy(), vn.denormalize(v.reshape(T * E, A)).cpu().numpy(),
+                                   rtol=3e-5, atol=3e-5)
+        # K15: the fused update against the torch update on IDENTICAL rollouts (both sampled by the torch rollout,
+        # whose Philox draws differ from K16's one-launch sampler)
+        res = []
+        for mode in ("fused", "torch"):
+            ppo = make(mode)
+            pol = ppo.policies["mat"]
+            assert (ppo._fused_updater("mat", B) is not None) == (mode == "fused")
+            pol.fused_step_unsupported_reason = lambda: "torch rollout forced by the test"
+            ppo.rollout()
+            loader = PermutationLoader(pol.dataset, B, ppo.loader_generator)
+            pol.train()
+            ppo._ppo_batch_train(loader, "mat")
+            sd = ppo.status_dict["mat"]
+            res.append((pol.actor_critic.flat_params.detach().cpu().numpy().copy(), pol.buffer.actions.cpu().numpy().copy(),
+                        [sd[k] for k in ("actor loss", "critic loss", "kl avg", "weighted entropy")]))
+        (w0, a0, s0), (w1, a1, s1) = res
+        np.testing.assert_array_equal(a0, a1)
+        np.testing.assert_allclose(s0, s1, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(w0, w1, rtol=2e-4, atol=3e-5)
+
+    @settings(max_examples=16, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(kind=st.sampled_from(["d", "c"]), NA=st.integers(2, 8), O=st.integers(1, 60), H=st.sampled_from([64, 128]),
+           d_inv=st.integers(1, 3), d_fwd=st.integers(1, 3), E=st.integers(1, 10), T=st.integers(2, 20), B=st.integers(2, 70))
+    def icm(kind, NA, O, H, d_inv, d_fwd, E, T, B):
+        space = Discrete(NA) if kind == "d" else Box(-1.0, 1.0, (NA,), np.float32)
+        icm_kw = dict(encoded_obs_dim=H, encoder_hidden_size=H, inverse_hidden_size=H, forward_hidden_size=H,
+                      inverse_hidden_depth=d_inv, forward_hidden_depth=d_fwd)
+        res = []
+        for mode in ("fused", "torch"):
+            env_gen = lambda: SyntheticFixedLengthEnv(E, O, space, T, dev, reward="uniform", seed=5, term_prob=0.05)
+            sp = Box(-np.inf, np.inf, (O,), np.float32)
+            ppo = PPO(env_gen, {"p": (None, sp, sp, space, dict(enable_icm=True, icm_kw_args=icm_kw))}, device=dev,
+                      random_seed=4, normalize_obs=False, normalize_rewards=False, envs_per_proc=E, ts_per_rollout=T,
+                      batch_size=B, epochs_per_iter=1, update_mode=mode, use_graphs=False)
+            pol = ppo.policies["p"]
+            assert (ppo._fused_icm_updater("p") is not None) == (mode == "fused")
+            ppo.rollout()
+            loader = PermutationLoader(pol.dataset, B, ppo.loader_generator)
+            ppo._icm_batch_train(loader, "p")
+            res.append((pol.icm_model.flat_params.detach().cpu().numpy().copy(), pol.buffer.rewards.cpu().numpy().copy(),
+                        ppo.status_dict["p"]["icm loss"]))
+        (w0, r0, l0), (w1, r1, l1) = res
+        np.testing.assert_allclose(r0, r1, rtol=3e-5, atol=3e-6)                 # rollout-time intrinsic rewards
+        np.testing.assert_allclose(l0, l1, rtol=5e-5)
+        np.testing.assert_allclose(w0, w1, rtol=2e-4, atol=3e-5)
+
+    mat()
+    icm()
