@@ -1062,3 +1062,79 @@ def test_fused_mat_and_icm_paths_fuzz_against_the_torch_paths():
 
     mat()
     icm()
+
+
+def test_rollout_dataset_order_fuzz_against_the_cpu_port():
+    """
+    Randomised episode structure (hypothesis, derandomised): any mix of terminations, max_ts_per_ep cuts (down to 1)
+    and the end-of-rollout bootstrap; the dataset's completion order, returns, advantages, episode lengths and the
+    rollout statistics against the CPU port's per-env Python loop (ppo.py:1804-1983, episode_info.py:44-135).
+    """
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(E=st.integers(1, 20), T=st.integers(1, 40), term=st.sampled_from([0.0, 0.05, 0.3, 0.9]),
+           max_ts=st.sampled_from([1, 2, 3, 7, 200]), fused=st.booleans())
+    def run(E, T, term, max_ts, fused):
+        ppo = _make(E, T, 32, 1, term, max_ts, update_mode="fused" if fused else "torch")
+        cpu = _oracle_like(ppo, 32)
+        ds = ppo.rollout()
+        env = ppo.env
+        buf = ppo.policies["p"].buffer
+        t_tab = None if env.term_table is None else env.term_table.cpu().numpy()
+        ref = cpu.rollout(env.obs_table.cpu().numpy(), env.reward_table.cpu().numpy(),
+                          actions=buf.actions[..., 0].cpu().numpy(), term_table=t_tab, max_ts_per_ep=max_ts)
+        assert len(ds) == len(ref) == E * T
+        tol = dict(rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(ds.observations.cpu().numpy(), ref.observations.numpy())
+        np.testing.assert_array_equal(ds.actions.cpu().numpy(), ref.actions.numpy())
+        np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), ref.rewards_to_go.numpy(), **tol)
+        np.testing.assert_allclose(ds.advantages.cpu().numpy(), ref.advantages.numpy(), **tol)
+        np.testing.assert_array_equal(ds.ep_lens.cpu().numpy(), [ep.length for ep in ref.episodes])
+
+    run()
+
+
+def test_fused_update_fuzz_with_different_actor_and_critic_shapes():
+    """
+    K12 / K6+K7 with the MAPPO shape: several agents share the policy, the critic sees the
+    concatenated observations of the env ("policy" view) and is wider than the actor -- the instantiated mixed
+    width pairs (128, 256) and (64, 128).  Fused kernels against the torch-ROCm path, random sizes.
+    """
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from ppo_and_friends_amd.ppo import PPO, PermutationLoader
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    dev = torch.device("cuda", 0)
+
+    @settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(A=st.integers(2, 4), O=st.integers(1, 24), NA=st.integers(2, 8), widths=st.sampled_from([(128, 256), (64, 128)]),
+           E=st.integers(1, 8), T=st.integers(2, 16), B=st.integers(2, 100), cont=st.booleans())
+    def run(A, O, NA, widths, E, T, B, cont):
+        space = Box(-1.0, 1.0, (NA,), np.float32) if cont else Discrete(NA)
+        res = []
+        for mode in ("fused", "torch"):
+            env_gen = lambda: SyntheticFixedLengthEnv(E, O, space, T, dev, reward="uniform", seed=21, num_agents=A,
+                                                      critic_view="policy", term_prob=0.05)
+            sp, csp = Box(-np.inf, np.inf, (O,), np.float32), Box(-np.inf, np.inf, (A * O,), np.float32)
+            pargs = dict(actor_kw_args=dict(hidden_size=widths[0]), critic_kw_args=dict(hidden_size=widths[1]))
+            ppo = PPO(env_gen, {"team": (None, sp, csp, space, pargs)}, device=dev, random_seed=3, normalize_obs=False,
+                      normalize_rewards=False, envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=1,
+                      update_mode=mode, use_graphs=False)
+            pol = ppo.policies["team"]
+            assert (ppo._fused_updater("team", B) is not None) == (mode == "fused")
+            ppo.rollout()
+            loader = PermutationLoader(pol.dataset, B, ppo.loader_generator)
+            pol.train()
+            ppo._ppo_batch_train(loader, "team")
+            sd = ppo.status_dict["team"]
+            res.append((pol.policy_params.detach().cpu().numpy().copy(), pol.buffer.log_probs.cpu().numpy().copy(),
+                        pol.buffer.values.cpu().numpy().copy(),
+                        [sd[k] for k in ("actor loss", "critic loss", "kl avg", "weighted entropy")]))
+        (w0, lp0, v0, s0), (w1, lp1, v1, s1) = res
+        np.testing.assert_allclose(lp0, lp1, rtol=3e-5, atol=3e-5)          # same Philox stream in both rollouts
+        np.testing.assert_allclose(s0, s1, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(w0, w1, rtol=2e-4, atol=3e-5)
+        np.testing.assert_allclose(v0, v1, rtol=2e-4, atol=3e-5)
+
+    run()
