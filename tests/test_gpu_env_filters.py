@@ -156,3 +156,42 @@ def test_two_rank_records_merge():
             np.testing.assert_allclose(_np(st[r]["rew"][3])[g], o_rew[r].stats[g].count, rtol=1e-12)
         np.testing.assert_allclose(_np(st[r]["obs"][0]).reshape(G, W), np.stack([s.mean for s in o_obs[r].stats]),
                                    rtol=1e-5, atol=1e-6)
+
+
+def test_filter_stack_fuzz_against_the_oracle():
+    """
+    Randomised stacks and shapes (hypothesis, derandomised): any subset of {obs normaliser, obs clipper, reward
+    normaliser, reward clipper}, 1-4 agents, 1-300 envs (E = 1: zero batch variance), critic views, termination
+    densities up to "every step", against oracle/filter_oracle.py on the same raw stream.
+    """
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from ppo_and_friends_amd.environments import filter_wrappers as fw
+
+    @settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(A=st.integers(1, 4), E=st.integers(1, 300), O=st.integers(1, 40), view=st.sampled_from(["local", "policy"]),
+           norm_obs=st.booleans(), norm_rew=st.booleans(), obs_clip=st.sampled_from([None, (-1.0, 1.0), (-0.1, 3.0)]),
+           rew_clip=st.sampled_from([None, (-0.5, 0.5)]), term=st.sampled_from([0.0, 0.2, 1.0]), T=st.integers(1, 10),
+           gamma=st.sampled_from([0.99, 0.9, 1.0]))
+    def run(A, E, O, view, norm_obs, norm_rew, obs_clip, rew_clip, term, T, gamma):
+        if not (norm_obs or norm_rew or obs_clip or rew_clip):
+            return
+        raw, twin = _envs(A, E, O, T, view, term_prob=term, seed=11)
+        env = fw.wrap_environment(lambda: raw, normalize_obs=norm_obs, normalize_rewards=norm_rew, obs_clip=obs_clip,
+                                  reward_clip=rew_clip, gamma=gamma)
+        orc = fo.FilteredEnvOracle(A, E, O, raw.critic_obs_dim, norm_obs, norm_rew, obs_clip, rew_clip, gamma=gamma)
+        obs, cobs = env.reset()
+        r_obs, r_cobs = twin.reset()
+        o_obs, o_cobs = orc.filter_obs(_np(r_obs), _np(r_cobs))
+        tol = dict(rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(_np(obs), o_obs, **tol)
+        np.testing.assert_allclose(_np(cobs), o_cobs, **tol)
+        action = torch.zeros(A * E, dtype=torch.int64, device="cuda")
+        for t in range(T):
+            obs, cobs, rew, term_t, trunc, tobs = env.step(action)
+            r_obs, r_cobs, r_rew, r_term, r_trunc, r_tobs = twin.step(action)
+            o_obs, o_cobs, o_rew = orc.filter_step(_np(r_obs), _np(r_cobs), _np(r_rew), _np(r_term), _np(r_trunc))
+            np.testing.assert_allclose(_np(obs), o_obs, err_msg=f"obs t={t}", **tol)
+            np.testing.assert_allclose(_np(cobs), o_cobs, err_msg=f"critic obs t={t}", **tol)
+            np.testing.assert_allclose(_np(rew), o_rew, rtol=1e-5, atol=1e-6, err_msg=f"reward t={t}")
+
+    run()
