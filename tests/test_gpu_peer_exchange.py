@@ -106,6 +106,24 @@ def _rank(rank, world, port, out, memory):
     # every rank's results identical by construction; cross-check one checksum through the control plane
     res["checksum"] = float(outs[-1].double().sum().item())
 
+    # 3b. other bucket sizes: one float4, a partial last group, and more than 256 groups' worth (strided groups)
+    ok = True
+    for n in (4, 1028, 300_000):
+        y, why_n = peer_exchange.open_exchange(n, dev)
+        g2 = torch.Generator().manual_seed(n + rank)
+        mine = torch.randn(n, generator=g2).to(dev)
+        want_n = torch.zeros(n, device=dev)
+        for r in range(world):
+            want_n = want_n + torch.randn(n, generator=torch.Generator().manual_seed(n + r)).to(dev)
+        for _ in range(3):                                    # both slots and their reuse
+            got_n = torch.empty(n, device=dev)
+            y.allreduce(mine, got_n)
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(got_n, want_n)
+        y.close()
+        dist.barrier()
+    res["other_sizes_exact"] = ok
+
     # 4. a peer that never shows up: the wait is bounded and reported
     dist.barrier()
     if rank != world - 1:
@@ -150,6 +168,11 @@ def test_sum_is_rank_ordered_and_bit_exact(run3):
         assert r["sum_exact"] and r["back_to_back_exact"]
         assert r["norms_close"], r["norms"]
     assert run3[0]["norms"] == run3[1]["norms"] == run3[2]["norms"], "fixed-order norm: identical on every rank"
+
+
+def test_other_bucket_sizes(run3):
+    for r in run3:
+        assert r["other_sizes_exact"]
 
 
 def test_graph_replay(run3):
