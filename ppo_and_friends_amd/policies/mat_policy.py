@@ -275,7 +275,7 @@ class MATPolicy(PPOPolicy):
 
     def save(self, save_path, tag="latest"):
         import os
-        path = os.path.join(save_path, f"{self.name}-policy", tag)
+        path = os.path.join(save_path, f"{self.name}-policy", str(tag))
         os.makedirs(path, exist_ok=True)
         self.actor_critic.save(path)                     # actor_critic_<rank>.model, as the reference
         torch.save(self.actor_critic_optim.state_dict(),
@@ -286,7 +286,7 @@ class MATPolicy(PPOPolicy):
 
     def load(self, load_path, tag="latest"):
         import os
-        path = os.path.join(load_path, f"{self.name}-policy", tag)
+        path = os.path.join(load_path, f"{self.name}-policy", str(tag))
         self.actor_critic.load(path)
         f = os.path.join(path, f"actor_critic_optim_{mpi_utils.get_rank()}")
         if not os.path.exists(f):

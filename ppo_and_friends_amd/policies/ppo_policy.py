@@ -31,19 +31,7 @@ from ..spaces import (get_action_prediction_shape, get_flattened_space_length,
 from ..utils import mpi_utils
 from ..utils.episode_info import PPODataset, RolloutBuffer
 from ..utils.mpi_utils import rank_print
-
-
-class CallableValue:
-    """utils/schedulers.py:11-29: constant wrapped as a callable with finalize()."""
-
-    def __init__(self, value):
-        self.value = value
-
-    def finalize(self, status_dict):
-        pass
-
-    def __call__(self):
-        return self.value
+from ..utils.schedulers import CallableValue
 
 
 def _callable(v):
@@ -561,7 +549,7 @@ class PPOPolicy:
     # ------------------------------------------------------------- save / load
     def save(self, save_path, tag="latest"):
         """ppo_policy.py:1215-1247 (`<name>-policy/<tag>/{actor,critic}_<rank>.model`, `*_optim_<rank>`)."""
-        policy_save_path = os.path.join(save_path, f"{self.name}-policy", tag)
+        policy_save_path = os.path.join(save_path, f"{self.name}-policy", str(tag))     # :1164-1165: any tag type
         os.makedirs(policy_save_path, exist_ok=True)
         self.actor.save(policy_save_path)
         self.critic.save(policy_save_path)
@@ -574,7 +562,7 @@ class PPOPolicy:
             torch.save(self.icm_optim.state_dict(), os.path.join(policy_save_path, f"icm_optim_{r}"))
 
     def load(self, load_path, tag="latest"):
-        policy_load_path = os.path.join(load_path, f"{self.name}-policy", tag)
+        policy_load_path = os.path.join(load_path, f"{self.name}-policy", str(tag))
         self.actor.load(policy_load_path)
         self.critic.load(policy_load_path)
         if self.enable_icm:

@@ -149,7 +149,8 @@ class PPO:
                  normalize_values=True, obs_clip=None, reward_clip=None, recalc_advantages=False,
                  soft_resets=False, state_path="./saved_state", load_state=False, checkpoint_every=100,
                  save_train_scores=False, save_avg_ep_len=False, save_running_time=False, save_bs_info=False,
-                 save_state=True, use_graphs=True, update_mode="auto", verbose=False, **kw_args):
+                 save_state=True, use_graphs=True, update_mode="auto", verbose=False, freeze_scheduler=None,
+                 **kw_args):
         """
         ppo.py:126-167.  `ts_per_rollout` is per environment (ppo.py:317-318
         multiplies by envs_per_proc).  normalize_obs / normalize_rewards / obs_clip / reward_clip
@@ -230,6 +231,16 @@ class PPO:
         for pol in self.policies.values():
             pol.finalize(self.status_dict, self.device)
             pol.fused_icm_reward = update_mode != "torch"       # K14's kernels for the rollout-time intrinsic reward
+        # ppo.py:663-678: freeze cycling over policy groups (utils/schedulers.py:FreezeCyclingScheduler)
+        from .utils.schedulers import FreezeCyclingScheduler
+        if freeze_scheduler is None:
+            freeze_scheduler = CallableValue(None)
+        elif not isinstance(freeze_scheduler, FreezeCyclingScheduler):
+            raise TypeError(f"freeze_scheduler must be a FreezeCyclingScheduler, got {type(freeze_scheduler)}")
+        self.freeze_scheduler = freeze_scheduler
+        self.freeze_scheduler.finalize(self.state_path, self.status_dict, self.policies)
+        if load_state:
+            self.freeze_scheduler.load_info()
         # ppo.py:325-354: policies may post-process what the environment returns
         self.have_policy_step_constraints = any(p.have_step_constraints for p in self.policies.values())
         self.have_policy_reset_constraints = any(p.have_reset_constraints for p in self.policies.values())
@@ -582,6 +593,7 @@ class PPO:
         best = {policy_id: -np.inf for policy_id in self.policies}
         iter_start = iter_stop = time.time()
         while gs["timesteps"] < ts_max:
+            self.freeze_scheduler()                               # ppo.py:2139
             pre_rollout_timesteps = gs["timesteps"]
             self.rollout()
             for policy_id in self.policies:                       # ppo.py:2144-2150
@@ -642,6 +654,7 @@ class PPO:
                 vn.save_info(info)
             with open(os.path.join(self.state_path, "state_0.pickle"), "wb") as fh:
                 pickle.dump(self.status_dict, fh, protocol=pickle.HIGHEST_PROTOCOL)
+            self.freeze_scheduler.save_info()                # ppo.py:2606
         if mpi_utils.distributed_path():
             torch.distributed.barrier()
 

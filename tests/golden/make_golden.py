@@ -12,7 +12,7 @@ Import recipe: a scratch directory on sys.path holding
 The scratch directory lives under /tmp and is removed afterwards.
 
 Importable with that recipe: utils.episode_info, utils.stats, utils.mpi_utils,
-networks.attention, networks.utils (fixtures g1-g6).  Everything routed through `gymnasium`
+networks.attention, networks.utils, utils.schedulers (fixtures g1-g7).  Everything routed through `gymnasium`
 (distributions, policies, ppo.py) is NOT importable here and is restated from
 text in oracle/ (pinned by torch primitives; see DESIGN.md "Oracle").
 
@@ -352,17 +352,86 @@ def gen_g6(nu, out):
     out["lin_w"], out["lin_b"] = lin.weight.detach().numpy(), lin.bias.detach().numpy()
 
 
+def scheduler_scenario():
+    """The status trajectory both the reference and the product schedulers are driven through (pure data)."""
+    rng = np.random.default_rng(77)
+    n = 40
+    timesteps = np.cumsum(rng.integers(500, 4000, n))
+    scores = np.round(np.cumsum(rng.normal(3.0, 10.0, n)), 3)
+    plateau = np.repeat(rng.integers(0, 5, n // 4), 4)           # a key that stays constant for stretches
+    return dict(iteration=np.arange(n), timesteps=timesteps, score=scores, plateau=plateau)
+
+
+def drive_schedulers(mod, sc):
+    """Every schedule of utils/schedulers.py over the scenario -> dict of output arrays (also used by the test)."""
+    n = len(sc["iteration"])
+    status = {"global status": {"iteration": 0, "timesteps": 0}, "p": {"score avg": 0.0, "plateau": 0}}
+    made = {
+        "linear_ts": mod.LinearScheduler("timesteps", status_max=60000, max_value=3e-4, min_value=1e-5),
+        "linear_it": mod.LinearScheduler("iteration", status_max=25, max_value=0.05, min_value=0.0),
+        "log_it": mod.LogScheduler("iteration", status_max=30, max_value=1.0, min_value=0.1),
+        "step_gt": mod.LinearStepScheduler(initial_value=1e-3, status_key="score avg", status_preface="p",
+                                           status_triggers=[10.0, 40.0, 90.0], step_values=[5e-4, 1e-4, 1e-5]),
+        "step_lt": mod.LinearStepScheduler(initial_value=0.0, status_key="score avg", status_preface="p",
+                                           status_triggers=[-5.0, -20.0], step_values=[1.0, 2.0], compare_fn=np.less),
+        "change": mod.ChangeInStateScheduler("plateau", status_preface="p"),
+        "change_persistent": mod.ChangeInStateScheduler("score avg", status_preface="p", compare_fn=np.greater,
+                                                        persistent=True),
+        "const": mod.CallableValue(0.25),
+    }
+    for s in made.values():
+        s.finalize(status)
+
+    class FakePolicy:
+        def __init__(self):
+            self.frozen, self.saved = False, []
+        def freeze(self): self.frozen = True
+        def unfreeze(self): self.frozen = False
+        def save(self, path, tag): self.saved.append(int(tag))
+
+    policies = {k: FakePolicy() for k in ("a", "b", "c", "d")}
+    cyc = mod.FreezeCyclingScheduler([["a", "b"], ["c"]], iterations=3, delay=4)
+    cyc.finalize("/nonexistent", status, policies)
+    out = {k: [] for k in made}
+    out["frozen"], out["active_idx"] = [], []
+    for i in range(n):
+        status["global status"]["iteration"] = int(sc["iteration"][i])
+        status["global status"]["timesteps"] = int(sc["timesteps"][i])
+        status["p"]["score avg"] = float(sc["score"][i])
+        status["p"]["plateau"] = int(sc["plateau"][i])
+        cyc()
+        for k, s in made.items():
+            out[k].append(float(s()))
+        out["frozen"].append([int(policies[k].frozen) for k in ("a", "b", "c", "d")])
+        out["active_idx"].append(cyc.active_idx)
+    res = {k: np.asarray(v) for k, v in out.items()}
+    res["groups"] = np.array([",".join(g) for g in cyc.policy_groups])
+    for k in ("a", "b", "c", "d"):
+        res[f"saved_{k}"] = np.asarray(policies[k].saved, dtype=np.int64)
+    return res
+
+
+def gen_g7(sched, out):
+    """G7: utils/schedulers.py -- every schedule and the freeze cycle over a 40-iteration status trajectory."""
+    sc = scheduler_scenario()
+    for k, v in sc.items():
+        out["in_" + k] = v
+    out.update(drive_schedulers(sched, sc))
+
+
 def main():
     only = set(sys.argv[1:])                      # e.g. `make_golden.py g6_network_utils`: just that fixture
     scratch, ei, st, at = _import_reference()
     from ppo_and_friends.networks import utils as nu
+    from ppo_and_friends.utils import schedulers as sched
     try:
         for name, fn, mod in (("g1_end_episode", gen_g1, ei),
                               ("g2_dataset", gen_g2, ei),
                               ("g3_shared", gen_g3, ei),
                               ("g4_running_stats", gen_g4, st),
                               ("g5_attention", gen_g5, at),
-                              ("g6_network_utils", gen_g6, nu)):
+                              ("g6_network_utils", gen_g6, nu),
+                              ("g7_schedulers", gen_g7, sched)):
             if only and name not in only:
                 continue
             out = {}

@@ -1229,3 +1229,42 @@ def test_graph_chunking_fuzz_equals_eager_launches():
         assert outs[0][1] == outs[1][1]
 
     run()
+
+
+def test_schedulers_and_freeze_cycling_in_the_training_loop(tmp_path):
+    """
+    utils/schedulers.py in PPO.learn (ppo.py:2139, 2254, 1406-1428): a LinearScheduler learning rate / entropy weight
+    follows the status dict (the lr through the device scalar, the entropy weight as a launch argument of the
+    re-captured chains), and a FreezeCyclingScheduler lets one of two policies train at a time -- a frozen
+    policy's weights and optimiser state do not move.
+    """
+    import os
+    from ppo_and_friends_amd.ppo import PPO
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    from ppo_and_friends_amd.utils.schedulers import LinearScheduler, FreezeCyclingScheduler
+    dev = torch.device("cuda", 0)
+    A, E, T, O, NA, B = 2, 8, 16, 5, 3, 32
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=21, num_agents=A)
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    total = 6 * E * T
+    sched = lambda hi, lo: LinearScheduler("timesteps", status_max=total, max_value=hi, min_value=lo)
+    settings = {"p0": (None, sp, sp, Discrete(NA), dict(lr=sched(1e-3, 1e-4), entropy_weight=sched(0.02, 0.0))),
+                "p1": (None, sp, sp, Discrete(NA), {})}
+    ppo = PPO(env_gen, settings, policy_mapping_fn=lambda a: "p0" if a == "agent0" else "p1", device=dev, random_seed=3,
+              normalize_obs=False, normalize_rewards=False, envs_per_proc=E, ts_per_rollout=T, batch_size=B,
+              epochs_per_iter=1, state_path=str(tmp_path), freeze_scheduler=FreezeCyclingScheduler([["p0"]], iterations=2))
+    snaps, lrs, ews, frozen = [], [], [], []
+    for it in range(6):
+        before = {k: p.policy_params.clone() for k, p in ppo.policies.items()}
+        ppo.learn(E * T)                                           # one iteration
+        frozen.append({k: p.frozen for k, p in ppo.policies.items()})
+        for k, p in ppo.policies.items():
+            moved = not torch.equal(before[k], p.policy_params)
+            assert moved == (not frozen[-1][k]), (it, k, frozen[-1])
+        lrs.append(float(ppo.policies["p0"].policy_lr.item())); ews.append(ppo.status_dict["p0"]["entropy weight"])
+    assert all(sum(f.values()) == 1 for f in frozen) and {f["p0"] for f in frozen} == {True, False}
+    assert lrs == sorted(lrs, reverse=True) and lrs[0] > lrs[-1] >= 1e-4 - 1e-9
+    assert ews == sorted(ews, reverse=True) and ews[-1] < ews[0]
+    assert os.path.exists(os.path.join(str(tmp_path), "FreezeCyclingScheduler.yaml"))
+    assert ppo.status_dict["p1"]["lr"] == 3e-4

@@ -226,3 +226,29 @@ def test_g6_sequential_network_structure_and_init(golden):
     np.testing.assert_array_equal(lin.bias.detach().numpy(), g["lin_b"])
     w = g["lin_w"]
     np.testing.assert_allclose(w @ w.T, 0.09 * np.eye(6), atol=1e-6)           # orthogonal rows, gain 0.3
+
+
+def test_g7_schedulers_match_the_reference(golden):
+    """
+    utils/schedulers.py of this package (host scalars of the update: lr, entropy / intrinsic weights, clip bounds,
+    and the policy freeze cycle) against the outputs recorded from the unmodified reference over the same
+    40-iteration status trajectory: bit-exact, incl. the clamped ends, the first-iteration rule of the step
+    schedule, persistent / per-call change detection, group completion and save tags of the freeze cycle.
+    """
+    import importlib.util
+    import os
+    import warnings
+    from ppo_and_friends_amd.utils import schedulers as mine
+    g = golden("g7_schedulers")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)                       # only its scenario / driver helpers (no reference import)
+    sc = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    for k, v in mk.scheduler_scenario().items():
+        np.testing.assert_array_equal(sc[k], v)       # the committed inputs are the generator's
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)   # log(0) at iteration 0, clamped -- as in the reference
+        got = mk.drive_schedulers(mine, sc)
+    for k, v in got.items():
+        np.testing.assert_array_equal(v, g[k], err_msg=k)
+    assert got["frozen"].any() and len(set(got["active_idx"])) == 3
