@@ -69,9 +69,12 @@ class _Episode:
     def end_episode(self, ending_value, ending_reward, rtg_accum="float64"):
         self.ending_value = ending_value
         self.length = len(self.rewards)
+        clip = self.clip
+        if clip == "dynamic":                      # ppo_policy.py:1104-1106: the episode's own reward range
+            clip = (min(self.rewards), max(self.rewards))
         self.advantages, self.rewards_to_go = eo.end_episode(
             self.rewards, self.values, ending_value, ending_reward, self.gamma, self.lambd,
-            self.clip, self.use_gae, rtg_accum)
+            clip, self.use_gae, rtg_accum)
         self.values = np.array(self.values).astype(np.float32)
 
 

@@ -61,7 +61,9 @@ void ppoaf_oracle_gae_rtg_tmajor(const float* rewards, const float* values,
             const int64_t i = (int64_t)t * E + e;
             const int k = end_kind[i];
             float vn;
-            if (k == 1) { vn = 0.f; a = 0.0; r = 0.0; }
+            /* terminal: end_episode(ending_value = 0, ending_reward = 0) -- the clip runs on that 0 as on any
+             * ending reward (episode_info.py:450-454): visible only for clip ranges that exclude zero */
+            if (k == 1) { vn = 0.f; a = 0.0; r = (double)clipf(0.f, has_clip, clip_lo, clip_hi); }
             else if (k == 2) { vn = boot_value[i]; a = 0.0; r = (double)clipf(boot_reward[i], has_clip, clip_lo, clip_hi); }
             else vn = (t + 1 < T) ? values[i + E] : 0.f;
             const double delta = (double)rewards[i] + (double)(gamma_f * vn) - (double)values[i];

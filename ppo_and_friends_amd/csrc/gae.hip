@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void gae_rtg_stream_kernel(
             for (int k = 0; k < VEC; ++k) {
                 const unsigned kind = (ek[i] >> (8 * k)) & 0xffu;
                 float vn = vnext[k];
-                if (kind == 1u) { vn = 0.f; A[k] = 0.0; R[k] = 0.0; }
+                // terminal: ending value 0, ending reward clip(0) -- the reference clips it like any other ending
+                // reward (episode_info.py:450-454), which matters only for clip ranges that exclude zero
+                if (kind == 1u) { vn = 0.f; A[k] = 0.0; R[k] = (double)clip_reward(0.f, p); }
                 else if (kind == 2u) {
                     const long b = dense ? idx + k : e0 + k;
                     vn = boot_value[b]; A[k] = 0.0;

@@ -138,8 +138,7 @@ class PPOPolicy:
         if vf_clip is not None:
             # the reference's vf_clip branch dereferences self.user_huber_loss (ppo.py:2432): unusable there too
             raise NotImplementedError("vf_clip raises AttributeError in the reference (ppo.py:2432); not reproduced")
-        if dynamic_bs_clip:
-            raise NotImplementedError("dynamic_bs_clip is outside this round's hot-path scope")
+        self.dynamic_bs_clip = bool(dynamic_bs_clip)
 
         self.action_dtype = get_space_dtype_str(self.action_space)
         if self.action_dtype not in ("discrete", "continuous"):
@@ -510,6 +509,10 @@ class PPOPolicy:
         """ppo_policy.py:1086-1112."""
         if not self.have_bootstrap_clip:
             return None
+        if self.dynamic_bs_clip:
+            # :1104-1106: (min, max) of the episode's own rewards.  The device buffer resolves it per episode
+            # segment in RolloutBuffer.compute_advantages; this marker selects that path.
+            return "dynamic"
         return (self.bootstrap_clip[0](), self.bootstrap_clip[1]())
 
     # ----------------------------------------------------------------- update

@@ -123,16 +123,54 @@ class RolloutBuffer:
         rtg_out = torch.empty_like(self.rewards_to_go) if adv_only else self.rewards_to_go
         T, cols = self.T, self.C * self.A
         v2 = lambda t: t.view(T, cols)
+        ek_kernel = None
+        if isinstance(bootstrap_clip, str):
+            # dynamic_bs_clip (ppo_policy.py:1104-1106): every ending reward is clipped to the (min, max) of its
+            # own episode's rewards -- a segment reduction over the buffer, applied to the stored ending rewards
+            # in place (idempotent, so recalculate_advantages may run it again)
+            assert bootstrap_clip == "dynamic", bootstrap_clip
+            ek_kernel = self._clip_boot_rewards_to_episode_range()
+            bootstrap_clip = None
         if self.fixed_length:
             K.gae_rtg_tmajor(v2(self.rewards), v2(self.values), self.boot_value[T - 1].reshape(-1),
                              self.boot_reward[T - 1].reshape(-1), None, gamma, lambd, bootstrap_clip,
                              use_gae, v2(self.advantages), v2(rtg_out), timing_events=timing_events)
         else:
-            ek = self.end_kind if self.A == 1 else \
-                self.end_kind.unsqueeze(-1).expand(T, self.C, self.A).contiguous().view(T, cols)
+            ek = ek_kernel if ek_kernel is not None else (self.end_kind if self.A == 1 else
+                                                          self.end_kind.unsqueeze(-1).expand(T, self.C, self.A).contiguous().view(T, cols))
             K.gae_rtg_tmajor(v2(self.rewards), v2(self.values), v2(self.boot_value), v2(self.boot_reward),
                              ek, gamma, lambd, bootstrap_clip, use_gae,
                              v2(self.advantages), v2(rtg_out), timing_events=timing_events)
+
+    def _clip_boot_rewards_to_episode_range(self):
+        T, cols = self.T, self.C * self.A
+        r = self.rewards.view(T, cols)
+        br = self.boot_reward.view(T, cols)
+        if self.fixed_length:                       # one episode per column, bootstrapped at the last row
+            br[T - 1].copy_(torch.minimum(torch.maximum(br[T - 1], r.amin(0)), r.amax(0)))
+            return None
+        ek = self.end_kind if self.A == 1 else \
+            self.end_kind.unsqueeze(-1).expand(T, self.C, self.A).contiguous().view(T, cols)
+        ends = (ek != 0).to(torch.int64)
+        seg = torch.cumsum(ends, 0) - ends                                  # episode index of every cell in its column
+        seg = (seg + torch.arange(cols, device=self.device, dtype=torch.int64)[None, :] * (T + 1)).reshape(-1)
+        n = cols * (T + 1)
+        lo = torch.full((n,), float("inf"), dtype=torch.float32, device=self.device)
+        hi = torch.full((n,), float("-inf"), dtype=torch.float32, device=self.device)
+        lo.scatter_reduce_(0, seg, r.reshape(-1), "amin", include_self=True)
+        hi.scatter_reduce_(0, seg, r.reshape(-1), "amax", include_self=True)
+        lo_c, hi_c = lo[seg].view(T, cols), hi[seg].view(T, cols)
+        clipped = torch.minimum(torch.maximum(br, lo_c), hi_c)
+        # The reference clips the ending reward of TERMINAL episodes too (episode_info.py:450-454 runs for every
+        # end): their 0.0 becomes the nearer bound whenever the episode's rewards do not straddle zero.  For the
+        # scan such an end is a bootstrapped one with ending value 0 and that clipped ending reward; end_kind
+        # itself (dataset order, statistics) stays as it is.
+        term = ek == 1
+        zero_clipped = torch.minimum(torch.maximum(torch.zeros_like(br), lo_c), hi_c)
+        br.copy_(torch.where(ek == 2, clipped, torch.where(term, zero_clipped, br)))
+        bv = self.boot_value.view(T, cols)
+        bv.copy_(torch.where(term, torch.zeros_like(bv), bv))
+        return torch.where(term, torch.full_like(ek, 2), ek).contiguous()
 
     def build_row_map(self):
         """

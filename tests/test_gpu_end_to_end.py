@@ -1268,3 +1268,35 @@ def test_schedulers_and_freeze_cycling_in_the_training_loop(tmp_path):
     assert ews == sorted(ews, reverse=True) and ews[-1] < ews[0]
     assert os.path.exists(os.path.join(str(tmp_path), "FreezeCyclingScheduler.yaml"))
     assert ppo.status_dict["p1"]["lr"] == 3e-4
+
+
+@pytest.mark.parametrize("term_prob,max_ts", [(0.0, 200), (0.08, 7), (0.3, 3)])
+def test_dynamic_bootstrap_clip_matches_cpu_port(term_prob, max_ts):
+    """
+    dynamic_bs_clip (ppo_policy.py:1086-1112; baselines/gymnasium/pendulum.py:33): the bootstrap reward of every
+    cut episode is clipped to the (min, max) of that episode's own rewards -- a per-segment reduction on the
+    device buffer -- against the CPU port's per-episode lists; recalculate_advantages keeps it.
+    """
+    E, T, B = 10, 24, 32
+    def biased(ppo):                                   # a critic that bootstraps far outside the reward range
+        with torch.no_grad():
+            list(ppo.policies["p"].critic.parameters())[-1].fill_(5.0)
+        return ppo
+    ppo = biased(_make(E, T, B, 1, term_prob, max_ts, policy_args=dict(dynamic_bs_clip=True)))
+    cpu = _oracle_like(ppo, B)
+    cpu.clip = "dynamic"
+    ds = ppo.rollout()
+    env, buf = ppo.env, ppo.policies["p"].buffer
+    t_tab = None if env.term_table is None else env.term_table.cpu().numpy()
+    ref = cpu.rollout(env.obs_table.cpu().numpy(), env.reward_table.cpu().numpy(), actions=buf.actions[..., 0].cpu().numpy(),
+                      term_table=t_tab, max_ts_per_ep=max_ts)
+    tol = dict(rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), ref.rewards_to_go.numpy(), **tol)
+    np.testing.assert_allclose(ds.advantages.cpu().numpy(), ref.advantages.numpy(), **tol)
+    # the clip was active somewhere (values ~ N(0,1)-scaled bootstraps vs rewards in [-1, 1])
+    plain = biased(_make(E, T, B, 1, term_prob, max_ts))
+    ds2 = plain.rollout()
+    assert not np.allclose(ds2.rewards_to_go.cpu().numpy(), ds.rewards_to_go.cpu().numpy())
+    before = ds.advantages.clone()
+    ds.recalculate_advantages()
+    torch.testing.assert_close(ds.advantages, before)

@@ -127,7 +127,7 @@ def test_gae_tmajor_fixed_length(K, T, E, use_gae):
 
 
 @pytest.mark.parametrize("T,E,p", [(12, 3, 0.15), (128, 70, 0.02), (64, 257, 0.3), (130, 9, 0.05)])
-@pytest.mark.parametrize("clip", [(-100.0, 100.0), (-0.5, 0.5), None])
+@pytest.mark.parametrize("clip", [(-100.0, 100.0), (-0.5, 0.5), None, (0.25, 2.0)])     # the last excludes 0: terminal ends clip too
 def test_gae_tmajor_with_episode_ends(K, T, E, p, clip):
     rng = np.random.default_rng(int(p * 100) + T)
     rew = rng.uniform(-1, 1, (T, E)).astype(np.float32)
@@ -176,6 +176,11 @@ def test_gae_tmajor_streaming_kernels(K, T, E, dense):
         ek = np.where(u < 0.1, 1, np.where(u < 0.2, 2, 0)).astype(np.int8)
         ek[-1] = np.where(ek[-1] == 0, 2, ek[-1])
         adv, rtg = K.gae_rtg_tmajor(dev(rew), dev(val), dev(bv), dev(br), dev(ek))
+        if T == 9:                       # once more with a clip range that excludes zero (terminal ends clip too)
+            a2, r2 = K.gae_rtg_tmajor(dev(rew), dev(val), dev(bv), dev(br), dev(ek), bootstrap_clip=(0.5, 3.0))
+            a2_ref, r2_ref = c_oracle.gae_rtg_tmajor(rew, val, bv, br, ek, clip=(0.5, 3.0))
+            np.testing.assert_allclose(a2.cpu().numpy(), a2_ref, rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(r2.cpu().numpy(), r2_ref, rtol=RTOL, atol=ATOL)
     else:
         boot = (rng.standard_normal(E) * 2).astype(np.float32)
         bv = np.zeros((T, E), dtype=np.float32); bv[-1] = boot
@@ -545,7 +550,7 @@ def test_gae_kernels_fuzz_against_the_oracle(K):
     from hypothesis import given, settings, strategies as st, HealthCheck
 
     params = st.sampled_from([(0.99, 0.95), (1.0, 1.0), (0.9, 0.0), (0.5, 0.99)])
-    clips = st.sampled_from([(-100.0, 100.0), (-0.25, 0.75), None])
+    clips = st.sampled_from([(-100.0, 100.0), (-0.25, 0.75), None, (0.1, 1.5)])
 
     @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(T=st.integers(1, 300), E=st.integers(1, 150), p_term=st.floats(0.0, 0.4), p_boot=st.floats(0.0, 0.4),
