@@ -464,6 +464,7 @@ class EpisodeInfo:
         self.critic_observations, self.observations, self.next_observations = [], [], []
         self.actions, self.raw_actions, self.log_probs = [], [], []
         self.rewards, self.values = [], []
+        self.actor_hidden, self.critic_hidden, self.actor_cell, self.critic_cell = [], [], [], []
         self.rewards_to_go = None
         self.advantages = None
         self.length = 0
@@ -471,9 +472,16 @@ class EpisodeInfo:
         self.has_hidden_states = False
 
     def add_info(self, observation, next_observation, raw_action, action, value, log_prob, reward,
-                 critic_observation=np.empty(0), **hidden):
-        if any(len(h) > 0 for h in hidden.values()):
-            raise NotImplementedError("LSTM hidden states are a 'next' row of SURVEY.md §8(f)")
+                 critic_observation=np.empty(0), actor_hidden=np.empty(0), actor_cell=np.empty(0),
+                 critic_hidden=np.empty(0), critic_cell=np.empty(0)):
+        given = [len(h) > 0 for h in (actor_hidden, actor_cell, critic_hidden, critic_cell)]
+        if any(given) and not all(given):          # episode_info.py:372-384
+            raise ValueError("if hidden state is provided for either the actor or the critic, both must be provided")
+        if given[0]:                               # :386-399: LSTM states of the step, staged as numpy like the rest
+            self.has_hidden_states = True
+            to_np = lambda h: h.detach().cpu().numpy() if torch.is_tensor(h) else np.asarray(h)
+            self.actor_hidden.append(to_np(actor_hidden)); self.critic_hidden.append(to_np(critic_hidden))
+            self.actor_cell.append(to_np(actor_cell)); self.critic_cell.append(to_np(critic_cell))
         self.observations.append(observation)
         self.next_observations.append(next_observation)
         self.actions.append(action)

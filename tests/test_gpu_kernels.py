@@ -595,3 +595,41 @@ def test_gae_kernels_fuzz_against_the_oracle(K):
 
     dense()
     ragged()
+
+
+def test_episode_info_drop_in_matches_golden_g1(K, golden):
+    """
+    utils/episode_info.py:EpisodeInfo -- the reference's per-trajectory class (episode_info.py:169-482: same
+    constructor, add_info / end_episode / compute_advantages), host-staged lists with the scans on the GPU -- driven
+    as policies/ppo_policy.py:638-651,684-691 drive it, against the reference's own recorded outputs (golden g1),
+    incl. staged LSTM states and the recalculation after a value update.
+    """
+    from ppo_and_friends_amd.utils.episode_info import EpisodeInfo
+    g = golden("g1_end_episode")
+    n = int(g["n_cases"][0])
+    checked = 0
+    for c in range(n):
+        p = g[f"c{c}_params"]
+        clip = None if np.isnan(p[3]) else (float(p[3]), float(p[4]))
+        rew, val = g[f"c{c}_rewards"], g[f"c{c}_values"]
+        ep = EpisodeInfo(starting_ts=3, use_gae=bool(p[2]), gamma=float(p[0]), lambd=float(p[1]), bootstrap_clip=clip)
+        L = len(rew)
+        for t in range(L):
+            h = torch.full((1, 4), float(t))
+            ep.add_info(observation=np.zeros(2), next_observation=np.ones(2), raw_action=np.zeros(1), action=np.zeros(1),
+                        value=float(val[t]), log_prob=-0.5, reward=float(rew[t]), critic_observation=np.zeros(2),
+                        actor_hidden=h, actor_cell=h + 1, critic_hidden=h + 2, critic_cell=h + 3)
+        ep.end_episode(ending_ts=3 + L, terminal=False, ending_value=float(p[5]), ending_reward=float(p[6]))
+        assert ep.is_finished and ep.length == L and ep.has_hidden_states and len(ep.critic_cell) == L
+        assert ep.values.dtype == np.float32
+        # float32 rewards on the device vs the reference's float64 lists: north_star tolerance
+        np.testing.assert_allclose(ep.rewards_to_go, g[f"c{c}_rtg_f64"], rtol=1e-5, atol=1e-5, err_msg=f"case {c}")
+        if bool(p[2]):
+            np.testing.assert_allclose(ep.advantages, g[f"c{c}_adv"], rtol=1e-5, atol=1e-5, err_msg=f"case {c}")
+        before = ep.advantages.copy()
+        ep.compute_advantages()                                    # recalculation keeps the clipped ending reward
+        np.testing.assert_array_equal(ep.advantages, before)
+        checked += 1
+    assert checked == n and n > 10
+    with pytest.raises(ValueError):
+        EpisodeInfo().add_info(np.zeros(1), np.zeros(1), 0, 0, 0.0, 0.0, 0.0, actor_hidden=torch.zeros(1, 2))
