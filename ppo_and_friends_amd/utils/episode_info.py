@@ -292,10 +292,59 @@ class PPODataset:
         self.buffer = buffer
         self.gae_args = (gamma, lambd, bootstrap_clip, use_gae)
 
+    def add_episode(self, episode):
+        """
+        episode_info.py:689-719: the reference's way of filling a dataset -- finished EpisodeInfo objects, one
+        at a time, concatenated in the order they are added.  For callers that drive single episodes; the
+        trainer itself writes whole env steps into an attached RolloutBuffer.
+        """
+        if self.buffer is not None and not getattr(self, "_from_episodes", False):
+            raise RuntimeError("this dataset is attached to a rollout buffer; episodes cannot be added to it")
+        if not episode.is_finished:
+            raise RuntimeError("attempting to add an unfinished episode to the dataset")
+        if episode.has_hidden_states:
+            raise NotImplementedError("episode-list datasets with LSTM states: use the rollout buffer path (PPOPolicy)")
+        self._from_episodes = True
+        self.__dict__.setdefault("episodes", []).append(episode)
+
+    def _buffer_from_episodes(self):
+        """One column holding the added episodes back to back; episode ends carry the stored (already clipped)
+        ending rewards, so the buffer's scan reproduces end_episode and serves recalculate_advantages."""
+        eps = self.episodes
+        N = sum(len(e.rewards) for e in eps)
+        if N == 0:
+            raise RuntimeError("attempting to build a dataset without transitions")
+        first = eps[0]
+        as2d = lambda rows: np.asarray(rows, dtype=np.float32).reshape(len(rows), -1)
+        obs_dim, cobs_dim = as2d(first.observations).shape[1], as2d(first.critic_observations).shape[1]
+        act = np.asarray(first.actions).reshape(len(first.actions), -1)
+        b = RolloutBuffer(N, 1, obs_dim, cobs_dim, act.shape[1], self.action_dtype, self.device, keep_next_observations=True)
+        t = 0
+        for e in eps:
+            L = len(e.rewards)
+            sl = slice(t, t + L)
+            put = lambda dst, rows, dt=torch.float32: dst[sl, 0].copy_(torch.as_tensor(np.asarray(rows), dtype=dt).reshape(dst[sl, 0].shape))
+            put(b.observations, as2d(e.observations)); put(b.next_observations, as2d(e.next_observations))
+            put(b.critic_observations, as2d(e.critic_observations))
+            put(b.actions, np.asarray(e.actions).reshape(L, -1), b.actions.dtype)
+            put(b.raw_actions, np.asarray(e.raw_actions).reshape(L, -1), b.raw_actions.dtype)
+            put(b.values, e.values); put(b.rewards, e.rewards)
+            put(b.log_probs, [float(x) for x in e.log_probs])
+            terminal = bool(getattr(e, "terminal", False))
+            b.end_kind[t + L - 1, 0] = END_TERMINAL if terminal else END_BOOTSTRAP
+            b.boot_value[t + L - 1, 0] = 0.0 if terminal else e.ending_value
+            b.boot_reward[t + L - 1, 0] = 0.0 if terminal else e._ending_reward
+            t += L
+        b.steps_written = N
+        b.fixed_length = False
+        self.attach(b, first.gamma, first.lambd, first.bootstrap_clip, first.use_gae)
+
     def build(self):
         """episode_info.py:745-914: scans + ordering; no list->tensor conversion is left to do."""
         if self.is_built:
             raise RuntimeError("attempting to build a dataset that has already been built")
+        if getattr(self, "_from_episodes", False):
+            self._buffer_from_episodes()
         b = self.buffer
         if b.steps_written != b.T:
             raise RuntimeError(f"rollout buffer holds {b.steps_written} of {b.T} steps")

@@ -633,3 +633,48 @@ def test_episode_info_drop_in_matches_golden_g1(K, golden):
     assert checked == n and n > 10
     with pytest.raises(ValueError):
         EpisodeInfo().add_info(np.zeros(1), np.zeros(1), 0, 0, 0.0, 0.0, 0.0, actor_hidden=torch.zeros(1, 2))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_dataset_from_episode_list_matches_golden_g2(K, golden, tag):
+    """
+    The reference's own way of filling a PPODataset (episode_info.py:689-719, 745-914): finished EpisodeInfo objects
+    added one by one in completion order, build(), 13-tuple items, values write-back + recalculate_advantages --
+    driven from the raw tables of golden g2 and compared with the tensors the unmodified reference built from them.
+    """
+    from ppo_and_friends_amd.utils.episode_info import EpisodeInfo, PPODataset
+    g = golden("g2_dataset")
+    pre = tag + "_"
+    rew, val, boot, ek = g[pre + "in_rewards"], g[pre + "in_values"], g[pre + "in_boot_v"], g[pre + "in_end_kind"]
+    obs, logp, act = g[pre + "in_obs"], g[pre + "in_logp"], g[pre + "in_actions"]
+    ds = PPODataset(device="cuda", action_dtype="discrete")
+    for (e, t0, t1, kind) in eo.segments_from_end_kind(ek):
+        ep = EpisodeInfo(starting_ts=t0, use_gae=True, gamma=0.99, lambd=0.95, bootstrap_clip=(-100.0, 100.0))
+        for t in range(t0, t1 + 1):
+            ep.add_info(observation=obs[t, e], next_observation=obs[t + 1, e], raw_action=act[t, e], action=act[t, e],
+                        value=float(val[t, e]), log_prob=float(logp[t, e]), reward=float(rew[t, e]),
+                        critic_observation=obs[t, e])
+        ev = 0.0 if kind == 1 else float(boot[t1, e])
+        ep.end_episode(ending_ts=t1 + 1, terminal=kind == 1, ending_value=ev, ending_reward=ev)
+        ds.add_episode(ep)
+    ds.build()
+    assert len(ds) == int(g[pre + "len"][0])
+    np.testing.assert_array_equal(ds.ep_lens.cpu().numpy(), g[pre + "ep_lens"])
+    np.testing.assert_array_equal(ds.observations.cpu().numpy(), g[pre + "obs"])
+    np.testing.assert_array_equal(ds.next_observations.cpu().numpy(), g[pre + "next_obs"])
+    np.testing.assert_array_equal(ds.actions.cpu().numpy(), g[pre + "actions"])
+    np.testing.assert_allclose(ds.log_probs.cpu().numpy(), g[pre + "logp"], rtol=1e-6)
+    np.testing.assert_array_equal(ds.values[torch.arange(len(ds))].cpu().numpy(), g[pre + "values"])
+    tol = dict(rtol=1e-5, atol=1e-5)                     # float32 rewards on the device, float64 lists in the reference
+    np.testing.assert_allclose(ds.advantages.cpu().numpy(), g[pre + "adv"], **tol)
+    np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), g[pre + "rtg"], **tol)
+    idx = int(g[pre + "item_idx"][0])
+    item = ds[idx]
+    assert len(item) == 13 and item[12] == idx
+    np.testing.assert_array_equal(item[1].cpu().numpy(), g[pre + "item_obs"])
+    np.testing.assert_allclose(float(item[5]), g[pre + "item_adv"][0], **tol)
+    ds.values[torch.arange(len(ds), device="cuda")] = dev(g[pre + "new_values"])
+    ds.recalculate_advantages()
+    np.testing.assert_allclose(ds.advantages.cpu().numpy(), g[pre + "adv_recalc"], **tol)
+    with pytest.raises(RuntimeError):
+        ds.build()
