@@ -567,3 +567,100 @@ class EpisodeInfo:
         self.rewards_to_go = rtg.cpu().numpy()
         self.advantages = adv.cpu().numpy()
         self.values = np.array(self.values).astype(np.float32)
+
+
+class AgentSharedEpisode:
+    """
+    The per-env container of an agent group's episodes (episode_info.py:485-644): one finished EpisodeInfo per
+    agent of the team, all of the same length, merged into rows of [A, .] in the order of `agent_ids`.
+    """
+
+    def __init__(self, agent_ids):
+        self.agent_ids = np.asarray(agent_ids)
+        self.agent_limit = len(self.agent_ids)
+        self.agent_episodes = [None] * self.agent_limit
+        self.added_agents = []
+        self.agent_count = 0
+        self.is_finished = False
+        self.length = 0
+
+    def verify_agent(self, agent_id):
+        if agent_id not in self.agent_ids:
+            raise KeyError(f"{agent_id} not in list of accepted agents {list(self.agent_ids)}")
+
+    def verify_episode(self, episode):
+        if not episode.is_finished:
+            raise RuntimeError("attempting to add an unfinished episode to an AgentSharedEpisode")
+
+    def add_episode(self, agent_id, episode):
+        if self.is_finished:
+            raise RuntimeError("AgentSharedEpisode is finished: cannot add more episodes")
+        self.verify_agent(agent_id)
+        self.verify_episode(episode)
+        self.agent_episodes[int(np.where(self.agent_ids == agent_id)[0][0])] = episode
+        self.added_agents.append(agent_id)
+        self.agent_count += 1
+        if self.agent_count == self.agent_limit:
+            lens = {len(e.rewards) for e in self.agent_episodes}
+            if len(lens) != 1 or 0 in lens:
+                raise RuntimeError(f"mismatched or empty episodes in AgentSharedEpisode: lengths {sorted(lens)}")
+            self.length = lens.pop()
+            self.is_finished = True
+
+
+class PPOSharedEpisodeDataset(PPODataset):
+    """
+    PPODataset whose rows hold the A agents of a team side by side (episode_info.py:990-1084), filled the
+    reference's way: every agent's finished episode of env `env_idx` is handed over separately; when all agents
+    of that env have delivered, the shared episode joins the dataset (completion order).
+    """
+
+    def __init__(self, num_envs, agent_ids, *args, **kw_args):
+        super().__init__(*args, **kw_args)
+        self.num_envs, self.agent_ids, self.shared = int(num_envs), np.asarray(agent_ids), True
+        self.episode_queue = [AgentSharedEpisode(self.agent_ids) for _ in range(self.num_envs)]
+        self.episodes = []
+        self._from_episodes = True
+
+    def add_shared_episode(self, episode, agent_id, env_idx):
+        q = self.episode_queue[env_idx]
+        q.add_episode(agent_id, episode)
+        if q.is_finished:
+            self.episodes.append(q)
+            self.episode_queue[env_idx] = AgentSharedEpisode(self.agent_ids)
+
+    def add_episode(self, episode):
+        raise RuntimeError("a shared-episode dataset is filled with add_shared_episode(episode, agent_id, env_idx)")
+
+    def _buffer_from_episodes(self):
+        """One column of [A, .] rows holding the shared episodes back to back (see PPODataset._buffer_from_episodes)."""
+        A = len(self.agent_ids)
+        N = sum(s.length for s in self.episodes)
+        if N == 0:
+            raise RuntimeError("attempting to build a dataset without transitions")
+        first = self.episodes[0].agent_episodes[0]
+        as2d = lambda rows: np.asarray(rows, dtype=np.float32).reshape(len(rows), -1)
+        act_dim = np.asarray(first.actions).reshape(len(first.actions), -1).shape[1]
+        b = RolloutBuffer(N, 1, as2d(first.observations).shape[1], as2d(first.critic_observations).shape[1], act_dim,
+                          self.action_dtype, self.device, keep_next_observations=True, agents_per_row=A)
+        t = 0
+        for s in self.episodes:
+            L = s.length
+            sl = slice(t, t + L)
+            terminal = bool(getattr(s.agent_episodes[0], "terminal", False))
+            for a, e in enumerate(s.agent_episodes):
+                put = lambda dst, rows, dt=torch.float32: dst[sl, 0, a].copy_(
+                    torch.as_tensor(np.asarray(rows), dtype=dt).reshape(dst[sl, 0, a].shape))
+                put(b.observations, as2d(e.observations)); put(b.next_observations, as2d(e.next_observations))
+                put(b.critic_observations, as2d(e.critic_observations))
+                put(b.actions, np.asarray(e.actions).reshape(L, -1), b.actions.dtype)
+                put(b.raw_actions, np.asarray(e.raw_actions).reshape(L, -1), b.raw_actions.dtype)
+                put(b.values, e.values); put(b.rewards, e.rewards)
+                put(b.log_probs, [float(x) for x in e.log_probs])
+                b.boot_value[t + L - 1, 0, a] = 0.0 if terminal else e.ending_value
+                b.boot_reward[t + L - 1, 0, a] = 0.0 if terminal else e._ending_reward
+            b.end_kind[t + L - 1, 0] = END_TERMINAL if terminal else END_BOOTSTRAP
+            t += L
+        b.steps_written = N
+        b.fixed_length = False
+        self.attach(b, first.gamma, first.lambd, first.bootstrap_clip, first.use_gae)

@@ -678,3 +678,37 @@ def test_dataset_from_episode_list_matches_golden_g2(K, golden, tag):
     np.testing.assert_allclose(ds.advantages.cpu().numpy(), g[pre + "adv_recalc"], **tol)
     with pytest.raises(RuntimeError):
         ds.build()
+
+
+def test_shared_episode_dataset_matches_golden_g3(K, golden):
+    """
+    AgentSharedEpisode / PPOSharedEpisodeDataset (episode_info.py:485-644, 990-1084) filled the reference's way --
+    every agent's finished EpisodeInfo handed over with its env index -- against the tensors the unmodified
+    reference built (golden g3): rows of [A, .], env-major, agents in `agent_ids` order.
+    """
+    from ppo_and_friends_amd.utils.episode_info import EpisodeInfo, PPOSharedEpisodeDataset
+    g = golden("g3_shared")
+    obs, rew, val = g["in_obs"], g["in_rewards"], g["in_values"]
+    boot, logp, act = g["in_boot"], g["in_logp"], g["in_actions"]
+    T, E, A = rew.shape
+    agent_ids = np.array(["a0", "a1", "a2"])
+    ds = PPOSharedEpisodeDataset(E, agent_ids, device="cuda", action_dtype="discrete")
+    for e in range(E):
+        for a in (2, 0, 1):                                   # delivery order within an env does not matter
+            ep = EpisodeInfo(starting_ts=0, use_gae=True, gamma=0.99, lambd=0.95, bootstrap_clip=(-100.0, 100.0))
+            for t in range(T):
+                ep.add_info(observation=obs[t, e, a], next_observation=obs[t + 1, e, a], raw_action=act[t, e, a],
+                            action=act[t, e, a], value=float(val[t, e, a]), log_prob=float(logp[t, e, a]),
+                            reward=float(rew[t, e, a]), critic_observation=obs[t, e, a])
+            ep.end_episode(ending_ts=T, terminal=False, ending_value=float(boot[e, a]), ending_reward=float(boot[e, a]))
+            ds.add_shared_episode(ep, agent_ids[a], e)
+    ds.build()
+    assert len(ds) == int(g["len"][0]) == E * T
+    np.testing.assert_array_equal(ds.observations.cpu().numpy(), g["obs"])
+    np.testing.assert_array_equal(ds.actions.cpu().numpy(), g["actions"])
+    np.testing.assert_array_equal(ds.values[torch.arange(E * T)].cpu().numpy(), g["values"])
+    np.testing.assert_allclose(ds.log_probs.cpu().numpy(), g["logp"], rtol=1e-6)
+    np.testing.assert_allclose(ds.advantages.cpu().numpy(), g["adv"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), g["rtg"], rtol=1e-5, atol=1e-5)
+    item = ds[5]
+    assert len(item) == 13 and item[1].shape == (A, obs.shape[-1]) and item[12] == 5
