@@ -57,6 +57,9 @@ __device__ __forceinline__ void xchg_publish(const XchgDev& x, long long seq, un
 __device__ __forceinline__ void xchg_wait(const XchgDev& x, long long seq, unsigned g, long long wait_ticks) {
     const int p = (int)threadIdx.x - 64;
     if (p >= 0 && p < x.n_ranks && p != x.rank) {
+        // once a wait has expired the exchange is broken for good (the host falls back at the end of the epoch):
+        // later launches must not each spend the budget again
+        if (__hip_atomic_load(&x.words[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) wait_ticks = 0;
         const long long t0 = (long long)wall_clock64();
         while (__hip_atomic_load(&x.my_flags[g * kMaxPeers + p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
             __builtin_amdgcn_s_sleep(1);

@@ -76,6 +76,27 @@ def _describe(net, bucket, with_log_std):
     return d, ""
 
 
+def _reduce_totals(upd, totals):
+    """
+    End of an epoch: the loss totals summed over ranks -- and, in the same all-reduce, whether any rank's peer
+    exchange ran out of time during the epoch.  If one did, the gradients of that step were garbage on that rank:
+    every rank then restores rank 0's state and continues on the RCCL path (PPO._heal_replicas), instead of
+    training on with diverged replicas or stopping the job.
+    """
+    t = totals.clone()
+    if not upd.multi:
+        return t.cpu().numpy()
+    broken = 0.0
+    if upd.xchg is not None:
+        broken = float(upd.xchg.status()[1] != 0)
+    t = torch.cat([t, torch.tensor([broken], dtype=t.dtype, device=t.device)])
+    mpi_utils.allreduce_sum_(t)
+    out = t.cpu().numpy()
+    if out[-1] > 0:
+        upd.ppo._heal_replicas("a peer exchange wait ran out of time")
+    return out[:-1]
+
+
 class FusedPolicyUpdate:
 
     graph_chunk = 32
@@ -369,13 +390,7 @@ class FusedPolicyUpdate:
             if self.tail == 1:
                 # ppo.py:2299-2306: a size-1 batch still updates the normaliser, then is skipped (quirk Q9)
                 rs.integrate_records(self.records[self.n_full].contiguous())
-        t = self.totals.clone()
-        if self.multi:
-            mpi_utils.allreduce_sum_(t)
-        out = t.cpu().numpy()
-        if self.xchg is not None:
-            self.xchg.check()                # a wait that ran out of time invalidates the epoch: raise, never continue
-        return out
+        return _reduce_totals(self, self.totals)
 
 
 # ======================================================================================
@@ -566,13 +581,7 @@ class FusedIcmUpdate:
 
     def end_epoch(self):
         """-> numpy [sum of icm_loss over mini-batches, mini-batch count] (summed over ranks)."""
-        t = self.totals.clone()
-        if self.multi:
-            mpi_utils.allreduce_sum_(t)
-        out = t.cpu().numpy()
-        if self.xchg is not None:
-            self.xchg.check()
-        return out
+        return _reduce_totals(self, self.totals)
 
 
 # ======================================================================================

@@ -789,21 +789,26 @@ class PPO:
         active = [f for f in getattr(self, "_fused", {}).values() if f is not None and getattr(f, "xchg", None) is not None]
         if not active or mpi_utils.get_num_procs() == 1:
             return True
-        state = self._replicated_state()
-        if mpi_utils.replicas_agree(state):
+        if mpi_utils.replicas_agree(self._replicated_state()):
             return True
-        print(f"[ppo_and_friends_amd] rank {mpi_utils.get_rank()}: replicas diverged under the peer gradient exchange; "
+        self._heal_replicas("replicas diverged")
+        return False
+
+    def _heal_replicas(self, why):
+        """Collective (every rank reaches it through the same all-reduced verdict): rank 0's parameter and optimiser
+        buckets everywhere, peer exchanges closed, RCCL all-reduce path from here on."""
+        active = [f for f in getattr(self, "_fused", {}).values() if f is not None and getattr(f, "xchg", None) is not None]
+        print(f"[ppo_and_friends_amd] rank {mpi_utils.get_rank()}: {why} under the peer gradient exchange; "
               "restoring rank 0's weights and optimiser state and switching to the RCCL all-reduce path",
               file=sys.stderr, flush=True)
-        for t in state:
+        for t in self._replicated_state():
             mpi_utils.broadcast_flat(t)
         for f in active:
             f.xchg.close()
-            f.xchg, f.xchg_reason = None, "disabled: replicas diverged"
+            f.xchg, f.xchg_reason = None, f"disabled: {why}"
             f._graphs.clear()
             f._args = {}
         self.status_dict["global status"]["peer exchange disabled"] = True
-        return False
 
     def _ppo_icm_epoch_overlapped(self, loader, policy_id):
         """

@@ -131,6 +131,11 @@ def _rank(rank, world, port, out, memory):
         x.allreduce(junk, junk, wait_seconds=0.25)
         torch.cuda.synchronize()
         res["missing_peer_reported"] = x.status()[1] != 0
+        import time
+        t0 = time.time()                                      # a broken exchange does not spend the budget again
+        x.allreduce(junk, junk, wait_seconds=30.0)
+        torch.cuda.synchronize()
+        res["later_waits_fail_fast"] = (time.time() - t0) < 5.0
         try:
             x.check()
             res["check_raises"] = False
@@ -184,7 +189,7 @@ def test_graph_replay(run3):
 
 def test_missing_peer_is_bounded_and_reported(run3):
     for r in run3[:-1]:
-        assert r["missing_peer_reported"] and r["check_raises"]
+        assert r["missing_peer_reported"] and r["check_raises"] and r["later_waits_fail_fast"]
 
 
 def test_single_rank_exchange_is_the_identity():
