@@ -84,6 +84,8 @@ def parse():
 
 def main():
     args = parse()
+    # dmabuf IPC (the K17 peer mappings, RCCL's own P2P): must be in the environment before HIP initialises
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -57,6 +57,7 @@ def init_process_group_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or rehearsing()) and not is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL / K17 (no effect once HIP is up)
         if backend is None:
             backend = os.environ.get("PPOAF_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
