@@ -195,6 +195,36 @@ def main():
     if exchange is not None and fused:                       # why that path (self-test verdict / fallback reason)
         exchange += f" [{getattr(fused[0], 'xchg_reason', '')}]"
 
+    # N > 1 only, after the timed region: what one gradient exchange of this bucket costs on this node, with the
+    # K17 kernel and with the process group's all-reduce (back-to-back launches, stream events) -- recorded so that
+    # a multi-GPU run documents the latency its scaling number rests on
+    probe = None
+    if mpi_utils.distributed_path() and fused:
+        n_f = pol.policy_grads.numel()
+        buf = torch.zeros(n_f, dtype=torch.float32, device=device)
+        reps = 200
+
+        def timed(fn):
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps
+        probe = {"bucket_floats": n_f, "launches": reps}
+        x = getattr(fused[0], "xchg", None)
+        if x is not None:
+            for _ in range(5):
+                x.allreduce(buf, buf)
+            probe["k17_exchange_us"] = round(timed(lambda: x.allreduce(buf, buf)), 2)
+            x.check()
+        if not mpi_utils._needs_staging(buf):                 # device collectives (RCCL); gloo rehearsals skip it
+            for _ in range(5):
+                dist.all_reduce(buf)
+            probe["process_group_allreduce_us"] = round(timed(lambda: dist.all_reduce(buf)), 2)
+
     out = {"metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
@@ -208,7 +238,7 @@ def main():
                       "global_env_steps_per_iteration": world * E * T,
                       "parallelism": f"dp{world}", "hip_graphs": (not args.no_graphs) and (not mpi_utils.distributed_path() or peer),
                       "multi_rank_path": mpi_utils.distributed_path(),
-                      "gradient_exchange": exchange,
+                      "gradient_exchange": exchange, "exchange_probe": probe,
                       "rollout_s": round(ppo.status_dict["global status"]["rollout time"], 4),
                       "train_s": round(ppo.status_dict["global status"]["train time"], 4)},
            "roofline": roofline}

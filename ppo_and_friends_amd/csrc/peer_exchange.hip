@@ -1,7 +1,7 @@
 // K17: per-mini-batch gradient exchange between the ranks of one node over peer mappings (xGMI).
 //
 // Replaces, inside the update loop, the Allreduce of mpi_avg_gradients (utils/mpi_utils.py:65-86 of the
-// reference, called from ppo.py:2443-2448 once per mini-batch): the bucket is ~136 KB, so the exchange is
+// reference, called from ppo.py:2443-2448 once per mini-batch): the bucket is ~271 KB at C2, so the exchange is
 // pure latency.  One launch per exchange, no library call and no host round trip -- the launch has fixed
 // arguments and can be captured in a hipGraph together with the update kernels:
 //

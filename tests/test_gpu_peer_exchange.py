@@ -17,7 +17,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-N_FLOATS = 34_820            # the C2 bucket is 34 563 parameters; any multiple of 4
+N_FLOATS = 34_820            # about one network of the C2 bucket (67 720 floats in all); any multiple of 4
 WORLD = 3
 
 
