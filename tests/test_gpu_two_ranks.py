@@ -137,7 +137,16 @@ def _rank_kind(rank, world, port, out, mode, kind):
     from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
     from ppo_and_friends_amd.spaces import Box, Discrete
     dev = torch.device("cuda", 0)
-    if kind in ("icm", "guard"):
+    if kind == "wide":
+        # C4 shape: 3 agents share the policy, 128-wide actor, 256-wide critic on the concatenated observations
+        # (bucket of ~180k floats: 176 exchange groups)
+        E_, T_, O_, NA_, B_, A_ = 8, 32, 18, 5, 32, 3
+        env_gen = lambda: SyntheticFixedLengthEnv(E_, O_, Discrete(NA_), T_, dev, reward="uniform", seed=79, rank=rank,
+                                                  num_agents=A_, critic_view="policy")
+        sp, csp = Box(-np.inf, np.inf, (O_,), np.float32), Box(-np.inf, np.inf, (A_ * O_,), np.float32)
+        settings = {"p": (None, sp, csp, Discrete(NA_), dict(actor_kw_args=dict(hidden_size=128),
+                                                             critic_kw_args=dict(hidden_size=256)))}
+    elif kind in ("icm", "guard"):
         E_, T_, O_, NA_, B_ = 16, 64, 6, 3, 16                 # 64 mini-batches per epoch: two graph chunks
         env_gen = lambda: SyntheticFixedLengthEnv(E_, O_, Discrete(NA_), T_, dev, reward="uniform", seed=77, rank=rank)
         sp = Box(-np.inf, np.inf, (O_,), np.float32)
@@ -169,6 +178,8 @@ def _rank_kind(rank, world, port, out, mode, kind):
         ppo.rollout()
         ppo.train_on_rollout()                                       # continues on the all-reduce path
         res["w"] = pol.policy_params.detach().cpu().clone()
+    elif kind == "wide":
+        res["w"] = pol.policy_params.detach().cpu().clone()
     elif kind == "icm":
         res["w"] = pol.policy_params.detach().cpu().clone()
         res["w_icm"] = pol.icm_model.flat_params.detach().cpu().clone()
@@ -179,7 +190,7 @@ def _rank_kind(rank, world, port, out, mode, kind):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["icm", "mat"])
+@pytest.mark.parametrize("kind", ["icm", "mat", "wide"])
 def test_peer_exchange_equals_allreduce_path(kind):
     runs = {}
     for mode in ("peer", "rccl"):
