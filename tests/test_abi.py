@@ -67,3 +67,33 @@ def test_missing_library_fails_loudly(built_lib, monkeypatch):
     monkeypatch.setattr(built_lib, "LIB_PATH", "/nonexistent/libppoaf_hip.so")
     with pytest.raises(built_lib.PpoafError):
         built_lib.load()
+
+
+def test_every_entry_point_sits_under_a_reference_citation():
+    """
+    include/ppoaf_hip.h is the drop-in boundary: every compute entry point is declared under a block comment that
+    names the reference interface it replaces, as file:line (a `.py:` path with line numbers).  Helpers that have
+    no reference counterpart (version / error string / events / diagnostics) are listed explicitly.
+    """
+    src = open(HEADER).read()
+    no_counterpart = {"ppoaf_abi_version", "ppoaf_last_error", "ppoaf_device_cu_count", "ppoaf_event_create",
+                      "ppoaf_event_destroy", "ppoaf_event_elapsed_ms"}
+    cite = re.compile(r"[\w/]+\.py:\d+")
+    last_cited_comment = -1
+    pos = 0
+    missing = []
+    for m in re.finditer(r"/\*.*?\*/|\b(?:int|const char\*|void\*)\s+(ppoaf_\w+)\s*\(", src, flags=re.S):
+        if m.group(1) is None:                                   # a comment
+            if cite.search(m.group(0)):
+                last_cited_comment = m.start()
+            continue
+        name = m.group(1)
+        if name in no_counterpart:
+            continue
+        if last_cited_comment < 0:
+            missing.append(name)
+    assert not missing, missing
+    # and the sections are specific: a few spot checks of the citation each section carries
+    for needle in ("episode_info.py:223-293", "ppo.py:2325-2333", "mpi_utils.py:65-86", "filter_wrappers.py:155-268",
+                   "mat_policy.py:441-519"):
+        assert needle in src, needle
