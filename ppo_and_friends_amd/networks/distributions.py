@@ -119,11 +119,90 @@ class GaussianDistribution(nn.Module):
         return s
 
 
+class MultiCategoricalDistribution:
+    """
+    networks/distributions.py:272-438 for MultiDiscrete action spaces: one categorical per action dimension over
+    its slice of the actor output (the per-slice softmax of the output function, :1046-1056, is fused in as for
+    the single categorical); log-probs and entropies are summed over the dimensions.  Each slice runs the K6
+    categorical kernels.
+    """
+
+    def __init__(self, nvec, seed=0, **kw_args):
+        self.nvec = [int(n) for n in nvec]
+        self.rng = _PhiloxStream(seed)
+
+    def _slices(self, logits):
+        start = 0
+        for n in self.nvec:
+            yield logits[:, start:start + n].contiguous()
+            start += n
+
+    def get_distribution(self, logits):
+        return logits
+
+    def sample_distribution(self, logits):
+        acts, lps = [], []
+        for sl in self._slices(logits):
+            seed, off = self.rng.take(sl.shape[0])
+            a, lp = K.categorical_sample(sl, seed, off)
+            acts.append(a); lps.append(lp)
+        a = torch.stack(acts, dim=1)
+        return a, a, torch.stack(lps, dim=-1).sum(dim=-1, keepdim=True)
+
+    def get_log_probs_and_entropy(self, logits, actions):
+        actions = actions.reshape(logits.shape[0], -1)
+        lps, ents = [], []
+        for d, sl in enumerate(self._slices(logits)):
+            lp, ent = _CategoricalEval.apply(sl, actions[:, d].contiguous())
+            lps.append(lp); ents.append(ent)
+        return torch.stack(lps, dim=-1).sum(dim=-1, keepdim=True), torch.stack(ents, dim=-1).sum(dim=-1)
+
+    def refine_prediction(self, logits):
+        return torch.stack([torch.argmax(sl, dim=-1) for sl in self._slices(logits)], dim=-1)
+
+
+class BernoulliDistribution:
+    """
+    networks/distributions.py:134-196 for MultiBinary action spaces: independent Bernoulli(sigmoid(logit)) per
+    bit (the sigmoid is the actor's output function), log-probs summed over the bits, entropy likewise
+    (torch.distributions.Bernoulli semantics incl. its probability clamp), elementwise torch-ROCm ops.
+    """
+
+    def __init__(self, seed=0, **kw_args):
+        self.rng = _PhiloxStream(seed)
+
+    def get_distribution(self, logits):
+        return logits
+
+    @staticmethod
+    def _dist(logits):
+        # validate_args=False: the argument check synchronises with the host, which a hipGraph capture forbids
+        return torch.distributions.Bernoulli(probs=torch.sigmoid(logits), validate_args=False)
+
+    def sample_distribution(self, logits):
+        seed, off = self.rng.take(logits.numel())
+        g = torch.Generator(device=logits.device).manual_seed((int(seed) * 1000003 + int(off)) % (1 << 62))
+        a = (torch.rand(logits.shape, device=logits.device, generator=g) < torch.sigmoid(logits)).float()
+        lp = self._dist(logits).log_prob(a).sum(dim=-1, keepdim=True)
+        return a, a, lp
+
+    def get_log_probs_and_entropy(self, logits, actions):
+        d = self._dist(logits)
+        return d.log_prob(actions.reshape(logits.shape).float()).sum(dim=-1, keepdim=True), d.entropy().sum(dim=-1)
+
+    def refine_prediction(self, logits):
+        return (torch.sigmoid(logits) >= 0.5).float()
+
+
 def get_actor_distribution(action_space, seed=0, **kw_args):
-    """networks/distributions.py:984-1115 for Discrete and Box action spaces."""
+    """networks/distributions.py:984-1115 for Discrete, MultiDiscrete, MultiBinary and Box action spaces."""
     dtype = get_space_dtype_str(action_space)
     if dtype == "discrete":
         return CategoricalDistribution(seed=seed)
+    if dtype == "multi-discrete":
+        return MultiCategoricalDistribution(action_space.nvec, seed=seed)
+    if dtype == "multi-binary":
+        return BernoulliDistribution(seed=seed)
     if dtype == "continuous":
         return GaussianDistribution(int(np.prod(action_space.shape)),
                                     distribution_min=action_space.low,

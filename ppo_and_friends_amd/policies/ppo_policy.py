@@ -141,7 +141,7 @@ class PPOPolicy:
         self.dynamic_bs_clip = bool(dynamic_bs_clip)
 
         self.action_dtype = get_space_dtype_str(self.action_space)
-        if self.action_dtype not in ("discrete", "continuous"):
+        if self.action_dtype not in ("discrete", "continuous", "multi-discrete", "multi-binary"):
             raise NotImplementedError(f"{name}: action dtype {self.action_dtype} is outside the hot-path scope")
         self.have_bootstrap_clip = bootstrap_clip is not None
         self.bootstrap_clip = (None if bootstrap_clip is None
@@ -403,7 +403,7 @@ class PPOPolicy:
             raise ValueError(f"get_intrinsic_reward expects a batch of observations, got shape {obs.shape}")
         obs_1 = self._to_device(prev_obs)
         obs_2 = self._to_device(obs)
-        adt = torch.int64 if self.action_dtype == "discrete" else torch.float32
+        adt = torch.int64 if self.action_dtype in ("discrete", "multi-discrete") else torch.float32
         act = self._to_device(action, adt)
         if act.dim() != 2:
             act = act.unsqueeze(1)

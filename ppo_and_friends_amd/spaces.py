@@ -46,8 +46,24 @@ class MultiDiscrete:
         return [seed]
 
 
+class MultiBinary:
+    """gymnasium.spaces.MultiBinary attributes used on this path: n, shape, dtype (int8, as gymnasium's)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+        self.shape = (self.n,)
+        self.dtype = np.dtype(np.int8)
+
+    def seed(self, seed=None):
+        return [seed]
+
+
 def is_multi_discrete(space):
     return hasattr(space, "nvec")
+
+
+def is_multi_binary(space):
+    return type(space).__name__ == "MultiBinary"
 
 
 def get_agent_shared_space(space, num_agents):
@@ -68,13 +84,16 @@ def get_agent_shared_space(space, num_agents):
 
 
 def is_discrete(space):
-    return hasattr(space, "n") and not hasattr(space, "nvec") and np.issubdtype(space.dtype, np.integer)
+    return hasattr(space, "n") and not hasattr(space, "nvec") and np.issubdtype(space.dtype, np.integer) \
+        and not is_multi_binary(space)
 
 
 def get_space_dtype_str(space):
     """utils/misc.py:17-46 for the space kinds on this path."""
     if is_multi_discrete(space):
         return "multi-discrete"
+    if is_multi_binary(space):
+        return "multi-binary"
     if is_discrete(space):
         return "discrete"
     if np.issubdtype(space.dtype, np.floating):
@@ -95,4 +114,4 @@ def get_action_prediction_shape(space):
     """utils/misc.py:295-346: Discrete -> (n,), MultiDiscrete -> (sum(nvec),), Box -> its shape."""
     if is_multi_discrete(space):
         return (int(np.sum(space.nvec)),)
-    return (space.n,) if is_discrete(space) else tuple(space.shape)
+    return (space.n,) if (is_discrete(space) or is_multi_binary(space)) else tuple(space.shape)

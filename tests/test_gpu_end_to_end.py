@@ -1362,3 +1362,43 @@ def test_policy_surface_add_episode_info_and_end_episodes(A):
     np.testing.assert_array_equal(n(got.ep_lens), n(want.ep_lens))
     for f in ("observations", "actions", "log_probs", "rewards_to_go", "advantages"):
         np.testing.assert_array_equal(n(getattr(got, f)), n(getattr(want, f)), err_msg=f)
+
+
+@pytest.mark.parametrize("kind", ["multi-discrete", "multi-binary"])
+def test_multi_discrete_and_multi_binary_action_spaces_train(kind):
+    """
+    MultiDiscrete / MultiBinary action spaces (networks/distributions.py:134-196, 272-438, 1046-1056) through the
+    whole loop on the torch-ROCm update path: actions of the right shape / dtype in the buffer, the first
+    mini-batch's ratio is exactly 1 (rollout log-probs == evaluation log-probs: kl == 0 before any update), two
+    iterations of training with finite statistics and moving weights.
+    """
+    from ppo_and_friends_amd.ppo import PPO, PermutationLoader
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, MultiBinary, MultiDiscrete
+    dev = torch.device("cuda", 0)
+    E, T, O, B = 8, 16, 5, 32
+    space = MultiDiscrete([3, 4, 2]) if kind == "multi-discrete" else MultiBinary(5)
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, space, T, dev, reward="uniform", seed=3)
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    ppo = PPO(env_gen, {"p": (None, sp, sp, space, {})}, device=dev, random_seed=4, normalize_obs=False,
+              normalize_rewards=False, envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=1, save_state=False)
+    pol = ppo.policies["p"]
+    assert ppo._fused_updater("p", B) is None                     # torch-ROCm path for these heads
+    ppo.rollout()
+    buf = pol.buffer
+    if kind == "multi-discrete":
+        assert buf.actions.shape == (T, E, 3) and buf.actions.dtype == torch.int64
+        assert all(int(buf.actions[..., i].max()) < k for i, k in enumerate((3, 4, 2)))
+    else:
+        assert buf.actions.shape == (T, E, 5) and set(buf.actions.unique().tolist()) <= {0.0, 1.0}
+    with torch.no_grad():
+        _, lp, _ = pol.evaluate(buf.critic_observations.view(T * E, O), buf.observations.view(T * E, O),
+                                buf.raw_actions.view(T * E, -1))
+    torch.testing.assert_close(lp.reshape(T, E), buf.log_probs, rtol=1e-5, atol=1e-6)
+    w0 = pol.policy_params.clone()
+    for _ in range(2):
+        ppo.train_on_rollout()
+        sd = ppo.status_dict["p"]
+        assert all(np.isfinite(sd[k]) for k in ("actor loss", "critic loss", "kl avg", "weighted entropy"))
+        ppo.rollout()
+    assert not torch.equal(w0, pol.policy_params)

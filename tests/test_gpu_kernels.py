@@ -712,3 +712,55 @@ def test_shared_episode_dataset_matches_golden_g3(K, golden):
     np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), g["rtg"], rtol=1e-5, atol=1e-5)
     item = ds[5]
     assert len(item) == 13 and item[1].shape == (A, obs.shape[-1]) and item[12] == 5
+
+
+def test_multi_categorical_and_bernoulli_distributions_match_torch(K):
+    """
+    networks/distributions.py:134-196 (Bernoulli, MultiBinary spaces) and :272-438 (MultiCategorical, MultiDiscrete
+    spaces; per-slice softmax of the actor output :1046-1056): log-probs, entropies, their gradients and the
+    deterministic refinement against torch.distributions on the CPU; samples are in range and their logged
+    log-probs equal a re-evaluation.
+    """
+    from ppo_and_friends_amd.networks.distributions import MultiCategoricalDistribution, BernoulliDistribution
+    from torch.distributions import Bernoulli, Categorical
+    torch.manual_seed(3)
+    n, nvec = 37, [3, 5, 2]
+    logits = torch.randn(n, sum(nvec))
+    acts = torch.stack([torch.randint(0, k, (n,)) for k in nvec], dim=1)
+    d = MultiCategoricalDistribution(nvec, seed=5)
+    lg = dev(logits.numpy()).requires_grad_(True)
+    lp, ent = d.get_log_probs_and_entropy(lg, dev(acts.numpy()))
+    (lp.sum() + 0.3 * ent.sum()).backward()
+    ref_l = logits.clone().requires_grad_(True)
+    start, lps, ents = 0, [], []
+    for i, k in enumerate(nvec):
+        c = Categorical(torch.softmax(ref_l[:, start:start + k], dim=-1))
+        lps.append(c.log_prob(acts[:, i])); ents.append(c.entropy()); start += k
+    rlp, rent = torch.stack(lps, -1).sum(-1), torch.stack(ents, -1).sum(-1)
+    (rlp.sum() + 0.3 * rent.sum()).backward()
+    np.testing.assert_allclose(lp.detach().cpu().numpy()[:, 0], rlp.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ent.detach().cpu().numpy(), rent.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), ref_l.grad.numpy(), rtol=1e-4, atol=1e-6)
+    a, raw, slp = d.sample_distribution(lg.detach())
+    assert a.shape == (n, 3) and torch.equal(a, raw) and all(int(a[:, i].max()) < k and int(a[:, i].min()) >= 0 for i, k in enumerate(nvec))
+    lp2, _ = d.get_log_probs_and_entropy(lg.detach(), a)
+    torch.testing.assert_close(slp, lp2, rtol=1e-5, atol=1e-6)
+    want = torch.stack([torch.argmax(logits[:, s:s + k], -1) for s, k in zip((0, 3, 8), nvec)], -1)
+    assert torch.equal(d.refine_prediction(lg.detach()).cpu(), want)
+
+    bits = 6
+    blog = torch.randn(n, bits)
+    bact = (torch.rand(n, bits) < 0.5).float()
+    b = BernoulliDistribution(seed=9)
+    bl = dev(blog.numpy()).requires_grad_(True)
+    lp, ent = b.get_log_probs_and_entropy(bl, dev(bact.numpy()))
+    (lp.sum() + 0.3 * ent.sum()).backward()
+    rb = blog.clone().requires_grad_(True)
+    rd = Bernoulli(probs=torch.sigmoid(rb))
+    (rd.log_prob(bact).sum() + 0.3 * rd.entropy().sum()).backward()
+    np.testing.assert_allclose(lp.detach().cpu().numpy()[:, 0], rd.log_prob(bact).sum(-1).detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bl.grad.cpu().numpy(), rb.grad.numpy(), rtol=1e-4, atol=1e-6)
+    a, raw, slp = b.sample_distribution(bl.detach())
+    assert set(a.unique().tolist()) <= {0.0, 1.0} and a.shape == (n, bits)
+    torch.testing.assert_close(slp, b.get_log_probs_and_entropy(bl.detach(), a)[0], rtol=1e-5, atol=1e-6)
+    assert torch.equal(b.refine_prediction(bl.detach()).cpu(), (torch.sigmoid(blog) >= 0.5).float())
