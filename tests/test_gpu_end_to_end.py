@@ -1402,3 +1402,37 @@ def test_multi_discrete_and_multi_binary_action_spaces_train(kind):
         assert all(np.isfinite(sd[k]) for k in ("actor loss", "critic loss", "kl avg", "weighted entropy"))
         ppo.rollout()
     assert not torch.equal(w0, pol.policy_params)
+
+
+def test_mat_policy_with_continuous_actions_is_self_consistent():
+    """
+    MATPolicy over a Box action space (mat_policy.py:308-344 continuous token block, :441-519 autoregressive
+    sampling with the tanh-Gaussian head): torch-ROCm path.  The autoregressive rollout's log-probs / values must
+    equal the teacher-forced evaluation of the same raw actions (kl == 0 before any update), and training moves
+    the weights with finite statistics.
+    """
+    from ppo_and_friends_amd.ppo import PPO
+    from ppo_and_friends_amd.policies.mat_policy import MATPolicy
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box
+    dev = torch.device("cuda", 0)
+    A, E, T, O, D, B = 3, 6, 10, 7, 2, 16
+    space = Box(-1.0, 1.0, (D,), np.float32)
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, space, T, dev, reward="uniform", seed=41, num_agents=A)
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    ppo = PPO(env_gen, {"mat": (MATPolicy, sp, sp, space, {})}, device=dev, random_seed=6, normalize_obs=False,
+              normalize_rewards=False, envs_per_proc=E, ts_per_rollout=T, batch_size=B, epochs_per_iter=1, save_state=False)
+    pol = ppo.policies["mat"]
+    assert ppo._fused_updater("mat", B) is None
+    ppo.rollout()
+    buf = pol.buffer
+    assert buf.actions.shape == (T, E, A, D) and float(buf.actions.abs().max()) <= 1.0
+    flat = lambda x: x.reshape((T * E,) + tuple(x.shape[2:]))
+    with torch.no_grad():
+        v, lp, _ = pol.evaluate(flat(buf.critic_observations), flat(buf.observations), flat(buf.raw_actions))
+    torch.testing.assert_close(lp.reshape(T, E, A), buf.log_probs, rtol=2e-5, atol=2e-5)
+    w0 = pol.actor_critic.flat_params.clone()
+    ppo.train_on_rollout()
+    sd = ppo.status_dict["mat"]
+    assert all(np.isfinite(sd[k]) for k in ("actor loss", "critic loss", "kl avg"))
+    assert not torch.equal(w0, pol.actor_critic.flat_params)
