@@ -246,10 +246,15 @@ class CpuPPO:
         self.dataset = _ListDataset(finished)
         return self.dataset
 
-    def icm_train_epoch(self):
+    def _loader(self, perm):
+        """DataLoader(shuffle=True) (ppo.py:2181-2184); `perm` replays a recorded shuffle instead of drawing one."""
+        if perm is not None:
+            return DataLoader(self.dataset, batch_size=self.batch_size, sampler=[int(i) for i in perm])
+        return DataLoader(self.dataset, batch_size=self.batch_size, shuffle=True, generator=self.loader_generator)
+
+    def icm_train_epoch(self, perm=None):
         """ppo.py:2487-2567."""
-        loader = DataLoader(self.dataset, batch_size=self.batch_size, shuffle=True,
-                            generator=self.loader_generator)
+        loader = self._loader(perm)
         total, n = 0.0, 0
         for batch in loader:
             _, obs, next_obs, _, actions, _, _, _, _, _, _, _, _ = batch
@@ -265,9 +270,8 @@ class CpuPPO:
         return total / max(n, 1)
 
     # ----- one epoch (ppo.py:2274-2485)
-    def train_epoch(self):
-        loader = DataLoader(self.dataset, batch_size=self.batch_size, shuffle=True,
-                            generator=self.loader_generator)
+    def train_epoch(self, perm=None):
+        loader = self._loader(perm)
         tot = dict(actor=0.0, critic=0.0, entropy=0.0, kl=0.0, n=0)
         for batch in loader:
             critic_obs, obs, _, raw_actions, _, advantages, log_probs, rewards_tg, _, _, _, _, idxs = batch
@@ -283,6 +287,13 @@ class CpuPPO:
             self.dataset.values[idxs] = values.detach()
             r = lo.ppo_minibatch_losses(cur_lp, log_probs, advantages, entropy, values, rewards_tg,
                                         self.normalize_adv, self.surr_clip, self.entropy_weight)
+            if getattr(self, "trace", None) is not None:     # tests: per-mini-batch losses + raw (unclipped) gradients
+                ga = torch.autograd.grad(r["actor_loss"], list(self.actor.parameters()), retain_graph=True)
+                gc = torch.autograd.grad(r["critic_loss"], list(self.critic.parameters()), retain_graph=True)
+                self.trace.append(dict(actor=r["actor"], critic=r["critic"], kl=r["kl"], entropy=r["entropy"],
+                                       adv_mean=r["adv_mean"], adv_std=r["adv_std"],
+                                       actor_grad=torch.cat([x.reshape(-1) for x in ga]).numpy(),
+                                       critic_grad=torch.cat([x.reshape(-1) for x in gc]).numpy()))
             self.actor_optim.zero_grad()
             r["actor_loss"].backward()
             nn.utils.clip_grad_norm_(self.actor.parameters(), self.gradient_clip)
