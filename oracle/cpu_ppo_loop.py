@@ -81,7 +81,7 @@ class _Episode:
 class _ListDataset(Dataset):
     """PPODataset.build + __getitem__ (episode_info.py:745-952), discrete actions."""
 
-    def __init__(self, episodes):
+    def __init__(self, episodes, action_dtype=torch.long):
         obs, nobs, cobs, act, ract, rtg, lp, adv, val = [], [], [], [], [], [], [], [], []
         for ep in episodes:
             obs.extend(ep.observations); nobs.extend(ep.next_observations)
@@ -92,8 +92,8 @@ class _ListDataset(Dataset):
         self.observations = torch.tensor(np.array(obs), dtype=torch.float32)
         self.next_observations = torch.tensor(np.array(nobs), dtype=torch.float32)
         self.critic_observations = torch.tensor(np.array(cobs), dtype=torch.float32)
-        self.actions = torch.tensor(np.array(act), dtype=torch.long)
-        self.raw_actions = torch.tensor(np.array(ract), dtype=torch.long)
+        self.actions = torch.tensor(np.array(act), dtype=action_dtype)           # episode_info.py:889-906
+        self.raw_actions = torch.tensor(np.array(ract), dtype=action_dtype)
         self.rewards_to_go = torch.tensor(np.array(rtg), dtype=torch.float32)
         self.log_probs = torch.tensor(lp, dtype=torch.float32)
         self.advantages = torch.tensor(np.array(adv), dtype=torch.float32)
@@ -120,13 +120,23 @@ class CpuPPO:
                  bootstrap_clip=(-100.0, 100.0), surr_clip=0.2, entropy_weight=0.01,
                  gradient_clip=0.5, batch_size=256, normalize_adv=True, normalize_values=True,
                  seed=0, rtg_accum="float64", critic_obs_dim=None, critic_hidden=None,
-                 enable_icm=False, icm_lr=3e-4, icm_beta=0.8, intr_reward_weight=1.0):
+                 enable_icm=False, icm_lr=3e-4, icm_beta=0.8, intr_reward_weight=1.0, activation=None,
+                 continuous=False, act_low=-1.0, act_high=1.0):
+        """continuous=True: Box action space of n_actions dims, tanh-Gaussian head with a learned log_std
+        (networks/distributions.py:441-694; log_std is a parameter of the ACTOR module, wrappers.py:30-31)."""
         torch.manual_seed(seed)
         critic_obs_dim = obs_dim if critic_obs_dim is None else critic_obs_dim
         critic_hidden = hidden if critic_hidden is None else critic_hidden
-        self.actor = make_mlp(obs_dim, n_actions, hidden, depth, out_gain=0.01)     # ppo_policy.py:433-439
-        self.critic = make_mlp(critic_obs_dim, 1, critic_hidden, depth, out_gain=1.0)   # :441-446
-        self.actor_optim = torch.optim.Adam(self.actor.parameters(), lr=lr, eps=1e-5)
+        self.actor = make_mlp(obs_dim, n_actions, hidden, depth, out_gain=0.01, activation=activation)     # ppo_policy.py:433-439
+        self.critic = make_mlp(critic_obs_dim, 1, critic_hidden, depth, out_gain=1.0, activation=activation)   # :441-446
+        self.continuous = continuous
+        self.actor_params = list(self.actor.parameters())
+        if continuous:                                 # distributions.py:491-492 (std_offset 0.5), :476-483 (bounds as arrays)
+            self.log_std = nn.Parameter(torch.as_tensor(-0.5 * np.ones(n_actions, dtype=np.float32)))
+            self.actor_params.append(self.log_std)
+            self.act_low = np.broadcast_to(np.asarray(act_low, dtype=np.float32), (n_actions,)).copy()
+            self.act_high = np.broadcast_to(np.asarray(act_high, dtype=np.float32), (n_actions,)).copy()
+        self.actor_optim = torch.optim.Adam(self.actor_params, lr=lr, eps=1e-5)
         self.critic_optim = torch.optim.Adam(self.critic.parameters(), lr=lr, eps=1e-5)
         self.gamma, self.lambd, self.clip = gamma, lambd, bootstrap_clip
         self.surr_clip, self.entropy_weight, self.gradient_clip = surr_clip, entropy_weight, gradient_clip
@@ -139,7 +149,7 @@ class CpuPPO:
         self.intrinsic_score_avg = 0.0                 # status_dict[...]["intrinsic score avg"], ppo.py:518
         if enable_icm:                                 # ppo_policy.py:461-468, 341-343
             from .icm_oracle import ICM
-            self.icm = ICM(obs_dim, n_actions, discrete=True)
+            self.icm = ICM(obs_dim, n_actions, discrete=not continuous)
             self.icm_optim = torch.optim.Adam(self.icm.parameters(), lr=icm_lr, eps=1e-5)
 
     # ----- value normaliser (utils/misc.py:84-128)
@@ -186,15 +196,24 @@ class CpuPPO:
             episode_lengths += 1
             obs = obs_table[t]
             t_obs = torch.tensor(obs, dtype=torch.float32)
-            with torch.no_grad():
-                probs = torch.softmax(self.actor(t_obs), dim=-1)
-            dist = Categorical(probs)
-            if actions is None:
-                a = dist.sample()
+            if self.continuous:                        # ppo_policy.py:758-794 with the Gaussian head
+                with torch.no_grad():
+                    mean = self.actor(t_obs)
+                    gd = lo.gaussian_dist(mean, self.log_std)
+                    raw = gd.sample() if actions is None else torch.as_tensor(actions[t], dtype=torch.float32)
+                    a = lo.gaussian_refine(raw, self.act_low, self.act_high)
+                    log_prob = lo.gaussian_tanh_logp(mean, self.log_std, raw).unsqueeze(-1)
+                a_np, raw_np = a.numpy(), raw.numpy()
             else:
-                a = torch.as_tensor(actions[t], dtype=torch.long)
-            log_prob = torch.unsqueeze(dist.log_prob(a), dim=-1)
-            a_np = a.unsqueeze(-1).numpy()
+                with torch.no_grad():
+                    probs = torch.softmax(self.actor(t_obs), dim=-1)
+                dist = Categorical(probs)
+                if actions is None:
+                    a = dist.sample()
+                else:
+                    a = torch.as_tensor(actions[t], dtype=torch.long)
+                log_prob = torch.unsqueeze(dist.log_prob(a), dim=-1)
+                a_np = raw_np = a.unsqueeze(-1).numpy()
             cobs = critic_obs_table[t]
             value = self.values_of(torch.tensor(cobs, dtype=torch.float32)).unsqueeze(-1)
             nxt = obs_table[t + 1]
@@ -202,14 +221,15 @@ class CpuPPO:
             intr = np.zeros((E, 1), dtype=np.float32)
             if self.enable_icm:                        # ppo.py:1719-1723 -> ppo_policy.py:954-1007
                 with torch.no_grad():
-                    ir, _, _ = self.icm(t_obs, torch.tensor(nxt_all[t], dtype=torch.float32), a.unsqueeze(1))
+                    ir, _, _ = self.icm(t_obs, torch.tensor(nxt_all[t], dtype=torch.float32),
+                                        a if self.continuous else a.unsqueeze(1))
                 intr = ir.numpy().reshape(E, 1) * self.intr_reward_weight
                 rew = rew + intr                       # float64 + float32 (ppo.py:1283)
                 total_intr += float(intr.sum())
             for e in range(E):                         # ppo_policy.py:638-651
                 episodes[e].add_info(
                     critic_observation=cobs[e], observation=obs[e], next_observation=nxt[e],
-                    raw_action=a_np[e], action=a_np[e], value=value[e].item(),
+                    raw_action=raw_np[e], action=a_np[e], value=value[e].item(),
                     log_prob=log_prob[e], reward=rew[e].item())
             where_term = np.where(term_table[t])[0] if term_table is not None else np.array([], dtype=np.int64)
             for e in where_term:                       # ppo.py:1810-1819
@@ -229,10 +249,14 @@ class CpuPPO:
             if where_maxed.size > 0:
                 next_value = self.values_of(torch.tensor(critic_obs_table[t + 1], dtype=torch.float32))
                 for e in where_maxed:                  # ppo.py:1932-1938 (each env its own value: quirk Q1 fixed)
-                    nr = next_value[e].item()
-                    if self.enable_icm:                # ppo.py:1926-1930 "surprise" (per env: quirk Q2 fixed)
-                        nr = float(np.float32(nr) + (intr[e, 0] - np.float32(ism)))
-                    episodes[e].end_episode(next_value[e].item(), nr, self.rtg_accum)
+                    nv = nr = next_value[e].item()
+                    if self.enable_icm:
+                        # ppo.py:1926-1930 "surprise" (per env: quirk Q2 fixed).  Quirk Q12: next_reward is
+                        # get_detached_dict(next_value) (ppo.py:1115-1141): on the CPU `.detach().cpu().numpy()`
+                        # SHARES the tensor's memory, so the in-place `+=` lands in next_value as well -- the
+                        # ending VALUE of the GAE carries the surprise too (pinned by fixture g12_c2_icm)
+                        nv = nr = float(np.float32(nr) + (intr[e, 0] - np.float32(ism)))
+                    episodes[e].end_episode(nv, nr, self.rtg_accum)
                     finished.append(episodes[e])
                     episodes[e] = new_ep()
                     ep_ts[e] = 0
@@ -243,7 +267,7 @@ class CpuPPO:
             avg_ep_len = combined / E if ts_before == 0 else ts_before / cur_total
             total_episodes += float((episode_lengths / avg_ep_len).sum())
             self.intrinsic_score_avg = total_intr / (total_episodes / E)
-        self.dataset = _ListDataset(finished)
+        self.dataset = _ListDataset(finished, torch.float32 if self.continuous else torch.long)
         return self.dataset
 
     def _loader(self, perm):
@@ -280,15 +304,20 @@ class CpuPPO:
             if obs.shape[0] == 1:
                 continue
             values = self.critic(critic_obs).squeeze()
-            probs = torch.softmax(self.actor(obs), dim=-1)
-            dist = Categorical(probs)
-            cur_lp = torch.unsqueeze(dist.log_prob(raw_actions.flatten()), dim=-1)
-            entropy = dist.entropy()
+            if self.continuous:                        # ppo_policy.py:930-952: entropy := -log_prob of the MEAN (distributions.py:694)
+                mean = self.actor(obs)
+                cur_lp = lo.gaussian_tanh_logp(mean, self.log_std, raw_actions)
+                entropy = -lo.gaussian_tanh_logp(mean, self.log_std, mean)
+            else:
+                probs = torch.softmax(self.actor(obs), dim=-1)
+                dist = Categorical(probs)
+                cur_lp = torch.unsqueeze(dist.log_prob(raw_actions.flatten()), dim=-1)
+                entropy = dist.entropy()
             self.dataset.values[idxs] = values.detach()
             r = lo.ppo_minibatch_losses(cur_lp, log_probs, advantages, entropy, values, rewards_tg,
                                         self.normalize_adv, self.surr_clip, self.entropy_weight)
             if getattr(self, "trace", None) is not None:     # tests: per-mini-batch losses + raw (unclipped) gradients
-                ga = torch.autograd.grad(r["actor_loss"], list(self.actor.parameters()), retain_graph=True)
+                ga = torch.autograd.grad(r["actor_loss"], self.actor_params, retain_graph=True)
                 gc = torch.autograd.grad(r["critic_loss"], list(self.critic.parameters()), retain_graph=True)
                 self.trace.append(dict(actor=r["actor"], critic=r["critic"], kl=r["kl"], entropy=r["entropy"],
                                        adv_mean=r["adv_mean"], adv_std=r["adv_std"],
@@ -296,7 +325,7 @@ class CpuPPO:
                                        critic_grad=torch.cat([x.reshape(-1) for x in gc]).numpy()))
             self.actor_optim.zero_grad()
             r["actor_loss"].backward()
-            nn.utils.clip_grad_norm_(self.actor.parameters(), self.gradient_clip)
+            nn.utils.clip_grad_norm_(self.actor_params, self.gradient_clip)
             self.actor_optim.step()
             self.critic_optim.zero_grad()
             r["critic_loss"].backward()

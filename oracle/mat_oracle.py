@@ -229,10 +229,11 @@ class CpuMATPPO:
         adv = np.zeros((E * T, A), dtype=np.float32); rtg = np.zeros((E * T, A), dtype=np.float32)
         for e in range(E):
             for a in range(A):
-                nr = float(next_value[e, a])
+                nv = nr = float(next_value[e, a])
                 if self.enable_icm:                      # ppo.py:1926-1930 "surprise" (per env: quirk Q2 fixed)
-                    nr = float(np.float32(nr) + (intr[T - 1, e, a] - np.float32(self.intrinsic_score_avg)))
-                ad, rg = eo.end_episode(reward_table[:, e, a], vals[:, e, a], float(next_value[e, a]),
+                    # quirk Q12: the in-place `+=` on the numpy view lands in next_value too (see cpu_ppo_loop.py)
+                    nv = nr = float(np.float32(nr) + (intr[T - 1, e, a] - np.float32(self.intrinsic_score_avg)))
+                ad, rg = eo.end_episode(reward_table[:, e, a], vals[:, e, a], nv,
                                         nr, self.gamma, self.lambd, self.clip, True)
                 adv[e * T:(e + 1) * T, a] = ad; rtg[e * T:(e + 1) * T, a] = rg
         flat = lambda x: np.concatenate([x[:, e] for e in range(E)], axis=0)

@@ -92,9 +92,13 @@ def gaussian_tanh_logp(mean, log_std, x, min_std=0.01, epsilon=1e-6):
 
 
 def gaussian_refine(sample, lo=-1.0, hi=1.0):
+    """lo / hi: scalars or per-dimension arrays (dist_min / dist_max are numpy arrays in the reference, :476-483)."""
+    import numpy as np
+    lo = np.atleast_1d(np.asarray(lo, dtype=np.float32))
+    hi = np.atleast_1d(np.asarray(hi, dtype=np.float32))
     s = torch.tanh(sample)                                                # :604
-    if lo != -1.0 or hi != 1.0:
-        s = ((s + 1.0) / 2.0) * (hi - lo) + lo                            # :580-581
+    if (lo != -1.0).any() or (hi != 1.0).any():                           # :606
+        s = ((s + 1.0) / 2.0) * (hi - lo) + lo                            # :580-581 (torch tensor x numpy array)
     return s
 
 

@@ -2,7 +2,9 @@
 TEST INFRASTRUCTURE (see oracle/__init__.py) -- literal restatement of the per-step statistics
 bookkeeping of the reference's rollout (ppo.py:1600-1631 initial values, :1756-1790 ranges and running
 scores, :1805-1851 terminations, :1863-1976 cuts and the end of the rollout, :1978-2099 the final block),
-for one policy with one agent per env on one rank.  "parity unpinned" (ppo.py imports gymnasium).
+for one policy on one rank (one agent per env, or A agents sharing the policy: trailing agent axis).
+PINNED by the rollout status blocks of fixtures g12_* (tests/test_oracle_update_golden.py), recorded from the
+unmodified reference's PPO.rollout.
 """
 import numpy as np
 
@@ -12,6 +14,13 @@ def rollout_statistics_loop(reward, nat, intr, next_obs_min, next_obs_max, term,
     reward, nat, intr [T, E]; next_obs_min/max [T] (extrema of the post-step observation);
     term, boot [T, E] bool; next_reward [T, E]: the critic's bootstrap rewards of the whole batch at step t.
     """
+    if reward.ndim == 3:                       # A agents of one policy: per-env scores sum the agents (ppo.py:1782-1787),
+        A = reward.shape[2]                    # extrema run over all of them, bootstraps count once per agent (:1901-1912)
+        r_all, n_all, i_all = reward, nat, intr
+        reward, nat, intr = reward.sum(2), nat.sum(2), intr.sum(2)
+    else:
+        A = 1
+        r_all, n_all, i_all = reward, nat, intr
     T, E = reward.shape
     fmax = np.finfo(np.float32).max
     top_rollout_score, top_reward = -fmax, -fmax
@@ -24,12 +33,12 @@ def rollout_statistics_loop(reward, nat, intr, next_obs_min, next_obs_max, term,
     longest_run, shortest_run, avg_run = 0, T, T
     for t in range(T):
         episode_lengths += 1
-        mx_r, mn_r = max(mx_r, reward[t].max()), min(mn_r, reward[t].min())
-        mx_n, mn_n = max(mx_n, nat[t].max()), min(mn_n, nat[t].min())
-        mx_i, mn_i = max(mx_i, intr[t].max()), min(mn_i, intr[t].min())
+        mx_r, mn_r = max(mx_r, r_all[t].max()), min(mn_r, r_all[t].min())
+        mx_n, mn_n = max(mx_n, n_all[t].max()), min(mn_n, n_all[t].min())
+        mx_i, mn_i = max(mx_i, i_all[t].max()), min(mn_i, i_all[t].min())
         mx_o, mn_o = max(mx_o, next_obs_max[t]), min(mn_o, next_obs_min[t])
         ep_sc += reward[t]; ep_nat += nat[t]; ep_in += intr[t]
-        top_reward = max(top_reward, nat[t].max())
+        top_reward = max(top_reward, n_all[t].max())
         where_term = np.where(term[t])[0]
         where_not_term = np.where(~term[t])[0]
         if where_term.size > 0:
@@ -45,8 +54,8 @@ def rollout_statistics_loop(reward, nat, intr, next_obs_min, next_obs_max, term,
             total_episodes += where_term.size
         if boot[t].any():
             bs_min, bs_max = min(bs_min, float(next_reward[t].min())), max(bs_max, float(next_reward[t].max()))
-            bs_sum += next_reward[t]
-            total_bs += 1
+            bs_sum += next_reward[t] if next_reward[t].ndim == 1 else next_reward[t].sum(1)
+            total_bs += A
         if t == T - 1:
             combined = episode_lengths.sum()
             ts_before = max(T * E - combined, 0)

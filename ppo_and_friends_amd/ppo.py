@@ -413,11 +413,19 @@ class PPO:
                 buf.boot_value[:-1].copy_(buf.values[1:])
             buf.boot_value[T - 1].copy_(next_value)
             buf.boot_reward.copy_(buf.boot_value)
+            buf.boot_stats = None
             if pol.enable_icm:
+                # the "bootstrap range / avg" statistics read next_reward BEFORE the surprise lands (ppo.py:1901-1912)
+                buf.boot_stats = buf.boot_value.clone()
                 # ppo.py:1926-1930: bootstrap reward += intrinsic reward of the step - "intrinsic score avg"
                 ism = float(self.status_dict[policy_id].get("intrinsic score avg", 0.0))
                 buf.boot_reward.add_((intr_buf - ism).view_as(buf.boot_reward))
+                # quirk Q12 (replicated; pinned by fixture g12_c2_icm): next_reward is a numpy VIEW of the
+                # next_value tensor on the reference's CPU path (ppo.py:1115-1141), so its in-place `+=` puts the
+                # surprise into the ending value of the GAE as well
+                buf.boot_value.copy_(buf.boot_reward)
         else:
+            buf.boot_stats = None
             buf.end_kind[T - 1].fill_(2)
             buf.boot_value[T - 1].copy_(next_value)
             buf.boot_reward[T - 1].copy_(next_value)
@@ -568,7 +576,9 @@ class PPO:
         if T > 1:
             b_lo, b_hi = mm(buf.observations[1:])
             o_lo, o_hi = torch.minimum(o_lo, b_lo), torch.maximum(o_hi, b_hi)
-        st = rollout_statistics(per_env(buf.rewards), nat_env, ek == 1, ek == 2, buf.boot_reward, A, mm(buf.rewards),
+        boot_stats = getattr(buf, "boot_stats", None)
+        st = rollout_statistics(per_env(buf.rewards), nat_env, ek == 1, ek == 2,
+                                buf.boot_reward if boot_stats is None else boot_stats, A, mm(buf.rewards),
                                 mm(nat_buf), (o_lo, o_hi), self.ts_per_rollout / self.envs_per_proc,
                                 None if intr_buf is None else per_env(intr_buf),
                                 None if intr_buf is None else mm(intr_buf))

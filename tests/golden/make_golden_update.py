@@ -24,6 +24,11 @@ import sys
 import tempfile
 
 sys.dont_write_bytecode = True
+if os.environ.get("PYTHONHASHSEED") != "0":
+    # PPOPolicy.register_agent orders a policy's agents through a set of strings (policies/ppo_policy.py:375-376):
+    # pin the hash seed so that regenerating a multi-agent fixture reproduces it bit for bit
+    os.environ["PYTHONHASHSEED"] = "0"
+    os.execv(sys.executable, [sys.executable] + sys.argv)
 
 import numpy as np
 import torch
@@ -179,14 +184,36 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
         def rec_denorm(values):
             v = orig_denorm(values)
             rec.setdefault("values", []).append({a: v[a].detach().numpy().copy() for a in v})
+            rec.setdefault("values_step", []).append(len(rec["steps"]))
             return v
         ppo.get_denormalized_values = rec_denorm
     else:
         def rec_values(cobs):
             v = orig_values(cobs)
             rec.setdefault("values", []).append({a: v[a].detach().numpy().copy() for a in v})
+            rec.setdefault("values_step", []).append(len(rec["steps"]))
             return v
         ppo.get_policy_values = rec_values
+
+    orig_intr = ppo.apply_intrinsic_rewards
+    orig_nat = ppo.get_natural_reward
+
+    def rec_intr(ext_rewards, prev_obs, obs, actions):
+        ext = {a: np.array(ext_rewards[a], dtype=np.float64).copy() for a in ext_rewards}
+        rewards, intr = orig_intr(ext_rewards, prev_obs, obs, actions)
+        rec.setdefault("rewards", []).append(dict(
+            ext=ext, reward={a: np.array(rewards[a], dtype=np.float64).copy() for a in rewards},
+            intr={a: np.broadcast_to(np.array(intr[a], dtype=np.float64), ext[a].shape).copy() for a in intr},
+            obs_minmax=np.array([min(float(np.min(obs[a])) for a in obs), max(float(np.max(obs[a])) for a in obs)])))
+        return rewards, intr
+
+    def rec_nat(info):
+        have, nat = orig_nat(info)
+        rec.setdefault("nat", []).append(None if not have else {a: np.array(nat[a], dtype=np.float64).copy() for a in nat})
+        return have, nat
+
+    ppo.apply_intrinsic_rewards = rec_intr
+    ppo.get_natural_reward = rec_nat
 
     orig_finalize = pol.finalize_dataset
 
@@ -264,7 +291,12 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
     # values: the first n_steps-per-rollout calls of each rollout are the per-step values; extra calls are bootstraps
     vals = rec["values"]
     out["values_calls"] = np.stack([np.stack([v[a] for a in agents], 1) for v in vals])
-    out["n_value_calls"] = np.array([len(vals)])
+    out["values_calls_step"] = np.array(rec["values_step"], dtype=np.int64)   # 1-based step the call belongs to
+    sr = lambda key: np.stack([np.stack([r[key][a] for a in agents], 1) for r in rec["rewards"]])[..., 0]   # [steps, E, A]
+    out["step_ext_rewards"], out["step_rewards"], out["step_intr_rewards"] = sr("ext"), sr("reward"), sr("intr")
+    out["step_natural_rewards"] = np.stack([
+        np.stack([(rec["rewards"][i]["ext"] if n is None else n)[a] for a in agents], 1) for i, n in enumerate(rec["nat"])])[..., 0]
+    out["step_next_obs_minmax"] = np.stack([r["obs_minmax"] for r in rec["rewards"]])
     for i, d in enumerate(rec["datasets"]):
         for k, v in d.items():
             out[f"it{i}_ds_{k}"] = v
@@ -303,21 +335,20 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
     out["env_actions_env0"] = np.stack([np.stack([np.asarray(s[a]) for a in agents]) for s in vec.envs[0].actions_seen])
     # filter stacks (obs / reward normalisers) keep running statistics worth pinning
     env = ppo.env
-    depth = 0
-    while hasattr(env, "env") and env is not None:
-        for attr in ("running_stats", "running_reward"):
-            if hasattr(env, attr):
-                val = getattr(env, attr)
-                if isinstance(val, dict):
-                    for a, rs in val.items():
-                        if hasattr(rs, "mean"):
-                            out[f"filter{depth}_{type(env).__name__}_{a}_mean"] = np.asarray(rs.mean, dtype=np.float64)
-                            out[f"filter{depth}_{type(env).__name__}_{a}_var"] = np.asarray(rs.variance, dtype=np.float64)
-                            out[f"filter{depth}_{type(env).__name__}_{a}_count"] = np.array([rs.count], dtype=np.float64)
-                        else:
-                            out[f"filter{depth}_{type(env).__name__}_{a}_{attr}"] = np.asarray(rs, dtype=np.float64)
+    while env is not None and hasattr(env, "env"):
+        cls = type(env).__name__
+        for attr in ("actor_running_stats", "critic_running_stats", "running_stats"):
+            val = getattr(env, attr, None)
+            if isinstance(val, dict):
+                for a, rs in val.items():
+                    out[f"filter_{cls}_{attr}_{a}_mean"] = np.asarray(rs.mean, dtype=np.float64)
+                    out[f"filter_{cls}_{attr}_{a}_var"] = np.asarray(rs.variance, dtype=np.float64)
+                    out[f"filter_{cls}_{attr}_{a}_count"] = np.array([rs.count], dtype=np.float64)
+        rr = getattr(env, "running_reward", None)
+        if isinstance(rr, dict):
+            for a, v in rr.items():
+                out[f"filter_{cls}_running_reward_{a}"] = np.asarray(v, dtype=np.float64)
         env = env.env
-        depth += 1
     import shutil
     shutil.rmtree(state_dir, ignore_errors=True)
     return out
@@ -335,6 +366,33 @@ def scenarios():
     # same, no terminations, episodes cut every 8 steps (all envs aligned), tail mini-batch (N=264 % 64 != 0 -> E=11,T=24)
     sc["g12_c2_cut"] = dict(seed=102, E=11, T=24, A=1, O=4, action_space=Discrete(2), reward="uniform", term_prob=0.0,
                             max_ts_per_ep=8, batch_size=64, epochs=3, iterations=1)
+    # C4 layer shapes (MAPPO): 3 agents share one policy, actor 128^3 on O=18 -> Discrete(5), critic 256^3 on the
+    # concatenated "policy" view (O_c = 54), LeakyReLU (baselines/pettingzoo/mpe_simple_spread.py:40-75)
+    sc["g12_c4_mappo"] = dict(seed=104, E=4, T=16, A=3, O=18, action_space=Discrete(5), reward="uniform", term_prob=0.05,
+                              batch_size=48, epochs=2, iterations=1, critic_view="policy",
+                              policy_args=dict(actor_kw_args=leaky(), critic_kw_args=big()))
+    # C3 layer shapes (HalfCheetah-v4: O=17, Box(6) in [-1,1], LeakyReLU actor 128^3 / critic 256^3, lr 1e-4;
+    # baselines/gymnasium/half_cheetah.py:20-49): the tanh-Gaussian head alone, with terminations
+    cheetah = lambda: Box(-1.0, 1.0, (6,), np.float32)
+    sc["g12_c3_gauss"] = dict(seed=105, E=6, T=16, A=1, O=17, action_space=cheetah(), reward="uniform", term_prob=0.05,
+                              batch_size=32, epochs=2, iterations=1,
+                              policy_args=dict(actor_kw_args=leaky(), critic_kw_args=big(), lr=1e-4))
+    # ... and the full C3 stack: ICM + observation / reward normalisers + clippers (tight clip ranges so that they
+    # bite), episodes cut every 8 steps with all envs aligned (the shapes quirks Q1 / Q2 are well defined for)
+    sc["g12_c3_full"] = dict(seed=106, E=6, T=16, A=1, O=17, action_space=cheetah(), reward="uniform", term_prob=0.0,
+                             max_ts_per_ep=8, batch_size=32, epochs=2, iterations=2, obs_scale=3.0, obs_shift=1.0,
+                             policy_args=dict(actor_kw_args=leaky(), critic_kw_args=big(), lr=1e-4, enable_icm=True),
+                             ppo_args=dict(normalize_obs=True, normalize_rewards=True, obs_clip=(-2.0, 2.0),
+                                           reward_clip=(-1.5, 1.5)))
+    # per-dimension action bounds (networks/distributions.py:476-483, 580-609): small networks, unequal Box sides
+    sc["g12_gauss_bounds"] = dict(seed=107, E=5, T=12, A=1, O=7, reward="uniform", term_prob=0.0, batch_size=20,
+                                  epochs=1, iterations=1,
+                                  action_space=Box(np.array([-1.0, -2.0, 0.0], np.float32), np.array([1.0, 2.0, 5.0], np.float32)),
+                                  policy_args=dict(actor_kw_args={"hidden_size": 32}, critic_kw_args={"hidden_size": 32}))
+    # discrete ICM at CartPole dims (ICM defaults: encoder O->128^3->128, inverse 256->128^2->n, forward 128+n->128^2->128)
+    sc["g12_c2_icm"] = dict(seed=108, E=6, T=16, A=1, O=4, action_space=Discrete(2), reward="ones", term_prob=0.0,
+                            max_ts_per_ep=8, batch_size=32, epochs=2, iterations=2,
+                            policy_args=dict(enable_icm=True))
     return sc
 
 

@@ -46,6 +46,10 @@ class Space:
     @property
     def shape(self): return self._shape
     def seed(self, s=None): return [s]
+    def __eq__(self, other):
+        return (type(self) is type(other) and self._shape == other._shape and self.dtype == other.dtype
+                and all(np.array_equal(getattr(self, k, None), getattr(other, k, None)) for k in ("low", "high", "n", "nvec")))
+    __hash__ = object.__hash__
 class Box(Space):
     def __init__(self, low, high, shape=None, dtype=np.float32):
         if shape is None:

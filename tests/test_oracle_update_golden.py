@@ -10,7 +10,8 @@ import pytest
 import torch
 
 from oracle import cpu_ppo_loop
-from oracle import rollout_stats_oracle as rso
+from oracle import filter_oracle
+from oracle.rollout_stats_oracle import rollout_statistics_loop
 
 
 def _load_seq(net, g, prefix):
@@ -34,45 +35,208 @@ def _cfg(g):
     return dict(zip([str(x) for x in g["cfg_names"]], [int(x) for x in g["cfg"]]))
 
 
-@pytest.mark.parametrize("name", ["g12_c2_term", "g12_c2_cut"])
+def row_mapping(ref_obs, got_obs):
+    """
+    pi with got[pi[i]] == ref[i].  The reference orders the episodes of one end-of-episode event by the policy's
+    agent_ids, which PPOPolicy.register_agent builds through a set of strings (policies/ppo_policy.py:375-376):
+    a hash-dependent agent order, not a contract.  The port / product use agent order 0..A-1.  Rows are matched by
+    their (unique, random) observation vectors; every other field is then compared under this mapping and the
+    recorded shuffles are mapped through it, so mini-batches hold the same transitions.
+    """
+    index = {row.tobytes(): i for i, row in enumerate(np.ascontiguousarray(got_obs))}
+    assert len(index) == len(got_obs), "observation rows are not unique"
+    return np.array([index[row.tobytes()] for row in np.ascontiguousarray(ref_obs)], dtype=np.int64)
+
+
+def agent_major(x):
+    """[steps, E, A, ...] (fixture layout) -> [steps, A*E, ...] agent-major columns (the oracle's / product's rows)."""
+    x = np.swapaxes(x, 1, 2)
+    return x.reshape((x.shape[0], x.shape[1] * x.shape[2]) + x.shape[3:])
+
+
+def policy_view(obs):
+    """critic_view="policy": per env the agents' observations side by side, the same row for every agent."""
+    S, E, A, O = obs.shape
+    v = obs.reshape(S, 1, E, A * O)
+    return np.broadcast_to(v, (S, A, E, A * O)).reshape(S, A * E, A * O)
+
+
+def build_cpu_port(g, c):
+    """The CPU port configured like the scenario's reference policy, holding the fixture's initial weights."""
+    names = set(g.files)
+    continuous = "init_actor.distribution.log_std" in names
+    n_act = int(g["init_actor.sequential_net.3.weight"].shape[0])
+    c_in = int(g["init_critic.sequential_net.0.weight"].shape[1])
+    c_hidden = int(g["init_critic.sequential_net.0.weight"].shape[0])
+    hidden = int(g["init_actor.sequential_net.0.weight"].shape[0])
+    extra = {k: v for k, v in SCENARIOS[c["name"]].items() if k != "filters"}
+    cpu = cpu_ppo_loop.CpuPPO(c["O"], n_act, hidden=hidden, batch_size=c["batch_size"], seed=0,
+                              rtg_accum="float32",                      # the fixtures were recorded under NumPy 2
+                              critic_obs_dim=c_in, critic_hidden=c_hidden, continuous=continuous,
+                              enable_icm=any(k.startswith("init_icm.") for k in names), **extra)
+    _load_seq(cpu.actor, g, "init_actor")
+    _load_seq(cpu.critic, g, "init_critic")
+    if continuous:
+        with torch.no_grad():
+            cpu.log_std.copy_(torch.from_numpy(g["init_actor.distribution.log_std"]))
+    if cpu.enable_icm:
+        cpu.icm.load_state_dict({k[len("init_icm."):]: torch.from_numpy(g[k]) for k in names if k.startswith("init_icm.")})
+    return cpu
+
+
+def final_params(g, tag, cpu):
+    if tag == "actor":
+        got = torch.cat([p.detach().reshape(-1) for p in cpu.actor_params]).numpy()
+        want = [g[f"final_actor.sequential_net.{k}"].reshape(-1) for k, _ in cpu.actor.named_parameters()]
+        if cpu.continuous:
+            want.append(g["final_actor.distribution.log_std"])
+        return got, np.concatenate(want)
+    if tag == "critic":
+        return _flat(cpu.critic), _flat_fixture(g, "final_critic", cpu.critic)
+    got = torch.cat([p.detach().reshape(-1) for p in cpu.icm.parameters()]).numpy()
+    return got, np.concatenate([g[f"final_icm.{k}"].reshape(-1) for k, _ in cpu.icm.named_parameters()])
+
+
+LEAKY = dict(activation=torch.nn.LeakyReLU())
+SCENARIOS = {
+    "g12_c2_term": {}, "g12_c2_cut": {}, "g12_c4_mappo": LEAKY,
+    "g12_c3_gauss": dict(lr=1e-4, **LEAKY),
+    "g12_gauss_bounds": dict(act_low=[-1.0, -2.0, 0.0], act_high=[1.0, 2.0, 5.0]),
+    "g12_c2_icm": {},
+    "g12_c3_full": dict(lr=1e-4, filters=dict(obs_clip=(-2.0, 2.0), reward_clip=(-1.5, 1.5)), **LEAKY),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
 def test_cpu_port_reproduces_the_reference_ppo_iterations(golden, name):
     g = golden(name)
     c = _cfg(g)
-    E, T, B = c["E"], c["T"], c["batch_size"]
-    n_act = int(g["init_actor.sequential_net.3.weight"].shape[0])
-    cpu = cpu_ppo_loop.CpuPPO(c["O"], n_act, batch_size=B, seed=0, rtg_accum="float32")   # NumPy-2 run recorded the fixture
-    _load_seq(cpu.actor, g, "init_actor")
-    _load_seq(cpu.critic, g, "init_critic")
-    obs_table = g["obs_table"][:, :, 0]
-    rew_table = g["reward_table"][:, :, 0]
-    term = g["term_table"]
-    ep = 0
+    c["name"] = name
+    E, T, B, A = c["E"], c["T"], c["batch_size"], c["A"]
+    cpu = build_cpu_port(g, c)
+    c_in = cpu.critic[0].weight.shape[1]
+    obs_table = agent_major(g["obs_table"])
+    cobs_table = policy_view(g["obs_table"]) if c_in != c["O"] else None
+    rew_table = agent_major(g["reward_table"])
+    term = np.tile(g["term_table"], (1, A))
+    ep = icm_ep = 0
+    filters = SCENARIOS[name].get("filters")
+    raw_obs, raw_rew = obs_table, rew_table
+    if filters is not None:                    # wrapper_utils.py:81-111: the env's streams pass the filter stack first
+        assert cobs_table is None
+        orc = filter_oracle.FilteredEnvOracle(A, E, c["O"], c["O"], True, True, filters["obs_clip"], filters["reward_clip"],
+                                              gamma=0.99)
     for it in range(c["iterations"]):
-        acts = g["step_actions"][it * T:(it + 1) * T, :, 0]
+        if filters is not None:
+            # the table env's streams do not depend on the actions: filter them up front, in the order the wrappers
+            # see them (every rollout starts with a hard reset that is filtered -- and counted -- again, ppo.py:1580-1586)
+            obs_table, rew_table = np.empty_like(raw_obs), np.empty_like(raw_rew)
+            obs_table[0], _ = orc.filter_obs(raw_obs[0], raw_obs[0])
+            for t in range(T):
+                obs_table[t + 1], _, rew_table[t] = orc.filter_step(raw_obs[t + 1], raw_obs[t + 1], raw_rew[t], term[t],
+                                                                    np.zeros(A * E, bool))
+            np.testing.assert_allclose(obs_table[:T], agent_major(g["step_obs"][it * T:(it + 1) * T]), rtol=1e-6, atol=1e-6)
+        acts = agent_major(g["step_raw_actions" if cpu.continuous else "step_actions"][it * T:(it + 1) * T])
         ds = cpu.rollout(obs_table, rew_table, actions=acts, term_table=term if term.any() else None,
-                         max_ts_per_ep=c["max_ts_per_ep"])
+                         max_ts_per_ep=c["max_ts_per_ep"], critic_obs_table=cobs_table)
         pre = f"it{it}_ds_"
-        np.testing.assert_array_equal(ds.observations.numpy(), g[pre + "observations"])
-        np.testing.assert_array_equal(ds.next_observations.numpy(), g[pre + "next_observations"])
-        np.testing.assert_array_equal(ds.actions.numpy(), g[pre + "actions"])
-        np.testing.assert_array_equal([e.length for e in ds.episodes], g[pre + "ep_lens"])
         tol = dict(rtol=1e-6, atol=1e-6)
-        np.testing.assert_allclose(ds.values.numpy(), g[pre + "values"], **tol)
-        np.testing.assert_allclose(ds.log_probs.numpy(), g[pre + "log_probs"], **tol)
-        np.testing.assert_allclose(ds.rewards_to_go.numpy(), g[pre + "rewards_to_go"], **tol)
-        np.testing.assert_allclose(ds.advantages.numpy(), g[pre + "advantages"], **tol)
+        if A == 1:                                                         # single agent: the order itself is the contract
+            pi = np.arange(len(ds))
+            np.testing.assert_allclose(ds.observations.numpy(), g[pre + "observations"], **tol)
+            np.testing.assert_array_equal([e.length for e in ds.episodes], g[pre + "ep_lens"])
+        else:
+            pi = row_mapping(g[pre + "observations"], ds.observations.numpy())
+            np.testing.assert_array_equal(np.sort([e.length for e in ds.episodes]), np.sort(g[pre + "ep_lens"]))
+        np.testing.assert_allclose(ds.critic_observations.numpy()[pi], g[pre + "critic_observations"], **tol)
+        np.testing.assert_allclose(ds.next_observations.numpy()[pi], g[pre + "next_observations"], **tol)
+        if cpu.continuous:
+            np.testing.assert_array_equal(ds.raw_actions.numpy()[pi], g[pre + "raw_actions"])
+            np.testing.assert_allclose(ds.actions.numpy()[pi], g[pre + "actions"], **tol)     # tanh + per-dimension rescale
+        else:
+            np.testing.assert_array_equal(ds.actions.numpy()[pi], g[pre + "actions"])
+        np.testing.assert_allclose(ds.values.numpy()[pi], g[pre + "values"], **tol)
+        np.testing.assert_allclose(ds.log_probs.numpy()[pi], g[pre + "log_probs"], **tol)
+        np.testing.assert_allclose(ds.rewards_to_go.numpy()[pi], g[pre + "rewards_to_go"], **tol)
+        np.testing.assert_allclose(ds.advantages.numpy()[pi], g[pre + "advantages"], **tol)
+        if cpu.enable_icm:
+            k = list(g["rollout_status_keys"]).index("intrinsic score avg")
+            np.testing.assert_allclose(cpu.intrinsic_score_avg, g["rollout_status"][it][k], rtol=1e-6)
         for e in range(c["epochs"]):
             cpu.trace = [] if ep == 0 else None
-            r = cpu.train_epoch(perm=g["epoch_perms"][ep])
+            r = cpu.train_epoch(perm=pi[g["epoch_perms"][ep]])
             if ep == 0:      # the very first mini-batch, before any optimiser step: losses and raw gradients
                 m = cpu.trace[0]
-                np.testing.assert_allclose([m["actor"], m["critic"]], g["mb0_losses"], rtol=1e-6, atol=1e-9)
-                np.testing.assert_allclose(m["actor_grad"], g["mb0_actor_grad"], rtol=1e-5, atol=1e-9)
-                np.testing.assert_allclose(m["critic_grad"], g["mb0_critic_grad"], rtol=1e-5, atol=1e-8)
+                np.testing.assert_allclose([m["actor"], m["critic"]], g["mb0_losses"], rtol=5e-6, atol=1e-9)
+                np.testing.assert_allclose(m["actor_grad"], g["mb0_actor_grad"], rtol=1e-5, atol=1e-7)
+                np.testing.assert_allclose(m["critic_grad"], g["mb0_critic_grad"], rtol=1e-5, atol=1e-7)
             got = np.array([r["actor loss"], r["critic loss"], r["kl avg"], r["weighted entropy"]])
-            np.testing.assert_allclose(got, g["epoch_stats"][ep], rtol=2e-6, atol=1e-8, err_msg=f"iteration {it} epoch {e}")
+            # (the surrogate loss and the KL are means of O(1) terms that cancel: absolute floor 1e-6)
+            np.testing.assert_allclose(got, g["epoch_stats"][ep], rtol=5e-6, atol=1e-6, err_msg=f"iteration {it} epoch {e}")
             ep += 1
-    for net, tag in ((cpu.actor, "final_actor"), (cpu.critic, "final_critic")):
-        np.testing.assert_allclose(_flat(net), _flat_fixture(g, tag, net), rtol=1e-5, atol=1e-7, err_msg=tag)
+            if cpu.enable_icm:                                             # ppo.py:2213-2214: the ICM pass follows each PPO epoch
+                loss = cpu.icm_train_epoch(perm=pi[g["icm_epoch_perms"][icm_ep]])
+                np.testing.assert_allclose(loss, g["icm_epoch_stats"][icm_ep][0], rtol=5e-6, err_msg=f"icm loss {it}/{e}")
+                icm_ep += 1
+    for tag in ("actor", "critic") + (("icm",) if cpu.enable_icm else ()):
+        got, want = final_params(g, tag, cpu)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7, err_msg=tag)
     vs = cpu.value_stats
     np.testing.assert_allclose([vs.mean, vs.variance, vs.count], g["value_stats"], rtol=1e-6)
+    if filters is not None:                    # running statistics of the wrappers after the last rollout
+        pre = "filter_ObservationNormalizer_actor_running_stats_agent0_"
+        st = orc.obs_norm.stats[0]
+        np.testing.assert_allclose(st.mean, g[pre + "mean"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(st.variance, g[pre + "var"], rtol=1e-6)
+        np.testing.assert_allclose(st.count, g[pre + "count"][0], rtol=1e-9)
+        pre = "filter_RewardNormalizer_running_stats_agent0_"
+        st = orc.rew_norm.stats[0]
+        np.testing.assert_allclose([st.mean, st.variance, st.count], [g[pre + "mean"], g[pre + "var"], g[pre + "count"][0]], rtol=1e-6)
+        np.testing.assert_allclose(orc.rew_norm.running_reward[0], g["filter_RewardNormalizer_running_reward_agent0"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_rollout_statistics_oracle_reproduces_the_reference_status_block(golden, name):
+    """ppo.py:1600-1631, 1756-2099: the literal statistics loop of the oracle on the per-step streams the reference
+    saw, against the status_dict the reference published after each rollout."""
+    g = golden(name)
+    c = _cfg(g)
+    E, T, A = c["E"], c["T"], c["A"]
+    keys, rkeys, gkeys = (list(g[k]) for k in ("rollout_status_keys", "rollout_range_keys", "global_status_keys"))
+    running_obs, top_nat, episodes = (np.inf, -np.inf), -np.inf, 0.0
+    calls_step = g["values_calls_step"]
+    for it in range(c["iterations"]):
+        sl = slice(it * T, (it + 1) * T)
+        term = g["term_table"]
+        ep_ts, boot = np.zeros(E, np.int64), np.zeros((T, E), bool)
+        for t in range(T):                                                  # ppo.py:1863-1877
+            ep_ts += 1
+            ep_ts[term[t]] = 0
+            cut = (ep_ts >= c["max_ts_per_ep"]) | (t == T - 1)
+            boot[t] = cut & ~term[t]
+            ep_ts[cut] = 0
+        # bootstrap rewards of the whole batch at every cut: the SECOND value call of a step (before the surprise)
+        next_reward = np.zeros((T, E, A))
+        seen = set()
+        for i, st in enumerate(calls_step):
+            if st in seen and it * T < st <= (it + 1) * T:
+                next_reward[st - 1 - it * T] = g["values_calls"][i]
+            seen.add(st)
+        sq = (lambda x: x[..., 0]) if A == 1 else (lambda x: x)
+        mm = g["step_next_obs_minmax"][sl]
+        st = rollout_statistics_loop(sq(g["step_rewards"][sl]), sq(g["step_natural_rewards"][sl]), sq(g["step_intr_rewards"][sl]),
+                                     mm[:, 0], mm[:, 1], term, boot, sq(next_reward), max_ts=c["max_ts_per_ep"])
+        if "filters" not in SCENARIOS[name]:                                # ppo.py:2010-2017: a running range without normalize_obs
+            running_obs = (min(running_obs[0], st["obs range"][0]), max(running_obs[1], st["obs range"][1]))
+            st["obs range"] = running_obs
+        top_nat = max(top_nat, st["top natural reward"]); st["top natural reward"] = top_nat
+        episodes += st["total episodes"]
+        for k in keys:
+            np.testing.assert_allclose(st[k], g["rollout_status"][it][keys.index(k)], rtol=1e-6, atol=1e-9, err_msg=f"{k} it {it}")
+        for k in rkeys:
+            np.testing.assert_allclose(st[k], g["rollout_ranges"][it][rkeys.index(k)], rtol=1e-6, atol=1e-9, err_msg=f"{k} it {it}")
+        gs = dict(zip(gkeys, g["global_status"][it]))
+        np.testing.assert_allclose(episodes, gs["total episodes"], rtol=1e-9)
+        for k in ("longest episode", "shortest episode", "average episode"):
+            np.testing.assert_allclose(st[k], gs[k], rtol=1e-9, err_msg=f"{k} it {it}")
+        assert gs["timesteps"] == (it + 1) * E * T
