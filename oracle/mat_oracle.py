@@ -202,8 +202,13 @@ class CpuMATPPO:
                 ir = ir.reshape(E, A)
         return ir.numpy() * np.float32(self.intr_reward_weight)
 
-    def rollout(self, obs_table, reward_table, actions, slot_order=None):
+    def rollout(self, obs_table, reward_table, actions, slot_order=None, dataset_slot_of=None):
         """
+        dataset_slot_of (quirk Q14, pinned by fixture g12_c5_mat): PPO.rollout creates the dataset BEFORE it reshuffles
+        the policy's agents (ppo.py:1546-1547 vs 1643-1644; PPOSharedEpisodeDataset keeps the agent_ids array it was
+        given, episode_info.py:1012), so the dataset's agent axis is in the PREVIOUS rollout's slot order while the
+        networks saw this rollout's.  dataset_slot_of[j] = the rollout slot whose agent sits in dataset slot j.
+
         obs_table [T+1,E,A,O], reward_table [T,E,A], actions [T,E,A] (recorded).  Fixed-length: every env's
         shared episode closes at the last step with the critic bootstrap; dataset rows are env-major
         (episode_info.py:584-637), each row [A, .].  slot_order[j] = original index of the agent in slot j
@@ -237,6 +242,10 @@ class CpuMATPPO:
                                         nr, self.gamma, self.lambd, self.clip, True)
                 adv[e * T:(e + 1) * T, a] = ad; rtg[e * T:(e + 1) * T, a] = rg
         flat = lambda x: np.concatenate([x[:, e] for e in range(E)], axis=0)
+        if dataset_slot_of is not None:
+            k = np.asarray(dataset_slot_of)
+            obs_table, actions, vals, logps = obs_table[:, :, k], actions[:, :, k], vals[:, :, k], logps[:, :, k]
+            adv, rtg = adv[:, k], rtg[:, k]
         self.dataset = _SharedDataset(torch.tensor(flat(obs_table[:-1])), torch.tensor(flat(actions)).long(),
                                       torch.tensor(adv), torch.tensor(flat(logps)), torch.tensor(rtg),
                                       torch.tensor(flat(vals)),
@@ -274,9 +283,13 @@ class CpuMATPPO:
             n += 1
         return total / max(n, 1)
 
-    def train_epoch(self):
-        """ppo.py:2274-2485 with MATPolicy.evaluate / update_weights (one optimiser, summed loss)."""
-        loader = DataLoader(self.dataset, batch_size=self.batch_size, shuffle=True, generator=self.loader_generator)
+    def train_epoch(self, perm=None):
+        """ppo.py:2274-2485 with MATPolicy.evaluate / update_weights (one optimiser, summed loss).
+        perm replays a recorded shuffle; self.trace (a list) collects per-mini-batch losses and raw gradients."""
+        if perm is not None:
+            loader = DataLoader(self.dataset, batch_size=self.batch_size, sampler=[int(i) for i in perm])
+        else:
+            loader = DataLoader(self.dataset, batch_size=self.batch_size, shuffle=True, generator=self.loader_generator)
         tot = dict(actor=0.0, critic=0.0, entropy=0.0, kl=0.0, n=0)
         for obs, actions, adv, logp_old, rtg, idxs in loader:
             shape = rtg.shape
@@ -290,6 +303,12 @@ class CpuMATPPO:
             self.dataset.values[idxs] = values.squeeze(-1).detach()
             r = lo.ppo_minibatch_losses(cur_lp, logp_old, adv, entropy, values, rtg, True, self.surr_clip,
                                         self.entropy_weight, use_huber=True)      # MATPolicy: use_huber_loss=True
+            if getattr(self, "trace", None) is not None:
+                ga = torch.autograd.grad(r["actor_loss"], list(self.ac.actor.parameters()), retain_graph=True)
+                gc = torch.autograd.grad(r["critic_loss"], list(self.ac.critic.parameters()), retain_graph=True)
+                self.trace.append(dict(actor=r["actor"], critic=r["critic"],
+                                       actor_grad=torch.cat([x.reshape(-1) for x in ga]).numpy(),
+                                       critic_grad=torch.cat([x.reshape(-1) for x in gc]).numpy()))
             self.optim.zero_grad()
             (r["actor_loss"] + r["critic_loss"]).backward()                       # mat_policy.py:677-699
             nn.utils.clip_grad_norm_(self.ac.parameters(), self.gradient_clip)

@@ -215,6 +215,15 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
     ppo.apply_intrinsic_rewards = rec_intr
     ppo.get_natural_reward = rec_nat
 
+    if getattr(pol, "agent_grouping", False):              # MAT: the agents' slot order is reshuffled every rollout (ppo.py:1643-1644)
+        orig_shuffle = pol.shuffle_agent_ids
+
+        def rec_shuffle():
+            orig_shuffle()
+            rec.setdefault("slot_orders", []).append(np.array([int(str(a)[len("agent"):]) for a in pol.agent_ids]))
+
+        pol.shuffle_agent_ids = rec_shuffle
+
     orig_finalize = pol.finalize_dataset
 
     def rec_finalize():
@@ -307,6 +316,8 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
     if icm_ep:
         out["icm_epoch_perms"] = np.stack([e["perm"] for e in icm_ep])
         out["icm_epoch_stats"] = np.stack([e["stats"] for e in icm_ep])
+    if "slot_orders" in rec:
+        out["slot_orders"] = np.stack(rec["slot_orders"])               # [rollouts, A]: original agent index in slot j
     mb = rec["mb"][0]
     out["mb0_losses"] = np.array([mb["actor_loss"], mb["critic_loss"]], dtype=np.float64)
     out["mb0_actor_grad"] = np.concatenate([g.reshape(-1) for g in mb["actor_grads"]])
@@ -393,6 +404,15 @@ def scenarios():
     sc["g12_c2_icm"] = dict(seed=108, E=6, T=16, A=1, O=4, action_space=Discrete(2), reward="ones", term_prob=0.0,
                             max_ts_per_ep=8, batch_size=32, epochs=2, iterations=2,
                             policy_args=dict(enable_icm=True))
+    # C5: MATPolicy (embedding 64, 1 block, 1 head), 3 agents, critic view "local"
+    # (baselines/pettingzoo/mpe_simple_spread.py:40-92); fixed-length shared episodes
+    from ppo_and_friends.policies.mat_policy import MATPolicy
+    import ppo_and_friends.networks.actor_critic.multi_agent_transformer as mat
+    # envs_per_proc = 1: the reference's autoregressive rollout assigns [E,1,1] tensors into [E,1] slices
+    # (policies/mat_policy.py:476-479), which only broadcasts for E = 1 (quirk Q13)
+    sc["g12_c5_mat"] = dict(seed=109, E=1, T=40, A=3, O=18, action_space=Discrete(5), reward="uniform", term_prob=0.0,
+                            batch_size=16, epochs=2, iterations=2, critic_view="local", policy_class=MATPolicy,
+                            ac_network=mat.MATActorCritic, policy_args=dict(mat_kw_args={"embedding size": 64}))
     return sc
 
 
