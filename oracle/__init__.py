@@ -8,12 +8,11 @@ from here, and only as the checker / reported baseline -- never as the product
 path.  The product (ppo_and_friends_amd/) has no import of this package and
 fails loudly if its HIP library is missing.
 
-Pinning status (see DESIGN.md "Oracle"):
-  * episode_info_oracle, running_stats_oracle, attention_oracle: PINNED against
-    outputs of the unmodified reference modules run in the build container
-    (tests/golden/*.npz, generator tests/golden/make_golden.py).
-  * ppo_loss_oracle, distributions_oracle, icm_oracle: the reference modules
-    import `gymnasium`, which this image lacks, and the reference's own tests
-    hold no numeric vectors for them -> restated from text; "parity unpinned"
-    beyond torch's own primitives (MSELoss/HuberLoss/Categorical/Normal).
+Pinning status (see DESIGN.md "Oracle"): every module is PINNED against outputs of the unmodified reference
+run in the build container (tests/golden/*.npz):
+  * episode_info_oracle, running_stats_oracle, attention blocks, network init:   g1-g7 (make_golden.py)
+  * ppo_loss_oracle, cpu_ppo_loop, icm_oracle, filter_oracle, lstm_oracle, mat_oracle, rollout_stats_oracle:
+    g8-g13 (make_golden_update.py): unit vectors plus whole iterations of the reference's own PPO object over a
+    table-driven env (the reference imports here with single-rank `mpi4py` and metadata-only `gymnasium` stand-ins,
+    tests/golden/ref_import.py).  Still restated from text only: the ICM-for-MAT branches of mat_oracle.
 """

@@ -14,8 +14,11 @@ dataset build (:815-887), torch DataLoader(shuffle=True) over per-sample
 value normaliser on every mini-batch (ppo.py:2299-2303), per-network backward /
 clip_grad_norm_ / Adam(eps=1e-5) (ppo_policy.py:1032-1055).
 
-"parity unpinned" for the update half (see oracle/ppo_loss_oracle.py); the buffer
-half is pinned through oracle/episode_info_oracle.py.
+PINNED end to end by the g12_* fixtures: the unmodified reference's own PPO object driven for whole iterations
+over a table-driven env (tests/golden/make_golden_update.py); this port reproduces its datasets, first-mini-batch
+losses and raw gradients, per-epoch statistics, final weights and value-normaliser state for the C2 / C3 / C4
+layer shapes, the tanh-Gaussian head, ICM and the filter stack (tests/test_oracle_update_golden.py).  The buffer
+half is additionally pinned bit-exact through oracle/episode_info_oracle.py (g1-g3).
 """
 import time
 

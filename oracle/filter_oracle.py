@@ -13,10 +13,9 @@ Follows /root/reference/environments/filter_wrappers.py:
   wiring order           wrapper_utils.py:81-111: obs normaliser -> obs clipper -> reward normaliser
                                     -> reward clipper; "terminal observation" entries stay unfiltered.
 
-PINNING: the wrapper classes route through `gymnasium`, which this image lacks, so they cannot be
-imported to generate vectors.  RunningMeanStd.update/_integrate_batch_data underneath IS pinned
-(tests/golden/g4); the arithmetic around it is restated from the text -- "parity unpinned" for the
-wrapper layer.
+PINNED by fixtures recorded from the unmodified wrapper classes: g13_filters (the stack of wrapper_utils.py:81-111
+stand-alone: 2 agents, terminations, two passes; per-step observations / critic observations / rewards and the
+final running statistics) and g12_c3_full (the stack inside whole PPO iterations); RunningMeanStd underneath by g4.
 
 `gathered` (a list of per-rank inputs) reproduces the comm.allgather of the raw data inside
 RunningMeanStd.update (stats.py:47-50) for the R > 1 tests.

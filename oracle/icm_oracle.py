@@ -1,7 +1,7 @@
 """
 TEST INFRASTRUCTURE (see oracle/__init__.py) -- torch-CPU restatement of the reference's ICM.
-"parity unpinned": networks/ppo_networks/icm.py imports `gymnasium` (absent here) and the reference
-holds no numeric vectors for it; restated from text on torch primitives.
+PINNED by fixtures recorded from the unmodified reference: g10_icm (forward outputs + every parameter gradient,
+discrete and continuous) and g12_c2_icm / g12_c3_full (rollout rewards, training epochs, final weights).
 
   ObsEncoder   <- LinearObservationEncoder   networks/encoders.py:9-56
   InverseModel <- LinearInverseModel         networks/ppo_networks/icm.py:22-114
@@ -38,16 +38,20 @@ class ObsEncoder(nn.Module):
 
 class ICM(nn.Module):
     def __init__(self, obs_size, act_size, discrete, reward_scale=0.01, out_init=1.0, enc=128, hidden=128, depth=2,
-                 nvec=None):
-        """nvec: the MultiDiscrete class counts of an agent-shared ICM (act_size = sum(nvec)); icm.py:322-324."""
+                 nvec=None, enc_hidden=None, inv_depth=None, fwd_depth=None):
+        """nvec: the MultiDiscrete class counts of an agent-shared ICM (act_size = sum(nvec)); icm.py:322-324.
+        enc_hidden / inv_depth / fwd_depth: encoder_hidden_size, inverse_hidden_depth, forward_hidden_depth when they
+        differ from `hidden` / `depth` (icm.py:228-240)."""
         super().__init__()
         self.discrete, self.act_size, self.reward_scale = discrete, act_size, reward_scale
         self.nvec = None if nvec is None else [int(n) for n in nvec]
-        self.obs_encoder = ObsEncoder(obs_size, enc, out_init, hidden)
+        self.obs_encoder = ObsEncoder(obs_size, enc, out_init, hidden if enc_hidden is None else enc_hidden)
         self.inv_model = nn.Module()
-        self.inv_model.sequential_net = make_mlp(2 * enc, act_size, hidden, depth, out_gain=out_init)
+        self.inv_model.sequential_net = make_mlp(2 * enc, act_size, hidden, depth if inv_depth is None else inv_depth,
+                                                 out_gain=out_init)
         self.forward_model = nn.Module()
-        self.forward_model.sequential_net = make_mlp(enc + act_size, enc, hidden, depth, out_gain=out_init)
+        self.forward_model.sequential_net = make_mlp(enc + act_size, enc, hidden, depth if fwd_depth is None else fwd_depth,
+                                                     out_gain=out_init)
 
     def forward(self, obs_1, obs_2, actions):
         e1, e2 = self.obs_encoder(obs_1), self.obs_encoder(obs_2)

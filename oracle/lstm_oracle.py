@@ -1,8 +1,9 @@
 """
 TEST INFRASTRUCTURE (see oracle/__init__.py) -- torch-CPU restatement of the reference's LSTM policy
-path, with the reference's list-based loop structure.  "parity unpinned": the modules involved import
-`gymnasium` (absent here) and the reference holds no numeric vectors for them; restated from text on
-torch primitives (nn.LSTM, LayerNorm, Categorical, Adam).
+path, with the reference's list-based loop structure, on torch primitives (nn.LSTM, LayerNorm, Categorical, Adam).
+PINNED by fixtures g12_lstm_term / g12_lstm_cut recorded from the unmodified reference's PPO object with
+LSTMNetwork actor / critic: logged hidden states, windows, masks, epochs with hand-over + write-back, final weights
+(tests/test_oracle_update_golden.py).
 
   LSTMNet                 <- LSTMNetwork.forward            networks/ppo_networks/lstm.py:13-127,
                              PPOLSTMNetwork                 networks/ppo_networks/base.py:136-185
@@ -176,8 +177,8 @@ class CpuLSTMPPO(CpuPPO):
         self.dataset = SequenceDataset(finished, self.S)
         return self.dataset
 
-    def train_epoch(self):
-        loader = DataLoader(self.dataset, batch_size=self.batch_size, shuffle=True, generator=self.loader_generator)
+    def train_epoch(self, perm=None):
+        loader = self._loader(perm)
         tot = dict(actor=0.0, critic=0.0, entropy=0.0, kl=0.0, n=0)
         ds = self.dataset
         for batch in loader:

@@ -4,11 +4,13 @@ multi-agent transformer path.
 
   SelfAttention / Encoding / Decoding blocks <- networks/attention.py:13-257        PINNED (golden g5)
   MATActor / MATCritic / MATActorCritic      <- networks/actor_critic/multi_agent_transformer.py:22-373
-  evaluate_actions / tokened action block    <- policies/mat_policy.py:308-439      "parity unpinned"
+  evaluate_actions / tokened action block    <- policies/mat_policy.py:308-439
   shared-episode dataset + update            <- utils/episode_info.py:485-644,990-1084 (layout PINNED: g3),
                                                 ppo.py:2274-2485, mat_policy.py:677-699
 
-The MAT modules import `gymnasium` in the reference (not importable here): restated from text.
+The policy loop is PINNED by fixture g12_c5_mat (the unmodified reference's PPO object with MATPolicy at the C5
+shapes: rollout log-probs / values, shared dataset incl. quirk Q14, first-mini-batch losses + gradients, epochs,
+final weights; tests/test_oracle_update_golden.py).  The ICM-for-MAT branches stay restated from text.
 """
 import math
 

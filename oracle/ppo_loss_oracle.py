@@ -2,13 +2,12 @@
 TEST INFRASTRUCTURE (see oracle/__init__.py) -- torch-CPU float32 restatement of
 the reference's mini-batch loss, distributions and optimiser tail.
 
-"parity unpinned": the reference modules holding this arithmetic (ppo.py,
-networks/distributions.py, policies/ppo_policy.py) import `gymnasium`, absent
-from this image, and the reference's own tests carry no numeric vectors for
-them.  The restatement follows the reference text line by line and leans on
-torch's own primitives (the same third-party code the reference calls):
-torch.distributions.Categorical / Normal, nn.MSELoss / nn.HuberLoss,
-nn.utils.clip_grad_norm_, torch.optim.Adam.
+PINNED by fixtures recorded from the unmodified reference (tests/golden/make_golden_update.py; the reference
+imports here with a metadata-only `gymnasium` stand-in): g8_distributions (log-probs, entropies, their gradients,
+refine_*), g12_* (first-mini-batch losses + raw gradients, per-epoch statistics, weights after the optimiser
+steps) -- tests/test_oracle_update_golden.py.  The restatement follows the reference text line by line on torch's
+own primitives (the same third-party code the reference calls): torch.distributions.Categorical / Normal,
+nn.MSELoss / nn.HuberLoss, nn.utils.clip_grad_norm_, torch.optim.Adam.
 
   ppo_minibatch_losses   <- PPO._ppo_batch_train              ppo.py:2325-2438
   categorical_*          <- CategoricalDistribution           networks/distributions.py:199-269

@@ -232,6 +232,9 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
         d = dict(observations=ds.observations, next_observations=ds.next_observations,
                  critic_observations=ds.critic_observations, actions=ds.actions, raw_actions=ds.raw_actions,
                  advantages=ds.advantages, log_probs=ds.log_probs, rewards_to_go=ds.rewards_to_go, values=ds.values)
+        if getattr(pol, "using_lstm", False):
+            d.update(actor_hidden=ds.actor_hidden, actor_cell=ds.actor_cell, critic_hidden=ds.critic_hidden,
+                     critic_cell=ds.critic_cell)
         rec["datasets"].append({k: v.detach().cpu().numpy().copy() for k, v in d.items()} | {"ep_lens": np.array(ds.ep_lens)})
 
     pol.finalize_dataset = rec_finalize
@@ -365,6 +368,157 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
     return out
 
 
+
+# ------------------------------------------------------------------------------------------------
+# small unit fixtures: g8 distributions, g9 value normaliser, g10 ICM forward / backward, g13 filter wrappers
+# ------------------------------------------------------------------------------------------------
+def gen_g8_distributions():
+    """networks/distributions.py:199-269 (Categorical), :441-694 (tanh-Gaussian) on fixed inputs."""
+    import ppo_and_friends.networks.distributions as D
+    from gymnasium.spaces import Box, Discrete
+    out = {}
+    g = torch.Generator().manual_seed(8)
+    # Categorical: softmax output_func (:1043-1045) -> Categorical(probs): log_prob, entropy, refine_prediction
+    for tag, (n, k) in {"c2": (64, 2), "c5": (96, 5), "c17": (10, 17)}.items():
+        dist, output_func = D.get_actor_distribution(Discrete(k))
+        logits = torch.randn(n, k, generator=g) * 3.0
+        logits[0] = 40.0 * torch.nn.functional.one_hot(torch.tensor(0), k) - 20.0          # a saturated row
+        actions = torch.randint(0, k, (n, 1), generator=g)
+        probs = output_func(logits.clone()).requires_grad_(False)
+        lg = logits.clone().requires_grad_(True)
+        td = dist.get_distribution(output_func(lg))
+        lp = dist.get_log_probs(td, actions)
+        ent = dist.get_entropy(td, output_func(lg))
+        glp, = torch.autograd.grad(lp.sum(), lg, retain_graph=True)
+        gent, = torch.autograd.grad(ent.sum(), lg)
+        out.update({f"{tag}_logits": logits.numpy(), f"{tag}_actions": actions.numpy(), f"{tag}_probs": probs.numpy(),
+                    f"{tag}_log_probs": lp.detach().numpy(), f"{tag}_entropy": ent.detach().numpy(),
+                    f"{tag}_dlogp_dlogits": glp.numpy(), f"{tag}_dent_dlogits": gent.numpy(),
+                    f"{tag}_refined": dist.refine_prediction(probs).numpy()})
+    # Gaussian: per-dimension bounds, min_std clamp, +-100 clamp, tanh correction, entropy := -log_prob(mean)
+    for tag, (lo, hi) in {"unit": ([-1.0] * 6, [1.0] * 6), "bounds": ([-1.0, -2.0, 0.0], [1.0, 2.0, 5.0])}.items():
+        space = Box(np.array(lo, np.float32), np.array(hi, np.float32))
+        dist, _ = D.get_actor_distribution(space)
+        n, d = 48, len(lo)
+        mean = (torch.randn(n, d, generator=g) * 1.5).requires_grad_(True)
+        raw = torch.randn(n, d, generator=g) * 2.0
+        raw[0] = 9.0                                                                      # tanh' below the 1e-6 clamp
+        raw[1, 0] = 60.0                                                                  # normal log-prob below the -100 clamp
+        with torch.no_grad():
+            dist.log_std.copy_(torch.linspace(-6.0, 0.5, d))                              # first dims hit min_std = 0.01
+        td = dist.get_distribution(mean)
+        lp = dist.get_log_probs(td, raw)
+        ent = dist.get_entropy(td, mean)
+        gm, gs = torch.autograd.grad(lp.sum(), [mean, dist.log_std], retain_graph=True)
+        em, es = torch.autograd.grad(ent.sum(), [mean, dist.log_std])
+        out.update({f"g_{tag}_low": np.array(lo, np.float32), f"g_{tag}_high": np.array(hi, np.float32),
+                    f"g_{tag}_mean": mean.detach().numpy(), f"g_{tag}_raw": raw.numpy(),
+                    f"g_{tag}_log_std": dist.log_std.detach().numpy().copy(), f"g_{tag}_std": td.stddev[0].detach().numpy(),
+                    f"g_{tag}_log_probs": lp.detach().numpy(), f"g_{tag}_entropy": ent.detach().numpy(),
+                    f"g_{tag}_dlogp_dmean": gm.numpy(), f"g_{tag}_dlogp_dlogstd": gs.numpy(),
+                    f"g_{tag}_dent_dmean": em.numpy(), f"g_{tag}_dent_dlogstd": es.numpy(),
+                    f"g_{tag}_refined_sample": dist.refine_sample(raw).numpy(),
+                    f"g_{tag}_refined_prediction": dist.refine_prediction(mean.detach()).numpy()})
+    return out
+
+
+def gen_g9_value_normalizer():
+    """utils/misc.py:61-128: RunningStatNormalizer.normalize (update + normalise) / denormalize sequences."""
+    from ppo_and_friends.utils.misc import RunningStatNormalizer
+    out = {}
+    rng = np.random.default_rng(9)
+    vn = RunningStatNormalizer("value_normalizer", torch.device("cpu"))
+    out["denorm_fresh"] = vn.denormalize(torch.tensor([0.5, -1.0, 3.0])).numpy()
+    for i, (n, s, m) in enumerate(((256, 1.0, 0.0), (256, 4.0, 12.0), (31, 0.05, -3.0), (1, 1.0, 7.0))):
+        x = torch.tensor((rng.standard_normal(n) * s + m).astype(np.float32))
+        y = vn.normalize(x)
+        probe = torch.tensor(rng.standard_normal(8).astype(np.float32))
+        out[f"in{i}"], out[f"norm{i}"], out[f"probe{i}"] = x.numpy(), y.numpy(), probe.numpy()
+        out[f"denorm{i}"] = vn.denormalize(probe).numpy()
+        out[f"norm_noupdate{i}"] = vn.normalize(probe, update_stats=False).numpy()
+        rs = vn.running_stats
+        out[f"state{i}"] = np.array([rs.mean, rs.variance, rs.count], dtype=np.float64)
+    return out
+
+
+def gen_g10_icm():
+    """networks/ppo_networks/icm.py:22-430: ICM.forward (intrinsic reward, inverse loss, forward loss) and the
+    gradients of the training loss ppo.py:2547-2548 w.r.t. every parameter; small widths keep the fixture small."""
+    from ppo_and_friends.networks.ppo_networks.icm import ICM
+    from gymnasium.spaces import Box, Discrete
+    out = {}
+    for tag, (O, space, kw) in {
+            "disc": (6, Discrete(3), dict(encoded_obs_dim=32, encoder_hidden_size=32, inverse_hidden_size=32, forward_hidden_size=32)),
+            "cont": (17, Box(-1.0, 1.0, (6,), np.float32), dict(encoded_obs_dim=32, encoder_hidden_size=64, inverse_hidden_size=32,
+                                                                forward_hidden_size=32, inverse_hidden_depth=3, forward_hidden_depth=1))}.items():
+        torch.manual_seed(10)
+        icm = ICM(obs_space=Box(-np.inf, np.inf, (O,), np.float32), action_space=space, name="icm", **kw)
+        n = 40
+        o1, o2 = torch.randn(n, O), torch.randn(n, O)
+        act = torch.randint(0, 3, (n, 1)) if tag == "disc" else torch.tanh(torch.randn(n, 6))
+        intr, inv_loss, f_loss = icm(o1, o2, act)
+        loss = (1.0 - 0.8) * f_loss + 0.8 * inv_loss
+        grads = torch.autograd.grad(loss, list(icm.parameters()))
+        for k, v in icm.state_dict().items():
+            out[f"{tag}_p_{k}"] = v.detach().numpy().copy()
+        out[f"{tag}_names"] = np.array([k for k, _ in icm.named_parameters()])
+        for (k, _), gr in zip(icm.named_parameters(), grads):
+            out[f"{tag}_g_{k}"] = gr.numpy()
+        out.update({f"{tag}_obs1": o1.numpy(), f"{tag}_obs2": o2.numpy(), f"{tag}_actions": act.numpy(),
+                    f"{tag}_intr": intr.detach().numpy(), f"{tag}_losses": np.array([inv_loss.item(), f_loss.item(), loss.item()])})
+    return out
+
+
+def gen_g13_filters():
+    """environments/filter_wrappers.py:113-719 stand-alone: 2 agents x 5 envs through ObservationNormalizer ->
+    ObservationClipper -> RewardNormalizer (quirk Q3) -> RewardClipper (wrapper_utils.py:81-111) for 12 steps with
+    terminations, then a second pass after a hard reset."""
+    from ppo_and_friends.environments.wrapper_utils import wrap_environment
+    from gymnasium.spaces import Discrete
+    TableEnv = table_env_class()
+    E, T, A, O = 5, 12, 2, 3
+    tables = make_tables(13, T, E, A, O, "uniform", 0.15, obs_scale=2.5, obs_shift=-1.0)
+    counter = {"n": 0}
+    pmap = lambda a: "agent"
+
+    def env_generator():
+        e = max(counter["n"] - 1, 0)
+        counter["n"] += 1
+        return TableEnv(tables, e, Discrete(2), A, critic_view="policy", policy_mapping_fn=pmap)
+
+    env = wrap_environment(env_generator, pmap, {}, envs_per_proc=E, random_seed=1, normalize_obs=True,
+                           normalize_rewards=True, obs_clip=(-1.5, 1.5), reward_clip=(-1.0, 1.0), gamma=0.99)
+    out = {"obs_table": tables[0], "reward_table": tables[1], "term_table": tables[2], "cfg": np.array([E, T, A, O])}
+    agents = [f"agent{a}" for a in range(A)]
+    stack = lambda d: np.stack([np.asarray(d[a]) for a in agents], 1)
+    for p in range(2):
+        obs, cobs = env.reset()
+        f_obs, f_cobs, f_rew, nat = [stack(obs)], [stack(cobs)], [], []
+        for t in range(T):
+            acts = {a: np.zeros((E, 1), dtype=np.int64) for a in agents}
+            obs, cobs, rew, term, trunc, info = env.step(acts)
+            f_obs.append(stack(obs)); f_cobs.append(stack(cobs)); f_rew.append(stack(rew)[..., 0])
+            nat.append(np.stack([[float(info[a][e]["natural reward"]) for a in agents] for e in range(E)]))
+        out[f"p{p}_obs"], out[f"p{p}_critic_obs"] = np.stack(f_obs), np.stack(f_cobs)      # [T+1, E, A, .]
+        out[f"p{p}_rewards"], out[f"p{p}_natural"] = np.stack(f_rew), np.stack(nat)        # [T, E, A]
+    w = env
+    while w is not None and hasattr(w, "env"):
+        cls = type(w).__name__
+        for attr in ("actor_running_stats", "critic_running_stats", "running_stats"):
+            val = getattr(w, attr, None)
+            if isinstance(val, dict):
+                for a, rs in val.items():
+                    out[f"{cls}_{attr}_{a}_mean"] = np.asarray(rs.mean, dtype=np.float64)
+                    out[f"{cls}_{attr}_{a}_var"] = np.asarray(rs.variance, dtype=np.float64)
+                    out[f"{cls}_{attr}_{a}_count"] = np.array([rs.count], dtype=np.float64)
+        w = w.env
+    return out
+
+
+UNIT_FIXTURES = {"g8_distributions": gen_g8_distributions, "g9_value_normalizer": gen_g9_value_normalizer,
+                 "g10_icm": gen_g10_icm, "g13_filters": gen_g13_filters}
+
+
 def scenarios():
     from gymnasium.spaces import Box, Discrete
     import torch.nn as nn
@@ -413,6 +567,16 @@ def scenarios():
     sc["g12_c5_mat"] = dict(seed=109, E=1, T=40, A=3, O=18, action_space=Discrete(5), reward="uniform", term_prob=0.0,
                             batch_size=16, epochs=2, iterations=2, critic_view="local", policy_class=MATPolicy,
                             ac_network=mat.MATActorCritic, policy_args=dict(mat_kw_args={"embedding size": 64}))
+    # LSTM actor / critic (networks/ppo_networks/lstm.py:13-127): sequence windows with terminal masks, hidden-state
+    # hand-over and write-back (episode_info.py:775-809,954-987; ppo.py:2312-2319,2450-2466)
+    from ppo_and_friends.networks.ppo_networks.lstm import LSTMNetwork
+    lstm_kw = lambda S: dict(sequence_length=S, lstm_hidden_size=32, ff_hidden_size=32)
+    sc["g12_lstm_term"] = dict(seed=110, E=5, T=20, A=1, O=4, action_space=Discrete(2), reward="uniform", term_prob=0.08,
+                               batch_size=24, epochs=2, iterations=2, ac_network=LSTMNetwork,
+                               policy_args=dict(actor_kw_args=lstm_kw(4), critic_kw_args=lstm_kw(4)))
+    sc["g12_lstm_cut"] = dict(seed=111, E=4, T=18, A=1, O=4, action_space=Discrete(3), reward="uniform", term_prob=0.0,
+                              max_ts_per_ep=6, batch_size=16, epochs=2, iterations=1, ac_network=LSTMNetwork,
+                              policy_args=dict(actor_kw_args=lstm_kw(3), critic_kw_args=lstm_kw(3)))
     return sc
 
 
@@ -420,6 +584,13 @@ def main():
     only = set(sys.argv[1:])
     scratch = ref_import.make_scratch()
     try:
+        for name, fn in UNIT_FIXTURES.items():
+            if only and name not in only:
+                continue
+            out = fn()
+            path = os.path.join(HERE, name + ".npz")
+            np.savez_compressed(path, **out)
+            print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} B")
         for name, cfg in scenarios().items():
             if only and name not in only:
                 continue

@@ -11,6 +11,10 @@ import torch
 
 from oracle import cpu_ppo_loop
 from oracle import filter_oracle
+from oracle import icm_oracle
+from oracle import lstm_oracle
+from oracle import ppo_loss_oracle as plo
+from oracle import running_stats_oracle as rso
 from oracle import mat_oracle
 from oracle.rollout_stats_oracle import rollout_statistics_loop
 
@@ -288,3 +292,147 @@ def test_cpu_mat_port_reproduces_the_reference_mat_iterations(golden):
         np.testing.assert_allclose(p.detach().numpy(), final[k], rtol=1e-5, atol=1e-7, err_msg=k)
     vs = cpu.value_stats
     np.testing.assert_allclose([vs.mean, vs.variance, vs.count], g["value_stats"], rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,S,n_act", [("g12_lstm_term", 4, 2), ("g12_lstm_cut", 3, 3)])
+def test_cpu_lstm_port_reproduces_the_reference_lstm_iterations(golden, name, S, n_act):
+    """LSTMNetwork actor / critic through the reference's own PPO object: per-step hidden states logged (zeroed at
+    terminations), sequence windows + terminal masks, hidden-state hand-over per mini-batch and write-back, the extra
+    stateful critic step at episode cuts -- against oracle/lstm_oracle.CpuLSTMPPO."""
+    g = golden(name)
+    c = _cfg(g)
+    E, T, B = c["E"], c["T"], c["batch_size"]
+    cpu = lstm_oracle.CpuLSTMPPO(c["O"], n_act, sequence_length=S, lstm_hidden=32, ff_hidden=32, batch_size=B, seed=0,
+                                 rtg_accum="float32")
+    for net, tag in ((cpu.actor, "init_actor."), (cpu.critic, "init_critic.")):
+        net.load_state_dict({k[len(tag):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag)})
+    obs_table, rew_table, term = g["obs_table"][:, :, 0], g["reward_table"][:, :, 0], g["term_table"]
+    tol = dict(rtol=1e-6, atol=1e-6)
+    ep = 0
+    for it in range(c["iterations"]):
+        ds = cpu.rollout(obs_table, rew_table, g["step_actions"][it * T:(it + 1) * T, :, 0],
+                         term_table=term if term.any() else None, max_ts_per_ep=c["max_ts_per_ep"])
+        pre = f"it{it}_ds_"
+        np.testing.assert_array_equal(ds.observations.numpy(), g[pre + "observations"])
+        np.testing.assert_allclose(ds.values.numpy(), g[pre + "values"], **tol)
+        np.testing.assert_allclose(ds.log_probs.numpy().reshape(-1), g[pre + "log_probs"].reshape(-1), **tol)
+        np.testing.assert_allclose(ds.rewards_to_go.numpy(), g[pre + "rewards_to_go"], **tol)
+        np.testing.assert_allclose(ds.advantages.numpy(), g[pre + "advantages"], **tol)
+        for k in ("actor_hidden", "actor_cell", "critic_hidden", "critic_cell"):
+            np.testing.assert_allclose(getattr(ds, k).numpy(), g[pre + k], err_msg=k, **tol)
+        assert len(ds) == g["epoch_perms"].shape[1] == E * T - (S - 1)
+        for e in range(c["epochs"]):
+            # the recorded shuffles are the 13th tuple entries, i.e. sampler index + (S - 1) (episode_info.py:960-962)
+            r = cpu.train_epoch(perm=g["epoch_perms"][ep] - (S - 1))
+            got = np.array([r["actor loss"], r["critic loss"], r["kl avg"], r["weighted entropy"]])
+            np.testing.assert_allclose(got, g["epoch_stats"][ep], rtol=5e-6, atol=1e-6, err_msg=f"iteration {it} epoch {e}")
+            ep += 1
+    for net, tag in ((cpu.actor, "final_actor."), (cpu.critic, "final_critic.")):
+        for k, p in net.named_parameters():
+            np.testing.assert_allclose(p.detach().numpy(), g[tag + k], rtol=1e-5, atol=1e-7, err_msg=tag + k)
+    vs = cpu.value_stats
+    np.testing.assert_allclose([vs.mean, vs.variance, vs.count], g["value_stats"], rtol=2e-6, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------- unit fixtures g8 / g9 / g10 / g13
+@pytest.mark.parametrize("tag", ["c2", "c5", "c17"])
+def test_g8_categorical_distribution(golden, tag):
+    g = golden("g8_distributions")
+    logits = torch.tensor(g[f"{tag}_logits"], requires_grad=True)
+    actions = torch.tensor(g[f"{tag}_actions"])
+    lp, ent, probs = plo.categorical_logp_entropy(logits, actions)
+    np.testing.assert_allclose(probs.detach().numpy(), g[f"{tag}_probs"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(lp.detach().numpy(), g[f"{tag}_log_probs"].reshape(-1), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(ent.detach().numpy(), g[f"{tag}_entropy"], rtol=1e-6, atol=1e-7)
+    glp, = torch.autograd.grad(lp.sum(), logits, retain_graph=True)
+    gent, = torch.autograd.grad(ent.sum(), logits)
+    np.testing.assert_allclose(glp.numpy(), g[f"{tag}_dlogp_dlogits"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(gent.numpy(), g[f"{tag}_dent_dlogits"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(torch.argmax(probs, dim=-1).numpy(), g[f"{tag}_refined"])
+
+
+@pytest.mark.parametrize("tag", ["unit", "bounds"])
+def test_g8_gaussian_distribution(golden, tag):
+    g = golden("g8_distributions")
+    mean = torch.tensor(g[f"g_{tag}_mean"], requires_grad=True)
+    log_std = torch.tensor(g[f"g_{tag}_log_std"], requires_grad=True)
+    raw = torch.tensor(g[f"g_{tag}_raw"])
+    np.testing.assert_allclose(plo.gaussian_dist(mean, log_std).stddev[0].detach().numpy(), g[f"g_{tag}_std"], rtol=1e-6)
+    lp = plo.gaussian_tanh_logp(mean, log_std, raw)
+    ent = -plo.gaussian_tanh_logp(mean, log_std, mean)                       # distributions.py:694 via ppo_policy.py:950
+    np.testing.assert_allclose(lp.detach().numpy(), g[f"g_{tag}_log_probs"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ent.detach().numpy(), g[f"g_{tag}_entropy"], rtol=1e-6, atol=1e-6)
+    gm, gs = torch.autograd.grad(lp.sum(), [mean, log_std], retain_graph=True)
+    em, es = torch.autograd.grad(ent.sum(), [mean, log_std])
+    for got, key in ((gm, "dlogp_dmean"), (gs, "dlogp_dlogstd"), (em, "dent_dmean"), (es, "dent_dlogstd")):
+        np.testing.assert_allclose(got.numpy(), g[f"g_{tag}_{key}"], rtol=1e-5, atol=1e-6, err_msg=key)
+    lo_, hi_ = g[f"g_{tag}_low"], g[f"g_{tag}_high"]
+    np.testing.assert_allclose(plo.gaussian_refine(raw, lo_, hi_).numpy(), g[f"g_{tag}_refined_sample"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(plo.gaussian_refine(mean.detach(), lo_, hi_).numpy(), g[f"g_{tag}_refined_prediction"],
+                               rtol=1e-6, atol=1e-7)
+
+
+def test_g9_value_normalizer(golden):
+    """RunningStatNormalizer (utils/misc.py:61-128) as the CPU port restates it (CpuPPO._norm_update / _denorm)."""
+    g = golden("g9_value_normalizer")
+    cpu = cpu_ppo_loop.CpuPPO(4, 2, seed=0)
+    np.testing.assert_allclose(cpu._denorm(torch.tensor([0.5, -1.0, 3.0])).numpy(), g["denorm_fresh"], rtol=1e-6)
+    for i in range(4):
+        y = cpu._norm_update(torch.tensor(g[f"in{i}"]))
+        np.testing.assert_allclose(y.numpy(), g[f"norm{i}"], rtol=1e-6, atol=1e-6)
+        probe = torch.tensor(g[f"probe{i}"])
+        np.testing.assert_allclose(cpu._denorm(probe).numpy(), g[f"denorm{i}"], rtol=1e-6, atol=1e-6)
+        vs = cpu.value_stats
+        mean, var = torch.tensor(vs.mean, dtype=torch.float32), torch.tensor(vs.variance, dtype=torch.float32)
+        np.testing.assert_allclose(((probe - mean) / torch.sqrt(var + torch.tensor([1e-8]))).numpy(), g[f"norm_noupdate{i}"],
+                                   rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose([vs.mean, vs.variance, vs.count], g[f"state{i}"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["disc", "cont"])
+def test_g10_icm_forward_and_gradients(golden, tag):
+    g = golden("g10_icm")
+    if tag == "disc":
+        icm = icm_oracle.ICM(6, 3, discrete=True, enc=32, hidden=32)
+    else:
+        icm = icm_oracle.ICM(17, 6, discrete=False, enc=32, hidden=32, enc_hidden=64, inv_depth=3, fwd_depth=1)
+    icm.load_state_dict({k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}_p_")})
+    act = torch.tensor(g[f"{tag}_actions"])
+    intr, inv_loss, f_loss = icm(torch.tensor(g[f"{tag}_obs1"]), torch.tensor(g[f"{tag}_obs2"]), act)
+    loss = (1.0 - 0.8) * f_loss + 0.8 * inv_loss                              # ppo.py:2547-2548
+    np.testing.assert_allclose(intr.detach().numpy(), g[f"{tag}_intr"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose([inv_loss.item(), f_loss.item(), loss.item()], g[f"{tag}_losses"], rtol=1e-6)
+    names = [str(n) for n in g[f"{tag}_names"]]
+    assert names == [k for k, _ in icm.named_parameters()]
+    grads = torch.autograd.grad(loss, list(icm.parameters()))
+    for k, gr in zip(names, grads):
+        np.testing.assert_allclose(gr.numpy(), g[f"{tag}_g_{k}"], rtol=1e-5, atol=1e-8, err_msg=k)
+
+
+def test_g13_filter_wrappers(golden):
+    """The wrapper stack of wrapper_utils.py:81-111 stand-alone: 2 agents sharing a policy ("policy" critic view),
+    terminations, two passes (the second starts with a hard reset that is filtered and counted again)."""
+    g = golden("g13_filters")
+    E, T, A, O = (int(x) for x in g["cfg"])
+    orc = filter_oracle.FilteredEnvOracle(A, E, O, A * O, True, True, (-1.5, 1.5), (-1.0, 1.0), gamma=0.99)
+    raw_obs, raw_cobs = agent_major(g["obs_table"]), policy_view(g["obs_table"])
+    raw_rew, term = agent_major(g["reward_table"]), np.tile(g["term_table"], (1, A))
+    tol = dict(rtol=1e-6, atol=1e-6)
+    for p in range(2):
+        o, c = orc.filter_obs(raw_obs[0], raw_cobs[0])
+        np.testing.assert_allclose(o, agent_major(g[f"p{p}_obs"])[0], **tol)
+        np.testing.assert_allclose(c, agent_major(g[f"p{p}_critic_obs"])[0], **tol)
+        for t in range(T):
+            # a finished env "resets" onto the observation it stopped on; the wrappers filter what reset() returned
+            o, c, r = orc.filter_step(raw_obs[t + 1], raw_cobs[t + 1], raw_rew[t], term[t], np.zeros(A * E, bool))
+            np.testing.assert_allclose(o, agent_major(g[f"p{p}_obs"])[t + 1], err_msg=f"obs pass {p} step {t}", **tol)
+            np.testing.assert_allclose(c, agent_major(g[f"p{p}_critic_obs"])[t + 1], err_msg=f"critic obs pass {p} step {t}", **tol)
+            np.testing.assert_allclose(r, agent_major(g[f"p{p}_rewards"])[t], err_msg=f"reward pass {p} step {t}", **tol)
+        np.testing.assert_array_equal(agent_major(g[f"p{p}_natural"]), raw_rew.astype(np.float64))
+    for a in range(A):
+        for oracle_stats, key in ((orc.obs_norm.stats[a], f"ObservationNormalizer_actor_running_stats_agent{a}_"),
+                                  (orc.cobs_norm.stats[a], f"ObservationNormalizer_critic_running_stats_agent{a}_"),
+                                  (orc.rew_norm.stats[a], f"RewardNormalizer_running_stats_agent{a}_")):
+            np.testing.assert_allclose(oracle_stats.mean, g[key + "mean"], rtol=1e-6, atol=1e-7, err_msg=key)
+            np.testing.assert_allclose(oracle_stats.variance, g[key + "var"], rtol=1e-6, err_msg=key)
+            np.testing.assert_allclose(oracle_stats.count, g[key + "count"][0], rtol=1e-9, err_msg=key)
