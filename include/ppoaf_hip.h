@@ -37,7 +37,7 @@ typedef void* ppoaf_stream_t;            /* hipStream_t */
 #define PPOAF_E_INVALID    -1            /* bad argument / unsupported shape   */
 #define PPOAF_E_LAUNCH     -2            /* hipLaunch / runtime error          */
 
-#define PPOAF_ABI_VERSION   1
+#define PPOAF_ABI_VERSION 2
 
 int         ppoaf_abi_version(void);
 const char* ppoaf_last_error(void);
@@ -246,10 +246,11 @@ int ppoaf_gaussian_tanh_eval_bwd(const float* mean, const float* log_std,
                                  float* d_mean, float* d_log_std,
                                  ppoaf_stream_t stream);
 /* Rollout: raw = mean + std * N(0,1) (Philox), action = tanh(raw) rescaled to
- * [act_lo, act_hi] (:580-609, :645-672), logp as above. */
+ * [act_lo[d], act_hi[d]] per action dimension (device float32[D]; both NULL: the
+ * unit box, no rescale) (:476-483, :580-609, :645-672), logp as above. */
 int ppoaf_gaussian_tanh_sample(const float* mean, const float* log_std,
                                int64_t n, int32_t D, float min_std,
-                               float act_lo, float act_hi,
+                               const float* act_lo, const float* act_hi,
                                uint64_t seed, uint64_t offset,
                                float* raw_out, float* action_out,
                                float* logp_out, ppoaf_stream_t stream);
@@ -393,7 +394,10 @@ typedef struct {
     ppoaf_mlp_desc_t actor, critic;
     const float* params;
     const float* obs; const float* critic_obs; int64_t E;
-    int32_t head_kind; float min_std, act_lo, act_hi;
+    int32_t head_kind; float min_std;
+    const float* act_lo; const float* act_hi;   /* Gaussian head: bounds per action dimension (device float32[D]); both NULL = [-1,1] */
+    const void* forced_raw_action;              /* NULL: sample.  Else the raw actions to log instead of sampling
+                                                   ([E] int64 / [E,D] float32): replay of a recorded rollout */
     uint64_t seed, offset;
     int32_t normalize_values, _pad;
     const float* vn_mean; const float* vn_var;
@@ -629,6 +633,7 @@ typedef struct {
     const float* vn_mean; const float* vn_var;
     int64_t* action_out; int64_t* raw_action_out; float* logp_out; float* value_out;
     float* critic_obs_copy_out; float* obs_copy_out;
+    const int64_t* forced_action;   /* NULL: sample.  Else [E, A] actions to log instead of sampling (replay) */
 } ppoaf_mat_step_args_t;
 
 int ppoaf_mat_policy_step(const ppoaf_mat_step_args_t* args, ppoaf_stream_t stream);

@@ -58,12 +58,16 @@ class PpoUpdateArgs(C.Structure):
                 ("mb_offset", C.c_int64), ("cursor_advance", C.c_int64)]
 
 
+ABI_VERSION = 2
+
+
 class PolicyStepArgs(C.Structure):
     """ppoaf_policy_step_args_t (include/ppoaf_hip.h)."""
     _fields_ = [("actor", MlpDesc), ("critic", MlpDesc), ("params", C.c_void_p),
                 ("obs", C.c_void_p), ("critic_obs", C.c_void_p), ("E", C.c_int64),
-                ("head_kind", C.c_int32), ("min_std", C.c_float), ("act_lo", C.c_float),
-                ("act_hi", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("head_kind", C.c_int32), ("min_std", C.c_float), ("act_lo", C.c_void_p),
+                ("act_hi", C.c_void_p), ("forced_raw_action", C.c_void_p),
+                ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("normalize_values", C.c_int32), ("_pad", C.c_int32),
                 ("vn_mean", C.c_void_p), ("vn_var", C.c_void_p),
                 ("raw_action_out", C.c_void_p), ("action_out", C.c_void_p),
@@ -119,7 +123,8 @@ class MatStepArgs(C.Structure):
                 ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("vn_mean", C.c_void_p), ("vn_var", C.c_void_p),
                 ("action_out", C.c_void_p), ("raw_action_out", C.c_void_p), ("logp_out", C.c_void_p),
-                ("value_out", C.c_void_p), ("critic_obs_copy_out", C.c_void_p), ("obs_copy_out", C.c_void_p)]
+                ("value_out", C.c_void_p), ("critic_obs_copy_out", C.c_void_p), ("obs_copy_out", C.c_void_p),
+                ("forced_action", C.c_void_p)]
 
 
 class ObsFilter(C.Structure):
@@ -173,8 +178,8 @@ SIGNATURES = {
                                                _ptr, _ptr, _ptr]),
     "ppoaf_gaussian_tanh_eval_bwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64, C.c_int32,
                                                C.c_float, _ptr, _ptr, _ptr]),
-    "ppoaf_gaussian_tanh_sample": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, C.c_float, C.c_float,
-                                             C.c_float, C.c_uint64, C.c_uint64, _ptr, _ptr, _ptr, _ptr]),
+    "ppoaf_gaussian_tanh_sample": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, C.c_float, _ptr,
+                                             _ptr, C.c_uint64, C.c_uint64, _ptr, _ptr, _ptr, _ptr]),
     "ppoaf_clip_adam_step": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr, _ptr,
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        _ptr, _ptr, _ptr]),
@@ -254,8 +259,8 @@ def load():
             raise PpoafError(f"{LIB_PATH} does not export {name}") from exc
         fn.restype = res
         fn.argtypes = args
-    if lib.ppoaf_abi_version() != 1:
-        raise PpoafError(f"ABI version mismatch: library {lib.ppoaf_abi_version()} != 1")
+    if lib.ppoaf_abi_version() != ABI_VERSION:
+        raise PpoafError(f"ABI version mismatch: library {lib.ppoaf_abi_version()} != {ABI_VERSION}")
     _check_single_hip_runtime()
     _lib = lib
     return lib

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void gaussian_eval_bwd_kernel(
 
 __global__ __launch_bounds__(256) void gaussian_sample_kernel(
     const float* __restrict__ mean, const float* __restrict__ log_std, long n, int D, float min_std,
-    float act_lo, float act_hi, uint64_t seed, uint64_t offset, float* __restrict__ raw_out,
+    const float* __restrict__ act_lo, const float* __restrict__ act_hi, uint64_t seed, uint64_t offset,
+    float* __restrict__ raw_out,
     float* __restrict__ action_out, float* __restrict__ logp_out) {
     const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
@@ -202,11 +203,11 @@ __global__ __launch_bounds__(256) void gaussian_sample_kernel(
             xr[d] = mean[row * D + d] + sd * z[j];
         }
     }
-    const bool rescale = (act_lo != -1.0f) || (act_hi != 1.0f);
+    const bool rescale = act_lo != nullptr;        // per-dimension bounds (distributions.py:476-483); NULL: [-1, 1]
     for (int d = 0; d < D; ++d) {
         raw_out[row * D + d] = xr[d];
         float a = tanhf(xr[d]);
-        if (rescale) a = ((a + 1.0f) / 2.0f) * (act_hi - act_lo) + act_lo;   // distributions.py:580-609
+        if (rescale) a = ((a + 1.0f) / 2.0f) * (act_hi[d] - act_lo[d]) + act_lo[d];   // distributions.py:580-609
         action_out[row * D + d] = a;
     }
     logp_out[row] = gauss_tanh_logp_row(mean + row * D, log_std, xr, D, min_std);
@@ -290,7 +291,8 @@ extern "C" int ppoaf_gaussian_tanh_eval_bwd(const float* mean, const float* log_
 }
 
 extern "C" int ppoaf_gaussian_tanh_sample(const float* mean, const float* log_std, int64_t n,
-                                          int32_t D, float min_std, float act_lo, float act_hi,
+                                          int32_t D, float min_std, const float* act_lo,
+                                          const float* act_hi,
                                           uint64_t seed, uint64_t offset, float* raw_out,
                                           float* action_out, float* logp_out,
                                           ppoaf_stream_t stream) {
@@ -299,6 +301,7 @@ extern "C" int ppoaf_gaussian_tanh_sample(const float* mean, const float* log_st
     if (n == 0) return PPOAF_OK;
     PPOAF_REQUIRE(mean && log_std && raw_out && action_out && logp_out,
                   "gaussian_tanh_sample: null pointer");
+    PPOAF_REQUIRE((act_lo == nullptr) == (act_hi == nullptr), "gaussian_tanh_sample: give both bounds or neither");
     hipLaunchKernelGGL(gaussian_sample_kernel, dim3(row_grid(n)), dim3(256), 0, (hipStream_t)stream,
                        mean, log_std, (long)n, D, min_std, act_lo, act_hi, seed, offset, raw_out,
                        action_out, logp_out);

@@ -827,6 +827,7 @@ struct MatStepDev {
     int normalize_values; const float* vn_mean; const float* vn_var;
     int64_t* action_out; int64_t* raw_action_out; float* logp_out; float* value_out;
     float* critic_obs_out; float* obs_out;
+    const int64_t* forced_action;                  // NULL: sample; else [E, L] actions to log (replay)
 };
 
 __global__ __launch_bounds__(kMT) void mat_policy_step_kernel(MatStepDev u) {
@@ -876,16 +877,21 @@ __global__ __launch_bounds__(kMT) void mat_policy_step_kernel(MatStepDev u) {
             float s2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) { p[k] *= inv; s2 += p[k]; }
-            const Philox4 rnd = philox4x32_10(u.seed, u.offset + (unsigned long long)(tok0 + tid), 0u);
-            const float uu = u32_to_unit(rnd.x) * s2;             // inverse CDF over the probability mass
             int a = NA - 1;
             float cum = 0.f, pa = 0.f;
-            bool found = false;
+            if (u.forced_action) {
+                const long fa = u.forced_action[tok0 + tid];
+                a = fa < 0 ? 0 : (fa >= NA ? NA - 1 : (int)fa);
+            } else {
+                const Philox4 rnd = philox4x32_10(u.seed, u.offset + (unsigned long long)(tok0 + tid), 0u);
+                const float uu = u32_to_unit(rnd.x) * s2;         // inverse CDF over the probability mass
+                bool found = false;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (k < NA && !found) {
-                    cum += p[k];
-                    if (uu < cum) { a = k; found = true; }
+                for (int k = 0; k < 8; ++k) {
+                    if (k < NA && !found) {
+                        cum += p[k];
+                        if (uu < cum) { a = k; found = true; }
+                    }
                 }
             }
 #pragma unroll
@@ -1067,6 +1073,7 @@ extern "C" int ppoaf_mat_policy_step(const ppoaf_mat_step_args_t* a, ppoaf_strea
     u.normalize_values = a->normalize_values; u.vn_mean = a->vn_mean; u.vn_var = a->vn_var;
     u.action_out = a->action_out; u.raw_action_out = a->raw_action_out; u.logp_out = a->logp_out;
     u.value_out = a->value_out; u.critic_obs_out = a->critic_obs_copy_out; u.obs_out = a->obs_copy_out;
+    u.forced_action = a->forced_action;
     const size_t lds = mat_lds_bytes(u.O);
     PPOAF_REQUIRE(lds <= 160 * 1024, "mat_policy_step: needs %zu B of LDS (> 160 KiB)", lds);
     static bool attr_set = false;

@@ -20,7 +20,9 @@ struct StepDev {
     NetDev net[2];
     const float* params;
     const float* obs; const float* critic_obs; long E;
-    int head_kind; float min_std, act_lo, act_hi;
+    int head_kind; float min_std;
+    const float* act_lo; const float* act_hi;      // per action dimension, NULL: [-1, 1] (no rescale)
+    const void* forced_raw_action;                 // NULL: sample; else the raw actions to log (replay / teacher forcing)
     unsigned long long seed, offset;
     int normalize_values; const float* vn_mean; const float* vn_var;
     void* raw_action_out; void* action_out; float* logp_out; float* value_out;
@@ -145,16 +147,21 @@ __device__ __forceinline__ void policy_step_body(const StepDev& u, const int whi
             float s2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) { p[k] *= inv; s2 += p[k]; }
-            const Philox4 rnd = philox4x32_10(u.seed, u.offset + (unsigned long long)e, 0u);
-            const float uu = u32_to_unit(rnd.x) * s2;
             int a = out_dim - 1;
             float c = 0.f, pa = p[0];
-            bool found = false;
+            if (u.forced_raw_action) {
+                const long fa = reinterpret_cast<const int64_t*>(u.forced_raw_action)[e];
+                a = fa < 0 ? 0 : (fa >= out_dim ? out_dim - 1 : (int)fa);
+            } else {
+                const Philox4 rnd = philox4x32_10(u.seed, u.offset + (unsigned long long)e, 0u);
+                const float uu = u32_to_unit(rnd.x) * s2;
+                bool found = false;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (k < out_dim) {
-                    c += p[k];
-                    if (!found && uu < c) { a = k; found = true; }
+                for (int k = 0; k < 8; ++k) {
+                    if (k < out_dim) {
+                        c += p[k];
+                        if (!found && uu < c) { a = k; found = true; }
+                    }
                 }
             }
 #pragma unroll
@@ -166,7 +173,8 @@ __device__ __forceinline__ void policy_step_body(const StepDev& u, const int whi
             const float* log_std = P + nd.log_std_off;
             float* raw = reinterpret_cast<float*>(u.raw_action_out) + e * out_dim;
             float* ac = reinterpret_cast<float*>(u.action_out) + e * out_dim;
-            const bool rescale = (u.act_lo != -1.0f) || (u.act_hi != 1.0f);
+            const bool rescale = u.act_lo != nullptr;
+            const float* forced = reinterpret_cast<const float*>(u.forced_raw_action);
             float lp = 0.f, slog = 0.f;
             for (int d0 = 0; d0 < out_dim; d0 += 4) {
                 const Philox4 r = philox4x32_10(u.seed, u.offset + (unsigned long long)e, (uint32_t)(d0 >> 2));
@@ -181,11 +189,11 @@ __device__ __forceinline__ void policy_step_body(const StepDev& u, const int whi
                     const int d = d0 + j;
                     const float sd = fmaxf(softplus_u(log_std[d]), u.min_std);
                     const float mean = sOut[s * kMaxOut + d];
-                    const float x = mean + sd * z[j];
+                    const float x = forced ? forced[e * out_dim + d] : mean + sd * z[j];
                     raw[d] = x;
                     float a = tanhf(x);
                     slog += logf(fmaxf(1.0f - a * a, 1e-6f));
-                    if (rescale) a = ((a + 1.0f) / 2.0f) * (u.act_hi - u.act_lo) + u.act_lo;
+                    if (rescale) a = ((a + 1.0f) / 2.0f) * (u.act_hi[d] - u.act_lo[d]) + u.act_lo[d];   // distributions.py:580-581
                     ac[d] = a;
                     const float zz = x - mean;
                     float l = -(zz * zz) / (2.0f * sd * sd) - logf(sd) - 0.91893853320467274178f;
@@ -256,7 +264,9 @@ extern "C" int ppoaf_policy_step(const ppoaf_policy_step_args_t* a, ppoaf_stream
                   "policy_step: log_std offset must be given exactly for the Gaussian head");
     PPOAF_REQUIRE(!a->normalize_values || (a->vn_mean && a->vn_var), "policy_step: normaliser state missing");
     u.params = a->params; u.obs = a->obs; u.critic_obs = a->critic_obs; u.E = a->E;
+    PPOAF_REQUIRE((a->act_lo == nullptr) == (a->act_hi == nullptr), "policy_step: give both action bounds or neither");
     u.head_kind = a->head_kind; u.min_std = a->min_std; u.act_lo = a->act_lo; u.act_hi = a->act_hi;
+    u.forced_raw_action = a->forced_raw_action;
     u.seed = a->seed; u.offset = a->offset; u.normalize_values = a->normalize_values;
     u.vn_mean = a->vn_mean; u.vn_var = a->vn_var; u.raw_action_out = a->raw_action_out;
     u.action_out = a->action_out; u.logp_out = a->logp_out; u.value_out = a->value_out;

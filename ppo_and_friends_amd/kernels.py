@@ -294,14 +294,19 @@ def gaussian_tanh_eval_bwd(mean, log_std, x, d_logp, d_entropy, min_std=0.01):
     return d_mean, d_log_std
 
 
-def gaussian_tanh_sample(mean, log_std, seed, offset, min_std=0.01, act_lo=-1.0, act_hi=1.0):
+def gaussian_tanh_sample(mean, log_std, seed, offset, min_std=0.01, act_lo=None, act_hi=None):
+    """act_lo / act_hi: float32[D] device tensors (bounds per action dimension) or both None for the unit box."""
     _f32(mean, "mean"); _f32(log_std, "log_std")
     n, D = mean.shape
+    _req((act_lo is None) == (act_hi is None), "gaussian_tanh_sample: give both bounds or neither")
+    if act_lo is not None:
+        _f32(act_lo, "act_lo"); _f32(act_hi, "act_hi")
+        _req(act_lo.numel() == D and act_hi.numel() == D, "gaussian_tanh_sample: bounds must hold one value per action dimension")
     raw = torch.empty_like(mean)
     act = torch.empty_like(mean)
     logp = torch.empty(n, dtype=torch.float32, device=mean.device)
     check(_lib.load().ppoaf_gaussian_tanh_sample(ptr(mean), ptr(log_std), n, D, float(min_std),
-                                                 float(act_lo), float(act_hi), int(seed),
+                                                 ptr(act_lo), ptr(act_hi), int(seed),
                                                  int(offset), ptr(raw), ptr(act), ptr(logp),
                                                  stream()), "gaussian_tanh_sample")
     return raw, act, logp

@@ -94,18 +94,33 @@ class GaussianDistribution(nn.Module):
                  distribution_max=1.0, seed=0, **kw_args):
         super().__init__()
         self.min_std = float(min_std)
-        self.dist_min = float(np.min(distribution_min))
-        self.dist_max = float(np.max(distribution_max))
+        # bounds per action dimension, as the reference keeps them (:476-483); scalars broadcast
+        self.dist_min = np.broadcast_to(np.asarray(distribution_min, dtype=np.float32).reshape(-1), (act_dim,)).copy() \
+            if np.size(distribution_min) in (1, act_dim) else np.asarray(distribution_min, dtype=np.float32).reshape(-1)
+        self.dist_max = np.broadcast_to(np.asarray(distribution_max, dtype=np.float32).reshape(-1), (act_dim,)).copy() \
+            if np.size(distribution_max) in (1, act_dim) else np.asarray(distribution_max, dtype=np.float32).reshape(-1)
+        if self.dist_min.size != act_dim or self.dist_max.size != act_dim:
+            raise ValueError(f"distribution_min / distribution_max must be scalars or hold {act_dim} values")
+        # :606: the rescale runs for every dimension as soon as ANY bound differs from the unit box
+        self.rescale = bool((self.dist_min != -1.0).any() or (self.dist_max != 1.0).any())
+        # device copies for the kernels; not part of the state_dict (the reference's holds log_std only)
+        self.register_buffer("dist_min_t", torch.from_numpy(self.dist_min.copy()), persistent=False)
+        self.register_buffer("dist_max_t", torch.from_numpy(self.dist_max.copy()), persistent=False)
         self.log_std = nn.Parameter(torch.as_tensor(-std_offset * np.ones(act_dim, dtype=np.float32)))
         self.rng = _PhiloxStream(seed)
+
+    def bound_tensors(self):
+        """(lo, hi) float32[D] device tensors for the kernels, or (None, None) for the unit box."""
+        return (self.dist_min_t, self.dist_max_t) if self.rescale else (None, None)
 
     def get_distribution(self, action_mean):
         return action_mean
 
     def sample_distribution(self, mean):
         seed, off = self.rng.take(mean.shape[0])
+        lo, hi = self.bound_tensors()
         raw, act, lp = K.gaussian_tanh_sample(mean.contiguous(), self.log_std.detach(), seed, off,
-                                              self.min_std, self.dist_min, self.dist_max)
+                                              self.min_std, lo, hi)
         return act, raw, lp.unsqueeze(-1)
 
     def get_log_probs_and_entropy(self, mean, raw_actions):
@@ -114,8 +129,8 @@ class GaussianDistribution(nn.Module):
 
     def refine_prediction(self, mean):
         s = torch.tanh(mean)
-        if self.dist_min != -1.0 or self.dist_max != 1.0:
-            s = ((s + 1.0) / 2.0) * (self.dist_max - self.dist_min) + self.dist_min
+        if self.rescale:                                                       # :580-581, :604-609
+            s = ((s + 1.0) / 2.0) * (self.dist_max_t - self.dist_min_t) + self.dist_min_t
         return s
 
 
@@ -204,8 +219,15 @@ def get_actor_distribution(action_space, seed=0, **kw_args):
     if dtype == "multi-binary":
         return BernoulliDistribution(seed=seed)
     if dtype == "continuous":
-        return GaussianDistribution(int(np.prod(action_space.shape)),
-                                    distribution_min=action_space.low,
-                                    distribution_max=action_space.high, seed=seed, **kw_args)
+        # :1058-1107: bounds given through the actor's kw_args win; else the action space's, which must be finite
+        kw_args = dict(kw_args)
+        for key, side in (("distribution_min", "low"), ("distribution_max", "high")):
+            if kw_args.get(key) is None:
+                bound = np.asarray(getattr(action_space, side), dtype=np.float32)
+                if np.isinf(bound).any():
+                    raise ValueError(f"the action space's {side} bound {bound} is infinite: the Gaussian {key} must be "
+                                     f"finite -- set it through the actor kw_args (actor_kw_args['{key}'] = k)")
+                kw_args[key] = bound
+        return GaussianDistribution(int(np.prod(action_space.shape)), seed=seed, **kw_args)
     raise NotImplementedError(f"action space dtype {dtype} is outside this build's hot path "
                               "(Discrete and Box only; SURVEY.md §2.1 #4)")

@@ -137,8 +137,10 @@ class MATPolicy(PPOPolicy):
         from ..fused_update import _describe_mat
         return _describe_mat(self)[1]
 
-    def rollout_step(self, t, critic_obs, actor_obs, value_normalizer=None):
+    def rollout_step(self, t, critic_obs, actor_obs, value_normalizer=None, forced_raw_action=None):
         """
+        forced_raw_action (optional int64 device tensor [E, A] / [E, A, 1]): log these actions instead of sampling
+        (replay of a recorded rollout).
         One env step of get_rollout_actions (encoder + A autoregressive decoder passes + sampling) and
         get_critic_values (+ denormalisation) as ONE launch (K16) that stores straight into row t of the
         rollout buffer.  critic_obs / actor_obs: grouped device tensors [E, A, .].  Returns the action row
@@ -169,6 +171,12 @@ class MATPolicy(PPOPolicy):
         actor_obs = actor_obs.contiguous()
         a.critic_obs, a.actor_obs = critic_obs.data_ptr(), actor_obs.data_ptr()
         a.seed, a.offset = self.actor.distribution.rng.take(E * A)
+        a.forced_action = None
+        if forced_raw_action is not None:
+            if not (forced_raw_action.is_cuda and forced_raw_action.dtype == torch.int64 and forced_raw_action.is_contiguous()
+                    and forced_raw_action.numel() == E * A):
+                raise _lib.PpoafError(f"mat rollout_step: forced_raw_action must be a contiguous int64 device tensor [{E}, {A}]")
+            a.forced_action = forced_raw_action.data_ptr()
         a.normalize_values = int(value_normalizer is not None)
         if value_normalizer is not None:
             a.vn_mean = value_normalizer.running_stats.mean_t.data_ptr()
@@ -196,8 +204,9 @@ class MATPolicy(PPOPolicy):
         blk[:, 0, 0] = 1
         return blk
 
-    def _get_autoregressive_actions(self, encoded_obs):
-        """mat_policy.py:441-519: A decoder passes, agent i conditioned on the actions of agents < i."""
+    def _get_autoregressive_actions(self, encoded_obs, forced_raw_action=None):
+        """mat_policy.py:441-519: A decoder passes, agent i conditioned on the actions of agents < i.
+        forced_raw_action [B, A, .]: recorded raw actions to log instead of sampling (replay)."""
         B, A = encoded_obs.shape[0], len(self.agent_ids)
         block = self._get_tokened_action_block(B)
         off = 1 if self.action_dtype == "discrete" else 0
@@ -208,7 +217,12 @@ class MATPolicy(PPOPolicy):
         with torch.no_grad():
             for i in range(A):
                 pred = self.actor(block, encoded_obs)[:, i, :].contiguous()
-                action, raw_action, log_prob = self.actor.distribution.sample_distribution(pred)
+                if forced_raw_action is None:
+                    action, raw_action, log_prob = self.actor.distribution.sample_distribution(pred)
+                else:
+                    raw_action = forced_raw_action.reshape(B, A, -1)[:, i, :].contiguous()
+                    log_prob, _ = self.actor.distribution.get_log_probs_and_entropy(pred, raw_action)
+                    action = raw_action if self.action_dtype == "discrete" else self.actor.distribution.refine_prediction(raw_action)
                 out_a[:, i, :] = action.reshape(B, self.action_dim)
                 out_raw[:, i, :] = raw_action.reshape(B, self.action_dim)
                 out_lp[:, i, :] = log_prob.reshape(B, 1)
@@ -219,7 +233,7 @@ class MATPolicy(PPOPolicy):
                         block[:, i + 1, off:] = action.reshape(B, -1)
         return out_a, out_raw, out_lp
 
-    def get_rollout_actions(self, obs):
+    def get_rollout_actions(self, obs, forced_raw_action=None):
         """
         mat_policy.py:587-626.  Device tensors arrive grouped, [E, A, O], and grouped tensors are
         returned ([E, A, .]); numpy arrives in the reference's [A, E, O] and is swapped like there.
@@ -228,7 +242,7 @@ class MATPolicy(PPOPolicy):
         t_obs = self._to_device(np.swapaxes(obs, 0, 1) if as_numpy else obs)
         with torch.no_grad():
             encoded_obs, _ = self.critic(t_obs)
-        actions, raw_actions, log_probs = self._get_autoregressive_actions(encoded_obs)
+        actions, raw_actions, log_probs = self._get_autoregressive_actions(encoded_obs, forced_raw_action)
         if as_numpy:
             return (torch.swapaxes(raw_actions, 0, 1).cpu().numpy(), torch.swapaxes(actions, 0, 1).cpu().numpy(),
                     torch.swapaxes(log_probs, 0, 1).detach())

@@ -293,10 +293,11 @@ class PPOPolicy:
             return x.to(device=self.device, dtype=dtype)
         return torch.as_tensor(np.asarray(x), dtype=dtype).to(self.device)
 
-    def get_rollout_actions(self, obs):
+    def get_rollout_actions(self, obs, forced_raw_action=None):
         """
         ppo_policy.py:729-794 -> (raw_action, action, log_prob).  numpy in -> numpy
         actions out (reference contract); device tensor in -> device tensors out.
+        forced_raw_action: recorded raw actions to log instead of sampling (replay of a rollout).
         """
         if len(obs.shape) < 2:
             raise ValueError(f"get_rollout_actions expects a batch of observations, got shape {obs.shape}")
@@ -304,7 +305,14 @@ class PPOPolicy:
         t_obs = self._to_device(obs)
         with torch.no_grad():
             pred = self.actor.forward_logits(t_obs)
-            action, raw_action, log_prob = self.actor.distribution.sample_distribution(pred)
+            if forced_raw_action is None:
+                action, raw_action, log_prob = self.actor.distribution.sample_distribution(pred)
+            else:
+                dist = self.actor.distribution
+                raw_action = self._to_device(forced_raw_action, torch.float32 if self.action_dtype == "continuous" else torch.int64)
+                raw_action = raw_action.reshape(pred.shape[0], -1)
+                log_prob, _ = dist.get_log_probs_and_entropy(pred, raw_action)
+                action = dist.refine_prediction(raw_action) if self.action_dtype == "continuous" else raw_action
         if as_numpy:
             return raw_action.cpu().numpy(), action.cpu().numpy(), log_prob.detach()
         return raw_action, action, log_prob
@@ -342,8 +350,11 @@ class PPOPolicy:
         from ..fused_update import FusedPolicyUpdate
         return FusedPolicyUpdate.unsupported_reason(self, 2)
 
-    def rollout_step(self, t, obs, critic_obs, value_normalizer=None):
+    def rollout_step(self, t, obs, critic_obs, value_normalizer=None, forced_raw_action=None):
         """
+        forced_raw_action (optional, [E] / [E,1] int64 or [E,D] float32 device tensor): log these raw actions
+        instead of sampling -- replay of a recorded rollout (log-probs, refined actions and values are computed
+        as usual).
         One env step of get_rollout_actions + get_critic_values (+ denormalisation) +
         add_episode_info's action/value/log-prob/observation writes, as ONE launch that
         stores straight into row t of the rollout buffer.  Returns the action row (a
@@ -365,8 +376,9 @@ class PPOPolicy:
             a.E = E
             a.head_kind = K.HEAD_GAUSSIAN if gauss else K.HEAD_CATEGORICAL
             a.min_std = float(getattr(self.actor.distribution, "min_std", 0.01))
-            a.act_lo = float(getattr(self.actor.distribution, "dist_min", -1.0))
-            a.act_hi = float(getattr(self.actor.distribution, "dist_max", 1.0))
+            lo, hi = self.actor.distribution.bound_tensors() if gauss else (None, None)
+            a.act_lo = None if lo is None else lo.data_ptr()
+            a.act_hi = None if hi is None else hi.data_ptr()
             self._step_args = a
         K._req(obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.numel() == E * a.actor.in_dim,
                "rollout_step: obs must be a contiguous float32 device tensor [E, obs_dim]")
@@ -374,6 +386,13 @@ class PPOPolicy:
                and critic_obs.numel() == E * a.critic.in_dim,
                "rollout_step: critic_obs must be a contiguous float32 device tensor [E, critic_obs_dim]")
         a.obs = obs.data_ptr(); a.critic_obs = critic_obs.data_ptr()
+        a.forced_raw_action = None
+        if forced_raw_action is not None:
+            want = torch.float32 if a.head_kind == K.HEAD_GAUSSIAN else torch.int64
+            K._req(forced_raw_action.is_cuda and forced_raw_action.dtype == want and forced_raw_action.is_contiguous()
+                   and forced_raw_action.numel() == buf.raw_actions[t].numel(),
+                   "rollout_step: forced_raw_action must be a contiguous device tensor shaped like the step's raw actions")
+            a.forced_raw_action = forced_raw_action.data_ptr()
         a.seed, a.offset = self.actor.distribution.rng.take(E)
         if value_normalizer is not None:
             a.normalize_values = 1

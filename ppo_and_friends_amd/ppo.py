@@ -323,13 +323,17 @@ class PPO:
 
         if pol.enable_icm:
             may_end_early = True          # bootstrap rewards carry the "surprise" term: dense end table
+        # replay of a recorded rollout: `self.replay_raw_actions` ([T, rows, .] device tensor in the buffer's row
+        # layout, or None) makes every step log the recorded raw action instead of sampling one
+        rec = getattr(self, "replay_raw_actions", None)
+        replay = (lambda t: None) if rec is None else (lambda t: rec[t].contiguous())
         nat_buf = self._scratch(f"nat_buf_{T}_{env.num_agents if hasattr(env, 'num_agents') else 1}_{n_envs}",
                                 T * (E if not grouped else E * pol.num_agents), torch.float32).view(T, -1)
         for t in range(T):
             if fused_step and grouped:
                 # K16: encoder + autoregressive decoder passes + sampling + values + the buffer row in one launch
                 g_obs, g_cobs = group(obs), group(critic_obs)
-                action = pol.rollout_step(t, g_cobs, g_cobs if pol.expanded_actor_space else g_obs, vn)
+                action = pol.rollout_step(t, g_cobs, g_cobs if pol.expanded_actor_space else g_obs, vn, forced_raw_action=replay(t))
                 act_env = ungroup(action)
                 nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(act_env))
                 nat_buf[t].copy_(self._natural_reward(env, reward))
@@ -343,7 +347,7 @@ class PPO:
                 terminated, truncated = terminated[:n_envs], truncated[:n_envs]   # agents of an env end together
             elif fused_step:
                 # K6+K7: inference, sampling, log-probs, values and the buffer row in one launch
-                action = pol.rollout_step(t, obs.contiguous(), critic_obs.contiguous(), vn)
+                action = pol.rollout_step(t, obs.contiguous(), critic_obs.contiguous(), vn, forced_raw_action=replay(t))
                 nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(action))
                 nat_buf[t].copy_(self._natural_reward(env, reward))
                 if self.ext_reward_weight != 1.0:
@@ -354,7 +358,7 @@ class PPO:
                 pol.finish_step(t, reward, term_obs)
             elif grouped:
                 g_obs, g_cobs = group(obs), group(critic_obs)
-                raw_action, action, log_prob = pol.get_rollout_actions(g_cobs if pol.expanded_actor_space else g_obs)
+                raw_action, action, log_prob = pol.get_rollout_actions(g_cobs if pol.expanded_actor_space else g_obs, forced_raw_action=replay(t))
                 value = self.get_policy_values(policy_id, g_cobs)
                 act_env = ungroup(action)
                 nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(act_env))
@@ -371,7 +375,7 @@ class PPO:
                 pol._t = t + 1
                 terminated, truncated = terminated[:n_envs], truncated[:n_envs]   # agents of an env end together
             else:
-                raw_action, action, log_prob = pol.get_rollout_actions(obs)
+                raw_action, action, log_prob = pol.get_rollout_actions(obs, forced_raw_action=replay(t))
                 value = self.get_policy_values(policy_id, critic_obs)
                 nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(action))
                 nat_buf[t].copy_(self._natural_reward(env, reward))

@@ -1,0 +1,253 @@
+"""
+-m gpu: the HIP path against fixtures recorded from the UNMODIFIED reference (tests/golden/g12_*.npz,
+make_golden_update.py): the reference's own PPO object was driven for whole iterations over a table-driven
+environment; here the product's PPO runs over the same tables from the same initial weights, replays the recorded
+raw actions (the one thing a device Philox stream cannot reproduce is the reference's CPU torch generator) and the
+recorded shuffles, and must reproduce
+
+  * every rollout: per-step values / log-probs / refined actions, the dataset (order, returns, advantages),
+    the rollout statistics block of the status dict,
+  * the very first mini-batch before any optimiser step: both losses and the full raw gradient of every parameter
+    (1e-5, the north_star tolerance),
+  * every epoch's statistics, and the weights / value-normaliser state after all optimiser steps.
+
+Both update paths (fused K12 / K14 kernels; torch-ROCm modules + K2..K11) are checked.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FF_SCENARIOS = {
+    # name: (policy kwargs, PPO kwargs)
+    "g12_c2_term": ({}, {}),
+    "g12_c2_cut": ({}, {}),
+    "g12_c4_mappo": (dict(leaky=True), {}),
+    "g12_c3_gauss": (dict(leaky=True, lr=1e-4), {}),
+    "g12_gauss_bounds": (dict(hidden=(32, 32)), {}),
+    "g12_c2_icm": (dict(enable_icm=True), {}),
+    "g12_c3_full": (dict(leaky=True, lr=1e-4, enable_icm=True),
+                    dict(normalize_obs=True, normalize_rewards=True, obs_clip=(-2.0, 2.0), reward_clip=(-1.5, 1.5))),
+}
+
+
+def _cfg(g):
+    return dict(zip([str(x) for x in g["cfg_names"]], [int(x) for x in g["cfg"]]))
+
+
+def agent_major(x):
+    """[steps, E, A, ...] (fixture layout) -> [steps, A*E, ...] agent-major columns (the product's rows)."""
+    x = np.swapaxes(x, 1, 2)
+    return np.ascontiguousarray(x.reshape((x.shape[0], x.shape[1] * x.shape[2]) + x.shape[3:]))
+
+
+def row_mapping(ref_obs, got_obs):
+    """pi with got[pi[i]] == ref[i] (see tests/test_oracle_update_golden.py: the reference orders the episodes of one
+    end-of-episode event by a hash-ordered agent list; rows are matched by their unique observation vectors)."""
+    index = {row.tobytes(): i for i, row in enumerate(np.ascontiguousarray(got_obs))}
+    assert len(index) == len(got_obs), "observation rows are not unique"
+    return np.array([index[row.tobytes()] for row in np.ascontiguousarray(ref_obs)], dtype=np.int64)
+
+
+class FixedPermLoader:
+    """The loader surface PPO._ppo_batch_train / _icm_batch_train read, replaying one recorded shuffle."""
+
+    def __init__(self, dataset, batch_size, perm):
+        self.dataset, self.batch_size = dataset, int(batch_size)
+        self._perm = torch.as_tensor(np.asarray(perm, dtype=np.int64), device=dataset.device)
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def epoch_permutation(self):
+        return self._perm
+
+    def prefetch(self):
+        pass
+
+
+def make_product(g, name, update_mode, dev):
+    """The product's PPO over the fixture's tables, holding the fixture's initial weights."""
+    from ppo_and_friends_amd.ppo import PPO
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    c = _cfg(g)
+    E, T, A, O = c["E"], c["T"], c["A"], c["O"]
+    pk, ppo_kw = FF_SCENARIOS[name]
+    names = set(g.files)
+    continuous = "init_actor.distribution.log_std" in names
+    n_out = int(g["init_actor.sequential_net.3.weight"].shape[0])
+    c_in = int(g["init_critic.sequential_net.0.weight"].shape[1])
+    if continuous:
+        lo = {"g12_gauss_bounds": np.array([-1.0, -2.0, 0.0], np.float32)}.get(name, -np.ones(n_out, np.float32))
+        hi = {"g12_gauss_bounds": np.array([1.0, 2.0, 5.0], np.float32)}.get(name, np.ones(n_out, np.float32))
+        act_space = Box(lo, hi, (n_out,), np.float32)
+    else:
+        act_space = Discrete(n_out)
+
+    class FixtureEnv(SyntheticFixedLengthEnv):
+        def __init__(self):
+            super().__init__(E, O, act_space, T, dev, num_agents=A, critic_view="policy" if c_in != O else "local",
+                             term_prob=0.5 if g["term_table"].any() else 0.0)
+            obs = agent_major(g["obs_table"])
+            self.obs_table = torch.from_numpy(obs).to(dev)
+            if c_in != O:
+                v = self.obs_table.view(T + 1, A, E, O).permute(0, 2, 1, 3).reshape(T + 1, 1, E, A * O)
+                self.critic_obs_table = v.expand(T + 1, A, E, A * O).reshape(T + 1, A * E, A * O).contiguous()
+            else:
+                self.critic_obs_table = self.obs_table
+            self.reward_table = torch.from_numpy(agent_major(g["reward_table"])).to(dev)
+            if g["term_table"].any():
+                self.term_table = torch.from_numpy(np.tile(g["term_table"], (1, A))).to(dev)
+
+    import torch.nn as nn
+    h_a, h_c = pk.get("hidden", (128, 256 if int(g["init_critic.sequential_net.0.weight"].shape[0]) == 256 else 128))
+    akw, ckw = dict(hidden_size=h_a), dict(hidden_size=h_c)
+    if pk.get("leaky"):
+        akw["activation"], ckw["activation"] = nn.LeakyReLU(), nn.LeakyReLU()
+    pargs = dict(actor_kw_args=akw, critic_kw_args=ckw, lr=pk.get("lr", 3e-4), enable_icm=pk.get("enable_icm", False))
+    sp, csp = Box(-np.inf, np.inf, (O,), np.float32), Box(-np.inf, np.inf, (c_in,), np.float32)
+    kw = dict(normalize_obs=False, normalize_rewards=False)
+    kw.update(ppo_kw)
+    ppo = PPO(FixtureEnv, {"agent": (None, sp, csp, act_space, pargs)}, device=dev, random_seed=c["seed"],
+              envs_per_proc=E, ts_per_rollout=T, batch_size=c["batch_size"], epochs_per_iter=c["epochs"],
+              max_ts_per_ep=c["max_ts_per_ep"], update_mode=update_mode, save_state=False, **kw)
+    pol = ppo.policies["agent"]
+    for tag, net in (("actor", pol.actor), ("critic", pol.critic)) + ((("icm", pol.icm_model),) if pol.enable_icm else ()):
+        sd = {k[len(f"init_{tag}."):]: torch.from_numpy(g[k]) for k in names if k.startswith(f"init_{tag}.")}
+        missing, unexpected = net.load_state_dict(sd, strict=False)
+        assert not unexpected and not [m for m in missing if "dist_m" not in m], (tag, missing, unexpected)
+    return ppo, pol, c, continuous
+
+
+def params_in_bucket_order(pol, bucket, net):
+    """The slices of a flat bucket (gradients, ...) that belong to `net`'s parameters, in module order."""
+    base = pol.policy_params.data_ptr()
+    out = []
+    for p in net.parameters():
+        off = (p.data_ptr() - base) // 4
+        out.append(bucket[off:off + p.numel()].reshape(-1))
+    return torch.cat(out).cpu().numpy()
+
+
+def first_minibatch_probe(ppo, pol, perm, B):
+    """
+    Losses + raw gradient bucket of the first mini-batch WITHOUT an optimiser step.
+    fused path: one K12 fwd_bwd + slab-reduce launch; torch path: one _minibatch_step (value-normaliser state restored).
+    """
+    from ppo_and_friends_amd import _lib
+    from ppo_and_friends_amd import kernels as K
+    fused = ppo._fused_updater("agent", B)
+    perm_t = torch.as_tensor(np.asarray(perm, dtype=np.int64), device=pol.device)
+    if fused is not None:
+        fused.begin_epoch(perm_t)
+        args = fused._args_for(B)
+        lib, st = _lib.load(), K.stream()
+        _lib.check(lib.ppoaf_ppo_update_fwd_bwd(C.byref(args), st), "fwd_bwd")
+        _lib.check(lib.ppoaf_ppo_update_reduce(C.byref(args), 1, st), "reduce")
+        torch.cuda.synchronize()
+        return fused.totals.cpu().numpy().copy(), pol.policy_grads.clone()
+    ds = pol.dataset
+    totals = torch.zeros(9, dtype=torch.float64, device=pol.device)
+    rs = ppo.value_normalizers["agent"].running_stats
+    keep = [x.clone() for x in (rs.mean_t, rs.var_t, rs.count_t)]
+    records = ppo._epoch_records("agent", ds, perm_t, B)
+    ppo._minibatch_step("agent", ds, perm_t[:B].contiguous(), records[:, 0].reshape(1, 3), totals)
+    torch.cuda.synchronize()
+    for dst, src in zip((rs.mean_t, rs.var_t, rs.count_t), keep):
+        dst.copy_(src)
+    return totals.cpu().numpy().copy(), pol.policy_grads.clone()
+
+
+@pytest.mark.parametrize("update_mode", ["fused", "torch"])
+@pytest.mark.parametrize("name", sorted(FF_SCENARIOS))
+def test_product_reproduces_the_reference_ppo_iterations(golden, name, update_mode):
+    from ppo_and_friends_amd import kernels as K
+    g = golden(name)
+    dev = torch.device("cuda", 0)
+    ppo, pol, c, continuous = make_product(g, name, update_mode, dev)
+    E, T, A, B = c["E"], c["T"], c["A"], c["batch_size"]
+    tol = dict(rtol=1e-5, atol=1e-5)                                   # north_star: within 1e-5 (fp32)
+    keys, rkeys, gkeys = (list(g[k]) for k in ("rollout_status_keys", "rollout_range_keys", "global_status_keys"))
+    ep = icm_ep = 0
+    for it in range(c["iterations"]):
+        sl = slice(it * T, (it + 1) * T)
+        raw = agent_major(g["step_raw_actions"][sl])
+        if not continuous:
+            raw = raw.reshape(T, A * E, 1)
+        ppo.replay_raw_actions = torch.from_numpy(raw).to(dev)
+        ds = ppo.rollout()
+        buf = pol.buffer
+        # ---- per-step quantities, rows agent-major
+        np.testing.assert_allclose(buf.observations.cpu().numpy(), agent_major(g["step_obs"][sl]).astype(np.float32), **tol)
+        np.testing.assert_allclose(buf.log_probs.cpu().numpy(), agent_major(g["step_log_probs"][sl])[..., 0], **tol)
+        per_step = [i for i, s in enumerate(g["values_calls_step"]) if it * T < s <= (it + 1) * T]
+        first = {}
+        for i in per_step:
+            first.setdefault(int(g["values_calls_step"][i]), i)        # a step's first value call = V(obs_t)
+        v_ref = agent_major(np.stack([g["values_calls"][first[s]] for s in range(it * T + 1, (it + 1) * T + 1)]))
+        np.testing.assert_allclose(buf.values.cpu().numpy(), v_ref, **tol)
+        got_act = buf.actions.cpu().numpy()
+        want_act = agent_major(g["step_actions"][sl])
+        np.testing.assert_allclose(got_act.reshape(want_act.shape), want_act, **tol)   # tanh + per-dimension rescale
+        np.testing.assert_allclose(buf.rewards.cpu().numpy(), agent_major(g["step_rewards"][sl]), **tol)
+        # ---- dataset
+        pre = f"it{it}_ds_"
+        assert len(ds) == len(g[pre + "advantages"])
+        got_obs = ds.observations.cpu().numpy()
+        if A == 1:                                                      # single agent: the order itself is the contract
+            pi = np.arange(len(ds))
+            np.testing.assert_allclose(got_obs, g[pre + "observations"], **tol)
+            np.testing.assert_array_equal(ds.ep_lens.cpu().numpy(), g[pre + "ep_lens"])
+        else:
+            pi = row_mapping(g[pre + "observations"], got_obs)
+        np.testing.assert_allclose(ds.critic_observations.cpu().numpy()[pi], g[pre + "critic_observations"], **tol)
+        np.testing.assert_allclose(ds.values[torch.arange(len(ds), device=dev)].cpu().numpy()[pi], g[pre + "values"], **tol)
+        np.testing.assert_allclose(ds.log_probs.cpu().numpy().reshape(-1)[pi], g[pre + "log_probs"], **tol)
+        np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy()[pi], g[pre + "rewards_to_go"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(ds.advantages.cpu().numpy()[pi], g[pre + "advantages"], rtol=1e-5, atol=2e-5)
+        # ---- the rollout statistics block of the status dict
+        sd, gs = ppo.status_dict["agent"], ppo.status_dict["global status"]
+        for k in keys:
+            np.testing.assert_allclose(sd[k], g["rollout_status"][it][keys.index(k)], rtol=1e-5, atol=1e-5, err_msg=f"{k} it {it}")
+        for k in rkeys:
+            np.testing.assert_allclose(sd[k], g["rollout_ranges"][it][rkeys.index(k)], rtol=1e-5, atol=1e-5, err_msg=f"{k} it {it}")
+        for k in gkeys:
+            np.testing.assert_allclose(gs[k], g["global_status"][it][gkeys.index(k)], rtol=1e-6, err_msg=f"{k} it {it}")
+        # ---- first mini-batch of the run: losses + raw gradients before any optimiser step
+        pol.train()
+        if it == 0:
+            sc, grads = first_minibatch_probe(ppo, pol, pi[g["epoch_perms"][0]], B)
+            assert sc[8] == 1
+            np.testing.assert_allclose([sc[K.SC_ACTOR], sc[K.SC_CRITIC]], g["mb0_losses"], rtol=1e-5, atol=1e-6)
+            ga = params_in_bucket_order(pol, grads, pol.actor)
+            gc = params_in_bucket_order(pol, grads, pol.critic)
+            scale_a, scale_c = np.abs(g["mb0_actor_grad"]).max(), np.abs(g["mb0_critic_grad"]).max()
+            np.testing.assert_allclose(ga, g["mb0_actor_grad"], rtol=1e-5, atol=1e-5 * scale_a,
+                                       err_msg=f"actor gradient (max |g| {scale_a:.3e})")
+            np.testing.assert_allclose(gc, g["mb0_critic_grad"], rtol=1e-5, atol=1e-5 * scale_c,
+                                       err_msg=f"critic gradient (max |g| {scale_c:.3e})")
+        # ---- epochs with the recorded shuffles
+        for e in range(c["epochs"]):
+            ppo._ppo_batch_train(FixedPermLoader(pol.dataset, B, pi[g["epoch_perms"][ep]]), "agent")
+            got = np.array([sd["actor loss"], sd["critic loss"], sd["kl avg"], sd["weighted entropy"]])
+            np.testing.assert_allclose(got, g["epoch_stats"][ep], rtol=2e-5, atol=2e-6,
+                                       err_msg=f"iteration {it} epoch {e}: max dev {np.abs(got - g['epoch_stats'][ep]).max():.2e}")
+            ep += 1
+            if pol.enable_icm:
+                ppo._icm_batch_train(FixedPermLoader(pol.dataset, B, pi[g["icm_epoch_perms"][icm_ep]]), "agent")
+                np.testing.assert_allclose(sd["icm loss"], g["icm_epoch_stats"][icm_ep][0], rtol=2e-5, err_msg=f"icm loss {it}/{e}")
+                icm_ep += 1
+        pol.clear_dataset()
+    # ---- weights after every optimiser step of the run (Adam's m / sqrt(v) is sign-like where v is tiny: the bulk of the
+    # weights stays within 2e-5, none moves by more than 2e-4; the measured maximum is in the message)
+    for tag, net in (("actor", pol.actor), ("critic", pol.critic)) + ((("icm", pol.icm_model),) if pol.enable_icm else ()):
+        want = np.concatenate([g[f"final_{tag}.{k}"].reshape(-1) for k, _ in net.named_parameters()])
+        got = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu().numpy()
+        d = np.abs(got - want)
+        assert d.max() < 2e-4 and np.mean(d > 2e-5) < 1e-2, f"{tag}: max |dw| {d.max():.2e}, share > 2e-5: {np.mean(d > 2e-5):.2e}"
+    rs = ppo.value_normalizers["agent"].running_stats
+    np.testing.assert_allclose([float(rs.mean_t), float(rs.var_t), float(rs.count_t)], g["value_stats"], rtol=1e-5, atol=1e-5)
