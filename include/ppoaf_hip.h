@@ -230,7 +230,8 @@ int ppoaf_categorical_eval_bwd(const float* probs, const int64_t* actions,
  *   std = max(softplus(log_std), min_std)                         :514-516
  *   logp = sum_d clamp(N(mean,std).log_prob(x), -100, 100)
  *          - sum_d log(clamp(1 - tanh(x)^2, 1e-6, inf))            :551-558
- *   entropy = -logp                                               :694
+ *   entropy = -logp(x := mean): PPOPolicy.evaluate asks for the entropy at the
+ *             distribution's own mean                  ppo_policy.py:950, :672-694
  * mean, x: [n,D]; log_std: [D]. */
 int ppoaf_gaussian_tanh_eval_fwd(const float* mean, const float* log_std,
                                  const float* x, int64_t n, int32_t D,
@@ -238,7 +239,7 @@ int ppoaf_gaussian_tanh_eval_fwd(const float* mean, const float* log_std,
                                  float* logp_out, float* entropy_out,
                                  ppoaf_stream_t stream);
 /* d_mean[n,D], d_log_std[D] (accumulated over rows; zeroed by the call) from
- * d_logp[n] and d_entropy[n] (entropy = -logp so they fold together). */
+ * d_logp[n] and d_entropy[n]. */
 int ppoaf_gaussian_tanh_eval_bwd(const float* mean, const float* log_std,
                                  const float* x, const float* d_logp,
                                  const float* d_entropy, int64_t n, int32_t D,

@@ -137,6 +137,21 @@ __device__ __forceinline__ float gauss_tanh_logp_row(const float* mean, const fl
     return lp - slog;
 }
 
+// GaussianDistribution.get_entropy as PPOPolicy.evaluate calls it (policies/ppo_policy.py:950,
+// networks/distributions.py:672-694): entropy = -get_log_probs(dist, action_pred), the tanh-corrected log-density
+// of the distribution's own MEAN (not of the logged raw action): sum_d [ -clamp(-log sd - log sqrt(2 pi), +-100)
+// + log(max(1 - tanh(mean)^2, 1e-6)) ].  Pinned by fixtures g8_distributions / g12_c3_*.
+__device__ __forceinline__ float gauss_tanh_entropy_row(const float* mean, const float* log_std, int D, float min_std) {
+    float e = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float sd = fmaxf(softplus_f(log_std[d]), min_std);
+        const float l0 = fminf(fmaxf(-logf(sd) - kHalfLog2Pi, -100.f), 100.f);
+        const float th = tanhf(mean[d]);
+        e += logf(fmaxf(1.0f - th * th, 1e-6f)) - l0;
+    }
+    return e;
+}
+
 __global__ __launch_bounds__(256) void gaussian_eval_fwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ log_std, const float* __restrict__ x,
     long n, int D, float min_std, float* __restrict__ logp_out, float* __restrict__ entropy_out) {
@@ -144,7 +159,7 @@ __global__ __launch_bounds__(256) void gaussian_eval_fwd_kernel(
     if (row >= n) return;
     const float lp = gauss_tanh_logp_row(mean + row * D, log_std, x + row * D, D, min_std);
     logp_out[row] = lp;
-    if (entropy_out) entropy_out[row] = -lp;
+    if (entropy_out) entropy_out[row] = gauss_tanh_entropy_row(mean + row * D, log_std, D, min_std);
 }
 
 // d_mean[n,D]; d_log_std[D] accumulated with one atomic per (workgroup, d).
@@ -155,9 +170,8 @@ __global__ __launch_bounds__(256) void gaussian_eval_bwd_kernel(
     __shared__ float red[17];
     const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = row < n;
-    // entropy = -logp -> effective upstream gradient on logp
-    float g = 0.f;
-    if (live) g = (d_logp ? d_logp[row] : 0.f) - (d_entropy ? d_entropy[row] : 0.f);
+    float g = 0.f, gH = 0.f;
+    if (live) { g = d_logp ? d_logp[row] : 0.f; gH = d_entropy ? d_entropy[row] : 0.f; }
     for (int d = 0; d < D; ++d) {
         float gls = 0.f;
         if (live) {
@@ -167,12 +181,17 @@ __global__ __launch_bounds__(256) void gaussian_eval_bwd_kernel(
             const float zz = x[row * D + d] - mean[row * D + d];
             const float l = -(zz * zz) / (2.0f * sd * sd) - logf(sd) - kHalfLog2Pi;
             const float pass = (l >= -100.f && l <= 100.f) ? 1.f : 0.f;   // clamp gradient
+            // entropy (at the mean): d/dmean log(max(1 - th^2, 1e-6)) = -2 th inside the clamp; d/dsd (+log sd) = 1/sd
+            const float thm = tanhf(mean[row * D + d]);
+            const float pass_t = (1.0f - thm * thm >= 1e-6f) ? 1.f : 0.f;
+            const float l0 = -logf(sd) - kHalfLog2Pi;
+            const float pass0 = (l0 >= -100.f && l0 <= 100.f) ? 1.f : 0.f;
             // dl/dmean = zz / sd^2 ; dl/dsd = zz^2/sd^3 - 1/sd
-            d_mean[row * D + d] = g * pass * zz / (sd * sd);
+            d_mean[row * D + d] = g * pass * zz / (sd * sd) - gH * pass_t * 2.0f * thm;
             // torch.max(std, min_std): gradient to std where std > min_std, split on ties
             const float dmax = sp > min_std ? 1.f : (sp == min_std ? 0.5f : 0.f);
             const float dsp = ls > 20.f ? 1.f : 1.0f / (1.0f + expf(-ls));  // softplus' = sigmoid
-            gls = g * pass * (zz * zz / (sd * sd * sd) - 1.0f / sd) * dmax * dsp;
+            gls = (g * pass * (zz * zz / (sd * sd * sd) - 1.0f / sd) + gH * pass0 / sd) * dmax * dsp;
         }
         const float tot = block_sum(gls, red);
         if (threadIdx.x == 0 && tot != 0.f) atomicAdd(&d_log_std[d], tot);

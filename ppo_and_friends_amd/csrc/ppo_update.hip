@@ -406,16 +406,22 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
                 const float* log_std = P + nd.log_std_off;
                 const float* x = sActF + s * 8;
                 float lp = 0.f, slog = 0.f;
+                ent = 0.f;
                 for (int d = 0; d < out_dim; ++d) {
                     const float sd = fmaxf(softplus_u(log_std[d]), u.min_std);
-                    const float zz = x[d] - sOut[s * kMaxOut + d];
-                    float l = -(zz * zz) / (2.0f * sd * sd) - logf(sd) - 0.91893853320467274178f;
+                    const float mu = sOut[s * kMaxOut + d];
+                    const float zz = x[d] - mu;
+                    const float l0 = -logf(sd) - 0.91893853320467274178f;
+                    float l = -(zz * zz) / (2.0f * sd * sd) + l0;
                     l = fminf(fmaxf(l, -100.f), 100.f);
                     lp += l;
                     const float th = tanhf(x[d]);
                     slog += logf(fmaxf(1.0f - th * th, 1e-6f));
+                    // entropy := -log_prob of the distribution's MEAN (ppo_policy.py:950, distributions.py:672-694)
+                    const float thm = tanhf(mu);
+                    ent += logf(fmaxf(1.0f - thm * thm, 1e-6f)) - fminf(fmaxf(l0, -100.f), 100.f);
                 }
-                logp = lp - slog; ent = -logp;
+                logp = lp - slog;
                 const float ratio = expf(logp - lpo);
                 if (isnan(ratio) || isinf(ratio)) part[7] = 1.f;
                 const float lo = 1.0f - u.surr_clip, hi = 1.0f + u.surr_clip;
@@ -428,19 +434,23 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
                 else glp = (ratio >= lo && ratio <= hi) ? -av * ratio : 0.f;
                 glp *= inv_B;
                 const float gH = (u.entropy_weight != 0.0f) ? -u.entropy_weight * inv_B : 0.f;
-                const float gg = glp - gH;                         // entropy = -logp
                 for (int d = 0; d < out_dim; ++d) {
                     const float ls = log_std[d];
                     const float sp = softplus_u(ls), sd = fmaxf(sp, u.min_std);
-                    const float zz = x[d] - sOut[s * kMaxOut + d];
-                    const float l = -(zz * zz) / (2.0f * sd * sd) - logf(sd) - 0.91893853320467274178f;
+                    const float mu = sOut[s * kMaxOut + d];
+                    const float zz = x[d] - mu;
+                    const float l0 = -logf(sd) - 0.91893853320467274178f;
+                    const float l = -(zz * zz) / (2.0f * sd * sd) + l0;
                     const float pass = (l >= -100.f && l <= 100.f) ? 1.f : 0.f;
-                    sDOut[s * kMaxOut + d] = gg * pass * zz / (sd * sd);
+                    const float pass0 = (l0 >= -100.f && l0 <= 100.f) ? 1.f : 0.f;
+                    const float thm = tanhf(mu);
+                    const float pass_t = (1.0f - thm * thm >= 1e-6f) ? 1.f : 0.f;
+                    sDOut[s * kMaxOut + d] = glp * pass * zz / (sd * sd) - gH * pass_t * 2.0f * thm;
                     if (d == 0) for (int k2 = out_dim; k2 < 8; ++k2) sDOut[s * kMaxOut + k2] = 0.f;
                     const float dmax = sp > u.min_std ? 1.f : (sp == u.min_std ? 0.5f : 0.f);
                     const float dsp = ls > 20.f ? 1.f : 1.0f / (1.0f + expf(-ls));
                     // per-row d logp / d log_std, parked in sOut's upper half for the reduction below
-                    sOut[s * kMaxOut + 8 + d] = gg * pass * (zz * zz / (sd * sd * sd) - 1.0f / sd) * dmax * dsp;
+                    sOut[s * kMaxOut + 8 + d] = (glp * pass * (zz * zz / (sd * sd * sd) - 1.0f / sd) + gH * pass0 / sd) * dmax * dsp;
                 }
             } else if (s < kRows) {
                 for (int k = 0; k < kMaxOut; ++k) sDOut[s * kMaxOut + k] = 0.f;

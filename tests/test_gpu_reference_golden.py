@@ -146,9 +146,11 @@ def first_minibatch_probe(ppo, pol, perm, B):
         fused.begin_epoch(perm_t)
         args = fused._args_for(B)
         lib, st = _lib.load(), K.stream()
+        steps = pol.policy_step_counts.clone()              # the reduce launch's bookkeeping advances Adam's step counters
         _lib.check(lib.ppoaf_ppo_update_fwd_bwd(C.byref(args), st), "fwd_bwd")
-        _lib.check(lib.ppoaf_ppo_update_reduce(C.byref(args), 1, st), "reduce")
+        _lib.check(lib.ppoaf_ppo_update_reduce(C.byref(args), 0, st), "reduce")    # 0: no clip-norm accumulation (the Adam launch would consume it)
         torch.cuda.synchronize()
+        pol.policy_step_counts.copy_(steps)
         return fused.totals.cpu().numpy().copy(), pol.policy_grads.clone()
     ds = pol.dataset
     totals = torch.zeros(9, dtype=torch.float64, device=pol.device)
