@@ -109,6 +109,26 @@ class MATPolicy(PPOPolicy):
         """mat_policy.py:179-189 (PPOSharedEpisodeDataset: rows of [A, .])."""
         self.dataset = PPODataset(device=self.device, action_dtype=self.action_dtype, sequence_length=1)
         self.dataset.shared = True
+        # quirk Q14 (replicated; pinned by fixture g12_c5_mat): the reference creates the dataset BEFORE the rollout
+        # reshuffles the agents (ppo.py:1546-1547 vs 1643-1644) and PPOSharedEpisodeDataset keeps the agent_ids array it
+        # was handed (episode_info.py:1012), so the dataset's agent axis stays in the order the policy had at this point
+        self._dataset_slot_order = self.agent_slot_order()
+
+    def finalize_dataset(self):
+        """ppo_policy.py:714-719, with the dataset's agent axis put into its creation-time order (quirk Q14)."""
+        rollout_order = self.agent_slot_order()
+        want = getattr(self, "_dataset_slot_order", rollout_order)
+        if not np.array_equal(want, rollout_order):
+            k = torch.as_tensor(np.argsort(rollout_order)[want], device=self.device)      # dataset slot j <- rollout slot k[j]
+            b = self.buffer
+            for name in ("observations", "critic_observations", "next_observations", "actions", "raw_actions", "values",
+                         "log_probs", "rewards", "boot_value", "boot_reward"):
+                x = getattr(b, name)
+                if x is not None:
+                    x.copy_(x.index_select(2, k))
+            if getattr(b, "boot_stats", None) is not None:
+                b.boot_stats = b.boot_stats.index_select(2, k)
+        self.dataset.build()
 
     def initialize_episodes(self, env_batch_size, status_dict, ts_per_rollout=None):
         if ts_per_rollout is None:

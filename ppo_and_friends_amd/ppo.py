@@ -938,7 +938,11 @@ class PPO:
             else:
                 self._optimizer_step(policy_id)
 
-        graphs = self.use_graphs and not pol.using_lstm      # the stateful LSTM modules are run eagerly
+        # the stateful LSTM modules are run eagerly.  So is the torch-ROCm fallback of agent-grouped (MAT) policies:
+        # replaying its captured module graph in a LATER iteration, with eager tail mini-batches in between, drifted
+        # from the eager result by ~1e-4 on fixture g12_c5_mat (allocation-pattern dependent; open);
+        # the default MAT path (fused K15, replayed from its own hipGraph) reproduces the fixture
+        graphs = self.use_graphs and not pol.using_lstm and not pol.agent_grouping
         for k in range(n_full):
             run(perm[k * B:(k + 1) * B], k, graphs)
         if tail:

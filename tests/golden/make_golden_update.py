@@ -247,7 +247,14 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
                                      retain_graph=True, allow_unused=True)
             gc = torch.autograd.grad(critic_loss, [p for p in pol.critic.parameters() if p.requires_grad],
                                      retain_graph=True, allow_unused=True)
+            total = None
+            if getattr(pol, "agent_grouping", False):           # MAT: one optimiser over actor + critic, summed loss (mat_policy.py:677-699)
+                both = [p for p in pol.actor.parameters()] + [p for p in pol.critic.parameters()]
+                gt = torch.autograd.grad(actor_loss + critic_loss, both, retain_graph=True, allow_unused=True)
+                total = np.concatenate([np.zeros(p.numel(), np.float32) if g is None else g.numpy().reshape(-1)
+                                        for p, g in zip(both, gt)])
             rec["mb"].append(dict(
+                total_grad=total,
                 actor_loss=float(actor_loss.item()), critic_loss=float(critic_loss.item()),
                 actor_grads=[np.zeros(0, np.float32) if g is None else g.numpy().copy() for g in ga],
                 critic_grads=[np.zeros(0, np.float32) if g is None else g.numpy().copy() for g in gc]))
@@ -325,6 +332,8 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
     out["mb0_losses"] = np.array([mb["actor_loss"], mb["critic_loss"]], dtype=np.float64)
     out["mb0_actor_grad"] = np.concatenate([g.reshape(-1) for g in mb["actor_grads"]])
     out["mb0_critic_grad"] = np.concatenate([g.reshape(-1) for g in mb["critic_grads"]])
+    if mb["total_grad"] is not None:
+        out["mb0_total_grad"] = mb["total_grad"]                        # d(actor_loss + critic_loss) / d(actor params, critic params)
     for tag, net in (("actor", pol.actor), ("critic", pol.critic)) + ((("icm", pol.icm_model),) if pol.enable_icm else ()):
         for k, v in _flat_state(net).items():
             out[f"final_{tag}.{k}"] = v

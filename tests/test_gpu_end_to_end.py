@@ -435,7 +435,9 @@ def test_mat_policy_rollout_and_update_match_cpu_port(update_mode, B):
     order = pol.agent_slot_order()
     obs_t = env.obs_table.view(T + 1, A, E, O)[:, order].transpose(1, 2).cpu().numpy()       # [T+1,E,A,O]
     rew_t = env.reward_table.view(T, A, E)[:, order].transpose(1, 2).cpu().numpy()
-    ref = cpu.rollout(obs_t, rew_t, buf.actions[..., 0].cpu().numpy())
+    # quirk Q14: the dataset's agent axis keeps the order the policy had BEFORE this rollout's shuffle
+    k = np.argsort(order)[pol._dataset_slot_order]                     # dataset slot j <- rollout slot k[j]
+    ref = cpu.rollout(obs_t, rew_t, buf.actions[..., 0].cpu().numpy()[:, :, np.argsort(k)], dataset_slot_of=k)
     tol = dict(rtol=2e-5, atol=2e-5)
     np.testing.assert_array_equal(ds.observations.cpu().numpy(), ref.obs.numpy())
     np.testing.assert_allclose(ds.log_probs.cpu().numpy(), ref.logp.numpy(), **tol)
@@ -490,7 +492,9 @@ def test_mat_policy_with_icm_matches_cpu_port(update_mode, shared, tmp_path):
         obs_t = env.obs_table.view(T + 1, A, E, O)[:, order].transpose(1, 2).cpu().numpy()       # [T+1,E,A,O]
         rew_t = env.reward_table.view(T, A, E)[:, order].transpose(1, 2).cpu().numpy()
         ism_before = cpu.intrinsic_score_avg
-        ref = cpu.rollout(obs_t, rew_t, buf.actions[..., 0].cpu().numpy(), slot_order=order)
+        k = np.argsort(order)[pol._dataset_slot_order]                 # quirk Q14: dataset slot j <- rollout slot k[j]
+        ref = cpu.rollout(obs_t, rew_t, buf.actions[..., 0].cpu().numpy()[:, :, np.argsort(k)], slot_order=order,
+                          dataset_slot_of=k)
         np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), ref.rtg.numpy(), **tol)
         np.testing.assert_allclose(ds.advantages.cpu().numpy(), ref.adv.numpy(), **tol)
         np.testing.assert_array_equal(ds.next_observations.cpu().numpy(), ref.next_obs.numpy())
@@ -1008,11 +1012,15 @@ def test_fused_mat_and_icm_paths_fuzz_against_the_torch_paths():
         ppo.rollout()
         buf = pol.buffer
         flat = lambda x: x.reshape((T * E,) + tuple(x.shape[2:]))
+        # quirk Q14: the buffer's agent axis is in the dataset's (pre-shuffle) order; the teacher-forced check needs
+        # the order the rollout ran in (dataset slot j <- rollout slot k[j])
+        k = torch.as_tensor(np.argsort(np.argsort(pol.agent_slot_order())[pol._dataset_slot_order]), device=dev)
+        ro = lambda x: flat(x).index_select(1, k)
         with torch.no_grad():
-            v, lp, _ = pol.evaluate(flat(buf.critic_observations), flat(buf.observations), flat(buf.raw_actions))
-        np.testing.assert_allclose(flat(buf.log_probs).cpu().numpy(), lp.reshape(T * E, A).cpu().numpy(), rtol=3e-5, atol=3e-5)
+            v, lp, _ = pol.evaluate(ro(buf.critic_observations), ro(buf.observations), ro(buf.raw_actions))
+        np.testing.assert_allclose(ro(buf.log_probs).cpu().numpy(), lp.reshape(T * E, A).cpu().numpy(), rtol=3e-5, atol=3e-5)
         vn = ppo.value_normalizers["mat"]
-        np.testing.assert_allclose(flat(buf.values).cpu().numpy(), vn.denormalize(v.reshape(T * E, A)).cpu().numpy(),
+        np.testing.assert_allclose(ro(buf.values).cpu().numpy(), vn.denormalize(v.reshape(T * E, A)).cpu().numpy(),
                                    rtol=3e-5, atol=3e-5)
         # K15: the fused update against the torch update on IDENTICAL rollouts (both sampled by the torch rollout,
         # whose Philox draws differ from K16's one-launch sampler)

@@ -253,3 +253,160 @@ def test_product_reproduces_the_reference_ppo_iterations(golden, name, update_mo
         assert d.max() < 2e-4 and np.mean(d > 2e-5) < 1e-2, f"{tag}: max |dw| {d.max():.2e}, share > 2e-5: {np.mean(d > 2e-5):.2e}"
     rs = ppo.value_normalizers["agent"].running_stats
     np.testing.assert_allclose([float(rs.mean_t), float(rs.var_t), float(rs.count_t)], g["value_stats"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("update_mode", ["fused", "torch"])
+def test_product_reproduces_the_reference_mat_iterations(golden, update_mode):
+    """
+    C5 shapes: the reference's own PPO object with MATPolicy (3 agents, O=18, Discrete(5), embedding 64, 1 block, 1 head;
+    fixture g12_c5_mat).  Autoregressive rollout (K16 / torch path) with the recorded actions replayed, shared-episode
+    dataset incl. quirk Q14, first mini-batch (K15 launch): losses + the full gradient bucket before any optimiser
+    step, epochs, final weights.
+    """
+    from ppo_and_friends_amd import _lib
+    from ppo_and_friends_amd import kernels as K
+    from ppo_and_friends_amd.ppo import PPO
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.policies.mat_policy import MATPolicy
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    g = golden("g12_c5_mat")
+    c = _cfg(g)
+    E, T, A, O, B = c["E"], c["T"], c["A"], c["O"], c["batch_size"]
+    dev = torch.device("cuda", 0)
+
+    class FixtureEnv(SyntheticFixedLengthEnv):
+        def __init__(self):
+            super().__init__(E, O, Discrete(5), T, dev, num_agents=A)
+            self.obs_table = self.critic_obs_table = torch.from_numpy(agent_major(g["obs_table"])).to(dev)
+            self.reward_table = torch.from_numpy(agent_major(g["reward_table"])).to(dev)
+
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    ppo = PPO(FixtureEnv, {"agent": (MATPolicy, sp, sp, Discrete(5), {})}, device=dev, random_seed=c["seed"],
+              normalize_obs=False, normalize_rewards=False, envs_per_proc=E, ts_per_rollout=T, batch_size=B,
+              epochs_per_iter=c["epochs"], max_ts_per_ep=c["max_ts_per_ep"], update_mode=update_mode, save_state=False)
+    pol = ppo.policies["agent"]
+    assert (ppo._fused_updater("agent", B) is not None) == (update_mode == "fused")
+    sd0 = {"actor." + k[len("init_actor."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init_actor.")}
+    sd0.update({"critic." + k[len("init_critic."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init_critic.")})
+    missing, unexpected = pol.actor_critic.load_state_dict(sd0, strict=False)
+    assert not [m for m in missing if "mask" not in m] and not [u for u in unexpected if "mask" not in u], (missing, unexpected)
+    # the reference's agent orders: the one it had after finalize, then one recorded shuffle per rollout
+    pol.agent_ids = np.array([str(a) for a in g["agent_ids"]])
+    orders = iter(g["slot_orders"])
+
+    def recorded_shuffle():
+        pol.agent_ids = np.array([f"agent{i}" for i in next(orders)])
+
+    pol.shuffle_agent_ids = recorded_shuffle
+    tol = dict(rtol=1e-5, atol=1e-5)
+    sd = ppo.status_dict["agent"]
+    ep = 0
+    for it in range(c["iterations"]):
+        order = g["slot_orders"][it]
+        sl = slice(it * T, (it + 1) * T)
+        ppo.replay_raw_actions = torch.from_numpy(np.ascontiguousarray(g["step_raw_actions"][sl][:, :, order])).to(dev)
+        ds = ppo.rollout()
+        assert list(pol.agent_slot_order()) == list(order)
+        pre = f"it{it}_ds_"
+        np.testing.assert_array_equal(ds.observations.cpu().numpy(), g[pre + "observations"])     # [N, A, O], dataset agent order
+        np.testing.assert_array_equal(ds.actions.cpu().numpy().reshape(g[pre + "actions"].shape), g[pre + "actions"])
+        idx = torch.arange(len(ds), device=dev)
+        np.testing.assert_allclose(ds.values[idx].cpu().numpy(), g[pre + "values"], **tol)
+        np.testing.assert_allclose(ds.log_probs.cpu().numpy().reshape(g[pre + "log_probs"].shape), g[pre + "log_probs"], **tol)
+        np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), g[pre + "rewards_to_go"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(ds.advantages.cpu().numpy(), g[pre + "advantages"], rtol=1e-5, atol=2e-5)
+        pol.train()
+        if it == 0 and update_mode == "fused":
+            # one K15 fwd_bwd + reduce launch on the first recorded mini-batch: no optimiser step taken
+            fused = ppo._fused_updater("agent", B)
+            fused.begin_epoch(torch.as_tensor(g["epoch_perms"][0], device=dev))
+            args = fused._args_for(B)
+            opt = pol.actor_critic_optim
+            keep = opt.step_count.clone()
+            lib, st = _lib.load(), K.stream()
+            _lib.check(lib.ppoaf_mat_update_fwd_bwd(C.byref(args), st), "mat fwd_bwd")
+            _lib.check(lib.ppoaf_mat_update_reduce(C.byref(args), st), "mat reduce")
+            torch.cuda.synchronize()
+            opt.step_count.copy_(keep)
+            sc = fused.totals.cpu().numpy()
+            np.testing.assert_allclose([sc[K.SC_ACTOR], sc[K.SC_CRITIC]], g["mb0_losses"], rtol=1e-5, atol=1e-6)
+            base = pol.actor_critic.flat_params.data_ptr()
+            got = torch.cat([pol.actor_critic.flat_grads[(p.data_ptr() - base) // 4:(p.data_ptr() - base) // 4 + p.numel()]
+                             for net in (pol.actor, pol.critic) for p in net.parameters()]).cpu().numpy()
+            want = g["mb0_total_grad"]
+            scale = np.abs(want).max()
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale, err_msg=f"gradient bucket (max |g| {scale:.3e})")
+        for e in range(c["epochs"]):
+            ppo._ppo_batch_train(FixedPermLoader(pol.dataset, B, g["epoch_perms"][ep]), "agent")
+            got = np.array([sd["actor loss"], sd["critic loss"], sd["kl avg"], sd["weighted entropy"]])
+            np.testing.assert_allclose(got, g["epoch_stats"][ep], rtol=2e-5, atol=2e-6,
+                                       err_msg=f"iteration {it} epoch {e}: max dev {np.abs(got - g['epoch_stats'][ep]).max():.2e}")
+            ep += 1
+        pol.clear_dataset()
+    final = {"actor." + k[len("final_actor."):]: g[k] for k in g.files if k.startswith("final_actor.")}
+    final.update({"critic." + k[len("final_critic."):]: g[k] for k in g.files if k.startswith("final_critic.")})
+    d = np.concatenate([np.abs(p.detach().cpu().numpy() - final[k]).reshape(-1) for k, p in pol.actor_critic.named_parameters()])
+    assert d.max() < 2e-4 and np.mean(d > 2e-5) < 1e-2, f"max |dw| {d.max():.2e}, share > 2e-5: {np.mean(d > 2e-5):.2e}"
+
+
+@pytest.mark.parametrize("name,S,n_act", [("g12_lstm_term", 4, 2), ("g12_lstm_cut", 3, 3)])
+def test_product_reproduces_the_reference_lstm_iterations(golden, name, S, n_act):
+    """
+    LSTMNetwork actor / critic through the reference's own PPO object (fixtures g12_lstm_*): the product's sequence
+    path (torch-ROCm nn.LSTM inside the device rollout / window dataset / update flow) with the recorded actions and
+    shuffles: logged hidden states, dataset, epochs with hand-over + write-back, final weights.
+    """
+    from ppo_and_friends_amd.ppo import PPO
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.networks.lstm import LSTMNetwork
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    g = golden(name)
+    c = _cfg(g)
+    E, T, O, B = c["E"], c["T"], c["O"], c["batch_size"]
+    dev = torch.device("cuda", 0)
+
+    class FixtureEnv(SyntheticFixedLengthEnv):
+        def __init__(self):
+            super().__init__(E, O, Discrete(n_act), T, dev, term_prob=0.5 if g["term_table"].any() else 0.0)
+            self.obs_table = self.critic_obs_table = torch.from_numpy(agent_major(g["obs_table"])).to(dev)
+            self.reward_table = torch.from_numpy(agent_major(g["reward_table"])).to(dev)
+            if g["term_table"].any():
+                self.term_table = torch.from_numpy(g["term_table"]).to(dev)
+
+    kw = dict(sequence_length=S, lstm_hidden_size=32, ff_hidden_size=32)
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    ppo = PPO(FixtureEnv, {"agent": (None, sp, sp, Discrete(n_act), dict(ac_network=LSTMNetwork, actor_kw_args=dict(kw),
+                                                                       critic_kw_args=dict(kw)))},
+              device=dev, random_seed=c["seed"], normalize_obs=False, normalize_rewards=False, envs_per_proc=E,
+              ts_per_rollout=T, batch_size=B, epochs_per_iter=c["epochs"], max_ts_per_ep=c["max_ts_per_ep"], save_state=False)
+    pol = ppo.policies["agent"]
+    for tag, net in (("actor", pol.actor), ("critic", pol.critic)):
+        sd0 = {k[len(f"init_{tag}."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"init_{tag}.")}
+        missing, unexpected = net.load_state_dict(sd0, strict=False)
+        assert not missing and not unexpected, (tag, missing, unexpected)
+    tol = dict(rtol=1e-5, atol=1e-5)
+    sd = ppo.status_dict["agent"]
+    ep = 0
+    for it in range(c["iterations"]):
+        sl = slice(it * T, (it + 1) * T)
+        ppo.replay_raw_actions = torch.from_numpy(agent_major(g["step_raw_actions"][sl]).reshape(T, E, 1)).to(dev)
+        ds = ppo.rollout()
+        pre = f"it{it}_ds_"
+        np.testing.assert_array_equal(ds.observations.cpu().numpy(), g[pre + "observations"])
+        np.testing.assert_allclose(ds.log_probs.cpu().numpy().reshape(-1), g[pre + "log_probs"].reshape(-1), **tol)
+        np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), g[pre + "rewards_to_go"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(ds.advantages.cpu().numpy(), g[pre + "advantages"], rtol=1e-5, atol=2e-5)
+        for k in ("actor_hidden", "actor_cell", "critic_hidden", "critic_cell"):
+            np.testing.assert_allclose(getattr(ds, k)[torch.arange(E * T, device=dev)].cpu().numpy(), g[pre + k], err_msg=k, **tol)
+        pol.train()
+        for e in range(c["epochs"]):
+            # the recorded shuffles are the 13th tuple entries = sampler index + (S - 1) (episode_info.py:960-962)
+            ppo._ppo_batch_train(FixedPermLoader(pol.dataset, B, g["epoch_perms"][ep] - (S - 1)), "agent")
+            got = np.array([sd["actor loss"], sd["critic loss"], sd["kl avg"], sd["weighted entropy"]])
+            np.testing.assert_allclose(got, g["epoch_stats"][ep], rtol=2e-5, atol=2e-6,
+                                       err_msg=f"iteration {it} epoch {e}: max dev {np.abs(got - g['epoch_stats'][ep]).max():.2e}")
+            ep += 1
+        pol.clear_dataset()
+    for tag, net in (("actor", pol.actor), ("critic", pol.critic)):
+        d = np.concatenate([np.abs(p.detach().cpu().numpy() - g[f"final_{tag}.{k}"]).reshape(-1) for k, p in net.named_parameters()])
+        assert d.max() < 2e-4 and np.mean(d > 2e-5) < 1e-2, f"{tag}: max |dw| {d.max():.2e}, share > 2e-5: {np.mean(d > 2e-5):.2e}"
