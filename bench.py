@@ -15,10 +15,16 @@ default_rng(1234 + rank).  value = N * E * T * K / max-over-ranks wall time.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line; `roofline` is the GAE kernel (the kernel the metric
-names) timed with HIP events on the launch stream inside the timed region;
-`cpu_baseline` is oracle/cpu_ppo_loop.py (a port with the reference's loop
-structure) on a bounded sample, rank 0, N=1 only.
+Rank 0 prints ONE JSON line:
+  roofline            the GAE kernel (the kernel the metric names), HIP kernel events inside the timed region
+  roofline_update     the kernel that dominates the step (K12 / K15 fwd_bwd): FLOP per launch / its launch time
+                      (kernel begin/end events on eager launches of the same chain right after the timed region --
+                      the in-region launches are hipGraph nodes, which cannot carry event stamps) vs the f32-MFMA peak
+  config.other_configs  short runs (2 steps) of the other BASELINE configs' shapes (C3, C4, C5) in the same process
+  cpu_baseline        oracle/cpu_ppo_loop.py (a port with the reference's loop structure, pinned against fixtures
+                      recorded from the reference) on a bounded sample: 1 process; cpu_baseline_mpi: R = 8 processes
+                      in the reference's launch model (oracle/cpu_ddppo.py, gloo); cpu_baseline_c1: C1 exactly.
+                      Rank 0, N = 1 only; fresh CPU-only child processes, run before the GPU is touched.
 """
 import argparse
 import json
@@ -31,6 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32_16x16x4_f32), 155 TF measured
 GAE_BYTES_PER_TRANSITION = 16  # read r, V; write adv, rtg
 
 
@@ -74,6 +81,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-envs", type=int, default=256)
     p.add_argument("--no-saturating", action="store_true")
+    p.add_argument("--no-other-configs", action="store_true")
+    p.add_argument("--cpu-ranks", type=int, default=8)
     p.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
                    help="C2 (default, the metric's config) | C3 dims: HalfCheetah O=17, Box(6), actor 128^3 / "
                         "critic 256^3, E=2048, ICM + obs/reward normalisers and clippers | C4 dims: SimpleSpread MAPPO, 3 agents, "
@@ -82,58 +91,165 @@ def parse():
     return p.parse_args()
 
 
-def main():
-    args = parse()
-    # dmabuf IPC (the K17 peer mappings, RCCL's own P2P): must be in the environment before HIP initialises
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+def cpu_baselines(args):
+    """
+    The reference's CPU path, timed on this box's host cores BEFORE anything touches the GPU, in fresh CPU-only
+    child processes (oracle/cpu_ddppo.py): one process (best of a few intra-op thread counts, found on a tiny
+    probe: the reference's own default -- all host cpus per process -- is far slower for 128-wide layers), R
+    processes in its mpirun launch model, and C1 exactly.
+    """
+    from oracle import cpu_ddppo
+    cores = os.cpu_count() or 1
+    try:
+        model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    T, B, K = args.ts, args.batch_size, args.epochs
+    cands = [c for c in (1, 4, 8) if c <= cores]
+    probe = {th: cpu_ddppo.run_ranks(1, 16, T, 1, B, th)["env_steps_per_s"] for th in cands}
+    th = max(probe, key=probe.get)
+    Ec = args.cpu_sample_envs
+    one = cpu_ddppo.run_ranks(1, Ec, T, K, B, th)
+    out = {"cpu_baseline": {
+        "value": round(one["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": th, "kind": "port",
+        "sample": f"one PPO iteration of the C2 workload at envs_per_proc={Ec} (T={T}, batch {B}, {K} epochs; per-transition "
+                  f"cost is flat in E): rollout {one['rollout_s']:.2f}s + update {one['update_s']:.2f}s; 1 process, torch "
+                  f"threads={th} (fastest of {cands} on a probe: {({k: round(v) for k, v in probe.items()})} env-steps/s)",
+        "cpu_model": model, "host_cpus": cores}}
+    R = max(1, min(args.cpu_ranks, cores))
+    if R > 1:
+        tpr = max(cores // R, 1)                                   # utils/mpi_utils.py:37-48
+        Er = max(Ec // R, 8)
+        many = cpu_ddppo.run_ranks(R, Er, T, K, B, tpr)
+        out["cpu_baseline_mpi"] = {
+            "value": round(many["env_steps_per_s"], 1), "unit": "env-steps/s", "ranks": R, "cores": R * tpr, "kind": "port",
+            "cpu_model": model,
+            "sample": f"the reference's launch model (mpirun -n {R}): {R} gloo processes x envs_per_proc={Er}, {tpr} torch "
+                      f"thread(s) each, per mini-batch an all-gather of the raw rewards-to-go, one all-reduce per parameter "
+                      f"tensor and a barrier; rollout {many['rollout_s']:.2f}s + update {many['update_s']:.2f}s"}
+    c1 = cpu_ddppo.run_ranks(1, 8, 128, 10, 256, 1)
+    out["cpu_baseline_c1"] = {"value": round(c1["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": 1, "kind": "port",
+                              "sample": "BASELINE configs[0] exactly: envs_per_proc=8, ts_per_rollout=128, 1 CPU rank, 1 thread, "
+                                        f"batch 256, 10 epochs: {c1['wall_s']:.2f}s per iteration"}
+    return out
+
+
+CONFIGS = ("C2", "C3", "C4", "C5")
+
+
+def build_config(name, args, device, rank):
+    """-> (ppo, pol, dims) for one BASELINE config's shapes (SURVEY.md §8 sizes)."""
     import numpy as np
-    import torch
-    import torch.distributed as dist
-    from ppo_and_friends_amd.utils import mpi_utils
     from ppo_and_friends_amd.ppo import PPO
     from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
     from ppo_and_friends_amd.spaces import Box, Discrete
-    from ppo_and_friends_amd import kernels as K
-
-    rank, world, local_rank = mpi_utils.init_process_group_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if os.environ.get("PPOAF_SHARE_DEVICE", "0") == "1":
-        local_rank = 0          # rehearsal on a one-GPU box (with PPOAF_BACKEND=gloo): all ranks on device 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    E, T, O, NA = args.envs, args.ts, 4, 2
-    A, critic_view, act_space, pargs, workload = 1, "local", Discrete(NA), {}, None
+    T = args.ts
+    E, O, NA = args.envs, 4, 2
+    A, critic_view, act_space, pargs, policy_class = 1, "local", Discrete(NA), {}, None
     filters = dict(normalize_obs=False, normalize_rewards=False)     # C2/C4/C5 as SURVEY.md §8(d) defines them
-    if args.config == "C3":
+    workload = (f"C2 CartPole-v1 MLP (4->128x3->2 actor, ->1 critic), envs_per_proc={E}, ts_per_rollout={T}, "
+                "fixed-length synthetic trajectories")
+    if name == "C3":
         E, O = (2048 if args.envs == 4096 else args.envs), 17
         act_space = Box(-1.0, 1.0, (6,), np.float32)
         pargs = dict(actor_kw_args=dict(hidden_size=128), critic_kw_args=dict(hidden_size=256), enable_icm=True)
         filters = dict(normalize_obs=True, normalize_rewards=True, obs_clip=(-10.0, 10.0), reward_clip=(-10.0, 10.0))
         workload = (f"C3 dims (HalfCheetah-v4: O=17, Box(6) tanh-Gaussian, actor 128^3, critic 256^3, ICM, "
                     f"obs/reward normalisers + clippers), envs_per_proc={E}, ts_per_rollout={T}")
-    elif args.config == "C4":
+    elif name == "C4":
         E, O, NA, A, critic_view = (1024 if args.envs == 4096 else args.envs), 18, 5, 3, "policy"
         act_space = Discrete(NA)
         pargs = dict(actor_kw_args=dict(hidden_size=128), critic_kw_args=dict(hidden_size=256))
         workload = (f"C4 dims (MPE simple_spread MAPPO: 3 agents share one policy, O=18, O_c=54, Discrete(5), "
                     f"actor 128^3, critic 256^3), envs_per_proc={E}, ts_per_rollout={T}")
-
-    policy_class = None
-    if args.config == "C5":
+    elif name == "C5":
         from ppo_and_friends_amd.policies.mat_policy import MATPolicy
         E, O, NA, A, critic_view = (1024 if args.envs == 4096 else args.envs), 18, 5, 3, "local"
         act_space, policy_class, pargs = Discrete(NA), MATPolicy, {}
         workload = (f"C5 dims (MPE simple_spread MATPolicy: 3 agents, O=18, Discrete(5), embedding 64, 1 block, "
                     f"1 head, attention core on f32 MFMA), envs_per_proc={E}, ts_per_rollout={T}")
-
-    env_gen = lambda: SyntheticFixedLengthEnv(E, O, act_space, T, device, reward="ones" if args.config == "C2" else "uniform",
+    env_gen = lambda: SyntheticFixedLengthEnv(E, O, act_space, T, device, reward="ones" if name == "C2" else "uniform",
                                               seed=1234, rank=rank, num_agents=A, critic_view=critic_view)
     obs_space = Box(-np.inf, np.inf, (O,), np.float32)
     cobs_space = Box(-np.inf, np.inf, (O * A if critic_view == "policy" else O,), np.float32)
     settings = {"cartpole": (policy_class, obs_space, cobs_space, act_space, pargs)}
     ppo = PPO(env_gen, settings, device=device, random_seed=1, envs_per_proc=E, ts_per_rollout=T,
-              batch_size=args.batch_size, epochs_per_iter=args.epochs, use_graphs=not args.no_graphs, **filters)
-    pol = ppo.policies["cartpole"]
+              batch_size=args.batch_size, epochs_per_iter=args.epochs, use_graphs=not args.no_graphs, save_state=False, **filters)
+    workload += f", batch_size={args.batch_size}, epochs_per_iter={args.epochs}"
+    return ppo, ppo.policies["cartpole"], dict(E=E, T=T, A=A, O=O, workload=workload)
+
+
+def update_kernel_roofline(ppo, pol, B, launches=64):
+    """
+    roofline_update: the kernel that dominates the step.  After the timed region the same per-mini-batch chain
+    (fwd_bwd -> reduce -> Adam, so every launch sees weights the Adam launch has just rewritten, as in the timed
+    chain) is launched eagerly `launches` times with the fwd_bwd kernel's own begin / end stamped into HIP events.
+    FLOP per launch = 3 x (forward FLOP per row) x rows: forward, dgrad and wgrad each cost one forward's worth.
+    """
+    import ctypes as C
+    import torch
+    from ppo_and_friends_amd import _lib
+    from ppo_and_friends_amd import kernels as K
+    fused = ppo._fused_updater("cartpole", B)
+    if fused is None:
+        return None
+    lib, st = _lib.load(), K.stream()
+    N = pol.buffer.num_transitions
+    fused.begin_epoch(torch.randperm(N, device=pol.device))
+    args = fused._args_for(B)
+    ref = C.byref(args)
+    lin = lambda net: sum(2 * m.weight.numel() for m in net.modules() if isinstance(m, torch.nn.Linear))
+    evs = []
+    if pol.agent_grouping:                                              # K15: one row = one env = A tokens
+        A = pol.num_agents
+        fwd = A * lin(pol.actor_critic) + 3 * 2 * 2 * A * A * 64        # linears per token + 3 attention cores (QK^T, PV)
+        kernel, desc = "mat_update_fwd_bwd_kernel", f"3 x ({A} tokens x 2 x sum(Linear weights) + 3 attention cores) x B"
+        opt, ac = pol.actor_critic_optim, pol.actor_critic
+        clip = pol.gradient_clip
+        for _ in range(launches):
+            ev = (K.event_create(), K.event_create())
+            _lib.check(lib.ppoaf_mat_update_fwd_bwd_timed(ref, ev[0], ev[1], st), "mat fwd_bwd")
+            _lib.check(lib.ppoaf_mat_update_reduce(ref, st), "mat reduce")
+            _lib.check(lib.ppoaf_adam_step_prenormed(
+                ac.flat_params.data_ptr(), ac.flat_grads.data_ptr(), opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr(),
+                ac.flat_params.numel(), opt.step_count.data_ptr(), opt.lr.data_ptr(), opt.betas[0], opt.betas[1], opt.eps,
+                1.0, float(clip) if clip is not None else 0.0, opt.norm_scratch.data_ptr(), opt.grad_norm.data_ptr(), st), "adam")
+            evs.append(ev)
+    else:
+        fwd = lin(pol.actor) + lin(pol.critic)
+        ha, hc = args.actor.hidden // 16, args.critic.hidden // 16
+        kernel, desc = f"ppo_update_fwd_bwd_kernel<{ha}, {hc}>", "3 x 2 x sum(Linear weights of actor + critic) x B"
+        for _ in range(launches):
+            ev = (K.event_create(), K.event_create())
+            _lib.check(lib.ppoaf_ppo_update_fwd_bwd_timed(ref, ev[0], ev[1], st), "fwd_bwd")
+            _lib.check(lib.ppoaf_ppo_update_reduce(ref, 1, st), "reduce")
+            _lib.check(lib.ppoaf_ppo_update_adam(ref, 0, st), "adam")
+            evs.append(ev)
+    torch.cuda.synchronize()
+    us = sorted(K.event_elapsed_ms(a, b) * 1e3 for a, b in evs)
+    avg = sum(us) / len(us)
+    flop = 3 * fwd * B
+    tf = flop / (avg * 1e-6) / 1e12
+    return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 5), "flop_per_launch": int(flop), "flop_formula": desc,
+            "avg_launch_us": round(avg, 2), "median_launch_us": round(us[len(us) // 2], 2), "launches": len(us),
+            "launches_per_step": (N // B) * ppo.epochs_per_iter,
+            "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on eager launches of the fwd_bwd -> reduce -> Adam chain "
+                      "right after the timed region (in-region launches are hipGraph nodes); profiles/ holds the rocprofv3 "
+                      "summary of the same command",
+            "traffic": None}
+
+
+def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline):
+    """Time `steps` PPO iterations of one config -> result dict (value, ms_per_step, rooflines, exchange info)."""
+    import torch
+    import torch.distributed as dist
+    from ppo_and_friends_amd.utils import mpi_utils
+    from ppo_and_friends_amd import kernels as K
+    import ppo_and_friends_amd.utils.episode_info as ei
+
+    ppo, pol, d = build_config(name, args, device, rank)
+    E, T, A = d["E"], d["T"], d["A"]
 
     def barrier():
         if mpi_utils.distributed_path():
@@ -148,7 +264,6 @@ def main():
         ppo.train_on_rollout()
 
     # GAE launch timing: HIP events on the launch stream, around the K1 launch of every timed rollout
-    import ppo_and_friends_amd.utils.episode_info as ei
     orig = ei.RolloutBuffer.compute_advantages
 
     def timed_compute(self, *a, **kw):
@@ -161,31 +276,35 @@ def main():
         return r
 
     ei.RolloutBuffer.compute_advantages = timed_compute
-
-    for _ in range(args.warmup):
-        iteration(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        iteration(True)
-    barrier()
-    dt = time.perf_counter() - t0
+    try:
+        for _ in range(warmup):
+            iteration(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            iteration(True)
+        barrier()
+        dt = time.perf_counter() - t0
+    finally:
+        ei.RolloutBuffer.compute_advantages = orig
     dt = float(mpi_utils.allreduce_scalars([dt], op="max")[0])        # MAX over ranks
-
-    env_steps = world * E * T * args.steps
-    value = env_steps / dt
-    gae_ms = [K.event_elapsed_ms(a, b) for a, b in gae_events]
-    gae_avg_s = (sum(gae_ms) / max(len(gae_ms), 1)) * 1e-3
-    gae_bytes = GAE_BYTES_PER_TRANSITION * E * T * A
-    achieved = gae_bytes / gae_avg_s / 1e9 if gae_avg_s > 0 else 0.0
-    pmc = pmc_traffic() if (E, T) == (4096, 128) else {}
-    roofline = {"kernel": "gae_rtg_chunked_kernel" if E < (1 << 17) else "gae_rtg_stream_kernel", "bound": "hbm", "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": pmc.get("ppoaf::gae_rtg_chunked_kernel"), "traffic_source": pmc.get("_source"),
-                "bytes_per_launch": gae_bytes,
-                "avg_launch_us": round(gae_avg_s * 1e6, 3), "launches": len(gae_ms),
-                "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on the launch stream, timed region",
-                "note": "config size (8.4 MB, fits L2/MALL) is latency-bound; see roofline_saturating"}
+    res = {"value": round(world * E * T * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "warmup": warmup, "workload": d["workload"], "E": E, "T": T, "A": A,
+           "rollout_s": round(ppo.status_dict["global status"]["rollout time"], 4),
+           "train_s": round(ppo.status_dict["global status"]["train time"], 4)}
+    if with_gae_roofline:
+        gae_ms = [K.event_elapsed_ms(a, b) for a, b in gae_events]
+        gae_avg_s = (sum(gae_ms) / max(len(gae_ms), 1)) * 1e-3
+        gae_bytes = GAE_BYTES_PER_TRANSITION * E * T * A
+        achieved = gae_bytes / gae_avg_s / 1e9 if gae_avg_s > 0 else 0.0
+        pmc = pmc_traffic() if (E, T) == (4096, 128) else {}
+        res["roofline"] = {
+            "kernel": "gae_rtg_chunked_kernel" if E < (1 << 17) else "gae_rtg_stream_kernel", "bound": "hbm",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": pmc.get("ppoaf::gae_rtg_chunked_kernel"), "traffic_source": pmc.get("_source"),
+            "bytes_per_launch": gae_bytes, "avg_launch_us": round(gae_avg_s * 1e6, 3), "launches": len(gae_ms),
+            "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on the launch stream, timed region",
+            "note": "config size (8.4 MB, fits L2/MALL) is latency-bound; see roofline_saturating"}
 
     # which per-mini-batch gradient exchange the update loops actually used (N > 1 or its rehearsal)
     fused = [f for f in getattr(ppo, "_fused", {}).values() if f is not None]
@@ -194,12 +313,13 @@ def main():
         ("K17 peer mappings (xGMI), in-graph" if peer else "RCCL all-reduce, eager loop")
     if exchange is not None and fused:                       # why that path (self-test verdict / fallback reason)
         exchange += f" [{getattr(fused[0], 'xchg_reason', '')}]"
+    res["gradient_exchange"], res["peer"] = exchange, peer
 
     # N > 1 only, after the timed region: what one gradient exchange of this bucket costs on this node, with the
     # K17 kernel and with the process group's all-reduce (back-to-back launches, stream events) -- recorded so that
     # a multi-GPU run documents the latency its scaling number rests on
     probe = None
-    if mpi_utils.distributed_path() and fused:
+    if mpi_utils.distributed_path() and fused and with_gae_roofline:
         n_f = pol.policy_grads.numel()
         buf = torch.zeros(n_f, dtype=torch.float32, device=device)
         reps = 200
@@ -224,24 +344,65 @@ def main():
             for _ in range(5):
                 dist.all_reduce(buf)
             probe["process_group_allreduce_us"] = round(timed(lambda: dist.all_reduce(buf)), 2)
+    res["exchange_probe"] = probe
+    if not mpi_utils.distributed_path():                      # single rank: the eager chain is this rank's own
+        res["roofline_update"] = update_kernel_roofline(ppo, pol, args.batch_size)
+    del ppo, pol
+    torch.cuda.empty_cache()
+    return res
 
-    out = {"metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s",
+
+def main():
+    args = parse()
+    # dmabuf IPC (the K17 peer mappings, RCCL's own P2P): must be in the environment before HIP initialises
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_rank = int(os.environ.get("RANK", "0"))
+    cpu = {}
+    if env_world == 1 and env_rank == 0 and not args.no_cpu_baseline and args.config == "C2":
+        cpu = cpu_baselines(args)                             # CPU-only child processes, before the GPU is touched
+
+    import torch
+    import torch.distributed as dist
+    from ppo_and_friends_amd.utils import mpi_utils
+    from ppo_and_friends_amd import kernels as K
+
+    rank, world, local_rank = mpi_utils.init_process_group_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("PPOAF_SHARE_DEVICE", "0") == "1":
+        local_rank = 0          # rehearsal on a one-GPU box (with PPOAF_BACKEND=gloo): all ranks on device 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    main_res = run_config(args.config, args, device, rank, world, args.steps, args.warmup, True)
+    others = {}
+    if args.config == "C2" and not args.no_other_configs:
+        for name in CONFIGS:
+            if name == "C2":
+                continue
+            r = run_config(name, args, device, rank, world, 2, 1, False)
+            others[name] = {"value": r["value"], "unit": "env-steps/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                            "warmup": r["warmup"], "workload": r["workload"],
+                            "agent_steps_per_iteration": world * r["E"] * r["T"] * r["A"],
+                            "gradient_exchange": r["gradient_exchange"], "roofline_update": r.get("roofline_update")}
+
+    E, T, A = main_res["E"], main_res["T"], main_res["A"]
+    out = {"metric": "env_steps_per_sec", "value": main_res["value"], "unit": "env-steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+           "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": (workload + f", batch_size={args.batch_size}, epochs_per_iter={args.epochs}"
-                                   if workload else
-                                   "C2 CartPole-v1 MLP (4->128x3->2 actor, ->1 critic), "
-                                   f"envs_per_proc={E}, ts_per_rollout={T}, batch_size={args.batch_size}, "
-                                   f"epochs_per_iter={args.epochs}, fixed-length synthetic trajectories"),
+           "config": {"workload": main_res["workload"],
                       "agent_steps_per_iteration": world * E * T * A,
                       "global_env_steps_per_iteration": world * E * T,
-                      "parallelism": f"dp{world}", "hip_graphs": (not args.no_graphs) and (not mpi_utils.distributed_path() or peer),
+                      "parallelism": f"dp{world}",
+                      "hip_graphs": (not args.no_graphs) and (not mpi_utils.distributed_path() or main_res["peer"]),
                       "multi_rank_path": mpi_utils.distributed_path(),
-                      "gradient_exchange": exchange, "exchange_probe": probe,
-                      "rollout_s": round(ppo.status_dict["global status"]["rollout time"], 4),
-                      "train_s": round(ppo.status_dict["global status"]["train time"], 4)},
-           "roofline": roofline}
+                      "gradient_exchange": main_res["gradient_exchange"], "exchange_probe": main_res["exchange_probe"],
+                      "rollout_s": main_res["rollout_s"], "train_s": main_res["train_s"],
+                      "other_configs": others or None},
+           "roofline": main_res["roofline"]}
+    if main_res.get("roofline_update") is not None:
+        out["roofline_update"] = main_res["roofline_update"]
 
     if rank == 0 and not args.no_saturating:
         # companion: same kernel at a bandwidth-saturating size (N = 2^28 transitions)
@@ -256,32 +417,17 @@ def main():
         for ev in evs:
             K.gae_rtg_tmajor(r, v, b, b, None, adv_out=adv, rtg_out=rtg, timing_events=ev)
         torch.cuda.synchronize()
-        s = sum(K.event_elapsed_ms(a, c) for a, c in evs) * 1e-3 / reps
+        sec = sum(K.event_elapsed_ms(a, c) for a, c in evs) * 1e-3 / reps
         bts = GAE_BYTES_PER_TRANSITION * T * Es
         out["roofline_saturating"] = {"kernel": "gae_rtg_stream_kernel<4, 8>", "bound": "hbm",
-                                      "transitions": T * Es, "achieved": round(bts / s / 1e9, 1),
+                                      "transitions": T * Es, "achieved": round(bts / sec / 1e9, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(bts / s / 1e9 / HBM_PEAK_GBS, 4),
-                                      "avg_launch_us": round(s * 1e6, 1),
+                                      "frac": round(bts / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                      "avg_launch_us": round(sec * 1e6, 1),
                                       "traffic": pmc_traffic().get("void ppoaf::gae_rtg_stream_kernel<4, 8>")}
         del r, v, b, adv, rtg
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "C2":
-        from oracle import cpu_ppo_loop
-        Ec = args.cpu_sample_envs
-        import os as _os
-        cands = [c for c in (1, 4, 8, 16) if c <= (_os.cpu_count() or 1)]
-        th = cpu_ppo_loop.pick_threads(cands, T)
-        cb = cpu_ppo_loop.time_iteration(Ec, T, O, NA, epochs=args.epochs, batch_size=args.batch_size,
-                                         threads=th)
-        out["cpu_baseline"] = {"value": round(cb["env_steps_per_s"], 1), "unit": "env-steps/s",
-                               "cores": cb["threads"], "kind": "port",
-                               "sample": f"one PPO iteration of the same workload at envs_per_proc={Ec} "
-                                         f"(T={T}, batch {args.batch_size}, {args.epochs} epochs; per-transition "
-                                         f"cost is flat in E): rollout {cb['rollout_s']:.2f}s + update "
-                                         f"{cb['update_s']:.2f}s; torch threads={cb['threads']} (fastest of "
-                                         f"{cands} on a probe; the reference's default would be all "
-                                         f"{os.cpu_count()} host cpus, which is slower)"}
+    out.update(cpu)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if mpi_utils.is_initialized():

@@ -374,6 +374,9 @@ typedef struct {
 } ppoaf_ppo_update_args_t;
 
 int ppoaf_ppo_update_fwd_bwd(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t stream);
+/* same launch with the kernel's own begin / end stamped into two events (as ppoaf_gae_rtg_tmajor_timed) */
+int ppoaf_ppo_update_fwd_bwd_timed(const ppoaf_ppo_update_args_t* args, void* start_event, void* stop_event,
+                                   ppoaf_stream_t stream);
 int ppoaf_ppo_update_reduce(const ppoaf_ppo_update_args_t* args, int compute_norms, ppoaf_stream_t stream);
 int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int compute_norms, ppoaf_stream_t stream);
 
@@ -612,6 +615,8 @@ typedef struct {
 } ppoaf_mat_update_args_t;
 
 int ppoaf_mat_update_fwd_bwd(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream);
+int ppoaf_mat_update_fwd_bwd_timed(const ppoaf_mat_update_args_t* args, void* start_event, void* stop_event,
+                                   ppoaf_stream_t stream);
 int ppoaf_mat_update_reduce(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream);
 
 /* ------------------------------------------------------------------------ *

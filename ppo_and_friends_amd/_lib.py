@@ -184,6 +184,7 @@ SIGNATURES = {
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        _ptr, _ptr, _ptr]),
     "ppoaf_ppo_update_fwd_bwd": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr]),
+    "ppoaf_ppo_update_fwd_bwd_timed": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, _ptr, _ptr]),
     "ppoaf_ppo_update_reduce": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
     "ppoaf_ppo_update_adam": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
     "ppoaf_icm_forward_loss_fwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, C.c_float, _ptr, _ptr, _ptr, _ptr]),
@@ -199,6 +200,7 @@ SIGNATURES = {
     "ppoaf_adam_step_prenormed": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr, _ptr, C.c_float, C.c_float,
                                             C.c_float, C.c_float, C.c_float, _ptr, _ptr, _ptr]),
     "ppoaf_mat_update_fwd_bwd": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
+    "ppoaf_mat_update_fwd_bwd_timed": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr, _ptr, _ptr]),
     "ppoaf_mat_update_reduce": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
     "ppoaf_mat_policy_step": (C.c_int, [C.POINTER(MatStepArgs), _ptr]),
     "ppoaf_peer_exchange_create": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),

@@ -16,6 +16,7 @@
 // A mini-batch of 256 envs is 52 workgroups; the ~80 dependent phases are barrier + LDS latency
 // bound, not MFMA bound -- the point is that they replace ~270 separate kernel launches.
 #include "mlp_device.hpp"
+#include <hip/hip_ext.h>
 
 namespace ppoaf {
 
@@ -1028,6 +1029,12 @@ static int make_mat(const ppoaf_mat_update_args_t* a, MatDev& u) {
 using namespace ppoaf;
 
 extern "C" int ppoaf_mat_update_fwd_bwd(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream) {
+    return ppoaf_mat_update_fwd_bwd_timed(args, nullptr, nullptr, stream);
+}
+
+extern "C" int ppoaf_mat_update_fwd_bwd_timed(const ppoaf_mat_update_args_t* args, void* start_event, void* stop_event,
+                                              ppoaf_stream_t stream) {
+    hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;
     MatDev u;
     const int rc = make_mat(args, u);
     if (rc) return rc;
@@ -1040,7 +1047,10 @@ extern "C" int ppoaf_mat_update_fwd_bwd(const ppoaf_mat_update_args_t* args, ppo
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(mat_update_fwd_bwd_kernel, dim3((unsigned)u.nT), dim3(kMT), lds, (hipStream_t)stream, u);
+    if (e0 || e1)
+        hipExtLaunchKernelGGL(mat_update_fwd_bwd_kernel, dim3((unsigned)u.nT), dim3(kMT), lds, (hipStream_t)stream, e0, e1, 0, u);
+    else
+        hipLaunchKernelGGL(mat_update_fwd_bwd_kernel, dim3((unsigned)u.nT), dim3(kMT), lds, (hipStream_t)stream, u);
     return check_launch("mat_update_fwd_bwd");
 }
 

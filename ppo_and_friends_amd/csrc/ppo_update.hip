@@ -13,6 +13,7 @@
 // are summed in a fixed order by the reduce kernel, so results are bitwise reproducible (float
 // atomics would not be) and nothing needs zeroing.
 #include "mlp_device.hpp"
+#include <hip/hip_ext.h>
 #include "peer_exchange_device.hpp"
 #include <cstdlib>
 
@@ -926,7 +927,7 @@ static size_t fwd_bwd_lds_bytes(const UpdateDev& u) {
 }
 
 template <int HTA, int HTC>
-static int launch_fwd_bwd(const UpdateDev& u, size_t lds, hipStream_t s) {
+static int launch_fwd_bwd(const UpdateDev& u, size_t lds, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_update_fwd_bwd_kernel<HTA, HTC>),
@@ -935,7 +936,10 @@ static int launch_fwd_bwd(const UpdateDev& u, size_t lds, hipStream_t s) {
         attr_set = true;
     }
     const unsigned grid = 8u * (unsigned)((u.n_wg + 3) / 4);     // groups of 4 actor + 4 critic blocks
-    hipLaunchKernelGGL((ppo_update_fwd_bwd_kernel<HTA, HTC>), dim3(grid), dim3(kThreadsU), lds, s, u);
+    if (e0 || e1)        // the kernel's own begin / end stamped into the events (bench.py: roofline_update)
+        hipExtLaunchKernelGGL((ppo_update_fwd_bwd_kernel<HTA, HTC>), dim3(grid), dim3(kThreadsU), lds, s, e0, e1, 0, u);
+    else
+        hipLaunchKernelGGL((ppo_update_fwd_bwd_kernel<HTA, HTC>), dim3(grid), dim3(kThreadsU), lds, s, u);
     return check_launch("ppo_update_fwd_bwd");
 }
 
@@ -944,6 +948,12 @@ static int launch_fwd_bwd(const UpdateDev& u, size_t lds, hipStream_t s) {
 using namespace ppoaf;
 
 extern "C" int ppoaf_ppo_update_fwd_bwd(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t stream) {
+    return ppoaf_ppo_update_fwd_bwd_timed(args, nullptr, nullptr, stream);
+}
+
+extern "C" int ppoaf_ppo_update_fwd_bwd_timed(const ppoaf_ppo_update_args_t* args, void* start_event, void* stop_event,
+                                              ppoaf_stream_t stream) {
+    hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;
     UpdateDev u;
     int rc = make_dev(args, u);
     if (rc) return rc;
@@ -952,12 +962,12 @@ extern "C" int ppoaf_ppo_update_fwd_bwd(const ppoaf_ppo_update_args_t* args, ppo
     hipStream_t s = (hipStream_t)stream;
     // instantiated (actor width, critic width) pairs; the host falls back to the torch path otherwise
     const int ha = u.net[0].H, hc = u.net[1].H;
-    if (ha == 32 && hc == 32) return launch_fwd_bwd<2, 2>(u, lds, s);
-    if (ha == 64 && hc == 64) return launch_fwd_bwd<4, 4>(u, lds, s);
-    if (ha == 128 && hc == 128) return launch_fwd_bwd<8, 8>(u, lds, s);
-    if (ha == 256 && hc == 256) return launch_fwd_bwd<16, 16>(u, lds, s);
-    if (ha == 128 && hc == 256) return launch_fwd_bwd<8, 16>(u, lds, s);
-    if (ha == 64 && hc == 128) return launch_fwd_bwd<4, 8>(u, lds, s);
+    if (ha == 32 && hc == 32) return launch_fwd_bwd<2, 2>(u, lds, s, e0, e1);
+    if (ha == 64 && hc == 64) return launch_fwd_bwd<4, 4>(u, lds, s, e0, e1);
+    if (ha == 128 && hc == 128) return launch_fwd_bwd<8, 8>(u, lds, s, e0, e1);
+    if (ha == 256 && hc == 256) return launch_fwd_bwd<16, 16>(u, lds, s, e0, e1);
+    if (ha == 128 && hc == 256) return launch_fwd_bwd<8, 16>(u, lds, s, e0, e1);
+    if (ha == 64 && hc == 128) return launch_fwd_bwd<4, 8>(u, lds, s, e0, e1);
     set_error("ppo_update_fwd_bwd: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
     return PPOAF_E_INVALID;
 }

@@ -250,4 +250,6 @@ def test_bench_contract_under_the_drivers_two_rank_launch():
     assert cfg["parallelism"] == "dp2" and cfg["global_env_steps_per_iteration"] == 2 * 4096 * 128
     assert cfg["multi_rank_path"] is True and cfg["hip_graphs"] is True and cfg["gradient_exchange"].startswith("K17")
     assert abs(out["value"] - 2 * 4096 * 128 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-3
+    others = cfg["other_configs"]                    # the other BASELINE configs' shapes ride in the same line
+    assert sorted(others) == ["C3", "C4", "C5"] and all(o["value"] > 0 for o in others.values())
     assert "roofline" in out and out["roofline"]["bound"] == "hbm"
