@@ -39,6 +39,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32_16x16x4_f32), 155 TF measured
 GAE_BYTES_PER_TRANSITION = 16  # read r, V; write adv, rtg
+STREAM_KERNEL = "void ppoaf::gae_rtg_stream_kernel<4, 1, 1024, false, 1>"   # the large-E form of K1 (csrc/gae.hip)
 
 
 def pmc_traffic():
@@ -60,7 +61,7 @@ def pmc_traffic():
         if m:
             vals[(m.group(1), m.group(2))] = float(m.group(3))
     out = {}
-    for name, mult in (("ppoaf::gae_rtg_chunked_kernel", 1.0), ("void ppoaf::gae_rtg_stream_kernel<4, 8>", 2.0)):
+    for name, mult in (("ppoaf::gae_rtg_chunked_kernel", 1.0), (STREAM_KERNEL, 2.0)):
         f, w = vals.get((name, "FETCH_SIZE")), vals.get((name, "WRITE_SIZE"))
         if f is not None and w is not None:
             out[name] = int((mult * f + w) * 1024)
@@ -82,7 +83,9 @@ def parse():
     p.add_argument("--cpu-sample-envs", type=int, default=256)
     p.add_argument("--no-saturating", action="store_true")
     p.add_argument("--no-other-configs", action="store_true")
-    p.add_argument("--cpu-ranks", type=int, default=8)
+    p.add_argument("--cpu-ranks", type=int, default=4,
+                   help="ranks of the multi-process CPU baseline (the GPU pool allows at most 6 processes that have "
+                        "loaded the ROCm runtime at once -- importing torch counts -- so 8 ranks cannot be started there)")
     p.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
                    help="C2 (default, the metric's config) | C3 dims: HalfCheetah O=17, Box(6), actor 128^3 / "
                         "critic 256^3, E=2048, ICM + obs/reward normalisers and clippers | C4 dims: SimpleSpread MAPPO, 3 agents, "
@@ -99,7 +102,12 @@ def cpu_baselines(args):
     processes in its mpirun launch model, and C1 exactly.
     """
     from oracle import cpu_ddppo
-    cores = os.cpu_count() or 1
+    # the host cores this job may use: its affinity mask, capped at the pool's per-GPU CPU share (16)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
     try:
         model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
     except Exception:
@@ -115,7 +123,7 @@ def cpu_baselines(args):
         "sample": f"one PPO iteration of the C2 workload at envs_per_proc={Ec} (T={T}, batch {B}, {K} epochs; per-transition "
                   f"cost is flat in E): rollout {one['rollout_s']:.2f}s + update {one['update_s']:.2f}s; 1 process, torch "
                   f"threads={th} (fastest of {cands} on a probe: {({k: round(v) for k, v in probe.items()})} env-steps/s)",
-        "cpu_model": model, "host_cpus": cores}}
+        "cpu_model": model, "host_cpus": os.cpu_count(), "cores_used_at_most": cores}}
     R = max(1, min(args.cpu_ranks, cores))
     if R > 1:
         tpr = max(cores // R, 1)                                   # utils/mpi_utils.py:37-48
@@ -124,7 +132,8 @@ def cpu_baselines(args):
         out["cpu_baseline_mpi"] = {
             "value": round(many["env_steps_per_s"], 1), "unit": "env-steps/s", "ranks": R, "cores": R * tpr, "kind": "port",
             "cpu_model": model,
-            "sample": f"the reference's launch model (mpirun -n {R}): {R} gloo processes x envs_per_proc={Er}, {tpr} torch "
+            "sample": f"the reference's launch model (mpirun -n {R}; {R} ranks is what this pool's process guard admits): "
+                      f"{R} gloo processes x envs_per_proc={Er}, {tpr} torch "
                       f"thread(s) each, per mini-batch an all-gather of the raw rewards-to-go, one all-reduce per parameter "
                       f"tensor and a barrier; rollout {many['rollout_s']:.2f}s + update {many['update_s']:.2f}s"}
     c1 = cpu_ddppo.run_ranks(1, 8, 128, 10, 256, 1)
@@ -194,6 +203,8 @@ def update_kernel_roofline(ppo, pol, B, launches=64):
     if fused is None:
         return None
     lib, st = _lib.load(), K.stream()
+    ppo.rollout()                                                       # a fresh dataset for the probe's epoch tables
+    pol.train()
     N = pol.buffer.num_transitions
     fused.begin_epoch(torch.randperm(N, device=pol.device))
     args = fused._args_for(B)
@@ -419,12 +430,12 @@ def main():
         torch.cuda.synchronize()
         sec = sum(K.event_elapsed_ms(a, c) for a, c in evs) * 1e-3 / reps
         bts = GAE_BYTES_PER_TRANSITION * T * Es
-        out["roofline_saturating"] = {"kernel": "gae_rtg_stream_kernel<4, 8>", "bound": "hbm",
+        out["roofline_saturating"] = {"kernel": "gae_rtg_stream_kernel<4, 1, 1024>", "bound": "hbm",
                                       "transitions": T * Es, "achieved": round(bts / sec / 1e9, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(bts / sec / 1e9 / HBM_PEAK_GBS, 4),
                                       "avg_launch_us": round(sec * 1e6, 1),
-                                      "traffic": pmc_traffic().get("void ppoaf::gae_rtg_stream_kernel<4, 8>")}
+                                      "traffic": pmc_traffic().get(STREAM_KERNEL)}
         del r, v, b, adv, rtg
 
     out.update(cpu)

@@ -39,6 +39,7 @@ __device__ __forceinline__ float clip_reward(float er, const GaeParams& p) {
 // ---------------------------------------------------------------------------------------------
 // tmajor, large E: streaming kernel.  A lane owns VEC adjacent env columns (16 B loads / stores
 // when VEC = 4), walks time backwards with U steps of loads in flight, state in registers.
+// Shipped shape for 16-B aligned rows: <VEC 4, U 1, 1024 threads> (round 2; round 1 ran <4, 8, 256>).
 // Algorithmic traffic 16 B per transition (+1 B of end flags in the dense form).
 // ---------------------------------------------------------------------------------------------
 template <int VEC> struct VecF;
@@ -53,38 +54,56 @@ __device__ __forceinline__ void vec_to_arr(const typename VecF<VEC>::type& v, fl
     for (int k = 0; k < VEC; ++k) a[k] = p[k];
 }
 
-template <int VEC, int U>
-__global__ __launch_bounds__(256) void gae_rtg_stream_kernel(
+template <int VEC, int U, int TPB = 256, bool NT = false, int G = 1>
+__global__ __launch_bounds__(TPB) void gae_rtg_stream_kernel(
     const float* __restrict__ rewards, const float* __restrict__ values,
     const float* __restrict__ boot_value, const float* __restrict__ boot_reward,
     const int8_t* __restrict__ end_kind, int T, long E, GaeParams p,
     float* __restrict__ adv_out, float* __restrict__ rtg_out) {
+    // A workgroup covers G * TPB * VEC adjacent env columns: G column groups of TPB * VEC, a lane owning VEC
+    // adjacent columns in each group.  Large workgroups matter: their waves walk time together, so every row of
+    // every array is touched in bursts of TPB * 16 B (16 KB at TPB = 1024) instead of 1 KB pieces that drift apart
+    // -- +24 % HBM rate at 2^28 transitions, independent of where the four arrays sit (tools/gae_sweep.py).
     using V = typename VecF<VEC>::type;
-    const long e0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
-    if (e0 >= E) return;
+    const long base = (long)blockIdx.x * (TPB * VEC * G) + (long)threadIdx.x * VEC;
+    if (base >= E) return;
     const bool dense = end_kind != nullptr;
-    double A[VEC], R[VEC];
-    float vnext[VEC];
+    double A[G][VEC], R[G][VEC];
+    float vnext[G][VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) { A[k] = 0.0; R[k] = 0.0; vnext[k] = 0.f; }
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { A[g][k] = 0.0; R[g][k] = 0.0; vnext[g][k] = 0.f; }
 
     for (int t_hi = T; t_hi > 0; t_hi -= U) {
-        V rv[U], vv[U];
-        unsigned ek[U];
+        V rv[U][G], vv[U][G];
+        unsigned ek[U][G];
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             const int t = t_hi - 1 - i;
-            ek[i] = 0u;
-            if (t >= 0) {
-                const long idx = (long)t * E + e0;
-                rv[i] = *reinterpret_cast<const V*>(rewards + idx);
-                vv[i] = *reinterpret_cast<const V*>(values + idx);
-                if (dense) {
-                    if (VEC == 4) ek[i] = *reinterpret_cast<const unsigned*>(end_kind + idx);
-                    else if (VEC == 2) ek[i] = *reinterpret_cast<const unsigned short*>(end_kind + idx);
-                    else ek[i] = (unsigned char)end_kind[idx];
-                } else if (t == T - 1) {
-                    ek[i] = 0x02020202u;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const long e0 = base + (long)g * (TPB * VEC);
+                ek[i][g] = 0u;
+                if (t >= 0 && e0 < E) {
+                    const long idx = (long)t * E + e0;
+                    if (NT && VEC == 4) {
+                        typedef float nt4 __attribute__((ext_vector_type(4)));
+                        const nt4 a = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(rewards + idx));
+                        const nt4 c = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(values + idx));
+                        rv[i][g] = *reinterpret_cast<const V*>(&a);
+                        vv[i][g] = *reinterpret_cast<const V*>(&c);
+                    } else {
+                        rv[i][g] = *reinterpret_cast<const V*>(rewards + idx);
+                        vv[i][g] = *reinterpret_cast<const V*>(values + idx);
+                    }
+                    if (dense) {
+                        if (VEC == 4) ek[i][g] = *reinterpret_cast<const unsigned*>(end_kind + idx);
+                        else if (VEC == 2) ek[i][g] = *reinterpret_cast<const unsigned short*>(end_kind + idx);
+                        else ek[i][g] = (unsigned char)end_kind[idx];
+                    } else if (t == T - 1) {
+                        ek[i][g] = 0x02020202u;
+                    }
                 }
             }
         }
@@ -92,31 +111,42 @@ __global__ __launch_bounds__(256) void gae_rtg_stream_kernel(
         for (int i = 0; i < U; ++i) {
             const int t = t_hi - 1 - i;
             if (t < 0) break;
-            const long idx = (long)t * E + e0;
-            float r[VEC], v[VEC], ao[VEC], ro[VEC];
-            vec_to_arr<VEC>(rv[i], r);
-            vec_to_arr<VEC>(vv[i], v);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const unsigned kind = (ek[i] >> (8 * k)) & 0xffu;
-                float vn = vnext[k];
-                // terminal: ending value 0, ending reward clip(0) -- the reference clips it like any other ending
-                // reward (episode_info.py:450-454), which matters only for clip ranges that exclude zero
-                if (kind == 1u) { vn = 0.f; A[k] = 0.0; R[k] = (double)clip_reward(0.f, p); }
-                else if (kind == 2u) {
-                    const long b = dense ? idx + k : e0 + k;
-                    vn = boot_value[b]; A[k] = 0.0;
-                    R[k] = (double)clip_reward(boot_reward[b], p);
+            for (int g = 0; g < G; ++g) {
+                const long e0 = base + (long)g * (TPB * VEC);
+                if (e0 >= E) continue;
+                const long idx = (long)t * E + e0;
+                float r[VEC], v[VEC], ao[VEC], ro[VEC];
+                vec_to_arr<VEC>(rv[i][g], r);
+                vec_to_arr<VEC>(vv[i][g], v);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const unsigned kind = (ek[i][g] >> (8 * k)) & 0xffu;
+                    float vn = vnext[g][k];
+                    // terminal: ending value 0, ending reward clip(0) -- the reference clips it like any other ending
+                    // reward (episode_info.py:450-454), which matters only for clip ranges that exclude zero
+                    if (kind == 1u) { vn = 0.f; A[g][k] = 0.0; R[g][k] = (double)clip_reward(0.f, p); }
+                    else if (kind == 2u) {
+                        const long b = dense ? idx + k : e0 + k;
+                        vn = boot_value[b]; A[g][k] = 0.0;
+                        R[g][k] = (double)clip_reward(boot_reward[b], p);
+                    }
+                    const double delta = (double)r[k] + (double)(p.gamma_f * vn) - (double)v[k];
+                    A[g][k] = delta + p.gl * A[g][k];
+                    R[g][k] = (double)r[k] + p.gamma * R[g][k];
+                    ro[k] = (float)R[g][k];
+                    ao[k] = p.use_gae ? (float)A[g][k] : (float)(R[g][k] - (double)v[k]);
+                    vnext[g][k] = v[k];
                 }
-                const double delta = (double)r[k] + (double)(p.gamma_f * vn) - (double)v[k];
-                A[k] = delta + p.gl * A[k];
-                R[k] = (double)r[k] + p.gamma * R[k];
-                ro[k] = (float)R[k];
-                ao[k] = p.use_gae ? (float)A[k] : (float)(R[k] - (double)v[k]);
-                vnext[k] = v[k];
+                if (NT && VEC == 4) {
+                    typedef float nt4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(*reinterpret_cast<const nt4*>(ao), reinterpret_cast<nt4*>(adv_out + idx));
+                    __builtin_nontemporal_store(*reinterpret_cast<const nt4*>(ro), reinterpret_cast<nt4*>(rtg_out + idx));
+                } else {
+                    *reinterpret_cast<V*>(adv_out + idx) = *reinterpret_cast<const V*>(ao);
+                    *reinterpret_cast<V*>(rtg_out + idx) = *reinterpret_cast<const V*>(ro);
+                }
             }
-            *reinterpret_cast<V*>(adv_out + idx) = *reinterpret_cast<const V*>(ao);
-            *reinterpret_cast<V*>(rtg_out + idx) = *reinterpret_cast<const V*>(ro);
         }
     }
 }
@@ -343,7 +373,26 @@ extern "C" int ppoaf_gae_rtg_tmajor_timed(const float* rewards, const float* val
                                             (uintptr_t)rtg_out | (uintptr_t)end_kind) % 16 == 0);
     if (E >= (1L << 20) && aligned4) {
         const long thr = E / 4;
-        hipExtLaunchKernelGGL((gae_rtg_stream_kernel<4, 8>), dim3((unsigned)((thr + 255) / 256)), dim3(256), 0,
+#ifdef PPOAF_GAE_SWEEP
+        // diagnostic build only (tools/gae_sweep.py): launch shape / unroll / cache policy variants of the same kernel
+        int variant = 0;
+        if (const char* ev = getenv("PPOAF_GAE_VARIANT")) variant = atoi(ev);
+#define PPOAF_GAE_V(ID, U_, TPB_, NT_, G_)                                                                               \
+        if (variant == ID) {                                                                                             \
+            const long per_wg = (long)TPB_ * 4 * G_;                                                                     \
+            hipExtLaunchKernelGGL((gae_rtg_stream_kernel<4, U_, TPB_, NT_, G_>), dim3((unsigned)((E + per_wg - 1) / per_wg)), \
+                                  dim3(TPB_), 0, s, e0, e1, 0, rewards, values, boot_value, boot_reward, end_kind,       \
+                                  (int)T, (long)E, p, adv_out, rtg_out);                                                 \
+            return check_launch("gae_rtg_tmajor(variant)");                                                              \
+        }
+        PPOAF_GAE_V(1, 4, 256, false, 1) PPOAF_GAE_V(2, 8, 256, false, 1) PPOAF_GAE_V(4, 8, 512, false, 1)
+        PPOAF_GAE_V(13, 4, 1024, false, 1) PPOAF_GAE_V(14, 2, 1024, false, 1) PPOAF_GAE_V(15, 1, 1024, false, 1)
+        PPOAF_GAE_V(16, 2, 1024, true, 1) PPOAF_GAE_V(17, 2, 1024, false, 2) PPOAF_GAE_V(18, 1, 1024, false, 2)
+        PPOAF_GAE_V(19, 2, 512, false, 2) PPOAF_GAE_V(20, 1, 1024, false, 4) PPOAF_GAE_V(21, 3, 1024, false, 1)
+        PPOAF_GAE_V(22, 2, 768, false, 1)
+#undef PPOAF_GAE_V
+#endif
+        hipExtLaunchKernelGGL((gae_rtg_stream_kernel<4, 1, 1024>), dim3((unsigned)((thr + 1023) / 1024)), dim3(1024), 0,
                               s, e0, e1, 0, rewards, values, boot_value, boot_reward, end_kind, (int)T,
                               (long)E, p, adv_out, rtg_out);
     } else if (E >= (1L << 17)) {
