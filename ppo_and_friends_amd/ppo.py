@@ -509,6 +509,11 @@ class PPO:
                     continue
                 if actions is None:
                     actions = torch.zeros((A, n_envs) + tuple(a.shape[1:]), dtype=a.dtype, device=self.device)
+                elif a.dtype != actions.dtype or tuple(a.shape[1:]) != tuple(actions.shape[2:]):
+                    raise ValueError(
+                        f"policy {c['id']} produces actions {a.dtype}{tuple(a.shape[1:])} but the env's combined action tensor "
+                        f"holds {actions.dtype}{tuple(actions.shape[2:])}: policies with different action spaces need an env "
+                        "that exchanges dicts keyed by agent id (environments/synthetic.py:SyntheticMixedAgentsEnv)")
                 actions[c["idx"]] = a.reshape((c["n"], n_envs) + tuple(a.shape[1:]))
             env_action = actions if dict_env else actions.reshape((A * n_envs,) + tuple(actions.shape[2:]))
             nxt_obs, nxt_cobs, reward, terminated, truncated, term_obs = self.apply_policy_step_constraints(*env.step(env_action))
@@ -800,9 +805,10 @@ class PPO:
         ever differ (a peer mapping misbehaving in a way the self-test did not show), say so loudly, restore
         rank 0's state everywhere and continue on the RCCL all-reduce path.  Returns True if all was well.
         """
-        active = [f for f in getattr(self, "_fused", {}).values() if f is not None and getattr(f, "xchg", None) is not None]
-        if not active or mpi_utils.get_num_procs() == 1:
+        if mpi_utils.get_num_procs() == 1:
             return True
+        # every N > 1 path: on the all-reduce path each rank folds its own clip norm with atomics in an order of its
+        # own, so the coefficient can differ in the last bit between ranks -- the same checksum catches that drift
         if mpi_utils.replicas_agree(self._replicated_state()):
             return True
         self._heal_replicas("replicas diverged")
@@ -812,9 +818,15 @@ class PPO:
         """Collective (every rank reaches it through the same all-reduced verdict): rank 0's parameter and optimiser
         buckets everywhere, peer exchanges closed, RCCL all-reduce path from here on."""
         active = [f for f in getattr(self, "_fused", {}).values() if f is not None and getattr(f, "xchg", None) is not None]
-        print(f"[ppo_and_friends_amd] rank {mpi_utils.get_rank()}: {why} under the peer gradient exchange; "
-              "restoring rank 0's weights and optimiser state and switching to the RCCL all-reduce path",
+        print(f"[ppo_and_friends_amd] rank {mpi_utils.get_rank()}: {why}; restoring one known-good state on every rank"
+              + (" and switching from the peer gradient exchange to the RCCL all-reduce path" if active else ""),
               file=sys.stderr, flush=True)
+        snap = getattr(self, "_epoch_snapshot", None)
+        if snap is not None and "ran out of time" in why:
+            # a timed-out exchange fed garbage gradients to the rest of that epoch on EVERY rank (rank 0 included):
+            # go back to the state all ranks held when the epoch began, then make it rank 0's everywhere
+            for t, keep in zip(self._replicated_state(), snap):
+                t.copy_(keep)
         for t in self._replicated_state():
             mpi_utils.broadcast_flat(t)
         for f in active:
@@ -908,6 +920,10 @@ class PPO:
         perm = data_loader.epoch_permutation()
         fused = self._fused_updater(policy_id, B)
         if fused is not None:
+            if getattr(fused, "xchg", None) is not None:
+                # known-good state to return to should an exchange wait run out of time during the epoch (<= 3 buckets
+                # of a few hundred KB: a device-to-device copy per epoch)
+                self._epoch_snapshot = [t.clone() for t in self._replicated_state()]
             fused.begin_epoch(perm)
             fused.run_epoch()                      # enqueued asynchronously
             data_loader.prefetch()                 # next shuffle drawn on the host while the GPU works

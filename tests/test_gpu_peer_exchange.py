@@ -192,6 +192,25 @@ def test_missing_peer_is_bounded_and_reported(run3):
         assert r["missing_peer_reported"] and r["check_raises"] and r["later_waits_fail_fast"]
 
 
+def test_four_ranks_group_and_flag_indexing():
+    """
+    R = 4 on the one GPU of the box: the per-(group, rank) flag words and the alternating slots at a rank count the
+    3-process fixture does not reach.  (The pool's process guard admits at most 6 processes with the GPU open, so 4
+    ranks + the test runner is the largest world that can be rehearsed here; R = 8 is the driver's 8-GPU run.)
+    """
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank, args=(4, _free_port(), out, "uncached"), nprocs=4, join=True)
+    res = [out[r] for r in range(4)]
+    for r in res:
+        assert r["opened"], r["why"]
+        assert r["sum_exact"] and r["back_to_back_exact"] and r["other_sizes_exact"] and r["graph_replay_exact"]
+        assert r["norms_close"], r["norms"]
+    assert len({str(r["norms"]) for r in res}) == 1 and len({r["checksum"] for r in res}) == 1
+    for r in res[:-1]:
+        assert r["missing_peer_reported"] and r["later_waits_fail_fast"]
+
+
 def test_single_rank_exchange_is_the_identity():
     from ppo_and_friends_amd.utils.peer_exchange import PeerExchange
     dev = torch.device("cuda", 0)
