@@ -53,7 +53,22 @@ __device__ __forceinline__ float softplus_u(float x) { return x > 20.f ? x : log
 #else
 #define PPOAF_DBG(bit) false
 #endif
-template <int HT>
+// Loads of data that ANOTHER CU of the same launch may have rewritten (the single-XCD persistent update kernel:
+// weights after the Adam phase, slabs, gradient bucket, statistics).  NT = true: non-temporal loads, which bypass
+// this CU's vector L1 and are served by the XCD's L2 (MI355X_MICROARCH.md, inter-workgroup visibility table) --
+// a CU's L1 is never refreshed by another CU's stores.  NT = false: plain loads (separate launches: the kernel
+// boundary does the invalidation).
+template <bool NT> __device__ __forceinline__ float ld1(const float* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ double ld1(const double* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ float4 ld4(const float* p) {
+    if (NT) {
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+
+template <int HT, bool NT = false>
 __device__ __forceinline__ void load_fwd_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT],
                                                int g_dbg = 0) {
     const float* w = W + (long)(n0 + (lane & 15)) * (16 * HT) + 4 * (lane >> 4);
@@ -63,10 +78,10 @@ __device__ __forceinline__ void load_fwd_frags(const float* __restrict__ W, int 
         return;
     }
 #pragma unroll
-    for (int c = 0; c < HT; ++c) fr[c] = *reinterpret_cast<const float4*>(w + 16 * c);
+    for (int c = 0; c < HT; ++c) fr[c] = ld4<NT>(w + 16 * c);
 }
 // B fragments of one dgrad tile: fr[c] = { W[16c+4*slot+j][n0 + (lane&15)] }_j
-template <int HT>
+template <int HT, bool NT = false>
 __device__ __forceinline__ void load_dgrad_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT],
                                                  int g_dbg = 0) {
     constexpr int H = 16 * HT;
@@ -79,7 +94,7 @@ __device__ __forceinline__ void load_dgrad_frags(const float* __restrict__ W, in
 #pragma unroll
     for (int c = 0; c < HT; ++c) {
         const float* wp = w + (long)(16 * c) * H;
-        fr[c] = make_float4(wp[0], wp[H], wp[2 * H], wp[3 * H]);
+        fr[c] = make_float4(ld1<NT>(wp), ld1<NT>(wp + H), ld1<NT>(wp + 2 * H), ld1<NT>(wp + 3 * H));
     }
 }
 // acc[16 rows, 16 cols] = init + A[16, H] . frags ; A rows in LDS with stride HS.  Two accumulators

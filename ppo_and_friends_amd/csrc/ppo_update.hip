@@ -61,18 +61,22 @@ __device__ unsigned long long g_ppo_update_stamps[2][16];
 #endif
 
 
-template <int HT>
-__device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, const int which, const int g) {
+// NT = true (single-XCD persistent kernel): everything another CU of the same launch rewrites between mini-batches --
+// the parameter bucket, the value-normaliser slots -- is read with L1-bypassing loads; mb_extra = the mini-batch's
+// position inside the launch's chunk.
+template <int HT, bool NT = false, typename U = UpdateDev>
+__device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int which, const int g,
+                                                        const long mb_extra = 0) {
     constexpr int H = 16 * HT, HS = H + 4;                 // which: 0 actor, 1 critic; g: 16-row block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const NetDev& nd = u.net[which];
+    const auto& nd = u.net[which];
     const int in_dim = nd.in_dim, depth = nd.depth, out_dim = nd.out_dim, act = nd.act;
     const int NT0 = (in_dim + 15) >> 4;                    // 16-column tiles of the input
     const int INP = 16 * NT0 + 4;
     const float* P = u.params + nd.offset;
     float* slab = u.slabs + (long)g * u.bucket_total + nd.offset;
     const long B = u.B;
-    const long mb = u.cursor[0] + u.mb_offset;
+    const long mb = u.cursor[0] + u.mb_offset + mb_extra;
     const long base = mb * u.batch_stride;
 #ifdef PPOAF_STAMPS
     const int dbg = u.debug;
@@ -103,7 +107,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
     float* sOut = sD1 + kRows * HS;                           // [16, 16]
     float* sDOut = sOut + kRows * kMaxOut;                    // [16, 16]
 
-    if (g == 0 && which == 0 && tid == 0) { u.norm_scratch[0] = 0.0; u.norm_scratch[1] = 0.0; }
+    if (!NT && g == 0 && which == 0 && tid == 0) { u.norm_scratch[0] = 0.0; u.norm_scratch[1] = 0.0; }
 
     // Deep prefetch (three hidden layers, one output tile per wave): the weights depend on nothing, so the
     // fragments of BOTH hidden-to-hidden layers are requested before anything else; as each set is consumed
@@ -114,8 +118,8 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
     const bool deep = depth == 3 && HT <= kNW && !dbg;
     float4 fr[HT], fr2[HT];
     if (deep && has_tile) {
-        load_fwd_frags<HT>(P + offW(1), wave * 16, lane, fr);
-        load_fwd_frags<HT>(P + offW(2), wave * 16, lane, fr2);
+        load_fwd_frags<HT, NT>(P + offW(1), wave * 16, lane, fr);
+        load_fwd_frags<HT, NT>(P + offW(2), wave * 16, lane, fr2);
     }
     // first layer with at most 16 inputs: its 4 weight values per lane are requested here as well
     const bool l0_pre = in_dim <= 16 && HT <= kNW && has_tile && !dbg;
@@ -123,14 +127,14 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
     if (l0_pre) {
         const float* w = P + offW(0) + (long)(wave * 16 + (lane & 15)) * in_dim;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int k = 4 * j + (lane >> 4); if (k < in_dim) l0w[j] = w[k]; }
+        for (int j = 0; j < 4; ++j) { const int k = 4 * j + (lane >> 4); if (k < in_dim) l0w[j] = ld1<NT>(w + k); }
     }
 
     // The weights were rewritten by the Adam kernel a moment ago, so this XCD's L2 does not hold them:
     // the first touch of every 128-B line of the network is requested here, before anything else, so
     // the misses overlap the index / gather / first-layer phases instead of stalling the hidden layers.
     float l2_touch = 0.f;
-    if (!deep) for (long i = (long)tid * 32; i < nd.size; i += (long)kThreadsU * 32) l2_touch += P[i];
+    if (!deep && !NT) for (long i = (long)tid * 32; i < nd.size; i += (long)kThreadsU * 32) l2_touch += P[i];
 
     // biases and output-layer weights: requested into registers now, stored to LDS after the row loads
     // below have been issued too -- one wait covers all of them (a store in between would serialise
@@ -144,8 +148,8 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
         for (int r = 0; r < kCopyRegs; ++r) {
             const int i = tid + r * kThreadsU;
             bias_reg[r] = 0.f; wout_reg[r] = 0.f;
-            if (i < n_bias) { const int l = i / H, j = i - l * H; if (l < depth || j < out_dim) bias_reg[r] = P[offB(l) + j]; }
-            if (i < n_wout) wout_reg[r] = P[offW(depth) + i];
+            if (i < n_bias) { const int l = i / H, j = i - l * H; if (l < depth || j < out_dim) bias_reg[r] = ld1<NT>(P + offB(l) + j); }
+            if (i < n_wout) wout_reg[r] = ld1<NT>(P + offW(depth) + i);
         }
     }
 
@@ -190,8 +194,8 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
             sMisc[0] = mean_f; sMisc[1] = std_f;
         } else {
             const int slot = (int)(mb & 1);
-            float m = u.vn_mean[slot], v = u.vn_var[slot];
-            double cnt = u.vn_count[slot];
+            float m = ld1<NT>(u.vn_mean + slot), v = ld1<NT>(u.vn_var + slot);
+            double cnt = ld1<NT>(u.vn_count + slot);
             if (u.normalize_values) {
                 // Chan merge of the R per-rank records of this mini-batch, then the reference's
                 // integrate (utils/stats.py:73-94) -- same arithmetic as running_moments_integrate_kernel.
@@ -230,9 +234,9 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
         for (int l = 0; l <= depth; ++l) {
             const int n = (l == depth) ? out_dim : H;
             const float* bb = P + offB(l);
-            for (int i = tid; i < n; i += kThreadsU) sBias[l * H + i] = bb[i];
+            for (int i = tid; i < n; i += kThreadsU) sBias[l * H + i] = ld1<NT>(bb + i);
         }
-        for (int i = tid; i < out_dim * H; i += kThreadsU) sWout[i] = P[offW(depth) + i];
+        for (int i = tid; i < out_dim * H; i += kThreadsU) sWout[i] = ld1<NT>(P + offW(depth) + i);
     }
     for (int i = tid; i < kRows * INP; i += kThreadsU) sX[i] = 0.f;
     __syncthreads();
@@ -249,7 +253,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
         }
     }
     // prefetch: fragments of the first hidden-to-hidden layer (or nothing if depth == 1)
-    if (!deep && depth > 1 && has_tile) load_fwd_frags<HT>(P + offW(1), wave * 16, lane, fr, dbg);
+    if (!deep && depth > 1 && has_tile) load_fwd_frags<HT, NT>(P + offW(1), wave * 16, lane, fr, dbg);
     __syncthreads();
     PPOAF_STAMP(2);
 
@@ -266,7 +270,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = k0 + 4 * j + (lane >> 4);
-                bq[j] = l0_pre ? l0w[j] : (k < in_dim ? w[k] : 0.f);
+                bq[j] = l0_pre ? l0w[j] : (k < in_dim ? ld1<NT>(w + k) : 0.f);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -288,19 +292,19 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
             if (deep) {
                 if (l == 1) {
                     acc = mfma_rows_x_frags<HT>(Hp, HS, lane, fr, sBias[l * H + o]);
-                    load_dgrad_frags<HT>(P + offW(2), wave * 16, lane, fr);      // first backward phase, two phases early
+                    load_dgrad_frags<HT, NT>(P + offW(2), wave * 16, lane, fr);  // first backward phase, two phases early
                 } else {
                     acc = mfma_rows_x_frags<HT>(Hp, HS, lane, fr2, sBias[l * H + o]);
-                    load_dgrad_frags<HT>(P + offW(1), wave * 16, lane, fr2);     // second backward phase
+                    load_dgrad_frags<HT, NT>(P + offW(1), wave * 16, lane, fr2); // second backward phase
                 }
             } else {
-            if (nt != wave) load_fwd_frags<HT>(P + offW(l), nt * 16, lane, fr, dbg);
+            if (nt != wave) load_fwd_frags<HT, NT>(P + offW(l), nt * 16, lane, fr, dbg);
             
             acc = (dbg & 2) ? f32x4{fr[0].x + fr[HT - 1].w, 0.f, 0.f, 0.f} : mfma_rows_x_frags<HT>(Hp, HS, lane, fr, sBias[l * H + o]);
             
             if (nt + kNW >= HT) {                           // last tile of this wave in this layer
-                if (l + 1 < depth) load_fwd_frags<HT>(P + offW(l + 1), wave * 16, lane, fr, dbg);
-                else load_dgrad_frags<HT>(P + offW(l), wave * 16, lane, fr, dbg);   // first backward phase
+                if (l + 1 < depth) load_fwd_frags<HT, NT>(P + offW(l + 1), wave * 16, lane, fr, dbg);
+                else load_dgrad_frags<HT, NT>(P + offW(l), wave * 16, lane, fr, dbg);   // first backward phase
             }
             }
 #pragma unroll
@@ -409,7 +413,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
                 float lp = 0.f, slog = 0.f;
                 ent = 0.f;
                 for (int d = 0; d < out_dim; ++d) {
-                    const float sd = fmaxf(softplus_u(log_std[d]), u.min_std);
+                    const float sd = fmaxf(softplus_u(ld1<NT>(log_std + d)), u.min_std);
                     const float mu = sOut[s * kMaxOut + d];
                     const float zz = x[d] - mu;
                     const float l0 = -logf(sd) - 0.91893853320467274178f;
@@ -436,7 +440,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
                 glp *= inv_B;
                 const float gH = (u.entropy_weight != 0.0f) ? -u.entropy_weight * inv_B : 0.f;
                 for (int d = 0; d < out_dim; ++d) {
-                    const float ls = log_std[d];
+                    const float ls = ld1<NT>(log_std + d);
                     const float sp = softplus_u(ls), sd = fmaxf(sp, u.min_std);
                     const float mu = sOut[s * kMaxOut + d];
                     const float zz = x[d] - mu;
@@ -563,9 +567,9 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, cons
             if (deep) {
                 acc = l == 2 ? mfma_rows_x_frags<HT>(Dc, HS, lane, fr, 0.f) : mfma_rows_x_frags<HT>(Dc, HS, lane, fr2, 0.f);
             } else {
-            if (nt != wave) load_dgrad_frags<HT>(P + offW(l), nt * 16, lane, fr, dbg);
+            if (nt != wave) load_dgrad_frags<HT, NT>(P + offW(l), nt * 16, lane, fr, dbg);
             acc = (dbg & 2) ? f32x4{fr[0].x + fr[HT - 1].w, 0.f, 0.f, 0.f} : mfma_rows_x_frags<HT>(Dc, HS, lane, fr, 0.f);
-            if (nt + kNW >= HT && l - 1 >= 1) load_dgrad_frags<HT>(P + offW(l - 1), wave * 16, lane, fr, dbg);
+            if (nt + kNW >= HT && l - 1 >= 1) load_dgrad_frags<HT, NT>(P + offW(l - 1), wave * 16, lane, fr, dbg);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -809,6 +813,193 @@ __global__ __launch_bounds__(256) void ppo_update_adam_kernel(UpdateDev u, const
     if (blockIdx.x == 0 && threadIdx.x == 0 && u.cursor_advance) u.cursor[0] += u.cursor_advance;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Single-XCD persistent form of the chain (single rank): ONE launch runs n_mb consecutive mini-batches,
+// fwd_bwd -> slab reduce -> clip + Adam each, on 2 * n_wg <= 32 workgroups that all sit on ONE XCD.
+//   * why one XCD: the whole per-mini-batch state (parameters, moments, gradient bucket: 4 x 271 KB at C2) then
+//     lives in that XCD's 4 MB L2 -- the weights Adam has just rewritten are L2 hits for the next forward instead
+//     of cold misses behind a kernel boundary -- and the three grid-wide dependencies of a mini-batch become
+//     flag barriers inside that L2 (~1 us each) instead of launch boundaries (~2.6 us each).
+//   * placement: 256 workgroups are launched (one per CU: the LDS footprint admits no second one); each reads
+//     HW_REG_XCC_ID, those of the target XCD draw a ticket, the first 2 * n_wg tickets are the workers, everyone
+//     else exits at once.  Every wait is bounded by a wall-clock budget: if the workers are not all resident the
+//     launch ends with the error word set (the host raises) instead of hanging.
+//   * visibility inside the launch (MI355X_MICROARCH.md, inter-workgroup visibility): producers finish their
+//     stores (s_waitcnt vmcnt(0): acknowledged by the L2 all workers share) before their flag store; consumers
+//     read cross-CU data with L1-bypassing loads (NT) -- plain stores keep the lines in the XCD's L2.
+// Arithmetic and summation orders are those of the three-launch chain (slabs in slab order, norm partials in
+// worker order), so both forms give the same weights.
+// ------------------------------------------------------------------------------------------------------------
+struct PersistCtl {
+    unsigned tickets, error, pad0[30];
+    unsigned flags[32];               // one word per worker: the barrier epoch it has reached
+    double norm_partials[64];         // [worker][2]: squared-norm partials of the two networks
+};
+
+// The fwd_bwd body as a real call inside the persistent kernel's mini-batch loop.  Inlined into the loop, LLVM hoists
+// the body's loop-invariant address arithmetic out of it, where all of it is live at once: 2 KB of scratch per lane
+// at 256 VGPRs.  As a call it keeps its own allocation (207 VGPRs, no spill); the price is the callee-saved VGPR
+// save / restore of the AMDGPU calling convention (344 B per lane per call).  The kernel arguments are read through
+// the kernarg segment pointer (constant address space), so they stay scalar loads inside the callee.
+typedef const UpdateDev __attribute__((address_space(4))) KUpdateDev;
+namespace {
+template <int HT>
+__device__ __attribute__((noinline)) void persist_fwd_bwd(KUpdateDev* ku, int which, int g, long i) {
+    ppo_update_fwd_bwd_body<HT, true, KUpdateDev>(*ku, which, g, i);
+}
+}  // namespace
+
+__device__ __forceinline__ unsigned hw_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xfu;
+}
+
+// All workers arrive; returns false when the wait ran out of its budget (the error word is then set).
+__device__ __forceinline__ bool persist_barrier(PersistCtl* c, const int w, const int n_workers, const unsigned epoch,
+                                                const long long budget, int* s_ok) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's stores have reached the L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *(volatile unsigned*)&c->flags[w] = epoch;            // plain store: the line stays in this XCD's L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (threadIdx.x < 64) {
+        const long long t0 = wall_clock64();
+        int ok = 1;
+        while (true) {
+            unsigned f = epoch;
+            if ((int)threadIdx.x < n_workers)
+                f = __hip_atomic_load(&c->flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: L2-served
+            if (__all((int)(f >= epoch))) break;
+            if (__hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                wall_clock64() - t0 > budget) { ok = 0; break; }
+        }
+        if (threadIdx.x == 0) {
+            if (!ok) *(volatile unsigned*)&c->error = 1u;
+            *s_ok = ok;
+        }
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+template <int HTA, int HTC>
+__global__ __launch_bounds__(kThreadsU) void ppo_update_persistent_kernel(UpdateDev u, PersistCtl* ctl, int n_mb,
+                                                                          int target_xcc, long long budget) {
+    __shared__ int s_ticket, s_ok;
+    __shared__ double s_red[17];
+    __shared__ double s_norm[2];
+    __shared__ float s_step[4];
+    const int tid = threadIdx.x;
+    KUpdateDev* ku = (KUpdateDev*)__builtin_amdgcn_kernarg_segment_ptr();   // `u` is the first kernel argument
+    if ((int)hw_xcc_id() != target_xcc) return;               // uniform per workgroup
+    if (tid == 0) s_ticket = (int)atomicAdd(&ctl->tickets, 1u);
+    __syncthreads();
+    const int n_workers = 2 * u.n_wg;
+    const int w = __builtin_amdgcn_readfirstlane(s_ticket);   // wave-uniform by construction: keep it in an SGPR
+    if (w >= n_workers) return;
+    const int which = w < u.n_wg ? 0 : 1, g = w < u.n_wg ? w : w - u.n_wg;
+    const long n4 = u.bucket_total >> 2;
+    const long stride = (long)n_workers * kThreadsU;
+    const float4* sl = reinterpret_cast<const float4*>(u.slabs);
+    unsigned epoch = 0;
+    for (int i = 0; i < n_mb; ++i) {
+        // ---- phase 1: forward + backward of this worker's 16 rows of its network -> its slab, loss partials
+        if (which == 0) persist_fwd_bwd<HTA>(ku, 0, g, i);
+        else persist_fwd_bwd<HTC>(ku, 1, g, i);
+        if (!persist_barrier(ctl, w, n_workers, ++epoch, budget, &s_ok)) return;
+
+        // ---- phase 2: slabs -> gradient bucket (slab order), squared-norm partials per worker; bookkeeping
+        double q0 = 0.0, q1 = 0.0;
+        for (long idx = (long)w * kThreadsU + tid; idx < n4; idx += stride) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g0 = 0; g0 < u.n_wg; g0 += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    v[k] = (g0 + k < u.n_wg) ? ld4<true>(reinterpret_cast<const float*>(sl + (long)(g0 + k) * n4 + idx))
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+            }
+            reinterpret_cast<float4*>(u.grads)[idx] = acc;
+            const float sc = u.grad_scale;
+            const double q = (double)(acc.x * sc) * (acc.x * sc) + (double)(acc.y * sc) * (acc.y * sc) +
+                             (double)(acc.z * sc) * (acc.z * sc) + (double)(acc.w * sc) * (acc.w * sc);
+            if (idx * 4 < u.net[0].size) q0 += q; else q1 += q;
+        }
+        q0 = block_sum(q0, s_red);
+        q1 = block_sum(q1, s_red);
+        if (tid == 0) { ctl->norm_partials[2 * w] = q0; ctl->norm_partials[2 * w + 1] = q1; }
+        if (w == n_workers - 1 && tid < 64) {
+            // the bookkeeping of ppo_update_bookkeeping, on loss partials other CUs wrote a moment ago
+            const int lane = tid;
+            float p0 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p7 = 0.f;
+            for (int gg = lane; gg < u.n_wg; gg += 64) {
+                const float* a = u.loss_partials + (long)gg * 8;
+                const float* cc = u.loss_partials + ((long)u.n_wg + gg) * 8;
+                p0 += ld1<true>(a); p3 += ld1<true>(a + 3); p4 += ld1<true>(a + 4); p7 += ld1<true>(a + 7); p2 += ld1<true>(cc + 2);
+            }
+            p0 = wave_sum(p0); p2 = wave_sum(p2); p3 = wave_sum(p3); p4 = wave_sum(p4); p7 = wave_sum(p7);
+            if (lane == 0) {
+                const float n = (float)u.B;
+                const float surr = p0 / n, ent = p3 / n, kl = p4 / n, crit = p2 / n;
+                float total = surr;
+                if (u.entropy_weight != 0.0f) total -= u.entropy_weight * ent;
+                if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
+                u.totals[0] += (double)surr; u.totals[1] += (double)total; u.totals[2] += (double)crit;
+                u.totals[3] += (double)ent; u.totals[4] += (double)kl;
+                u.totals[5] += (double)ld1<true>(u.loss_partials + 5); u.totals[6] += (double)ld1<true>(u.loss_partials + 6);
+                u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
+                u.totals[8] += 1.0;
+            }
+            if (lane < 2) {
+                const int64_t t = u.step_counts[lane] + 1;        // only this lane ever touches the counters in the launch
+                u.step_counts[lane] = t;
+                u.norm_scratch[2 + 2 * lane] = 1.0 - pow((double)u.beta1, (double)t);
+                u.norm_scratch[3 + 2 * lane] = sqrt(1.0 - pow((double)u.beta2, (double)t));
+            }
+        }
+        if (!persist_barrier(ctl, w, n_workers, ++epoch, budget, &s_ok)) return;
+
+        // ---- phase 3: clip + Adam on the columns this worker reduced; norms = partials in worker order
+        if (tid < 2) {
+            double sq = 0.0;
+            for (int k = 0; k < n_workers; ++k) sq += ld1<true>(ctl->norm_partials + 2 * k + tid);
+            s_norm[tid] = sq;
+            s_step[2 * tid] = (float)((double)u.lr[0] / ld1<true>(u.norm_scratch + 2 + 2 * tid));
+            s_step[2 * tid + 1] = (float)ld1<true>(u.norm_scratch + 3 + 2 * tid);
+        }
+        __syncthreads();
+        for (long idx = (long)w * kThreadsU + tid; idx < n4; idx += stride) {
+            const int wh = (idx * 4 < u.net[0].size) ? 0 : 1;
+            float4 p = ld4<true>(u.params + 4 * idx);
+            const float4 gr = ld4<true>(u.grads + 4 * idx);
+            float4 m = ld4<true>(u.exp_avg + 4 * idx), v = ld4<true>(u.exp_avg_sq + 4 * idx);
+            const float total_norm = (float)sqrt(s_norm[wh]);
+            float coef = 1.0f;
+            if (u.max_norm > 0.f) coef = fminf(u.max_norm / (total_norm + 1e-6f), 1.0f);
+            const float gs = u.grad_scale * coef;
+            const float step_size = s_step[2 * wh], bc2_sqrt = s_step[2 * wh + 1];
+#define PPOAF_ADAM1(c)                                                   \
+            {                                                            \
+                const float gi = gr.c * gs;                              \
+                m.c = u.beta1 * m.c + (1.0f - u.beta1) * gi;             \
+                v.c = u.beta2 * v.c + (1.0f - u.beta2) * gi * gi;        \
+                p.c = p.c - step_size * (m.c / (sqrtf(v.c) / bc2_sqrt + u.adam_eps)); \
+            }
+            PPOAF_ADAM1(x) PPOAF_ADAM1(y) PPOAF_ADAM1(z) PPOAF_ADAM1(w)
+#undef PPOAF_ADAM1
+            reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx] = p;
+            reinterpret_cast<float4*>(u.exp_avg)[idx] = m;
+            reinterpret_cast<float4*>(u.exp_avg_sq)[idx] = v;
+        }
+        if (!persist_barrier(ctl, w, n_workers, ++epoch, budget, &s_ok)) return;
+    }
+    if (w == 0 && tid == 0) u.cursor[0] += n_mb;
+}
+
 // (n, mean, M2) of every mini-batch's rewards-to-go: one workgroup per mini-batch
 __global__ __launch_bounds__(256) void minibatch_moments_kernel(const float* __restrict__ data,
                                                                 const int64_t* __restrict__ perm,
@@ -969,6 +1160,53 @@ extern "C" int ppoaf_ppo_update_fwd_bwd_timed(const ppoaf_ppo_update_args_t* arg
     if (ha == 128 && hc == 256) return launch_fwd_bwd<8, 16>(u, lds, s, e0, e1);
     if (ha == 64 && hc == 128) return launch_fwd_bwd<4, 8>(u, lds, s, e0, e1);
     set_error("ppo_update_fwd_bwd: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
+    return PPOAF_E_INVALID;
+}
+
+template <int HTA, int HTC>
+static int launch_persistent(const UpdateDev& u, size_t lds, PersistCtl* ctl, int n_mb, int xcc, long long budget,
+                             hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_update_persistent_kernel<HTA, HTC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+        attr_set = true;
+    }
+    // one workgroup per CU of the whole device: only those on the target XCD that draw a worker ticket stay
+    hipLaunchKernelGGL((ppo_update_persistent_kernel<HTA, HTC>), dim3(256), dim3(kThreadsU), lds, s, u, ctl, n_mb, xcc, budget);
+    return check_launch("ppo_update_persistent");
+}
+
+extern "C" int ppoaf_ppo_update_persistent_ctl_bytes(void) { return (int)sizeof(PersistCtl); }
+
+extern "C" int ppoaf_ppo_update_persistent(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl,
+                                           int32_t target_xcc, double wait_seconds, ppoaf_stream_t stream) {
+    UpdateDev u;
+    int rc = make_dev(args, u);
+    if (rc) return rc;
+    PPOAF_REQUIRE(ctl && (((uintptr_t)ctl) & 15) == 0, "ppo_update_persistent: control block missing or misaligned");
+    PPOAF_REQUIRE(n_minibatches >= 1 && n_minibatches <= (1 << 20), "ppo_update_persistent: n_minibatches=%ld", (long)n_minibatches);
+    PPOAF_REQUIRE(2 * u.n_wg <= 32, "ppo_update_persistent: %d workgroups needed, one XCD holds 32 (batch size <= 256)", 2 * u.n_wg);
+    PPOAF_REQUIRE(target_xcc >= 0 && target_xcc < 8, "ppo_update_persistent: target_xcc=%d", target_xcc);
+    PPOAF_REQUIRE(wait_seconds > 0.0 && wait_seconds <= 600.0, "ppo_update_persistent: wait_seconds=%g", wait_seconds);
+    PPOAF_REQUIRE(u.mb_offset == 0, "ppo_update_persistent: mb_offset must be 0 (the launch walks the cursor itself)");
+    // the persistent form needs a little static LDS beside the fwd_bwd carve
+    const size_t lds = fwd_bwd_lds_bytes(u);
+    PPOAF_REQUIRE(lds <= 159 * 1024, "ppo_update_persistent: needs %zu B of LDS", lds);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ctl, 0, sizeof(PersistCtl), s);       // tickets, error word, barrier epochs
+    if (e != hipSuccess) { set_error("ppo_update_persistent: memset: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+    const long long budget = (long long)(wait_seconds * 1.0e8);          // wall_clock64 ticks at 100 MHz
+    PersistCtl* c = reinterpret_cast<PersistCtl*>(ctl);
+    const int ha = u.net[0].H, hc = u.net[1].H;
+    if (ha == 32 && hc == 32) return launch_persistent<2, 2>(u, lds, c, (int)n_minibatches, target_xcc, budget, s);
+    if (ha == 64 && hc == 64) return launch_persistent<4, 4>(u, lds, c, (int)n_minibatches, target_xcc, budget, s);
+    if (ha == 128 && hc == 128) return launch_persistent<8, 8>(u, lds, c, (int)n_minibatches, target_xcc, budget, s);
+    if (ha == 256 && hc == 256) return launch_persistent<16, 16>(u, lds, c, (int)n_minibatches, target_xcc, budget, s);
+    if (ha == 128 && hc == 256) return launch_persistent<8, 16>(u, lds, c, (int)n_minibatches, target_xcc, budget, s);
+    if (ha == 64 && hc == 128) return launch_persistent<4, 8>(u, lds, c, (int)n_minibatches, target_xcc, budget, s);
+    set_error("ppo_update_persistent: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
     return PPOAF_E_INVALID;
 }
 

@@ -345,9 +345,54 @@ class FusedPolicyUpdate:
         finally:
             args.mb_offset, args.cursor_advance = 0, 1
 
+    # ---- single-XCD persistent form (csrc/ppo_update.hip: ppo_update_persistent_kernel)
+    persistent_chunk = 4096            # mini-batches per launch (one launch per epoch at the BASELINE sizes)
+
+    def _persistent_ctl(self):
+        ctl = getattr(self, "_persist_ctl", None)
+        if ctl is None:
+            n = int(self._lib.ppoaf_ppo_update_persistent_ctl_bytes())
+            ctl = self._persist_ctl = torch.zeros((n + 3) // 4, dtype=torch.int32, device=self.pol.device)
+        return ctl
+
+    def persistent_reason(self):
+        """'' when the epoch's full mini-batches can run as one persistent launch, else why not."""
+        import os
+        if type(self) is not FusedPolicyUpdate:
+            return "K12 (MLP policies) only"
+        if os.environ.get("PPOAF_PERSISTENT", "1") == "0":
+            return "disabled by PPOAF_PERSISTENT=0"
+        if self.multi:
+            return "N > 1: the gradient exchange sits between the reduce and the Adam phase (three-launch chain)"
+        if 2 * self.n_wg > 32:
+            return f"batch size {self.B} needs {2 * self.n_wg} workgroups, one XCD holds 32"
+        return ""
+
+    def _check_persistent(self):
+        """After a host synchronisation: did a wait inside a persistent launch run out of time?"""
+        ctl = getattr(self, "_persist_ctl", None)
+        if ctl is not None and getattr(self, "_persist_used", False):
+            self._persist_used = False
+            if int(ctl[1].item()) != 0:
+                raise _lib.PpoafError(
+                    "ppo_update_persistent: a barrier wait ran out of time -- the launch did not get all of its workgroups "
+                    "onto one XCD (another process on this GPU?).  Set PPOAF_PERSISTENT=0 to use the three-launch chain.")
+
     def run_epoch(self):
         args = self._args_for(self.B)
         left = self.n_full
+        if left > 0 and self.persistent_reason() == "":
+            import os
+            ctl = self._persistent_ctl()
+            xcc = int(os.environ.get("PPOAF_PERSISTENT_XCC", "0")) % 8
+            st = K.stream()
+            while left > 0:
+                n = min(left, self.persistent_chunk)
+                _lib.check(self._lib.ppoaf_ppo_update_persistent(C.byref(args), n, ctl.data_ptr(), xcc, 2.0, st),
+                           "ppo_update_persistent")
+                self._persist_used = True
+                left -= n
+                self.n_done += n
         use_graph = self.ppo.use_graphs and (not self.multi or self.xchg is not None)   # RCCL calls are not captured
         chunk = self.graph_chunk if self.n_full < 8 * self.graph_chunk else 4 * self.graph_chunk   # long epochs: fewer, longer graphs
         while left > 0:
@@ -390,7 +435,9 @@ class FusedPolicyUpdate:
             if self.tail == 1:
                 # ppo.py:2299-2306: a size-1 batch still updates the normaliser, then is skipped (quirk Q9)
                 rs.integrate_records(self.records[self.n_full].contiguous())
-        return _reduce_totals(self, self.totals)
+        out = _reduce_totals(self, self.totals)          # synchronises with the device
+        self._check_persistent()
+        return out
 
 
 # ======================================================================================
