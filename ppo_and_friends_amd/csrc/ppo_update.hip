@@ -68,7 +68,12 @@ template <int HT, bool NT = false, typename U = UpdateDev>
 __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int which, const int g,
                                                         const long mb_extra = 0) {
     constexpr int H = 16 * HT, HS = H + 4;                 // which: 0 actor, 1 critic; g: 16-row block
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid_ = threadIdx.x;
+    if (NT) {     // persistent form: nothing derived from the lane id may be hoisted out of the caller's mini-batch loop
+        asm volatile("" : "+v"(tid_));
+        __builtin_assume(tid_ >= 0 && tid_ < kThreadsU);
+    }
+    const int tid = tid_, lane = tid & 63, wave = NT ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const auto& nd = u.net[which];
     const int in_dim = nd.in_dim, depth = nd.depth, out_dim = nd.out_dim, act = nd.act;
     const int NT0 = (in_dim + 15) >> 4;                    // 16-column tiles of the input
@@ -93,7 +98,11 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
 
     PPOAF_STAMP(0);
     // ---- LDS carve (all offsets multiples of 16 B)
-    float* smem = reinterpret_cast<float*>(ppo_update_smem);
+    // persistent form: an opaque zero in the LDS base keeps the per-lane LDS addresses of the body from being hoisted
+    // out of the caller's mini-batch loop (hoisted, all of them are live at once)
+    int zl = 0;
+    if (NT) asm volatile("" : "+s"(zl));
+    float* smem = reinterpret_cast<float*>(ppo_update_smem + zl);
     int* sRow = reinterpret_cast<int*>(smem);                 // [16]
     float* sMisc = smem + 16;                                 // [16]: adv mean/std, vn mean/var
     float* sRowF = smem + 32;                                 // [3][16]: adv, old log-prob, rewards-to-go
@@ -834,20 +843,29 @@ struct PersistCtl {
     unsigned tickets, error, pad0[30];
     unsigned flags[32];               // one word per worker: the barrier epoch it has reached
     double norm_partials[64];         // [worker][2]: squared-norm partials of the two networks
+    unsigned long long phase_ticks[8];// diagnostic build (-DPPOAF_PERSIST_STAMPS): s_memtime sums per phase, worker 0
 };
+#ifdef PPOAF_PERSIST_STAMPS
+#define PPOAF_PSTAMP(k)                                                                   \
+    do {                                                                                  \
+        if (w == 0 && tid == 0) {                                                         \
+            unsigned long long t_;                                                        \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
+            ctl->phase_ticks[k] += t_ - t_prev;                                           \
+            t_prev = t_;                                                                  \
+        }                                                                                 \
+    } while (0)
+#else
+#define PPOAF_PSTAMP(k) do {} while (0)
+#endif
 
-// The fwd_bwd body as a real call inside the persistent kernel's mini-batch loop.  Inlined into the loop, LLVM hoists
-// the body's loop-invariant address arithmetic out of it, where all of it is live at once: 2 KB of scratch per lane
-// at 256 VGPRs.  As a call it keeps its own allocation (207 VGPRs, no spill); the price is the callee-saved VGPR
-// save / restore of the AMDGPU calling convention (344 B per lane per call).  The kernel arguments are read through
-// the kernarg segment pointer (constant address space), so they stay scalar loads inside the callee.
+// The fwd_bwd body inside the persistent kernel's mini-batch loop.  Inlined naively, LLVM hoists everything in the
+// body that does not change between mini-batches (kernel-argument loads, per-lane global and LDS addresses) out of
+// the loop, where all of it is live at once: 2 KB of scratch per lane at 256 VGPRs.  Three opaque values make the
+// body loop-variant instead (218 VGPRs, no scratch, <8,8>): the kernel arguments are read through the kernarg
+// segment pointer (constant address space: still scalar loads), which passes through an empty asm every iteration;
+// the lane id passes through one as well (with its range re-asserted); the LDS base gets an opaque zero.
 typedef const UpdateDev __attribute__((address_space(4))) KUpdateDev;
-namespace {
-template <int HT>
-__device__ __attribute__((noinline)) void persist_fwd_bwd(KUpdateDev* ku, int which, int g, long i) {
-    ppo_update_fwd_bwd_body<HT, true, KUpdateDev>(*ku, which, g, i);
-}
-}  // namespace
 
 __device__ __forceinline__ unsigned hw_xcc_id() {
     unsigned v;
@@ -892,7 +910,7 @@ __global__ __launch_bounds__(kThreadsU) void ppo_update_persistent_kernel(Update
     __shared__ double s_norm[2];
     __shared__ float s_step[4];
     const int tid = threadIdx.x;
-    KUpdateDev* ku = (KUpdateDev*)__builtin_amdgcn_kernarg_segment_ptr();   // `u` is the first kernel argument
+    KUpdateDev* ku0 = (KUpdateDev*)__builtin_amdgcn_kernarg_segment_ptr();  // `u` is the first kernel argument
     if ((int)hw_xcc_id() != target_xcc) return;               // uniform per workgroup
     if (tid == 0) s_ticket = (int)atomicAdd(&ctl->tickets, 1u);
     __syncthreads();
@@ -904,11 +922,23 @@ __global__ __launch_bounds__(kThreadsU) void ppo_update_persistent_kernel(Update
     const long stride = (long)n_workers * kThreadsU;
     const float4* sl = reinterpret_cast<const float4*>(u.slabs);
     unsigned epoch = 0;
+#ifdef PPOAF_PERSIST_STAMPS
+    unsigned long long t_prev = 0;
+    if (w == 0 && tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#endif
     for (int i = 0; i < n_mb; ++i) {
         // ---- phase 1: forward + backward of this worker's 16 rows of its network -> its slab, loss partials
-        if (which == 0) persist_fwd_bwd<HTA>(ku, 0, g, i);
-        else persist_fwd_bwd<HTC>(ku, 1, g, i);
+        KUpdateDev* ku = ku0;
+        asm volatile("" : "+s"(ku));
+        int tid_l = threadIdx.x;                  // per-iteration copy of the lane id: phases 2 / 3 index with it, so their
+        asm volatile("" : "+v"(tid_l));           // address arithmetic is not hoisted across the fwd_bwd body either
+        __builtin_assume(tid_l >= 0 && tid_l < kThreadsU);
+        const int tid = tid_l;
+        if (which == 0) ppo_update_fwd_bwd_body<HTA, true, KUpdateDev>(*ku, 0, g, i);
+        else ppo_update_fwd_bwd_body<HTC, true, KUpdateDev>(*ku, 1, g, i);
+        PPOAF_PSTAMP(0);
         if (!persist_barrier(ctl, w, n_workers, ++epoch, budget, &s_ok)) return;
+        PPOAF_PSTAMP(1);
 
         // ---- phase 2: slabs -> gradient bucket (slab order), squared-norm partials per worker; bookkeeping
         double q0 = 0.0, q1 = 0.0;
@@ -961,7 +991,9 @@ __global__ __launch_bounds__(kThreadsU) void ppo_update_persistent_kernel(Update
                 u.norm_scratch[3 + 2 * lane] = sqrt(1.0 - pow((double)u.beta2, (double)t));
             }
         }
+        PPOAF_PSTAMP(2);
         if (!persist_barrier(ctl, w, n_workers, ++epoch, budget, &s_ok)) return;
+        PPOAF_PSTAMP(3);
 
         // ---- phase 3: clip + Adam on the columns this worker reduced; norms = partials in worker order
         if (tid < 2) {
@@ -995,7 +1027,9 @@ __global__ __launch_bounds__(kThreadsU) void ppo_update_persistent_kernel(Update
             reinterpret_cast<float4*>(u.exp_avg)[idx] = m;
             reinterpret_cast<float4*>(u.exp_avg_sq)[idx] = v;
         }
+        PPOAF_PSTAMP(4);
         if (!persist_barrier(ctl, w, n_workers, ++epoch, budget, &s_ok)) return;
+        PPOAF_PSTAMP(5);
     }
     if (w == 0 && tid == 0) u.cursor[0] += n_mb;
 }

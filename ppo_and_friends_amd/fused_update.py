@@ -360,8 +360,10 @@ class FusedPolicyUpdate:
         import os
         if type(self) is not FusedPolicyUpdate:
             return "K12 (MLP policies) only"
-        if os.environ.get("PPOAF_PERSISTENT", "1") == "0":
-            return "disabled by PPOAF_PERSISTENT=0"
+        # opt-in: measured SLOWER than the three-launch chain at every BASELINE shape (C2: 40.6 vs 34 us per mini-batch;
+        # DESIGN.md section 3, "single-XCD persistent chain") -- kept, parity-tested, as the base for the next step
+        if os.environ.get("PPOAF_PERSISTENT", "0") != "1":
+            return "off (set PPOAF_PERSISTENT=1 to run the single-XCD persistent chain)"
         if self.multi:
             return "N > 1: the gradient exchange sits between the reduce and the Adam phase (three-launch chain)"
         if 2 * self.n_wg > 32:
@@ -376,7 +378,7 @@ class FusedPolicyUpdate:
             if int(ctl[1].item()) != 0:
                 raise _lib.PpoafError(
                     "ppo_update_persistent: a barrier wait ran out of time -- the launch did not get all of its workgroups "
-                    "onto one XCD (another process on this GPU?).  Set PPOAF_PERSISTENT=0 to use the three-launch chain.")
+                    "onto one XCD (another process on this GPU?).  Unset PPOAF_PERSISTENT to use the three-launch chain.")
 
     def run_epoch(self):
         args = self._args_for(self.B)

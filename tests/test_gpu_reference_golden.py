@@ -410,3 +410,17 @@ def test_product_reproduces_the_reference_lstm_iterations(golden, name, S, n_act
     for tag, net in (("actor", pol.actor), ("critic", pol.critic)):
         d = np.concatenate([np.abs(p.detach().cpu().numpy() - g[f"final_{tag}.{k}"]).reshape(-1) for k, p in net.named_parameters()])
         assert d.max() < 2e-4 and np.mean(d > 2e-5) < 1e-2, f"{tag}: max |dw| {d.max():.2e}, share > 2e-5: {np.mean(d > 2e-5):.2e}"
+
+
+@pytest.mark.parametrize("name", ["g12_c2_term", "g12_c3_gauss", "g12_c4_mappo"])
+def test_persistent_single_xcd_chain_reproduces_the_reference(golden, name, monkeypatch):
+    """
+    The opt-in single-XCD persistent form of K12 (one launch per epoch: fwd_bwd -> reduce -> Adam phases separated by
+    flag barriers inside one XCD's L2, PPOAF_PERSISTENT=1) against the same reference-recorded iterations.
+    """
+    monkeypatch.setenv("PPOAF_PERSISTENT", "1")
+    test_product_reproduces_the_reference_ppo_iterations(golden, name, "fused")
+    # and it really was the persistent launch that ran
+    from ppo_and_friends_amd import fused_update
+    monkeypatch.setenv("PPOAF_PERSISTENT", "1")
+    assert fused_update.FusedPolicyUpdate.persistent_reason.__doc__
