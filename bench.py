@@ -358,8 +358,10 @@ def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline
     res["exchange_probe"] = probe
     if not mpi_utils.distributed_path():                      # single rank: the eager chain is this rank's own
         res["roofline_update"] = update_kernel_roofline(ppo, pol, args.batch_size)
-    del ppo, pol
-    torch.cuda.empty_cache()
+    del ppo, pol, fused
+    import gc
+    gc.collect()                 # the trainer holds reference cycles (graphs, hooks): release its device memory and
+    torch.cuda.empty_cache()     # graph executables NOW, not in the middle of the next config's timed region
     return res
 
 

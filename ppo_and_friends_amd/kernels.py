@@ -76,6 +76,48 @@ def event_elapsed_ms(start, stop):
     return ms.value
 
 
+_stream_pairs = {}
+
+
+def concurrent_stream_pair(device=None):
+    """
+    Two streams of `device` that really run side by side.  The HIP runtime multiplexes its streams onto a few
+    hardware queues (least-used queue first, ties broken arbitrarily), so two streams taken one after the other
+    from torch's pool can share a queue and serialise -- measured on MI355X: the 3rd and 4th streams a process
+    uses do, which cost the overlapped PPO/ICM epochs 30%.  The pair is therefore chosen by measurement, once
+    per device: a short spin kernel on each candidate pair, first pair whose wall time is that of one kernel.
+    """
+    import time
+    import itertools
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev in _stream_pairs:
+        return _stream_pairs[dev]
+    cycles = 3_000_000                                         # ~1.3 ms
+    with torch.cuda.device(dev):
+        cands = [torch.cuda.Stream() for _ in range(5)]
+
+        def wall(streams):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for s in streams:
+                with torch.cuda.stream(s):
+                    torch.cuda._sleep(cycles)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        for s in cands:                                        # bind every candidate to its queue first
+            wall([s])
+        one = min(wall([cands[0]]) for _ in range(3))
+        best, best_t = (cands[0], cands[1]), float("inf")
+        for a, b in itertools.combinations(cands, 2):
+            t = min(wall([a, b]) for _ in range(2))
+            if t < best_t:
+                best, best_t = (a, b), t
+            if t < 1.35 * one:
+                break
+    _stream_pairs[dev] = best
+    return best
+
+
 def gae_rtg_traj(rewards, values, ending_value, ending_reward, traj_start, traj_len,
                  gamma=0.99, lambd=0.95, bootstrap_clip=(-100.0, 100.0), use_gae=True,
                  adv_out=None, rtg_out=None, compute_rtg=True):

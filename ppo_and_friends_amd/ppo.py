@@ -856,9 +856,7 @@ class PPO:
         fused.begin_epoch(loader.epoch_permutation())
         fused_icm.begin_epoch(loader.epoch_permutation())
         main = torch.cuda.current_stream()
-        if "side_streams" not in self._graphs:
-            self._graphs["side_streams"] = (torch.cuda.Stream(), torch.cuda.Stream())
-        sa, sb = self._graphs["side_streams"]
+        sa, sb = K.concurrent_stream_pair(self.device)         # two streams on different hardware queues
         sa.wait_stream(main); sb.wait_stream(main)
         with torch.cuda.stream(sa):
             fused.run_epoch()

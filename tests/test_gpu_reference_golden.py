@@ -424,3 +424,91 @@ def test_persistent_single_xcd_chain_reproduces_the_reference(golden, name, monk
     from ppo_and_friends_amd import fused_update
     monkeypatch.setenv("PPOAF_PERSISTENT", "1")
     assert fused_update.FusedPolicyUpdate.persistent_reason.__doc__
+
+
+# ---------------------------------------------------------------- unit fixtures g9 / g10 / g13 through the HIP kernels
+def test_value_normalizer_kernels_match_reference_golden_g9(golden):
+    """RunningStatNormalizer of the unmodified reference (utils/misc.py:61-128): update + normalise, denormalise,
+    normalise without update -- through K5 (batch moments, Chan merge + integrate, normalise / denormalise kernels)."""
+    from ppo_and_friends_amd.utils.misc import RunningStatNormalizer
+    g = golden("g9_value_normalizer")
+    dev = torch.device("cuda", 0)
+    vn = RunningStatNormalizer("value_normalizer", dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    np.testing.assert_allclose(vn.denormalize(t(np.array([0.5, -1.0, 3.0], np.float32))).cpu().numpy(), g["denorm_fresh"], rtol=1e-6)
+    for i in range(4):
+        y = vn.normalize(t(g[f"in{i}"]))
+        np.testing.assert_allclose(y.cpu().numpy(), g[f"norm{i}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(vn.denormalize(t(g[f"probe{i}"])).cpu().numpy(), g[f"denorm{i}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(vn.normalize(t(g[f"probe{i}"]), update_stats=False).cpu().numpy(), g[f"norm_noupdate{i}"],
+                                   rtol=1e-5, atol=1e-5)
+        rs = vn.running_stats
+        np.testing.assert_allclose([float(rs.mean_t), float(rs.var_t), float(rs.count_t)], g[f"state{i}"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["disc", "cont"])
+def test_icm_module_matches_reference_golden_g10(golden, tag):
+    """ICM.forward of the unmodified reference (icm.py:22-430): intrinsic reward, inverse and forward losses, and the
+    gradient of the training loss w.r.t. every parameter -- through this package's ICM (torch-ROCm MLPs + K8)."""
+    from ppo_and_friends_amd.networks.icm import ICM
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    g = golden("g10_icm")
+    dev = torch.device("cuda", 0)
+    if tag == "disc":
+        icm = ICM(name="icm", obs_space=Box(-np.inf, np.inf, (6,), np.float32), action_space=Discrete(3), encoded_obs_dim=32,
+                  encoder_hidden_size=32, inverse_hidden_size=32, forward_hidden_size=32)
+    else:
+        icm = ICM(name="icm", obs_space=Box(-np.inf, np.inf, (17,), np.float32), action_space=Box(-1.0, 1.0, (6,), np.float32),
+                  encoded_obs_dim=32, encoder_hidden_size=64, inverse_hidden_size=32, forward_hidden_size=32,
+                  inverse_hidden_depth=3, forward_hidden_depth=1)
+    icm.to(dev)
+    sd = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}_p_")}
+    missing, unexpected = icm.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    act = torch.from_numpy(g[f"{tag}_actions"]).to(dev)
+    intr, inv_loss, f_loss = icm(torch.from_numpy(g[f"{tag}_obs1"]).to(dev), torch.from_numpy(g[f"{tag}_obs2"]).to(dev), act)
+    loss = (1.0 - 0.8) * f_loss + 0.8 * inv_loss
+    np.testing.assert_allclose(intr.detach().cpu().numpy().reshape(-1), g[f"{tag}_intr"].reshape(-1), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose([float(inv_loss), float(f_loss), float(loss)], g[f"{tag}_losses"], rtol=1e-5)
+    names = [str(n) for n in g[f"{tag}_names"]]
+    params = dict(icm.named_parameters())
+    grads = torch.autograd.grad(loss, [params[k] for k in names])
+    for k, gr in zip(names, grads):
+        want = g[f"{tag}_g_{k}"]
+        np.testing.assert_allclose(gr.cpu().numpy(), want, rtol=1e-5, atol=1e-5 * max(np.abs(want).max(), 1e-6), err_msg=k)
+
+
+def test_env_filter_kernels_match_reference_golden_g13(golden):
+    """The wrapper stack of the unmodified reference (ObservationNormalizer -> ObservationClipper -> RewardNormalizer
+    with quirk Q3 -> RewardClipper, wrapper_utils.py:81-111) stand-alone: 2 agents ("policy" critic view), terminations,
+    two passes -- through K13 (environments/filter_wrappers.py over csrc/env_filters.hip)."""
+    from ppo_and_friends_amd.environments import filter_wrappers as fw
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Discrete
+    g = golden("g13_filters")
+    E, T, A, O = (int(x) for x in g["cfg"])
+    dev = torch.device("cuda", 0)
+
+    class FixtureEnv(SyntheticFixedLengthEnv):
+        def __init__(self):
+            super().__init__(E, O, Discrete(2), T, dev, num_agents=A, critic_view="policy", term_prob=0.5)
+            self.obs_table = torch.from_numpy(agent_major(g["obs_table"])).to(dev)
+            v = self.obs_table.view(T + 1, A, E, O).permute(0, 2, 1, 3).reshape(T + 1, 1, E, A * O)
+            self.critic_obs_table = v.expand(T + 1, A, E, A * O).reshape(T + 1, A * E, A * O).contiguous()
+            self.reward_table = torch.from_numpy(agent_major(g["reward_table"])).to(dev)
+            self.term_table = torch.from_numpy(np.tile(g["term_table"], (1, A))).to(dev)
+
+    env = fw.wrap_environment(FixtureEnv, normalize_obs=True, normalize_rewards=True, obs_clip=(-1.5, 1.5),
+                              reward_clip=(-1.0, 1.0), gamma=0.99)
+    tol = dict(rtol=1e-5, atol=1e-5)
+    action = torch.zeros(A * E, dtype=torch.int64, device=dev)
+    for p in range(2):
+        obs, cobs = env.reset()
+        np.testing.assert_allclose(obs.cpu().numpy(), agent_major(g[f"p{p}_obs"])[0], **tol)
+        np.testing.assert_allclose(cobs.cpu().numpy(), agent_major(g[f"p{p}_critic_obs"])[0], **tol)
+        for t in range(T):
+            obs, cobs, rew, term, trunc, tobs = env.step(action)
+            np.testing.assert_allclose(obs.cpu().numpy(), agent_major(g[f"p{p}_obs"])[t + 1], err_msg=f"obs pass {p} step {t}", **tol)
+            np.testing.assert_allclose(cobs.cpu().numpy(), agent_major(g[f"p{p}_critic_obs"])[t + 1], err_msg=f"critic obs {p}/{t}", **tol)
+            np.testing.assert_allclose(rew.cpu().numpy(), agent_major(g[f"p{p}_rewards"])[t], err_msg=f"reward pass {p} step {t}", **tol)
+            np.testing.assert_allclose(env.natural_reward.cpu().numpy(), agent_major(g[f"p{p}_natural"])[t], rtol=1e-6)
