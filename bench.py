@@ -226,6 +226,38 @@ def update_kernel_roofline(ppo, pol, B, launches=64):
                 ac.flat_params.numel(), opt.step_count.data_ptr(), opt.lr.data_ptr(), opt.betas[0], opt.betas[1], opt.eps,
                 1.0, float(clip) if clip is not None else 0.0, opt.norm_scratch.data_ptr(), opt.grad_norm.data_ptr(), st), "adam")
             evs.append(ev)
+    elif fused.ws_reason() == "":
+        # the two-XCD persistent kernel: ONE launch = every full mini-batch of an epoch; begin / end of each launch
+        # stamped into events by the launch itself
+        fwd = lin(pol.actor) + lin(pol.critic)
+        ha, hc = args.actor.hidden, args.critic.hidden
+        mask = fused._ws_mask()
+        mask = ((1 if ha >= 256 else 0) | (2 if hc >= 256 else 0)) if mask is None or mask < 0 else mask
+        mode = lambda bit: "true" if mask & bit else "false"
+        n_mb = N // B
+        kernel = f"ppo_update_ws_kernel<{ha}, {hc}, {mode(1)}, {mode(2)}>"
+        desc = "3 x 2 x sum(Linear weights of actor + critic) x B x mini-batches in the launch"
+        reps = 4
+        for _ in range(reps):
+            ev = (K.event_create(), K.event_create())
+            fused.begin_epoch(torch.randperm(N, device=pol.device))
+            fused.ws_timing_events = [ev]
+            fused.run_epoch()
+            fused.end_epoch()
+            evs.append(ev)
+        torch.cuda.synchronize()
+        us = sorted(K.event_elapsed_ms(a, b) * 1e3 for a, b in evs)
+        avg = sum(us) / len(us)
+        flop = 3 * fwd * B * n_mb
+        tf = flop / (avg * 1e-6) / 1e12
+        return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 5), "flop_per_launch": int(flop), "flop_formula": desc,
+                "avg_launch_us": round(avg, 2), "median_launch_us": round(us[len(us) // 2], 2), "launches": len(us),
+                "minibatches_per_launch": n_mb, "us_per_minibatch": round(avg / n_mb, 3),
+                "launches_per_step": ppo.epochs_per_iter,
+                "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on epoch launches right after the timed region; "
+                          "profiles/ holds the rocprofv3 summary of the same command",
+                "traffic": None}
     else:
         fwd = lin(pol.actor) + lin(pol.critic)
         ha, hc = args.actor.hidden // 16, args.critic.hidden // 16

@@ -388,6 +388,31 @@ int ppoaf_ppo_update_persistent_ctl_bytes(void);
 int ppoaf_ppo_update_persistent(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl,
                                 int32_t target_xcc, double wait_seconds, ppoaf_stream_t stream);
 int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int compute_norms, ppoaf_stream_t stream);
+/* Weight-stationary persistent form of the same update (csrc/ppo_update_ws.hip; single rank): n_minibatches
+ * consecutive mini-batches in ONE launch, processed layer by layer over all B rows -- forward / dgrad as 64x32 output
+ * tiles, weight gradients as complete 32x32 tiles (K = the B rows: no slabs, no reduce pass), clip + Adam by the owner
+ * of each parameter column -- on `workers` (<= 32) workgroups per network, the actor's all on XCD xcc_actor and the
+ * critic's on xcc_critic (two different XCDs, 0..7), phases separated by flag barriers inside the XCD's L2.
+ * Replaces ppo.py:2292-2469 for a run of mini-batches exactly as fwd_bwd -> reduce -> adam does (same arguments, same
+ * totals / value-normaliser / step-counter bookkeeping; summation orders differ, results agree to float32 rounding).
+ * ctl: ppoaf_ppo_update_ws_ctl_bytes() of device memory, 16-byte aligned, owned by the caller during the launch;
+ * workspace: ppoaf_ppo_update_ws_workspace_bytes() of device memory, 256-byte aligned (activations, dLoss/dz and the
+ * output-layer partials of one mini-batch).  The third 32-bit word of ctl is non-zero afterwards if a wait ran out of
+ * wait_seconds.  Shapes: hidden width 32, 64, 128 or 256, out_dim <= 8, 16 <= B <= 512; anything else returns
+ * PPOAF_E_INVALID (callers keep the three-launch chain for those).  mb_offset must be 0; the cursor advances by
+ * n_minibatches once both networks have finished.
+ * layered_mask selects each network's decomposition: bit 0 (actor) / bit 1 (critic) set = layered as described above
+ * (in_dim <= 64); clear = ROW-TILED: phase 1 is the fwd_bwd body of the three-launch chain on ceil(B/16) of the
+ * workers (slabs), phase 2 folds the slabs for the parameter columns each worker owns -- sums stay in registers next
+ * to the prefetched parameter / moment values -- and phase 3 applies clip + Adam to them (three barriers per
+ * mini-batch); -1 = automatic (layered for 256-wide networks, whose 16-row workgroups sit at their MFMA floor,
+ * row-tiled below).  start_event / stop_event (from ppoaf_event_create, or NULL) receive the kernel's begin / end. */
+int ppoaf_ppo_update_ws_ctl_bytes(void);
+int ppoaf_ppo_update_ws_workspace_bytes(const ppoaf_ppo_update_args_t* args, int32_t layered_mask, int64_t* bytes_out);
+int ppoaf_ppo_update_ws(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl, void* workspace,
+                        int64_t workspace_bytes, int32_t workers, int32_t xcc_actor, int32_t xcc_critic,
+                        int32_t layered_mask, double wait_seconds, void* start_event, void* stop_event,
+                        ppoaf_stream_t stream);
 
 
 /* ------------------------------------------------------------------------ *

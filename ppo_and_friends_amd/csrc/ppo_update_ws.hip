@@ -1,0 +1,1183 @@
+// K12, weight-stationary persistent form: ONE launch runs n_mb consecutive PPO mini-batches (ppo.py:2292-2469)
+// for MLP actor / critic networks, single rank.
+//
+// Why a second decomposition.  The row-tiled chain (ppo_update.hip) gives every workgroup 16 rows and has it stream
+// the network's whole weight set, twice, per mini-batch; B = 256 rows fill 16 workgroups per network and a 256-wide
+// critic workgroup sits at its own f32-MFMA floor (~20 us).  Here the mini-batch is processed LAYER BY LAYER over all
+// of its rows: a phase is a set of independent 64x32 (forward / dgrad) or 32x32 (wgrad, K = all rows) output tiles,
+// each needing one slice of a weight matrix and one slice of an activation matrix, spread over W <= 32 workgroups
+// per network.  Weight gradients are complete sums over the mini-batch where they are produced -- no slabs, no
+// reduce pass -- and the owner of a parameter column applies clip + Adam to it in the same launch.
+//
+// What makes that affordable on MI355X: the W workers of a network are all placed on ONE XCD (HW_REG_XCC_ID + a
+// ticket, as in the single-XCD persistent form of ppo_update.hip; actor and critic take two different XCDs and never
+// wait for each other), so a phase boundary is a flag barrier inside that XCD's L2 (~1.2 us including the first
+// dependent load, measured with tools/probes/xcd_persist_probe.hip) and everything a phase hands to the next --
+// activations, dz, gradients, the rewritten parameters -- is an L2 hit read with L1-bypassing loads.
+//
+// Phases of one mini-batch (depth d hidden layers; z_l = W_l h_{l-1} + b_l, h_l = act(z_l), D_l = dLoss/dz_l):
+//   F(0..d-1)   h_l tiles                                             | barrier after each
+//   HEAD        per 16-row block: output layer, distribution head, losses, d out, D_{d-1}, output-layer gradient
+//               partials (K6 + K3; same device code as the row-tiled kernel)
+//   BW(d-1..1)  D_{l-1} tiles (dgrad)  +  dW_l / db_l tiles (wgrad)  [+ output-layer partials -> gradient]
+//   W0          dW_0 / db_0 tiles, loss bookkeeping, squared-norm partials
+//   ADAM        clip + Adam on this worker's parameter columns
+// Summation orders are fixed (K order inside a tile, K halves, workers in index order): bitwise reproducible.
+#include "ppo_update_rowtile.hpp"
+#include <hip/hip_ext.h>
+#include <cstdlib>
+
+namespace ppoaf {
+
+constexpr int kWsPS = 36;                 // row stride of a 32-column panel slice (conflict-free scalar reads)
+constexpr int kWsMaxWorkers = 32;
+
+struct WsDev {
+    float* hbuf[2];                       // [depth][Bp][H]   hidden activations of the mini-batch
+    float* dbuf[2];                       // [depth][Bp][H]   dLoss / dz
+    float* outpart[2];                    // [ceil(B/16)][seg] output-layer (+ log_std) gradient partials per row block
+    int W;                                // workers per network
+    int xcc[2];                           // XCD of the actor / critic workers
+    int Bp;                               // B rounded up to 64
+};
+
+struct WsCtl {
+    unsigned tickets[2], error, done, pad0[28];
+    unsigned flags[2][kWsMaxWorkers];     // barrier epoch each worker has reached
+    double norm_partials[2][kWsMaxWorkers];
+    unsigned long long phase_ticks[16];   // diagnostic build (-DPPOAF_WS_STAMPS): s_memtime sums per phase, actor worker 0
+};
+
+#ifdef PPOAF_WS_STAMPS
+#define PPOAF_WSTAMP(k)                                                                   \
+    do {                                                                                  \
+        if (which == PPOAF_WS_STAMP_NET && w == 0 && tid == 0) {                          \
+            unsigned long long t_;                                                        \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
+            ctl->phase_ticks[k] += t_ - t_prev;                                           \
+            t_prev = t_;                                                                  \
+        }                                                                                 \
+    } while (0)
+#ifndef PPOAF_WS_STAMP_NET
+#define PPOAF_WS_STAMP_NET 0
+#endif
+#else
+#define PPOAF_WSTAMP(k) do {} while (0)
+#endif
+
+extern __shared__ __attribute__((aligned(16))) unsigned char ppo_update_ws_smem[];
+
+// All W workers of network `which` arrive; false when the wait ran out of its budget (error word set).
+// One poll = ONE load instruction: lanes < W read the workers' flag words, lane 63 the error word.
+__device__ __forceinline__ bool ws_barrier(WsCtl* c, const int which, const int w, const int W, const unsigned epoch,
+                                           const long long budget, int* s_ok) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's stores have reached the L2
+    __syncthreads();
+    if (threadIdx.x == 0) *(volatile unsigned*)&c->flags[which][w] = epoch;   // plain store: the line stays in this XCD's L2
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const unsigned* word = lane < W ? &c->flags[which][lane] : &c->error;
+        const long long t0 = wall_clock64();
+        int ok = 1;
+        for (unsigned spin = 1;; ++spin) {
+            const unsigned f = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: served by the L2
+            if (__all((int)(lane >= W || f >= epoch))) break;
+            if (__shfl(f, 63, 64) != 0u || ((spin & 15u) == 0u && wall_clock64() - t0 > budget)) { ok = 0; break; }
+        }
+        if (lane == 0) {
+            if (!ok) *(volatile unsigned*)&c->error = 1u;
+            *s_ok = ok;
+        }
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+// ---- 16x16 output tile of one wave, K in chunks of 16 (four v_mfma_f32_16x16x4_f32 each; the k order inside a
+//      chunk is permuted the same way on both operands).  "row" operands: element (i, k) at p[i * stride + k],
+//      read as one 16-byte LDS load per chunk; "col" operands: element (k, j) at p[k * kWsPS + j], four scalars.
+__device__ __forceinline__ f32x4 ws_mfma_row_row(const float* __restrict__ A, const float* __restrict__ Bm, const int stride,
+                                                 const int c0, const int c1, const int lane, const float init) {
+    const float* a = A + (lane & 15) * stride + 4 * (lane >> 4);
+    const float* b = Bm + (lane & 15) * stride + 4 * (lane >> 4);
+    f32x4 acc0 = {init, init, init, init}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int c = c0;
+    for (; c + 1 < c1; c += 2) {
+        const float4 a0 = *reinterpret_cast<const float4*>(a + 16 * c), b0 = *reinterpret_cast<const float4*>(b + 16 * c);
+        const float4 a1 = *reinterpret_cast<const float4*>(a + 16 * c + 16), b1 = *reinterpret_cast<const float4*>(b + 16 * c + 16);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
+    }
+    if (c < c1) {
+        const float4 a0 = *reinterpret_cast<const float4*>(a + 16 * c), b0 = *reinterpret_cast<const float4*>(b + 16 * c);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
+    }
+    return acc0 + acc1;
+}
+
+__device__ __forceinline__ f32x4 ws_mfma_row_col(const float* __restrict__ A, const int stride, const float* __restrict__ Bc,
+                                                 const int c0, const int c1, const int lane) {
+    const float* a = A + (lane & 15) * stride + 4 * (lane >> 4);
+    const float* b = Bc + (4 * (lane >> 4)) * kWsPS + (lane & 15);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int c = c0;
+    for (; c + 1 < c1; c += 2) {
+        const float4 a0 = *reinterpret_cast<const float4*>(a + 16 * c), a1 = *reinterpret_cast<const float4*>(a + 16 * c + 16);
+        const float* bp = b + (16 * c) * kWsPS;
+        const float b00 = bp[0], b01 = bp[kWsPS], b02 = bp[2 * kWsPS], b03 = bp[3 * kWsPS];
+        const float b10 = bp[16 * kWsPS], b11 = bp[17 * kWsPS], b12 = bp[18 * kWsPS], b13 = bp[19 * kWsPS];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b00, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b10, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b01, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b11, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b02, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b12, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b03, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b13, acc1, 0, 0, 0);
+    }
+    if (c < c1) {
+        const float4 a0 = *reinterpret_cast<const float4*>(a + 16 * c);
+        const float* bp = b + (16 * c) * kWsPS;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bp[0], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bp[kWsPS], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bp[2 * kWsPS], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bp[3 * kWsPS], acc0, 0, 0, 0);
+    }
+    return acc0 + acc1;
+}
+
+// C[m][n] = sum_k Ac[k][m] * Bc[k][n]: both operands are 32-column slices with K (the mini-batch rows) down the rows
+__device__ __forceinline__ f32x4 ws_mfma_col_col(const float* __restrict__ Ac, const float* __restrict__ Bc,
+                                                 const int c0, const int c1, const int lane) {
+    const float* a = Ac + (4 * (lane >> 4)) * kWsPS + (lane & 15);
+    const float* b = Bc + (4 * (lane >> 4)) * kWsPS + (lane & 15);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int c = c0;
+    for (; c + 1 < c1; c += 2) {
+        const float* ap = a + (16 * c) * kWsPS;
+        const float* bp = b + (16 * c) * kWsPS;
+        const float a00 = ap[0], a01 = ap[kWsPS], a02 = ap[2 * kWsPS], a03 = ap[3 * kWsPS];
+        const float b00 = bp[0], b01 = bp[kWsPS], b02 = bp[2 * kWsPS], b03 = bp[3 * kWsPS];
+        const float a10 = ap[16 * kWsPS], a11 = ap[17 * kWsPS], a12 = ap[18 * kWsPS], a13 = ap[19 * kWsPS];
+        const float b10 = bp[16 * kWsPS], b11 = bp[17 * kWsPS], b12 = bp[18 * kWsPS], b13 = bp[19 * kWsPS];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a00, b00, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a10, b10, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a01, b01, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11, b11, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a02, b02, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a12, b12, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a03, b03, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a13, b13, acc1, 0, 0, 0);
+    }
+    if (c < c1) {
+        const float* ap = a + (16 * c) * kWsPS;
+        const float* bp = b + (16 * c) * kWsPS;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], bp[0], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kWsPS], bp[kWsPS], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[2 * kWsPS], bp[2 * kWsPS], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[3 * kWsPS], bp[3 * kWsPS], acc0, 0, 0, 0);
+    }
+    return acc0 + acc1;
+}
+
+
+// the same with a compile-time chunk count: fully unrolled, so the LDS reads are scheduled ahead of the MFMA chain
+template <int NCK>
+__device__ __forceinline__ f32x4 ws_mfma_row_row_c(const float* __restrict__ A, const float* __restrict__ Bm, const int stride,
+                                                   const int lane, const float init) {
+    const float* a = A + (lane & 15) * stride + 4 * (lane >> 4);
+    const float* b = Bm + (lane & 15) * stride + 4 * (lane >> 4);
+    f32x4 acc0 = {init, init, init, init}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) {
+        const float4 av = *reinterpret_cast<const float4*>(a + 16 * c), bv = *reinterpret_cast<const float4*>(b + 16 * c);
+        if (c & 1) {
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
+        } else {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc0, 0, 0, 0);
+        }
+    }
+    return acc0 + acc1;
+}
+template <int NCK>
+__device__ __forceinline__ f32x4 ws_mfma_row_col_c(const float* __restrict__ A, const int stride, const float* __restrict__ Bc,
+                                                   const int lane) {
+    const float* a = A + (lane & 15) * stride + 4 * (lane >> 4);
+    const float* b = Bc + (4 * (lane >> 4)) * kWsPS + (lane & 15);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) {
+        const float4 av = *reinterpret_cast<const float4*>(a + 16 * c);
+        const float* bp = b + (16 * c) * kWsPS;
+        const float b0 = bp[0], b1 = bp[kWsPS], b2 = bp[2 * kWsPS], b3 = bp[3 * kWsPS];
+        if (c & 1) {
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b2, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b3, acc1, 0, 0, 0);
+        } else {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b2, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b3, acc0, 0, 0, 0);
+        }
+    }
+    return acc0 + acc1;
+}
+
+// Panel loads, in two halves so that several panels share ONE L2 round trip: issue() requests rows [r0, r0 + nrows)
+// of a row-major [*, ld] matrix (16-byte aligned rows), columns [c0, c0 + NCOLS), into registers with L1-bypassing
+// 16-byte loads (rows >= row_limit: zero); commit() stores them to dst[r * dstride + c].  NCOLS / 4 is a power of two
+// <= 128; MAXROWS bounds nrows (both compile-time: the thread -> (row, column) map is shifts and masks).
+template <int NCOLS, int MAXROWS>
+struct WsPanel {
+    static constexpr int n4 = NCOLS / 4, rpp = kThreadsU / n4, its = (MAXROWS + rpp - 1) / rpp;
+    float4 v[its];
+};
+
+template <int NCOLS, int MAXROWS>
+__device__ __forceinline__ void ws_panel_issue(WsPanel<NCOLS, MAXROWS>& R, const float* __restrict__ src, const long ld,
+                                               const int r0, const int nrows, const int row_limit, const int c0, const int tid) {
+    using P = WsPanel<NCOLS, MAXROWS>;
+    const int r = tid / P::n4, c4 = tid % P::n4;
+    const float* sp = src + (long)(r0 + r) * ld + c0 + 4 * c4;
+#pragma unroll
+    for (int it = 0; it < P::its; ++it) {
+        const int rr = r + it * P::rpp;
+        R.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < nrows && r0 + rr < row_limit) R.v[it] = ld4<true>(sp + (long)it * P::rpp * ld);
+    }
+}
+template <int NCOLS, int MAXROWS>
+__device__ __forceinline__ void ws_panel_commit(const WsPanel<NCOLS, MAXROWS>& R, float* __restrict__ dst, const int dstride,
+                                                const int nrows, const int tid) {
+    using P = WsPanel<NCOLS, MAXROWS>;
+    const int r = tid / P::n4, c4 = tid % P::n4;
+#pragma unroll
+    for (int it = 0; it < P::its; ++it) {
+        const int rr = r + it * P::rpp;
+        if (rr < nrows) *reinterpret_cast<float4*>(dst + rr * dstride + 4 * c4) = R.v[it];
+    }
+}
+
+// n scalar elements: element e is read from src(e, valid) -- always a readable address; valid = false: the value is
+// replaced by zero -- and stored to dst(e).  The loads of a chunk of 8 per thread are unconditional and issued before
+// its stores (one round trip per chunk).  NT: L1-bypassing (data another CU of this launch has rewritten).
+template <bool NT, typename SrcF, typename DstF>
+__device__ __forceinline__ void ws_fill_scalar(const int n, const int tid, SrcF src, DstF dst) {
+    for (int base = 0; base < n; base += 8 * kThreadsU) {
+        float v[8];
+        bool ok[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = base + k * kThreadsU + tid;
+            ok[k] = e < n;
+            const float* p = src(ok[k] ? e : 0, ok[k]);
+            v[k] = ld1<NT>(p);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = base + k * kThreadsU + tid;
+            if (e < n) *dst(e) = ok[k] ? v[k] : 0.f;
+        }
+    }
+}
+
+// One weight-gradient tile: dW[o0 + 32][i0 + 32] = Dp^T . Xp over the Bk mini-batch rows (both panels [Bk][kWsPS]),
+// the K range split over the two wave halves and folded in a fixed order; bias gradient = column sums of Dp when
+// `dst_b`.  Returns this thread's contribution to the squared gradient norm (scaled gradients, double).
+__device__ __forceinline__ double ws_wgrad_tile(const float* __restrict__ Dp, const float* __restrict__ Xp, float* __restrict__ sRed,
+                                                const int Bk, float* __restrict__ dstW, const long ldw, const int o0,
+                                                const int i0, const int i_valid, float* __restrict__ dst_b,
+                                                const float sc, const int tid, const int wave, const int lane) {
+    const int ot2 = wave & 1, it2 = (wave >> 1) & 1, kh = wave >> 2;
+    const int nc = Bk >> 4, half = (nc + 1) >> 1;
+    const f32x4 acc = ws_mfma_col_col(Dp + 16 * ot2, Xp + 16 * it2, kh ? half : 0, kh ? nc : half, lane);
+    if (kh) *reinterpret_cast<f32x4*>(sRed + ((wave & 3) * 64 + lane) * 4) = acc;
+    // bias gradient partials: 16 row classes x 32 columns
+    float* sB = sRed + 1024;
+    if (dst_b) {
+        const int col = tid & 31, part = tid >> 5;
+        float a = 0.f;
+        for (int s = part; s < Bk; s += 16) a += Dp[s * kWsPS + col];
+        sB[part * 32 + col] = a;
+    }
+    __syncthreads();
+    double q = 0.0;
+    if (!kh) {
+        const f32x4 other = *reinterpret_cast<const f32x4*>(sRed + ((wave & 3) * 64 + lane) * 4);
+        const int i = i0 + 16 * it2 + (lane & 15);
+        if (i < i_valid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + 16 * ot2 + 4 * (lane >> 4) + r;
+                const float g = acc[r] + other[r];
+                dstW[(long)o * ldw + i] = g;
+                q += (double)(g * sc) * (g * sc);
+            }
+        }
+    }
+    if (dst_b && tid >= 256 && tid < 288) {
+        const int col = tid - 256;
+        float a = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) a += sB[p * 32 + col];
+        dst_b[o0 + col] = a;
+        q += (double)(a * sc) * (a * sc);
+    }
+    return q;
+}
+
+struct WsArgs { UpdateDev u; WsDev ws; };
+typedef const WsArgs __attribute__((address_space(4))) KWsArgs;
+
+// One worker of network WHICH (hidden width H) for the whole launch.  Everything the body derives from the kernel
+// arguments or the lane id is re-derived per mini-batch from laundered copies (see ppo_update.hip, persistent form):
+// hoisted out of the mini-batch loop it would all be live at once and spill.
+template <int WHICH, int H>
+__device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w, const int n_mb, const long long budget,
+                                          int* s_ok, double* s_red, double* s_norm, float* s_step) {
+    constexpr int which = WHICH;
+    constexpr int HS = H + 4, NCH = H / 16, nct = H / 32;
+    // ---- LDS carve
+    float* smem = reinterpret_cast<float*>(ppo_update_ws_smem);
+    int* sRow = reinterpret_cast<int*>(smem);                 // [512] dataset row of every mini-batch row (-1: dead)
+    int* sDi = sRow + 512;                                    // [512] where its inputs are read from (-1: dead)
+    float* sMisc = smem + 1024;                               // [16]
+    float* sRowF = sMisc + 16;                                // [3][16]
+    float* sActF = sRowF + 48;                                // [16][8]
+    float* sOut = sActF + 128;                                // [16][16]
+    float* sDOut = sOut + 256;                                // [16][16]
+    float* sRed = sDOut + 256;                                // [1024 + 512] wgrad K-half fold, bias partials
+    float* sP = sRed + 1536;                                  // panels
+
+    const long cursor0 = ka0->u.cursor[0];                    // rewritten only after both networks have finished
+    const int W = ka0->ws.W;
+    unsigned epoch = 0;
+#ifdef PPOAF_WS_STAMPS
+    unsigned long long t_prev = 0;
+    if (which == PPOAF_WS_STAMP_NET && w == 0 && threadIdx.x == 0)
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#endif
+
+    for (int it = 0; it < n_mb; ++it) {
+        KWsArgs* ka = ka0;
+        asm volatile("" : "+s"(ka));
+        const auto& u = ka->u;
+        const auto& ws = ka->ws;
+        int tid_l = threadIdx.x;
+        asm volatile("" : "+v"(tid_l));
+        __builtin_assume(tid_l >= 0 && tid_l < kThreadsU);
+        const int tid = tid_l, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+        const auto& nd = u.net[which];
+        const int in_dim = nd.in_dim, depth = nd.depth, out_dim = nd.out_dim, act = nd.act;
+        const int in_pad = (in_dim + 15) & ~15;
+        const long B = u.B;
+        const int Bp = ws.Bp, Bk = ((int)B + 15) & ~15;
+        const int n_rt = Bp >> 6, n_hb = ((int)B + 15) >> 4;
+        const long szW0 = ((long)H * in_dim + 3) & ~3L;
+        auto offW = [&](int l) -> long { return l == 0 ? 0 : szW0 + H + (long)(l - 1) * ((long)H * H + H); };
+        auto offB = [&](int l) -> long {
+            return l == 0 ? szW0 : offW(l) + (l < depth ? (long)H * H : (((long)out_dim * H + 3) & ~3L));
+        };
+        const long seg_off = offW(depth), seg_len = nd.size - seg_off;
+        const long relB = ((long)out_dim * H + 3) & ~3L, relLS = relB + ((out_dim + 3) & ~3);
+        const float* P = u.params + nd.offset;
+        float* G = u.grads + nd.offset;
+        float* hbuf = ws.hbuf[which];
+        float* dbuf = ws.dbuf[which];
+        float* outpart = ws.outpart[which];
+        const long plane = (long)Bp * H;
+        const float* xsrc = which == 0 ? u.obs : u.critic_obs;
+        const long mb = cursor0 + it;
+        const long base = mb * u.batch_stride;
+        double sumsq = 0.0;
+
+        // ---- row table of the mini-batch
+        for (int s = tid; s < Bp; s += kThreadsU) {
+            int row = -1;
+            long di = -1;
+            if (s < B) {
+                const long p = u.perm[base + s];
+                if (p >= 0 && p < u.n_rows) row = u.row_map ? u.row_map[p] : (int)p;
+                di = u.pregathered ? base + s : row;
+            }
+            sRow[s] = row;
+            sDi[s] = row >= 0 ? (int)di : -1;
+        }
+        __syncthreads();
+
+        // ---- forward layer 0: h_0[64 rows][32 columns] tiles, K = in_pad (<= 64): 16 threads per row, no divisions
+        {
+            const int AS = in_pad + 4, nck = in_pad >> 4;
+            float* sA = sP;
+            float* sW = sP + 64 * AS;
+            const float* W0 = P;
+            const float* b0 = P + offB(0);
+            for (int j = w; j < n_rt * nct; j += W) {
+                const int rt = j / nct, ct = j % nct;
+                const int o = ct * 32 + 16 * (wave >> 2) + (lane & 15);
+                const float bias = ld1<true>(b0 + o);
+                const int r16 = tid >> 4, kq = tid & 15;
+                float xa[8], wv[4];
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int di = sDi[rt * 64 + r16 + 32 * ps];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = kq + 16 * i;
+                        const bool ok = di >= 0 && k < in_dim;
+                        const float v = xsrc[(long)(di >= 0 ? di : 0) * in_dim + (k < in_dim ? k : 0)];
+                        xa[ps * 4 + i] = ok ? v : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = kq + 16 * i;
+                    const float v = ld1<true>(W0 + (long)(ct * 32 + r16) * in_dim + (k < in_dim ? k : 0));
+                    wv[i] = k < in_dim ? v : 0.f;
+                }
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < nck) sA[(r16 + 32 * ps) * AS + kq + 16 * i] = xa[ps * 4 + i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < nck) sW[r16 * AS + kq + 16 * i] = wv[i];
+                __syncthreads();
+                const f32x4 acc = ws_mfma_row_row(sA + 16 * (wave & 3) * AS, sW + 16 * (wave >> 2) * AS, AS, 0, nck, lane, bias);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s = rt * 64 + 16 * (wave & 3) + 4 * (lane >> 4) + r;
+                    if (s < B) hbuf[(long)s * H + o] = act_fwd(acc[r], act);
+                }
+                __syncthreads();
+            }
+            PPOAF_WSTAMP(0);
+            if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
+            PPOAF_WSTAMP(1);
+        }
+
+        // ---- forward, hidden layers: h_l[64 rows][32 columns] tiles
+        for (int l = 1; l < depth; ++l) {
+            float* sA = sP;
+            float* sW = sP + 64 * HS;
+            const float* Wl = P + offW(l);
+            const float* bl = P + offB(l);
+            float* hout = hbuf + (long)l * plane;
+            for (int j = w; j < n_rt * nct; j += W) {
+                const int rt = j / nct, ct = j % nct;
+                const int o = ct * 32 + 16 * (wave >> 2) + (lane & 15);
+                const float bias = ld1<true>(bl + o);
+                WsPanel<H, 64> ra;
+                WsPanel<H, 32> rw;
+                ws_panel_issue(ra, hbuf + (long)(l - 1) * plane, H, rt * 64, 64, (int)B, 0, tid);
+                ws_panel_issue(rw, Wl, H, ct * 32, 32, H, 0, tid);
+                ws_panel_commit(ra, sA, HS, 64, tid);
+                ws_panel_commit(rw, sW, HS, 32, tid);
+                __syncthreads();
+                const f32x4 acc = ws_mfma_row_row_c<NCH>(sA + 16 * (wave & 3) * HS, sW + 16 * (wave >> 2) * HS, HS, lane, bias);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s = rt * 64 + 16 * (wave & 3) + 4 * (lane >> 4) + r;
+                    if (s < B) hout[(long)s * H + o] = act_fwd(acc[r], act);
+                }
+                __syncthreads();
+            }
+            PPOAF_WSTAMP(0);
+            if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
+            PPOAF_WSTAMP(1);
+        }
+
+        // ---- HEAD: output layer, distribution head + losses, D_{depth-1}, output-layer gradient partials
+        {
+            float* sH = sP;                                   // [16][HS]
+            float* sWout = sH + 16 * HS;                      // [8][H]
+            float* sBout = sWout + 8 * H;                     // [16]
+            const float* hlast = hbuf + (long)(depth - 1) * plane;
+            float* dlast = dbuf + (long)(depth - 1) * plane;
+            for (int g = w; g < n_hb; g += W) {
+                WsPanel<H, 16> rh;
+                ws_panel_issue(rh, hlast, H, g * 16, 16, (int)B, 0, tid);
+                float wo[(8 * H + kThreadsU - 1) / kThreadsU];
+#pragma unroll
+                for (int i = 0; i < (8 * H + kThreadsU - 1) / kThreadsU; ++i) {
+                    const int e = tid + i * kThreadsU;
+                    wo[i] = ld1<true>(P + offW(depth) + (e < out_dim * H ? e : 0));
+                }
+                float bo = 0.f;
+                if (tid < out_dim) bo = ld1<true>(P + offB(depth) + tid);
+                if (tid < kRows) {
+                    const int s = g * kRows + tid;
+                    const int di = sDi[s];
+                    float av = 0.f, lpo = 0.f, rt = 0.f;
+                    if (di >= 0) {
+                        if (which == 0) {
+                            av = u.adv[di]; lpo = u.old_lp[di];
+                            if (u.head_kind == PPOAF_HEAD_CATEGORICAL)
+                                reinterpret_cast<int*>(sActF)[tid * 8] = (int)reinterpret_cast<const int64_t*>(u.raw_actions)[di];
+                            else
+                                for (int d = 0; d < out_dim; ++d)
+                                    sActF[tid * 8 + d] = reinterpret_cast<const float*>(u.raw_actions)[(long)di * out_dim + d];
+                        } else {
+                            rt = u.rtg[di];
+                        }
+                    }
+                    sRowF[tid] = av; sRowF[16 + tid] = lpo; sRowF[32 + tid] = rt;
+                }
+                if (tid == 64) {                              // mini-batch statistics (as the row-tiled kernel's S0)
+                    if (which == 0) {
+                        float mean_f = 0.f, std_f = 1.f;
+                        if (u.normalize_adv) {                // ppo.py:2326-2333, from the per-epoch table
+                            const double* rec = u.adv_records + mb * 3;
+                            mean_f = (float)rec[1];
+                            std_f = (float)sqrt(rec[2] / (rec[0] - 1.0));
+                        }
+                        sMisc[0] = mean_f; sMisc[1] = std_f;
+                    } else {
+                        const int slot = (int)(mb & 1);
+                        float m = ld1<true>(u.vn_mean + slot), v = ld1<true>(u.vn_var + slot);
+                        double cnt = ld1<true>(u.vn_count + slot);
+                        if (u.normalize_values) {             // Chan merge of the per-rank records + utils/stats.py:73-94
+                            double n = 0.0, bm = 0.0, M2 = 0.0;
+                            for (int r = 0; r < u.n_ranks; ++r) {
+                                const double* rec = u.vn_records + (mb * u.n_ranks + r) * 3;
+                                const double nb = rec[0];
+                                if (nb <= 0.0) continue;
+                                const double d = rec[1] - bm, nn = n + nb;
+                                bm += d * (nb / nn);
+                                M2 += rec[2] + d * d * n * nb / nn;
+                                n = nn;
+                            }
+                            if (n > 0.0) {
+                                const float batch_mean = (float)bm, batch_var = (float)(M2 / n);
+                                const float delta = batch_mean - m;
+                                const double new_count = cnt + n;
+                                const float new_mean = (float)((double)m + (double)delta * (n / new_count));
+                                const double m_2 = (double)v * cnt + (double)batch_var * n +
+                                                   (double)(delta * delta) * cnt * n / (cnt + n);
+                                m = new_mean; v = (float)(m_2 / (cnt + n)); cnt = new_count;
+                            }
+                        }
+                        sMisc[2] = m; sMisc[3] = v;
+                        if (g == 0) { u.vn_mean[slot ^ 1] = m; u.vn_var[slot ^ 1] = v; u.vn_count[slot ^ 1] = cnt; }
+                    }
+                }
+                ws_panel_commit(rh, sH, HS, 16, tid);
+#pragma unroll
+                for (int i = 0; i < (8 * H + kThreadsU - 1) / kThreadsU; ++i) {
+                    const int e = tid + i * kThreadsU;
+                    if (e < out_dim * H) sWout[e] = wo[i];
+                }
+                if (tid < out_dim) sBout[tid] = bo;
+                __syncthreads();
+                if (tid < 256) {                              // output layer: 16 lanes per row
+                    const int s = tid >> 4, part = tid & 15;
+                    for (int k = 0; k < out_dim; ++k) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int i = 0; i < H; i += 16) acc = fmaf(sH[s * HS + part + i], sWout[k * H + part + i], acc);
+                        acc = group16_sum(acc);
+                        if (part == 0) sOut[s * kMaxOut + k] = acc + sBout[k];
+                    }
+                }
+                __syncthreads();
+                if (wave == 0)
+                    ppo_head_loss<true>(u, which, g, out_dim, P + nd.log_std_off, sRow + g * kRows, sRowF, sMisc, sActF, sOut,
+                                        sDOut, lane, B);
+                __syncthreads();
+                float* op = outpart + (long)g * seg_len;
+                if (tid < H) {                                // dW_out partial of this row block
+                    const int i = tid;
+                    float h[kRows];
+#pragma unroll
+                    for (int s = 0; s < kRows; ++s) h[s] = sH[s * HS + i];
+                    for (int k = 0; k < out_dim; ++k) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int s = 0; s < kRows; ++s) acc = fmaf(sDOut[s * kMaxOut + k], h[s], acc);
+                        op[(long)k * H + i] = acc;
+                    }
+                }
+                if (tid >= 256 && tid < 256 + ((out_dim + 3) & ~3)) {
+                    const int k = tid - 256;
+                    float acc = 0.f;
+                    if (k < out_dim)
+                        for (int s = 0; s < kRows; ++s) acc += sDOut[s * kMaxOut + k];
+                    op[relB + k] = acc;
+                }
+                if (which == 0 && u.head_kind == PPOAF_HEAD_GAUSSIAN && tid >= 320 && tid < 320 + ((out_dim + 3) & ~3)) {
+                    const int d = tid - 320;
+                    float acc = 0.f;
+                    if (d < out_dim)
+                        for (int s = 0; s < kRows; ++s) acc += sOut[s * kMaxOut + 8 + d];
+                    op[relLS + d] = acc;
+                }
+#pragma unroll
+                for (int idx = tid; idx < kRows * H; idx += kThreadsU) {          // D_{depth-1} rows of this block
+                    const int s = idx / H, i = idx % H;
+                    float acc = 0.f;
+                    for (int k = 0; k < out_dim; ++k) acc = fmaf(sDOut[s * kMaxOut + k], sWout[k * H + i], acc);
+                    const int gs = g * kRows + s;
+                    if (gs < B) dlast[(long)gs * H + i] = acc * act_bwd(sH[s * HS + i], act);
+                }
+                __syncthreads();
+            }
+        }
+        PPOAF_WSTAMP(2);
+        if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
+        PPOAF_WSTAMP(3);
+
+        // ---- backward through the hidden layers: D_{l-1} tiles and dW_l tiles side by side
+        for (int l = depth - 1; l >= 0; --l) {
+            const float* Dl = dbuf + (long)l * plane;
+            const float* Wl = P + offW(l);
+            const int n_dg = l >= 1 ? n_rt * nct : 0;
+            const int n_it = l >= 1 ? nct : (in_dim + 31) >> 5;        // column tiles of the layer's input
+            const int n_wg = nct * n_it;
+            const bool out_job = l == depth - 1;                       // fold the output-layer partials in this phase
+            const int n_jobs = n_dg + n_wg + (out_job ? 1 : 0);
+            for (int j = w; j < n_jobs; j += W) {
+                if (j < n_dg) {
+                    // D_{l-1}[64 rows][32 cols] = (D_l . W_l[:, cols]) * act'(h_{l-1})
+                    const int rt = j / nct, ct = j % nct;
+                    float* sA = sP;                           // D_l rows [64][HS]
+                    float* sWc = sP + 64 * HS;                // W_l[:, ct*32 .. +32]  [H][kWsPS]
+                    const float* hin = hbuf + (long)(l - 1) * plane;
+                    float* dout = dbuf + (long)(l - 1) * plane;
+                    const int i = ct * 32 + 16 * (wave >> 2) + (lane & 15);
+                    float hv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int s = rt * 64 + 16 * (wave & 3) + 4 * (lane >> 4) + r;
+                        hv[r] = ld1<true>(hin + (long)(s < B ? s : 0) * H + i);
+                    }
+                    WsPanel<H, 64> ra;
+                    WsPanel<32, H> rw;
+                    ws_panel_issue(ra, Dl, H, rt * 64, 64, (int)B, 0, tid);
+                    ws_panel_issue(rw, Wl, H, 0, H, H, ct * 32, tid);
+                    ws_panel_commit(ra, sA, HS, 64, tid);
+                    ws_panel_commit(rw, sWc, kWsPS, H, tid);
+                    __syncthreads();
+                    const f32x4 acc = ws_mfma_row_col_c<NCH>(sA + 16 * (wave & 3) * HS, HS, sWc + 16 * (wave >> 2), lane);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int s = rt * 64 + 16 * (wave & 3) + 4 * (lane >> 4) + r;
+                        if (s < B) dout[(long)s * H + i] = acc[r] * act_bwd(hv[r], act);
+                    }
+                    __syncthreads();
+                } else if (j < n_dg + n_wg) {
+                    const int jj = j - n_dg;
+                    const int ot = jj / n_it, itile = jj - ot * n_it;
+                    float* sD = sP;                           // D_l[:, ot*32 .. +32]      [Bk][kWsPS]
+                    float* sX = sP + Bk * kWsPS;              // h_{l-1}[:, it*32 .. +32]  [Bk][kWsPS]
+                    WsPanel<32, 512> rd;
+                    ws_panel_issue(rd, Dl, H, 0, Bk, (int)B, ot * 32, tid);
+                    if (l >= 1) {
+                        WsPanel<32, 512> rx;
+                        ws_panel_issue(rx, hbuf + (long)(l - 1) * plane, H, 0, Bk, (int)B, itile * 32, tid);
+                        ws_panel_commit(rx, sX, kWsPS, Bk, tid);
+                    } else {
+                        // input columns [itile * 32, +32) of all rows (gathered): cp (power of two >= the valid
+                        // columns) threads per row; the columns beyond the valid ones are zero
+                        const int k0 = itile * 32, ncv = in_dim - k0 < 32 ? in_dim - k0 : 32;
+                        const int shc = ncv <= 1 ? 0 : 32 - __clz(ncv - 1), cp = 1 << shc, rpp = kThreadsU >> shc;
+                        const int c = tid & (cp - 1), r = tid >> shc;
+                        for (int s0 = 0; s0 < Bk; s0 += 8 * rpp) {
+                            float xv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int s = s0 + q * rpp + r;
+                                const int di = s < Bk ? sDi[s < Bp ? s : 0] : -1;
+                                const float v = xsrc[(long)(di >= 0 ? di : 0) * in_dim + k0 + (c < ncv ? c : 0)];
+                                xv[q] = (di >= 0 && c < ncv) ? v : 0.f;
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int s = s0 + q * rpp + r;
+                                if (s < Bk) {
+                                    sX[s * kWsPS + c] = xv[q];
+                                    for (int cc = c + cp; cc < 32; cc += cp) sX[s * kWsPS + cc] = 0.f;
+                                }
+                            }
+                        }
+                    }
+                    ws_panel_commit(rd, sD, kWsPS, Bk, tid);
+                    __syncthreads();
+                    const long ldw = l >= 1 ? H : in_dim;
+                    sumsq += ws_wgrad_tile(sD, sX, sRed, Bk, G + offW(l), ldw, ot * 32, itile * 32, (int)ldw,
+                                           itile == 0 ? G + offB(l) : nullptr, u.grad_scale, tid, wave, lane);
+                    __syncthreads();
+                } else {
+                    // output layer (+ log_std): row-block partials -> gradient, in block order
+                    const float sc = u.grad_scale;
+                    for (long idx = tid; idx < seg_len; idx += kThreadsU) {
+                        float acc = 0.f;
+                        for (int g0 = 0; g0 < n_hb; g0 += 8) {
+                            float pv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) pv[q] = ld1<true>(outpart + (long)(g0 + q < n_hb ? g0 + q : 0) * seg_len + idx);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) if (g0 + q < n_hb) acc += pv[q];
+                        }
+                        G[seg_off + idx] = acc;
+                        sumsq += (double)(acc * sc) * (acc * sc);
+                    }
+                }
+            }
+            if (l == 0) {
+                // loss bookkeeping of this network (the partials are complete since the HEAD barrier), Adam step
+                // counter + bias corrections, then this worker's squared-norm partial
+                if (w == W - 1 && tid < 64) {
+                    float p0 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p7 = 0.f;
+                    for (int gg = lane; gg < n_hb; gg += 64) {
+                        const float* a = u.loss_partials + ((long)which * n_hb + gg) * 8;
+                        p0 += ld1<true>(a); p2 += ld1<true>(a + 2); p3 += ld1<true>(a + 3); p4 += ld1<true>(a + 4); p7 += ld1<true>(a + 7);
+                    }
+                    p0 = wave_sum(p0); p2 = wave_sum(p2); p3 = wave_sum(p3); p4 = wave_sum(p4); p7 = wave_sum(p7);
+                    if (lane == 0) {
+                        const float n = (float)B;
+                        if (which == 0) {
+                            const float surr = p0 / n, ent = p3 / n, kl = p4 / n;
+                            float total = surr;
+                            if (u.entropy_weight != 0.0f) total -= u.entropy_weight * ent;
+                            if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
+                            u.totals[0] += (double)surr; u.totals[1] += (double)total;
+                            u.totals[3] += (double)ent; u.totals[4] += (double)kl;
+                            u.totals[5] += (double)ld1<true>(u.loss_partials + 5); u.totals[6] += (double)ld1<true>(u.loss_partials + 6);
+                            u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
+                            u.totals[8] += 1.0;
+                        } else {
+                            u.totals[2] += (double)(p2 / n);
+                        }
+                        const int64_t t = u.step_counts[which] + 1;       // only this lane touches the counter in the launch
+                        u.step_counts[which] = t;
+                        u.norm_scratch[2 + 2 * which] = 1.0 - pow((double)u.beta1, (double)t);
+                        u.norm_scratch[3 + 2 * which] = sqrt(1.0 - pow((double)u.beta2, (double)t));
+                    }
+                }
+                const double q = block_sum(sumsq, s_red);
+                if (tid == 0) ctl->norm_partials[which][w] = q;
+            }
+            const int stamp = l == 0 ? 8 : (l == depth - 1 ? 4 : 6);     // W0 / first backward phase / middle ones
+            (void)stamp;
+            PPOAF_WSTAMP(stamp);
+            if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
+            PPOAF_WSTAMP(stamp + 1);
+        }
+
+        // ---- clip + Adam on this worker's columns of the network; norm = partials in worker order.  The parameter /
+        //      moment / gradient loads depend on nothing computed here, so they are requested first.
+        {
+            const long lo4 = nd.offset >> 2, hi4 = (nd.offset + nd.size) >> 2;
+            const long idx0 = lo4 + (long)w * kThreadsU + tid;
+            const bool have0 = idx0 < hi4;
+            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), g0 = p0, m0 = p0, v0 = p0;
+            if (have0) {
+                p0 = ld4<true>(u.params + 4 * idx0); g0 = ld4<true>(u.grads + 4 * idx0);
+                m0 = ld4<true>(u.exp_avg + 4 * idx0); v0 = ld4<true>(u.exp_avg_sq + 4 * idx0);
+            }
+            if (tid < 64) {
+                const double part = lane < W ? ld1<true>(&ctl->norm_partials[which][lane]) : 0.0;
+                const double bc1 = ld1<true>(u.norm_scratch + 2 + 2 * which), bc2 = ld1<true>(u.norm_scratch + 3 + 2 * which);
+                double sq = 0.0;
+                for (int k = 0; k < W; ++k) sq += __shfl(part, k, 64);          // worker order, every lane the same sum
+                if (lane == 0) {
+                    s_norm[0] = sq;
+                    s_step[0] = (float)((double)u.lr[0] / bc1);
+                    s_step[1] = (float)bc2;
+                }
+            }
+            __syncthreads();
+            const float total_norm = (float)sqrt(s_norm[0]);
+            float coef = 1.0f;
+            if (u.max_norm > 0.f) coef = fminf(u.max_norm / (total_norm + 1e-6f), 1.0f);
+            const float gs = u.grad_scale * coef;
+            const float step_size = s_step[0], bc2_sqrt = s_step[1];
+            const float beta1 = u.beta1, beta2 = u.beta2, adam_eps = u.adam_eps;
+#define PPOAF_ADAM1(c)                                                   \
+            {                                                            \
+                const float gi = gr.c * gs;                              \
+                m.c = beta1 * m.c + (1.0f - beta1) * gi;                 \
+                v.c = beta2 * v.c + (1.0f - beta2) * gi * gi;            \
+                p.c = p.c - step_size * (m.c / (sqrtf(v.c) / bc2_sqrt + adam_eps)); \
+            }
+            for (long idx = idx0; idx < hi4; idx += (long)W * kThreadsU) {
+                float4 p, gr, m, v;
+                if (idx == idx0) { p = p0; gr = g0; m = m0; v = v0; }
+                else {
+                    p = ld4<true>(u.params + 4 * idx); gr = ld4<true>(u.grads + 4 * idx);
+                    m = ld4<true>(u.exp_avg + 4 * idx); v = ld4<true>(u.exp_avg_sq + 4 * idx);
+                }
+                PPOAF_ADAM1(x) PPOAF_ADAM1(y) PPOAF_ADAM1(z) PPOAF_ADAM1(w)
+                reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx] = p;
+                reinterpret_cast<float4*>(u.exp_avg)[idx] = m;
+                reinterpret_cast<float4*>(u.exp_avg_sq)[idx] = v;
+            }
+#undef PPOAF_ADAM1
+        }
+        PPOAF_WSTAMP(10);
+        if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
+        PPOAF_WSTAMP(11);
+    }
+    // the cursor moves once BOTH networks are done with the launch (each read it when it started)
+    if (w == 0 && threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == 1u) ka0->u.cursor[0] = cursor0 + n_mb;
+    }
+}
+
+// Row-tiled mode of a network's worker group (hidden widths <= 128, where a 16-row workgroup is far from its MFMA
+// floor): phase 1 is the three-launch chain's fwd_bwd body on ceil(B/16) of the W workers (slabs), phase 2 folds the
+// slabs for the columns this worker owns -- the sums stay in registers, next to the parameter / moment values that
+// were requested before the slab loads -- and phase 3 applies clip + Adam to them: three barriers per mini-batch, no
+// gradient round trip.  At most kRtCols float4 columns per thread (W * 512 * kRtCols * 4 floats per network).
+constexpr int kRtCols = 4;
+
+template <int WHICH, int H>
+__device__ __forceinline__ void rt_worker(KWsArgs* ka0, WsCtl* ctl, const int w, const int n_mb, const long long budget,
+                                          int* s_ok, double* s_red, double* s_norm, float* s_step) {
+    constexpr int which = WHICH;
+    typedef const UpdateDev __attribute__((address_space(4))) KU;
+    const long cursor0 = ka0->u.cursor[0];
+    const int W = ka0->ws.W;
+    unsigned epoch = 0;
+#ifdef PPOAF_WS_STAMPS
+    unsigned long long t_prev = 0;
+    if (which == PPOAF_WS_STAMP_NET && w == 0 && threadIdx.x == 0)
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#endif
+    for (int it = 0; it < n_mb; ++it) {
+        KWsArgs* ka = ka0;
+        asm volatile("" : "+s"(ka));
+        KU& u = ka->u;
+        int tid_l = threadIdx.x;
+        asm volatile("" : "+v"(tid_l));
+        __builtin_assume(tid_l >= 0 && tid_l < kThreadsU);
+        const int tid = tid_l, lane = tid & 63;
+        const int n_wg = u.n_wg;
+
+        // ---- phase 1: forward + backward of 16 rows -> this worker's slab, loss partials
+        if (w < n_wg) ppo_update_fwd_bwd_body<H / 16, true, KU>(u, which, w, it);
+        PPOAF_WSTAMP(0);
+        if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
+        PPOAF_WSTAMP(1);
+
+        // ---- phase 2: slabs -> gradient columns (slab order) in registers; bookkeeping; squared-norm partial
+        const auto& nd = u.net[which];
+        const long n4_all = u.bucket_total >> 2;
+        const long lo4 = nd.offset >> 2, hi4 = (nd.offset + nd.size) >> 2;
+        const float4* sl = reinterpret_cast<const float4*>(u.slabs);
+        float4 p[kRtCols], m[kRtCols], v[kRtCols], gr[kRtCols];
+        long idx[kRtCols];
+#pragma unroll
+        for (int c = 0; c < kRtCols; ++c) {
+            idx[c] = lo4 + ((long)c * W + w) * kThreadsU + tid;
+            const long ix = idx[c] < hi4 ? idx[c] : lo4;
+            p[c] = ld4<true>(u.params + 4 * ix);
+            m[c] = ld4<true>(u.exp_avg + 4 * ix);
+            v[c] = ld4<true>(u.exp_avg_sq + 4 * ix);
+        }
+        double sumsq = 0.0;
+        const float sc = u.grad_scale;
+#pragma unroll
+        for (int c = 0; c < kRtCols; ++c) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx[c] < hi4) {                                       // uniform per wave except at the range end
+                for (int g0 = 0; g0 < n_wg; g0 += 8) {
+                    float4 t[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        t[k] = ld4<true>(reinterpret_cast<const float*>(sl + (long)(g0 + k < n_wg ? g0 + k : 0) * n4_all + idx[c]));
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (g0 + k < n_wg) { acc.x += t[k].x; acc.y += t[k].y; acc.z += t[k].z; acc.w += t[k].w; }
+                }
+                sumsq += (double)(acc.x * sc) * (acc.x * sc) + (double)(acc.y * sc) * (acc.y * sc) +
+                         (double)(acc.z * sc) * (acc.z * sc) + (double)(acc.w * sc) * (acc.w * sc);
+            }
+            gr[c] = acc;
+        }
+        if (w == W - 1 && tid < 64) {
+            const long B = u.B;
+            float p0 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p7 = 0.f;
+            for (int gg = lane; gg < n_wg; gg += 64) {
+                const float* a = u.loss_partials + ((long)which * n_wg + gg) * 8;
+                p0 += ld1<true>(a); p2 += ld1<true>(a + 2); p3 += ld1<true>(a + 3); p4 += ld1<true>(a + 4); p7 += ld1<true>(a + 7);
+            }
+            p0 = wave_sum(p0); p2 = wave_sum(p2); p3 = wave_sum(p3); p4 = wave_sum(p4); p7 = wave_sum(p7);
+            if (lane == 0) {
+                const float n = (float)B;
+                if (which == 0) {
+                    const float surr = p0 / n, ent = p3 / n, kl = p4 / n;
+                    float total = surr;
+                    if (u.entropy_weight != 0.0f) total -= u.entropy_weight * ent;
+                    if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
+                    u.totals[0] += (double)surr; u.totals[1] += (double)total;
+                    u.totals[3] += (double)ent; u.totals[4] += (double)kl;
+                    u.totals[5] += (double)ld1<true>(u.loss_partials + 5); u.totals[6] += (double)ld1<true>(u.loss_partials + 6);
+                    u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
+                    u.totals[8] += 1.0;
+                } else {
+                    u.totals[2] += (double)(p2 / n);
+                }
+                const int64_t t = u.step_counts[which] + 1;
+                u.step_counts[which] = t;
+                u.norm_scratch[2 + 2 * which] = 1.0 - pow((double)u.beta1, (double)t);
+                u.norm_scratch[3 + 2 * which] = sqrt(1.0 - pow((double)u.beta2, (double)t));
+            }
+        }
+        {
+            const double q = block_sum(sumsq, s_red);
+            if (tid == 0) ctl->norm_partials[which][w] = q;
+        }
+        PPOAF_WSTAMP(2);
+        if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
+        PPOAF_WSTAMP(3);
+
+        // ---- phase 3: clip + Adam on the columns held in registers; norm = partials in worker order
+        if (tid < 64) {
+            const double part = lane < W ? ld1<true>(&ctl->norm_partials[which][lane]) : 0.0;
+            const double bc1 = ld1<true>(u.norm_scratch + 2 + 2 * which), bc2 = ld1<true>(u.norm_scratch + 3 + 2 * which);
+            double sq = 0.0;
+            for (int k = 0; k < W; ++k) sq += __shfl(part, k, 64);
+            if (lane == 0) {
+                s_norm[0] = sq;
+                s_step[0] = (float)((double)u.lr[0] / bc1);
+                s_step[1] = (float)bc2;
+            }
+        }
+        __syncthreads();
+        {
+            const float total_norm = (float)sqrt(s_norm[0]);
+            float coef = 1.0f;
+            if (u.max_norm > 0.f) coef = fminf(u.max_norm / (total_norm + 1e-6f), 1.0f);
+            const float gs = sc * coef;
+            const float step_size = s_step[0], bc2_sqrt = s_step[1];
+            const float beta1 = u.beta1, beta2 = u.beta2, adam_eps = u.adam_eps;
+#pragma unroll
+            for (int c = 0; c < kRtCols; ++c) {
+                if (idx[c] < hi4) {
+#define PPOAF_ADAM1(f)                                                               \
+                    {                                                                \
+                        const float gi = gr[c].f * gs;                               \
+                        m[c].f = beta1 * m[c].f + (1.0f - beta1) * gi;               \
+                        v[c].f = beta2 * v[c].f + (1.0f - beta2) * gi * gi;          \
+                        p[c].f = p[c].f - step_size * (m[c].f / (sqrtf(v[c].f) / bc2_sqrt + adam_eps)); \
+                    }
+                    PPOAF_ADAM1(x) PPOAF_ADAM1(y) PPOAF_ADAM1(z) PPOAF_ADAM1(w)
+#undef PPOAF_ADAM1
+                    reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx[c]] = p[c];
+                    reinterpret_cast<float4*>(u.exp_avg)[idx[c]] = m[c];
+                    reinterpret_cast<float4*>(u.exp_avg_sq)[idx[c]] = v[c];
+                    reinterpret_cast<float4*>(u.grads)[idx[c]] = gr[c];
+                }
+            }
+        }
+        PPOAF_WSTAMP(4);
+        if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
+        PPOAF_WSTAMP(5);
+    }
+    if (w == 0 && threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == 1u) ka0->u.cursor[0] = cursor0 + n_mb;
+    }
+}
+
+template <int HA, int HC, bool LAYERED_A, bool LAYERED_C>
+__global__ __launch_bounds__(kThreadsU) void ppo_update_ws_kernel(WsArgs a, WsCtl* ctl, int n_mb, long long budget) {
+    __shared__ int s_ticket, s_ok;
+    __shared__ double s_red[17];
+    __shared__ double s_norm[2];
+    __shared__ float s_step[4];
+    KWsArgs* ka = (KWsArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // `a` is the first kernel argument
+    const int xcc = (int)hw_xcc_id();
+    const int which = xcc == a.ws.xcc[0] ? 0 : (xcc == a.ws.xcc[1] ? 1 : -1);
+    if (which < 0) return;                                    // uniform per workgroup
+    if (threadIdx.x == 0) s_ticket = (int)atomicAdd(&ctl->tickets[which], 1u);
+    __syncthreads();
+    const int w = __builtin_amdgcn_readfirstlane(s_ticket);
+    if (w >= a.ws.W) return;
+    if (which == 0) {
+        if (LAYERED_A) ws_worker<0, HA>(ka, ctl, w, n_mb, budget, &s_ok, s_red, s_norm, s_step);
+        else rt_worker<0, HA>(ka, ctl, w, n_mb, budget, &s_ok, s_red, s_norm, s_step);
+    } else {
+        if (LAYERED_C) ws_worker<1, HC>(ka, ctl, w, n_mb, budget, &s_ok, s_red, s_norm, s_step);
+        else rt_worker<1, HC>(ka, ctl, w, n_mb, budget, &s_ok, s_red, s_norm, s_step);
+    }
+}
+
+static size_t ws_lds_floats(const NetDev& n, long B) {
+    const size_t H = n.H, in_pad = (n.in_dim + 15) & ~15, Bk = (B + 15) & ~15L;
+    const size_t K = in_pad > H ? in_pad : H;
+    size_t p = 96 * (K + 4);                                             // forward: A [64][K+4] + W [32][K+4]
+    const size_t dg = 64 * (H + 4) + H * kWsPS, wg = 2 * Bk * kWsPS, hd = 16 * (H + 4) + 8 * H + 16;
+    if (dg > p) p = dg;
+    if (wg > p) p = wg;
+    if (hd > p) p = hd;
+    return 1024 + 16 + 48 + 128 + 256 + 256 + 1536 + p;
+}
+
+static long ws_seg_len(const NetDev& n) {
+    const long szW0 = ((long)n.H * n.in_dim + 3) & ~3L;
+    const long seg_off = n.depth == 0 ? 0 : szW0 + n.H + (long)(n.depth - 1) * ((long)n.H * n.H + n.H);
+    return n.size - seg_off;
+}
+
+// workspace layout: per network hbuf, dbuf ([depth][Bp][H] each) and outpart ([ceil(B/16)][seg]); 256-byte aligned pieces
+static size_t ws_layout(const UpdateDev& u, WsDev* ws, char* base) {
+    const long Bp = (u.B + 63) & ~63L;
+    size_t off = 0;
+    auto take = [&](size_t floats) { const size_t o = off; off += (floats * 4 + 255) & ~(size_t)255; return o; };
+    for (int w = 0; w < 2; ++w) {
+        const NetDev& n = u.net[w];
+        const size_t plane = (size_t)n.depth * Bp * n.H;
+        const size_t oh = take(plane), od = take(plane), oo = take((size_t)((u.B + 15) / 16) * ws_seg_len(n));
+        if (ws) {
+            ws->hbuf[w] = reinterpret_cast<float*>(base + oh);
+            ws->dbuf[w] = reinterpret_cast<float*>(base + od);
+            ws->outpart[w] = reinterpret_cast<float*>(base + oo);
+        }
+    }
+    if (ws) ws->Bp = (int)Bp;
+    return off;
+}
+
+// which decomposition each network's worker group runs: bit 0 actor, bit 1 critic set = layered (weight-stationary
+// tiles), clear = row-tiled (fwd_bwd body + in-register slab fold); mask < 0: automatic -- layered for 256-wide
+// networks (a 16-row workgroup is then at its MFMA floor), row-tiled below.
+static int ws_resolve_mask(const UpdateDev& u, int mask) {
+    if (mask >= 0) return mask & 3;
+    return (u.net[0].H >= 256 ? 1 : 0) | (u.net[1].H >= 256 ? 2 : 0);
+}
+
+static int ws_check_shapes(const UpdateDev& u, int mask, int workers) {
+    mask = ws_resolve_mask(u, mask);
+    for (int w = 0; w < 2; ++w) {
+        const NetDev& n = u.net[w];
+        PPOAF_REQUIRE(n.depth >= 1 && (n.H == 32 || n.H == 64 || n.H == 128 || n.H == 256),
+                      "ppo_update_ws: hidden width %d / depth %d not supported (32, 64, 128 or 256; depth >= 1)", n.H, n.depth);
+        PPOAF_REQUIRE(n.out_dim >= 1 && n.out_dim <= 8, "ppo_update_ws: out_dim=%d", n.out_dim);
+        if (mask & (1 << w)) {
+            PPOAF_REQUIRE(n.in_dim >= 1 && n.in_dim <= 64, "ppo_update_ws: in_dim=%d (1..64 in the layered mode)", n.in_dim);
+            PPOAF_REQUIRE(ws_lds_floats(n, u.B) * 4 <= 156 * 1024, "ppo_update_ws: needs %zu B of LDS", ws_lds_floats(n, u.B) * 4);
+        } else {
+            PPOAF_REQUIRE(u.n_wg <= workers, "ppo_update_ws: batch size %ld needs %d row-tile workers, %d given", u.B, u.n_wg, workers);
+            PPOAF_REQUIRE(n.size <= (long)workers * kThreadsU * kRtCols * 4,
+                          "ppo_update_ws: network of %ld floats exceeds the in-register fold of %d workers", n.size, workers);
+            PPOAF_REQUIRE(rowtile_lds_floats(n) * 4 <= 156 * 1024, "ppo_update_ws: needs %zu B of LDS", rowtile_lds_floats(n) * 4);
+        }
+    }
+    const int ha = u.net[0].H, hc = u.net[1].H;
+    PPOAF_REQUIRE((ha == hc && (ha == 32 || ha == 64 || ha == 128 || ha == 256)) || (ha == 128 && hc == 256) || (ha == 64 && hc == 128),
+                  "ppo_update_ws: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
+    const bool same = mask == 0 || mask == 3;
+    PPOAF_REQUIRE(same || (ha == 128 && hc == 256 && mask == 2),
+                  "ppo_update_ws: mode mask %d not instantiated for widths (%d, %d)", mask, ha, hc);
+    PPOAF_REQUIRE(u.B >= 16 && u.B <= 512, "ppo_update_ws: batch size %ld not supported (16..512)", u.B);
+    PPOAF_REQUIRE(u.n_rows < (1L << 31), "ppo_update_ws: %ld rows", u.n_rows);
+    return PPOAF_OK;
+}
+
+template <int HA, int HC, bool LA, bool LC>
+static int ws_launch(const WsArgs& a, WsCtl* ctl, int n_mb, long long budget, size_t lds, hipStream_t s, hipEvent_t e0,
+                     hipEvent_t e1) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_update_ws_kernel<HA, HC, LA, LC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+        attr_set = true;
+    }
+    // one workgroup per CU of the whole device: those on the two target XCDs that draw a worker ticket stay
+    if (e0 || e1)        // the kernel's own begin / end stamped into the events (bench.py: roofline_update)
+        hipExtLaunchKernelGGL((ppo_update_ws_kernel<HA, HC, LA, LC>), dim3(256), dim3(kThreadsU), lds, s, e0, e1, 0, a, ctl, n_mb, budget);
+    else
+        hipLaunchKernelGGL((ppo_update_ws_kernel<HA, HC, LA, LC>), dim3(256), dim3(kThreadsU), lds, s, a, ctl, n_mb, budget);
+    return check_launch("ppo_update_ws");
+}
+
+}  // namespace ppoaf
+
+using namespace ppoaf;
+
+extern "C" int ppoaf_ppo_update_ws_ctl_bytes(void) { return (int)sizeof(WsCtl); }
+
+extern "C" int ppoaf_ppo_update_ws_workspace_bytes(const ppoaf_ppo_update_args_t* args, int32_t layered_mask, int64_t* bytes_out) {
+    UpdateDev u;
+    int rc = make_update_dev(args, u);
+    if (rc) return rc;
+    rc = ws_check_shapes(u, layered_mask, kWsMaxWorkers);
+    if (rc) return rc;
+    PPOAF_REQUIRE(bytes_out, "ppo_update_ws_workspace_bytes: null output");
+    *bytes_out = (int64_t)ws_layout(u, nullptr, nullptr);
+    return PPOAF_OK;
+}
+
+extern "C" int ppoaf_ppo_update_ws(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl, void* workspace,
+                                   int64_t workspace_bytes, int32_t workers, int32_t xcc_actor, int32_t xcc_critic,
+                                   int32_t layered_mask, double wait_seconds, void* start_event, void* stop_event,
+                                   ppoaf_stream_t stream) {
+    hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;
+    UpdateDev u;
+    int rc = make_update_dev(args, u);
+    if (rc) return rc;
+    PPOAF_REQUIRE(workers >= 1 && workers <= kWsMaxWorkers, "ppo_update_ws: workers=%d (1..%d: one XCD holds 32 CUs)", workers, kWsMaxWorkers);
+    rc = ws_check_shapes(u, layered_mask, workers);
+    if (rc) return rc;
+    const int mask = ws_resolve_mask(u, layered_mask);
+    PPOAF_REQUIRE(ctl && (((uintptr_t)ctl) & 15) == 0, "ppo_update_ws: control block missing or misaligned");
+    PPOAF_REQUIRE(workspace && (((uintptr_t)workspace) & 255) == 0, "ppo_update_ws: workspace missing or not 256-byte aligned");
+    PPOAF_REQUIRE(n_minibatches >= 1 && n_minibatches <= (1 << 20), "ppo_update_ws: n_minibatches=%ld", (long)n_minibatches);
+    PPOAF_REQUIRE(xcc_actor >= 0 && xcc_actor < 8 && xcc_critic >= 0 && xcc_critic < 8 && xcc_actor != xcc_critic,
+                  "ppo_update_ws: XCDs %d / %d (two different ones of 0..7)", xcc_actor, xcc_critic);
+    PPOAF_REQUIRE(wait_seconds > 0.0 && wait_seconds <= 600.0, "ppo_update_ws: wait_seconds=%g", wait_seconds);
+    PPOAF_REQUIRE(u.mb_offset == 0, "ppo_update_ws: mb_offset must be 0 (the launch walks the cursor itself)");
+    WsDev ws;
+    const size_t need = ws_layout(u, &ws, reinterpret_cast<char*>(workspace));
+    PPOAF_REQUIRE((size_t)workspace_bytes >= need, "ppo_update_ws: workspace of %ld B, %zu needed", (long)workspace_bytes, need);
+    ws.W = workers; ws.xcc[0] = xcc_actor; ws.xcc[1] = xcc_critic;
+    size_t lds = 0;
+    for (int w = 0; w < 2; ++w) {
+        const size_t f = (mask & (1 << w)) ? ws_lds_floats(u.net[w], u.B) : rowtile_lds_floats(u.net[w]);
+        if (f > lds) lds = f;
+    }
+    lds = (lds * 4 + 15) / 16 * 16;
+    if (lds < 96 * 1024) lds = 96 * 1024;      // one workgroup per CU: the 256 launched workgroups then cover every CU
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ctl, 0, sizeof(WsCtl), s);            // tickets, error word, barrier epochs
+    if (e != hipSuccess) { set_error("ppo_update_ws: memset: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+    const long long budget = (long long)(wait_seconds * 1.0e8);          // wall_clock64 ticks at 100 MHz
+    WsArgs a;
+    a.u = u; a.ws = ws;
+    WsCtl* c = reinterpret_cast<WsCtl*>(ctl);
+    const int ha = u.net[0].H, hc = u.net[1].H, n = (int)n_minibatches;
+#define PPOAF_WS_PAIR(A, C)                                                                     \
+    if (ha == A && hc == C) {                                                                   \
+        if (mask == 3) return ws_launch<A, C, true, true>(a, c, n, budget, lds, s, e0, e1);     \
+        if (mask == 0) return ws_launch<A, C, false, false>(a, c, n, budget, lds, s, e0, e1);   \
+    }
+    PPOAF_WS_PAIR(32, 32) PPOAF_WS_PAIR(64, 64) PPOAF_WS_PAIR(128, 128) PPOAF_WS_PAIR(256, 256)
+    PPOAF_WS_PAIR(128, 256) PPOAF_WS_PAIR(64, 128)
+#undef PPOAF_WS_PAIR
+    if (ha == 128 && hc == 256 && mask == 2) return ws_launch<128, 256, false, true>(a, c, n, budget, lds, s, e0, e1);
+    set_error("ppo_update_ws: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
+    return PPOAF_E_INVALID;
+}

@@ -372,6 +372,13 @@ class FusedPolicyUpdate:
 
     def _check_persistent(self):
         """After a host synchronisation: did a wait inside a persistent launch run out of time?"""
+        ctl = getattr(self, "_ws_ctl", None)
+        if ctl is not None and getattr(self, "_ws_used", False):
+            self._ws_used = False
+            if int(ctl[2].item()) != 0:
+                raise _lib.PpoafError(
+                    "ppo_update_ws: a barrier wait ran out of time -- a network did not get all of its workgroups onto its "
+                    "XCD (another process on this GPU?).  Set PPOAF_WS=0 to use the three-launch chain.")
         ctl = getattr(self, "_persist_ctl", None)
         if ctl is not None and getattr(self, "_persist_used", False):
             self._persist_used = False
@@ -380,9 +387,65 @@ class FusedPolicyUpdate:
                     "ppo_update_persistent: a barrier wait ran out of time -- the launch did not get all of its workgroups "
                     "onto one XCD (another process on this GPU?).  Unset PPOAF_PERSISTENT to use the three-launch chain.")
 
+    # ---- weight-stationary persistent form (csrc/ppo_update_ws.hip: ppo_update_ws_kernel)
+    ws_chunk = 4096                    # mini-batches per launch
+    ws_launch_count = 0                # launches of the kernel in this process (tests: the path really ran)
+
+    def ws_reason(self):
+        """'' when the epoch's full mini-batches can run through the weight-stationary persistent kernel, else why not."""
+        import os
+        if type(self) is not FusedPolicyUpdate:
+            return "K12 (MLP policies) only"
+        if os.environ.get("PPOAF_WS", "1") == "0":
+            return "off (PPOAF_WS=0)"
+        if not getattr(self, "ws_allowed", True):
+            return "the epoch shares the GPU with the ICM update on a second stream (a persistent kernel would starve it)"
+        if self.multi:
+            return "N > 1: the gradient exchange sits between the gradient and the Adam phase (three-launch chain)"
+        mask = self._ws_mask()
+        cached = getattr(self, "_ws_shape_reason", None)
+        if cached is None or cached[0] != (self.B, mask):
+            need = C.c_int64(0)
+            rc = self._lib.ppoaf_ppo_update_ws_workspace_bytes(C.byref(self._args_for(self.B)), mask, C.byref(need))
+            cached = self._ws_shape_reason = ((self.B, mask), "" if rc == 0 else self._lib.ppoaf_last_error().decode("utf-8", "replace"), int(need.value))
+        return cached[1]
+
+    @staticmethod
+    def _ws_mask():
+        """PPOAF_WS_MODE: auto (layered for 256-wide networks, row-tiled below), layered, rowtile, or a bit mask."""
+        import os
+        m = os.environ.get("PPOAF_WS_MODE", "auto")
+        return {"auto": -1, "layered": 3, "rowtile": 0}.get(m, None) if not m.lstrip("-").isdigit() else int(m)
+
+    def _ws_buffers(self):
+        need = self._ws_shape_reason[2]
+        ctl = getattr(self, "_ws_ctl", None)
+        if ctl is None:
+            n = int(self._lib.ppoaf_ppo_update_ws_ctl_bytes())
+            ctl = self._ws_ctl = torch.zeros((n + 3) // 4, dtype=torch.int32, device=self.pol.device)
+        wsb = getattr(self, "_ws_space", None)
+        if wsb is None or wsb.numel() < need:
+            wsb = self._ws_space = torch.zeros(need, dtype=torch.uint8, device=self.pol.device)
+        return ctl, wsb
+
     def run_epoch(self):
         args = self._args_for(self.B)
         left = self.n_full
+        if left > 0 and self.ws_reason() == "":
+            import os
+            ctl, wsb = self._ws_buffers()
+            workers = int(os.environ.get("PPOAF_WS_WORKERS", "32"))
+            xa, xc = int(os.environ.get("PPOAF_WS_XCC_ACTOR", "0")) % 8, int(os.environ.get("PPOAF_WS_XCC_CRITIC", "1")) % 8
+            st = K.stream()
+            while left > 0:
+                n = min(left, self.ws_chunk)
+                ev = self.ws_timing_events.pop() if getattr(self, "ws_timing_events", None) else (None, None)
+                _lib.check(self._lib.ppoaf_ppo_update_ws(C.byref(args), n, ctl.data_ptr(), wsb.data_ptr(), wsb.numel(), workers,
+                                                         xa, xc, self._ws_mask(), 2.0, ev[0], ev[1], st), "ppo_update_ws")
+                self._ws_used = True
+                FusedPolicyUpdate.ws_launch_count += 1
+                left -= n
+                self.n_done += n
         if left > 0 and self.persistent_reason() == "":
             import os
             ctl = self._persistent_ctl()

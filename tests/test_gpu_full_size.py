@@ -66,8 +66,11 @@ def test_c3_filters_counts_and_moments_at_full_size():
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
 
 
-def test_c3_icm_update_makes_progress_and_overlap_is_exact():
-    """K14 + K12 at C3 size: the ICM loss falls over an epoch; two-stream overlap == sequential, bitwise."""
+def test_c3_icm_update_makes_progress_and_overlap_is_exact(monkeypatch):
+    """K14 + K12 at C3 size: the ICM loss falls over an epoch; two-stream overlap == sequential, bitwise (both on the
+    three-launch chain: the sequential order would otherwise take the two-XCD persistent kernel, whose sums associate
+    differently)."""
+    monkeypatch.setenv("PPOAF_WS", "0")
     outs = []
     for overlap in (True, False):
         ppo, E, T, A = _c_config("C3")

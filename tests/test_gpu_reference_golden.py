@@ -426,6 +426,23 @@ def test_persistent_single_xcd_chain_reproduces_the_reference(golden, name, monk
     assert fused_update.FusedPolicyUpdate.persistent_reason.__doc__
 
 
+@pytest.mark.parametrize("mode", ["auto", "layered", "rowtile"])
+@pytest.mark.parametrize("name", ["g12_c2_term", "g12_c2_cut", "g12_c3_gauss", "g12_c3_full", "g12_c4_mappo", "g12_gauss_bounds"])
+def test_weight_stationary_persistent_update_reproduces_the_reference(golden, name, mode, monkeypatch):
+    """
+    The weight-stationary persistent form of K12 (csrc/ppo_update_ws.hip: one launch per epoch, the mini-batch processed
+    layer by layer over all of its rows on two single-XCD worker groups, complete weight gradients, clip + Adam by the
+    column owners) against the same reference-recorded iterations: first-mini-batch losses and gradient bucket,
+    every epoch's statistics, final weights.
+    """
+    from ppo_and_friends_amd import fused_update
+    monkeypatch.setenv("PPOAF_WS", "1")
+    monkeypatch.setenv("PPOAF_WS_MODE", mode)
+    before = fused_update.FusedPolicyUpdate.ws_launch_count
+    test_product_reproduces_the_reference_ppo_iterations(golden, name, "fused")
+    assert fused_update.FusedPolicyUpdate.ws_launch_count > before, "the weight-stationary kernel did not run"
+
+
 # ---------------------------------------------------------------- unit fixtures g9 / g10 / g13 through the HIP kernels
 def test_value_normalizer_kernels_match_reference_golden_g9(golden):
     """RunningStatNormalizer of the unmodified reference (utils/misc.py:61-128): update + normalise, denormalise,
