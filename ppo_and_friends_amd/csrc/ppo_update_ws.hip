@@ -346,14 +346,53 @@ __device__ __forceinline__ double ws_wgrad_tile(const float* __restrict__ Dp, co
 struct WsArgs { UpdateDev u; WsDev ws; };
 typedef const WsArgs __attribute__((address_space(4))) KWsArgs;
 
-// One worker of network WHICH (hidden width H) for the whole launch.  Everything the body derives from the kernel
-// arguments or the lane id is re-derived per mini-batch from laundered copies (see ppo_update.hip, persistent form):
-// hoisted out of the mini-batch loop it would all be live at once and spill.
+// dgrad tile product with the weight matrix held ROW-major in LDS (rows = k, row stride PSTR): the tail phase reads the
+// same [H][H + 4] copy of W forwards (row_row) and backwards (this)
+template <int NCK, int PSTR>
+__device__ __forceinline__ f32x4 ws_mfma_row_colT_c(const float* __restrict__ A, const int stride, const float* __restrict__ Bc,
+                                                    const int lane) {
+    const float* a = A + (lane & 15) * stride + 4 * (lane >> 4);
+    const float* b = Bc + (4 * (lane >> 4)) * PSTR + (lane & 15);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) {
+        const float4 av = *reinterpret_cast<const float4*>(a + 16 * c);
+        const float* bp = b + (16 * c) * PSTR;
+        const float b0 = bp[0], b1 = bp[PSTR], b2 = bp[2 * PSTR], b3 = bp[3 * PSTR];
+        if (c & 1) {
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b2, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b3, acc1, 0, 0, 0);
+        } else {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b2, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b3, acc0, 0, 0, 0);
+        }
+    }
+    return acc0 + acc1;
+}
+
+// One worker of network WHICH (hidden width H) for the whole launch, layered mode.  Everything the body derives from
+// the kernel arguments or the lane id is re-derived per mini-batch from laundered copies (see ppo_update.hip,
+// persistent form): hoisted out of the mini-batch loop it would all be live at once and spill.
+//
+// Phase schedule of one mini-batch (d = depth; a barrier after each line):
+//   generic (H = 256):      F(0) | F(1) | .. | F(d-1) | HEAD | {DG(l), WG(l)} for l = d-1 .. 1 (OUT with the first) |
+//                           {WG(0), bookkeeping} | ADAM
+//   H <= 128 and d >= 2:    the last hidden layer's weights fit in LDS next to a 16-row block, so F(d-1), HEAD and
+//                           DG(d-1) run row-locally in ONE phase ("tail"): F(0) | .. | F(d-2) | TAIL |
+//                           {DG(m), WG(m+1)} for m = d-2 .. 1 | {WG(1), WG(0), OUT, bookkeeping} | ADAM
+//   in_dim <= 16, d >= 3 (or generic d >= 2): F(0) is computed on the fly inside the F(1) jobs (K = 16: four MFMAs
+//                           per tile); the jobs of column tile 0 also publish h_0 for the backward pass
+// DG(l): D_{l-1} = (D_l . W_l) * act'(h_{l-1});  WG(l): dW_l = D_l^T h_{l-1}, db_l;  OUT: output-layer partials -> gradient.
 template <int WHICH, int H>
 __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w, const int n_mb, const long long budget,
                                           int* s_ok, double* s_red, double* s_norm, float* s_step) {
     constexpr int which = WHICH;
     constexpr int HS = H + 4, NCH = H / 16, nct = H / 32;
+    constexpr bool kTail = H <= 128;
     // ---- LDS carve
     float* smem = reinterpret_cast<float*>(ppo_update_ws_smem);
     int* sRow = reinterpret_cast<int*>(smem);                 // [512] dataset row of every mini-batch row (-1: dead)
@@ -391,6 +430,8 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
         const long B = u.B;
         const int Bp = ws.Bp, Bk = ((int)B + 15) & ~15;
         const int n_rt = Bp >> 6, n_hb = ((int)B + 15) >> 4;
+        const bool tail = kTail && depth >= 2;
+        const bool fuse0 = in_pad == 16 && depth >= (tail ? 3 : 2);
         const long szW0 = ((long)H * in_dim + 3) & ~3L;
         auto offW = [&](int l) -> long { return l == 0 ? 0 : szW0 + H + (long)(l - 1) * ((long)H * H + H); };
         auto offB = [&](int l) -> long {
@@ -423,368 +464,488 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
         }
         __syncthreads();
 
-        // ---- forward layer 0: h_0[64 rows][32 columns] tiles, K = in_pad (<= 64): 16 threads per row, no divisions
-        {
+        // ================================================================ job bodies
+        // forward layer 0 alone: h_0[64 rows][32 columns] tile, K = in_pad (<= 64): 16 threads per row, no divisions
+        auto f0_job = [&](const int j) {
             const int AS = in_pad + 4, nck = in_pad >> 4;
             float* sA = sP;
             float* sW = sP + 64 * AS;
-            const float* W0 = P;
-            const float* b0 = P + offB(0);
-            for (int j = w; j < n_rt * nct; j += W) {
-                const int rt = j / nct, ct = j % nct;
-                const int o = ct * 32 + 16 * (wave >> 2) + (lane & 15);
-                const float bias = ld1<true>(b0 + o);
-                const int r16 = tid >> 4, kq = tid & 15;
-                float xa[8], wv[4];
+            const int rt = j / nct, ct = j % nct;
+            const int o = ct * 32 + 16 * (wave >> 2) + (lane & 15);
+            const float bias = ld1<true>(P + offB(0) + o);
+            const int r16 = tid >> 4, kq = tid & 15;
+            float xa[8], wv[4];
 #pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int di = sDi[rt * 64 + r16 + 32 * ps];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int k = kq + 16 * i;
-                        const bool ok = di >= 0 && k < in_dim;
-                        const float v = xsrc[(long)(di >= 0 ? di : 0) * in_dim + (k < in_dim ? k : 0)];
-                        xa[ps * 4 + i] = ok ? v : 0.f;
-                    }
-                }
+            for (int ps = 0; ps < 2; ++ps) {
+                const int di = sDi[rt * 64 + r16 + 32 * ps];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int k = kq + 16 * i;
-                    const float v = ld1<true>(W0 + (long)(ct * 32 + r16) * in_dim + (k < in_dim ? k : 0));
-                    wv[i] = k < in_dim ? v : 0.f;
+                    const bool ok = di >= 0 && k < in_dim;
+                    const float v = xsrc[(long)(di >= 0 ? di : 0) * in_dim + (k < in_dim ? k : 0)];
+                    xa[ps * 4 + i] = ok ? v : 0.f;
                 }
+            }
 #pragma unroll
-                for (int ps = 0; ps < 2; ++ps)
+            for (int i = 0; i < 4; ++i) {
+                const int k = kq + 16 * i;
+                const float v = ld1<true>(P + (long)(ct * 32 + r16) * in_dim + (k < in_dim ? k : 0));
+                wv[i] = k < in_dim ? v : 0.f;
+            }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (i < nck) sA[(r16 + 32 * ps) * AS + kq + 16 * i] = xa[ps * 4 + i];
+            for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (i < nck) sW[r16 * AS + kq + 16 * i] = wv[i];
-                __syncthreads();
-                const f32x4 acc = ws_mfma_row_row(sA + 16 * (wave & 3) * AS, sW + 16 * (wave >> 2) * AS, AS, 0, nck, lane, bias);
+                    if (i < nck) sA[(r16 + 32 * ps) * AS + kq + 16 * i] = xa[ps * 4 + i];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int s = rt * 64 + 16 * (wave & 3) + 4 * (lane >> 4) + r;
-                    if (s < B) hbuf[(long)s * H + o] = act_fwd(acc[r], act);
-                }
-                __syncthreads();
+            for (int i = 0; i < 4; ++i)
+                if (i < nck) sW[r16 * AS + kq + 16 * i] = wv[i];
+            __syncthreads();
+            const f32x4 acc = ws_mfma_row_row(sA + 16 * (wave & 3) * AS, sW + 16 * (wave >> 2) * AS, AS, 0, nck, lane, bias);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = rt * 64 + 16 * (wave & 3) + 4 * (lane >> 4) + r;
+                if (s < B) hbuf[(long)s * H + o] = act_fwd(acc[r], act);
             }
-            PPOAF_WSTAMP(0);
-            if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
-            PPOAF_WSTAMP(1);
-        }
+            __syncthreads();
+        };
 
-        // ---- forward, hidden layers: h_l[64 rows][32 columns] tiles
-        for (int l = 1; l < depth; ++l) {
-            float* sA = sP;
-            float* sW = sP + 64 * HS;
+        // forward hidden layer l: h_l[64 rows][32 columns] tile; with x0 (in_dim <= 16) h_0 of the 64 rows is computed
+        // here from the inputs instead of read back (and published by the jobs of column tile 0)
+        auto f_job = [&](const int l, const int j, const bool x0) {
+            float* sA = sP;                                   // [64][HS]
+            float* sW = sP + 64 * HS;                         // [32][HS]
+            float* sX0 = sW + 32 * HS;                        // [64][20]   x0 only
+            float* sW0 = sX0 + 64 * 20;                       // [H][20]
+            float* sB0 = sW0 + H * 20;                        // [H]
             const float* Wl = P + offW(l);
-            const float* bl = P + offB(l);
             float* hout = hbuf + (long)l * plane;
-            for (int j = w; j < n_rt * nct; j += W) {
-                const int rt = j / nct, ct = j % nct;
-                const int o = ct * 32 + 16 * (wave >> 2) + (lane & 15);
-                const float bias = ld1<true>(bl + o);
+            const int rt = j / nct, ct = j % nct;
+            const int o = ct * 32 + 16 * (wave >> 2) + (lane & 15);
+            const float bias = ld1<true>(P + offB(l) + o);
+            WsPanel<H, 32> rw;
+            ws_panel_issue(rw, Wl, H, ct * 32, 32, H, 0, tid);
+            if (!x0) {
                 WsPanel<H, 64> ra;
-                WsPanel<H, 32> rw;
                 ws_panel_issue(ra, hbuf + (long)(l - 1) * plane, H, rt * 64, 64, (int)B, 0, tid);
-                ws_panel_issue(rw, Wl, H, ct * 32, 32, H, 0, tid);
                 ws_panel_commit(ra, sA, HS, 64, tid);
-                ws_panel_commit(rw, sW, HS, 32, tid);
-                __syncthreads();
-                const f32x4 acc = ws_mfma_row_row_c<NCH>(sA + 16 * (wave & 3) * HS, sW + 16 * (wave >> 2) * HS, HS, lane, bias);
+            } else {
+                // x rows [64][16] (2 values per thread), W_0 [H][16], b_0 [H]
+                const int r8 = tid >> 3, k2 = (tid & 7) * 2;
+                const int di = sDi[rt * 64 + r8];
+                const float* xp = xsrc + (long)(di >= 0 ? di : 0) * in_dim;
+                const float x_a = xp[k2 < in_dim ? k2 : 0], x_b = xp[k2 + 1 < in_dim ? k2 + 1 : 0];
+                float w0v[H * 16 / kThreadsU];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int s = rt * 64 + 16 * (wave & 3) + 4 * (lane >> 4) + r;
-                    if (s < B) hout[(long)s * H + o] = act_fwd(acc[r], act);
+                for (int i = 0; i < H * 16 / kThreadsU; ++i) {
+                    const int e = tid + i * kThreadsU, r = e >> 4, k = e & 15;
+                    w0v[i] = ld1<true>(P + (long)r * in_dim + (k < in_dim ? k : 0));
                 }
+                const float b0v = tid < H ? ld1<true>(P + offB(0) + tid) : 0.f;
+                sX0[r8 * 20 + k2] = (di >= 0 && k2 < in_dim) ? x_a : 0.f;
+                sX0[r8 * 20 + k2 + 1] = (di >= 0 && k2 + 1 < in_dim) ? x_b : 0.f;
+#pragma unroll
+                for (int i = 0; i < H * 16 / kThreadsU; ++i) {
+                    const int e = tid + i * kThreadsU, r = e >> 4, k = e & 15;
+                    sW0[r * 20 + k] = k < in_dim ? w0v[i] : 0.f;
+                }
+                if (tid < H) sB0[tid] = b0v;
                 __syncthreads();
+                for (int t = wave; t < 4 * NCH; t += kNW) {           // 4 row tiles x NCH column tiles of h_0
+                    const int rt4 = t & 3, c16 = t >> 2;
+                    const int oc = 16 * c16 + (lane & 15);
+                    const f32x4 a0 = ws_mfma_row_row(sX0 + 16 * rt4 * 20, sW0 + 16 * c16 * 20, 20, 0, 1, lane, sB0[oc]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int sl = 16 * rt4 + 4 * (lane >> 4) + r, s = rt * 64 + sl;
+                        const float hv = act_fwd(a0[r], act);
+                        sA[sl * HS + oc] = hv;
+                        if (ct == 0 && s < B) hbuf[(long)s * H + oc] = hv;
+                    }
+                }
             }
-            PPOAF_WSTAMP(0);
-            if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
-            PPOAF_WSTAMP(1);
-        }
+            ws_panel_commit(rw, sW, HS, 32, tid);
+            __syncthreads();
+            const f32x4 acc = ws_mfma_row_row_c<NCH>(sA + 16 * (wave & 3) * HS, sW + 16 * (wave >> 2) * HS, HS, lane, bias);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = rt * 64 + 16 * (wave & 3) + 4 * (lane >> 4) + r;
+                if (s < B) hout[(long)s * H + o] = act_fwd(acc[r], act);
+            }
+            __syncthreads();
+        };
 
-        // ---- HEAD: output layer, distribution head + losses, D_{depth-1}, output-layer gradient partials
-        {
-            float* sH = sP;                                   // [16][HS]
+        // HEAD on one 16-row block.  with_tail: the block's h_{d-1} is first computed from h_{d-2} with W_{d-1} held in
+        // LDS, and D_{d-2} is produced from D_{d-1} with the same copy afterwards.
+        auto head_job = [&](const int g, const bool with_tail) {
+            float* sH = sP;                                   // [16][HS]  h_{d-1}
             float* sWout = sH + 16 * HS;                      // [8][H]
             float* sBout = sWout + 8 * H;                     // [16]
+            float* sHp = sBout + 16;                          // [16][HS]  h_{d-2}            (tail)
+            float* sDl = sHp + 16 * HS;                       // [16][HS]  D_{d-1}            (tail)
+            float* sBl = sDl + 16 * HS;                       // [H]       b_{d-1}            (tail)
+            float* sWl = sBl + H;                             // [H][HS]   W_{d-1}            (tail)
             const float* hlast = hbuf + (long)(depth - 1) * plane;
             float* dlast = dbuf + (long)(depth - 1) * plane;
-            for (int g = w; g < n_hb; g += W) {
-                WsPanel<H, 16> rh;
+            WsPanel<H, 16> rh;
+            WsPanel<H, kTail ? H : 16> rwl;
+            float bl = 0.f;
+            if (with_tail) {
+                ws_panel_issue(rh, hbuf + (long)(depth - 2) * plane, H, g * 16, 16, (int)B, 0, tid);
+                ws_panel_issue(rwl, P + offW(depth - 1), H, 0, H, H, 0, tid);
+                if (tid < H) bl = ld1<true>(P + offB(depth - 1) + tid);
+            } else {
                 ws_panel_issue(rh, hlast, H, g * 16, 16, (int)B, 0, tid);
-                float wo[(8 * H + kThreadsU - 1) / kThreadsU];
+            }
+            float wo[(8 * H + kThreadsU - 1) / kThreadsU];
 #pragma unroll
-                for (int i = 0; i < (8 * H + kThreadsU - 1) / kThreadsU; ++i) {
-                    const int e = tid + i * kThreadsU;
-                    wo[i] = ld1<true>(P + offW(depth) + (e < out_dim * H ? e : 0));
-                }
-                float bo = 0.f;
-                if (tid < out_dim) bo = ld1<true>(P + offB(depth) + tid);
-                if (tid < kRows) {
-                    const int s = g * kRows + tid;
-                    const int di = sDi[s];
-                    float av = 0.f, lpo = 0.f, rt = 0.f;
-                    if (di >= 0) {
-                        if (which == 0) {
-                            av = u.adv[di]; lpo = u.old_lp[di];
-                            if (u.head_kind == PPOAF_HEAD_CATEGORICAL)
-                                reinterpret_cast<int*>(sActF)[tid * 8] = (int)reinterpret_cast<const int64_t*>(u.raw_actions)[di];
-                            else
-                                for (int d = 0; d < out_dim; ++d)
-                                    sActF[tid * 8 + d] = reinterpret_cast<const float*>(u.raw_actions)[(long)di * out_dim + d];
-                        } else {
-                            rt = u.rtg[di];
-                        }
-                    }
-                    sRowF[tid] = av; sRowF[16 + tid] = lpo; sRowF[32 + tid] = rt;
-                }
-                if (tid == 64) {                              // mini-batch statistics (as the row-tiled kernel's S0)
+            for (int i = 0; i < (8 * H + kThreadsU - 1) / kThreadsU; ++i) {
+                const int e = tid + i * kThreadsU;
+                wo[i] = ld1<true>(P + offW(depth) + (e < out_dim * H ? e : 0));
+            }
+            float bo = 0.f;
+            if (tid < out_dim) bo = ld1<true>(P + offB(depth) + tid);
+            if (tid < kRows) {
+                const int s = g * kRows + tid;
+                const int di = sDi[s];
+                float av = 0.f, lpo = 0.f, rt = 0.f;
+                if (di >= 0) {
                     if (which == 0) {
-                        float mean_f = 0.f, std_f = 1.f;
-                        if (u.normalize_adv) {                // ppo.py:2326-2333, from the per-epoch table
-                            const double* rec = u.adv_records + mb * 3;
-                            mean_f = (float)rec[1];
-                            std_f = (float)sqrt(rec[2] / (rec[0] - 1.0));
-                        }
-                        sMisc[0] = mean_f; sMisc[1] = std_f;
+                        av = u.adv[di]; lpo = u.old_lp[di];
+                        if (u.head_kind == PPOAF_HEAD_CATEGORICAL)
+                            reinterpret_cast<int*>(sActF)[tid * 8] = (int)reinterpret_cast<const int64_t*>(u.raw_actions)[di];
+                        else
+                            for (int d = 0; d < out_dim; ++d)
+                                sActF[tid * 8 + d] = reinterpret_cast<const float*>(u.raw_actions)[(long)di * out_dim + d];
                     } else {
-                        const int slot = (int)(mb & 1);
-                        float m = ld1<true>(u.vn_mean + slot), v = ld1<true>(u.vn_var + slot);
-                        double cnt = ld1<true>(u.vn_count + slot);
-                        if (u.normalize_values) {             // Chan merge of the per-rank records + utils/stats.py:73-94
-                            double n = 0.0, bm = 0.0, M2 = 0.0;
-                            for (int r = 0; r < u.n_ranks; ++r) {
-                                const double* rec = u.vn_records + (mb * u.n_ranks + r) * 3;
-                                const double nb = rec[0];
-                                if (nb <= 0.0) continue;
-                                const double d = rec[1] - bm, nn = n + nb;
-                                bm += d * (nb / nn);
-                                M2 += rec[2] + d * d * n * nb / nn;
-                                n = nn;
-                            }
-                            if (n > 0.0) {
-                                const float batch_mean = (float)bm, batch_var = (float)(M2 / n);
-                                const float delta = batch_mean - m;
-                                const double new_count = cnt + n;
-                                const float new_mean = (float)((double)m + (double)delta * (n / new_count));
-                                const double m_2 = (double)v * cnt + (double)batch_var * n +
-                                                   (double)(delta * delta) * cnt * n / (cnt + n);
-                                m = new_mean; v = (float)(m_2 / (cnt + n)); cnt = new_count;
-                            }
+                        rt = u.rtg[di];
+                    }
+                }
+                sRowF[tid] = av; sRowF[16 + tid] = lpo; sRowF[32 + tid] = rt;
+            }
+            if (tid == 64) {                                  // mini-batch statistics (as the row-tiled kernel's S0)
+                if (which == 0) {
+                    float mean_f = 0.f, std_f = 1.f;
+                    if (u.normalize_adv) {                    // ppo.py:2326-2333, from the per-epoch table
+                        const double* rec = u.adv_records + mb * 3;
+                        mean_f = (float)rec[1];
+                        std_f = (float)sqrt(rec[2] / (rec[0] - 1.0));
+                    }
+                    sMisc[0] = mean_f; sMisc[1] = std_f;
+                } else {
+                    const int slot = (int)(mb & 1);
+                    float m = ld1<true>(u.vn_mean + slot), v = ld1<true>(u.vn_var + slot);
+                    double cnt = ld1<true>(u.vn_count + slot);
+                    if (u.normalize_values) {                 // Chan merge of the per-rank records + utils/stats.py:73-94
+                        double n = 0.0, bm = 0.0, M2 = 0.0;
+                        for (int r = 0; r < u.n_ranks; ++r) {
+                            const double* rec = u.vn_records + (mb * u.n_ranks + r) * 3;
+                            const double nb = rec[0];
+                            if (nb <= 0.0) continue;
+                            const double d = rec[1] - bm, nn = n + nb;
+                            bm += d * (nb / nn);
+                            M2 += rec[2] + d * d * n * nb / nn;
+                            n = nn;
                         }
-                        sMisc[2] = m; sMisc[3] = v;
-                        if (g == 0) { u.vn_mean[slot ^ 1] = m; u.vn_var[slot ^ 1] = v; u.vn_count[slot ^ 1] = cnt; }
+                        if (n > 0.0) {
+                            const float batch_mean = (float)bm, batch_var = (float)(M2 / n);
+                            const float delta = batch_mean - m;
+                            const double new_count = cnt + n;
+                            const float new_mean = (float)((double)m + (double)delta * (n / new_count));
+                            const double m_2 = (double)v * cnt + (double)batch_var * n +
+                                               (double)(delta * delta) * cnt * n / (cnt + n);
+                            m = new_mean; v = (float)(m_2 / (cnt + n)); cnt = new_count;
+                        }
                     }
+                    sMisc[2] = m; sMisc[3] = v;
+                    if (g == 0) { u.vn_mean[slot ^ 1] = m; u.vn_var[slot ^ 1] = v; u.vn_count[slot ^ 1] = cnt; }
                 }
+            }
+#pragma unroll
+            for (int i = 0; i < (8 * H + kThreadsU - 1) / kThreadsU; ++i) {
+                const int e = tid + i * kThreadsU;
+                if (e < out_dim * H) sWout[e] = wo[i];
+            }
+            if (tid < out_dim) sBout[tid] = bo;
+            if (with_tail) {
+                ws_panel_commit(rh, sHp, HS, 16, tid);
+                ws_panel_commit(rwl, sWl, HS, H, tid);
+                if (tid < H) sBl[tid] = bl;
+                __syncthreads();
+                for (int t = wave; t < NCH; t += kNW) {               // h_{d-1}[16][H]: one 16-column tile per wave
+                    const int oc = 16 * t + (lane & 15);
+                    const f32x4 acc = ws_mfma_row_row_c<NCH>(sHp, sWl + 16 * t * HS, HS, lane, sBl[oc]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sH[(4 * (lane >> 4) + r) * HS + oc] = act_fwd(acc[r], act);
+                }
+            } else {
                 ws_panel_commit(rh, sH, HS, 16, tid);
+            }
+            __syncthreads();
+            if (tid < 256) {                                  // output layer: 16 lanes per row
+                const int s = tid >> 4, part = tid & 15;
+                for (int k = 0; k < out_dim; ++k) {
+                    float acc = 0.f;
 #pragma unroll
-                for (int i = 0; i < (8 * H + kThreadsU - 1) / kThreadsU; ++i) {
-                    const int e = tid + i * kThreadsU;
-                    if (e < out_dim * H) sWout[e] = wo[i];
+                    for (int i = 0; i < H; i += 16) acc = fmaf(sH[s * HS + part + i], sWout[k * H + part + i], acc);
+                    acc = group16_sum(acc);
+                    if (part == 0) sOut[s * kMaxOut + k] = acc + sBout[k];
                 }
-                if (tid < out_dim) sBout[tid] = bo;
-                __syncthreads();
-                if (tid < 256) {                              // output layer: 16 lanes per row
-                    const int s = tid >> 4, part = tid & 15;
-                    for (int k = 0; k < out_dim; ++k) {
-                        float acc = 0.f;
+            }
+            __syncthreads();
+            if (wave == 0)
+                ppo_head_loss<true>(u, which, g, out_dim, P + nd.log_std_off, sRow + g * kRows, sRowF, sMisc, sActF, sOut,
+                                    sDOut, lane, B);
+            __syncthreads();
+            float* op = outpart + (long)g * seg_len;
+            if (tid < H) {                                    // dW_out partial of this row block
+                const int i = tid;
+                float h[kRows];
 #pragma unroll
-                        for (int i = 0; i < H; i += 16) acc = fmaf(sH[s * HS + part + i], sWout[k * H + part + i], acc);
-                        acc = group16_sum(acc);
-                        if (part == 0) sOut[s * kMaxOut + k] = acc + sBout[k];
+                for (int s = 0; s < kRows; ++s) h[s] = sH[s * HS + i];
+                for (int k = 0; k < out_dim; ++k) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int s = 0; s < kRows; ++s) acc = fmaf(sDOut[s * kMaxOut + k], h[s], acc);
+                    op[(long)k * H + i] = acc;
+                }
+            }
+            if (tid >= 256 && tid < 256 + ((out_dim + 3) & ~3)) {
+                const int k = tid - 256;
+                float acc = 0.f;
+                if (k < out_dim)
+                    for (int s = 0; s < kRows; ++s) acc += sDOut[s * kMaxOut + k];
+                op[relB + k] = acc;
+            }
+            if (which == 0 && u.head_kind == PPOAF_HEAD_GAUSSIAN && tid >= 320 && tid < 320 + ((out_dim + 3) & ~3)) {
+                const int d = tid - 320;
+                float acc = 0.f;
+                if (d < out_dim)
+                    for (int s = 0; s < kRows; ++s) acc += sOut[s * kMaxOut + 8 + d];
+                op[relLS + d] = acc;
+            }
+#pragma unroll
+            for (int idx = tid; idx < kRows * H; idx += kThreadsU) {              // D_{depth-1} rows of this block
+                const int s = idx / H, i = idx % H;
+                float acc = 0.f;
+                for (int k = 0; k < out_dim; ++k) acc = fmaf(sDOut[s * kMaxOut + k], sWout[k * H + i], acc);
+                const int gs = g * kRows + s;
+                const float dz = acc * act_bwd(sH[s * HS + i], act);
+                if (gs < B) dlast[(long)gs * H + i] = dz;
+                if (with_tail) sDl[s * HS + i] = dz;
+            }
+            __syncthreads();
+            if (with_tail) {
+                float* dprev = dbuf + (long)(depth - 2) * plane;
+                for (int t = wave; t < NCH; t += kNW) {               // D_{d-2}[16][H] = (D_{d-1} . W_{d-1}) * act'(h_{d-2})
+                    const int ic = 16 * t + (lane & 15);
+                    const f32x4 acc = ws_mfma_row_colT_c<NCH, HS>(sDl, HS, sWl + 16 * t, lane);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int sl = 4 * (lane >> 4) + r, gs = g * kRows + sl;
+                        if (gs < B) dprev[(long)gs * H + ic] = acc[r] * act_bwd(sHp[sl * HS + ic], act);
                     }
-                }
-                __syncthreads();
-                if (wave == 0)
-                    ppo_head_loss<true>(u, which, g, out_dim, P + nd.log_std_off, sRow + g * kRows, sRowF, sMisc, sActF, sOut,
-                                        sDOut, lane, B);
-                __syncthreads();
-                float* op = outpart + (long)g * seg_len;
-                if (tid < H) {                                // dW_out partial of this row block
-                    const int i = tid;
-                    float h[kRows];
-#pragma unroll
-                    for (int s = 0; s < kRows; ++s) h[s] = sH[s * HS + i];
-                    for (int k = 0; k < out_dim; ++k) {
-                        float acc = 0.f;
-#pragma unroll
-                        for (int s = 0; s < kRows; ++s) acc = fmaf(sDOut[s * kMaxOut + k], h[s], acc);
-                        op[(long)k * H + i] = acc;
-                    }
-                }
-                if (tid >= 256 && tid < 256 + ((out_dim + 3) & ~3)) {
-                    const int k = tid - 256;
-                    float acc = 0.f;
-                    if (k < out_dim)
-                        for (int s = 0; s < kRows; ++s) acc += sDOut[s * kMaxOut + k];
-                    op[relB + k] = acc;
-                }
-                if (which == 0 && u.head_kind == PPOAF_HEAD_GAUSSIAN && tid >= 320 && tid < 320 + ((out_dim + 3) & ~3)) {
-                    const int d = tid - 320;
-                    float acc = 0.f;
-                    if (d < out_dim)
-                        for (int s = 0; s < kRows; ++s) acc += sOut[s * kMaxOut + 8 + d];
-                    op[relLS + d] = acc;
-                }
-#pragma unroll
-                for (int idx = tid; idx < kRows * H; idx += kThreadsU) {          // D_{depth-1} rows of this block
-                    const int s = idx / H, i = idx % H;
-                    float acc = 0.f;
-                    for (int k = 0; k < out_dim; ++k) acc = fmaf(sDOut[s * kMaxOut + k], sWout[k * H + i], acc);
-                    const int gs = g * kRows + s;
-                    if (gs < B) dlast[(long)gs * H + i] = acc * act_bwd(sH[s * HS + i], act);
                 }
                 __syncthreads();
             }
-        }
-        PPOAF_WSTAMP(2);
-        if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
-        PPOAF_WSTAMP(3);
+        };
 
-        // ---- backward through the hidden layers: D_{l-1} tiles and dW_l tiles side by side
-        for (int l = depth - 1; l >= 0; --l) {
+        // DG(l), l >= 1: D_{l-1}[64 rows][32 cols] = (D_l . W_l[:, cols]) * act'(h_{l-1})
+        auto dgrad_job = [&](const int l, const int j) {
             const float* Dl = dbuf + (long)l * plane;
             const float* Wl = P + offW(l);
-            const int n_dg = l >= 1 ? n_rt * nct : 0;
-            const int n_it = l >= 1 ? nct : (in_dim + 31) >> 5;        // column tiles of the layer's input
-            const int n_wg = nct * n_it;
-            const bool out_job = l == depth - 1;                       // fold the output-layer partials in this phase
-            const int n_jobs = n_dg + n_wg + (out_job ? 1 : 0);
-            for (int j = w; j < n_jobs; j += W) {
-                if (j < n_dg) {
-                    // D_{l-1}[64 rows][32 cols] = (D_l . W_l[:, cols]) * act'(h_{l-1})
-                    const int rt = j / nct, ct = j % nct;
-                    float* sA = sP;                           // D_l rows [64][HS]
-                    float* sWc = sP + 64 * HS;                // W_l[:, ct*32 .. +32]  [H][kWsPS]
-                    const float* hin = hbuf + (long)(l - 1) * plane;
-                    float* dout = dbuf + (long)(l - 1) * plane;
-                    const int i = ct * 32 + 16 * (wave >> 2) + (lane & 15);
-                    float hv[4];
+            const int rt = j / nct, ct = j % nct;
+            float* sA = sP;                                   // D_l rows [64][HS]
+            float* sWc = sP + 64 * HS;                        // W_l[:, ct*32 .. +32]  [H][kWsPS]
+            const float* hin = hbuf + (long)(l - 1) * plane;
+            float* dout = dbuf + (long)(l - 1) * plane;
+            const int i = ct * 32 + 16 * (wave >> 2) + (lane & 15);
+            float hv[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int s = rt * 64 + 16 * (wave & 3) + 4 * (lane >> 4) + r;
-                        hv[r] = ld1<true>(hin + (long)(s < B ? s : 0) * H + i);
+            for (int r = 0; r < 4; ++r) {
+                const int s = rt * 64 + 16 * (wave & 3) + 4 * (lane >> 4) + r;
+                hv[r] = ld1<true>(hin + (long)(s < B ? s : 0) * H + i);
+            }
+            WsPanel<H, 64> ra;
+            WsPanel<32, H> rw;
+            ws_panel_issue(ra, Dl, H, rt * 64, 64, (int)B, 0, tid);
+            ws_panel_issue(rw, Wl, H, 0, H, H, ct * 32, tid);
+            ws_panel_commit(ra, sA, HS, 64, tid);
+            ws_panel_commit(rw, sWc, kWsPS, H, tid);
+            __syncthreads();
+            const f32x4 acc = ws_mfma_row_col_c<NCH>(sA + 16 * (wave & 3) * HS, HS, sWc + 16 * (wave >> 2), lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = rt * 64 + 16 * (wave & 3) + 4 * (lane >> 4) + r;
+                if (s < B) dout[(long)s * H + i] = acc[r] * act_bwd(hv[r], act);
+            }
+            __syncthreads();
+        };
+
+        // WG(l): dW_l[32 outputs][32 inputs] = D_l^T . h_{l-1} over all rows (h_{-1} = the inputs), db_l with input tile 0
+        auto wgrad_job = [&](const int l, const int jj) {
+            const float* Dl = dbuf + (long)l * plane;
+            const int n_it = l >= 1 ? nct : (in_dim + 31) >> 5;
+            const int ot = jj / n_it, itile = jj - ot * n_it;
+            float* sD = sP;                                   // D_l[:, ot*32 .. +32]      [Bk][kWsPS]
+            float* sX = sP + Bk * kWsPS;                      // h_{l-1}[:, it*32 .. +32]  [Bk][kWsPS]
+            WsPanel<32, 512> rd;
+            ws_panel_issue(rd, Dl, H, 0, Bk, (int)B, ot * 32, tid);
+            if (l >= 1) {
+                WsPanel<32, 512> rx;
+                ws_panel_issue(rx, hbuf + (long)(l - 1) * plane, H, 0, Bk, (int)B, itile * 32, tid);
+                ws_panel_commit(rx, sX, kWsPS, Bk, tid);
+            } else {
+                // input columns [itile * 32, +32) of all rows (gathered): cp (power of two >= the valid columns)
+                // threads per row; the columns beyond the valid ones are zero
+                const int k0 = itile * 32, ncv = in_dim - k0 < 32 ? in_dim - k0 : 32;
+                const int shc = ncv <= 1 ? 0 : 32 - __clz(ncv - 1), cp = 1 << shc, rpp = kThreadsU >> shc;
+                const int c = tid & (cp - 1), r = tid >> shc;
+                for (int s0 = 0; s0 < Bk; s0 += 8 * rpp) {
+                    float xv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int s = s0 + q * rpp + r;
+                        const int di = s < Bk ? sDi[s < Bp ? s : 0] : -1;
+                        const float v = xsrc[(long)(di >= 0 ? di : 0) * in_dim + k0 + (c < ncv ? c : 0)];
+                        xv[q] = (di >= 0 && c < ncv) ? v : 0.f;
                     }
-                    WsPanel<H, 64> ra;
-                    WsPanel<32, H> rw;
-                    ws_panel_issue(ra, Dl, H, rt * 64, 64, (int)B, 0, tid);
-                    ws_panel_issue(rw, Wl, H, 0, H, H, ct * 32, tid);
-                    ws_panel_commit(ra, sA, HS, 64, tid);
-                    ws_panel_commit(rw, sWc, kWsPS, H, tid);
-                    __syncthreads();
-                    const f32x4 acc = ws_mfma_row_col_c<NCH>(sA + 16 * (wave & 3) * HS, HS, sWc + 16 * (wave >> 2), lane);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int s = rt * 64 + 16 * (wave & 3) + 4 * (lane >> 4) + r;
-                        if (s < B) dout[(long)s * H + i] = acc[r] * act_bwd(hv[r], act);
-                    }
-                    __syncthreads();
-                } else if (j < n_dg + n_wg) {
-                    const int jj = j - n_dg;
-                    const int ot = jj / n_it, itile = jj - ot * n_it;
-                    float* sD = sP;                           // D_l[:, ot*32 .. +32]      [Bk][kWsPS]
-                    float* sX = sP + Bk * kWsPS;              // h_{l-1}[:, it*32 .. +32]  [Bk][kWsPS]
-                    WsPanel<32, 512> rd;
-                    ws_panel_issue(rd, Dl, H, 0, Bk, (int)B, ot * 32, tid);
-                    if (l >= 1) {
-                        WsPanel<32, 512> rx;
-                        ws_panel_issue(rx, hbuf + (long)(l - 1) * plane, H, 0, Bk, (int)B, itile * 32, tid);
-                        ws_panel_commit(rx, sX, kWsPS, Bk, tid);
-                    } else {
-                        // input columns [itile * 32, +32) of all rows (gathered): cp (power of two >= the valid
-                        // columns) threads per row; the columns beyond the valid ones are zero
-                        const int k0 = itile * 32, ncv = in_dim - k0 < 32 ? in_dim - k0 : 32;
-                        const int shc = ncv <= 1 ? 0 : 32 - __clz(ncv - 1), cp = 1 << shc, rpp = kThreadsU >> shc;
-                        const int c = tid & (cp - 1), r = tid >> shc;
-                        for (int s0 = 0; s0 < Bk; s0 += 8 * rpp) {
-                            float xv[8];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const int s = s0 + q * rpp + r;
-                                const int di = s < Bk ? sDi[s < Bp ? s : 0] : -1;
-                                const float v = xsrc[(long)(di >= 0 ? di : 0) * in_dim + k0 + (c < ncv ? c : 0)];
-                                xv[q] = (di >= 0 && c < ncv) ? v : 0.f;
-                            }
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const int s = s0 + q * rpp + r;
-                                if (s < Bk) {
-                                    sX[s * kWsPS + c] = xv[q];
-                                    for (int cc = c + cp; cc < 32; cc += cp) sX[s * kWsPS + cc] = 0.f;
-                                }
-                            }
+                    for (int q = 0; q < 8; ++q) {
+                        const int s = s0 + q * rpp + r;
+                        if (s < Bk) {
+                            sX[s * kWsPS + c] = xv[q];
+                            for (int cc = c + cp; cc < 32; cc += cp) sX[s * kWsPS + cc] = 0.f;
                         }
-                    }
-                    ws_panel_commit(rd, sD, kWsPS, Bk, tid);
-                    __syncthreads();
-                    const long ldw = l >= 1 ? H : in_dim;
-                    sumsq += ws_wgrad_tile(sD, sX, sRed, Bk, G + offW(l), ldw, ot * 32, itile * 32, (int)ldw,
-                                           itile == 0 ? G + offB(l) : nullptr, u.grad_scale, tid, wave, lane);
-                    __syncthreads();
-                } else {
-                    // output layer (+ log_std): row-block partials -> gradient, in block order
-                    const float sc = u.grad_scale;
-                    for (long idx = tid; idx < seg_len; idx += kThreadsU) {
-                        float acc = 0.f;
-                        for (int g0 = 0; g0 < n_hb; g0 += 8) {
-                            float pv[8];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) pv[q] = ld1<true>(outpart + (long)(g0 + q < n_hb ? g0 + q : 0) * seg_len + idx);
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) if (g0 + q < n_hb) acc += pv[q];
-                        }
-                        G[seg_off + idx] = acc;
-                        sumsq += (double)(acc * sc) * (acc * sc);
                     }
                 }
             }
-            if (l == 0) {
-                // loss bookkeeping of this network (the partials are complete since the HEAD barrier), Adam step
-                // counter + bias corrections, then this worker's squared-norm partial
-                if (w == W - 1 && tid < 64) {
-                    float p0 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p7 = 0.f;
-                    for (int gg = lane; gg < n_hb; gg += 64) {
-                        const float* a = u.loss_partials + ((long)which * n_hb + gg) * 8;
-                        p0 += ld1<true>(a); p2 += ld1<true>(a + 2); p3 += ld1<true>(a + 3); p4 += ld1<true>(a + 4); p7 += ld1<true>(a + 7);
-                    }
-                    p0 = wave_sum(p0); p2 = wave_sum(p2); p3 = wave_sum(p3); p4 = wave_sum(p4); p7 = wave_sum(p7);
-                    if (lane == 0) {
-                        const float n = (float)B;
-                        if (which == 0) {
-                            const float surr = p0 / n, ent = p3 / n, kl = p4 / n;
-                            float total = surr;
-                            if (u.entropy_weight != 0.0f) total -= u.entropy_weight * ent;
-                            if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
-                            u.totals[0] += (double)surr; u.totals[1] += (double)total;
-                            u.totals[3] += (double)ent; u.totals[4] += (double)kl;
-                            u.totals[5] += (double)ld1<true>(u.loss_partials + 5); u.totals[6] += (double)ld1<true>(u.loss_partials + 6);
-                            u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
-                            u.totals[8] += 1.0;
-                        } else {
-                            u.totals[2] += (double)(p2 / n);
-                        }
-                        const int64_t t = u.step_counts[which] + 1;       // only this lane touches the counter in the launch
-                        u.step_counts[which] = t;
-                        u.norm_scratch[2 + 2 * which] = 1.0 - pow((double)u.beta1, (double)t);
-                        u.norm_scratch[3 + 2 * which] = sqrt(1.0 - pow((double)u.beta2, (double)t));
-                    }
+            ws_panel_commit(rd, sD, kWsPS, Bk, tid);
+            __syncthreads();
+            const long ldw = l >= 1 ? H : in_dim;
+            sumsq += ws_wgrad_tile(sD, sX, sRed, Bk, G + offW(l), ldw, ot * 32, itile * 32, (int)ldw,
+                                   itile == 0 ? G + offB(l) : nullptr, u.grad_scale, tid, wave, lane);
+            __syncthreads();
+        };
+
+        // OUT: output layer (+ log_std): row-block partials -> gradient, in block order
+        auto out_job = [&]() {
+            const float sc = u.grad_scale;
+            for (long idx = tid; idx < seg_len; idx += kThreadsU) {
+                float acc = 0.f;
+                for (int g0 = 0; g0 < n_hb; g0 += 8) {
+                    float pv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) pv[q] = ld1<true>(outpart + (long)(g0 + q < n_hb ? g0 + q : 0) * seg_len + idx);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (g0 + q < n_hb) acc += pv[q];
                 }
+                G[seg_off + idx] = acc;
+                sumsq += (double)(acc * sc) * (acc * sc);
+            }
+        };
+
+        // loss bookkeeping of this network (the partials are complete since the HEAD barrier), Adam step counter +
+        // bias corrections: one wave of the last worker
+        auto bookkeeping = [&]() {
+            if (w == W - 1 && tid < 64) {
+                float p0 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p7 = 0.f;
+                for (int gg = lane; gg < n_hb; gg += 64) {
+                    const float* a = u.loss_partials + ((long)which * n_hb + gg) * 8;
+                    p0 += ld1<true>(a); p2 += ld1<true>(a + 2); p3 += ld1<true>(a + 3); p4 += ld1<true>(a + 4); p7 += ld1<true>(a + 7);
+                }
+                p0 = wave_sum(p0); p2 = wave_sum(p2); p3 = wave_sum(p3); p4 = wave_sum(p4); p7 = wave_sum(p7);
+                if (lane == 0) {
+                    const float n = (float)B;
+                    if (which == 0) {
+                        const float surr = p0 / n, ent = p3 / n, kl = p4 / n;
+                        float total = surr;
+                        if (u.entropy_weight != 0.0f) total -= u.entropy_weight * ent;
+                        if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
+                        u.totals[0] += (double)surr; u.totals[1] += (double)total;
+                        u.totals[3] += (double)ent; u.totals[4] += (double)kl;
+                        u.totals[5] += (double)ld1<true>(u.loss_partials + 5); u.totals[6] += (double)ld1<true>(u.loss_partials + 6);
+                        u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
+                        u.totals[8] += 1.0;
+                    } else {
+                        u.totals[2] += (double)(p2 / n);
+                    }
+                    const int64_t t = u.step_counts[which] + 1;           // only this lane touches the counter in the launch
+                    u.step_counts[which] = t;
+                    u.norm_scratch[2 + 2 * which] = 1.0 - pow((double)u.beta1, (double)t);
+                    u.norm_scratch[3 + 2 * which] = sqrt(1.0 - pow((double)u.beta2, (double)t));
+                }
+            }
+        };
+#define PPOAF_WS_BARRIER(k)                                                           \
+        PPOAF_WSTAMP(k);                                                              \
+        if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;             \
+        PPOAF_WSTAMP((k) + 1);
+
+        // ================================================================ forward
+        const int n_tile = n_rt * nct;
+        if (!fuse0) {
+            for (int j = w; j < n_tile; j += W) f0_job(j);
+            PPOAF_WS_BARRIER(0)
+        }
+        const int l_fwd_end = tail ? depth - 1 : depth;           // hidden layers [1, l_fwd_end) as tile phases
+        for (int l = 1; l < l_fwd_end; ++l) {
+            for (int j = w; j < n_tile; j += W) f_job(l, j, fuse0 && l == 1);
+            PPOAF_WS_BARRIER(0)
+        }
+        // ================================================================ HEAD (+ tail)
+        for (int g = w; g < n_hb; g += W) head_job(g, tail);
+        PPOAF_WS_BARRIER(2)
+
+        // ================================================================ backward
+        if (!tail) {
+            for (int l = depth - 1; l >= 0; --l) {
+                const int n_dg = l >= 1 ? n_tile : 0;
+                const int n_wg = nct * (l >= 1 ? nct : (in_dim + 31) >> 5);
+                const int n_jobs = n_dg + n_wg + (l == depth - 1 ? 1 : 0);
+                for (int j = w; j < n_jobs; j += W) {
+                    if (j < n_dg) dgrad_job(l, j);
+                    else if (j < n_dg + n_wg) wgrad_job(l, j - n_dg);
+                    else out_job();
+                }
+                if (l == 0) {
+                    bookkeeping();
+                    const double q = block_sum(sumsq, s_red);
+                    if (tid == 0) ctl->norm_partials[which][w] = q;
+                }
+                const int stamp = l == 0 ? 8 : (l == depth - 1 ? 4 : 6);
+                (void)stamp;
+                PPOAF_WS_BARRIER(stamp)
+            }
+        } else {
+            // D_{d-1} and D_{d-2} are known.  {DG(m), WG(m+1)} for m = d-2 .. 1, then {WG(1), WG(0), OUT}
+            for (int m = depth - 2; m >= 1; --m) {
+                const int n_jobs = n_tile + nct * nct;
+                for (int j = w; j < n_jobs; j += W) {
+                    if (j < n_tile) dgrad_job(m, j);
+                    else wgrad_job(m + 1, j - n_tile);
+                }
+                PPOAF_WS_BARRIER(4)
+            }
+            {
+                const int n1 = nct * nct, n0 = nct * ((in_dim + 31) >> 5);
+                const int n_jobs = n1 + n0 + 1;
+                // the single OUT job first (worker 0 of a 21-job phase would otherwise run two tiles)
+                for (int j = W - 1 - w; j < n_jobs; j += W) {
+                    if (j < n1) wgrad_job(1, j);
+                    else if (j < n1 + n0) wgrad_job(0, j - n1);
+                    else out_job();
+                }
+                bookkeeping();
                 const double q = block_sum(sumsq, s_red);
                 if (tid == 0) ctl->norm_partials[which][w] = q;
+                PPOAF_WS_BARRIER(8)
             }
-            const int stamp = l == 0 ? 8 : (l == depth - 1 ? 4 : 6);     // W0 / first backward phase / middle ones
-            (void)stamp;
-            PPOAF_WSTAMP(stamp);
-            if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
-            PPOAF_WSTAMP(stamp + 1);
         }
 
-        // ---- clip + Adam on this worker's columns of the network; norm = partials in worker order.  The parameter /
-        //      moment / gradient loads depend on nothing computed here, so they are requested first.
+        // ================================================================ clip + Adam on this worker's columns of the
+        // network; norm = partials in worker order.  The parameter / moment / gradient loads depend on nothing
+        // computed here, so they are requested first.
         {
             const long lo4 = nd.offset >> 2, hi4 = (nd.offset + nd.size) >> 2;
             const long idx0 = lo4 + (long)w * kThreadsU + tid;
@@ -833,9 +994,8 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
             }
 #undef PPOAF_ADAM1
         }
-        PPOAF_WSTAMP(10);
-        if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
-        PPOAF_WSTAMP(11);
+        PPOAF_WS_BARRIER(10)
+#undef PPOAF_WS_BARRIER
     }
     // the cursor moves once BOTH networks are done with the launch (each read it when it started)
     if (w == 0 && threadIdx.x == 0) {
@@ -1027,8 +1187,10 @@ __global__ __launch_bounds__(kThreadsU) void ppo_update_ws_kernel(WsArgs a, WsCt
 static size_t ws_lds_floats(const NetDev& n, long B) {
     const size_t H = n.H, in_pad = (n.in_dim + 15) & ~15, Bk = (B + 15) & ~15L;
     const size_t K = in_pad > H ? in_pad : H;
-    size_t p = 96 * (K + 4);                                             // forward: A [64][K+4] + W [32][K+4]
-    const size_t dg = 64 * (H + 4) + H * kWsPS, wg = 2 * Bk * kWsPS, hd = 16 * (H + 4) + 8 * H + 16;
+    size_t p = 96 * (K + 4) + 64 * 20 + H * 20 + H;                      // forward: A [64][K+4] + W [32][K+4] (+ on-the-fly layer 0)
+    const size_t dg = 64 * (H + 4) + H * kWsPS, wg = 2 * Bk * kWsPS;
+    size_t hd = 16 * (H + 4) + 8 * H + 16;                               // head
+    if (H <= 128) hd += 32 * (H + 4) + H + H * (H + 4);                  //   + tail: h_{d-2}, D_{d-1}, b_{d-1}, W_{d-1}
     if (dg > p) p = dg;
     if (wg > p) p = wg;
     if (hd > p) p = hd;

@@ -375,10 +375,13 @@ class FusedPolicyUpdate:
         ctl = getattr(self, "_ws_ctl", None)
         if ctl is not None and getattr(self, "_ws_used", False):
             self._ws_used = False
-            if int(ctl[2].item()) != 0:
+            words = ctl[:4].tolist()                      # tickets[2], error, done
+            if words[2] != 0 or words[3] != 2:
                 raise _lib.PpoafError(
-                    "ppo_update_ws: a barrier wait ran out of time -- a network did not get all of its workgroups onto its "
-                    "XCD (another process on this GPU?).  Set PPOAF_WS=0 to use the three-launch chain.")
+                    f"ppo_update_ws: the last launch did not complete (error word {words[2]}, networks finished {words[3]} of 2, "
+                    f"worker tickets drawn {words[0]} / {words[1]}): a network did not get all of its workgroups onto its XCD "
+                    "(another process on this GPU, or a partition mode that exposes a single XCD?).  Set PPOAF_WS=0 to use "
+                    "the three-launch chain.")
         ctl = getattr(self, "_persist_ctl", None)
         if ctl is not None and getattr(self, "_persist_used", False):
             self._persist_used = False
