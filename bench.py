@@ -17,9 +17,11 @@ default_rng(1234 + rank).  value = N * E * T * K / max-over-ranks wall time.
 
 Rank 0 prints ONE JSON line:
   roofline            the GAE kernel (the kernel the metric names), HIP kernel events inside the timed region
-  roofline_update     the kernel that dominates the step (K12 / K15 fwd_bwd): FLOP per launch / its launch time
-                      (kernel begin/end events on eager launches of the same chain right after the timed region --
-                      the in-region launches are hipGraph nodes, which cannot carry event stamps) vs the f32-MFMA peak
+  roofline_update     the kernel that dominates the step: FLOP per launch / its launch time vs the f32-MFMA peak.
+                      Single rank, MLP policies: the two-XCD persistent kernel (ONE launch per epoch = all full
+                      mini-batches; begin / end events of epoch launches made right after the timed region).
+                      Otherwise K12 / K15 fwd_bwd (kernel begin/end events on eager launches of the same chain right
+                      after the timed region -- the in-region launches are hipGraph nodes, which cannot carry stamps)
   config.other_configs  short runs (2 steps) of the other BASELINE configs' shapes (C3, C4, C5) in the same process
   cpu_baseline        oracle/cpu_ppo_loop.py (a port with the reference's loop structure, pinned against fixtures
                       recorded from the reference) on a bounded sample: 1 process; cpu_baseline_mpi: R = 8 processes
@@ -324,8 +326,14 @@ def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline
             iteration(False)
         barrier()
         t0 = time.perf_counter()
+        step_ts = []
         for _ in range(steps):
             iteration(True)
+            if os.environ.get("PPOAF_BENCH_STEP_TIMES") == "1":           # diagnostic only: one host sync per step
+                torch.cuda.synchronize()
+                step_ts.append(round(time.perf_counter() - t0, 4))
+        if step_ts:
+            print(f"[bench] {name}: cumulative step end times (s): {step_ts}", file=sys.stderr, flush=True)
         barrier()
         dt = time.perf_counter() - t0
     finally:
