@@ -394,7 +394,9 @@ int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int compute_norms
  * of each parameter column -- on `workers` (<= 32) workgroups per network, the actor's all on XCD xcc_actor and the
  * critic's on xcc_critic (two different XCDs, 0..7), phases separated by flag barriers inside the XCD's L2.
  * Replaces ppo.py:2292-2469 for a run of mini-batches exactly as fwd_bwd -> reduce -> adam does (same arguments, same
- * totals / value-normaliser / step-counter bookkeeping; summation orders differ, results agree to float32 rounding).
+ * totals / value-normaliser / step-counter bookkeeping).  A row-tiled network (see layered_mask) runs the chain's own
+ * arithmetic in the chain's own order: bitwise the chain's parameters; a layered network sums its weight gradients in
+ * another association (float32 rounding apart).
  * ctl: ppoaf_ppo_update_ws_ctl_bytes() of device memory, 16-byte aligned, owned by the caller during the launch;
  * workspace: ppoaf_ppo_update_ws_workspace_bytes() of device memory, 256-byte aligned (activations, dLoss/dz and the
  * output-layer partials of one mini-batch).  The third 32-bit word of ctl is non-zero afterwards if a wait ran out of

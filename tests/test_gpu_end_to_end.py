@@ -113,10 +113,14 @@ def test_c1_config_two_full_iterations_match_cpu_port(update_mode):
         assert d.max() < 5e-4 and np.mean(d > 3e-5) < 1e-2, (d.max(), np.mean(d > 3e-5))
 
 
-@pytest.mark.parametrize("update_mode,use_graphs", [("fused", True), ("fused", False),
+@pytest.mark.parametrize("update_mode,use_graphs", [("fused", True), ("fused", False), ("fused", None),
                                                     ("torch", True), ("torch", False)])
-def test_update_epochs_match_cpu_port(update_mode, use_graphs):
-    """Both product update paths (fused K12 kernels; torch-ROCm MLPs + K2..K11) against the CPU port."""
+def test_update_epochs_match_cpu_port(update_mode, use_graphs, monkeypatch):
+    """Both product update paths (fused K12 kernels; torch-ROCm MLPs + K2..K11) against the CPU port.  The fused path
+    runs its three-launch chain (graph-replayed / eager) for use_graphs True / False and the two-XCD persistent kernel
+    when use_graphs is None."""
+    monkeypatch.setenv("PPOAF_WS", "0" if use_graphs is not None else "1")
+    use_graphs = bool(use_graphs)
     E, T, B, epochs = 16, 32, 64, 2
     ppo = _make(E, T, B, epochs, use_graphs=use_graphs, update_mode=update_mode)
     cpu = _oracle_like(ppo, B)
@@ -231,8 +235,12 @@ def test_fused_update_equals_torch_update(cfg):
     np.testing.assert_allclose(val0, val1, rtol=1e-4, atol=2e-5)
 
 
-def test_fused_update_fuzz_against_the_torch_path():
+@pytest.mark.parametrize("k12_form", ["chain", "auto", "layered", "rowtile"])
+def test_fused_update_fuzz_against_the_torch_path(k12_form, monkeypatch):
     """
+    k12_form: which form of K12 the fused path takes for the epoch's full mini-batches -- the three-launch chain, or
+    the two-XCD persistent kernel with its automatic / all-layered / all-row-tiled decomposition (shapes a form does
+    not cover fall back to the chain by themselves).
     Randomised shapes (hypothesis, derandomised) for K12 + K6/K7: observation widths that are not multiples of
     4 or 16, 1-8 actions of either kind, every instantiated width pair with equal actor / critic width, depth
     1-3, batch sizes with ragged last workgroups and epoch tails, terminations.  Fused kernels against the
@@ -242,10 +250,13 @@ def test_fused_update_fuzz_against_the_torch_path():
     from hypothesis import given, settings, strategies as st, HealthCheck
     from ppo_and_friends_amd.spaces import Box, Discrete
     from ppo_and_friends_amd.ppo import PermutationLoader
+    monkeypatch.setenv("PPOAF_WS", "0" if k12_form == "chain" else "1")
+    monkeypatch.setenv("PPOAF_WS_MODE", "auto" if k12_form == "chain" else k12_form)
 
-    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=40 if k12_form in ("chain", "auto") else 25, deadline=None, derandomize=True,
+              suppress_health_check=list(HealthCheck))
     @given(O=st.integers(1, 70), kind=st.sampled_from(["d", "c"]), n=st.integers(1, 8),
-           hidden=st.sampled_from([32, 64, 128, 256]), depth=st.integers(1, 3), B=st.integers(2, 130),
+           hidden=st.sampled_from([32, 64, 128, 256]), depth=st.integers(1, 4), B=st.integers(2, 300),
            E=st.integers(1, 12), T=st.integers(2, 24), act_fn=st.sampled_from([nn.ReLU, nn.LeakyReLU, nn.Tanh]),
            huber=st.booleans(), term=st.sampled_from([0.0, 0.1]))
     def run(O, kind, n, hidden, depth, B, E, T, act_fn, huber, term):
@@ -1103,7 +1114,8 @@ def test_rollout_dataset_order_fuzz_against_the_cpu_port():
     run()
 
 
-def test_fused_update_fuzz_with_different_actor_and_critic_shapes():
+@pytest.mark.parametrize("k12_form", ["chain", "auto", "layered"])
+def test_fused_update_fuzz_with_different_actor_and_critic_shapes(k12_form, monkeypatch):
     """
     K12 / K6+K7 with the MAPPO shape: several agents share the policy, the critic sees the
     concatenated observations of the env ("policy" view) and is wider than the actor -- the instantiated mixed
@@ -1114,10 +1126,12 @@ def test_fused_update_fuzz_with_different_actor_and_critic_shapes():
     from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
     from ppo_and_friends_amd.spaces import Box, Discrete
     dev = torch.device("cuda", 0)
+    monkeypatch.setenv("PPOAF_WS", "0" if k12_form == "chain" else "1")
+    monkeypatch.setenv("PPOAF_WS_MODE", "auto" if k12_form == "chain" else k12_form)
 
     @settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(A=st.integers(2, 4), O=st.integers(1, 24), NA=st.integers(2, 8), widths=st.sampled_from([(128, 256), (64, 128)]),
-           E=st.integers(1, 8), T=st.integers(2, 16), B=st.integers(2, 100), cont=st.booleans())
+           E=st.integers(1, 8), T=st.integers(2, 16), B=st.integers(2, 200), cont=st.booleans())
     def run(A, O, NA, widths, E, T, B, cont):
         space = Box(-1.0, 1.0, (NA,), np.float32) if cont else Discrete(NA)
         res = []
@@ -1203,12 +1217,13 @@ def test_lstm_sequence_path_fuzz_against_the_cpu_port():
     run()
 
 
-def test_graph_chunking_fuzz_equals_eager_launches():
+def test_graph_chunking_fuzz_equals_eager_launches(monkeypatch):
     """
     hipGraph chunking of the fused chains (32-mini-batch chunks, eager remainder, epoch tail, a second epoch that
     replays the captured chunk): for random small batch sizes and dataset lengths the graph-replayed run and the
-    eager run of the same kernels must agree bitwise -- K12, and K15 for a MATPolicy.
+    eager run of the same kernels must agree bitwise -- K12 (three-launch chain: PPOAF_WS=0), and K15 for a MATPolicy.
     """
+    monkeypatch.setenv("PPOAF_WS", "0")
     from hypothesis import given, settings, strategies as st, HealthCheck
     from ppo_and_friends_amd.ppo import PPO
     from ppo_and_friends_amd.policies.mat_policy import MATPolicy

@@ -115,12 +115,14 @@ def test_c5_mat_update_full_size_properties():
 
 
 @pytest.mark.parametrize("name", ["C2", "C4"])
-def test_k12_full_size_graph_replay_equals_eager_launches(name):
+def test_k12_full_size_graph_replay_equals_eager_launches(name, monkeypatch):
     """
+    (three-launch chain: PPOAF_WS=0; the persistent kernel has its own full-size test below)
     K12 at the metric's own size (C2: 2048 mini-batches per epoch; C4: MAPPO shape, 3 agents, 256-wide critic):
     the hipGraph-replayed chain and the eager launches are two execution modes of the same kernels -- bitwise
     equal weights, optimiser state and statistics; every mini-batch counted once; value normaliser saw every row.
     """
+    monkeypatch.setenv("PPOAF_WS", "0")
     outs = []
     for graphs in (True, False):
         ppo, E, T, A = _c_config(name, use_graphs=graphs)
@@ -137,3 +139,39 @@ def test_k12_full_size_graph_replay_equals_eager_launches(name):
                      [sd[k] for k in ("actor loss", "critic loss", "kl avg", "weighted entropy")], vs.mean.copy()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][2] == outs[1][2] and np.array_equal(outs[0][3], outs[1][3])
+
+
+@pytest.mark.parametrize("name", ["C2", "C4"])
+def test_k12_full_size_persistent_kernel_matches_the_chain_and_is_reproducible(name, monkeypatch):
+    """
+    The two-XCD persistent kernel (one launch per epoch) at the metric's own size against the three-launch chain on the
+    same rollout and shuffle.  Row-tiled networks (C2: both; C4: the actor) run the chain's own arithmetic in the
+    chain's own order: BITWISE equal parameters and optimiser state.  The layered 256-wide critic of C4 sums in another
+    association: statistics to tolerance -- its weights after 1536 Adam steps on unlearnable targets are as far from
+    the chain's as the chain's are from a run of itself with ONE critic weight moved by 1 ulp (max |dw| 0.04, 79 % of
+    the weights off by > 1e-4: `tools/probes/c4_chaos.py`), so they are not compared.  And bitwise equal to itself run
+    to run.
+    """
+    from ppo_and_friends_amd import fused_update
+    outs = []
+    for ws in ("1", "1", "0"):
+        monkeypatch.setenv("PPOAF_WS", ws)
+        before = fused_update.FusedPolicyUpdate.ws_launch_count
+        ppo, E, T, A = _c_config(name)
+        ppo.rollout()
+        pol = ppo.policies["p"]
+        ppo.train_on_rollout()
+        assert (fused_update.FusedPolicyUpdate.ws_launch_count > before) == (ws == "1")
+        n_mb = E * T * A // 256
+        assert int(pol.policy_step_counts[0].item()) == int(pol.policy_step_counts[1].item()) == n_mb
+        vs = ppo.value_normalizers["p"].running_stats
+        assert abs(vs.count - (E * T * A + 1e-4)) < 1e-3
+        sd = ppo.status_dict["p"]
+        n_actor = int(ppo._fused_updater("p", 256).actor_desc.size)
+        outs.append((pol.policy_params.clone(), pol.policy_exp_avg_sq.clone(),
+                     np.array([sd[k] for k in ("actor loss", "critic loss", "kl avg", "weighted entropy")]), vs.mean.copy(), n_actor))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    np.testing.assert_allclose(outs[0][2], outs[2][2], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(outs[0][3], outs[2][3], rtol=1e-6)
+    n = outs[0][4] if name == "C4" else outs[0][0].numel()          # C4: the critic is layered
+    assert torch.equal(outs[0][0][:n], outs[2][0][:n]) and torch.equal(outs[0][1][:n], outs[2][1][:n])
