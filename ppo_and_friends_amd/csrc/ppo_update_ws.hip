@@ -36,6 +36,7 @@ struct WsDev {
     float* hbuf[2];                       // [depth][Bp][H]   hidden activations of the mini-batch
     float* dbuf[2];                       // [depth][Bp][H]   dLoss / dz
     float* outpart[2];                    // [ceil(B/16)][seg] output-layer (+ log_std) gradient partials per row block
+    float* xbuf[2];                       // [Bp][64]         the mini-batch's gathered input rows, zero padded (layer-0 wgrad)
     int W;                                // workers per network
     int xcc[2];                           // XCD of the actor / critic workers
     int Bp;                               // B rounded up to 64
@@ -51,7 +52,7 @@ struct WsCtl {
 #ifdef PPOAF_WS_STAMPS
 #define PPOAF_WSTAMP(k)                                                                   \
     do {                                                                                  \
-        if (which == PPOAF_WS_STAMP_NET && w == 0 && tid == 0) {                          \
+        if (which == PPOAF_WS_STAMP_NET && w == PPOAF_WS_STAMP_WORKER && tid == 0) {      \
             unsigned long long t_;                                                        \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
             ctl->phase_ticks[k] += t_ - t_prev;                                           \
@@ -60,6 +61,9 @@ struct WsCtl {
     } while (0)
 #ifndef PPOAF_WS_STAMP_NET
 #define PPOAF_WS_STAMP_NET 0
+#endif
+#ifndef PPOAF_WS_STAMP_WORKER
+#define PPOAF_WS_STAMP_WORKER 0
 #endif
 #else
 #define PPOAF_WSTAMP(k) do {} while (0)
@@ -343,6 +347,69 @@ __device__ __forceinline__ double ws_wgrad_tile(const float* __restrict__ Dp, co
     return q;
 }
 
+constexpr int kWsPSW = 68;                // row stride of a 64-column panel slice
+
+// The same for a 64 x 64 tile (mini-batches of at most 256 rows: both [Bk][kWsPSW] panels fit in LDS): 16 sub-tiles,
+// wave w owns output tile (w & 3) x input tiles {2 (w >> 2), 2 (w >> 2) + 1} over the whole K range -- four times the
+// MFMA work of the 32 x 32 tile per panel byte and per barrier, and no K fold.
+__device__ __forceinline__ double ws_wgrad_tile_wide(const float* __restrict__ Dp, const float* __restrict__ Xp, float* __restrict__ sRed,
+                                                     const int Bk, float* __restrict__ dstW, const long ldw, const int o0,
+                                                     const int i0, const int i_valid, float* __restrict__ dst_b,
+                                                     const float sc, const int tid, const int wave, const int lane) {
+    const int ot4 = wave & 3, ip = (wave >> 2) * 2;
+    const float* a = Dp + (4 * (lane >> 4)) * kWsPSW + 16 * ot4 + (lane & 15);
+    const float* b = Xp + (4 * (lane >> 4)) * kWsPSW + 16 * ip + (lane & 15);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int nc = Bk >> 4;
+#pragma unroll 2
+    for (int c = 0; c < nc; ++c) {
+        const float* ap = a + (16 * c) * kWsPSW;
+        const float* bp = b + (16 * c) * kWsPSW;
+        const float a0 = ap[0], a1 = ap[kWsPSW], a2 = ap[2 * kWsPSW], a3 = ap[3 * kWsPSW];
+        const float b00 = bp[0], b01 = bp[kWsPSW], b02 = bp[2 * kWsPSW], b03 = bp[3 * kWsPSW];
+        const float b10 = bp[16], b11 = bp[kWsPSW + 16], b12 = bp[2 * kWsPSW + 16], b13 = bp[3 * kWsPSW + 16];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b00, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b10, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b01, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b11, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b02, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b12, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b03, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b13, acc1, 0, 0, 0);
+    }
+    // bias gradient partials: 8 row classes x 64 columns
+    float* sB = sRed;
+    if (dst_b) {
+        const int col = tid & 63, part = tid >> 6;
+        float s8 = 0.f;
+        for (int s = part; s < Bk; s += 8) s8 += Dp[s * kWsPSW + col];
+        sB[part * 64 + col] = s8;
+        __syncthreads();
+    }
+    double q = 0.0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x4 acc = t ? acc1 : acc0;
+        const int i = i0 + 16 * (ip + t) + (lane & 15);
+        if (i < i_valid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + 16 * ot4 + 4 * (lane >> 4) + r;
+                dstW[(long)o * ldw + i] = acc[r];
+                q += (double)(acc[r] * sc) * (acc[r] * sc);
+            }
+        }
+    }
+    if (dst_b && tid < 64) {
+        float s8 = 0.f;
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) s8 += sB[p8 * 64 + tid];
+        dst_b[o0 + tid] = s8;
+        q += (double)(s8 * sc) * (s8 * sc);
+    }
+    return q;
+}
+
 struct WsArgs { UpdateDev u; WsDev ws; };
 typedef const WsArgs __attribute__((address_space(4))) KWsArgs;
 
@@ -410,7 +477,7 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
     unsigned epoch = 0;
 #ifdef PPOAF_WS_STAMPS
     unsigned long long t_prev = 0;
-    if (which == PPOAF_WS_STAMP_NET && w == 0 && threadIdx.x == 0)
+    if (which == PPOAF_WS_STAMP_NET && w == PPOAF_WS_STAMP_WORKER && threadIdx.x == 0)
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
 #endif
 
@@ -444,6 +511,7 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
         float* hbuf = ws.hbuf[which];
         float* dbuf = ws.dbuf[which];
         float* outpart = ws.outpart[which];
+        float* xbuf = ws.xbuf[which];
         const long plane = (long)Bp * H;
         const float* xsrc = which == 0 ? u.obs : u.critic_obs;
         const long mb = cursor0 + it;
@@ -495,8 +563,10 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
                     if (i < nck) sA[(r16 + 32 * ps) * AS + kq + 16 * i] = xa[ps * 4 + i];
+                    if (ct == 0) xbuf[(long)(rt * 64 + r16 + 32 * ps) * 64 + kq + 16 * i] = i < nck ? xa[ps * 4 + i] : 0.f;
+                }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < nck) sW[r16 * AS + kq + 16 * i] = wv[i];
@@ -542,8 +612,15 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
                     w0v[i] = ld1<true>(P + (long)r * in_dim + (k < in_dim ? k : 0));
                 }
                 const float b0v = tid < H ? ld1<true>(P + offB(0) + tid) : 0.f;
-                sX0[r8 * 20 + k2] = (di >= 0 && k2 < in_dim) ? x_a : 0.f;
-                sX0[r8 * 20 + k2 + 1] = (di >= 0 && k2 + 1 < in_dim) ? x_b : 0.f;
+                const float xa0 = (di >= 0 && k2 < in_dim) ? x_a : 0.f, xb0 = (di >= 0 && k2 + 1 < in_dim) ? x_b : 0.f;
+                sX0[r8 * 20 + k2] = xa0;
+                sX0[r8 * 20 + k2 + 1] = xb0;
+                if (ct == 0) {
+                    float* xr = xbuf + (long)(rt * 64 + r8) * 64;
+                    xr[k2] = xa0; xr[k2 + 1] = xb0;
+#pragma unroll
+                    for (int kk = 16; kk < 64; kk += 16) { xr[kk + k2] = 0.f; xr[kk + k2 + 1] = 0.f; }
+                }
 #pragma unroll
                 for (int i = 0; i < H * 16 / kThreadsU; ++i) {
                     const int e = tid + i * kThreadsU, r = e >> 4, k = e & 15;
@@ -782,49 +859,55 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
             __syncthreads();
         };
 
-        // WG(l): dW_l[32 outputs][32 inputs] = D_l^T . h_{l-1} over all rows (h_{-1} = the inputs), db_l with input tile 0
+        // WG(l): one tile of dW_l = D_l^T . h_{l-1} over all rows (h_{-1} = the inputs), db_l with input tile 0.
+        // Tiles are 64 x 64 when both [Bk][68] panels fit in LDS (B <= 256, H >= 64), else 32 x 32 with a K split.
+        const bool wide = H >= 64 && Bk <= 256;
+        const int TW = wide ? 64 : 32, PSW = wide ? kWsPSW : kWsPS;
+        const int n_ot = H / TW, n_it0 = (in_dim + TW - 1) / TW;
+        auto n_wg_jobs = [&](const int l) { return n_ot * (l >= 1 ? n_ot : n_it0); };
         auto wgrad_job = [&](const int l, const int jj) {
             const float* Dl = dbuf + (long)l * plane;
-            const int n_it = l >= 1 ? nct : (in_dim + 31) >> 5;
+            const int n_it = l >= 1 ? n_ot : n_it0;
             const int ot = jj / n_it, itile = jj - ot * n_it;
-            float* sD = sP;                                   // D_l[:, ot*32 .. +32]      [Bk][kWsPS]
-            float* sX = sP + Bk * kWsPS;                      // h_{l-1}[:, it*32 .. +32]  [Bk][kWsPS]
+            float* sD = sP;                                   // D_l[:, ot*TW .. +TW]      [Bk][PSW]
+            float* sX = sP + Bk * PSW;                        // h_{l-1}[:, it*TW .. +TW]  [Bk][PSW]
             WsPanel<32, 512> rd;
-            ws_panel_issue(rd, Dl, H, 0, Bk, (int)B, ot * 32, tid);
+            WsPanel<64, 256> rdw;
+            if (wide) ws_panel_issue(rdw, Dl, H, 0, Bk, (int)B, ot * 64, tid);
+            else ws_panel_issue(rd, Dl, H, 0, Bk, (int)B, ot * 32, tid);
             if (l >= 1) {
-                WsPanel<32, 512> rx;
-                ws_panel_issue(rx, hbuf + (long)(l - 1) * plane, H, 0, Bk, (int)B, itile * 32, tid);
-                ws_panel_commit(rx, sX, kWsPS, Bk, tid);
+                if (wide) {
+                    WsPanel<64, 256> rx;
+                    ws_panel_issue(rx, hbuf + (long)(l - 1) * plane, H, 0, Bk, (int)B, itile * 64, tid);
+                    ws_panel_commit(rx, sX, kWsPSW, Bk, tid);
+                } else {
+                    WsPanel<32, 512> rx;
+                    ws_panel_issue(rx, hbuf + (long)(l - 1) * plane, H, 0, Bk, (int)B, itile * 32, tid);
+                    ws_panel_commit(rx, sX, kWsPS, Bk, tid);
+                }
             } else {
-                // input columns [itile * 32, +32) of all rows (gathered): cp (power of two >= the valid columns)
-                // threads per row; the columns beyond the valid ones are zero
-                const int k0 = itile * 32, ncv = in_dim - k0 < 32 ? in_dim - k0 : 32;
-                const int shc = ncv <= 1 ? 0 : 32 - __clz(ncv - 1), cp = 1 << shc, rpp = kThreadsU >> shc;
-                const int c = tid & (cp - 1), r = tid >> shc;
-                for (int s0 = 0; s0 < Bk; s0 += 8 * rpp) {
-                    float xv[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int s = s0 + q * rpp + r;
-                        const int di = s < Bk ? sDi[s < Bp ? s : 0] : -1;
-                        const float v = xsrc[(long)(di >= 0 ? di : 0) * in_dim + k0 + (c < ncv ? c : 0)];
-                        xv[q] = (di >= 0 && c < ncv) ? v : 0.f;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int s = s0 + q * rpp + r;
-                        if (s < Bk) {
-                            sX[s * kWsPS + c] = xv[q];
-                            for (int cc = c + cp; cc < 32; cc += cp) sX[s * kWsPS + cc] = 0.f;
-                        }
-                    }
+                // the inputs of the mini-batch were published (gathered, zero padded to 64 columns) by the forward jobs
+                if (wide) {
+                    WsPanel<64, 256> rx;
+                    ws_panel_issue(rx, xbuf, 64, 0, Bk, Bp, 0, tid);
+                    ws_panel_commit(rx, sX, kWsPSW, Bk, tid);
+                } else {
+                    WsPanel<32, 512> rx;
+                    ws_panel_issue(rx, xbuf, 64, 0, Bk, Bp, itile * 32, tid);
+                    ws_panel_commit(rx, sX, kWsPS, Bk, tid);
                 }
             }
-            ws_panel_commit(rd, sD, kWsPS, Bk, tid);
+            if (wide) ws_panel_commit(rdw, sD, kWsPSW, Bk, tid);
+            else ws_panel_commit(rd, sD, kWsPS, Bk, tid);
             __syncthreads();
             const long ldw = l >= 1 ? H : in_dim;
-            sumsq += ws_wgrad_tile(sD, sX, sRed, Bk, G + offW(l), ldw, ot * 32, itile * 32, (int)ldw,
-                                   itile == 0 ? G + offB(l) : nullptr, u.grad_scale, tid, wave, lane);
+            float* dst_b = itile == 0 ? G + offB(l) : nullptr;
+            if (wide)
+                sumsq += ws_wgrad_tile_wide(sD, sX, sRed, Bk, G + offW(l), ldw, ot * 64, itile * 64, (int)ldw, dst_b,
+                                            u.grad_scale, tid, wave, lane);
+            else
+                sumsq += ws_wgrad_tile(sD, sX, sRed, Bk, G + offW(l), ldw, ot * 32, itile * 32, (int)ldw, dst_b,
+                                       u.grad_scale, tid, wave, lane);
             __syncthreads();
         };
 
@@ -898,49 +981,37 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
         PPOAF_WS_BARRIER(2)
 
         // ================================================================ backward
-        if (!tail) {
-            for (int l = depth - 1; l >= 0; --l) {
-                const int n_dg = l >= 1 ? n_tile : 0;
-                const int n_wg = nct * (l >= 1 ? nct : (in_dim + 31) >> 5);
-                const int n_jobs = n_dg + n_wg + (l == depth - 1 ? 1 : 0);
-                for (int j = w; j < n_jobs; j += W) {
-                    if (j < n_dg) dgrad_job(l, j);
-                    else if (j < n_dg + n_wg) wgrad_job(l, j - n_dg);
-                    else out_job();
-                }
-                if (l == 0) {
-                    bookkeeping();
-                    const double q = block_sum(sumsq, s_red);
-                    if (tid == 0) ctl->norm_partials[which][w] = q;
-                }
-                const int stamp = l == 0 ? 8 : (l == depth - 1 ? 4 : 6);
-                (void)stamp;
-                PPOAF_WS_BARRIER(stamp)
-            }
-        } else {
-            // D_{d-1} and D_{d-2} are known.  {DG(m), WG(m+1)} for m = d-2 .. 1, then {WG(1), WG(0), OUT}
-            for (int m = depth - 2; m >= 1; --m) {
-                const int n_jobs = n_tile + nct * nct;
-                for (int j = w; j < n_jobs; j += W) {
+        // D_{d-1} is known (and D_{d-2} after a tail phase).  {DG(m) -> D_{m-1}, WG(m+1)} for m = m0 .. 1, then
+        // {WG(1), WG(0), OUT, bookkeeping}: every wgrad runs one phase after the dgrad that produced its D.
+        for (int m = tail ? depth - 2 : depth - 1; m >= 1; --m) {
+            const int n_w = m + 1 <= depth - 1 ? n_wg_jobs(m + 1) : 0;
+            if (n_w > 0 && 2 * n_w <= W) {
+                // a wgrad tile costs about two dgrad tiles: the last n_w workers take one wgrad tile each, the dgrad
+                // tiles go round the others
+                const int n_d = W - n_w;
+                if (w >= n_d) wgrad_job(m + 1, w - n_d);
+                else for (int j = w; j < n_tile; j += n_d) dgrad_job(m, j);
+            } else {
+                for (int j = w; j < n_tile + n_w; j += W) {
                     if (j < n_tile) dgrad_job(m, j);
                     else wgrad_job(m + 1, j - n_tile);
                 }
-                PPOAF_WS_BARRIER(4)
             }
-            {
-                const int n1 = nct * nct, n0 = nct * ((in_dim + 31) >> 5);
-                const int n_jobs = n1 + n0 + 1;
-                // the single OUT job first (worker 0 of a 21-job phase would otherwise run two tiles)
-                for (int j = W - 1 - w; j < n_jobs; j += W) {
-                    if (j < n1) wgrad_job(1, j);
-                    else if (j < n1 + n0) wgrad_job(0, j - n1);
-                    else out_job();
-                }
-                bookkeeping();
-                const double q = block_sum(sumsq, s_red);
-                if (tid == 0) ctl->norm_partials[which][w] = q;
-                PPOAF_WS_BARRIER(8)
+            PPOAF_WS_BARRIER(4)
+        }
+        {
+            const int n1 = depth >= 2 ? n_wg_jobs(1) : 0, n0 = n_wg_jobs(0);
+            const int n_jobs = n1 + n0 + 1;
+            // the bookkeeping worker (W - 1) gets a tile only when there are more jobs than other workers
+            for (int j = w; j < n_jobs; j += W) {
+                if (j < n1) wgrad_job(1, j);
+                else if (j < n1 + n0) wgrad_job(0, j - n1);
+                else out_job();
             }
+            bookkeeping();
+            const double q = block_sum(sumsq, s_red);
+            if (tid == 0) ctl->norm_partials[which][w] = q;
+            PPOAF_WS_BARRIER(8)
         }
 
         // ================================================================ clip + Adam on this worker's columns of the
@@ -1021,7 +1092,7 @@ __device__ __forceinline__ void rt_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
     unsigned epoch = 0;
 #ifdef PPOAF_WS_STAMPS
     unsigned long long t_prev = 0;
-    if (which == PPOAF_WS_STAMP_NET && w == 0 && threadIdx.x == 0)
+    if (which == PPOAF_WS_STAMP_NET && w == PPOAF_WS_STAMP_WORKER && threadIdx.x == 0)
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
 #endif
     for (int it = 0; it < n_mb; ++it) {
@@ -1188,7 +1259,7 @@ static size_t ws_lds_floats(const NetDev& n, long B) {
     const size_t H = n.H, in_pad = (n.in_dim + 15) & ~15, Bk = (B + 15) & ~15L;
     const size_t K = in_pad > H ? in_pad : H;
     size_t p = 96 * (K + 4) + 64 * 20 + H * 20 + H;                      // forward: A [64][K+4] + W [32][K+4] (+ on-the-fly layer 0)
-    const size_t dg = 64 * (H + 4) + H * kWsPS, wg = 2 * Bk * kWsPS;
+    const size_t dg = 64 * (H + 4) + H * kWsPS, wg = 2 * Bk * ((H >= 64 && Bk <= 256) ? kWsPSW : kWsPS);
     size_t hd = 16 * (H + 4) + 8 * H + 16;                               // head
     if (H <= 128) hd += 32 * (H + 4) + H + H * (H + 4);                  //   + tail: h_{d-2}, D_{d-1}, b_{d-1}, W_{d-1}
     if (dg > p) p = dg;
@@ -1212,10 +1283,12 @@ static size_t ws_layout(const UpdateDev& u, WsDev* ws, char* base) {
         const NetDev& n = u.net[w];
         const size_t plane = (size_t)n.depth * Bp * n.H;
         const size_t oh = take(plane), od = take(plane), oo = take((size_t)((u.B + 15) / 16) * ws_seg_len(n));
+        const size_t ox = take((size_t)Bp * 64);
         if (ws) {
             ws->hbuf[w] = reinterpret_cast<float*>(base + oh);
             ws->dbuf[w] = reinterpret_cast<float*>(base + od);
             ws->outpart[w] = reinterpret_cast<float*>(base + oo);
+            ws->xbuf[w] = reinterpret_cast<float*>(base + ox);
         }
     }
     if (ws) ws->Bp = (int)Bp;
