@@ -440,11 +440,12 @@ class FusedPolicyUpdate:
             workers = int(os.environ.get("PPOAF_WS_WORKERS", "32"))
             xa, xc = int(os.environ.get("PPOAF_WS_XCC_ACTOR", "0")) % 8, int(os.environ.get("PPOAF_WS_XCC_CRITIC", "1")) % 8
             st = K.stream()
+            wait_s = float(os.environ.get("PPOAF_WS_WAIT_SECONDS", "2.0"))    # bound of every in-kernel wait
             while left > 0:
                 n = min(left, self.ws_chunk)
                 ev = self.ws_timing_events.pop() if getattr(self, "ws_timing_events", None) else (None, None)
                 _lib.check(self._lib.ppoaf_ppo_update_ws(C.byref(args), n, ctl.data_ptr(), wsb.data_ptr(), wsb.numel(), workers,
-                                                         xa, xc, self._ws_mask(), 2.0, ev[0], ev[1], st), "ppo_update_ws")
+                                                         xa, xc, self._ws_mask(), wait_s, ev[0], ev[1], st), "ppo_update_ws")
                 self._ws_used = True
                 FusedPolicyUpdate.ws_launch_count += 1
                 left -= n

@@ -97,3 +97,23 @@ def test_every_entry_point_sits_under_a_reference_citation():
     for needle in ("episode_info.py:223-293", "ppo.py:2325-2333", "mpi_utils.py:65-86", "filter_wrappers.py:155-268",
                    "mat_policy.py:441-519"):
         assert needle in src, needle
+
+
+def test_two_xcd_kernel_completion_guard_raises_on_the_host():
+    """
+    The persistent update kernel reports through its control block (tickets[2], error word, networks finished); the host
+    side must raise -- never train on -- when a wait ran out of its budget or a network's worker group never ran
+    (e.g. a partition mode that exposes one XCD).  Pure host logic: checked on fabricated control blocks.
+    """
+    import types
+    import pytest
+    import torch
+    from ppo_and_friends_amd import _lib
+    from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
+    ok = types.SimpleNamespace(_ws_ctl=torch.tensor([32, 32, 0, 2] + [0] * 12, dtype=torch.int32), _ws_used=True)
+    FusedPolicyUpdate._check_persistent(ok)                      # complete launch: silent, flag consumed
+    assert ok._ws_used is False
+    for words in ([32, 32, 1, 1], [32, 0, 0, 1], [32, 32, 0, 0]):
+        bad = types.SimpleNamespace(_ws_ctl=torch.tensor(words + [0] * 12, dtype=torch.int32), _ws_used=True)
+        with pytest.raises(_lib.PpoafError, match="did not complete"):
+            FusedPolicyUpdate._check_persistent(bad)

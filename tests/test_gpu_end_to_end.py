@@ -1504,3 +1504,4 @@ def test_full_pipeline_fuzz_fused_equals_torch():
         np.testing.assert_allclose(i0, i1, rtol=3e-4, atol=5e-5)
 
     run()
+
