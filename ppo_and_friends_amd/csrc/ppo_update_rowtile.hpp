@@ -31,9 +31,15 @@ static __device__ unsigned long long g_ppo_update_stamps[2][16];
 // NT = true (single-XCD persistent kernel): everything another CU of the same launch rewrites between mini-batches --
 // the parameter bucket, the value-normaliser slots -- is read with L1-bypassing loads; mb_extra = the mini-batch's
 // position inside the launch's chunk.
-template <int HT, bool NT = false, typename U = UpdateDev>
+// `before_weights` (persistent forms only, NT = true): called once by every thread after the mini-batch's row / index /
+// statistics loads and BEFORE the first load of a parameter -- the two-XCD kernel waits there for the previous
+// mini-batch's Adam phase, so that barrier's latency overlaps the dependent index loads.  Returning false abandons the
+// body (a bounded wait ran out).
+struct RowtileNoHook { __device__ __forceinline__ bool operator()() const { return true; } };
+
+template <int HT, bool NT = false, typename U = UpdateDev, typename Hook = RowtileNoHook>
 __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int which, const int g,
-                                                        const long mb_extra = 0) {
+                                                        const long mb_extra = 0, Hook before_weights = Hook()) {
     constexpr int H = 16 * HT, HS = H + 4;                 // which: 0 actor, 1 critic; g: 16-row block
     int tid_ = threadIdx.x;
     if (NT) {     // persistent form: nothing derived from the lane id may be hoisted out of the caller's mini-batch loop
@@ -93,25 +99,10 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     const bool has_tile = wave < HT;          // waves beyond the tile count idle in MFMA phases (H < 128)
     const bool deep = depth == 3 && HT <= kNW && !dbg;
     float4 fr[HT], fr2[HT];
-    if (deep && has_tile) {
-        load_fwd_frags<HT, NT>(P + offW(1), wave * 16, lane, fr);
-        load_fwd_frags<HT, NT>(P + offW(2), wave * 16, lane, fr2);
-    }
-    // first layer with at most 16 inputs: its 4 weight values per lane are requested here as well
+    // first layer with at most 16 inputs: its 4 weight values per lane are requested early as well
     const bool l0_pre = in_dim <= 16 && HT <= kNW && has_tile && !dbg;
     float l0w[4] = {0.f, 0.f, 0.f, 0.f};
-    if (l0_pre) {
-        const float* w = P + offW(0) + (long)(wave * 16 + (lane & 15)) * in_dim;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int k = 4 * j + (lane >> 4); if (k < in_dim) l0w[j] = ld1<NT>(w + k); }
-    }
-
-    // The weights were rewritten by the Adam kernel a moment ago, so this XCD's L2 does not hold them:
-    // the first touch of every 128-B line of the network is requested here, before anything else, so
-    // the misses overlap the index / gather / first-layer phases instead of stalling the hidden layers.
     float l2_touch = 0.f;
-    if (!deep && !NT) for (long i = (long)tid * 32; i < nd.size; i += (long)kThreadsU * 32) l2_touch += P[i];
-
     // biases and output-layer weights: requested into registers now, stored to LDS after the row loads
     // below have been issued too -- one wait covers all of them (a store in between would serialise
     // the cold misses: this bucket was rewritten by the Adam kernel a moment ago)
@@ -119,15 +110,33 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     float bias_reg[kCopyRegs], wout_reg[kCopyRegs];
     const int n_bias = (depth + 1) * H, n_wout = out_dim * H;
     const bool copy_fits = n_bias <= kCopyRegs * kThreadsU && n_wout <= kCopyRegs * kThreadsU;
-    if (copy_fits) {
-#pragma unroll
-        for (int r = 0; r < kCopyRegs; ++r) {
-            const int i = tid + r * kThreadsU;
-            bias_reg[r] = 0.f; wout_reg[r] = 0.f;
-            if (i < n_bias) { const int l = i / H, j = i - l * H; if (l < depth || j < out_dim) bias_reg[r] = ld1<NT>(P + offB(l) + j); }
-            if (i < n_wout) wout_reg[r] = ld1<NT>(P + offW(depth) + i);
+    auto request_weights = [&]() {
+        if (deep && has_tile) {
+            load_fwd_frags<HT, NT>(P + offW(1), wave * 16, lane, fr);
+            load_fwd_frags<HT, NT>(P + offW(2), wave * 16, lane, fr2);
         }
-    }
+        if (l0_pre) {
+            const float* w = P + offW(0) + (long)(wave * 16 + (lane & 15)) * in_dim;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int k = 4 * j + (lane >> 4); if (k < in_dim) l0w[j] = ld1<NT>(w + k); }
+        }
+        // The weights were rewritten by the Adam kernel a moment ago, so this XCD's L2 does not hold them:
+        // the first touch of every 128-B line of the network is requested here, before anything else, so
+        // the misses overlap the index / gather / first-layer phases instead of stalling the hidden layers.
+        if (!deep && !NT) for (long i = (long)tid * 32; i < nd.size; i += (long)kThreadsU * 32) l2_touch += P[i];
+        if (copy_fits) {
+#pragma unroll
+            for (int r = 0; r < kCopyRegs; ++r) {
+                const int i = tid + r * kThreadsU;
+                bias_reg[r] = 0.f; wout_reg[r] = 0.f;
+                if (i < n_bias) { const int l = i / H, j = i - l * H; if (l < depth || j < out_dim) bias_reg[r] = ld1<NT>(P + offB(l) + j); }
+                if (i < n_wout) wout_reg[r] = ld1<NT>(P + offW(depth) + i);
+            }
+        }
+    };
+    // three-launch chain: the weights first (cold misses, nothing to wait for).  Persistent forms: the row loads
+    // first, then the hook (the wait for the previous Adam phase), then the weights (L2 hits).
+    if (!NT) request_weights();
 
     if (tid < kRows) {
         const long s = (long)g * kRows + tid;
@@ -198,6 +207,10 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
             sMisc[2] = m; sMisc[3] = v;
             if (g == 0) { u.vn_mean[slot ^ 1] = m; u.vn_var[slot ^ 1] = v; u.vn_count[slot ^ 1] = cnt; }
         }
+    }
+    if (NT) {
+        if (!before_weights()) return;
+        request_weights();
     }
     if (copy_fits) {
 #pragma unroll

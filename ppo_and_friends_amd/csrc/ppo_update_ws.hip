@@ -1,13 +1,16 @@
-// K12, weight-stationary persistent form: ONE launch runs n_mb consecutive PPO mini-batches (ppo.py:2292-2469)
-// for MLP actor / critic networks, single rank.
+// K12, two-XCD persistent form: ONE launch runs n_mb consecutive PPO mini-batches (ppo.py:2292-2469) for MLP actor /
+// critic networks, single rank.  Each network has its own group of W <= 32 workgroups ("workers"), all on one XCD,
+// and one of two decompositions of the mini-batch:
 //
-// Why a second decomposition.  The row-tiled chain (ppo_update.hip) gives every workgroup 16 rows and has it stream
-// the network's whole weight set, twice, per mini-batch; B = 256 rows fill 16 workgroups per network and a 256-wide
-// critic workgroup sits at its own f32-MFMA floor (~20 us).  Here the mini-batch is processed LAYER BY LAYER over all
-// of its rows: a phase is a set of independent 64x32 (forward / dgrad) or 32x32 (wgrad, K = all rows) output tiles,
-// each needing one slice of a weight matrix and one slice of an activation matrix, spread over W <= 32 workgroups
-// per network.  Weight gradients are complete sums over the mini-batch where they are produced -- no slabs, no
-// reduce pass -- and the owner of a parameter column applies clip + Adam to it in the same launch.
+//  * ROW-TILED (widths <= 128): the three-launch chain's fwd_bwd body on ceil(B/16) workers, then the slab fold and
+//    clip + Adam by parameter-column owners, with the folded gradient held in registers in between.
+//  * LAYERED / weight-stationary (256-wide networks).  The row-tiled chain gives every workgroup 16 rows and has it
+//    stream the network's whole weight set, twice, per mini-batch: a 256-wide critic workgroup then sits at its own
+//    f32-MFMA floor (~20 us).  Layered, the mini-batch is processed LAYER BY LAYER over all of its rows: a phase is a
+//    set of independent 64x32 (forward / dgrad) or 64x64 (wgrad, K = all rows) output tiles, each needing one slice
+//    of a weight matrix and one slice of an activation matrix, spread over the workers.  Weight gradients are complete
+//    sums over the mini-batch where they are produced -- no slabs, no reduce pass -- and the owner of a parameter
+//    column applies clip + Adam to it.
 //
 // What makes that affordable on MI355X: the W workers of a network are all placed on ONE XCD (HW_REG_XCC_ID + a
 // ticket, as in the single-XCD persistent form of ppo_update.hip; actor and critic take two different XCDs and never
@@ -15,14 +18,18 @@
 // dependent load, measured with tools/probes/xcd_persist_probe.hip) and everything a phase hands to the next --
 // activations, dz, gradients, the rewritten parameters -- is an L2 hit read with L1-bypassing loads.
 //
-// Phases of one mini-batch (depth d hidden layers; z_l = W_l h_{l-1} + b_l, h_l = act(z_l), D_l = dLoss/dz_l):
-//   F(0..d-1)   h_l tiles                                             | barrier after each
+// Phases of one mini-batch of a LAYERED network (depth d hidden layers; z_l = W_l h_{l-1} + b_l, h_l = act(z_l),
+// D_l = dLoss/dz_l; a flag barrier after each line):
+//   F(0..d-1)   h_l tiles
 //   HEAD        per 16-row block: output layer, distribution head, losses, d out, D_{d-1}, output-layer gradient
 //               partials (K6 + K3; same device code as the row-tiled kernel)
-//   BW(d-1..1)  D_{l-1} tiles (dgrad)  +  dW_l / db_l tiles (wgrad)  [+ output-layer partials -> gradient]
-//   W0          dW_0 / db_0 tiles, loss bookkeeping, squared-norm partials
+//   {DG(m), WG(m+1)} for m = d-1 .. 1   D_{m-1} tiles (dgrad) beside the dW_{m+1} / db_{m+1} tiles (wgrad) of the layer above
+//   {WG(1), WG(0), OUT}                  the last weight-gradient tiles, output-layer partials -> gradient, loss
+//                                        bookkeeping, squared-norm partials
 //   ADAM        clip + Adam on this worker's parameter columns
-// Summation orders are fixed (K order inside a tile, K halves, workers in index order): bitwise reproducible.
+// (see ws_worker for the fused variants at widths <= 128).  A ROW-TILED network (rt_worker) has three phases: the
+// three-launch chain's fwd_bwd body, the slab fold into registers, clip + Adam on those registers.
+// Summation orders are fixed (K order inside a tile, K halves, blocks and workers in index order): bitwise reproducible.
 #include "ppo_update_rowtile.hpp"
 #include <hip/hip_ext.h>
 #include <cstdlib>
@@ -71,13 +78,16 @@ struct WsCtl {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ppo_update_ws_smem[];
 
-// All W workers of network `which` arrive; false when the wait ran out of its budget (error word set).
-// One poll = ONE load instruction: lanes < W read the workers' flag words, lane 63 the error word.
-__device__ __forceinline__ bool ws_barrier(WsCtl* c, const int which, const int w, const int W, const unsigned epoch,
-                                           const long long budget, int* s_ok) {
+// Flag barrier of the W workers of network `which`, in two halves.  arrive: this worker's stores have reached the L2,
+// its flag word says so.  wait: all W flags have reached `epoch`; false when the wait ran out of its budget (error
+// word set).  One poll = ONE load instruction: lanes < W read the workers' flag words, lane 63 the error word.
+__device__ __forceinline__ void ws_arrive(WsCtl* c, const int which, const int w, const unsigned epoch) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's stores have reached the L2
     __syncthreads();
     if (threadIdx.x == 0) *(volatile unsigned*)&c->flags[which][w] = epoch;   // plain store: the line stays in this XCD's L2
+}
+__device__ __forceinline__ bool ws_wait(WsCtl* c, const int which, const int W, const unsigned epoch, const long long budget,
+                                        int* s_ok) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const unsigned* word = lane < W ? &c->flags[which][lane] : &c->error;
@@ -95,6 +105,11 @@ __device__ __forceinline__ bool ws_barrier(WsCtl* c, const int which, const int 
     }
     __syncthreads();
     return *s_ok != 0;
+}
+__device__ __forceinline__ bool ws_barrier(WsCtl* c, const int which, const int w, const int W, const unsigned epoch,
+                                           const long long budget, int* s_ok) {
+    ws_arrive(c, which, w, epoch);
+    return ws_wait(c, which, W, epoch, budget, s_ok);
 }
 
 // ---- 16x16 output tile of one wave, K in chunks of 16 (four v_mfma_f32_16x16x4_f32 each; the k order inside a
@@ -124,37 +139,6 @@ __device__ __forceinline__ f32x4 ws_mfma_row_row(const float* __restrict__ A, co
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
-    }
-    return acc0 + acc1;
-}
-
-__device__ __forceinline__ f32x4 ws_mfma_row_col(const float* __restrict__ A, const int stride, const float* __restrict__ Bc,
-                                                 const int c0, const int c1, const int lane) {
-    const float* a = A + (lane & 15) * stride + 4 * (lane >> 4);
-    const float* b = Bc + (4 * (lane >> 4)) * kWsPS + (lane & 15);
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    int c = c0;
-    for (; c + 1 < c1; c += 2) {
-        const float4 a0 = *reinterpret_cast<const float4*>(a + 16 * c), a1 = *reinterpret_cast<const float4*>(a + 16 * c + 16);
-        const float* bp = b + (16 * c) * kWsPS;
-        const float b00 = bp[0], b01 = bp[kWsPS], b02 = bp[2 * kWsPS], b03 = bp[3 * kWsPS];
-        const float b10 = bp[16 * kWsPS], b11 = bp[17 * kWsPS], b12 = bp[18 * kWsPS], b13 = bp[19 * kWsPS];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b00, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b10, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b01, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b11, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b02, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b12, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b03, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b13, acc1, 0, 0, 0);
-    }
-    if (c < c1) {
-        const float4 a0 = *reinterpret_cast<const float4*>(a + 16 * c);
-        const float* bp = b + (16 * c) * kWsPS;
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bp[0], acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bp[kWsPS], acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bp[2 * kWsPS], acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bp[3 * kWsPS], acc0, 0, 0, 0);
     }
     return acc0 + acc1;
 }
@@ -276,29 +260,6 @@ __device__ __forceinline__ void ws_panel_commit(const WsPanel<NCOLS, MAXROWS>& R
     for (int it = 0; it < P::its; ++it) {
         const int rr = r + it * P::rpp;
         if (rr < nrows) *reinterpret_cast<float4*>(dst + rr * dstride + 4 * c4) = R.v[it];
-    }
-}
-
-// n scalar elements: element e is read from src(e, valid) -- always a readable address; valid = false: the value is
-// replaced by zero -- and stored to dst(e).  The loads of a chunk of 8 per thread are unconditional and issued before
-// its stores (one round trip per chunk).  NT: L1-bypassing (data another CU of this launch has rewritten).
-template <bool NT, typename SrcF, typename DstF>
-__device__ __forceinline__ void ws_fill_scalar(const int n, const int tid, SrcF src, DstF dst) {
-    for (int base = 0; base < n; base += 8 * kThreadsU) {
-        float v[8];
-        bool ok[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int e = base + k * kThreadsU + tid;
-            ok[k] = e < n;
-            const float* p = src(ok[k] ? e : 0, ok[k]);
-            v[k] = ld1<NT>(p);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int e = base + k * kThreadsU + tid;
-            if (e < n) *dst(e) = ok[k] ? v[k] : 0.f;
-        }
     }
 }
 
@@ -1016,15 +977,17 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
 
         // ================================================================ clip + Adam on this worker's columns of the
         // network; norm = partials in worker order.  The parameter / moment / gradient loads depend on nothing
-        // computed here, so they are requested first.
+        // computed here, so the first kWsAdamCols columns of every thread are requested before the norm is read.
         {
+            constexpr int kWsAdamCols = 3;
             const long lo4 = nd.offset >> 2, hi4 = (nd.offset + nd.size) >> 2;
-            const long idx0 = lo4 + (long)w * kThreadsU + tid;
-            const bool have0 = idx0 < hi4;
-            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), g0 = p0, m0 = p0, v0 = p0;
-            if (have0) {
-                p0 = ld4<true>(u.params + 4 * idx0); g0 = ld4<true>(u.grads + 4 * idx0);
-                m0 = ld4<true>(u.exp_avg + 4 * idx0); v0 = ld4<true>(u.exp_avg_sq + 4 * idx0);
+            const long idx0 = lo4 + (long)w * kThreadsU + tid, cstride = (long)W * kThreadsU;
+            float4 pp[kWsAdamCols], gg[kWsAdamCols], mm[kWsAdamCols], vv[kWsAdamCols];
+#pragma unroll
+            for (int c = 0; c < kWsAdamCols; ++c) {
+                const long ix = idx0 + c * cstride < hi4 ? idx0 + c * cstride : lo4;
+                pp[c] = ld4<true>(u.params + 4 * ix); gg[c] = ld4<true>(u.grads + 4 * ix);
+                mm[c] = ld4<true>(u.exp_avg + 4 * ix); vv[c] = ld4<true>(u.exp_avg_sq + 4 * ix);
             }
             if (tid < 64) {
                 const double part = lane < W ? ld1<true>(&ctl->norm_partials[which][lane]) : 0.0;
@@ -1051,10 +1014,14 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
                 v.c = beta2 * v.c + (1.0f - beta2) * gi * gi;            \
                 p.c = p.c - step_size * (m.c / (sqrtf(v.c) / bc2_sqrt + adam_eps)); \
             }
-            for (long idx = idx0; idx < hi4; idx += (long)W * kThreadsU) {
+            int c = 0;
+            for (long idx = idx0; idx < hi4; idx += cstride, ++c) {
                 float4 p, gr, m, v;
-                if (idx == idx0) { p = p0; gr = g0; m = m0; v = v0; }
-                else {
+                if (c < kWsAdamCols) {
+                    // (compile-time indices only: a runtime index would send the arrays to scratch)
+                    p = c == 0 ? pp[0] : (c == 1 ? pp[1] : pp[2]); gr = c == 0 ? gg[0] : (c == 1 ? gg[1] : gg[2]);
+                    m = c == 0 ? mm[0] : (c == 1 ? mm[1] : mm[2]); v = c == 0 ? vv[0] : (c == 1 ? vv[1] : vv[2]);
+                } else {
                     p = ld4<true>(u.params + 4 * idx); gr = ld4<true>(u.grads + 4 * idx);
                     m = ld4<true>(u.exp_avg + 4 * idx); v = ld4<true>(u.exp_avg_sq + 4 * idx);
                 }
@@ -1105,8 +1072,19 @@ __device__ __forceinline__ void rt_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
         const int tid = tid_l, lane = tid & 63;
         const int n_wg = u.n_wg;
 
-        // ---- phase 1: forward + backward of 16 rows -> this worker's slab, loss partials
-        if (w < n_wg) ppo_update_fwd_bwd_body<H / 16, true, KU>(u, which, w, it);
+        // ---- phase 1: forward + backward of 16 rows -> this worker's slab, loss partials.  The wait for the previous
+        //      mini-batch's Adam phase (its arrive is at the bottom of the loop) sits inside the body, after the row /
+        //      index loads and before the first parameter load.
+        {
+            const unsigned adam_epoch = epoch;
+            auto adam_done = [&]() -> bool { return it == 0 || ws_wait(ctl, which, W, adam_epoch, budget, s_ok); };
+            if (w < n_wg) {
+                ppo_update_fwd_bwd_body<H / 16, true, KU>(u, which, w, it, adam_done);
+                if (it > 0 && *s_ok == 0) return;
+            } else if (!adam_done()) {
+                return;
+            }
+        }
         PPOAF_WSTAMP(0);
         if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
         PPOAF_WSTAMP(1);
@@ -1132,13 +1110,13 @@ __device__ __forceinline__ void rt_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
         for (int c = 0; c < kRtCols; ++c) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx[c] < hi4) {                                       // uniform per wave except at the range end
-                for (int g0 = 0; g0 < n_wg; g0 += 8) {
-                    float4 t[8];
+                for (int g0 = 0; g0 < n_wg; g0 += 16) {              // 16 slabs in flight: one L2 round trip at B = 256
+                    float4 t[16];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
+                    for (int k = 0; k < 16; ++k)
                         t[k] = ld4<true>(reinterpret_cast<const float*>(sl + (long)(g0 + k < n_wg ? g0 + k : 0) * n4_all + idx[c]));
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
+                    for (int k = 0; k < 16; ++k)
                         if (g0 + k < n_wg) { acc.x += t[k].x; acc.y += t[k].y; acc.z += t[k].z; acc.w += t[k].w; }
                 }
                 sumsq += (double)(acc.x * sc) * (acc.x * sc) + (double)(acc.y * sc) * (acc.y * sc) +
@@ -1223,7 +1201,7 @@ __device__ __forceinline__ void rt_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
             }
         }
         PPOAF_WSTAMP(4);
-        if (!ws_barrier(ctl, which, w, W, ++epoch, budget, s_ok)) return;
+        ws_arrive(ctl, which, w, ++epoch);            // the matching wait is inside the next mini-batch's phase 1
         PPOAF_WSTAMP(5);
     }
     if (w == 0 && threadIdx.x == 0) {
