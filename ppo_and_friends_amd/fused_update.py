@@ -418,7 +418,11 @@ class FusedPolicyUpdate:
         """PPOAF_WS_MODE: auto (layered for 256-wide networks, row-tiled below), layered, rowtile, or a bit mask."""
         import os
         m = os.environ.get("PPOAF_WS_MODE", "auto")
-        return {"auto": -1, "layered": 3, "rowtile": 0}.get(m, None) if not m.lstrip("-").isdigit() else int(m)
+        if m.lstrip("-").isdigit():
+            return int(m)
+        if m not in ("auto", "layered", "rowtile"):
+            raise ValueError(f"PPOAF_WS_MODE={m!r}: expected auto, layered, rowtile or a bit mask (bit 0 actor, bit 1 critic)")
+        return {"auto": -1, "layered": 3, "rowtile": 0}[m]
 
     def _ws_buffers(self):
         need = self._ws_shape_reason[2]
