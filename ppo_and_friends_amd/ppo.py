@@ -855,7 +855,9 @@ class PPO:
             return False
         fused.begin_epoch(loader.epoch_permutation())
         fused_icm.begin_epoch(loader.epoch_permutation())
-        fused.ws_allowed = False          # two concurrent kernel chains: the persistent two-XCD kernel would serialise them
+        import os
+        # two concurrent kernel chains: the persistent two-XCD kernel would serialise them (experiment switch only)
+        fused.ws_allowed = os.environ.get("PPOAF_WS_WITH_ICM", "0") == "1"
         main = torch.cuda.current_stream()
         sa, sb = K.concurrent_stream_pair(self.device)         # two streams on different hardware queues
         sa.wait_stream(main); sb.wait_stream(main)
