@@ -425,7 +425,9 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
     float* smem = reinterpret_cast<float*>(ppo_update_ws_smem);
     int* sRow = reinterpret_cast<int*>(smem);                 // [512] dataset row of every mini-batch row (-1: dead)
     int* sDi = sRow + 512;                                    // [512] where its inputs are read from (-1: dead)
-    float* sMisc = smem + 1024;                               // [16]
+    float* sT0 = smem + 1024;                                 // [512] per row: advantage (actor) / rewards-to-go (critic)
+    float* sT1 = sT0 + 512;                                   // [512] per row: old log-prob (actor)
+    float* sMisc = smem + 2048;                               // [16]
     float* sRowF = sMisc + 16;                                // [3][16]
     float* sActF = sRowF + 48;                                // [16][8]
     float* sOut = sActF + 128;                                // [16][16]
@@ -479,19 +481,31 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
         const long base = mb * u.batch_stride;
         double sumsq = 0.0;
 
-        // ---- row table of the mini-batch
-        for (int s = tid; s < Bp; s += kThreadsU) {
-            int row = -1;
-            long di = -1;
-            if (s < B) {
-                const long p = u.perm[base + s];
-                if (p >= 0 && p < u.n_rows) row = u.row_map ? u.row_map[p] : (int)p;
-                di = u.pregathered ? base + s : row;
+        // ---- row table of a mini-batch: dataset row, where its inputs are read from, and the per-row scalars of the loss
+        //      (index chains and cold reads: built for mini-batch it + 1 while the Adam barrier of mini-batch it
+        //      propagates -- the table is dead after the HEAD phase -- so that none of it sits on the critical path)
+        auto build_row_table = [&](const long mbi) {
+            const long bs = mbi * u.batch_stride;
+            for (int s = tid; s < Bp; s += kThreadsU) {
+                int row = -1;
+                long di = -1;
+                if (s < B) {
+                    const long p = u.perm[bs + s];
+                    if (p >= 0 && p < u.n_rows) row = u.row_map ? u.row_map[p] : (int)p;
+                    di = u.pregathered ? bs + s : row;
+                }
+                const bool live = row >= 0;
+                const long dl = live ? di : 0;
+                const float t0 = which == 0 ? u.adv[dl] : u.rtg[dl];
+                const float t1 = which == 0 ? u.old_lp[dl] : 0.f;
+                sRow[s] = row;
+                sDi[s] = live ? (int)di : -1;
+                sT0[s] = live ? t0 : 0.f;
+                sT1[s] = live ? t1 : 0.f;
             }
-            sRow[s] = row;
-            sDi[s] = row >= 0 ? (int)di : -1;
-        }
-        __syncthreads();
+            __syncthreads();
+        };
+        if (it == 0) build_row_table(mb);
 
         // ================================================================ job bodies
         // forward layer 0 alone: h_0[64 rows][32 columns] tile, K = in_pad (<= 64): 16 threads per row, no divisions
@@ -646,20 +660,14 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
             if (tid < kRows) {
                 const int s = g * kRows + tid;
                 const int di = sDi[s];
-                float av = 0.f, lpo = 0.f, rt = 0.f;
-                if (di >= 0) {
-                    if (which == 0) {
-                        av = u.adv[di]; lpo = u.old_lp[di];
-                        if (u.head_kind == PPOAF_HEAD_CATEGORICAL)
-                            reinterpret_cast<int*>(sActF)[tid * 8] = (int)reinterpret_cast<const int64_t*>(u.raw_actions)[di];
-                        else
-                            for (int d = 0; d < out_dim; ++d)
-                                sActF[tid * 8 + d] = reinterpret_cast<const float*>(u.raw_actions)[(long)di * out_dim + d];
-                    } else {
-                        rt = u.rtg[di];
-                    }
+                if (di >= 0 && which == 0) {
+                    if (u.head_kind == PPOAF_HEAD_CATEGORICAL)
+                        reinterpret_cast<int*>(sActF)[tid * 8] = (int)reinterpret_cast<const int64_t*>(u.raw_actions)[di];
+                    else
+                        for (int d = 0; d < out_dim; ++d)
+                            sActF[tid * 8 + d] = reinterpret_cast<const float*>(u.raw_actions)[(long)di * out_dim + d];
                 }
-                sRowF[tid] = av; sRowF[16 + tid] = lpo; sRowF[32 + tid] = rt;
+                sRowF[tid] = which == 0 ? sT0[s] : 0.f; sRowF[16 + tid] = sT1[s]; sRowF[32 + tid] = which == 1 ? sT0[s] : 0.f;
             }
             if (tid == 64) {                                  // mini-batch statistics (as the row-tiled kernel's S0)
                 if (which == 0) {
@@ -1032,7 +1040,11 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
             }
 #undef PPOAF_ADAM1
         }
-        PPOAF_WS_BARRIER(10)
+        PPOAF_WSTAMP(10);
+        ws_arrive(ctl, which, w, ++epoch);
+        if (it + 1 < n_mb) build_row_table(mb + 1);
+        if (!ws_wait(ctl, which, W, epoch, budget, s_ok)) return;
+        PPOAF_WSTAMP(11);
 #undef PPOAF_WS_BARRIER
     }
     // the cursor moves once BOTH networks are done with the launch (each read it when it started)
@@ -1243,7 +1255,7 @@ static size_t ws_lds_floats(const NetDev& n, long B) {
     if (dg > p) p = dg;
     if (wg > p) p = wg;
     if (hd > p) p = hd;
-    return 1024 + 16 + 48 + 128 + 256 + 256 + 1536 + p;
+    return 2048 + 16 + 48 + 128 + 256 + 256 + 1536 + p;
 }
 
 static long ws_seg_len(const NetDev& n) {
