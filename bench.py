@@ -428,25 +428,30 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    update_note = None
-    try:
-        main_res = run_config(args.config, args, device, rank, world, args.steps, args.warmup, True)
-    except _lib.PpoafError as e:
-        # the two-XCD persistent kernel needs the GPU to itself (all CUs of two XCDs for an epoch); if its launch could
-        # not complete, say so in the line and measure the three-launch chain instead of printing nothing
-        if "ppo_update_ws" not in str(e) or os.environ.get("PPOAF_WS", "1") == "0":
-            raise
-        update_note = f"three-launch chain (the persistent kernel failed: {str(e)[:200]})"
-        print(f"[bench] {update_note}", file=sys.stderr, flush=True)
-        os.environ["PPOAF_WS"] = "0"
-        torch.cuda.synchronize()
-        main_res = run_config(args.config, args, device, rank, world, args.steps, args.warmup, True)
+    notes = {}
+
+    def run_measured(name, steps, warmup, with_gae):
+        """run_config; if the two-XCD persistent kernel (which needs the GPU to itself: all CUs of two XCDs for an
+        epoch) cannot complete its launch, say so in the line and measure the three-launch chain instead of nothing."""
+        try:
+            return run_config(name, args, device, rank, world, steps, warmup, with_gae)
+        except _lib.PpoafError as e:
+            if "ppo_update_ws" not in str(e) or os.environ.get("PPOAF_WS", "1") == "0":
+                raise
+            notes[name] = f"three-launch chain (the persistent kernel failed: {str(e)[:200]})"
+            print(f"[bench] {name}: {notes[name]}", file=sys.stderr, flush=True)
+            os.environ["PPOAF_WS"] = "0"
+            torch.cuda.synchronize()
+            return run_config(name, args, device, rank, world, steps, warmup, with_gae)
+
+    main_res = run_measured(args.config, args.steps, args.warmup, True)
+    update_note = notes.get(args.config)
     others = {}
     if args.config == "C2" and not args.no_other_configs:
         for name in CONFIGS:
             if name == "C2":
                 continue
-            r = run_config(name, args, device, rank, world, 2, 1, False)
+            r = run_measured(name, 2, 1, False)
             others[name] = {"value": r["value"], "unit": "env-steps/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
                             "warmup": r["warmup"], "workload": r["workload"],
                             "agent_steps_per_iteration": world * r["E"] * r["T"] * r["A"],

@@ -406,6 +406,11 @@ class FusedPolicyUpdate:
         if self.multi:
             return "N > 1: the gradient exchange sits between the gradient and the Adam phase (three-launch chain)"
         mask = self._ws_mask()
+        if mask < 0 and max(self.actor_desc.hidden, self.critic_desc.hidden) < 256:
+            # measured (C2, after the host-side shuffle prefetch stopped stalling): graph-replayed chain 29.4 us per
+            # mini-batch, persistent kernel with both networks row-tiled 32.4 us.  The persistent kernel wins where a
+            # network is layered (256-wide: C4 52 vs 74 us); PPOAF_WS_MODE=rowtile|layered forces it.
+            return "both networks narrower than 256: the graph-replayed three-launch chain is faster"
         cached = getattr(self, "_ws_shape_reason", None)
         if cached is None or cached[0] != (self.B, mask):
             need = C.c_int64(0)

@@ -108,15 +108,30 @@ class PermutationLoader:
         if g is None:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
             g = torch.Generator().manual_seed(seed)
-        # drawn into a pinned staging buffer that is allocated once (allocating pinned memory
-        # synchronises with the device and would serialise the prefetch behind the running epoch)
+        # drawn in ordinary (cached) host memory, then copied with one sequential pass into a pinned staging buffer that
+        # is allocated once (allocating pinned memory synchronises with the device and would serialise the prefetch
+        # behind the running epoch).
         c = self.prefetch_cache
-        buf = c.get("pinned")
+        buf, work = c.get("pinned"), c.get("work")
         if buf is None or buf.numel() != n:
             buf = torch.empty(n, dtype=torch.int64, pin_memory=torch.cuda.is_available())
-            c["pinned"] = buf
-        torch.randperm(n, generator=g, out=buf)
-        torch.randperm(n, generator=g)       # RandomSampler's trailing `randperm(n)[:num_samples % n]` draw
+            work = torch.empty(n, dtype=torch.int64)
+            c["pinned"], c["work"] = buf, work
+        # ONE intra-op thread for the draw: the shuffle is sequential anyway (1.8 ms for 524 288 indices with one thread,
+        # 5 ms with torch's default pool), and with the default pool on a host whose CPU quota is smaller than its core
+        # count (128 OpenMP threads on a 16-CPU share of the GPU boxes) single statements of this function stalled
+        # for 30-90 ms at random -- longer than the epoch the prefetch hides behind, which made whole training steps
+        # prefetch-bound (tools/probes/prefetch_probe.py).  The reference pins its thread count too (mpi_utils.py:37-48).
+        nt = torch.get_num_threads()
+        if nt > 1:
+            torch.set_num_threads(1)
+        try:
+            torch.randperm(n, generator=g, out=work)
+            buf.copy_(work)
+            torch.randperm(n, generator=g, out=work)   # RandomSampler's trailing `randperm(n)[:num_samples % n]` draw (discarded)
+        finally:
+            if nt > 1:
+                torch.set_num_threads(nt)
         return buf
 
     def prefetch(self):

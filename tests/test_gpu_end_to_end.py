@@ -120,6 +120,7 @@ def test_update_epochs_match_cpu_port(update_mode, use_graphs, monkeypatch):
     runs its three-launch chain (graph-replayed / eager) for use_graphs True / False and the two-XCD persistent kernel
     when use_graphs is None."""
     monkeypatch.setenv("PPOAF_WS", "0" if use_graphs is not None else "1")
+    monkeypatch.setenv("PPOAF_WS_MODE", "rowtile")      # (128-wide networks: "auto" would keep the chain)
     use_graphs = bool(use_graphs)
     E, T, B, epochs = 16, 32, 64, 2
     ppo = _make(E, T, B, epochs, use_graphs=use_graphs, update_mode=update_mode)

@@ -153,6 +153,7 @@ def test_k12_full_size_persistent_kernel_matches_the_chain_and_is_reproducible(n
     to run.
     """
     from ppo_and_friends_amd import fused_update
+    monkeypatch.setenv("PPOAF_WS_MODE", "rowtile" if name == "C2" else "auto")   # C2: "auto" would keep the chain
     outs = []
     for ws in ("1", "1", "0"):
         monkeypatch.setenv("PPOAF_WS", ws)
