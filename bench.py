@@ -407,6 +407,11 @@ def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: libraries chat on file descriptor 1 (RCCL prints its version banner
+    # there when the process group initialises), so everything but the final line is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     # dmabuf IPC (the K17 peer mappings, RCCL's own P2P): must be in the environment before HIP initialises
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -501,7 +506,8 @@ def main():
 
     out.update(cpu)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if mpi_utils.is_initialized():
         dist.destroy_process_group()
 
