@@ -360,8 +360,11 @@ def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline
     # which per-mini-batch gradient exchange the update loops actually used (N > 1 or its rehearsal)
     fused = [f for f in getattr(ppo, "_fused", {}).values() if f is not None]
     peer = bool(fused) and all(getattr(f, "xchg", None) is not None for f in fused)
+    from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
+    c_loop = FusedPolicyUpdate._rccl_comm_cache not in ("unset", None)
     exchange = None if not mpi_utils.distributed_path() else \
-        ("K17 peer mappings (xGMI), in-graph" if peer else "RCCL all-reduce, eager loop")
+        ("K17 peer mappings (xGMI), in-graph" if peer else
+         ("RCCL all-reduce, chain issued from C (ppoaf_ppo_update_chain_allreduce)" if c_loop else "RCCL all-reduce, eager loop"))
     if exchange is not None and fused:                       # why that path (self-test verdict / fallback reason)
         exchange += f" [{getattr(fused[0], 'xchg_reason', '')}]"
     res["gradient_exchange"], res["peer"] = exchange, peer

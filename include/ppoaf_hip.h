@@ -742,10 +742,17 @@ typedef struct ppoaf_comm ppoaf_comm_t;
 int ppoaf_comm_unique_id(void* out /* host, PPOAF_COMM_UNIQUE_ID_BYTES */);
 int ppoaf_comm_init(int rank, int world, const void* unique_id, ppoaf_comm_t** out);
 int ppoaf_allreduce_avg_f32(ppoaf_comm_t* comm, float* buf, int64_t n, ppoaf_stream_t stream);
+int ppoaf_allreduce_sum_f32(ppoaf_comm_t* comm, float* buf, int64_t n, ppoaf_stream_t stream);   /* sum only */
 int ppoaf_bcast_f32(ppoaf_comm_t* comm, float* buf, int64_t n, int root, ppoaf_stream_t stream);
 int ppoaf_allgather_moments(ppoaf_comm_t* comm, const double* record, int64_t n_doubles, double* out,
                             ppoaf_stream_t stream);
 int ppoaf_comm_destroy(ppoaf_comm_t* comm);
+/* mpi_avg_gradients at its per-mini-batch call site (ppo.py:2443-2448) when the K17 peer exchange is not available:
+ * fwd_bwd -> reduce -> RCCL sum all-reduce of the gradient bucket -> norms + clip + Adam for n_minibatches consecutive
+ * mini-batches (cursor .. cursor + n - 1; the cursor advances by n), all launches issued from this one call (the
+ * 1 / world factor is args->grad_scale, as in the three-launch chain).  mb_offset must be 0. */
+int ppoaf_ppo_update_chain_allreduce(const ppoaf_ppo_update_args_t* args, ppoaf_comm_t* comm, int64_t n_minibatches,
+                                     ppoaf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -219,6 +219,8 @@ SIGNATURES = {
     "ppoaf_comm_init": (C.c_int, [C.c_int, C.c_int, _ptr, C.POINTER(C.c_void_p)]),
     "ppoaf_allreduce_avg_f32": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr]),
     "ppoaf_bcast_f32": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int, _ptr]),
+    "ppoaf_allreduce_sum_f32": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr]),
+    "ppoaf_ppo_update_chain_allreduce": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_int64, _ptr]),
     "ppoaf_allgather_moments": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr, _ptr]),
     "ppoaf_comm_destroy": (C.c_int, [_ptr]),
     "ppoaf_ppo_update_reduce_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr]),

@@ -122,6 +122,16 @@ extern "C" int ppoaf_allreduce_avg_f32(ppoaf_comm_t* c, float* buf, int64_t n, p
     return PPOAF_OK;
 }
 
+extern "C" int ppoaf_allreduce_sum_f32(ppoaf_comm_t* c, float* buf, int64_t n, ppoaf_stream_t stream) {
+    PPOAF_REQUIRE(c && c->comm, "allreduce_sum_f32: communicator missing");
+    PPOAF_REQUIRE(n >= 0, "allreduce_sum_f32: n=%ld", (long)n);
+    if (n == 0) return PPOAF_OK;
+    PPOAF_REQUIRE(buf, "allreduce_sum_f32: null buffer");
+    RcclApi* api = rccl_api();
+    PPOAF_RCCL_TRY(api->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream), "allreduce_sum_f32");
+    return PPOAF_OK;
+}
+
 extern "C" int ppoaf_bcast_f32(ppoaf_comm_t* c, float* buf, int64_t n, int root, ppoaf_stream_t stream) {
     PPOAF_REQUIRE(c && c->comm, "bcast_f32: communicator missing");
     PPOAF_REQUIRE(n >= 0 && root >= 0 && root < c->world, "bcast_f32: n=%ld root=%d", (long)n, root);

@@ -678,6 +678,28 @@ extern "C" int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int co
     return check_launch("ppo_update_adam");
 }
 
+// The N > 1 fallback chain in one call: fwd_bwd -> reduce -> RCCL sum all-reduce of the gradient bucket -> norms +
+// Adam, for n consecutive mini-batches.  What `fused_update._eager_multi_rank` does from Python (4 launches + one
+// torch.distributed call per mini-batch: ~42 us of host time, more than the kernels take) issued from C: the host cost
+// per mini-batch drops below the GPU's.
+extern "C" int ppoaf_ppo_update_chain_allreduce(const ppoaf_ppo_update_args_t* args, ppoaf_comm_t* comm, int64_t n_minibatches,
+                                                ppoaf_stream_t stream) {
+    PPOAF_REQUIRE(args && comm, "ppo_update_chain_allreduce: null argument");
+    PPOAF_REQUIRE(n_minibatches >= 1 && n_minibatches <= (1 << 20), "ppo_update_chain_allreduce: n_minibatches=%ld", (long)n_minibatches);
+    PPOAF_REQUIRE(args->mb_offset == 0, "ppo_update_chain_allreduce: mb_offset must be 0");
+    ppoaf_ppo_update_args_t a = *args;
+    for (int64_t j = 0; j < n_minibatches; ++j) {
+        a.mb_offset = j;
+        a.cursor_advance = (j == n_minibatches - 1) ? n_minibatches : 0;
+        int rc = ppoaf_ppo_update_fwd_bwd(&a, stream);
+        if (rc == PPOAF_OK) rc = ppoaf_ppo_update_reduce(&a, 0, stream);
+        if (rc == PPOAF_OK) rc = ppoaf_allreduce_sum_f32(comm, a.grads, a.bucket_total, stream);
+        if (rc == PPOAF_OK) rc = ppoaf_ppo_update_adam(&a, 1, stream);
+        if (rc != PPOAF_OK) return rc;
+    }
+    return PPOAF_OK;
+}
+
 extern "C" int ppoaf_ppo_update_adam_exchanged(const ppoaf_ppo_update_args_t* args, ppoaf_peer_exchange_t* xchg,
                                                ppoaf_stream_t stream) {
     UpdateDev u;

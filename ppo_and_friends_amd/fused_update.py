@@ -312,6 +312,45 @@ class FusedPolicyUpdate:
         if rc != 0:
             _lib.check(rc, "ppo_update")
 
+    _rccl_comm_cache = "unset"         # process-wide: libppoaf_hip's own RCCL communicator (or None)
+
+    def _rccl_comm(self):
+        """
+        The communicator of the C-level fallback loop (`ppoaf_ppo_update_chain_allreduce`): a second RCCL communicator
+        owned by libppoaf_hip.so, created once per process with the id travelling over torch.distributed.  None --
+        on EVERY rank, by a MIN vote -- when the backend is not RCCL, the library cannot bind librccl, the init fails
+        anywhere, or PPOAF_RCCL_LOOP=python asks for the Python loop.
+        """
+        import os
+        import torch.distributed as dist
+        cls = FusedPolicyUpdate
+        if cls._rccl_comm_cache != "unset":
+            return cls._rccl_comm_cache
+        comm = None
+        dev = self.pol.device
+        if dist.get_backend() == "nccl" and os.environ.get("PPOAF_RCCL_LOOP", "c") == "c":
+            rank, world = mpi_utils.get_rank(), mpi_utils.get_num_procs()
+            msg = torch.zeros(129, dtype=torch.uint8)                       # [ok flag, 128 id bytes]
+            if rank == 0:
+                buf = (C.c_char * 128)()
+                if self._lib.ppoaf_comm_unique_id(buf) == 0:
+                    msg[0] = 1
+                    msg[1:] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+            msg = msg.to(dev)
+            dist.broadcast(msg, src=0)
+            raw = bytes(msg.cpu().numpy().tobytes())
+            if raw[0] == 1:                                                  # every rank calls the collective init, or none
+                h = C.c_void_p()
+                if self._lib.ppoaf_comm_init(rank, world, raw[1:], C.byref(h)) == 0:
+                    comm = h
+            vote = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+            if int(vote.item()) == 0 and comm is not None:
+                self._lib.ppoaf_comm_destroy(comm)
+                comm = None
+        cls._rccl_comm_cache = comm
+        return comm
+
     def _eager_multi_rank(self, args, n):
         """
         n mini-batches of the N > 1 path: fwd_bwd, reduce, the gradient all-reduce (RCCL), norm + Adam.
@@ -320,8 +359,18 @@ class FusedPolicyUpdate:
         """
         import torch.distributed as dist
         lib, ref, st = self._lib, C.byref(args), K.stream()
-        fwd, red, adam = lib.ppoaf_ppo_update_fwd_bwd, lib.ppoaf_ppo_update_reduce, lib.ppoaf_ppo_update_adam
         grads = self.pol.policy_grads
+        if not mpi_utils._needs_staging(grads):
+            comm = self._rccl_comm()
+            if comm is not None:
+                # the whole loop from C: 5 launches per mini-batch without returning to Python (host cost below the GPU's)
+                left = n
+                while left > 0:
+                    k = min(left, 256)
+                    _lib.check(lib.ppoaf_ppo_update_chain_allreduce(ref, comm, k, st), "ppo_update_chain_allreduce")
+                    left -= k
+                return
+        fwd, red, adam = lib.ppoaf_ppo_update_fwd_bwd, lib.ppoaf_ppo_update_reduce, lib.ppoaf_ppo_update_adam
         if mpi_utils._needs_staging(grads):                  # gloo (tests): through a host copy
             allreduce = lambda: mpi_utils.allreduce_sum_(grads)
         else:

@@ -253,3 +253,31 @@ def test_bench_contract_under_the_drivers_two_rank_launch():
     others = cfg["other_configs"]                    # the other BASELINE configs' shapes ride in the same line
     assert sorted(others) == ["C3", "C4", "C5"] and all(o["value"] > 0 for o in others.values())
     assert "roofline" in out and out["roofline"]["bound"] == "hbm"
+
+
+def test_rccl_fallback_loops_agree():
+    """
+    The N > 1 fallback when the K17 exchange is not available: fwd_bwd -> reduce -> RCCL all-reduce -> Adam per
+    mini-batch.  Issued from C in one call per 256 mini-batches (`ppoaf_ppo_update_chain_allreduce`, the library's own
+    RCCL communicator, id over torch.distributed) or from the Python loop (PPOAF_RCCL_LOOP=python): the same kernels
+    in the same order -- bitwise equal parameters.  One rank rehearsing the N > 1 path (a one-GPU box cannot host two
+    RCCL ranks).
+    """
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for loop in ("c", "python"):
+        env = dict(os.environ, PPOAF_REHEARSE_MULTI_RANK="1", PPOAF_GRAD_EXCHANGE="rccl", PPOAF_RCCL_LOOP=loop,
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PPOAF_BACKEND"):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "rccl_fallback_run.py")], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        outs[loop] = json.loads(line[len("RESULT "):])
+    assert outs["c"]["c_loop"] is True and outs["python"]["c_loop"] is False
+    assert outs["c"]["steps"] == outs["python"]["steps"] == 2 * 2 * (16 * 32 // 64)
+    assert outs["c"]["digest"] == outs["python"]["digest"], outs
