@@ -390,7 +390,7 @@ int ppoaf_ppo_update_persistent(const ppoaf_ppo_update_args_t* args, int64_t n_m
 int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int compute_norms, ppoaf_stream_t stream);
 /* Weight-stationary persistent form of the same update (csrc/ppo_update_ws.hip; single rank): n_minibatches
  * consecutive mini-batches in ONE launch, processed layer by layer over all B rows -- forward / dgrad as 64x32 output
- * tiles, weight gradients as complete 32x32 tiles (K = the B rows: no slabs, no reduce pass), clip + Adam by the owner
+ * tiles, weight gradients as complete 64x64 tiles (K = the B rows: no slabs, no reduce pass), clip + Adam by the owner
  * of each parameter column -- on `workers` (<= 32) workgroups per network, the actor's all on XCD xcc_actor and the
  * critic's on xcc_critic (two different XCDs, 0..7), phases separated by flag barriers inside the XCD's L2.
  * Replaces ppo.py:2292-2469 for a run of mini-batches exactly as fwd_bwd -> reduce -> adam does (same arguments, same
@@ -408,7 +408,9 @@ int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int compute_norms
  * workers (slabs), phase 2 folds the slabs for the parameter columns each worker owns -- sums stay in registers next
  * to the prefetched parameter / moment values -- and phase 3 applies clip + Adam to them (three barriers per
  * mini-batch); -1 = automatic (layered for 256-wide networks, whose 16-row workgroups sit at their MFMA floor,
- * row-tiled below).  start_event / stop_event (from ppoaf_event_create, or NULL) receive the kernel's begin / end. */
+ * row-tiled below).  Measured on MI355X: with a 256-wide critic (C4 shapes) 52 us per mini-batch against 74 us for the
+ * three-launch chain; with two 128-wide networks (C2) 30-33 us against 29 us for the hipGraph-replayed chain -- this
+ * package's host therefore calls it only when a network is 256 wide.  start_event / stop_event (from ppoaf_event_create, or NULL) receive the kernel's begin / end. */
 int ppoaf_ppo_update_ws_ctl_bytes(void);
 int ppoaf_ppo_update_ws_workspace_bytes(const ppoaf_ppo_update_args_t* args, int32_t layered_mask, int64_t* bytes_out);
 int ppoaf_ppo_update_ws(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl, void* workspace,
