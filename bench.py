@@ -295,6 +295,8 @@ def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline
 
     ppo, pol, d = build_config(name, args, device, rank)
     E, T, A = d["E"], d["T"], d["A"]
+    from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
+    ws_xchg_before = FusedPolicyUpdate.ws_exchange_launch_count
 
     def barrier():
         if mpi_utils.distributed_path():
@@ -360,10 +362,11 @@ def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline
     # which per-mini-batch gradient exchange the update loops actually used (N > 1 or its rehearsal)
     fused = [f for f in getattr(ppo, "_fused", {}).values() if f is not None]
     peer = bool(fused) and all(getattr(f, "xchg", None) is not None for f in fused)
-    from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
     c_loop = FusedPolicyUpdate._rccl_comm_cache not in ("unset", None)
+    in_launch = FusedPolicyUpdate.ws_exchange_launch_count > ws_xchg_before
     exchange = None if not mpi_utils.distributed_path() else \
-        ("K17 peer mappings (xGMI), in-graph" if peer else
+        ("K17 peer mappings (xGMI) inside the persistent two-XCD update kernel (one launch per epoch; tail mini-batch: in-graph chain)"
+         if peer and in_launch else "K17 peer mappings (xGMI), in-graph" if peer else
          ("RCCL all-reduce, chain issued from C (ppoaf_ppo_update_chain_allreduce)" if c_loop else "RCCL all-reduce, eager loop"))
     if exchange is not None and fused:                       # why that path (self-test verdict / fallback reason)
         exchange += f" [{getattr(fused[0], 'xchg_reason', '')}]"

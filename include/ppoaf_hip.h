@@ -723,6 +723,22 @@ int ppoaf_ppo_update_reduce_exchange(const ppoaf_ppo_update_args_t* args, ppoaf_
                                      double wait_seconds, ppoaf_stream_t stream);
 int ppoaf_ppo_update_adam_exchanged(const ppoaf_ppo_update_args_t* args, ppoaf_peer_exchange_t* x,
                                     ppoaf_stream_t stream);
+/* ppoaf_ppo_update_ws for N > 1 ranks: the same persistent launch with the K17 exchange as a phase of every mini-batch
+ * (mpi_avg_gradients at ppo.py:2443-2448 without leaving the kernel).  Worker w of a network owns the same parameter
+ * columns on every rank and is exchange group (network * 32 + w): a row-tiled network sends its folded column sums
+ * from registers between its second and third barrier; a layered network gets one more phase (its owners' columns of
+ * the complete gradient -> slot -> rank-ordered sum -> gradient bucket + the summed gradient's norm partial) before
+ * clip + Adam.  Sums are added in rank order: every rank ends with bitwise the same parameters.  x must have been
+ * created for args->bucket_total floats and must be used by these launches only (its element -> group map differs
+ * from ppoaf_peer_exchange_allreduce's); every rank issues the same launches with the same `workers`.  Slot, flag and
+ * peer accesses are system-scope atomic accesses (no cache invalidates inside the epoch-long launch); xchg_fences != 0
+ * adds system-scope release / acquire fences around them (always on for coarse-grained slots).  A peer that does not
+ * show up within xchg_wait_seconds sets the exchange's error word (ppoaf_peer_exchange_status) and the launch drains. */
+int ppoaf_ppo_update_ws_exchange(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl, void* workspace,
+                                 int64_t workspace_bytes, int32_t workers, int32_t xcc_actor, int32_t xcc_critic,
+                                 int32_t layered_mask, double wait_seconds, ppoaf_peer_exchange_t* x,
+                                 double xchg_wait_seconds, int32_t xchg_fences, void* start_event, void* stop_event,
+                                 ppoaf_stream_t stream);
 int ppoaf_peer_exchange_destroy(ppoaf_peer_exchange_t* x);
 
 /* ------------------------------------------------------------------------ *

@@ -191,6 +191,8 @@ SIGNATURES = {
     "ppoaf_ppo_update_ws_workspace_bytes": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int32, C.POINTER(C.c_int64)]),
     "ppoaf_ppo_update_ws": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int64, _ptr, _ptr, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_double, _ptr, _ptr, _ptr]),
+    "ppoaf_ppo_update_ws_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int64, _ptr, _ptr, C.c_int64, C.c_int32, C.c_int32,
+                                               C.c_int32, C.c_int32, C.c_double, _ptr, C.c_double, C.c_int32, _ptr, _ptr, _ptr]),
     "ppoaf_ppo_update_reduce": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
     "ppoaf_ppo_update_adam": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
     "ppoaf_icm_forward_loss_fwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, C.c_float, _ptr, _ptr, _ptr, _ptr]),

@@ -31,6 +31,7 @@
 // three-launch chain's fwd_bwd body, the slab fold into registers, clip + Adam on those registers.
 // Summation orders are fixed (K order inside a tile, K halves, blocks and workers in index order): bitwise reproducible.
 #include "ppo_update_rowtile.hpp"
+#include "peer_exchange_device.hpp"
 #include <hip/hip_ext.h>
 #include <cstdlib>
 
@@ -371,8 +372,89 @@ __device__ __forceinline__ double ws_wgrad_tile_wide(const float* __restrict__ D
     return q;
 }
 
-struct WsArgs { UpdateDev u; WsDev ws; };
+// x: the K17 exchange of an N > 1 launch (xchg_ranks = its rank count, 0 on a single rank: no exchange phase at all)
+struct WsArgs { UpdateDev u; WsDev ws; XchgDev x; long long xchg_ticks; int xchg_ranks, xchg_fences; };
 typedef const WsArgs __attribute__((address_space(4))) KWsArgs;
+
+// ---- K17 inside the persistent launch (N > 1 ranks; the reference's per-mini-batch mpi_avg_gradients,
+//      utils/mpi_utils.py:89-111 at ppo.py:2443-2448).  Worker w of network `which` on every rank owns the same float4
+//      columns of the bucket (idx = lo4 + (c W + w) 512 + tid), so exchange group g = which * 32 + w of every rank
+//      depends only on group g of its peers, exactly as in peer_exchange.hip: own columns -> this rank's slot, flag
+//      words into every peer, poll the local flag words, peers' columns added in rank order (bitwise the same sum on
+//      every rank).  Differences from the stand-alone launch, because this launch lives on for a whole epoch and the
+//      XCD's L2 holds its working set:
+//        * slot stores, flag stores, flag polls and peer reads are all system-scope (sc0 sc1) atomic accesses of 8
+//          bytes: each is coherent by itself (written through / fetched from memory), so no cache invalidate
+//          (buffer_inv sc1 would also drop this XCD's L2 lines: measured +14 us per phase, l1_inv_probe.hip) and no
+//          L2 write-back is needed around them; xchg_fences = 1 adds the formal system-scope release / acquire
+//          fences anyway (exchange slots in ordinary coarse-grained memory need them);
+//        * the group's sequence number lives in a register for the launch (read at start, written back at the end).
+template <typename KA>
+__device__ __forceinline__ void ws_xchg_store(KA* ka, const long at, const float4& v) {
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(ka->x.my_slots + at);
+    const unsigned long long lo = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+    const unsigned long long hi = ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
+    __hip_atomic_store(d, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(d + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float4 ws_xchg_load(const float4* src) {
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
+    const unsigned long long lo = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long hi = __hip_atomic_load(s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                       __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+}
+// all of the workgroup's slot stores are acknowledged -> this rank's sequence number into every peer's flag word for
+// (group g, this rank); then the second wave polls the local flag words (lane p: peer p), bounded by the wall clock
+template <typename KA>
+__device__ __forceinline__ void ws_xchg_publish_wait(KA* ka, const long long seq, const unsigned g) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int R = ka->x.n_ranks, me = ka->x.rank;
+    if (threadIdx.x == 0) {
+        if (ka->xchg_fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        for (int p = 0; p < R; ++p)
+            if (p != me)
+                __hip_atomic_store(&ka->x.peer_flags[p][g * kMaxPeers + me], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const int p = (int)threadIdx.x - 64;
+    if (p >= 0 && p < R && p != me) {
+        long long* words = ka->x.words;
+        long long budget = ka->xchg_ticks;
+        if (__hip_atomic_load(&words[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) budget = 0;   // broken for good
+        const long long* flag = &ka->x.my_flags[g * kMaxPeers + p];
+        const long long t0 = (long long)wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((long long)wall_clock64() - t0 > budget) {
+                __hip_atomic_store(&words[3], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (ka->xchg_fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+// column `at` (slot offset included) of the rank-ordered sum; `own` = this rank's contribution
+template <typename KA>
+__device__ __forceinline__ float4 ws_xchg_sum(KA* ka, const long at, const float4& own) {
+    const int R = ka->x.n_ranks, me = ka->x.rank;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p0 = 0; p0 < R; p0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = p0 + k;
+            if (p >= R) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            else if (p == me) v[k] = own;
+            else v[k] = ws_xchg_load(ka->x.peer_slots[p] + at);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (p0 + k < R) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+    }
+    return acc;
+}
 
 // dgrad tile product with the weight matrix held ROW-major in LDS (rows = k, row stride PSTR): the tail phase reads the
 // same [H][H + 4] copy of W forwards (row_row) and backwards (this)
@@ -438,6 +520,8 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
     const long cursor0 = ka0->u.cursor[0];                    // rewritten only after both networks have finished
     const int W = ka0->ws.W;
     unsigned epoch = 0;
+    const unsigned xg = (unsigned)(which * kWsMaxWorkers + w);                // exchange group of this worker (N > 1)
+    long long xseq = ka0->xchg_ranks > 0 ? ka0->x.group_seq[xg] : 0;
 #ifdef PPOAF_WS_STAMPS
     unsigned long long t_prev = 0;
     if (which == PPOAF_WS_STAMP_NET && w == PPOAF_WS_STAMP_WORKER && threadIdx.x == 0)
@@ -982,6 +1066,26 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
             if (tid == 0) ctl->norm_partials[which][w] = q;
             PPOAF_WS_BARRIER(8)
         }
+        if (ka->xchg_ranks > 0) {
+            // N > 1: the gradient is complete in G.  Every worker sends the columns it owns (the ones it applies Adam
+            // to) through the exchange, writes the cross-rank sum back to G and replaces the norm partial by that of
+            // the summed gradient -- one phase and one barrier more than a single rank has.
+            const long lo4x = nd.offset >> 2, hi4x = (nd.offset + nd.size) >> 2;
+            const long i0 = lo4x + (long)w * kThreadsU + tid, cs = (long)W * kThreadsU;
+            const long long seq = ++xseq;
+            const long slot = (long)(seq & 1) * ka->x.n4;
+            for (long i = i0; i < hi4x; i += cs) ws_xchg_store(ka, slot + i, ld4<true>(u.grads + 4 * i));
+            ws_xchg_publish_wait(ka, seq, xg);
+            double q2 = 0.0;
+            for (long i = i0; i < hi4x; i += cs) {
+                const float4 acc = ws_xchg_sum(ka, slot + i, ld4<true>(u.grads + 4 * i));
+                reinterpret_cast<float4*>(u.grads)[i] = acc;
+                q2 += xchg_sq(acc, u.grad_scale);
+            }
+            q2 = block_sum(q2, s_red);
+            if (tid == 0) ctl->norm_partials[which][w] = q2;
+            PPOAF_WS_BARRIER(12)
+        }
 
         // ================================================================ clip + Adam on this worker's columns of the
         // network; norm = partials in worker order.  The parameter / moment / gradient loads depend on nothing
@@ -1047,6 +1151,10 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
         PPOAF_WSTAMP(11);
 #undef PPOAF_WS_BARRIER
     }
+    if (ka0->xchg_ranks > 0 && threadIdx.x == 0) {
+        ka0->x.group_seq[xg] = xseq;
+        if (xg == 0) ka0->x.words[0] = xseq;
+    }
     // the cursor moves once BOTH networks are done with the launch (each read it when it started)
     if (w == 0 && threadIdx.x == 0) {
         const unsigned prev = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -1069,6 +1177,8 @@ __device__ __forceinline__ void rt_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
     const long cursor0 = ka0->u.cursor[0];
     const int W = ka0->ws.W;
     unsigned epoch = 0;
+    const unsigned xg = (unsigned)(which * kWsMaxWorkers + w);                // exchange group of this worker (N > 1)
+    long long xseq = ka0->xchg_ranks > 0 ? ka0->x.group_seq[xg] : 0;
 #ifdef PPOAF_WS_STAMPS
     unsigned long long t_prev = 0;
     if (which == PPOAF_WS_STAMP_NET && w == PPOAF_WS_STAMP_WORKER && threadIdx.x == 0)
@@ -1118,6 +1228,7 @@ __device__ __forceinline__ void rt_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
         }
         double sumsq = 0.0;
         const float sc = u.grad_scale;
+        const int xr = ka->xchg_ranks;
 #pragma unroll
         for (int c = 0; c < kRtCols; ++c) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1131,10 +1242,25 @@ __device__ __forceinline__ void rt_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
                     for (int k = 0; k < 16; ++k)
                         if (g0 + k < n_wg) { acc.x += t[k].x; acc.y += t[k].y; acc.z += t[k].z; acc.w += t[k].w; }
                 }
-                sumsq += (double)(acc.x * sc) * (acc.x * sc) + (double)(acc.y * sc) * (acc.y * sc) +
-                         (double)(acc.z * sc) * (acc.z * sc) + (double)(acc.w * sc) * (acc.w * sc);
+                if (xr == 0) sumsq += xchg_sq(acc, sc);
             }
             gr[c] = acc;
+        }
+        if (xr > 0) {
+            // N > 1: this rank's column sums -> exchange slot, the ranks' sums added in rank order; the clip norm is
+            // that of the cross-rank gradient (mpi_avg_gradients before clip_grad_norm_, ppo_policy.py:1035-1038)
+            const long long seq = ++xseq;
+            const long slot = (long)(seq & 1) * ka->x.n4;
+#pragma unroll
+            for (int c = 0; c < kRtCols; ++c)
+                if (idx[c] < hi4) ws_xchg_store(ka, slot + idx[c], gr[c]);
+            ws_xchg_publish_wait(ka, seq, xg);
+#pragma unroll
+            for (int c = 0; c < kRtCols; ++c)
+                if (idx[c] < hi4) {
+                    gr[c] = ws_xchg_sum(ka, slot + idx[c], gr[c]);
+                    sumsq += xchg_sq(gr[c], sc);
+                }
         }
         if (w == W - 1 && tid < 64) {
             const long B = u.B;
@@ -1215,6 +1341,10 @@ __device__ __forceinline__ void rt_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
         PPOAF_WSTAMP(4);
         ws_arrive(ctl, which, w, ++epoch);            // the matching wait is inside the next mini-batch's phase 1
         PPOAF_WSTAMP(5);
+    }
+    if (ka0->xchg_ranks > 0 && threadIdx.x == 0) {
+        ka0->x.group_seq[xg] = xseq;
+        if (xg == 0) ka0->x.words[0] = xseq;
     }
     if (w == 0 && threadIdx.x == 0) {
         const unsigned prev = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -1356,10 +1486,10 @@ extern "C" int ppoaf_ppo_update_ws_workspace_bytes(const ppoaf_ppo_update_args_t
     return PPOAF_OK;
 }
 
-extern "C" int ppoaf_ppo_update_ws(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl, void* workspace,
-                                   int64_t workspace_bytes, int32_t workers, int32_t xcc_actor, int32_t xcc_critic,
-                                   int32_t layered_mask, double wait_seconds, void* start_event, void* stop_event,
-                                   ppoaf_stream_t stream) {
+static int ws_update(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl, void* workspace,
+                     int64_t workspace_bytes, int32_t workers, int32_t xcc_actor, int32_t xcc_critic,
+                     int32_t layered_mask, double wait_seconds, ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds,
+                     int32_t xchg_fences, void* start_event, void* stop_event, ppoaf_stream_t stream) {
     hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;
     UpdateDev u;
     int rc = make_update_dev(args, u);
@@ -1392,6 +1522,22 @@ extern "C" int ppoaf_ppo_update_ws(const ppoaf_ppo_update_args_t* args, int64_t 
     const long long budget = (long long)(wait_seconds * 1.0e8);          // wall_clock64 ticks at 100 MHz
     WsArgs a;
     a.u = u; a.ws = ws;
+    a.xchg_ranks = 0; a.xchg_fences = 0; a.xchg_ticks = 0;
+    a.x = XchgDev();
+    if (xchg) {
+        PPOAF_REQUIRE(xchg->connected, "ppo_update_ws_exchange: the exchange is not connected");
+        PPOAF_REQUIRE(xchg->dev.n4 == (u.bucket_total >> 2), "ppo_update_ws_exchange: exchange made for %ld float4, bucket has %ld",
+                      xchg->dev.n4, (long)(u.bucket_total >> 2));
+        PPOAF_REQUIRE(xchg->dev.n_ranks == u.n_ranks || !u.normalize_values, "ppo_update_ws_exchange: %d ranks in the exchange, %d in args",
+                      xchg->dev.n_ranks, u.n_ranks);
+        PPOAF_REQUIRE(xchg_wait_seconds > 0.0 && xchg_wait_seconds <= 600.0, "ppo_update_ws_exchange: xchg_wait_seconds=%g", xchg_wait_seconds);
+        static_assert(2 * kWsMaxWorkers <= kXchgMaxGrid, "one exchange group per worker");
+        a.x = xchg->dev;
+        a.xchg_ranks = xchg->dev.n_ranks;
+        // coarse-grained slots are only coherent through the fences; the other kinds may ask for them too
+        a.xchg_fences = (xchg_fences || xchg->memory_kind == 3) ? 1 : 0;
+        a.xchg_ticks = (long long)(xchg_wait_seconds * 1.0e8);
+    }
     WsCtl* c = reinterpret_cast<WsCtl*>(ctl);
     const int ha = u.net[0].H, hc = u.net[1].H, n = (int)n_minibatches;
 #define PPOAF_WS_PAIR(A, C)                                                                     \
@@ -1405,4 +1551,22 @@ extern "C" int ppoaf_ppo_update_ws(const ppoaf_ppo_update_args_t* args, int64_t 
     if (ha == 128 && hc == 256 && mask == 2) return ws_launch<128, 256, false, true>(a, c, n, budget, lds, s, e0, e1);
     set_error("ppo_update_ws: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
     return PPOAF_E_INVALID;
+}
+
+extern "C" int ppoaf_ppo_update_ws(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl, void* workspace,
+                                   int64_t workspace_bytes, int32_t workers, int32_t xcc_actor, int32_t xcc_critic,
+                                   int32_t layered_mask, double wait_seconds, void* start_event, void* stop_event,
+                                   ppoaf_stream_t stream) {
+    return ws_update(args, n_minibatches, ctl, workspace, workspace_bytes, workers, xcc_actor, xcc_critic, layered_mask,
+                     wait_seconds, nullptr, 0.0, 0, start_event, stop_event, stream);
+}
+
+extern "C" int ppoaf_ppo_update_ws_exchange(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl, void* workspace,
+                                            int64_t workspace_bytes, int32_t workers, int32_t xcc_actor, int32_t xcc_critic,
+                                            int32_t layered_mask, double wait_seconds, ppoaf_peer_exchange_t* xchg,
+                                            double xchg_wait_seconds, int32_t xchg_fences, void* start_event,
+                                            void* stop_event, ppoaf_stream_t stream) {
+    PPOAF_REQUIRE(xchg, "ppo_update_ws_exchange: null exchange (single rank: ppoaf_ppo_update_ws)");
+    return ws_update(args, n_minibatches, ctl, workspace, workspace_bytes, workers, xcc_actor, xcc_critic, layered_mask,
+                     wait_seconds, xchg, xchg_wait_seconds, xchg_fences, start_event, stop_event, stream);
 }

@@ -87,8 +87,9 @@ def _reduce_totals(upd, totals):
     if not upd.multi:
         return t.cpu().numpy()
     broken = 0.0
-    if upd.xchg is not None:
-        broken = float(upd.xchg.status()[1] != 0)
+    for x in (upd.xchg, getattr(upd, "xchg_ws", None)):
+        if x is not None and x.status()[1] != 0:
+            broken = 1.0
     t = torch.cat([t, torch.tensor([broken], dtype=t.dtype, device=t.device)])
     mpi_utils.allreduce_sum_(t)
     out = t.cpu().numpy()
@@ -160,6 +161,20 @@ class FusedPolicyUpdate:
         # N > 1: the per-mini-batch gradient exchange.  K17 over peer mappings when every rank can (same
         # host, IPC + self-test passed: collective decision), else the RCCL all-reduce in an eager loop.
         self.xchg, self.xchg_reason = (peer_exchange.open_exchange(total, dev) if self.multi else (None, "single rank"))
+        # the persistent two-XCD kernel of an N > 1 run carries the exchange inside the launch, with its own element ->
+        # group map (one group per worker), hence its own slots and flag words; opened collectively, like the first
+        self.xchg_ws = None
+        if self.xchg is not None and self._ws_wanted():
+            self.xchg_ws, why = peer_exchange.open_exchange(total, dev)
+            if self.xchg_ws is None:
+                self.xchg_reason += f"; persistent-kernel exchange refused ({why})"
+
+    def _ws_wanted(self):
+        """Would `ws_reason` pick the persistent kernel for this policy's shapes (before any epoch table exists)?"""
+        import os
+        if os.environ.get("PPOAF_WS", "1") == "0" or os.environ.get("PPOAF_WS_MULTI", "1") == "0":
+            return False
+        return self._ws_mask() >= 0 or max(self.actor_desc.hidden, self.critic_desc.hidden) >= 256
 
     # ------------------------------------------------------------------ args
     def _make_args(self, B):
@@ -442,6 +457,7 @@ class FusedPolicyUpdate:
     # ---- weight-stationary persistent form (csrc/ppo_update_ws.hip: ppo_update_ws_kernel)
     ws_chunk = 4096                    # mini-batches per launch
     ws_launch_count = 0                # launches of the kernel in this process (tests: the path really ran)
+    ws_exchange_launch_count = 0       # ... of which with the K17 exchange inside the launch (N > 1)
 
     def ws_reason(self):
         """'' when the epoch's full mini-batches can run through the weight-stationary persistent kernel, else why not."""
@@ -452,8 +468,8 @@ class FusedPolicyUpdate:
             return "off (PPOAF_WS=0)"
         if not getattr(self, "ws_allowed", True):
             return "the epoch shares the GPU with the ICM update on a second stream (a persistent kernel would starve it)"
-        if self.multi:
-            return "N > 1: the gradient exchange sits between the gradient and the Adam phase (three-launch chain)"
+        if self.multi and self.xchg_ws is None:
+            return "N > 1 without a K17 exchange for the persistent kernel (three-launch chain)"
         mask = self._ws_mask()
         if mask < 0 and max(self.actor_desc.hidden, self.critic_desc.hidden) < 256:
             # measured (C2, after the host-side shuffle prefetch stopped stalling): graph-replayed chain 29.4 us per
@@ -496,14 +512,26 @@ class FusedPolicyUpdate:
             import os
             ctl, wsb = self._ws_buffers()
             workers = int(os.environ.get("PPOAF_WS_WORKERS", "32"))
-            xa, xc = int(os.environ.get("PPOAF_WS_XCC_ACTOR", "0")) % 8, int(os.environ.get("PPOAF_WS_XCC_CRITIC", "1")) % 8
+            # one GPU per rank: XCDs 0 / 1.  Ranks rehearsing on ONE device (PPOAF_SHARE_DEVICE=1, tests) take XCD pairs of
+            # their own -- two worker groups cannot share a CU's LDS, and every rank's workers must be resident at once
+            slot = mpi_utils.get_rank() % 4 if os.environ.get("PPOAF_SHARE_DEVICE", "0") == "1" else 0
+            xa = int(os.environ.get("PPOAF_WS_XCC_ACTOR", str(2 * slot))) % 8
+            xc = int(os.environ.get("PPOAF_WS_XCC_CRITIC", str(2 * slot + 1))) % 8
             st = K.stream()
             wait_s = float(os.environ.get("PPOAF_WS_WAIT_SECONDS", "2.0"))    # bound of every in-kernel wait
             while left > 0:
                 n = min(left, self.ws_chunk)
                 ev = self.ws_timing_events.pop() if getattr(self, "ws_timing_events", None) else (None, None)
-                _lib.check(self._lib.ppoaf_ppo_update_ws(C.byref(args), n, ctl.data_ptr(), wsb.data_ptr(), wsb.numel(), workers,
-                                                         xa, xc, self._ws_mask(), wait_s, ev[0], ev[1], st), "ppo_update_ws")
+                if self.xchg_ws is not None:
+                    # N > 1: K17 as a phase of every mini-batch inside the launch (PPOAF_WS_XCHG_FENCES=1: formal fences too)
+                    _lib.check(self._lib.ppoaf_ppo_update_ws_exchange(
+                        C.byref(args), n, ctl.data_ptr(), wsb.data_ptr(), wsb.numel(), workers, xa, xc, self._ws_mask(), wait_s,
+                        self.xchg_ws.handle, self.xchg_ws.wait_seconds, int(os.environ.get("PPOAF_WS_XCHG_FENCES", "0")),
+                        ev[0], ev[1], st), "ppo_update_ws_exchange")
+                    FusedPolicyUpdate.ws_exchange_launch_count += 1
+                else:
+                    _lib.check(self._lib.ppoaf_ppo_update_ws(C.byref(args), n, ctl.data_ptr(), wsb.data_ptr(), wsb.numel(), workers,
+                                                             xa, xc, self._ws_mask(), wait_s, ev[0], ev[1], st), "ppo_update_ws")
                 self._ws_used = True
                 FusedPolicyUpdate.ws_launch_count += 1
                 left -= n

@@ -847,6 +847,9 @@ class PPO:
         for f in active:
             f.xchg.close()
             f.xchg, f.xchg_reason = None, f"disabled: {why}"
+            if getattr(f, "xchg_ws", None) is not None:
+                f.xchg_ws.close()
+                f.xchg_ws = None
             f._graphs.clear()
             f._args = {}
         self.status_dict["global status"]["peer exchange disabled"] = True

@@ -24,6 +24,12 @@ def _free_port():
 
 
 def _rank(rank, world, port, out, mode):
+    ws_mode = None
+    if mode.startswith("peer_ws_"):
+        # the persistent two-XCD kernel with the K17 exchange as a phase of every mini-batch (forced here: at these
+        # widths `auto` keeps the chain); the ranks share one GPU, so each takes its own pair of XCDs
+        mode, ws_mode = "peer", mode[len("peer_ws_"):]
+        os.environ.update(PPOAF_WS_MODE=ws_mode, PPOAF_SHARE_DEVICE="1")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
                       PPOAF_GRAD_EXCHANGE=mode)
@@ -49,8 +55,11 @@ def _rank(rank, world, port, out, mode):
         stats.append(dict(ppo.status_dict["p"]))
     vs = ppo.value_normalizers["p"].running_stats
     fused = [f for f in getattr(ppo, "_fused", {}).values() if f is not None]
+    from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
     out[rank] = dict(w0=w0, w=pol.policy_params.detach().cpu().clone(),
                      peer_exchange=[getattr(f, "xchg", None) is not None for f in fused],
+                     ws_exchange_launches=FusedPolicyUpdate.ws_exchange_launch_count,
+                     exp_avg=pol.policy_exp_avg.detach().cpu().clone(),
                      actor_sd={k: v.detach().cpu().clone() for k, v in pol.actor.state_dict().items()},
                      critic_sd={k: v.detach().cpu().clone() for k, v in pol.critic.state_dict().items()},
                      obs=ppo.env.obs_table.cpu().numpy(), rew=ppo.env.reward_table.cpu().numpy(),
@@ -62,8 +71,9 @@ def _rank(rank, world, port, out, mode):
 
 
 # "peer": K17 exchange over IPC mappings inside hipGraph-replayed chains; "rccl": the eager loop with the
-# process group's all-reduce (gloo here, staged through the host)
-@pytest.fixture(scope="module", params=["peer", "rccl"])
+# process group's all-reduce (gloo here, staged through the host); "peer_ws_*": K17 inside the persistent two-XCD
+# kernel (ppoaf_ppo_update_ws_exchange), both networks row-tiled / layered
+@pytest.fixture(scope="module", params=["peer", "rccl", "peer_ws_rowtile", "peer_ws_layered"])
 def run2(request):
     world = 2
     mgr = mp.Manager()
@@ -71,8 +81,29 @@ def run2(request):
     mp.spawn(_rank, args=(world, _free_port(), out, request.param), nprocs=world, join=True)
     res = [out[r] for r in range(world)]
     for r in res:
-        assert r["peer_exchange"] == [request.param == "peer"], r["peer_exchange"]
+        assert r["peer_exchange"] == [request.param.startswith("peer")], r["peer_exchange"]
+        # 2 epochs = 2 persistent launches when the exchange runs inside the kernel, none otherwise
+        assert r["ws_exchange_launches"] == (2 if request.param.startswith("peer_ws_") else 0), r["ws_exchange_launches"]
+    res[0]["mode"] = request.param
     return res
+
+
+def test_rowtiled_persistent_kernel_with_exchange_is_bitwise_the_chain():
+    """K17 inside the persistent kernel (row-tiled networks) against K17 inside the graph-replayed three-launch chain:
+    the same arithmetic in the same order on both ranks -- bitwise equal parameters, moments and statistics."""
+    runs = {}
+    for mode in ("peer", "peer_ws_rowtile"):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_rank, args=(2, _free_port(), out, mode), nprocs=2, join=True)
+        runs[mode] = [out[r] for r in range(2)]
+    a, b = runs["peer"], runs["peer_ws_rowtile"]
+    assert b[0]["ws_exchange_launches"] == 2 and a[0]["ws_exchange_launches"] == 0
+    for r in range(2):
+        assert torch.equal(a[r]["w"], b[r]["w"]) and torch.equal(a[r]["exp_avg"], b[r]["exp_avg"])
+        assert a[r]["stats"] == b[r]["stats"]
+        np.testing.assert_array_equal(a[r]["vn"], b[r]["vn"])
+    assert torch.equal(b[0]["w"], b[1]["w"])
 
 
 def test_ranks_start_and_stay_identical(run2):
@@ -129,7 +160,8 @@ def test_two_rank_update_matches_ddppo_oracle(run2):
 # the eager loop with the process group's all-reduce -- same sums, so the same training.
 def _rank_kind(rank, world, port, out, mode, kind):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PPOAF_GRAD_EXCHANGE=mode)
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PPOAF_GRAD_EXCHANGE=mode,
+                      PPOAF_SHARE_DEVICE="1")          # one GPU for both ranks: each persistent kernel on its own XCD pair
     import torch.distributed as dist
     from ppo_and_friends_amd.utils import mpi_utils
     mpi_utils.init_process_group_from_env(backend="gloo")
@@ -164,7 +196,9 @@ def _rank_kind(rank, world, port, out, mode, kind):
     ppo.rollout()
     ppo.train_on_rollout()
     fused = [f for f in getattr(ppo, "_fused", {}).values() if f is not None]
+    from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
     res = dict(peer_exchange=[getattr(f, "xchg", None) is not None for f in fused],
+               ws_exchange_launches=FusedPolicyUpdate.ws_exchange_launch_count,
                stats={k: float(v) for k, v in ppo.status_dict["p"].items()
                       if isinstance(v, (int, float)) and not isinstance(v, bool)})
     if kind == "guard":
@@ -201,6 +235,8 @@ def test_peer_exchange_equals_allreduce_path(kind):
         r0, r1 = runs[mode]
         assert r0["peer_exchange"] and all(x == (mode == "peer") for x in r0["peer_exchange"]), r0["peer_exchange"]
         assert torch.equal(r0["w"], r1["w"]), f"{mode}: replicas identical"
+        # the 256-wide critic puts the update on the persistent two-XCD kernel: with ranks, the exchange runs inside it
+        assert r0["ws_exchange_launches"] == (2 if (kind, mode) == ("wide", "peer") else 0), r0["ws_exchange_launches"]
         if kind == "icm":
             assert torch.equal(r0["w_icm"], r1["w_icm"])
     a, b = runs["peer"][0], runs["rccl"][0]
