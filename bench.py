@@ -226,7 +226,8 @@ def update_kernel_roofline(ppo, pol, B, launches=64):
             _lib.check(lib.ppoaf_adam_step_prenormed(
                 ac.flat_params.data_ptr(), ac.flat_grads.data_ptr(), opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr(),
                 ac.flat_params.numel(), opt.step_count.data_ptr(), opt.lr.data_ptr(), opt.betas[0], opt.betas[1], opt.eps,
-                1.0, float(clip) if clip is not None else 0.0, opt.norm_scratch.data_ptr(), opt.grad_norm.data_ptr(), st), "adam")
+                1.0, float(clip) if clip is not None else 0.0, opt.norm_scratch.data_ptr(), fused.norm_partials,
+                opt.grad_norm.data_ptr(), st), "adam")
             evs.append(ev)
     elif fused.ws_reason() == "":
         # the two-XCD persistent kernel: ONE launch = every full mini-batch of an epoch; begin / end of each launch

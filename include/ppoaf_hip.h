@@ -37,7 +37,7 @@ typedef void* ppoaf_stream_t;            /* hipStream_t */
 #define PPOAF_E_INVALID    -1            /* bad argument / unsupported shape   */
 #define PPOAF_E_LAUNCH     -2            /* hipLaunch / runtime error          */
 
-#define PPOAF_ABI_VERSION 2
+#define PPOAF_ABI_VERSION 3
 
 int         ppoaf_abi_version(void);
 const char* ppoaf_last_error(void);
@@ -238,8 +238,8 @@ int ppoaf_gaussian_tanh_eval_fwd(const float* mean, const float* log_std,
                                  float min_std,
                                  float* logp_out, float* entropy_out,
                                  ppoaf_stream_t stream);
-/* d_mean[n,D], d_log_std[D] (accumulated over rows; zeroed by the call) from
- * d_logp[n] and d_entropy[n]. */
+/* d_mean[n,D], d_log_std[D] (the sum over all rows, in a fixed order: one launch, no memset, no atomics -- safe
+ * inside a captured hipGraph) from d_logp[n] and d_entropy[n]. */
 int ppoaf_gaussian_tanh_eval_bwd(const float* mean, const float* log_std,
                                  const float* x, const float* d_logp,
                                  const float* d_entropy, int64_t n, int32_t D,
@@ -267,8 +267,11 @@ int ppoaf_gaussian_tanh_sample(const float* mean, const float* log_std,
  * coef = min(1, max_norm / (||grad_scale*g||_2 + 1e-6)) as torch does.
  * step_count is the 1-based Adam step kept on the device (int64[1],
  * incremented by the call) so the launch is graph-replayable.
- * norm_scratch: float64[1] device scratch owned by the caller.
+ * norm_scratch: float64[PPOAF_NORM_SCRATCH_DOUBLES] device scratch owned by the caller: [0] receives the squared
+ * norm, [2..] per-workgroup partials.  No atomics anywhere: the partials are added in a fixed association, so the
+ * clip coefficient is bitwise the same in every run and on every rank of a DD-PPO job.
  * ------------------------------------------------------------------------ */
+#define PPOAF_NORM_SCRATCH_DOUBLES 66
 int ppoaf_clip_adam_step(float* params, const float* grads,
                          float* exp_avg, float* exp_avg_sq, int64_t n,
                          int64_t* step_count, const float* lr /* device [1] */,
@@ -276,14 +279,16 @@ int ppoaf_clip_adam_step(float* params, const float* grads,
                          float grad_scale, float max_norm,
                          double* norm_scratch, float* grad_norm_out /* NULL ok */,
                          ppoaf_stream_t stream);
-/* The Adam half alone: norm_scratch[0] already holds ||grad_scale * grads||^2 and step_count has
- * been advanced for this step (a producer kernel did both, e.g. K15's reduce with fuse_norm). */
+/* The Adam half alone: step_count has been advanced for this step and ||grad_scale * grads||^2 is known -- as
+ * norm_scratch[0] (n_norm_partials = 0: e.g. ppoaf_peer_exchange_allreduce's norm_out), or as n_norm_partials
+ * per-workgroup partials norm_scratch[2 ..] left by a producer kernel (K15's reduce with fuse_norm), which are added
+ * in a fixed association here (and the sum stored to norm_scratch[0]). */
 int ppoaf_adam_step_prenormed(float* params, const float* grads,
                               float* exp_avg, float* exp_avg_sq, int64_t n,
                               const int64_t* step_count, const float* lr /* device [1] */,
                               float beta1, float beta2, float eps,
                               float grad_scale, float max_norm,
-                              const double* norm_scratch, float* grad_norm_out /* NULL ok */,
+                              double* norm_scratch, int32_t n_norm_partials, float* grad_norm_out /* NULL ok */,
                               ppoaf_stream_t stream);
 
 
@@ -308,6 +313,13 @@ int ppoaf_adam_step_prenormed(float* params, const float* grads,
  *        between this and the next call on multi-rank runs.
  *   ppoaf_ppo_update_adam    : [norms if not done] clip + Adam for both
  *        networks (ppo_policy.py:1037-1055), advances the mini-batch cursor.
+ *        compute_norms 0: the reduce launch (compute_norms = 1 there) left the
+ *        per-workgroup squared-norm partials in norm_scratch[6 ..]; 1: compute
+ *        those partials now (after an all-reduce of the bucket); 2:
+ *        norm_scratch[0..1] already hold the two squared norms
+ *        (ppoaf_peer_exchange_allreduce's norm_out).  Partials are added in a
+ *        fixed association -- no atomics: the clip coefficients are bitwise the
+ *        same in every run and on every rank.
  *
  * All three read the mini-batch index from a device cursor, so one captured
  * hipGraph of N repetitions walks N consecutive mini-batches of the epoch.
@@ -339,7 +351,8 @@ typedef struct {
     int64_t bucket_total;
     int64_t* step_counts;         /* [2] Adam steps (actor, critic), incremented per call  */
     const float* lr;              /* [1] device                                            */
-    double* norm_scratch;         /* [6] squared norms (2) + Adam bias corrections (4)     */
+    double* norm_scratch;         /* [6 + 2 * ceil(bucket_total / 1024)]: squared norms (2) + Adam bias corrections (4)
+                                   * + per-workgroup squared-norm partials (actor, critic) of the reduce / norm pass */
     float beta1, beta2, adam_eps, grad_scale, max_norm; int32_t head_kind;
     /* rollout buffer (time-major rows) */
     const float* obs; const float* critic_obs; const void* raw_actions;  /* int64 [n,1] or f32 [n,D] */
@@ -646,9 +659,10 @@ typedef struct {
     float surr_clip, entropy_weight, kl_loss_weight, huber_delta;
     float* loss_partials;            /* [n_workgroups, 8] */
     double* totals;                  /* [9] */
-    /* single-rank fusion of K11's norm pass: with fuse_norm the reduce launch also accumulates
-     * ||grads||^2 into norm_scratch[0] (zeroed by fwd_bwd) and advances step_count, so the caller
-     * follows with ppoaf_adam_step_prenormed instead of ppoaf_clip_adam_step */
+    /* single-rank fusion of K11's norm pass: with fuse_norm the reduce launch also leaves the ceil(bucket_total /
+     * 1024) per-workgroup partials of ||grads||^2 in norm_scratch[2 ..] (float64[2 + that many], at least
+     * PPOAF_NORM_SCRATCH_DOUBLES) and advances step_count, so the caller follows with ppoaf_adam_step_prenormed
+     * (n_norm_partials = that count) instead of ppoaf_clip_adam_step */
     double* norm_scratch; int64_t* step_count; int32_t fuse_norm, _pad;
 } ppoaf_mat_update_args_t;
 
@@ -771,6 +785,15 @@ int ppoaf_comm_destroy(ppoaf_comm_t* comm);
  * 1 / world factor is args->grad_scale, as in the three-launch chain).  mb_offset must be 0. */
 int ppoaf_ppo_update_chain_allreduce(const ppoaf_ppo_update_args_t* args, ppoaf_comm_t* comm, int64_t n_minibatches,
                                      ppoaf_stream_t stream);
+/* The same for the ICM update (ppo.py:2556-2562: averaged gradients, Adam without clipping; args->fused_adam must be 0;
+ * norm_scratch as for ppoaf_clip_adam_step) and for the MAT update (mat_policy.py:692-699: one clip + Adam over the
+ * shared bucket; args->fuse_norm must be 0, args->norm_scratch / step_count are the optimiser's). */
+int ppoaf_icm_update_chain_allreduce(const ppoaf_icm_update_args_t* args, ppoaf_comm_t* comm, int64_t n_minibatches,
+                                     double* norm_scratch, float* grad_norm_out /* NULL ok */, ppoaf_stream_t stream);
+int ppoaf_mat_update_chain_allreduce(const ppoaf_mat_update_args_t* args, ppoaf_comm_t* comm, int64_t n_minibatches,
+                                     float* exp_avg, float* exp_avg_sq, const float* lr /* device [1] */,
+                                     float beta1, float beta2, float eps, float grad_scale, float max_norm,
+                                     float* grad_norm_out /* NULL ok */, ppoaf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libppoaf_hip.so")
+# PPOAF_LIB: a diagnostic build of the same sources (A/B timing of compile-time variants, in-kernel stamps); never a fallback
+LIB_PATH = os.environ.get("PPOAF_LIB") or os.path.join(_HERE, "csrc", "libppoaf_hip.so")
 
 MAX_GATHER_FIELDS = 8
 
@@ -58,7 +59,7 @@ class PpoUpdateArgs(C.Structure):
                 ("mb_offset", C.c_int64), ("cursor_advance", C.c_int64)]
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class PolicyStepArgs(C.Structure):
@@ -206,7 +207,7 @@ SIGNATURES = {
     "ppoaf_icm_update_reduce": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
     "ppoaf_icm_intrinsic_reward": (C.c_int, [C.POINTER(IcmUpdateArgs), C.c_float, _ptr, _ptr]),
     "ppoaf_adam_step_prenormed": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr, _ptr, C.c_float, C.c_float,
-                                            C.c_float, C.c_float, C.c_float, _ptr, _ptr, _ptr]),
+                                            C.c_float, C.c_float, C.c_float, _ptr, C.c_int32, _ptr, _ptr]),
     "ppoaf_mat_update_fwd_bwd": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
     "ppoaf_mat_update_fwd_bwd_timed": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr, _ptr, _ptr]),
     "ppoaf_mat_update_reduce": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
@@ -223,6 +224,9 @@ SIGNATURES = {
     "ppoaf_bcast_f32": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int, _ptr]),
     "ppoaf_allreduce_sum_f32": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr]),
     "ppoaf_ppo_update_chain_allreduce": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_int64, _ptr]),
+    "ppoaf_icm_update_chain_allreduce": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr, C.c_int64, _ptr, _ptr, _ptr]),
+    "ppoaf_mat_update_chain_allreduce": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr, C.c_int64, _ptr, _ptr, _ptr, C.c_float,
+                                                   C.c_float, C.c_float, C.c_float, C.c_float, _ptr, _ptr]),
     "ppoaf_allgather_moments": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr, _ptr]),
     "ppoaf_comm_destroy": (C.c_int, [_ptr]),
     "ppoaf_ppo_update_reduce_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr]),

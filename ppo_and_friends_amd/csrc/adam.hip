@@ -11,7 +11,9 @@
 
 namespace ppoaf {
 
-// scratch[0] = sum of squares (zeroed by a memset node before this kernel)
+// Squared-norm partials, one per workgroup, into scratch[2 + blockIdx.x]: plain stores, no atomics -- the consumer
+// adds them in a fixed association (ordered_partial_sum), so the clip coefficient is the same in every run and on
+// every rank of a DD-PPO job (replicas must stay bitwise identical).
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, long n,
                                                           float scale, double* __restrict__ scratch,
                                                           int64_t* __restrict__ step_count) {
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
     }
     s = block_sum(s, red);
     if (threadIdx.x == 0) {
-        atomicAdd(&scratch[0], s);
+        scratch[2 + blockIdx.x] = s;
         if (blockIdx.x == 0) step_count[0] += 1;      // consumed by the next kernel on the stream
     }
 }
@@ -45,9 +47,13 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         long n, const int64_t* __restrict__ step_count,
                                                         const float* __restrict__ lr_dev, AdamParams a,
-                                                        const double* __restrict__ scratch,
+                                                        double* __restrict__ scratch, unsigned n_partials,
                                                         float* __restrict__ grad_norm_out) {
-    const float total_norm = (float)sqrt(scratch[0]);
+    // n_partials > 0: the squared norm arrives as per-workgroup partials scratch[2 ..] (every wave adds them in the
+    // same fixed association); 0: scratch[0] already holds it
+    const double sq = n_partials ? ordered_partial_sum(scratch + 2, n_partials) : scratch[0];
+    if (n_partials && blockIdx.x == 0 && threadIdx.x == 0) scratch[0] = sq;
+    const float total_norm = (float)sqrt(sq);
     float coef = 1.0f;
     if (a.max_norm > 0.f) coef = fminf(a.max_norm / (total_norm + 1e-6f), 1.0f);
     const float gs = a.grad_scale * coef;
@@ -84,11 +90,9 @@ extern "C" int ppoaf_clip_adam_step(float* params, const float* grads, float* ex
                   "clip_adam_step: null pointer");
     PPOAF_REQUIRE(((uintptr_t)grads & 15) == 0, "clip_adam_step: grads must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(norm_scratch, 0, sizeof(double), s);
-    if (e != hipSuccess) { set_error("clip_adam_step: memset: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
     long blocks = (n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > PPOAF_NORM_SCRATCH_DOUBLES - 2) blocks = PPOAF_NORM_SCRATCH_DOUBLES - 2;
     hipLaunchKernelGGL(grad_sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, grads, (long)n,
                        grad_scale, norm_scratch, step_count);
     int rc = check_launch("clip_adam_step/sqnorm");
@@ -97,22 +101,24 @@ extern "C" int ppoaf_clip_adam_step(float* params, const float* grads, float* ex
     long blocks2 = (n + 255) / 256;
     if (blocks2 > 2048) blocks2 = 2048;
     hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks2), dim3(256), 0, s, params, grads,
-                       exp_avg, exp_avg_sq, (long)n, step_count, lr, a, norm_scratch, grad_norm_out);
+                       exp_avg, exp_avg_sq, (long)n, step_count, lr, a, norm_scratch, (unsigned)blocks, grad_norm_out);
     return check_launch("clip_adam_step/adam");
 }
 
 extern "C" int ppoaf_adam_step_prenormed(float* params, const float* grads, float* exp_avg,
                                          float* exp_avg_sq, int64_t n, const int64_t* step_count,
                                          const float* lr, float beta1, float beta2, float eps,
-                                         float grad_scale, float max_norm, const double* norm_scratch,
-                                         float* grad_norm_out, ppoaf_stream_t stream) {
+                                         float grad_scale, float max_norm, double* norm_scratch,
+                                         int32_t n_norm_partials, float* grad_norm_out, ppoaf_stream_t stream) {
     PPOAF_REQUIRE(n >= 1, "adam_step_prenormed: n must be >= 1");
+    PPOAF_REQUIRE(n_norm_partials >= 0 && n_norm_partials <= (1 << 20), "adam_step_prenormed: n_norm_partials=%d", n_norm_partials);
     PPOAF_REQUIRE(params && grads && exp_avg && exp_avg_sq && step_count && lr && norm_scratch,
                   "adam_step_prenormed: null pointer");
     AdamParams a{beta1, beta2, eps, grad_scale, max_norm};
     long blocks2 = (n + 255) / 256;
     if (blocks2 > 2048) blocks2 = 2048;
     hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks2), dim3(256), 0, (hipStream_t)stream, params,
-                       grads, exp_avg, exp_avg_sq, (long)n, step_count, lr, a, norm_scratch, grad_norm_out);
+                       grads, exp_avg, exp_avg_sq, (long)n, step_count, lr, a, norm_scratch, (unsigned)n_norm_partials,
+                       grad_norm_out);
     return check_launch("adam_step_prenormed");
 }

@@ -65,6 +65,16 @@ __device__ __forceinline__ T block_sum(T v, T* smem) {
     return smem[16];
 }
 
+// Sum of n partials in a FIXED association, by one wave (all 64 lanes call it, all get the result): lane-strided
+// ascending per lane, then the xor butterfly.  IEEE addition is commutative, so every lane, every wave, every run and
+// every rank computes the bitwise identical total -- what clip coefficients of replicated optimisers must be built on.
+__device__ __forceinline__ double ordered_partial_sum(const double* partials, unsigned n) {
+    const unsigned lane = threadIdx.x & 63;
+    double p = 0.0;
+    for (unsigned b = lane; b < n; b += 64) p += __hip_atomic_load(&partials[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return wave_sum(p);
+}
+
 // ---- Philox4x32-10 (counter-based RNG; one 128-bit block per call) --------
 struct Philox4 { uint32_t x, y, z, w; };
 

@@ -162,19 +162,22 @@ __global__ __launch_bounds__(256) void gaussian_eval_fwd_kernel(
     if (entropy_out) entropy_out[row] = gauss_tanh_entropy_row(mean + row * D, log_std, D, min_std);
 }
 
-// d_mean[n,D]; d_log_std[D] accumulated with one atomic per (workgroup, d).
-__global__ __launch_bounds__(256) void gaussian_eval_bwd_kernel(
+// d_mean[n,D]; d_log_std[D] = sums over ALL rows, by ONE workgroup walking the rows (mini-batch sized n): every thread
+// adds its rows in ascending order, the workgroup folds in a fixed association, plain stores -- no zero-fill before the
+// launch and no atomics.  (Rounds 1-2 zeroed d_log_std with hipMemsetAsync and added per-workgroup atomics.  A memset
+// node captured into a hipGraph does not reliably write its value when the graph is replayed on this stack -- from the
+// second replay on the destination held junk, tools/probes/memset_capture_probe.py -- so under graph replay the gradient
+// of log_std started from junk: the "graph-replay drift" of the torch update path.  No captured path uses a memset now.)
+constexpr int kGaussBwdThreads = 1024;
+__global__ __launch_bounds__(kGaussBwdThreads) void gaussian_eval_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ log_std, const float* __restrict__ x,
     const float* __restrict__ d_logp, const float* __restrict__ d_entropy, long n, int D,
     float min_std, float* __restrict__ d_mean, float* __restrict__ d_log_std) {
     __shared__ float red[17];
-    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = row < n;
-    float g = 0.f, gH = 0.f;
-    if (live) { g = d_logp ? d_logp[row] : 0.f; gH = d_entropy ? d_entropy[row] : 0.f; }
     for (int d = 0; d < D; ++d) {
         float gls = 0.f;
-        if (live) {
+        for (long row = threadIdx.x; row < n; row += kGaussBwdThreads) {
+            const float g = d_logp ? d_logp[row] : 0.f, gH = d_entropy ? d_entropy[row] : 0.f;
             const float ls = log_std[d];
             const float sp = softplus_f(ls);
             const float sd = fmaxf(sp, min_std);
@@ -191,10 +194,10 @@ __global__ __launch_bounds__(256) void gaussian_eval_bwd_kernel(
             // torch.max(std, min_std): gradient to std where std > min_std, split on ties
             const float dmax = sp > min_std ? 1.f : (sp == min_std ? 0.5f : 0.f);
             const float dsp = ls > 20.f ? 1.f : 1.0f / (1.0f + expf(-ls));  // softplus' = sigmoid
-            gls = (g * pass * (zz * zz / (sd * sd * sd) - 1.0f / sd) + gH * pass0 / sd) * dmax * dsp;
+            gls += (g * pass * (zz * zz / (sd * sd * sd) - 1.0f / sd) + gH * pass0 / sd) * dmax * dsp;
         }
         const float tot = block_sum(gls, red);
-        if (threadIdx.x == 0 && tot != 0.f) atomicAdd(&d_log_std[d], tot);
+        if (threadIdx.x == 0) d_log_std[d] = tot;
     }
 }
 
@@ -299,11 +302,9 @@ extern "C" int ppoaf_gaussian_tanh_eval_bwd(const float* mean, const float* log_
     ROWS_OK(n, "gaussian_tanh_eval_bwd");
     PPOAF_REQUIRE(D >= 1 && D <= kMaxD, "gaussian_tanh_eval_bwd: D=%d out of [1,%d]", D, kMaxD);
     PPOAF_REQUIRE(d_log_std, "gaussian_tanh_eval_bwd: null d_log_std");
-    hipError_t e = hipMemsetAsync(d_log_std, 0, sizeof(float) * D, (hipStream_t)stream);
-    if (e != hipSuccess) { set_error("gaussian_tanh_eval_bwd: memset: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
-    if (n == 0) return PPOAF_OK;
-    PPOAF_REQUIRE(mean && log_std && x && d_mean, "gaussian_tanh_eval_bwd: null pointer");
-    hipLaunchKernelGGL(gaussian_eval_bwd_kernel, dim3(row_grid(n)), dim3(256), 0,
+    PPOAF_REQUIRE(n == 0 || (mean && log_std && x && d_mean), "gaussian_tanh_eval_bwd: null pointer");
+    // one workgroup (n = 0: it stores the zeros): no memset node, no atomics -- see the kernel
+    hipLaunchKernelGGL(gaussian_eval_bwd_kernel, dim3(1), dim3(kGaussBwdThreads), 0,
                        (hipStream_t)stream, mean, log_std, x, d_logp, d_entropy, (long)n, D, min_std,
                        d_mean, d_log_std);
     return check_launch("gaussian_tanh_eval_bwd");

@@ -749,3 +749,25 @@ extern "C" int ppoaf_icm_intrinsic_reward(const ppoaf_icm_update_args_t* args, f
     if (u.H == 64) return launch_icm_reward<4>(u, scale, intr_out, (hipStream_t)stream);
     return launch_icm_reward<8>(u, scale, intr_out, (hipStream_t)stream);
 }
+
+// mpi_avg_gradients at the ICM update's per-mini-batch call site (ppo.py:2556-2558) when the K17 peer exchange is not
+// available: fwd_bwd (3 launches) -> reduce -> RCCL sum all-reduce of the gradient bucket -> K11 Adam (no clipping in
+// the ICM update, ppo.py:2559-2562), for n consecutive mini-batches issued from this one call -- the host cost per
+// mini-batch stays below the GPU's, as with ppoaf_ppo_update_chain_allreduce.
+extern "C" int ppoaf_icm_update_chain_allreduce(const ppoaf_icm_update_args_t* args, ppoaf_comm_t* comm, int64_t n_minibatches,
+                                                double* norm_scratch, float* grad_norm_out, ppoaf_stream_t stream) {
+    PPOAF_REQUIRE(args && comm && norm_scratch, "icm_update_chain_allreduce: null argument");
+    PPOAF_REQUIRE(n_minibatches >= 1 && n_minibatches <= (1 << 20), "icm_update_chain_allreduce: n_minibatches=%ld", (long)n_minibatches);
+    PPOAF_REQUIRE(args->fused_adam == 0, "icm_update_chain_allreduce: fused_adam must be 0 (Adam follows the all-reduce)");
+    for (int64_t j = 0; j < n_minibatches; ++j) {
+        int rc = ppoaf_icm_update_fwd_bwd(args, stream);
+        if (rc == PPOAF_OK) rc = ppoaf_icm_update_reduce(args, stream);
+        if (rc == PPOAF_OK) rc = ppoaf_allreduce_sum_f32(comm, args->grads, args->bucket_total, stream);
+        if (rc == PPOAF_OK)
+            rc = ppoaf_clip_adam_step(const_cast<float*>(args->params), args->grads, args->exp_avg, args->exp_avg_sq,
+                                      args->bucket_total, args->step_count, args->lr, args->beta1, args->beta2, args->adam_eps,
+                                      args->grad_scale, 0.0f, norm_scratch, grad_norm_out, stream);
+        if (rc != PPOAF_OK) return rc;
+    }
+    return PPOAF_OK;
+}

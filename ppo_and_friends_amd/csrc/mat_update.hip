@@ -515,7 +515,6 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     float* sDOutC = c.sDOutC; float* sDOutA = c.sDOutA;
     auto G = [&](int k) -> float* { return slab + u.off[k]; };
 
-    if (u.fuse_norm && g == 0 && tid == 192) u.norm_scratch[0] = 0.0;          // accumulated by the reduce launch
     // L2 warm-up: the bucket was rewritten by the Adam kernel a moment ago, so this XCD's L2 holds none of it and
     // each of the ~50 dependent linears below would otherwise start with a cold miss.  One load per 128-byte
     // line of the whole bucket is issued here; they complete during the gather / first phases.
@@ -954,7 +953,7 @@ __global__ __launch_bounds__(kMatRedThreads) void mat_update_reduce_kernel(MatDe
     if (u.fuse_norm) {                                        // uniform per launch: every thread reaches the barriers
         double q = (double)acc.x * acc.x + (double)acc.y * acc.y + (double)acc.z * acc.z + (double)acc.w * acc.w;
         q = block_sum(q, red);
-        if (threadIdx.x == 0 && q != 0.0) atomicAdd(&u.norm_scratch[0], q);
+        if (threadIdx.x == 0) u.norm_scratch[2 + blockIdx.x] = q;      // partials: ppoaf_adam_step_prenormed adds them in a fixed order
     }
 }
 
@@ -1097,4 +1096,28 @@ extern "C" int ppoaf_mat_policy_step(const ppoaf_mat_step_args_t* a, ppoaf_strea
     PPOAF_REQUIRE(n_wg <= 0x7fffffffL, "mat_policy_step: too many envs");
     hipLaunchKernelGGL(mat_policy_step_kernel, dim3((unsigned)n_wg), dim3(kMT), lds, (hipStream_t)stream, u);
     return check_launch("mat_policy_step");
+}
+
+// mpi_avg_gradients at the MAT update's per-mini-batch call site (mat_policy.py:692) when the K17 peer exchange is not
+// available: fwd_bwd -> reduce -> RCCL sum all-reduce of the shared bucket -> K11 clip + Adam (mat_policy.py:694-699),
+// for n consecutive mini-batches issued from this one call.
+extern "C" int ppoaf_mat_update_chain_allreduce(const ppoaf_mat_update_args_t* args, ppoaf_comm_t* comm, int64_t n_minibatches,
+                                                float* exp_avg, float* exp_avg_sq, const float* lr, float beta1, float beta2,
+                                                float eps, float grad_scale, float max_norm, float* grad_norm_out,
+                                                ppoaf_stream_t stream) {
+    PPOAF_REQUIRE(args && comm && exp_avg && exp_avg_sq && lr, "mat_update_chain_allreduce: null argument");
+    PPOAF_REQUIRE(n_minibatches >= 1 && n_minibatches <= (1 << 20), "mat_update_chain_allreduce: n_minibatches=%ld", (long)n_minibatches);
+    PPOAF_REQUIRE(args->fuse_norm == 0 && args->norm_scratch && args->step_count,
+                  "mat_update_chain_allreduce: fuse_norm must be 0 (the norm is that of the all-reduced gradient)");
+    for (int64_t j = 0; j < n_minibatches; ++j) {
+        int rc = ppoaf_mat_update_fwd_bwd(args, stream);
+        if (rc == PPOAF_OK) rc = ppoaf_mat_update_reduce(args, stream);
+        if (rc == PPOAF_OK) rc = ppoaf_allreduce_sum_f32(comm, args->grads, args->bucket_total, stream);
+        if (rc == PPOAF_OK)
+            rc = ppoaf_clip_adam_step(const_cast<float*>(args->params), args->grads, exp_avg, exp_avg_sq, args->bucket_total,
+                                      args->step_count, lr, beta1, beta2, eps, grad_scale, max_norm, args->norm_scratch,
+                                      grad_norm_out, stream);
+        if (rc != PPOAF_OK) return rc;
+    }
+    return PPOAF_OK;
 }

@@ -53,11 +53,18 @@ __device__ __forceinline__ float softplus_u(float x) { return x > 20.f ? x : log
 #else
 #define PPOAF_DBG(bit) false
 #endif
-// Loads of data that ANOTHER CU of the same launch may have rewritten (the single-XCD persistent update kernel:
-// weights after the Adam phase, slabs, gradient bucket, statistics).  NT = true: non-temporal loads, which bypass
-// this CU's vector L1 and are served by the XCD's L2 (MI355X_MICROARCH.md, inter-workgroup visibility table) --
-// a CU's L1 is never refreshed by another CU's stores.  NT = false: plain loads (separate launches: the kernel
-// boundary does the invalidation).
+// Loads of data that ANOTHER CU of the same launch may have rewritten (the persistent update kernels: weights after
+// the Adam phase, slabs, activations, the gradient bucket, statistics).  A CU's vector L1 is never refreshed by
+// another CU's stores, so these loads must not be served by it.  NT = true: AGENT-SCOPE loads (`sc1`), the form the
+// AMDGPU memory model defines for reading other CUs' data -- 4-byte values as relaxed agent-scope atomic loads, 16-byte
+// values as two 8-byte ones (MI355X_MICROARCH.md, inter-workgroup visibility, "8-B agent atomics" / `sc1` loads): they
+// miss in the L1 by definition and are served by the L2 all workers of a network share (one XCD), whatever other loads
+// have touched the same lines before.  (Rounds 1-2 used non-temporal loads here: a cache-policy HINT that happened to
+// bypass the L1 as long as every access to those lines was non-temporal; -DPPOAF_XCU_LOADS_NT keeps that form for A/B
+// timing.)  The producers' side is `s_waitcnt vmcnt(0)` + workgroup barrier before the flag store: their write-through
+// stores have been acknowledged by that same L2.  NT = false: plain loads (separate launches: the kernel boundary does
+// the invalidation).
+#ifdef PPOAF_XCU_LOADS_NT
 template <bool NT> __device__ __forceinline__ float ld1(const float* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 template <bool NT> __device__ __forceinline__ double ld1(const double* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 template <bool NT> __device__ __forceinline__ float4 ld4(const float* p) {
@@ -67,6 +74,46 @@ template <bool NT> __device__ __forceinline__ float4 ld4(const float* p) {
     }
     return *reinterpret_cast<const float4*>(p);
 }
+#else
+template <bool NT> __device__ __forceinline__ float ld1(const float* p) {
+    if (NT) return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return *p;
+}
+template <bool NT> __device__ __forceinline__ double ld1(const double* p) {
+    if (NT) return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT));
+    return *p;
+}
+#ifdef PPOAF_XCU_LOADS_X2
+template <bool NT> __device__ __forceinline__ float4 ld4(const float* p) {
+    if (NT) {
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+        const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                           __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+#else
+// 16 bytes in ONE instruction: `buffer_load_dwordx4 ... sc1` (two 8-byte agent-scope loads measured 8-10 % slower per
+// mini-batch at C4).  A buffer resource needs a wave-uniform base: the first active lane's address minus 2 GiB, each lane
+// then carries its own 32-bit byte offset (the lanes of a wave read one array: far less than 2 GiB apart).  The compiler
+// tracks it with vmcnt like any other load.
+typedef unsigned ppoaf_u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 ld4(const float* p) {
+    if (NT) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo0 = __builtin_amdgcn_readfirstlane((unsigned)a), hi0 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const unsigned long long base = (((unsigned long long)hi0 << 32) | lo0) - 0x80000000ull;
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, 0xFFFFFFFF, 0x00020000);
+        const ppoaf_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(a - base), 0, 16 /* sc1 */);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+#endif
+#endif
 
 template <int HT, bool NT = false>
 __device__ __forceinline__ void load_fwd_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT],

@@ -75,10 +75,8 @@ __global__ __launch_bounds__(kRedThreads) void ppo_update_reduce_kernel(UpdateDe
     if (compute_norms) {
         q0 = block_sum(q0, red);
         q1 = block_sum(q1, red);
-        if (threadIdx.x == 0) {
-            if (q0 != 0.0) atomicAdd(&u.norm_scratch[0], q0);
-            if (q1 != 0.0) atomicAdd(&u.norm_scratch[1], q1);
-        }
+        // per-workgroup partials (no atomics): the Adam launch adds them in a fixed association
+        if (threadIdx.x == 0) { u.norm_scratch[6 + 2 * blockIdx.x] = q0; u.norm_scratch[7 + 2 * blockIdx.x] = q1; }
     }
 }
 
@@ -172,10 +170,7 @@ __global__ __launch_bounds__(256) void ppo_update_sqnorm_kernel(UpdateDev u) {
     }
     q0 = block_sum(q0, red);
     q1 = block_sum(q1, red);
-    if (threadIdx.x == 0) {
-        if (q0 != 0.0) atomicAdd(&u.norm_scratch[0], q0);
-        if (q1 != 0.0) atomicAdd(&u.norm_scratch[1], q1);
-    }
+    if (threadIdx.x == 0) { u.norm_scratch[6 + 2 * blockIdx.x] = q0; u.norm_scratch[7 + 2 * blockIdx.x] = q1; }
 }
 
 // norm_partials != nullptr: the squared norms arrive as per-workgroup partials of the fused reduce + exchange
@@ -668,13 +663,17 @@ extern "C" int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int co
     if (rc) return rc;
     const long n4 = u.bucket_total >> 2;
     const unsigned grid = (unsigned)((n4 + 255) / 256);
-    if (compute_norms) {
+    PPOAF_REQUIRE(compute_norms >= 0 && compute_norms <= 2, "ppo_update_adam: compute_norms=%d (0, 1 or 2)", compute_norms);
+    static_assert(kRedThreads == 256, "the reduce launch and the norm pass leave one partial pair per 256 float4 columns");
+    if (compute_norms == 1) {
         hipLaunchKernelGGL(ppo_update_sqnorm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u);
         rc = check_launch("ppo_update_adam/sqnorm");
         if (rc) return rc;
     }
+    // 0 / 1: squared norms = the per-workgroup partials at norm_scratch + 6, added in a fixed association;
+    // 2: norm_scratch[0..1] hold them already (ppoaf_peer_exchange_allreduce's norm_out)
     hipLaunchKernelGGL(ppo_update_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u,
-                       (const double*)nullptr, 0u);
+                       compute_norms == 2 ? (const double*)nullptr : (const double*)(u.norm_scratch + 6), grid);
     return check_launch("ppo_update_adam");
 }
 

@@ -318,7 +318,7 @@ class FusedPolicyUpdate:
             g = self.pol.policy_grads
             self.xchg.allreduce(g, g, split_floats=self.actor_desc.size, norm_scale=args.grad_scale,
                                 norm_out=self.pol.policy_norm_scratch, stream=st)
-            rc = lib.ppoaf_ppo_update_adam(ref, 0, st)
+            rc = lib.ppoaf_ppo_update_adam(ref, 2, st)
         else:
             if rc == 0 and not single:
                 mpi_utils.allreduce_sum_(self.pol.policy_grads)
@@ -331,11 +331,13 @@ class FusedPolicyUpdate:
 
     def _rccl_comm(self):
         """
-        The communicator of the C-level fallback loop (`ppoaf_ppo_update_chain_allreduce`): a second RCCL communicator
-        owned by libppoaf_hip.so, created once per process with the id travelling over torch.distributed.  None --
-        on EVERY rank, by a MIN vote -- when the backend is not RCCL, the library cannot bind librccl, the init fails
-        anywhere, or PPOAF_RCCL_LOOP=python asks for the Python loop.
+        The communicator of the C-level fallback loops (`ppoaf_{ppo,icm,mat}_update_chain_allreduce`): a second RCCL
+        communicator owned by libppoaf_hip.so, created once per process with the id travelling over torch.distributed.
+        None -- on EVERY rank -- when the backend is not RCCL, PPOAF_RCCL_LOOP=python asks for the Python loop, or any
+        rank cannot bind librccl: that is voted on BEFORE the collective init (ncclCommInitRank blocks until every rank
+        has called it, so no rank may enter it alone); a second vote covers an init that returned an error.
         """
+        import atexit
         import os
         import torch.distributed as dist
         cls = FusedPolicyUpdate
@@ -343,28 +345,44 @@ class FusedPolicyUpdate:
             return cls._rccl_comm_cache
         comm = None
         dev = self.pol.device
+        lib = self._lib
         if dist.get_backend() == "nccl" and os.environ.get("PPOAF_RCCL_LOOP", "c") == "c":
             rank, world = mpi_utils.get_rank(), mpi_utils.get_num_procs()
-            msg = torch.zeros(129, dtype=torch.uint8)                       # [ok flag, 128 id bytes]
-            if rank == 0:
-                buf = (C.c_char * 128)()
-                if self._lib.ppoaf_comm_unique_id(buf) == 0:
-                    msg[0] = 1
-                    msg[1:] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
-            msg = msg.to(dev)
-            dist.broadcast(msg, src=0)
-            raw = bytes(msg.cpu().numpy().tobytes())
-            if raw[0] == 1:                                                  # every rank calls the collective init, or none
+
+            def vote(ok):
+                v = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(v, op=dist.ReduceOp.MIN)
+                return int(v.item()) == 1
+
+            buf = (C.c_char * 128)()
+            if vote(lib.ppoaf_comm_unique_id(buf) == 0):                     # every rank can bind librccl (the id call is local)
+                msg = torch.zeros(128, dtype=torch.uint8)
+                if rank == 0:
+                    msg[:] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+                msg = msg.to(dev)
+                dist.broadcast(msg, src=0)                                   # rank 0's id is the communicator's
                 h = C.c_void_p()
-                if self._lib.ppoaf_comm_init(rank, world, raw[1:], C.byref(h)) == 0:
+                if lib.ppoaf_comm_init(rank, world, bytes(msg.cpu().numpy().tobytes()), C.byref(h)) == 0:
                     comm = h
-            vote = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(vote, op=dist.ReduceOp.MIN)
-            if int(vote.item()) == 0 and comm is not None:
-                self._lib.ppoaf_comm_destroy(comm)
-                comm = None
+                if not vote(comm is not None):
+                    if comm is not None:
+                        lib.ppoaf_comm_destroy(comm)
+                    comm = None
+            if comm is not None:
+                atexit.register(cls._destroy_rccl_comm)
         cls._rccl_comm_cache = comm
         return comm
+
+    @staticmethod
+    def _destroy_rccl_comm():
+        cls = FusedPolicyUpdate
+        comm, cls._rccl_comm_cache = cls._rccl_comm_cache, None
+        if comm not in ("unset", None):
+            try:
+                torch.cuda.synchronize()
+                _lib.load().ppoaf_comm_destroy(comm)
+            except Exception:                                                # interpreter shutdown: nothing left to release into
+                pass
 
     def _eager_multi_rank(self, args, n):
         """
@@ -411,6 +429,7 @@ class FusedPolicyUpdate:
 
     # ---- single-XCD persistent form (csrc/ppo_update.hip: ppo_update_persistent_kernel)
     persistent_chunk = 4096            # mini-batches per launch (one launch per epoch at the BASELINE sizes)
+    persistent_launch_count = 0        # launches of the single-XCD persistent kernel in this process (tests)
 
     def _persistent_ctl(self):
         ctl = getattr(self, "_persist_ctl", None)
@@ -546,6 +565,7 @@ class FusedPolicyUpdate:
                 _lib.check(self._lib.ppoaf_ppo_update_persistent(C.byref(args), n, ctl.data_ptr(), xcc, 2.0, st),
                            "ppo_update_persistent")
                 self._persist_used = True
+                FusedPolicyUpdate.persistent_launch_count += 1
                 left -= n
                 self.n_done += n
         use_graph = self.ppo.use_graphs and (not self.multi or self.xchg is not None)   # RCCL calls are not captured
@@ -567,7 +587,7 @@ class FusedPolicyUpdate:
                     g.replay()
                 left -= chunk
                 self.n_done += chunk
-            elif self.multi and self.xchg is None and type(self)._one is FusedPolicyUpdate._one:
+            elif self.multi and self.xchg is None:
                 self._eager_multi_rank(args, left)
                 self.n_done += left
                 left = 0
@@ -752,11 +772,30 @@ class FusedIcmUpdate:
                 mpi_utils.allreduce_sum_(g)
             self.pol.icm_optim.step(grad_scale=1.0 / self.world, max_norm=None)
 
+    def _c_loop(self, args, n):
+        """The RCCL fallback (no K17 exchange) issued from C: ppoaf_icm_update_chain_allreduce, <= 256 mini-batches per call.
+        False when the library has no RCCL communicator of its own (gloo tests, PPOAF_RCCL_LOOP=python)."""
+        g = self.pol.icm_model.flat_grads
+        if not self.multi or self.xchg is not None or mpi_utils._needs_staging(g):
+            return False
+        comm = FusedPolicyUpdate._rccl_comm(self)
+        if comm is None:
+            return False
+        opt, st, ref = self.pol.icm_optim, K.stream(), C.byref(args)
+        while n > 0:
+            k = min(n, 256)
+            _lib.check(self._lib.ppoaf_icm_update_chain_allreduce(ref, comm, k, opt.norm_scratch.data_ptr(), opt.grad_norm.data_ptr(), st),
+                       "icm_update_chain_allreduce")
+            n -= k
+        return True
+
     def run_epoch(self):
         args = self._args_for(self.B)
         left = self.n_full
         use_graph = self.ppo.use_graphs and (not self.multi or self.xchg is not None)   # RCCL calls are not captured
         chunk = self.graph_chunk if self.n_full < 8 * self.graph_chunk else 4 * self.graph_chunk   # long epochs: fewer, longer graphs
+        if left > 0 and self._c_loop(args, left):
+            left = 0
         while left > 0:
             if use_graph and left >= chunk:
                 g = self._graphs.get(chunk)
@@ -913,6 +952,31 @@ class FusedMatUpdate(FusedPolicyUpdate):
         a.fuse_norm = int(not self.multi or self.xchg is not None)
         return a
 
+    @property
+    def norm_partials(self):
+        """How ppoaf_adam_step_prenormed finds ||g||^2: the reduce launch's per-workgroup partials (single rank), or
+        norm_scratch[0] as K17's exchange left it (0)."""
+        return 0 if self.xchg is not None else (self.topo["bucket_total"] // 4 + 255) // 256
+
+    def _eager_multi_rank(self, args, n):
+        """The RCCL fallback (no K17 exchange): fwd_bwd -> reduce -> all-reduce -> K11 clip + Adam per mini-batch, issued from
+        C (ppoaf_mat_update_chain_allreduce, <= 256 mini-batches per call) when the library owns an RCCL communicator."""
+        pol = self.pol
+        opt, ac, clip = pol.actor_critic_optim, pol.actor_critic, pol.gradient_clip
+        comm = None if mpi_utils._needs_staging(ac.flat_grads) else FusedPolicyUpdate._rccl_comm(self)
+        if comm is None:
+            for _ in range(n):
+                self._one(args)
+            return
+        st, ref = K.stream(), C.byref(args)
+        while n > 0:
+            k = min(n, 256)
+            _lib.check(self._lib.ppoaf_mat_update_chain_allreduce(
+                ref, comm, k, opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr(), opt.lr.data_ptr(), opt.betas[0], opt.betas[1],
+                opt.eps, 1.0 / self.world, float(clip) if clip is not None else 0.0, opt.grad_norm.data_ptr(), st),
+                "mat_update_chain_allreduce")
+            n -= k
+
     def begin_epoch(self, perm):
         pol, ppo, buf = self.pol, self.ppo, self.pol.buffer
         ds = pol.dataset
@@ -969,6 +1033,7 @@ class FusedMatUpdate(FusedPolicyUpdate):
         rc = lib.ppoaf_adam_step_prenormed(
             ac.flat_params.data_ptr(), ac.flat_grads.data_ptr(), opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr(),
             ac.flat_params.numel(), opt.step_count.data_ptr(), opt.lr.data_ptr(), opt.betas[0], opt.betas[1], opt.eps,
-            1.0 / self.world, float(clip) if clip is not None else 0.0, opt.norm_scratch.data_ptr(), opt.grad_norm.data_ptr(), st)
+            1.0 / self.world, float(clip) if clip is not None else 0.0, opt.norm_scratch.data_ptr(), self.norm_partials,
+            opt.grad_norm.data_ptr(), st)
         if rc != 0:
             _lib.check(rc, "adam_step_prenormed")

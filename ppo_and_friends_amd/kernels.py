@@ -357,6 +357,9 @@ def gaussian_tanh_sample(mean, log_std, seed, offset, min_std=0.01, act_lo=None,
 # --------------------------------------------------------------------------
 # K11
 # --------------------------------------------------------------------------
+NORM_SCRATCH_DOUBLES = 66          # PPOAF_NORM_SCRATCH_DOUBLES
+
+
 def clip_adam_step(params, grads, exp_avg, exp_avg_sq, step_count, lr, norm_scratch,
                    beta1=0.9, beta2=0.999, eps=1e-5, grad_scale=1.0, max_norm=0.5,
                    grad_norm_out=None):
@@ -367,7 +370,8 @@ def clip_adam_step(params, grads, exp_avg, exp_avg_sq, step_count, lr, norm_scra
         _req(t.numel() == n and t.dim() == 1, f"{nme} must be flat float32[{n}]")
     _req(step_count.dtype == torch.int64 and step_count.numel() == 1, "step_count int64[1]")
     _req(lr.dtype == torch.float32 and lr.numel() == 1, "lr float32[1] on the device")
-    _req(norm_scratch.dtype == torch.float64 and norm_scratch.numel() >= 1, "norm_scratch float64[>=1]")
+    _req(norm_scratch.dtype == torch.float64 and norm_scratch.numel() >= NORM_SCRATCH_DOUBLES,
+         f"norm_scratch float64[>={NORM_SCRATCH_DOUBLES}] (norm + per-workgroup partials)")
     check(_lib.load().ppoaf_clip_adam_step(
         ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), n, ptr(step_count), ptr(lr),
         float(beta1), float(beta2), float(eps), float(grad_scale),

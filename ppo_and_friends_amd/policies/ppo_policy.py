@@ -45,16 +45,19 @@ class FlatAdam:
     """
 
     def __init__(self, network, lr, eps=1e-5, betas=(0.9, 0.999), storage=None):
-        """storage = (exp_avg, exp_avg_sq, step_count[1], lr[1], norm_scratch[1]) views of a
-        policy-wide allocation (so the fused update kernels see actor and critic state adjacent)."""
+        """storage = (exp_avg, exp_avg_sq, step_count[1], lr[1], norm_scratch or None) views of a policy-wide
+        allocation (so the fused update kernels see actor and critic state adjacent).  norm_scratch is this
+        optimiser's own float64[2 + partials] (K11's / K15's per-workgroup squared-norm partials)."""
         self.network = network
         dev = network.flat_params.device
         if storage is None:
             storage = (torch.zeros_like(network.flat_params), torch.zeros_like(network.flat_params),
                        torch.zeros(1, dtype=torch.int64, device=dev),
-                       torch.full((1,), float(lr), dtype=torch.float32, device=dev),
-                       torch.zeros(1, dtype=torch.float64, device=dev))
+                       torch.full((1,), float(lr), dtype=torch.float32, device=dev), None)
         self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.norm_scratch = storage
+        if self.norm_scratch is None:
+            self.norm_scratch = torch.zeros(max(K.NORM_SCRATCH_DOUBLES, 2 + (network.flat_params.numel() + 1023) // 1024),
+                                            dtype=torch.float64, device=dev)
         self.lr.fill_(float(lr))
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.eps = eps
@@ -180,13 +183,12 @@ class PPOPolicy:
         self.policy_exp_avg_sq = torch.zeros_like(self.policy_params)
         self.policy_step_counts = torch.zeros(2, dtype=torch.int64, device=dev)
         self.policy_lr = torch.full((1,), float(self.lr()), dtype=torch.float32, device=dev)
-        self.policy_norm_scratch = torch.zeros(6, dtype=torch.float64, device=dev)   # norms + bias corrections
+        # K12: squared norms (2) + Adam bias corrections (4) + per-workgroup squared-norm partials of the bucket
+        self.policy_norm_scratch = torch.zeros(6 + 2 * ((self.policy_params.numel() + 1023) // 1024), dtype=torch.float64, device=dev)
         self.actor_optim = FlatAdam(self.actor, self.lr(), eps=1e-5, storage=(
-            self.policy_exp_avg[:na], self.policy_exp_avg_sq[:na], self.policy_step_counts[0:1],
-            self.policy_lr, self.policy_norm_scratch[0:1]))
+            self.policy_exp_avg[:na], self.policy_exp_avg_sq[:na], self.policy_step_counts[0:1], self.policy_lr, None))
         self.critic_optim = FlatAdam(self.critic, self.lr(), eps=1e-5, storage=(
-            self.policy_exp_avg[na:], self.policy_exp_avg_sq[na:], self.policy_step_counts[1:2],
-            self.policy_lr, self.policy_norm_scratch[1:2]))
+            self.policy_exp_avg[na:], self.policy_exp_avg_sq[na:], self.policy_step_counts[1:2], self.policy_lr, None))
         self.icm_optim = FlatAdam(self.icm_model, self.icm_lr(), eps=1e-5) if self.enable_icm else None
 
     def _initialize_networks(self, ac_network, enable_icm, icm_network, actor_kw_args,

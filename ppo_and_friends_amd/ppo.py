@@ -183,7 +183,7 @@ class PPO:
         self.normalize_values = normalize_values
         self.recalc_advantages = recalc_advantages
         self.ext_reward_weight = ext_reward_weight
-        self.use_graphs = use_graphs and self.device.type == "cuda"
+        self.use_graphs = use_graphs and self.device.type == "cuda" and os.environ.get("PPOAF_GRAPHS", "1") != "0"
         # "fused": K12 kernels (MLP policies); "torch": torch-ROCm MLPs + K2..K11; "auto": fused when covered
         self.update_mode = update_mode
         self._fused = {}
@@ -973,11 +973,13 @@ class PPO:
             else:
                 self._optimizer_step(policy_id)
 
-        # the stateful LSTM modules are run eagerly.  So is the torch-ROCm fallback of agent-grouped (MAT) policies:
-        # replaying its captured module graph in a LATER iteration, with eager tail mini-batches in between, drifted
-        # from the eager result by ~1e-4 on fixture g12_c5_mat (allocation-pattern dependent; open);
-        # the default MAT path (fused K15, replayed from its own hipGraph) reproduces the fixture
-        graphs = self.use_graphs and not pol.using_lstm and not pol.agent_grouping
+        # the stateful LSTM modules are run eagerly; everything else replays two hipGraphs per mini-batch.  (Rounds 1-2 also
+        # kept the torch-ROCm fallback of agent-grouped (MAT) policies eager because its replayed results drifted by ~1e-4
+        # in later iterations.  Root cause, round 3: hipMemsetAsync nodes captured into a hipGraph do not reliably write
+        # their value on replay on this stack -- tools/probes/memset_capture_probe.py -- so the clip norm's accumulator,
+        # zeroed by a memset inside the optimiser graph, started from junk.  No captured path of the library uses a
+        # memset any more: tests/test_gpu_graph_replay.py.)
+        graphs = self.use_graphs and not pol.using_lstm
         for k in range(n_full):
             run(perm[k * B:(k + 1) * B], k, graphs)
         if tail:

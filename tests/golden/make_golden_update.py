@@ -583,6 +583,22 @@ def scenarios():
     sc["g12_lstm_term"] = dict(seed=110, E=5, T=20, A=1, O=4, action_space=Discrete(2), reward="uniform", term_prob=0.08,
                                batch_size=24, epochs=2, iterations=2, ac_network=LSTMNetwork,
                                policy_args=dict(actor_kw_args=lstm_kw(4), critic_kw_args=lstm_kw(4)))
+    # ---- the metric's own mini-batch shape: batch_size = 256 (the reference's default, ppo.py:134) -- 16 row tiles per
+    # network in K12, the multi-tile layered critic, 86 K15 tiles; two full mini-batches per epoch (+ a tail at C4)
+    sc["g12_c2_b256"] = dict(seed=121, E=16, T=32, A=1, O=4, action_space=Discrete(2), reward="ones", term_prob=0.06,
+                             batch_size=256, epochs=2, iterations=1)
+    sc["g12_c4_b256"] = dict(seed=124, E=6, T=32, A=3, O=18, action_space=Discrete(5), reward="uniform", term_prob=0.05,
+                             batch_size=256, epochs=2, iterations=1, critic_view="policy",
+                             policy_args=dict(actor_kw_args=leaky(), critic_kw_args=big()))
+    sc["g12_c3_b256"] = dict(seed=126, E=16, T=32, A=1, O=17, action_space=cheetah(), reward="uniform", term_prob=0.0,
+                             max_ts_per_ep=8, batch_size=256, epochs=2, iterations=1, obs_scale=3.0, obs_shift=1.0,
+                             policy_args=dict(actor_kw_args=leaky(), critic_kw_args=big(), lr=1e-4, enable_icm=True),
+                             ppo_args=dict(normalize_obs=True, normalize_rewards=True, obs_clip=(-2.0, 2.0),
+                                           reward_clip=(-1.5, 1.5)))
+    # MAT: envs_per_proc must be 1 in the reference (quirk Q13), so the 256-row mini-batch comes from a long rollout
+    sc["g12_c5_b256"] = dict(seed=129, E=1, T=512, A=3, O=18, action_space=Discrete(5), reward="uniform", term_prob=0.0,
+                             max_ts_per_ep=512, batch_size=256, epochs=2, iterations=1, critic_view="local", policy_class=MATPolicy,
+                             ac_network=mat.MATActorCritic, policy_args=dict(mat_kw_args={"embedding size": 64}))
     sc["g12_lstm_cut"] = dict(seed=111, E=4, T=18, A=1, O=4, action_space=Discrete(3), reward="uniform", term_prob=0.0,
                               max_ts_per_ep=6, batch_size=16, epochs=2, iterations=1, ac_network=LSTMNetwork,
                               policy_args=dict(actor_kw_args=lstm_kw(3), critic_kw_args=lstm_kw(3)))

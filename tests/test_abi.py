@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = built_lib.load()
     for name in _declared():
         assert hasattr(lib, name), f"libppoaf_hip.so lacks {name}"
-    assert lib.ppoaf_abi_version() == 2
+    assert lib.ppoaf_abi_version() == 3
 
 
 def test_ctypes_table_matches_header(built_lib):
@@ -117,3 +117,18 @@ def test_two_xcd_kernel_completion_guard_raises_on_the_host():
         bad = types.SimpleNamespace(_ws_ctl=torch.tensor(words + [0] * 12, dtype=torch.int32), _ws_used=True)
         with pytest.raises(_lib.PpoafError, match="did not complete"):
             FusedPolicyUpdate._check_persistent(bad)
+
+
+def test_no_memset_in_capturable_paths():
+    """Source-level guard: hipMemsetAsync stays out of every entry point that may be captured into a hipGraph.  The three
+    allowed uses are never captured: the control blocks of the persistent launches (one launch per epoch, issued eagerly)
+    and the one-time clears of ppoaf_peer_exchange_create."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ppo_and_friends_amd", "csrc")
+    allowed = {("ppo_update.hip", "ctl"), ("ppo_update_ws.hip", "ctl"), ("peer_exchange.hip", "local"), ("peer_exchange.hip", "x->base")}
+    found = set()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".hpp")):
+            for m in re.finditer(r"hipMemset(?:Async)?\(\s*([^,]+),", open(os.path.join(root, f)).read()):
+                found.add((f, m.group(1).strip()))
+    assert found <= allowed, found - allowed

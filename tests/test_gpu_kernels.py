@@ -431,7 +431,7 @@ def test_clip_adam_matches_torch(K, max_norm, grad_scale):
     m = torch.zeros_like(flat); v = torch.zeros_like(flat)
     step = torch.zeros(1, dtype=torch.int64, device="cuda")
     lr = torch.full((1,), 3e-4, device="cuda")
-    scratch = torch.zeros(2, dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(K.NORM_SCRATCH_DOUBLES, dtype=torch.float64, device="cuda")
     gn = torch.zeros(1, device="cuda")
     for k in range(steps):
         g = torch.cat([x.flatten() for x in grads[k]]).cuda()

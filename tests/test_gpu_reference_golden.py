@@ -31,7 +31,13 @@ FF_SCENARIOS = {
     "g12_c2_icm": (dict(enable_icm=True), {}),
     "g12_c3_full": (dict(leaky=True, lr=1e-4, enable_icm=True),
                     dict(normalize_obs=True, normalize_rewards=True, obs_clip=(-2.0, 2.0), reward_clip=(-1.5, 1.5))),
+    # the metric's own mini-batch shape, batch_size = 256 (ppo.py:134): 16 row tiles per network, multi-tile layered critic
+    "g12_c2_b256": ({}, {}),
+    "g12_c4_b256": (dict(leaky=True), {}),
+    "g12_c3_b256": (dict(leaky=True, lr=1e-4, enable_icm=True),
+                    dict(normalize_obs=True, normalize_rewards=True, obs_clip=(-2.0, 2.0), reward_clip=(-1.5, 1.5))),
 }
+B256 = ["g12_c2_b256", "g12_c3_b256", "g12_c4_b256"]
 
 
 def _cfg(g):
@@ -136,7 +142,9 @@ def params_in_bucket_order(pol, bucket, net):
 def first_minibatch_probe(ppo, pol, perm, B):
     """
     Losses + raw gradient bucket of the first mini-batch WITHOUT an optimiser step.
-    fused path: one K12 fwd_bwd + slab-reduce launch; torch path: one _minibatch_step (value-normaliser state restored).
+    fused path: one K12 fwd_bwd + slab-reduce launch -- or, when a persistent form of K12 is selected (two-XCD kernel,
+    single-XCD chain), ONE mini-batch through that very kernel with every piece of state it advances put back afterwards;
+    torch path: one _minibatch_step (value-normaliser state restored).
     """
     from ppo_and_friends_amd import _lib
     from ppo_and_friends_amd import kernels as K
@@ -144,6 +152,22 @@ def first_minibatch_probe(ppo, pol, perm, B):
     perm_t = torch.as_tensor(np.asarray(perm, dtype=np.int64), device=pol.device)
     if fused is not None:
         fused.begin_epoch(perm_t)
+        if fused.n_full >= 1 and (fused.ws_reason() == "" or fused.persistent_reason() == ""):
+            state = [pol.policy_params, pol.policy_exp_avg, pol.policy_exp_avg_sq, pol.policy_step_counts, pol.policy_norm_scratch,
+                     fused.vn_mean, fused.vn_var, fused.vn_count, fused.cursor, fused.totals, pol.buffer.values]
+            keep = [t.clone() for t in state]
+            n_full, tail, n_done = fused.n_full, fused.tail, fused.n_done
+            fused.n_full, fused.tail = 1, 0
+            try:
+                fused.run_epoch()                      # one mini-batch, the kernel's own gradient left in policy_grads
+                torch.cuda.synchronize()
+                fused._check_persistent()
+            finally:
+                fused.n_full, fused.tail, fused.n_done = n_full, tail, n_done
+            out = fused.totals.cpu().numpy().copy(), pol.policy_grads.clone()
+            for t, k in zip(state, keep):
+                t.copy_(k)
+            return out
         args = fused._args_for(B)
         lib, st = _lib.load(), K.stream()
         steps = pol.policy_step_counts.clone()              # the reduce launch's bookkeeping advances Adam's step counters
@@ -256,12 +280,13 @@ def test_product_reproduces_the_reference_ppo_iterations(golden, name, update_mo
 
 
 @pytest.mark.parametrize("update_mode", ["fused", "torch"])
-def test_product_reproduces_the_reference_mat_iterations(golden, update_mode):
+@pytest.mark.parametrize("name", ["g12_c5_mat", "g12_c5_b256"])
+def test_product_reproduces_the_reference_mat_iterations(golden, name, update_mode):
     """
     C5 shapes: the reference's own PPO object with MATPolicy (3 agents, O=18, Discrete(5), embedding 64, 1 block, 1 head;
-    fixture g12_c5_mat).  Autoregressive rollout (K16 / torch path) with the recorded actions replayed, shared-episode
-    dataset incl. quirk Q14, first mini-batch (K15 launch): losses + the full gradient bucket before any optimiser
-    step, epochs, final weights.
+    fixtures g12_c5_mat: 16-env mini-batches = 4 K15 tiles; g12_c5_b256: batch_size 256 = 52 tiles).  Autoregressive
+    rollout (K16 / torch path) with the recorded actions replayed, shared-episode dataset incl. quirk Q14, first
+    mini-batch (K15 launch): losses + the full gradient bucket before any optimiser step, epochs, final weights.
     """
     from ppo_and_friends_amd import _lib
     from ppo_and_friends_amd import kernels as K
@@ -269,7 +294,7 @@ def test_product_reproduces_the_reference_mat_iterations(golden, update_mode):
     from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
     from ppo_and_friends_amd.policies.mat_policy import MATPolicy
     from ppo_and_friends_amd.spaces import Box, Discrete
-    g = golden("g12_c5_mat")
+    g = golden(name)
     c = _cfg(g)
     E, T, A, O, B = c["E"], c["T"], c["A"], c["O"], c["batch_size"]
     dev = torch.device("cuda", 0)
@@ -412,22 +437,26 @@ def test_product_reproduces_the_reference_lstm_iterations(golden, name, S, n_act
         assert d.max() < 2e-4 and np.mean(d > 2e-5) < 1e-2, f"{tag}: max |dw| {d.max():.2e}, share > 2e-5: {np.mean(d > 2e-5):.2e}"
 
 
-@pytest.mark.parametrize("name", ["g12_c2_term", "g12_c3_gauss", "g12_c4_mappo"])
+@pytest.mark.parametrize("name", ["g12_c2_term", "g12_c3_gauss", "g12_c4_mappo"] + B256)
 def test_persistent_single_xcd_chain_reproduces_the_reference(golden, name, monkeypatch):
     """
     The opt-in single-XCD persistent form of K12 (one launch per epoch: fwd_bwd -> reduce -> Adam phases separated by
     flag barriers inside one XCD's L2, PPOAF_PERSISTENT=1) against the same reference-recorded iterations.
     """
-    monkeypatch.setenv("PPOAF_PERSISTENT", "1")
-    test_product_reproduces_the_reference_ppo_iterations(golden, name, "fused")
-    # and it really was the persistent launch that ran
     from ppo_and_friends_amd import fused_update
     monkeypatch.setenv("PPOAF_PERSISTENT", "1")
-    assert fused_update.FusedPolicyUpdate.persistent_reason.__doc__
+    monkeypatch.setenv("PPOAF_WS", "0")                   # (a 256-wide critic would otherwise take the two-XCD kernel)
+    before = fused_update.FusedPolicyUpdate.persistent_launch_count
+    test_product_reproduces_the_reference_ppo_iterations(golden, name, "fused")
+    # and it really was the persistent launch that ran: the first-mini-batch probe + one launch per epoch
+    g = golden(name)
+    c = _cfg(g)
+    ran = fused_update.FusedPolicyUpdate.persistent_launch_count - before
+    assert ran == 1 + c["iterations"] * c["epochs"], f"single-XCD persistent launches: {ran}"
 
 
 @pytest.mark.parametrize("mode", ["auto", "layered", "rowtile"])
-@pytest.mark.parametrize("name", ["g12_c2_term", "g12_c2_cut", "g12_c3_gauss", "g12_c3_full", "g12_c4_mappo", "g12_gauss_bounds"])
+@pytest.mark.parametrize("name", ["g12_c2_term", "g12_c2_cut", "g12_c3_gauss", "g12_c3_full", "g12_c4_mappo", "g12_gauss_bounds"] + B256)
 def test_weight_stationary_persistent_update_reproduces_the_reference(golden, name, mode, monkeypatch):
     """
     The weight-stationary persistent form of K12 (csrc/ppo_update_ws.hip: one launch per epoch, the mini-batch processed
@@ -442,7 +471,7 @@ def test_weight_stationary_persistent_update_reproduces_the_reference(golden, na
     test_product_reproduces_the_reference_ppo_iterations(golden, name, "fused")
     # "auto" takes the persistent kernel only where a network is 256 wide (the C3 / C4 critics); forced modes always
     ran = fused_update.FusedPolicyUpdate.ws_launch_count > before
-    wide = name in ("g12_c3_gauss", "g12_c3_full", "g12_c4_mappo")
+    wide = name in ("g12_c3_gauss", "g12_c3_full", "g12_c4_mappo", "g12_c3_b256", "g12_c4_b256")
     assert ran == (mode != "auto" or wide), f"persistent kernel ran: {ran} (mode {mode}, 256-wide critic: {wide})"
 
 

@@ -291,13 +291,15 @@ def test_bench_contract_under_the_drivers_two_rank_launch():
     assert "roofline" in out and out["roofline"]["bound"] == "hbm"
 
 
-def test_rccl_fallback_loops_agree():
+@pytest.mark.parametrize("kind", ["ppo", "icm", "mat"])
+def test_rccl_fallback_loops_agree(kind):
     """
-    The N > 1 fallback when the K17 exchange is not available: fwd_bwd -> reduce -> RCCL all-reduce -> Adam per
-    mini-batch.  Issued from C in one call per 256 mini-batches (`ppoaf_ppo_update_chain_allreduce`, the library's own
-    RCCL communicator, id over torch.distributed) or from the Python loop (PPOAF_RCCL_LOOP=python): the same kernels
-    in the same order -- bitwise equal parameters.  One rank rehearsing the N > 1 path (a one-GPU box cannot host two
-    RCCL ranks).
+    The N > 1 fallback when the K17 exchange is not available: fwd_bwd -> reduce -> RCCL all-reduce -> [norm +] Adam per
+    mini-batch, for the PPO (K12), ICM (K14) and MAT (K15) updates.  Issued from C in one call per 256 mini-batches
+    (`ppoaf_{ppo,icm,mat}_update_chain_allreduce`, the library's own RCCL communicator, id over torch.distributed) or
+    from the Python loop (PPOAF_RCCL_LOOP=python): the same kernels in the same order -- bitwise equal parameters and
+    moments (the clip norms are fixed-order sums: no atomics).  One rank rehearsing the N > 1 path (a one-GPU box cannot
+    host two RCCL ranks).
     """
     import json
     import subprocess
@@ -306,6 +308,7 @@ def test_rccl_fallback_loops_agree():
     outs = {}
     for loop in ("c", "python"):
         env = dict(os.environ, PPOAF_REHEARSE_MULTI_RANK="1", PPOAF_GRAD_EXCHANGE="rccl", PPOAF_RCCL_LOOP=loop,
+                   PPOAF_FALLBACK_KIND=kind,
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PPOAF_BACKEND"):
             env.pop(k, None)
@@ -315,5 +318,8 @@ def test_rccl_fallback_loops_agree():
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
         outs[loop] = json.loads(line[len("RESULT "):])
     assert outs["c"]["c_loop"] is True and outs["python"]["c_loop"] is False
-    assert outs["c"]["steps"] == outs["python"]["steps"] == 2 * 2 * (16 * 32 // 64)
+    want_fused = {"ppo": ["FusedPolicyUpdate"], "icm": ["FusedIcmUpdate", "FusedPolicyUpdate"], "mat": ["FusedMatUpdate"]}[kind]
+    assert outs["c"]["fused"] == outs["python"]["fused"] == want_fused
+    per_update = 2 * 2 * (16 * 32 // 64)                       # iterations x epochs x mini-batches
+    assert outs["c"]["steps"] == outs["python"]["steps"] == per_update * (2 if kind == "icm" else 1)
     assert outs["c"]["digest"] == outs["python"]["digest"], outs

@@ -109,6 +109,9 @@ SCENARIOS = {
     "g12_gauss_bounds": dict(act_low=[-1.0, -2.0, 0.0], act_high=[1.0, 2.0, 5.0]),
     "g12_c2_icm": {},
     "g12_c3_full": dict(lr=1e-4, filters=dict(obs_clip=(-2.0, 2.0), reward_clip=(-1.5, 1.5)), **LEAKY),
+    # batch_size = 256, the reference's default and the metric's mini-batch shape (ppo.py:134)
+    "g12_c2_b256": {}, "g12_c4_b256": LEAKY,
+    "g12_c3_b256": dict(lr=1e-4, filters=dict(obs_clip=(-2.0, 2.0), reward_clip=(-1.5, 1.5)), **LEAKY),
 }
 
 
@@ -172,7 +175,8 @@ def test_cpu_port_reproduces_the_reference_ppo_iterations(golden, name):
             r = cpu.train_epoch(perm=pi[g["epoch_perms"][ep]])
             if ep == 0:      # the very first mini-batch, before any optimiser step: losses and raw gradients
                 m = cpu.trace[0]
-                np.testing.assert_allclose([m["actor"], m["critic"]], g["mb0_losses"], rtol=5e-6, atol=1e-9)
+                # (the actor loss is a mean of B O(1) surrogate terms that nearly cancel: float32 noise is ~1e-7 absolute)
+                np.testing.assert_allclose([m["actor"], m["critic"]], g["mb0_losses"], rtol=1e-5, atol=1e-7)
                 np.testing.assert_allclose(m["actor_grad"], g["mb0_actor_grad"], rtol=1e-5, atol=1e-7)
                 np.testing.assert_allclose(m["critic_grad"], g["mb0_critic_grad"], rtol=1e-5, atol=1e-7)
             got = np.array([r["actor loss"], r["critic loss"], r["kl avg"], r["weighted entropy"]])
@@ -247,11 +251,12 @@ def test_rollout_statistics_oracle_reproduces_the_reference_status_block(golden,
         assert gs["timesteps"] == (it + 1) * E * T
 
 
-def test_cpu_mat_port_reproduces_the_reference_mat_iterations(golden):
+@pytest.mark.parametrize("name", ["g12_c5_mat", "g12_c5_b256"])
+def test_cpu_mat_port_reproduces_the_reference_mat_iterations(golden, name):
     """MATPolicy (C5 shapes: 3 agents, O=18, Discrete(5), embedding 64, 1 block, 1 head) through the reference's own
     PPO object: autoregressive rollout log-probs, shared-episode dataset, teacher-forced evaluate, Huber value loss,
     one optimiser over actor + critic -- against oracle/mat_oracle.CpuMATPPO."""
-    g = golden("g12_c5_mat")
+    g = golden(name)
     c = _cfg(g)
     E, T, A, B = c["E"], c["T"], c["A"], c["batch_size"]
     cpu = mat_oracle.CpuMATPPO(c["O"], 5, A, batch_size=B, seed=0)
@@ -273,14 +278,18 @@ def test_cpu_mat_port_reproduces_the_reference_mat_iterations(golden):
         np.testing.assert_array_equal(ds.actions.numpy(), g[pre + "actions"])
         np.testing.assert_allclose(ds.values.numpy(), g[pre + "values"], **tol)
         np.testing.assert_allclose(ds.logp.numpy(), g[pre + "log_probs"], **tol)        # teacher-forced == autoregressive
-        np.testing.assert_allclose(ds.rtg.numpy(), g[pre + "rewards_to_go"], **tol)
+        # the fixture was recorded under NumPy 2, where the reference's rewards-to-go scan accumulates in float32
+        # (float64 under its pinned numpy < 1.24, which the oracle restates): 5e-6 apart after 512 steps
+        long_tol = tol if T <= 64 else dict(rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(ds.rtg.numpy(), g[pre + "rewards_to_go"], **long_tol)
         np.testing.assert_allclose(ds.adv.numpy(), g[pre + "advantages"], **tol)
         for e in range(c["epochs"]):
             cpu.trace = [] if ep == 0 else None
             r = cpu.train_epoch(perm=g["epoch_perms"][ep])
             if ep == 0:
                 m = cpu.trace[0]
-                np.testing.assert_allclose([m["actor"], m["critic"]], g["mb0_losses"], rtol=5e-6, atol=1e-9)
+                # (the actor loss is a mean of B O(1) surrogate terms that nearly cancel: float32 noise is ~1e-7 absolute)
+                np.testing.assert_allclose([m["actor"], m["critic"]], g["mb0_losses"], rtol=1e-5, atol=1e-7)
                 np.testing.assert_allclose(m["actor_grad"], g["mb0_actor_grad"], rtol=1e-5, atol=1e-7)
                 np.testing.assert_allclose(m["critic_grad"], g["mb0_critic_grad"], rtol=1e-5, atol=1e-7)
             got = np.array([r["actor loss"], r["critic loss"], r["kl avg"], r["weighted entropy"]])
