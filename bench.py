@@ -71,6 +71,30 @@ def pmc_traffic():
     return out
 
 
+def update_pmc_traffic(config, kernel):
+    """
+    HBM-side bytes per launch of an update kernel from the committed PMC passes (profiles/*_update_pmc.csv:
+    `bash tools/update_pmc.sh`, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of tools/update_pmc_driver.py,
+    KB units).  FETCH_SIZE is doubled: these kernels read 16 B per lane, which gfx950 tallies at half
+    (MI355X_MICROARCH.md, HBM), calibrated in this very access pattern on the slab reduce (16 slabs x 271 KB read:
+    2 x FETCH_SIZE = 4.41 MB) and the Adam launch (4 buckets: 2 x FETCH_SIZE = 1.12 MB).  -> dict or None.
+    """
+    import glob, re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_update_pmc.csv")))
+    if not files:
+        return None
+    vals = {}
+    for line in open(files[-1]):
+        m = re.match(r"^(C\d),(.*),(FETCH_SIZE|WRITE_SIZE),dispatches=(\d+),avg=([0-9.]+)", line)
+        if m and m.group(1) == config and m.group(2).replace("ppoaf::", "").startswith(kernel.split("<")[0]):
+            vals[m.group(3)] = (float(m.group(5)), int(m.group(4)))
+    if len(vals) != 2:
+        return None
+    return {"bytes": int((2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024),
+            "fetch_kb_raw": vals["FETCH_SIZE"][0], "write_kb": vals["WRITE_SIZE"][0], "dispatches": vals["FETCH_SIZE"][1],
+            "source": os.path.relpath(files[-1], ROOT)}
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -190,7 +214,10 @@ def build_config(name, args, device, rank):
     return ppo, ppo.policies["cartpole"], dict(E=E, T=T, A=A, O=O, workload=workload)
 
 
-def update_kernel_roofline(ppo, pol, B, launches=64):
+PMC_WS_MINIBATCHES = 16          # tools/update_pmc_driver.py --minibatches (one persistent launch)
+
+
+def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
     """
     roofline_update: the kernel that dominates the step.  After the timed region the same per-mini-batch chain
     (fwd_bwd -> reduce -> Adam, so every launch sees weights the Adam launch has just rewritten, as in the timed
@@ -253,6 +280,8 @@ def update_kernel_roofline(ppo, pol, B, launches=64):
         avg = sum(us) / len(us)
         flop = 3 * fwd * B * n_mb
         tf = flop / (avg * 1e-6) / 1e12
+        pmc = update_pmc_traffic(config, "ppo_update_ws_kernel")
+        per_mb = None if pmc is None else pmc["bytes"] // PMC_WS_MINIBATCHES       # the profiled launch ran that many mini-batches
         return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 5), "flop_per_launch": int(flop), "flop_formula": desc,
                 "avg_launch_us": round(avg, 2), "median_launch_us": round(us[len(us) // 2], 2), "launches": len(us),
@@ -260,7 +289,9 @@ def update_kernel_roofline(ppo, pol, B, launches=64):
                 "launches_per_step": ppo.epochs_per_iter,
                 "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on epoch launches right after the timed region; "
                           "profiles/ holds the rocprofv3 summary of the same command",
-                "traffic": None}
+                "traffic": None if per_mb is None else per_mb * n_mb, "traffic_per_minibatch": per_mb,
+                "traffic_source": None if pmc is None else
+                f"{pmc['source']}: (2 x FETCH_SIZE + WRITE_SIZE) of a profiled {PMC_WS_MINIBATCHES}-mini-batch launch, scaled to this launch's mini-batches"}
     else:
         fwd = lin(pol.actor) + lin(pol.critic)
         ha, hc = args.actor.hidden // 16, args.critic.hidden // 16
@@ -276,6 +307,7 @@ def update_kernel_roofline(ppo, pol, B, launches=64):
     avg = sum(us) / len(us)
     flop = 3 * fwd * B
     tf = flop / (avg * 1e-6) / 1e12
+    pmc = update_pmc_traffic(config, kernel)
     return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 5), "flop_per_launch": int(flop), "flop_formula": desc,
             "avg_launch_us": round(avg, 2), "median_launch_us": round(us[len(us) // 2], 2), "launches": len(us),
@@ -283,7 +315,8 @@ def update_kernel_roofline(ppo, pol, B, launches=64):
             "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on eager launches of the fwd_bwd -> reduce -> Adam chain "
                       "right after the timed region (in-region launches are hipGraph nodes); profiles/ holds the rocprofv3 "
                       "summary of the same command",
-            "traffic": None}
+            "traffic": None if pmc is None else pmc["bytes"],
+            "traffic_source": None if pmc is None else f"{pmc['source']}: 2 x FETCH_SIZE + WRITE_SIZE per launch ({pmc['dispatches']} launches)"}
 
 
 def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline):
@@ -404,7 +437,7 @@ def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline
             probe["process_group_allreduce_us"] = round(timed(lambda: dist.all_reduce(buf)), 2)
     res["exchange_probe"] = probe
     if not mpi_utils.distributed_path():                      # single rank: the eager chain is this rank's own
-        res["roofline_update"] = update_kernel_roofline(ppo, pol, args.batch_size)
+        res["roofline_update"] = update_kernel_roofline(ppo, pol, args.batch_size, config=name)
     del ppo, pol, fused
     import gc
     gc.collect()                 # the trainer holds reference cycles (graphs, hooks): release its device memory and
