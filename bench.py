@@ -296,11 +296,14 @@ def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
         fwd = lin(pol.actor) + lin(pol.critic)
         ha, hc = args.actor.hidden // 16, args.critic.hidden // 16
         kernel, desc = f"ppo_update_fwd_bwd_kernel<{ha}, {hc}>", "3 x 2 x sum(Linear weights of actor + critic) x B"
+        if fused.split:
+            desc += " (the chain's FLOPs; the hidden layers' wgrad third runs in ppo_update_wgrad_kernel)"
+        if fused.split:
+            kernel = kernel.replace(">", ", true>")                  # the split-wgrad instantiation of the same kernel
         for _ in range(launches):
             ev = (K.event_create(), K.event_create())
-            _lib.check(lib.ppoaf_ppo_update_fwd_bwd_timed(ref, ev[0], ev[1], st), "fwd_bwd")
-            _lib.check(lib.ppoaf_ppo_update_reduce(ref, 1, st), "reduce")
-            _lib.check(lib.ppoaf_ppo_update_adam(ref, 0, st), "adam")
+            fused.gradient_only(args, ev)                          # fwd_bwd (timed) + wgrad launch / slab reduce
+            _lib.check(lib.ppoaf_ppo_update_adam(ref, 3 if fused.split else 0, st), "adam")
             evs.append(ev)
     torch.cuda.synchronize()
     us = sorted(K.event_elapsed_ms(a, b) * 1e3 for a, b in evs)

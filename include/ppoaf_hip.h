@@ -384,6 +384,11 @@ typedef struct {
      * and advances the cursor once, by n, in the last one: the cursor word is then rewritten once per
      * chain instead of once per mini-batch, so all but the first read of it hit the reader's L2. */
     int64_t mb_offset, cursor_advance;
+    /* split-wgrad chain (NULL: weight-gradient slabs + ppoaf_ppo_update_reduce).  With a workspace of
+     * ppoaf_ppo_update_split_workspace_bytes() bytes (256-byte aligned) fwd_bwd computes no hidden-layer weight gradient:
+     * every workgroup publishes its 16 rows of the inputs, hidden activations and dLoss/dz of the mini-batch there, and
+     * ppoaf_ppo_update_wgrad forms the complete gradients from those panels (then ppoaf_ppo_update_adam, compute_norms 3). */
+    void* split_workspace; int64_t split_workspace_bytes;
 } ppoaf_ppo_update_args_t;
 
 int ppoaf_ppo_update_fwd_bwd(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t stream);
@@ -391,6 +396,17 @@ int ppoaf_ppo_update_fwd_bwd(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t
 int ppoaf_ppo_update_fwd_bwd_timed(const ppoaf_ppo_update_args_t* args, void* start_event, void* stop_event,
                                    ppoaf_stream_t stream);
 int ppoaf_ppo_update_reduce(const ppoaf_ppo_update_args_t* args, int compute_norms, ppoaf_stream_t stream);
+/* Split-wgrad chain: fwd_bwd (args->split_workspace set) -> ppoaf_ppo_update_wgrad -> ppoaf_ppo_update_adam(compute_norms 3).
+ * The weight gradients of ppo.py:2443 (loss.backward()) are formed ONCE per mini-batch over all B rows -- one workgroup
+ * per 16 x 16 tile of dW_l = dz_l^T h_{l-1} on f32 MFMA with K = B, db_l as column sums of dz_l, the output layer's
+ * per-block partials folded in block order -- instead of 16-row partials written to B/16 slabs of the whole bucket and
+ * summed by ppoaf_ppo_update_reduce: 8.7 MB of slab traffic per mini-batch at C2 become 1.6 MB of panels.  The same
+ * launch folds the loss partials into totals, advances the step counters and leaves one pair of squared-norm partials
+ * per workgroup in norm_scratch[6 ..] (needs 6 + 2 * ppoaf_ppo_update_split_blocks(args) doubles).  Sums run in MFMA K
+ * order: float32-rounding-level differences from the slab chain, bitwise reproducible run to run. */
+int ppoaf_ppo_update_split_workspace_bytes(const ppoaf_ppo_update_args_t* args, int64_t* bytes_out);
+int ppoaf_ppo_update_split_blocks(const ppoaf_ppo_update_args_t* args);
+int ppoaf_ppo_update_wgrad(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t stream);
 /* The same chain for n_minibatches consecutive mini-batches (cursor .. cursor + n - 1) in ONE launch that keeps all
  * 2 * ceil(B/16) <= 32 workgroups on one XCD (target_xcc, 0..7): parameters, moments and gradients stay in that XCD's
  * L2 between mini-batches and the chain's three grid-wide dependencies are flag barriers inside it (single rank;

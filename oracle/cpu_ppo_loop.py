@@ -258,7 +258,9 @@ class CpuPPO:
                         # get_detached_dict(next_value) (ppo.py:1115-1141): on the CPU `.detach().cpu().numpy()`
                         # SHARES the tensor's memory, so the in-place `+=` lands in next_value as well -- the
                         # ending VALUE of the GAE carries the surprise too (pinned by fixture g12_c2_icm)
-                        nv = nr = float(np.float32(nr) + (intr[e, 0] - np.float32(ism)))
+                        nr = float(np.float32(nr) + (intr[e, 0] - np.float32(ism)))
+                        # (a reference running on a CUDA device copies in `.cpu()`: the ending value keeps V(next obs))
+                        nv = nr if getattr(self, "reference_device", "cpu") == "cpu" else nv
                     episodes[e].end_episode(nv, nr, self.rtg_accum)
                     finished.append(episodes[e])
                     episodes[e] = new_ep()

@@ -56,7 +56,8 @@ class PpoUpdateArgs(C.Structure):
                 ("kl_loss_weight", C.c_float), ("huber_delta", C.c_float),
                 ("min_std", C.c_float), ("inputs_in_batch_order", C.c_int32),
                 ("loss_partials", C.c_void_p), ("totals", C.c_void_p),
-                ("mb_offset", C.c_int64), ("cursor_advance", C.c_int64)]
+                ("mb_offset", C.c_int64), ("cursor_advance", C.c_int64),
+                ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64)]
 
 
 ABI_VERSION = 3
@@ -195,6 +196,9 @@ SIGNATURES = {
     "ppoaf_ppo_update_ws_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int64, _ptr, _ptr, C.c_int64, C.c_int32, C.c_int32,
                                                C.c_int32, C.c_int32, C.c_double, _ptr, C.c_double, C.c_int32, _ptr, _ptr, _ptr]),
     "ppoaf_ppo_update_reduce": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
+    "ppoaf_ppo_update_split_workspace_bytes": (C.c_int, [C.POINTER(PpoUpdateArgs), C.POINTER(C.c_int64)]),
+    "ppoaf_ppo_update_split_blocks": (C.c_int, [C.POINTER(PpoUpdateArgs)]),
+    "ppoaf_ppo_update_wgrad": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr]),
     "ppoaf_ppo_update_adam": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
     "ppoaf_icm_forward_loss_fwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, C.c_float, _ptr, _ptr, _ptr, _ptr]),
     "ppoaf_icm_forward_loss_bwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, _ptr, _ptr, _ptr, _ptr]),

@@ -25,14 +25,14 @@ namespace ppoaf {
 // an XCD under the observed round-robin dispatch): XCDs 0-3 take the actor, 4-7 the critic, and
 // each weight line is then fetched into an XCD's L2 once for its 4 consumers instead of once per
 // pair.  Placement only changes speed; nothing depends on it.
-template <int HTA, int HTC>
+template <int HTA, int HTC, bool SPLIT>
 __global__ __launch_bounds__(kThreadsU) void ppo_update_fwd_bwd_kernel(UpdateDev u) {
     const int b = blockIdx.x;
     const int which = (b >> 2) & 1;                        // b % 8 in {0..3} -> actor, {4..7} -> critic
     const int g = ((b >> 3) << 2) | (b & 3);
     if (g >= u.n_wg) return;                               // uniform per workgroup, before any barrier
-    if (which == 0) ppo_update_fwd_bwd_body<HTA>(u, 0, g);
-    else ppo_update_fwd_bwd_body<HTC>(u, 1, g);
+    if (which == 0) ppo_update_fwd_bwd_body<HTA, false, UpdateDev, RowtileNoHook, SPLIT>(u, 0, g);
+    else ppo_update_fwd_bwd_body<HTC, false, UpdateDev, RowtileNoHook, SPLIT>(u, 1, g);
 }
 
 // slabs -> gradient bucket in a fixed order.  The slabs were just written by other CUs, so every
@@ -520,10 +520,19 @@ int make_update_dev(const ppoaf_ppo_update_args_t* a, UpdateDev& u) {
     u.huber_delta = a->huber_delta; u.min_std = a->min_std; u.pregathered = a->inputs_in_batch_order != 0; u.loss_partials = a->loss_partials;
     u.totals = a->totals;
     u.n_wg = (int)((a->B + kRows - 1) / kRows);
-    u.debug = 0;
-#ifdef PPOAF_STAMPS
-    if (const char* e = getenv("PPOAF_DEBUG")) u.debug = atoi(e);
-#endif
+    // split-wgrad chain: the caller's workspace holds this mini-batch's activation / dz panels
+    u.split = 0;
+    u.sp = WsDev();
+    if (a->split_workspace) {
+        PPOAF_REQUIRE((((uintptr_t)a->split_workspace) & 255) == 0, "ppo_update: split_workspace must be 256-byte aligned");
+        PPOAF_REQUIRE(u.net[0].in_dim <= 64 && u.net[1].in_dim <= 64 && u.B <= 512,
+                      "ppo_update: the split-wgrad chain covers in_dim <= 64 and B <= 512 (got %d / %d, %ld)", u.net[0].in_dim,
+                      u.net[1].in_dim, u.B);
+        const size_t need = ws_layout(u, &u.sp, reinterpret_cast<char*>(a->split_workspace));
+        PPOAF_REQUIRE((size_t)a->split_workspace_bytes >= need, "ppo_update: split_workspace of %ld B, %zu needed",
+                      (long)a->split_workspace_bytes, need);
+        u.split = 1;
+    }
     return PPOAF_OK;
 }
 
@@ -532,21 +541,26 @@ static size_t fwd_bwd_lds_bytes(const UpdateDev& u) {
     return ((a > c ? a : c) * 4 + 15) / 16 * 16;
 }
 
-template <int HTA, int HTC>
-static int launch_fwd_bwd(const UpdateDev& u, size_t lds, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+template <int HTA, int HTC, bool SPLIT>
+static int launch_fwd_bwd_as(const UpdateDev& u, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_update_fwd_bwd_kernel<HTA, HTC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_update_fwd_bwd_kernel<HTA, HTC, SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
         attr_set = true;
     }
     const unsigned grid = 8u * (unsigned)((u.n_wg + 3) / 4);     // groups of 4 actor + 4 critic blocks
     if (e0 || e1)        // the kernel's own begin / end stamped into the events (bench.py: roofline_update)
-        hipExtLaunchKernelGGL((ppo_update_fwd_bwd_kernel<HTA, HTC>), dim3(grid), dim3(kThreadsU), lds, s, e0, e1, 0, u);
+        hipExtLaunchKernelGGL((ppo_update_fwd_bwd_kernel<HTA, HTC, SPLIT>), dim3(grid), dim3(kThreadsU), lds, s, e0, e1, 0, u);
     else
-        hipLaunchKernelGGL((ppo_update_fwd_bwd_kernel<HTA, HTC>), dim3(grid), dim3(kThreadsU), lds, s, u);
+        hipLaunchKernelGGL((ppo_update_fwd_bwd_kernel<HTA, HTC, SPLIT>), dim3(grid), dim3(kThreadsU), lds, s, u);
     return check_launch("ppo_update_fwd_bwd");
+}
+
+template <int HTA, int HTC>
+static int launch_fwd_bwd(const UpdateDev& u, size_t lds, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+    return u.split ? launch_fwd_bwd_as<HTA, HTC, true>(u, lds, s, e0, e1) : launch_fwd_bwd_as<HTA, HTC, false>(u, lds, s, e0, e1);
 }
 
 }  // namespace ppoaf
@@ -663,7 +677,8 @@ extern "C" int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int co
     if (rc) return rc;
     const long n4 = u.bucket_total >> 2;
     const unsigned grid = (unsigned)((n4 + 255) / 256);
-    PPOAF_REQUIRE(compute_norms >= 0 && compute_norms <= 2, "ppo_update_adam: compute_norms=%d (0, 1 or 2)", compute_norms);
+    PPOAF_REQUIRE(compute_norms >= 0 && compute_norms <= 3, "ppo_update_adam: compute_norms=%d (0 .. 3)", compute_norms);
+    PPOAF_REQUIRE(compute_norms != 3 || u.split, "ppo_update_adam: compute_norms = 3 follows ppoaf_ppo_update_wgrad (split_workspace set)");
     static_assert(kRedThreads == 256, "the reduce launch and the norm pass leave one partial pair per 256 float4 columns");
     if (compute_norms == 1) {
         hipLaunchKernelGGL(ppo_update_sqnorm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u);
@@ -672,8 +687,10 @@ extern "C" int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int co
     }
     // 0 / 1: squared norms = the per-workgroup partials at norm_scratch + 6, added in a fixed association;
     // 2: norm_scratch[0..1] hold them already (ppoaf_peer_exchange_allreduce's norm_out)
+    // 3: the partials of ppoaf_ppo_update_wgrad, one pair per workgroup of that launch
     hipLaunchKernelGGL(ppo_update_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u,
-                       compute_norms == 2 ? (const double*)nullptr : (const double*)(u.norm_scratch + 6), grid);
+                       compute_norms == 2 ? (const double*)nullptr : (const double*)(u.norm_scratch + 6),
+                       compute_norms == 3 ? (unsigned)split_wgrad_blocks(u) : grid);
     return check_launch("ppo_update_adam");
 }
 

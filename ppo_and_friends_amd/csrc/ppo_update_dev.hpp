@@ -6,6 +6,18 @@
 
 namespace ppoaf {
 
+// Per-mini-batch panels shared by the layered mode of the two-XCD persistent kernel and by the split-wgrad chain
+// (fwd_bwd publishes them, the wgrad launch consumes them): workspace memory, 256-byte aligned pieces.
+struct WsDev {
+    float* hbuf[2];                       // [depth][Bp][H]   hidden activations of the mini-batch
+    float* dbuf[2];                       // [depth][Bp][H]   dLoss / dz
+    float* outpart[2];                    // [ceil(B/16)][seg] output-layer (+ log_std) gradient partials per row block
+    float* xbuf[2];                       // [Bp][64]         the mini-batch's gathered input rows, zero padded (layer-0 wgrad)
+    int W;                                // workers per network (persistent kernel)
+    int xcc[2];                           // XCD of the actor / critic workers (persistent kernel)
+    int Bp;                               // B rounded up to 64
+};
+
 struct UpdateDev {
     NetDev net[2];
     const float* params; float* grads; float* exp_avg; float* exp_avg_sq; float* slabs;
@@ -23,8 +35,45 @@ struct UpdateDev {
     float surr_clip, entropy_weight, kl_loss_weight, huber_delta, min_std;
     float* loss_partials; double* totals;
     int n_wg;
-    int debug;           // diagnostic build only (PPOAF_STAMPS): ablation switches
+    int split;           // 1: split-wgrad chain -- fwd_bwd publishes activation / dz panels (sp) instead of weight-gradient slabs
+    WsDev sp;
 };
+
+// offset of the output layer's segment (W_out, b_out, log_std) inside a network's bucket, and its length
+inline long ws_seg_off(const NetDev& n) {
+    const long szW0 = ((long)n.H * n.in_dim + 3) & ~3L;
+    return n.depth == 0 ? 0 : szW0 + n.H + (long)(n.depth - 1) * ((long)n.H * n.H + n.H);
+}
+inline long ws_seg_len(const NetDev& n) { return n.size - ws_seg_off(n); }
+
+// split-wgrad launch: one 4-wave workgroup per 16 x 16 tile of every layer's weight gradient (layer 0: ceil(in_dim / 16)
+// column tiles) + one per network for the output layer's segment; the bookkeeping workgroup comes last
+inline int split_wgrad_jobs(const NetDev& n) {
+    const int t = n.H / 16;
+    return (n.depth - 1) * t * t + t * ((n.in_dim + 15) / 16) + 1;
+}
+inline int split_wgrad_blocks(const UpdateDev& u) { return split_wgrad_jobs(u.net[0]) + split_wgrad_jobs(u.net[1]); }
+
+// workspace layout: per network hbuf, dbuf ([depth][Bp][H] each), outpart ([ceil(B/16)][seg]) and xbuf ([Bp][64])
+inline size_t ws_layout(const UpdateDev& u, WsDev* ws, char* base) {
+    const long Bp = (u.B + 63) & ~63L;
+    size_t off = 0;
+    auto take = [&](size_t floats) { const size_t o = off; off += (floats * 4 + 255) & ~(size_t)255; return o; };
+    for (int w = 0; w < 2; ++w) {
+        const NetDev& n = u.net[w];
+        const size_t plane = (size_t)n.depth * Bp * n.H;
+        const size_t oh = take(plane), od = take(plane), oo = take((size_t)((u.B + 15) / 16) * ws_seg_len(n));
+        const size_t ox = take((size_t)Bp * 64);
+        if (ws) {
+            ws->hbuf[w] = reinterpret_cast<float*>(base + oh);
+            ws->dbuf[w] = reinterpret_cast<float*>(base + od);
+            ws->outpart[w] = reinterpret_cast<float*>(base + oo);
+            ws->xbuf[w] = reinterpret_cast<float*>(base + ox);
+        }
+    }
+    if (ws) ws->Bp = (int)Bp;
+    return off;
+}
 
 // host: validate ppoaf_ppo_update_args_t and fill the device view (ppo_update.hip)
 int make_update_dev(const ppoaf_ppo_update_args_t* a, UpdateDev& u);

@@ -35,9 +35,13 @@ static __device__ unsigned long long g_ppo_update_stamps[2][16];
 // statistics loads and BEFORE the first load of a parameter -- the two-XCD kernel waits there for the previous
 // mini-batch's Adam phase, so that barrier's latency overlaps the dependent index loads.  Returning false abandons the
 // body (a bounded wait ran out).
+// SPLIT = true (split-wgrad chain): the body keeps forward, losses and dgrad, but computes NO weight gradient of a hidden
+// layer.  It publishes what a complete-K wgrad launch needs instead -- its 16 rows of the input x, of every hidden
+// activation h_l and of every dLoss/dz_l (u.sp: hbuf / dbuf / xbuf planes, 16 KB per layer per workgroup at H = 128
+// against a 135 KB slab) -- and the output layer's partials go to u.sp.outpart (folded in block order by that launch).
 struct RowtileNoHook { __device__ __forceinline__ bool operator()() const { return true; } };
 
-template <int HT, bool NT = false, typename U = UpdateDev, typename Hook = RowtileNoHook>
+template <int HT, bool NT = false, typename U = UpdateDev, typename Hook = RowtileNoHook, bool SPLIT = false>
 __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int which, const int g,
                                                         const long mb_extra = 0, Hook before_weights = Hook()) {
     constexpr int H = 16 * HT, HS = H + 4;                 // which: 0 actor, 1 critic; g: 16-row block
@@ -52,15 +56,9 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     const int NT0 = (in_dim + 15) >> 4;                    // 16-column tiles of the input
     const int INP = 16 * NT0 + 4;
     const float* P = u.params + nd.offset;
-    float* slab = u.slabs + (long)g * u.bucket_total + nd.offset;
     const long B = u.B;
     const long mb = u.cursor[0] + u.mb_offset + mb_extra;
     const long base = mb * u.batch_stride;
-#ifdef PPOAF_STAMPS
-    const int dbg = u.debug;
-#else
-    constexpr int dbg = 0;
-#endif
     // Layer offsets inside the bucket, by arithmetic: indexing a table in the kernel arguments with a
     // loop variable compiles to a vector load of kernarg memory plus a full vmcnt drain (~6k cycles).
     const long szW0 = ((long)H * in_dim + 3) & ~3L;
@@ -68,6 +66,19 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     auto offB = [&](int l) -> long {
         return l == 0 ? szW0 : offW(l) + (l < depth ? (long)H * H : (((long)out_dim * H + 3) & ~3L));
     };
+    // where this block's gradient partials go: its slab of the whole bucket, or (SPLIT: only the output layer's segment is
+    // produced here) its row of the output-layer partials, addressed with the same bucket offsets
+    float* slab = SPLIT ? u.sp.outpart[which] + (long)g * (nd.size - offW(depth)) - offW(depth)
+                        : u.slabs + (long)g * u.bucket_total + nd.offset;
+    // 16 rows x H floats of LDS (row stride HS) -> rows [16 g, +16) of a [Bp][H] panel: one float4 per thread at H = 128
+    auto publish_rows = [&](const float* src, float* panel) {
+        float* dst = panel + (long)g * kRows * H;
+        for (int i = tid; i < kRows * (H / 4); i += kThreadsU) {
+            const int r = i / (H / 4), c4 = i - r * (H / 4);
+            *reinterpret_cast<float4*>(dst + (long)r * H + 4 * c4) = *reinterpret_cast<const float4*>(src + r * HS + 4 * c4);
+        }
+    };
+    const long sp_plane = SPLIT ? (long)u.sp.Bp * H : 0;
 
     PPOAF_STAMP(0);
     // ---- LDS carve (all offsets multiples of 16 B)
@@ -97,10 +108,10 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     // weight load is then in flight for at least two phases -- including the cold first touch after the
     // Adam kernel rewrote the bucket -- instead of one barrier.
     const bool has_tile = wave < HT;          // waves beyond the tile count idle in MFMA phases (H < 128)
-    const bool deep = depth == 3 && HT <= kNW && !dbg;
+    const bool deep = depth == 3 && HT <= kNW;
     float4 fr[HT], fr2[HT];
     // first layer with at most 16 inputs: its 4 weight values per lane are requested early as well
-    const bool l0_pre = in_dim <= 16 && HT <= kNW && has_tile && !dbg;
+    const bool l0_pre = in_dim <= 16 && HT <= kNW && has_tile;
     float l0w[4] = {0.f, 0.f, 0.f, 0.f};
     float l2_touch = 0.f;
     // biases and output-layer weights: requested into registers now, stored to LDS after the row loads
@@ -143,14 +154,14 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
         int row = -1;
         long di = -1;                                      // where this row's inputs are read from
         if (s < B) {
-            long p = (dbg & 32) ? (base + s) : u.perm[base + s];
-            if (p >= 0 && p < u.n_rows) row = (u.row_map && !(dbg & 32)) ? u.row_map[p] : (int)p;
+            const long p = u.perm[base + s];
+            if (p >= 0 && p < u.n_rows) row = u.row_map ? u.row_map[p] : (int)p;
             // per-epoch tables in shuffled order: the address depends on the cursor only, so these loads
             // go out together with the perm load instead of after it
             di = u.pregathered ? base + s : row;
         }
         float av = 0.f, lpo = 0.f, rt = 0.f;
-        if (di >= 0 && !(dbg & 64)) {
+        if (di >= 0) {
             if (which == 0) {
                 av = u.adv[di]; lpo = u.old_lp[di];
                 if (u.head_kind == PPOAF_HEAD_CATEGORICAL)
@@ -242,12 +253,18 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
         }
     }
     // prefetch: fragments of the first hidden-to-hidden layer (or nothing if depth == 1)
-    if (!deep && depth > 1 && has_tile) load_fwd_frags<HT, NT>(P + offW(1), wave * 16, lane, fr, dbg);
+    if (!deep && depth > 1 && has_tile) load_fwd_frags<HT, NT>(P + offW(1), wave * 16, lane, fr);
     __syncthreads();
     PPOAF_STAMP(2);
+    if (SPLIT) {            // the block's input rows, zero padded to 64 columns: the layer-0 wgrad's K-panel
+        float* xb = u.sp.xbuf[which] + (long)g * kRows * 64;
+        for (int i = tid; i < kRows * 64; i += kThreadsU) {
+            const int r = i >> 6, c = i & 63;
+            xb[i] = c < 16 * NT0 ? sX[r * INP + c] : 0.f;
+        }
+    }
 
     // ---- L0: first layer on MFMA, K = in_dim padded to a multiple of 4 (sX is zero padded)
-    if (!(dbg & 128))
     for (int nt = wave; nt < HT; nt += kNW) {
         const int o = nt * 16 + (lane & 15);
         const float bv = sBias[o];
@@ -275,6 +292,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     for (int l = 1; l < depth; ++l) {
         const float* Hp = sH + (long)(l - 1) * kRows * HS;
         float* Hc = sH + (long)l * kRows * HS;
+        if (SPLIT) publish_rows(Hp, u.sp.hbuf[which] + (long)(l - 1) * sp_plane);      // h_{l-1}: the K-panel of dW_l
         for (int nt = wave; nt < HT; nt += kNW) {
             const int o = nt * 16 + (lane & 15);
             f32x4 acc;
@@ -287,13 +305,11 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
                     load_dgrad_frags<HT, NT>(P + offW(1), wave * 16, lane, fr2); // second backward phase
                 }
             } else {
-            if (nt != wave) load_fwd_frags<HT, NT>(P + offW(l), nt * 16, lane, fr, dbg);
-            
-            acc = (dbg & 2) ? f32x4{fr[0].x + fr[HT - 1].w, 0.f, 0.f, 0.f} : mfma_rows_x_frags<HT>(Hp, HS, lane, fr, sBias[l * H + o]);
-            
+            if (nt != wave) load_fwd_frags<HT, NT>(P + offW(l), nt * 16, lane, fr);
+            acc = mfma_rows_x_frags<HT>(Hp, HS, lane, fr, sBias[l * H + o]);
             if (nt + kNW >= HT) {                           // last tile of this wave in this layer
-                if (l + 1 < depth) load_fwd_frags<HT, NT>(P + offW(l + 1), wave * 16, lane, fr, dbg);
-                else load_dgrad_frags<HT, NT>(P + offW(l), wave * 16, lane, fr, dbg);   // first backward phase
+                if (l + 1 < depth) load_fwd_frags<HT, NT>(P + offW(l + 1), wave * 16, lane, fr);
+                else load_dgrad_frags<HT, NT>(P + offW(l), wave * 16, lane, fr);   // first backward phase
             }
             }
 #pragma unroll
@@ -321,7 +337,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     PPOAF_STAMP(5);
 
     // ---- distribution head + loss terms for this workgroup's rows (K6 + K3)
-    if (wave == 0 && !(dbg & 8)) {
+    if (wave == 0) {
         ppo_head_loss<NT>(u, which, g, out_dim, P + nd.log_std_off, sRow, sRowF, sMisc, sActF, sOut, sDOut, lane, B);
     }
     __syncthreads();
@@ -329,7 +345,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
 
     // ---- output layer backward (weights from LDS).  Operands are pulled into registers with
     //      independent LDS reads first; a read-per-FMA loop is LDS-latency bound (~64 cycles each).
-    if (!(dbg & 16)) {
+    {
         if (tid < H) {
             const int i = tid;
             float h[kRows];
@@ -389,15 +405,16 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     float* Dn = sD1;
     for (int l = depth - 1; l >= 1; --l) {
         const float* Hin = sH + (long)(l - 1) * kRows * HS;
+        if (SPLIT) publish_rows(Dc, u.sp.dbuf[which] + (long)l * sp_plane);            // dz_l: the other panel of dW_l, db_l
         // dgrad first (its operands were prefetched): dh[s][i] = sum_o dz[s][o] * W[o][i]
         for (int nt = wave; nt < HT; nt += kNW) {
             f32x4 acc;
             if (deep) {
                 acc = l == 2 ? mfma_rows_x_frags<HT>(Dc, HS, lane, fr, 0.f) : mfma_rows_x_frags<HT>(Dc, HS, lane, fr2, 0.f);
             } else {
-            if (nt != wave) load_dgrad_frags<HT, NT>(P + offW(l), nt * 16, lane, fr, dbg);
-            acc = (dbg & 2) ? f32x4{fr[0].x + fr[HT - 1].w, 0.f, 0.f, 0.f} : mfma_rows_x_frags<HT>(Dc, HS, lane, fr, 0.f);
-            if (nt + kNW >= HT && l - 1 >= 1) load_dgrad_frags<HT, NT>(P + offW(l - 1), wave * 16, lane, fr, dbg);
+            if (nt != wave) load_dgrad_frags<HT, NT>(P + offW(l), nt * 16, lane, fr);
+            acc = mfma_rows_x_frags<HT>(Dc, HS, lane, fr, 0.f);
+            if (nt + kNW >= HT && l - 1 >= 1) load_dgrad_frags<HT, NT>(P + offW(l - 1), wave * 16, lane, fr);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -406,18 +423,19 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
             }
         }
         if (l == depth - 1) PPOAF_STAMP(10);
-        // wgrad: dW[o][i] = sum_s dz[s][o] * Hin[s][i]
-        if (!(dbg & 4))
-        for (int mt = wave; mt < HT; mt += kNW) {
-            if (HT <= 8) wgrad_mtile_full<(HT <= 8 ? HT : 1)>(Dc, HS, Hin, HS, mt * 16, lane, slab + offW(l), H);
-            else wgrad_mtile(Dc, HS, Hin, HS, mt * 16, HT, H, lane, slab + offW(l), H);
-        }
-        if (l == depth - 1) PPOAF_STAMP(11);
-        for (int o = tid; o < H; o += kThreadsU) {
-            float acc = 0.f;
+        // wgrad: dW[o][i] = sum_s dz[s][o] * Hin[s][i]   (SPLIT: left to the wgrad launch, over all rows at once)
+        if (!SPLIT) {
+            for (int mt = wave; mt < HT; mt += kNW) {
+                if (HT <= 8) wgrad_mtile_full<(HT <= 8 ? HT : 1)>(Dc, HS, Hin, HS, mt * 16, lane, slab + offW(l), H);
+                else wgrad_mtile(Dc, HS, Hin, HS, mt * 16, HT, H, lane, slab + offW(l), H);
+            }
+            if (l == depth - 1) PPOAF_STAMP(11);
+            for (int o = tid; o < H; o += kThreadsU) {
+                float acc = 0.f;
 #pragma unroll
-            for (int s = 0; s < kRows; ++s) acc += Dc[s * HS + o];
-            slab[offB(l) + o] = acc;
+                for (int s = 0; s < kRows; ++s) acc += Dc[s * HS + o];
+                slab[offB(l) + o] = acc;
+            }
         }
         if (l == depth - 1) PPOAF_STAMP(12);
         __syncthreads();
@@ -427,16 +445,19 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     PPOAF_STAMP(8);
 
     // ---- first layer backward: dW0[o][i] = sum_s dz0[s][o] * x[s][i] on MFMA against the padded sX
-    if (!(dbg & 256))
-    for (int mt = wave; mt < HT; mt += kNW)
-        wgrad_mtile(Dc, HS, sX, INP, mt * 16, NT0, in_dim, lane, slab + offW(0), in_dim);
-    for (int o = tid; o < H; o += kThreadsU) {
-        float acc = 0.f;
+    if (SPLIT) {
+        publish_rows(Dc, u.sp.dbuf[which]);                   // dz_0 (its K-panel is x, published after the gather)
+    } else {
+        for (int mt = wave; mt < HT; mt += kNW)
+            wgrad_mtile(Dc, HS, sX, INP, mt * 16, NT0, in_dim, lane, slab + offW(0), in_dim);
+        for (int o = tid; o < H; o += kThreadsU) {
+            float acc = 0.f;
 #pragma unroll
-        for (int s = 0; s < kRows; ++s) acc += Dc[s * HS + o];
-        slab[offB(0) + o] = acc;
+            for (int s = 0; s < kRows; ++s) acc += Dc[s * HS + o];
+            slab[offB(0) + o] = acc;
+        }
     }
-    if (l2_touch == 1.2345e38f) slab[0] = l2_touch;        // keeps the early line touches alive
+    if (l2_touch == 1.2345e38f) u.loss_partials[0] = l2_touch;   // keeps the early line touches alive
     PPOAF_STAMP(9);
 }
 

@@ -40,16 +40,6 @@ namespace ppoaf {
 constexpr int kWsPS = 36;                 // row stride of a 32-column panel slice (conflict-free scalar reads)
 constexpr int kWsMaxWorkers = 32;
 
-struct WsDev {
-    float* hbuf[2];                       // [depth][Bp][H]   hidden activations of the mini-batch
-    float* dbuf[2];                       // [depth][Bp][H]   dLoss / dz
-    float* outpart[2];                    // [ceil(B/16)][seg] output-layer (+ log_std) gradient partials per row block
-    float* xbuf[2];                       // [Bp][64]         the mini-batch's gathered input rows, zero padded (layer-0 wgrad)
-    int W;                                // workers per network
-    int xcc[2];                           // XCD of the actor / critic workers
-    int Bp;                               // B rounded up to 64
-};
-
 struct WsCtl {
     unsigned tickets[2], error, done, pad0[28];
     unsigned flags[2][kWsMaxWorkers];     // barrier epoch each worker has reached
@@ -1388,33 +1378,6 @@ static size_t ws_lds_floats(const NetDev& n, long B) {
     return 2048 + 16 + 48 + 128 + 256 + 256 + 1536 + p;
 }
 
-static long ws_seg_len(const NetDev& n) {
-    const long szW0 = ((long)n.H * n.in_dim + 3) & ~3L;
-    const long seg_off = n.depth == 0 ? 0 : szW0 + n.H + (long)(n.depth - 1) * ((long)n.H * n.H + n.H);
-    return n.size - seg_off;
-}
-
-// workspace layout: per network hbuf, dbuf ([depth][Bp][H] each) and outpart ([ceil(B/16)][seg]); 256-byte aligned pieces
-static size_t ws_layout(const UpdateDev& u, WsDev* ws, char* base) {
-    const long Bp = (u.B + 63) & ~63L;
-    size_t off = 0;
-    auto take = [&](size_t floats) { const size_t o = off; off += (floats * 4 + 255) & ~(size_t)255; return o; };
-    for (int w = 0; w < 2; ++w) {
-        const NetDev& n = u.net[w];
-        const size_t plane = (size_t)n.depth * Bp * n.H;
-        const size_t oh = take(plane), od = take(plane), oo = take((size_t)((u.B + 15) / 16) * ws_seg_len(n));
-        const size_t ox = take((size_t)Bp * 64);
-        if (ws) {
-            ws->hbuf[w] = reinterpret_cast<float*>(base + oh);
-            ws->dbuf[w] = reinterpret_cast<float*>(base + od);
-            ws->outpart[w] = reinterpret_cast<float*>(base + oo);
-            ws->xbuf[w] = reinterpret_cast<float*>(base + ox);
-        }
-    }
-    if (ws) ws->Bp = (int)Bp;
-    return off;
-}
-
 // which decomposition each network's worker group runs: bit 0 actor, bit 1 critic set = layered (weight-stationary
 // tiles), clear = row-tiled (fwd_bwd body + in-register slab fold); mask < 0: automatic -- layered for 256-wide
 // networks (a 16-row workgroup is then at its MFMA floor), row-tiled below.
@@ -1467,6 +1430,176 @@ static int ws_launch(const WsArgs& a, WsCtl* ctl, int n_mb, long long budget, si
     else
         hipLaunchKernelGGL((ppo_update_ws_kernel<HA, HC, LA, LC>), dim3(256), dim3(kThreadsU), lds, s, a, ctl, n_mb, budget);
     return check_launch("ppo_update_ws");
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Split-wgrad chain (the default single-rank chain): the launch between fwd_bwd<SPLIT> and Adam.  fwd_bwd's workgroups
+// have published the mini-batch's inputs, hidden activations and dLoss/dz as [Bp][H] panels (u.sp); here ONE 4-wave
+// workgroup forms one 16 x 16 tile of dW_l = dz_l^T . h_{l-1} over ALL B rows: every lane requests its MFMA operands
+// straight from the panels (element (k, o) of dz and (k, i) of h for its k = 4 c + lane / 16: no LDS staging, all loads
+// of the tile in flight at once -- the panels were written by other XCDs a moment ago, so the launch is one cold round
+// trip long), wave w takes K chunks w, w + 4, ...; the four partial tiles are folded through LDS in wave order; db_l =
+// the column sums of dz_l, on the tiles of input tile 0.  One workgroup per network folds the output layer's per-block
+// partials in block order; the last one does the per-mini-batch bookkeeping.  Every workgroup leaves a pair of
+// squared-norm partials (scaled gradients, double) for the Adam launch to add in workgroup order.  No slabs, no atomics:
+// 8.7 MB of slab round trip per mini-batch at C2 become 1.6 MB of panels, and the hidden-layer wgrad MFMAs leave
+// fwd_bwd's dependent chain.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kWgradThreads = 256;
+
+__device__ __forceinline__ void ppo_update_bookkeeping_split(const UpdateDev& u) {
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    float p0 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p7 = 0.f;
+    for (int g = lane; g < u.n_wg; g += 64) {
+        const float* a = u.loss_partials + (long)g * 8;
+        const float* cc = u.loss_partials + ((long)u.n_wg + g) * 8;
+        p0 += a[0]; p3 += a[3]; p4 += a[4]; p7 += a[7]; p2 += cc[2];
+    }
+    p0 = wave_sum(p0); p2 = wave_sum(p2); p3 = wave_sum(p3); p4 = wave_sum(p4); p7 = wave_sum(p7);
+    if (lane == 0) {
+        const float n = (float)u.B;
+        const float surr = p0 / n, ent = p3 / n, kl = p4 / n, crit = p2 / n;
+        float total = surr;
+        if (u.entropy_weight != 0.0f) total -= u.entropy_weight * ent;
+        if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
+        u.totals[0] += (double)surr; u.totals[1] += (double)total; u.totals[2] += (double)crit;
+        u.totals[3] += (double)ent; u.totals[4] += (double)kl;
+        u.totals[5] += (double)u.loss_partials[5]; u.totals[6] += (double)u.loss_partials[6];
+        u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
+        u.totals[8] += 1.0;
+    }
+    if (lane < 2) {                                       // one lane per network: step counter + bias corrections
+        const int w = lane;
+        const int64_t t = u.step_counts[w] + 1;
+        u.step_counts[w] = t;
+        u.norm_scratch[2 + 2 * w] = 1.0 - pow((double)u.beta1, (double)t);
+        u.norm_scratch[3 + 2 * w] = sqrt(1.0 - pow((double)u.beta2, (double)t));
+    }
+}
+
+// MAXC = chunks of 16 rows a wave may own (B <= 512: 32 chunks over 4 waves)
+template <int H>
+__device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int which, const int job, float* sFold /* [3][256] + [4][16] */) {
+    constexpr int MAXC = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const auto& nd = u.net[which];
+    const int in_dim = nd.in_dim, depth = nd.depth, out_dim = nd.out_dim;
+    const int B = (int)u.B;
+    const long plane = (long)u.sp.Bp * H;
+    const long szW0 = ((long)H * in_dim + 3) & ~3L;
+    auto offW = [&](int l) -> long { return l == 0 ? 0 : szW0 + H + (long)(l - 1) * ((long)H * H + H); };
+    auto offB = [&](int l) -> long {
+        return l == 0 ? szW0 : offW(l) + (l < depth ? (long)H * H : (((long)out_dim * H + 3) & ~3L));
+    };
+    float* G = u.grads + nd.offset;
+    constexpr int t = H / 16;
+    const int n_hidden = (depth - 1) * t * t, n_it0 = (in_dim + 15) / 16, n_l0 = t * n_it0;
+    const float sc = u.grad_scale;
+    double q = 0.0;
+    if (job < n_hidden + n_l0) {
+        int l, ot, itile;
+        if (job < n_hidden) { l = 1 + job / (t * t); const int jj = job % (t * t); ot = jj / t; itile = jj % t; }
+        else { l = 0; const int jj = job - n_hidden; ot = jj / n_it0; itile = jj % n_it0; }
+        const float* Dp = u.sp.dbuf[which] + (long)l * plane + ot * 16 + (lane & 15);
+        const float* Xp = l >= 1 ? u.sp.hbuf[which] + (long)(l - 1) * plane + itile * 16 + (lane & 15)
+                                 : u.sp.xbuf[which] + itile * 16 + (lane & 15);
+        const long ldx = l >= 1 ? H : 64;
+        const int nc = (B + 15) >> 4;                         // 16-row chunks of the mini-batch
+        float a[MAXC][4], x[MAXC][4];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = wave + 4 * c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 16 * ch + 4 * j + (lane >> 4);
+                const bool ok = ch < nc && row < B;
+                a[c][j] = ok ? Dp[(long)row * H] : 0.f;
+                x[c][j] = ok ? Xp[(long)row * ldx] : 0.f;
+            }
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        float bsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (wave + 4 * c < nc) {                          // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (c & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x[c][j], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x[c][j], acc0, 0, 0, 0);
+                    bsum += a[c][j];
+                }
+            }
+        }
+        f32x4 acc = acc0 + acc1;
+        // fold the four waves' partial tiles in wave order (waves 1..3 park theirs in LDS)
+        if (wave > 0) *reinterpret_cast<f32x4*>(sFold + ((wave - 1) * 64 + lane) * 4) = acc;
+        // bias: column o = lane & 15 summed over this lane group's rows, then over the 4 lane groups, then over the waves
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 16) sFold[768 + wave * 16 + lane] = bsum;
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) acc += *reinterpret_cast<const f32x4*>(sFold + (w * 64 + lane) * 4);
+            const long ldw = l >= 1 ? H : in_dim;
+            const int i = itile * 16 + (lane & 15);           // C layout: column = lane & 15, rows 4 (lane >> 4) + r
+            if (i < ldw) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = ot * 16 + 4 * (lane >> 4) + r;
+                    G[offW(l) + (long)o * ldw + i] = acc[r];
+                    q += (double)(acc[r] * sc) * (acc[r] * sc);
+                }
+            }
+            if (itile == 0 && lane < 16) {
+                const float bg = sFold[768 + lane] + sFold[768 + 16 + lane] + sFold[768 + 32 + lane] + sFold[768 + 48 + lane];
+                G[offB(l) + ot * 16 + lane] = bg;
+                q += (double)(bg * sc) * (bg * sc);
+            }
+        }
+    } else {
+        // output layer (+ log_std): row-block partials -> gradient, in block order
+        const long seg_off = offW(depth), seg_len = nd.size - seg_off;
+        const float* outpart = u.sp.outpart[which];
+        const int n_hb = (B + 15) >> 4;
+        for (long idx = tid; idx < seg_len; idx += kWgradThreads) {
+            float acc = 0.f;
+            for (int g0 = 0; g0 < n_hb; g0 += 8) {
+                float pv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pv[k] = outpart[(long)(g0 + k < n_hb ? g0 + k : 0) * seg_len + idx];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (g0 + k < n_hb) acc += pv[k];
+            }
+            G[seg_off + idx] = acc;
+            q += (double)(acc * sc) * (acc * sc);
+        }
+    }
+    return q;
+}
+
+template <int HA, int HC>
+__global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_kernel(UpdateDev u, int jobs_a, int jobs_c) {
+    __shared__ double s_red[17];
+    __shared__ __attribute__((aligned(16))) float s_fold[3 * 256 + 64];
+    const int b = blockIdx.x;
+    if (b == jobs_a + jobs_c) { ppo_update_bookkeeping_split(u); return; }      // uniform per workgroup
+    const int which = b < jobs_a ? 0 : 1;
+    double q = which == 0 ? split_wgrad_job<HA>(u, 0, b, s_fold) : split_wgrad_job<HC>(u, 1, b - jobs_a, s_fold);
+    q = block_sum(q, s_red);
+    if (threadIdx.x == 0) {
+        u.norm_scratch[6 + 2 * b] = which == 0 ? q : 0.0;
+        u.norm_scratch[7 + 2 * b] = which == 1 ? q : 0.0;
+    }
+}
+
+template <int HA, int HC>
+static int wgrad_launch(const UpdateDev& u, hipStream_t s) {
+    const int ja = split_wgrad_jobs(u.net[0]), jc = split_wgrad_jobs(u.net[1]);
+    hipLaunchKernelGGL((ppo_update_wgrad_kernel<HA, HC>), dim3((unsigned)(ja + jc + 1)), dim3(kWgradThreads), 0, s, u, ja, jc);
+    return check_launch("ppo_update_wgrad");
 }
 
 }  // namespace ppoaf
@@ -1569,4 +1702,45 @@ extern "C" int ppoaf_ppo_update_ws_exchange(const ppoaf_ppo_update_args_t* args,
     PPOAF_REQUIRE(xchg, "ppo_update_ws_exchange: null exchange (single rank: ppoaf_ppo_update_ws)");
     return ws_update(args, n_minibatches, ctl, workspace, workspace_bytes, workers, xcc_actor, xcc_critic, layered_mask,
                      wait_seconds, xchg, xchg_wait_seconds, xchg_fences, start_event, stop_event, stream);
+}
+
+extern "C" int ppoaf_ppo_update_split_workspace_bytes(const ppoaf_ppo_update_args_t* args, int64_t* bytes_out) {
+    PPOAF_REQUIRE(args && bytes_out, "ppo_update_split_workspace_bytes: null argument");
+    ppoaf_ppo_update_args_t a = *args;
+    a.split_workspace = nullptr;
+    UpdateDev u;
+    int rc = make_update_dev(&a, u);
+    if (rc) return rc;
+    PPOAF_REQUIRE(u.net[0].in_dim <= 64 && u.net[1].in_dim <= 64 && u.B <= 512,
+                  "ppo_update_split_workspace_bytes: the split-wgrad chain covers in_dim <= 64 and B <= 512 (got %d / %d, %ld)",
+                  u.net[0].in_dim, u.net[1].in_dim, u.B);
+    *bytes_out = (int64_t)ws_layout(u, nullptr, nullptr);
+    return PPOAF_OK;
+}
+
+extern "C" int ppoaf_ppo_update_split_blocks(const ppoaf_ppo_update_args_t* args) {
+    UpdateDev u;
+    ppoaf_ppo_update_args_t a;
+    if (!args) return -1;
+    a = *args;
+    a.split_workspace = nullptr;
+    if (make_update_dev(&a, u)) return -1;
+    return split_wgrad_blocks(u);
+}
+
+extern "C" int ppoaf_ppo_update_wgrad(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t stream) {
+    UpdateDev u;
+    int rc = make_update_dev(args, u);
+    if (rc) return rc;
+    PPOAF_REQUIRE(u.split, "ppo_update_wgrad: args->split_workspace is not set (the slab chain uses ppoaf_ppo_update_reduce)");
+    hipStream_t s = (hipStream_t)stream;
+    const int ha = u.net[0].H, hc = u.net[1].H;
+    if (ha == 32 && hc == 32) return wgrad_launch<32, 32>(u, s);
+    if (ha == 64 && hc == 64) return wgrad_launch<64, 64>(u, s);
+    if (ha == 128 && hc == 128) return wgrad_launch<128, 128>(u, s);
+    if (ha == 256 && hc == 256) return wgrad_launch<256, 256>(u, s);
+    if (ha == 128 && hc == 256) return wgrad_launch<128, 256>(u, s);
+    if (ha == 64 && hc == 128) return wgrad_launch<64, 128>(u, s);
+    set_error("ppo_update_wgrad: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
+    return PPOAF_E_INVALID;
 }

@@ -90,6 +90,10 @@ def _reduce_totals(upd, totals):
     for x in (upd.xchg, getattr(upd, "xchg_ws", None)):
         if x is not None and x.status()[1] != 0:
             broken = 1.0
+    ws_failure = upd._persistent_failure() if hasattr(upd, "_persistent_failure") else ""
+    if ws_failure:                 # this rank's persistent launch did not complete: its peers' exchanges timed out on it
+        upd._ws_disabled = ws_failure
+        broken = 1.0
     t = torch.cat([t, torch.tensor([broken], dtype=t.dtype, device=t.device)])
     mpi_utils.allreduce_sum_(t)
     out = t.cpu().numpy()
@@ -158,6 +162,8 @@ class FusedPolicyUpdate:
         self.perm = None
         self._graphs = {}
         self._args = {}
+        self.split, self.split_reason = self._split_wanted()
+        self._split_space = None
         # N > 1: the per-mini-batch gradient exchange.  K17 over peer mappings when every rank can (same
         # host, IPC + self-test passed: collective decision), else the RCCL all-reduce in an eager loop.
         self.xchg, self.xchg_reason = (peer_exchange.open_exchange(total, dev) if self.multi else (None, "single rank"))
@@ -168,6 +174,36 @@ class FusedPolicyUpdate:
             self.xchg_ws, why = peer_exchange.open_exchange(total, dev)
             if self.xchg_ws is None:
                 self.xchg_reason += f"; persistent-kernel exchange refused ({why})"
+
+    def _split_wanted(self):
+        """
+        (bool, why): the split-wgrad chain (fwd_bwd publishes activation / dz panels, ppoaf_ppo_update_wgrad forms the complete
+        weight gradients) instead of weight-gradient slabs + the slab reduce.  PPOAF_SPLIT_WGRAD = auto | 1 | 0; auto =
+        single rank (the N > 1 chain fuses the K17 exchange into the slab reduce launch) and shapes the panels cover.
+        """
+        import os
+        mode = os.environ.get("PPOAF_SPLIT_WGRAD", "auto")
+        if mode not in ("auto", "0", "1"):
+            raise ValueError(f"PPOAF_SPLIT_WGRAD={mode!r}: expected auto, 0 or 1")
+        if mode == "0":
+            return False, "off (PPOAF_SPLIT_WGRAD=0)"
+        if type(self) is not FusedPolicyUpdate:
+            return False, "K12 (MLP policies) only"
+        if max(self.actor_desc.in_dim, self.critic_desc.in_dim) > 64 or self.B > 512:
+            return False, "the panels cover in_dim <= 64 and batch sizes <= 512"
+        if self.multi:
+            return False, "N > 1: the slab reduce launch carries the K17 exchange"
+        return True, ""
+
+    def gradient_only(self, args, timing_events=(None, None)):
+        """fwd_bwd + the launch that completes the gradient bucket (wgrad / slab reduce) of ONE mini-batch, no optimiser step:
+        what tests and bench probes compare.  The bookkeeping of that launch (totals, step counters) runs as usual."""
+        lib, st, ref = self._lib, K.stream(), C.byref(args)
+        _lib.check(lib.ppoaf_ppo_update_fwd_bwd_timed(ref, timing_events[0], timing_events[1], st), "ppo_update_fwd_bwd")
+        if args.split_workspace:
+            _lib.check(lib.ppoaf_ppo_update_wgrad(ref, st), "ppo_update_wgrad")
+        else:
+            _lib.check(lib.ppoaf_ppo_update_reduce(ref, 1, st), "ppo_update_reduce")
 
     def _ws_wanted(self):
         """Would `ws_reason` pick the persistent kernel for this policy's shapes (before any epoch table exists)?"""
@@ -213,6 +249,17 @@ class FusedPolicyUpdate:
         a.min_std = float(getattr(pol.actor.distribution, "min_std", 0.01))
         a.loss_partials = self.loss_partials.data_ptr(); a.totals = self.totals.data_ptr()
         a.mb_offset, a.cursor_advance = 0, 1
+        a.split_workspace, a.split_workspace_bytes = None, 0
+        if self.split:
+            if self._split_space is None:            # sized once for the full batch size; a tail mini-batch needs less
+                need = C.c_int64(0)
+                _lib.check(self._lib.ppoaf_ppo_update_split_workspace_bytes(C.byref(a), C.byref(need)), "split_workspace_bytes")
+                self._split_space = torch.zeros(int(need.value), dtype=torch.uint8, device=pol.device)
+                blocks = int(self._lib.ppoaf_ppo_update_split_blocks(C.byref(a)))
+                if pol.policy_norm_scratch.numel() < 6 + 2 * blocks:      # one pair of norm partials per wgrad workgroup
+                    pol.policy_norm_scratch = torch.zeros(6 + 2 * blocks, dtype=torch.float64, device=pol.device)
+                    a.norm_scratch = pol.policy_norm_scratch.data_ptr()
+            a.split_workspace, a.split_workspace_bytes = self._split_space.data_ptr(), self._split_space.numel()
         return a
 
     def _signature(self):
@@ -304,6 +351,12 @@ class FusedPolicyUpdate:
         ref = C.byref(args)
         single = not self.multi
         rc = lib.ppoaf_ppo_update_fwd_bwd(ref, st)
+        if rc == 0 and args.split_workspace:
+            # split-wgrad chain (single rank): complete weight gradients from the published panels, then clip + Adam
+            rc = lib.ppoaf_ppo_update_wgrad(ref, st) or lib.ppoaf_ppo_update_adam(ref, 3, st)
+            if rc != 0:
+                _lib.check(rc, "ppo_update")
+            return
         if rc == 0 and self.xchg is not None and self.pol.policy_grads.numel() <= 256 * 1024:
             # slab reduce + K17 exchange in one launch (sums travel from registers to the exchange slot)
             rc = lib.ppoaf_ppo_update_reduce_exchange(ref, self.xchg.handle, self.xchg.wait_seconds, st) \
@@ -447,31 +500,57 @@ class FusedPolicyUpdate:
         # DESIGN.md section 3, "single-XCD persistent chain") -- kept, parity-tested, as the base for the next step
         if os.environ.get("PPOAF_PERSISTENT", "0") != "1":
             return "off (set PPOAF_PERSISTENT=1 to run the single-XCD persistent chain)"
+        if getattr(self, "_ws_disabled", ""):
+            return "disabled after a failed launch: " + self._ws_disabled
         if self.multi:
             return "N > 1: the gradient exchange sits between the reduce and the Adam phase (three-launch chain)"
         if 2 * self.n_wg > 32:
             return f"batch size {self.B} needs {2 * self.n_wg} workgroups, one XCD holds 32"
         return ""
 
-    def _check_persistent(self):
-        """After a host synchronisation: did a wait inside a persistent launch run out of time?"""
+    def _persistent_failure(self):
+        """After a host synchronisation: '' or why the last persistent launch did not complete (its control block)."""
         ctl = getattr(self, "_ws_ctl", None)
         if ctl is not None and getattr(self, "_ws_used", False):
             self._ws_used = False
             words = ctl[:4].tolist()                      # tickets[2], error, done
             if words[2] != 0 or words[3] != 2:
-                raise _lib.PpoafError(
-                    f"ppo_update_ws: the last launch did not complete (error word {words[2]}, networks finished {words[3]} of 2, "
-                    f"worker tickets drawn {words[0]} / {words[1]}): a network did not get all of its workgroups onto its XCD "
-                    "(another process on this GPU, or a partition mode that exposes a single XCD?).  Set PPOAF_WS=0 to use "
-                    "the three-launch chain.")
+                return (f"ppo_update_ws: the last launch did not complete (error word {words[2]}, networks finished {words[3]} of 2, "
+                        f"worker tickets drawn {words[0]} / {words[1]}): a network did not get all of its workgroups onto its XCD "
+                        "(another process on this GPU, or a partition mode that exposes a single XCD?)")
         ctl = getattr(self, "_persist_ctl", None)
         if ctl is not None and getattr(self, "_persist_used", False):
             self._persist_used = False
             if int(ctl[1].item()) != 0:
-                raise _lib.PpoafError(
-                    "ppo_update_persistent: a barrier wait ran out of time -- the launch did not get all of its workgroups "
-                    "onto one XCD (another process on this GPU?).  Unset PPOAF_PERSISTENT to use the three-launch chain.")
+                return ("ppo_update_persistent: a barrier wait ran out of time -- the launch did not get all of its workgroups "
+                        "onto one XCD (another process on this GPU?)")
+        return ""
+
+    def _check_persistent(self):
+        """Raising form (tests, probes that drive single launches)."""
+        why = self._persistent_failure()
+        if why:
+            raise _lib.PpoafError(why + ".  Set PPOAF_WS=0 / unset PPOAF_PERSISTENT to use the three-launch chain.")
+
+    # ---- a persistent launch that cannot get its workers resident must not cost the run: the epoch is redone on the chain
+    def _epoch_state(self):
+        pol = self.pol
+        return [pol.policy_params, pol.policy_exp_avg, pol.policy_exp_avg_sq, pol.policy_step_counts, pol.policy_norm_scratch,
+                self.vn_mean, self.vn_var, self.vn_count, pol.buffer.values]
+
+    def _recover_on_the_chain(self, why):
+        """Single rank: the state the epoch began with comes back, the persistent kernels are switched off for good (with
+        the reason) and the epoch's mini-batches run again through the three-launch chain."""
+        import sys
+        print(f"[ppo_and_friends_amd] {why}; restoring the epoch's starting state and continuing on the three-launch chain",
+              file=sys.stderr, flush=True)
+        self._ws_disabled = why
+        for t, keep in zip(self._epoch_state(), self._ws_snapshot):
+            t.copy_(keep)
+        self.cursor.zero_()
+        self.totals.zero_()
+        self.n_done = 0
+        self.run_epoch()
 
     # ---- weight-stationary persistent form (csrc/ppo_update_ws.hip: ppo_update_ws_kernel)
     ws_chunk = 4096                    # mini-batches per launch
@@ -485,6 +564,8 @@ class FusedPolicyUpdate:
             return "K12 (MLP policies) only"
         if os.environ.get("PPOAF_WS", "1") == "0":
             return "off (PPOAF_WS=0)"
+        if getattr(self, "_ws_disabled", ""):
+            return "disabled after a failed launch: " + self._ws_disabled
         if not getattr(self, "ws_allowed", True):
             return "the epoch shares the GPU with the ICM update on a second stream (a persistent kernel would starve it)"
         if self.multi and self.xchg_ws is None:
@@ -527,6 +608,10 @@ class FusedPolicyUpdate:
     def run_epoch(self):
         args = self._args_for(self.B)
         left = self.n_full
+        self._ws_snapshot = None
+        if left > 0 and self.n_done == 0 and (self.ws_reason() == "" or self.persistent_reason() == ""):
+            # what the epoch starts from (a few buckets of <= 1 MB: device-to-device copies), should the launch not complete
+            self._ws_snapshot = [t.clone() for t in self._epoch_state()]
         if left > 0 and self.ws_reason() == "":
             import os
             ctl, wsb = self._ws_buffers()
@@ -602,6 +687,13 @@ class FusedPolicyUpdate:
     def end_epoch(self):
         """-> numpy totals[9] (sums of the 8 loss scalars over mini-batches, mini-batch count)."""
         ppo = self.ppo
+        if not self.multi and (getattr(self, "_ws_used", False) or getattr(self, "_persist_used", False)):
+            torch.cuda.current_stream().synchronize()
+            why = self._persistent_failure()
+            if why:                                       # before anything of the failed epoch reaches the normaliser
+                if self._ws_snapshot is None:
+                    raise _lib.PpoafError(why)
+                self._recover_on_the_chain(why)
         if ppo.normalize_values:
             rs = ppo.value_normalizers[self.policy_id].running_stats
             slot = self.n_done & 1
@@ -610,9 +702,7 @@ class FusedPolicyUpdate:
             if self.tail == 1:
                 # ppo.py:2299-2306: a size-1 batch still updates the normaliser, then is skipped (quirk Q9)
                 rs.integrate_records(self.records[self.n_full].contiguous())
-        out = _reduce_totals(self, self.totals)          # synchronises with the device
-        self._check_persistent()
-        return out
+        return _reduce_totals(self, self.totals)         # synchronises with the device (N > 1: a failed launch is voted on there)
 
 
 # ======================================================================================

@@ -165,7 +165,7 @@ class PPO:
                  soft_resets=False, state_path="./saved_state", load_state=False, checkpoint_every=100,
                  save_train_scores=False, save_avg_ep_len=False, save_running_time=False, save_bs_info=False,
                  save_state=True, use_graphs=True, update_mode="auto", verbose=False, freeze_scheduler=None,
-                 **kw_args):
+                 reference_device="cpu", **kw_args):
         """
         ppo.py:126-167.  `ts_per_rollout` is per environment (ppo.py:317-318
         multiplies by envs_per_proc).  normalize_obs / normalize_rewards / obs_clip / reward_clip
@@ -174,6 +174,13 @@ class PPO:
         """
         mpi_utils.set_torch_threads()
         self.device = torch.device(device)
+        # Which of the reference's two behaviours to reproduce where they DIFFER by the device the reference itself runs
+        # on: "cpu" (its default device, ppo.py:130, the path north_star compares against and the one every fixture was
+        # recorded on) or "cuda".  One place so far, quirk Q12: on a CPU tensor `.detach().cpu().numpy()` is a VIEW
+        # (ppo.py:1115-1141), on a CUDA tensor `.cpu()` copies.
+        if reference_device not in ("cpu", "cuda"):
+            raise ValueError(f"reference_device={reference_device!r}: 'cpu' or 'cuda'")
+        self.reference_device = reference_device
         self.envs_per_proc = int(envs_per_proc)
         self.ts_per_rollout = int(ts_per_rollout) * self.envs_per_proc
         self.max_ts_per_ep = int(max_ts_per_ep)
@@ -439,10 +446,12 @@ class PPO:
                 # ppo.py:1926-1930: bootstrap reward += intrinsic reward of the step - "intrinsic score avg"
                 ism = float(self.status_dict[policy_id].get("intrinsic score avg", 0.0))
                 buf.boot_reward.add_((intr_buf - ism).view_as(buf.boot_reward))
-                # quirk Q12 (replicated; pinned by fixture g12_c2_icm): next_reward is a numpy VIEW of the
-                # next_value tensor on the reference's CPU path (ppo.py:1115-1141), so its in-place `+=` puts the
-                # surprise into the ending value of the GAE as well
-                buf.boot_value.copy_(buf.boot_reward)
+                # quirk Q12 (pinned by fixtures g12_c2_icm / g12_c3_full / g12_c3_b256, all recorded on the reference's
+                # CPU device): next_reward is a numpy VIEW of the next_value tensor there (ppo.py:1115-1141), so its
+                # in-place `+=` puts the surprise into the ending VALUE of the GAE as well.  On a CUDA device the
+                # reference's `.cpu()` copies and the ending value stays V(next obs): reference_device="cuda".
+                if self.reference_device == "cpu":
+                    buf.boot_value.copy_(buf.boot_reward)
         else:
             buf.boot_stats = None
             buf.end_kind[T - 1].fill_(2)
@@ -879,10 +888,13 @@ class PPO:
         main = torch.cuda.current_stream()
         sa, sb = K.concurrent_stream_pair(self.device)         # two streams on different hardware queues
         sa.wait_stream(main); sb.wait_stream(main)
-        with torch.cuda.stream(sa):
-            fused.run_epoch()
-        with torch.cuda.stream(sb):
-            fused_icm.run_epoch()
+        try:
+            with torch.cuda.stream(sa):
+                fused.run_epoch()
+            with torch.cuda.stream(sb):
+                fused_icm.run_epoch()
+        finally:
+            fused.ws_allowed = True                     # the restriction belongs to this overlapped epoch only
         main.wait_stream(sa); main.wait_stream(sb)
         loader.prefetch()
         self._publish_epoch_stats(policy_id, fused.end_epoch())

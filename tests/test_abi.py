@@ -99,24 +99,32 @@ def test_every_entry_point_sits_under_a_reference_citation():
         assert needle in src, needle
 
 
-def test_two_xcd_kernel_completion_guard_raises_on_the_host():
+def test_two_xcd_kernel_completion_guard_reports_on_the_host():
     """
     The persistent update kernel reports through its control block (tickets[2], error word, networks finished); the host
-    side must raise -- never train on -- when a wait ran out of its budget or a network's worker group never ran
-    (e.g. a partition mode that exposes one XCD).  Pure host logic: checked on fabricated control blocks.
+    side must notice -- never train on -- when a wait ran out of its budget or a network's worker group never ran
+    (e.g. a partition mode that exposes one XCD): `_persistent_failure` names the reason (the epoch is then redone on the
+    three-launch chain, tests/test_gpu_ws_recovery.py), `_check_persistent` raises it.  Pure host logic: checked on
+    fabricated control blocks.
     """
     import types
     import pytest
     import torch
     from ppo_and_friends_amd import _lib
     from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
-    ok = types.SimpleNamespace(_ws_ctl=torch.tensor([32, 32, 0, 2] + [0] * 12, dtype=torch.int32), _ws_used=True)
-    FusedPolicyUpdate._check_persistent(ok)                      # complete launch: silent, flag consumed
+
+    def block(words):
+        ns = types.SimpleNamespace(_ws_ctl=torch.tensor(words + [0] * 12, dtype=torch.int32), _ws_used=True)
+        ns._persistent_failure = lambda: FusedPolicyUpdate._persistent_failure(ns)
+        return ns
+
+    ok = block([32, 32, 0, 2])
+    assert FusedPolicyUpdate._persistent_failure(ok) == ""        # complete launch: silent, flag consumed
     assert ok._ws_used is False
     for words in ([32, 32, 1, 1], [32, 0, 0, 1], [32, 32, 0, 0]):
-        bad = types.SimpleNamespace(_ws_ctl=torch.tensor(words + [0] * 12, dtype=torch.int32), _ws_used=True)
+        assert "did not complete" in FusedPolicyUpdate._persistent_failure(block(words))
         with pytest.raises(_lib.PpoafError, match="did not complete"):
-            FusedPolicyUpdate._check_persistent(bad)
+            FusedPolicyUpdate._check_persistent(block(words))
 
 
 def test_no_memset_in_capturable_paths():

@@ -364,6 +364,39 @@ def test_mappo_shared_policy_three_agents(update_mode):
     np.testing.assert_allclose(_flat_params(pol.critic), _flat_params(cpu.critic), rtol=1e-4, atol=2e-5)
 
 
+def test_icm_bootstrap_surprise_follows_the_reference_device():
+    """Quirk Q12 is a property of the reference's CPU device (a numpy view aliases the bootstrap value tensor,
+    ppo.py:1115-1141, 1926-1930); with reference_device="cuda" the ICM surprise lands in the ending reward only."""
+    from ppo_and_friends_amd.ppo import PPO
+    from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
+    from ppo_and_friends_amd.spaces import Box, Discrete
+    dev = torch.device("cuda", 0)
+    E, T, O, NA, B, seed = 6, 12, 5, 3, 24, 9
+    sp = Box(-np.inf, np.inf, (O,), np.float32)
+    got = {}
+    for ref_dev in ("cpu", "cuda"):
+        env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(NA), T, dev, reward="uniform", seed=33)
+        ppo = PPO(env_gen, {"p": (None, sp, sp, Discrete(NA), dict(enable_icm=True))}, device=dev, random_seed=seed,
+                  normalize_obs=False, normalize_rewards=False, envs_per_proc=E, ts_per_rollout=T, batch_size=B,
+                  epochs_per_iter=1, reference_device=ref_dev, save_state=False)
+        pol = ppo.policies["p"]
+        cpu = cpu_ppo_loop.CpuPPO(O, NA, batch_size=B, seed=seed, enable_icm=True)
+        cpu.reference_device = ref_dev
+        strip = lambda sd: {k.replace("sequential_net.", ""): v.detach().cpu().clone() for k, v in sd.items()
+                            if k.startswith("sequential_net.")}
+        cpu.actor.load_state_dict(strip(pol.actor.state_dict()))
+        cpu.critic.load_state_dict(strip(pol.critic.state_dict()))
+        cpu.icm.load_state_dict({k: v.detach().cpu().clone() for k, v in pol.icm_model.state_dict().items()})
+        ds = ppo.rollout()
+        ref = cpu.rollout(ppo.env.obs_table.cpu().numpy(), ppo.env.reward_table.cpu().numpy(),
+                          actions=pol.buffer.actions[..., 0].cpu().numpy())
+        np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy(), ref.rewards_to_go.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(ds.advantages.cpu().numpy(), ref.advantages.numpy(), rtol=1e-4, atol=1e-4)
+        got[ref_dev] = (ds.advantages.cpu().numpy().copy(), ds.rewards_to_go.cpu().numpy().copy())
+    np.testing.assert_array_equal(got["cpu"][1], got["cuda"][1])              # the ending REWARD carries the surprise either way
+    assert np.abs(got["cpu"][0] - got["cuda"][0]).max() > 1e-3                # the ending VALUE only on the CPU device
+
+
 @pytest.mark.parametrize("update_mode", ["fused", "torch"])
 def test_icm_rollout_rewards_and_training_match_cpu_port(update_mode):
     """

@@ -154,6 +154,7 @@ def test_k12_full_size_persistent_kernel_matches_the_chain_and_is_reproducible(n
     """
     from ppo_and_friends_amd import fused_update
     monkeypatch.setenv("PPOAF_WS_MODE", "rowtile" if name == "C2" else "auto")   # C2: "auto" would keep the chain
+    monkeypatch.setenv("PPOAF_SPLIT_WGRAD", "0")     # bitwise claim: against the SLAB chain, whose arithmetic the row-tiled workers repeat
     outs = []
     for ws in ("1", "1", "0"):
         monkeypatch.setenv("PPOAF_WS", ws)
@@ -176,3 +177,99 @@ def test_k12_full_size_persistent_kernel_matches_the_chain_and_is_reproducible(n
     np.testing.assert_allclose(outs[0][3], outs[2][3], rtol=1e-6)
     n = outs[0][4] if name == "C4" else outs[0][0].numel()          # C4: the critic is layered
     assert torch.equal(outs[0][0][:n], outs[2][0][:n]) and torch.equal(outs[0][1][:n], outs[2][1][:n])
+
+
+@pytest.mark.parametrize("name", ["C2", "C3", "C4"])
+def test_full_size_single_minibatch_gradient_persistent_kernel_vs_chain(name, monkeypatch):
+    """
+    ONE mini-batch of 256 rows at the BASELINE shapes, no optimiser step compared: the gradient bucket and the loss
+    scalars the two-XCD persistent kernel produces (C2: both networks row-tiled -> bitwise; C3 / C4: row-tiled actor ->
+    bitwise, layered 256-wide critic -> complete-K wgrad sums in another association, 1e-5 of the bucket's largest entry)
+    against the three-launch chain's fwd_bwd + slab reduce on the same rollout, weights and shuffle.  (What the
+    whole-epoch test above cannot compare for the layered critic, whose weights are chaotic after 1536 Adam steps.)
+    """
+    import ctypes as C
+    from ppo_and_friends_amd import _lib, fused_update
+    from ppo_and_friends_amd import kernels as K
+    monkeypatch.setenv("PPOAF_WS_MODE", "rowtile" if name == "C2" else "auto")
+    monkeypatch.setenv("PPOAF_WS", "1")
+    monkeypatch.setenv("PPOAF_SPLIT_WGRAD", "0")          # the slab arithmetic is what a row-tiled worker group repeats bitwise
+    ppo, E, T, A = _c_config(name)
+    ppo.rollout()
+    pol = ppo.policies["p"]
+    pol.train()
+    fused = ppo._fused_updater("p", 256)
+    perm = torch.randperm(len(pol.dataset), device=pol.device, generator=torch.Generator(device=pol.device).manual_seed(3))
+    state = lambda: [pol.policy_params, pol.policy_exp_avg, pol.policy_exp_avg_sq, pol.policy_step_counts, pol.policy_norm_scratch,
+                     fused.vn_mean, fused.vn_var, fused.vn_count, fused.cursor, fused.totals, pol.buffer.values]
+    # ---- the slab chain: fwd_bwd + slab reduce only
+    fused.begin_epoch(perm)
+    keep = [t.clone() for t in state()]
+    args = fused._args_for(256)
+    fused.gradient_only(args)
+    torch.cuda.synchronize()
+    g_chain, t_chain = pol.policy_grads.clone(), fused.totals.clone()
+    for t, k in zip(state(), keep):
+        t.copy_(k)
+    # ---- one mini-batch through the persistent kernel (its Adam phase runs too; the gradient bucket is what it reduced)
+    before = fused_update.FusedPolicyUpdate.ws_launch_count
+    fused.begin_epoch(perm)
+    assert fused.ws_reason() == "", fused.ws_reason()
+    fused.n_full, fused.tail = 1, 0
+    fused.run_epoch()
+    torch.cuda.synchronize()
+    fused._check_persistent()
+    assert fused_update.FusedPolicyUpdate.ws_launch_count == before + 1
+    g_ws, t_ws = pol.policy_grads.clone(), fused.totals.clone()
+    na = int(fused.actor_desc.size)
+    assert torch.equal(g_ws[:na], g_chain[:na]), "row-tiled actor: the chain's arithmetic in the chain's order"
+    scale = float(g_chain[na:].abs().max())
+    d = float((g_ws[na:] - g_chain[na:]).abs().max())
+    if name == "C2":
+        assert torch.equal(g_ws[na:], g_chain[na:])
+    else:
+        assert d <= 1e-5 * scale, f"layered critic gradient: max |dg| {d:.3e} against max |g| {scale:.3e}"
+    np.testing.assert_allclose(t_ws.cpu().numpy(), t_chain.cpu().numpy(), rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["C2", "C3", "C4"])
+def test_full_size_split_wgrad_chain_matches_the_slab_chain(name, monkeypatch):
+    """
+    The split-wgrad chain (fwd_bwd publishes activation / dz panels, one launch forms the complete weight gradients over
+    all 256 rows on MFMA) against the slab chain (16-row partials in 16 slabs, summed in slab order) at the BASELINE
+    shapes: ONE mini-batch's gradient bucket within 1e-5 of its largest entry per network and the same loss scalars;
+    then a whole epoch of each: every mini-batch counted once, statistics to 2e-4, and the split chain bitwise equal to
+    itself run to run (graph replay and eager alike).
+    """
+    monkeypatch.setenv("PPOAF_WS", "0")
+    grads, totals, epochs = {}, {}, {}
+    for split in ("0", "1", "1"):
+        monkeypatch.setenv("PPOAF_SPLIT_WGRAD", split)
+        ppo, E, T, A = _c_config(name, use_graphs=len(epochs.get("1", [])) == 0)      # second split run: eager launches
+        ppo.rollout()
+        pol = ppo.policies["p"]
+        pol.train()
+        fused = ppo._fused_updater("p", 256)
+        assert fused.split == (split == "1"), fused.split_reason
+        perm = torch.randperm(len(pol.dataset), device=pol.device, generator=torch.Generator(device=pol.device).manual_seed(3))
+        fused.begin_epoch(perm)
+        steps = pol.policy_step_counts.clone()
+        fused.gradient_only(fused._args_for(256))
+        torch.cuda.synchronize()
+        pol.policy_step_counts.copy_(steps)
+        grads.setdefault(split, pol.policy_grads.clone()); totals.setdefault(split, fused.totals.clone())
+        fused.begin_epoch(perm)
+        fused.run_epoch()
+        t = fused.end_epoch()
+        n_mb = E * T * A // 256
+        assert t[8] == n_mb and int(pol.policy_step_counts[0].item()) == n_mb
+        epochs.setdefault(split, []).append((pol.policy_params.clone(), pol.policy_exp_avg_sq.clone(), t.copy()))
+    na = int(ppo._fused_updater("p", 256).actor_desc.size)
+    for sl, tag in ((slice(0, na), "actor"), (slice(na, None), "critic")):
+        scale = float(grads["0"][sl].abs().max())
+        d = float((grads["1"][sl] - grads["0"][sl]).abs().max())
+        assert d <= 1e-5 * scale, f"{tag}: max |dg| {d:.3e} against max |g| {scale:.3e}"
+    np.testing.assert_allclose(totals["1"].cpu().numpy(), totals["0"].cpu().numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(epochs["1"][0][2][:5] / n_mb, epochs["0"][0][2][:5] / n_mb, rtol=2e-4, atol=1e-4)   # (means of cancelling O(1) terms)
+    a, b = epochs["1"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2])

@@ -169,10 +169,8 @@ def first_minibatch_probe(ppo, pol, perm, B):
                 t.copy_(k)
             return out
         args = fused._args_for(B)
-        lib, st = _lib.load(), K.stream()
-        steps = pol.policy_step_counts.clone()              # the reduce launch's bookkeeping advances Adam's step counters
-        _lib.check(lib.ppoaf_ppo_update_fwd_bwd(C.byref(args), st), "fwd_bwd")
-        _lib.check(lib.ppoaf_ppo_update_reduce(C.byref(args), 0, st), "reduce")    # 0: no clip-norm accumulation (the Adam launch would consume it)
+        steps = pol.policy_step_counts.clone()              # the gradient launch's bookkeeping advances Adam's step counters
+        fused.gradient_only(args)                           # fwd_bwd + (complete-K wgrad launch | slab reduce)
         torch.cuda.synchronize()
         pol.policy_step_counts.copy_(steps)
         return fused.totals.cpu().numpy().copy(), pol.policy_grads.clone()

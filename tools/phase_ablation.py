@@ -1,7 +1,7 @@
 import sys, os, ctypes as C, time; sys.path.insert(0,'.')
 import numpy as np, torch
 from ppo_and_friends_amd import _lib
-_lib.LIB_PATH='tools/libppoaf_hip_stamps.so'
+_lib.LIB_PATH=os.path.abspath('tools/libppoaf_hip_stamps.so')
 from ppo_and_friends_amd.ppo import PPO, PermutationLoader
 from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
 from ppo_and_friends_amd.spaces import Box, Discrete
@@ -14,7 +14,7 @@ ppo.rollout(); pol=ppo.policies["p"]
 loader=PermutationLoader(pol.dataset,256,ppo.loader_generator)
 f=ppo._fused_updater("p",256); f.begin_epoch(loader.epoch_permutation())
 args=f._args_for(256)
-for dbg in (0,1,2,3,4,7,511):
+for dbg in (0,4,260,4,0):
     os.environ["PPOAF_DEBUG"]=str(dbg)
     res=[]
     for mode in ("warm","real"):
