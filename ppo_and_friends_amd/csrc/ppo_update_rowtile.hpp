@@ -361,18 +361,25 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
                 slab[offW(depth) + (long)k * H + i] = acc;
             }
         }
-        if (tid >= 256 && tid < 256 + out_dim) {
+        // (SPLIT: the padding slots of the segment are written too, as zeros -- the partials row lives in a workspace whose
+        //  layout changes with the mini-batch size, so nothing in it may be assumed to be zero; a slab's padding is never touched)
+        const int out_pad = SPLIT ? ((out_dim + 3) & ~3) : out_dim;
+        if (tid >= 256 && tid < 256 + out_pad) {
             const int k = tid - 256;
             float acc = 0.f;
+            if (k < out_dim) {
 #pragma unroll
-            for (int s = 0; s < kRows; ++s) acc += sDOut[s * kMaxOut + k];
+                for (int s = 0; s < kRows; ++s) acc += sDOut[s * kMaxOut + k];
+            }
             slab[offB(depth) + k] = acc;
         }
-        if (which == 0 && u.head_kind == PPOAF_HEAD_GAUSSIAN && tid >= 320 && tid < 320 + out_dim) {
+        if (which == 0 && u.head_kind == PPOAF_HEAD_GAUSSIAN && tid >= 320 && tid < 320 + out_pad) {
             const int d = tid - 320;
             float acc = 0.f;
+            if (d < out_dim) {
 #pragma unroll
-            for (int s = 0; s < kRows; ++s) acc += sOut[s * kMaxOut + 8 + d];
+                for (int s = 0; s < kRows; ++s) acc += sOut[s * kMaxOut + 8 + d];
+            }
             slab[nd.log_std_off + d] = acc;
         }
         // dz_last = (dOut . W_out) * act'(Hlast): waves 4..7 (the others store dW_out above)
