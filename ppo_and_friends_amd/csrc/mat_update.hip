@@ -57,6 +57,22 @@ struct MatDev {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char mat_smem[];
 
+// Diagnostic build only (-DPPOAF_MAT_STAMPS, tools/mat_stamps.py): s_memtime of workgroup 0 / thread 0 at the marked points
+// of the update kernel, into a buffer nothing else reads.  The shipped library executes no stamp.
+#ifdef PPOAF_MAT_STAMPS
+static __device__ unsigned long long g_mat_stamps[64];
+#define MAT_STAMP(k)                                                                     \
+    do {                                                                                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                       \
+            unsigned long long t_;                                                       \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
+            g_mat_stamps[k] = t_;                                                        \
+        }                                                                                \
+    } while (0)
+#else
+#define MAT_STAMP(k) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // element-wise passes over a [16, 64] tile: thread = (row = tid >> 4, lane16 = tid & 15), 4 columns each
 // ------------------------------------------------------------------------------------------------
@@ -224,9 +240,7 @@ __device__ __forceinline__ void att_fwd(const float* Q, const float* K, const fl
             bool ok = row < n_rows && col < n_rows && (row / L) == (col / L);
             if (masked) ok = ok && (col % L) <= (row % L);
             const float x = ok ? s[r] * 0.125f : -INFINITY;             // 1 / sqrt(64)
-            float m = x;
-            m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
-            m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 1, 64));
+            const float m = group16_max(x);
             const float e = ok ? expf(x - m) : 0.f;
             const float den = group16_sum(e);
             sP[row * 17 + col] = den > 0.f ? e / den : 0.f;
@@ -410,36 +424,49 @@ __device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, in
     MAT_TILES(c);
     tile_ln_fwd(sYO, OS, O, W(C_OLN_G), W(C_OLN_B), sXO, rstd(0), sYO, tid);                 // obs_encoder.0
     MAT_SYNC();
+    MAT_STAMP(16);
     narrow_fwd(W(C_ENC_W), O, W(C_ENC_B), sYO, OS, cZ1, wave, lane);                          // obs_encoder.1
     MAT_SYNC();
+    MAT_STAMP(17);
     tile_gelu(cZ1, S0, tid);
     tile_ln_fwd(S0, kMHS, kMD, W(C_LN_G), W(C_LN_B), cN0, rstd(1), S1, tid);                  // critic.ln -> H0 in S1
     MAT_SYNC();
+    MAT_STAMP(18);
     lin_fwd(W(C_Q_W), W(C_Q_B), S1, cQ, wave, lane);
     lin_fwd(W(C_K_W), W(C_K_B), S1, cK, wave, lane);
     lin_fwd(W(C_V_W), W(C_V_B), S1, cV, wave, lane);
     MAT_SYNC();
+    MAT_STAMP(19);
     att_fwd(cQ, cK, cV, cY, sP0, L, n_rows, false, wave, lane);
     MAT_SYNC();
+    MAT_STAMP(20);
     lin_fwd(W(C_P_W), W(C_P_B), cY, S2, wave, lane);
     MAT_SYNC();
+    MAT_STAMP(21);
     tile_add(S1, S2, S2, tid);
     tile_ln_fwd(S2, kMHS, kMD, W(C_LN1_G), W(C_LN1_B), cN1, rstd(2), S0, tid);                // H1 in S0
     MAT_SYNC();
+    MAT_STAMP(22);
     lin_fwd(W(C_M1_W), W(C_M1_B), S0, cZM, wave, lane);
     MAT_SYNC();
+    MAT_STAMP(23);
     tile_gelu(cZM, S2, tid);
     MAT_SYNC();
+    MAT_STAMP(24);
     lin_fwd(W(C_M2_W), W(C_M2_B), S2, S3, wave, lane);
     MAT_SYNC();
+    MAT_STAMP(25);
     tile_add(S0, S3, S3, tid);
     tile_ln_fwd(S3, kMHS, kMD, W(C_LN2_G), W(C_LN2_B), cN2, rstd(3), cENC, tid);              // rep_enc
     MAT_SYNC();
+    MAT_STAMP(26);
     lin_fwd(W(C_H1_W), W(C_H1_B), cENC, cZH, wave, lane);
     MAT_SYNC();
+    MAT_STAMP(27);
     tile_gelu(cZH, S0, tid);
     tile_ln_fwd(S0, kMHS, kMD, W(C_HLN_G), W(C_HLN_B), cNH, rstd(4), S1, tid);
     MAT_SYNC();
+    MAT_STAMP(28);
     head_out_fwd(W(C_H2_W), W(C_H2_B), 1, S1, sOutC, tid);
 
 }
@@ -506,6 +533,7 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     const int n_seq = (int)(rem < u.per_tile ? (rem < 0 ? 0 : rem) : u.per_tile);
     const float inv_n = 1.0f / (float)(u.B * u.L);
 
+    MAT_STAMP(0);
     // ---- LDS carve
     MatCtx c;
     c.P = P; c.off = u.off; c.L = u.L; c.NA = u.NA; c.Ain = u.Ain; c.n_rows = n_seq * u.L;
@@ -579,6 +607,7 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     for (int i = tid; i < kRows * OS; i += kMT) { sXO[i] = 0.f; sYO[i] = 0.f; }
     for (int i = tid; i < kRows * kMXS; i += kMT) sXA[i] = 0.f;
     MAT_SYNC();
+    MAT_STAMP(1);
     // observations of the tile's tokens; the shifted one-hot token block (mat_policy.py:308-344,378-416)
     for (int idx = tid; idx < n_rows * O; idx += kMT) {
         const int s = idx / O, i = idx - s * O;
@@ -591,9 +620,12 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
         else sXA[tid * kMXS + 1 + sAct[tid - 1]] = 1.0f;
     }
     MAT_SYNC();
+    MAT_STAMP(2);
 
     mat_encoder_forward(c, tid, wave, lane);
+    MAT_STAMP(3);
     mat_decoder_forward(c, tid, wave, lane);
+    MAT_STAMP(4);
 
     // =========================================== heads: distribution + losses (K6 + K3) =============================
     if (wave == 0) {
@@ -686,6 +718,7 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     }
     MAT_SYNC();
 
+    MAT_STAMP(5);
     // =========================================== actor backward ===========================================
     // S1 still holds the head LayerNorm output
     head_out_bwd(W(A_H2_W), NA, S1, sDOutA, S2, G(A_H2_W), G(A_H2_B), tid);                   // d head-LN out -> S2
@@ -714,8 +747,10 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     lin_wgrad(DENC, aY2, G(A_P2_W), G(A_P2_B), wave, lane, tid);
     lin_dgrad<false>(W(A_P2_W), DENC, S2, wave, lane);                                        // d Y2 -> S2
     MAT_SYNC();
+    MAT_STAMP(6);
     att_bwd(aQ2, aK2, aV2, sP2, S2, S0, S3, S4, sS, wave, lane);                              // dQ2 -> S0, dK2 -> S3, dV2 -> S4
     MAT_SYNC();
+    MAT_STAMP(7);
     lin_wgrad(S0, cENC, G(A_Q2_W), G(A_Q2_B), wave, lane, tid);
     lin_dgrad<true>(W(A_Q2_W), S0, DENC, wave, lane);                                         // rep_enc gradient from the query path
     tile_affine(aN1, W(A_LN1_G), W(A_LN1_B), S1, tid);                                        // x1
@@ -747,6 +782,7 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     MAT_SYNC();
     layer_wgrad<4, kMNW>(S1, sXA, kMXS, 1, Ain, G(A_ENC_W), Ain, nullptr, wave, lane, tid);
 
+    MAT_STAMP(8);
     // =========================================== critic backward ===========================================
     tile_affine(cNH, W(C_HLN_G), W(C_HLN_B), S0, tid);                                        // head LayerNorm output
     MAT_SYNC();
@@ -792,6 +828,7 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     layer_wgrad<4, kMNW>(S1, sYO, OS, NT0, O, G(C_ENC_W), O, G(C_ENC_B), wave, lane, tid);
     narrow_dgrad(W(C_ENC_W), O, S1, S2, kMHS, wave, lane);                                     // d (obs LayerNorm output) in S2[:, :O]
     MAT_SYNC();
+    MAT_STAMP(9);
     if (l2_touch == 1.2345e38f) slab[0] = l2_touch;            // keeps the warm-up loads alive
     // observation LayerNorm: only its affine parameters receive gradient
     if (tid < 64) {
@@ -1121,3 +1158,9 @@ extern "C" int ppoaf_mat_update_chain_allreduce(const ppoaf_mat_update_args_t* a
     }
     return PPOAF_OK;
 }
+
+#ifdef PPOAF_MAT_STAMPS
+extern "C" int ppoaf_debug_read_mat_stamps(unsigned long long* out /* host [64] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ppoaf::g_mat_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -32,11 +32,29 @@ __device__ __forceinline__ float act_bwd(float h, int act) {
     return 1.f - h * h;
 }
 
+// ---- 16-lane (DPP "row") reductions.  `__shfl_xor` compiles to ds_bpermute_b32 -- a round trip through the LDS
+//      hardware, ~100+ cycles, four of them dependent per sum (K15 carried 324 of them: a fifth of its wave cycles).  The
+//      same xor butterfly on DPP row operations is four VALU instructions: xor 8 = row_ror:8 exactly; after it the values
+//      are 8-periodic inside the row, so lane i ^ 4 holds what row_ror:4 delivers (and likewise 2 / 1, which are quad
+//      permutes anyway): the same additions of the same operand pairs -- bitwise the __shfl_xor result.  Every lane of the
+//      wave must be active at the call (all call sites are whole waves).
+template <int CTRL> __device__ __forceinline__ float dpp_row(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kDppRor8 = 0x128, kDppRor4 = 0x124, kDppXor2 = 0x4E /* quad_perm [2,3,0,1] */, kDppXor1 = 0xB1 /* [1,0,3,2] */;
 __device__ __forceinline__ float group16_sum(float v) {
-    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+    v += dpp_row<kDppRor8>(v); v += dpp_row<kDppRor4>(v);
+    v += dpp_row<kDppXor2>(v); v += dpp_row<kDppXor1>(v);
     return v;
 }
+__device__ __forceinline__ float group16_max(float v) {
+    v = fmaxf(v, dpp_row<kDppRor8>(v)); v = fmaxf(v, dpp_row<kDppRor4>(v));
+    v = fmaxf(v, dpp_row<kDppXor2>(v)); v = fmaxf(v, dpp_row<kDppXor1>(v));
+    return v;
+}
+// 4-lane groups (xor 1, xor 2): quad permutes
+__device__ __forceinline__ float group4_sum(float v) { v += dpp_row<kDppXor1>(v); v += dpp_row<kDppXor2>(v); return v; }
+__device__ __forceinline__ float group4_max(float v) { v = fmaxf(v, dpp_row<kDppXor1>(v)); return fmaxf(v, dpp_row<kDppXor2>(v)); }
 
 __device__ __forceinline__ float clamp_prob_u(float n) {
     return fminf(fmaxf(n, FLT_EPSILON), 1.0f - FLT_EPSILON);

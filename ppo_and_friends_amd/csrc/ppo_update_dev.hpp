@@ -118,8 +118,8 @@ __device__ __forceinline__ void ppo_head_loss(const U& u, const int which, const
                 av4 = sRowF[s4]; lpo4 = sRowF[16 + s4];
                 if (u.normalize_adv) av4 = (av4 - sMisc[0]) / (sMisc[1] + 1e-8f);
             }
-            auto rsum = [](float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); return v; };
-            auto rmax = [](float v) { v = fmaxf(v, __shfl_xor(v, 1, 64)); return fmaxf(v, __shfl_xor(v, 2, 64)); };
+            auto rsum = [](float v) { return group4_sum(v); };       // xor 1, xor 2 as DPP quad permutes (mlp_device.hpp)
+            auto rmax = [](float v) { return group4_max(v); };
             const int k0 = q, k1 = q + 4;
             const bool v0 = k0 < out_dim, v1 = k1 < out_dim;
             const float z0 = v0 ? sOut[s4 * kMaxOut + k0] : -INFINITY, z1 = v1 ? sOut[s4 * kMaxOut + k1] : -INFINITY;
