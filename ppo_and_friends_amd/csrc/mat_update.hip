@@ -17,6 +17,7 @@
 // bound, not MFMA bound -- the point is that they replace ~270 separate kernel launches.
 #include "mlp_device.hpp"
 #include <hip/hip_ext.h>
+#include <cstdlib>
 
 namespace ppoaf {
 
@@ -53,6 +54,7 @@ struct MatDev {
     float surr_clip, entropy_weight, kl_loss_weight, huber_delta;
     float* loss_partials; double* totals;
     double* norm_scratch; int64_t* step_count; int fuse_norm;
+    int l2_warmup;       // diagnostic (PPOAF_MAT_L2_WARMUP=1): touch every line of the bucket at kernel start, as rounds 1-2 did
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char mat_smem[];
@@ -76,12 +78,25 @@ static __device__ unsigned long long g_mat_stamps[64];
 // ------------------------------------------------------------------------------------------------
 // element-wise passes over a [16, 64] tile: thread = (row = tid >> 4, lane16 = tid & 15), 4 columns each
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_d(float z) {
-    const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
-    const float pdf = expf(-0.5f * z * z) * 0.39894228040143267794f;
-    return cdf + z * pdf;
+// Exact (erf) GELU, nn.GELU's default (multi_agent_transformer.py:51-60).  erf by Abramowitz & Stegun 7.1.26 --
+// erf(x) = 1 - (a1 t + .. + a5 t^5) exp(-x^2), t = 1 / (1 + p x), |error| <= 1.5e-7 -- instead of the library erff:
+// one exponential (the SAME exp(-z^2 / 2) the derivative's density term needs), one reciprocal and five FMAs against
+// ~85 instructions per element; a GELU pass over a tile was 1400 of a phase's 1500 cycles (tools/mat_stamps.py) and 16 of
+// the kernel's 71 phases contain one.  1.5e-7 absolute on erf is 25 x below the 1e-5 parity tolerance of every output.
+__device__ __forceinline__ void gelu_parts(float z, float& cdf, float& pdf) {
+    const float x = fabsf(z) * 0.70710678118654752440f;
+    const float e = __expf(-x * x);                            // = exp(-z^2 / 2)
+    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erf_abs = 1.0f - poly * t * e;
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, z));
+    pdf = e * 0.39894228040143267794f;
 }
+__device__ __forceinline__ float gelu_f(float z) { float cdf, pdf; gelu_parts(z, cdf, pdf); return z * cdf; }
+__device__ __forceinline__ float gelu_d(float z) { float cdf, pdf; gelu_parts(z, cdf, pdf); return cdf + z * pdf; }
 
 // out = gelu(Z)
 __device__ __forceinline__ void tile_gelu(const float* __restrict__ Z, float* __restrict__ out, int tid) {
@@ -193,6 +208,38 @@ __device__ __forceinline__ void lin_dgrad(const float* __restrict__ W, const flo
     for (int r = 0; r < 4; ++r) {
         const int idx = (4 * (lane >> 4) + r) * kMHS + wave * 16 + (lane & 15);
         out[idx] = ACCUM ? out[idx] + acc[r] : acc[r];
+    }
+}
+
+// The same linears with their weight fragments REQUESTED AHEAD: a wave's share of a 64x64 linear is 4 float4 per lane (+ its
+// bias element).  A phase of this kernel is a dependent chain -- barrier, weight fragments from the L2 (~400 cycles), A
+// from LDS, 16 MFMAs (32 cycles each), LDS stores, barrier: ~1800 cycles by in-kernel stamps, tools/mat_stamps.py -- and
+// the 400 cycles of fragment latency sit at the head of 45 of the 71 phases.  The update kernel therefore requests the
+// fragments of the NEXT linear at the start of the phase that runs the current one (they land behind its MFMAs and the
+// barrier).  Not deeper: vmcnt retires in order, so with a whole pass's fragments in flight every small load issued
+// after them (LayerNorm gains, biases) waited for all of them -- measured slower than no prefetch at all.
+struct MatFr { float4 f[4]; float b; };
+__device__ __forceinline__ void pf_fwd(const float* __restrict__ W, const float* __restrict__ bias, int wave, int lane, MatFr& r) {
+    load_fwd_frags_ld<4, true>(W, kMD, wave * 16, lane, r.f);
+    r.b = bias[wave * 16 + (lane & 15)];
+}
+__device__ __forceinline__ void pf_dgrad(const float* __restrict__ W, int wave, int lane, MatFr& r) {
+    load_dgrad_frags_ld<4>(W, kMD, wave * 16, lane, r.f);
+    r.b = 0.f;
+}
+__device__ __forceinline__ void lin_fwd_r(const MatFr& r, const float* __restrict__ A, float* __restrict__ out, int wave, int lane) {
+    const int o = wave * 16 + (lane & 15);
+    const f32x4 acc = mfma_rows_x_frags<4>(A, kMHS, lane, r.f, r.b);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[(4 * (lane >> 4) + q) * kMHS + o] = acc[q];
+}
+template <bool ACCUM>
+__device__ __forceinline__ void lin_dgrad_r(const MatFr& r, const float* __restrict__ Dt, float* __restrict__ out, int wave, int lane) {
+    const f32x4 acc = mfma_rows_x_frags<4>(Dt, kMHS, lane, r.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = (4 * (lane >> 4) + q) * kMHS + wave * 16 + (lane & 15);
+        out[idx] = ACCUM ? out[idx] + acc[q] : acc[q];
     }
 }
 
@@ -420,8 +467,15 @@ enum { cZ1_ = 0, cN0_, cQ_, cK_, cV_, cY_, cN1_, cZM_, cN2_, cENC_, cZH_, cNH_,
     auto rstd = [&](int k) -> float* { return c.rstd(k); }
 
 // critic (encoder): observations in sYO -> rep_enc in cENC, value in sOutC[:, 0]; ends WITHOUT a barrier
+// PF (K15): the fragments of linear `n` are requested one phase ahead -- MAT_NEXT(n) at the start of the phase before;
+// else (K16: its registers are spoken for) at the point of use
+#define MAT_LIN(r, Wk, Bk, A, out) do { if (!PF) pf_fwd(W(Wk), W(Bk), wave, lane, r); lin_fwd_r(r, A, out, wave, lane); } while (0)
+#define MAT_NEXT(r, Wk, Bk) do { if (PF) pf_fwd(W(Wk), W(Bk), wave, lane, r); } while (0)
+template <bool PF>
 __device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, int wave, int lane) {
     MAT_TILES(c);
+    MatFr rq, rk, rv, rp, rm1, rm2, rh1;
+    MAT_NEXT(rq, C_Q_W, C_Q_B); MAT_NEXT(rk, C_K_W, C_K_B); MAT_NEXT(rv, C_V_W, C_V_B);       // two phases ahead of their use
     tile_ln_fwd(sYO, OS, O, W(C_OLN_G), W(C_OLN_B), sXO, rstd(0), sYO, tid);                 // obs_encoder.0
     MAT_SYNC();
     MAT_STAMP(16);
@@ -432,35 +486,39 @@ __device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, in
     tile_ln_fwd(S0, kMHS, kMD, W(C_LN_G), W(C_LN_B), cN0, rstd(1), S1, tid);                  // critic.ln -> H0 in S1
     MAT_SYNC();
     MAT_STAMP(18);
-    lin_fwd(W(C_Q_W), W(C_Q_B), S1, cQ, wave, lane);
-    lin_fwd(W(C_K_W), W(C_K_B), S1, cK, wave, lane);
-    lin_fwd(W(C_V_W), W(C_V_B), S1, cV, wave, lane);
+    MAT_NEXT(rp, C_P_W, C_P_B);
+    MAT_LIN(rq, C_Q_W, C_Q_B, S1, cQ);
+    MAT_LIN(rk, C_K_W, C_K_B, S1, cK);
+    MAT_LIN(rv, C_V_W, C_V_B, S1, cV);
     MAT_SYNC();
     MAT_STAMP(19);
     att_fwd(cQ, cK, cV, cY, sP0, L, n_rows, false, wave, lane);
     MAT_SYNC();
     MAT_STAMP(20);
-    lin_fwd(W(C_P_W), W(C_P_B), cY, S2, wave, lane);
+    MAT_NEXT(rm1, C_M1_W, C_M1_B);
+    MAT_LIN(rp, C_P_W, C_P_B, cY, S2);
     MAT_SYNC();
     MAT_STAMP(21);
     tile_add(S1, S2, S2, tid);
     tile_ln_fwd(S2, kMHS, kMD, W(C_LN1_G), W(C_LN1_B), cN1, rstd(2), S0, tid);                // H1 in S0
     MAT_SYNC();
     MAT_STAMP(22);
-    lin_fwd(W(C_M1_W), W(C_M1_B), S0, cZM, wave, lane);
+    MAT_NEXT(rm2, C_M2_W, C_M2_B);
+    MAT_LIN(rm1, C_M1_W, C_M1_B, S0, cZM);
     MAT_SYNC();
     MAT_STAMP(23);
     tile_gelu(cZM, S2, tid);
     MAT_SYNC();
     MAT_STAMP(24);
-    lin_fwd(W(C_M2_W), W(C_M2_B), S2, S3, wave, lane);
+    MAT_NEXT(rh1, C_H1_W, C_H1_B);
+    MAT_LIN(rm2, C_M2_W, C_M2_B, S2, S3);
     MAT_SYNC();
     MAT_STAMP(25);
     tile_add(S0, S3, S3, tid);
     tile_ln_fwd(S3, kMHS, kMD, W(C_LN2_G), W(C_LN2_B), cN2, rstd(3), cENC, tid);              // rep_enc
     MAT_SYNC();
     MAT_STAMP(26);
-    lin_fwd(W(C_H1_W), W(C_H1_B), cENC, cZH, wave, lane);
+    MAT_LIN(rh1, C_H1_W, C_H1_B, cENC, cZH);
     MAT_SYNC();
     MAT_STAMP(27);
     tile_gelu(cZH, S0, tid);
@@ -472,45 +530,54 @@ __device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, in
 }
 
 // actor (decoder): token block in sXA + rep_enc in cENC -> logits in sOutA; starts and ends with the tiles settled
+template <bool PF>
 __device__ __forceinline__ void mat_decoder_forward(const MatCtx& c, int tid, int wave, int lane) {
     MAT_TILES(c);
+    MatFr rk1, rq1, rv1, rp1, rk2, rv2, rq2, rp2, rm1, rm2, rh1;
+    MAT_NEXT(rk1, A_K1_W, A_K1_B); MAT_NEXT(rq1, A_Q1_W, A_Q1_B); MAT_NEXT(rv1, A_V1_W, A_V1_B);
     narrow_fwd(W(A_ENC_W), Ain, nullptr, sXA, kMXS, aZ, wave, lane);                          // action_encoder.0 (no bias)
     MAT_SYNC();
     tile_gelu(aZ, S0, tid);
     tile_ln_fwd(S0, kMHS, kMD, W(A_LN_G), W(A_LN_B), aN0, rstd(5), S1, tid);                  // x0 in S1
     MAT_SYNC();
-    lin_fwd(W(A_K1_W), W(A_K1_B), S1, aK1, wave, lane);
-    lin_fwd(W(A_Q1_W), W(A_Q1_B), S1, aQ1, wave, lane);
-    lin_fwd(W(A_V1_W), W(A_V1_B), S1, aV1, wave, lane);
+    MAT_NEXT(rp1, A_P1_W, A_P1_B);
+    MAT_LIN(rk1, A_K1_W, A_K1_B, S1, aK1);
+    MAT_LIN(rq1, A_Q1_W, A_Q1_B, S1, aQ1);
+    MAT_LIN(rv1, A_V1_W, A_V1_B, S1, aV1);
     MAT_SYNC();
     att_fwd(aQ1, aK1, aV1, aY1, sP1, L, n_rows, true, wave, lane);
     MAT_SYNC();
-    lin_fwd(W(A_P1_W), W(A_P1_B), aY1, S2, wave, lane);
+    MAT_NEXT(rk2, A_K2_W, A_K2_B); MAT_NEXT(rv2, A_V2_W, A_V2_B); MAT_NEXT(rq2, A_Q2_W, A_Q2_B);
+    MAT_LIN(rp1, A_P1_W, A_P1_B, aY1, S2);
     MAT_SYNC();
     tile_add(S1, S2, S2, tid);
     tile_ln_fwd(S2, kMHS, kMD, W(A_LN1_G), W(A_LN1_B), aN1, rstd(6), S0, tid);                // x1 in S0
     MAT_SYNC();
-    lin_fwd(W(A_K2_W), W(A_K2_B), S0, aK2, wave, lane);                                       // key = value = x1
-    lin_fwd(W(A_V2_W), W(A_V2_B), S0, aV2, wave, lane);
-    lin_fwd(W(A_Q2_W), W(A_Q2_B), cENC, aQ2, wave, lane);                                     // query = rep_enc
+    MAT_NEXT(rp2, A_P2_W, A_P2_B);
+    MAT_LIN(rk2, A_K2_W, A_K2_B, S0, aK2);                                       // key = value = x1
+    MAT_LIN(rv2, A_V2_W, A_V2_B, S0, aV2);
+    MAT_LIN(rq2, A_Q2_W, A_Q2_B, cENC, aQ2);                                     // query = rep_enc
     MAT_SYNC();
     att_fwd(aQ2, aK2, aV2, aY2, sP2, L, n_rows, true, wave, lane);
     MAT_SYNC();
-    lin_fwd(W(A_P2_W), W(A_P2_B), aY2, S2, wave, lane);
+    MAT_NEXT(rm1, A_M1_W, A_M1_B);
+    MAT_LIN(rp2, A_P2_W, A_P2_B, aY2, S2);
     MAT_SYNC();
     tile_add(cENC, S2, S2, tid);
     tile_ln_fwd(S2, kMHS, kMD, W(A_LN2_G), W(A_LN2_B), aN2, rstd(7), S1, tid);                // x2 in S1
     MAT_SYNC();
-    lin_fwd(W(A_M1_W), W(A_M1_B), S1, aZM, wave, lane);
+    MAT_NEXT(rm2, A_M2_W, A_M2_B);
+    MAT_LIN(rm1, A_M1_W, A_M1_B, S1, aZM);
     MAT_SYNC();
     tile_gelu(aZM, S2, tid);
     MAT_SYNC();
-    lin_fwd(W(A_M2_W), W(A_M2_B), S2, S3, wave, lane);
+    MAT_NEXT(rh1, A_H1_W, A_H1_B);
+    MAT_LIN(rm2, A_M2_W, A_M2_B, S2, S3);
     MAT_SYNC();
     tile_add(S1, S3, S3, tid);
     tile_ln_fwd(S3, kMHS, kMD, W(A_LN3_G), W(A_LN3_B), aN3, rstd(8), S0, tid);                // x3 in S0
     MAT_SYNC();
-    lin_fwd(W(A_H1_W), W(A_H1_B), S0, aZH, wave, lane);
+    MAT_LIN(rh1, A_H1_W, A_H1_B, S0, aZH);
     MAT_SYNC();
     tile_gelu(aZH, S2, tid);
     tile_ln_fwd(S2, kMHS, kMD, W(A_HLN_G), W(A_HLN_B), aNH, rstd(9), S1, tid);                // head LayerNorm output in S1
@@ -547,7 +614,7 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     // each of the ~50 dependent linears below would otherwise start with a cold miss.  One load per 128-byte
     // line of the whole bucket is issued here; they complete during the gather / first phases.
     float l2_touch = 0.f;
-    for (long i = (long)tid * 32; i < u.total; i += (long)kMT * 32) l2_touch += P[i];
+    if (u.l2_warmup) for (long i = (long)tid * 32; i < u.total; i += (long)kMT * 32) l2_touch += P[i];
     // ---- rows, per-token scalars, mini-batch statistics
     if (tid < kRows) {
         int row = -1, act = 0;
@@ -622,10 +689,13 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     MAT_SYNC();
     MAT_STAMP(2);
 
-    mat_encoder_forward(c, tid, wave, lane);
+    mat_encoder_forward<true>(c, tid, wave, lane);
     MAT_STAMP(3);
-    mat_decoder_forward(c, tid, wave, lane);
+    mat_decoder_forward<true>(c, tid, wave, lane);
     MAT_STAMP(4);
+    // input-gradient (dgrad) fragment sets of the backward: each requested at the start of the phase before its use
+    MatFr dH1, dM2, dM1, dP2, dQ2, dK2, dV2, dP1, dQ1, dK1, dV1;
+    pf_dgrad(W(A_H1_W), wave, lane, dH1);
 
     // =========================================== heads: distribution + losses (K6 + K3) =============================
     if (wave == 0) {
@@ -728,43 +798,50 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     tile_affine(aN3, W(A_LN3_G), W(A_LN3_B), S0, tid);                                        // x3
     MAT_SYNC();
     lin_wgrad(S3, S0, G(A_H1_W), G(A_H1_B), wave, lane, tid);
-    lin_dgrad<false>(W(A_H1_W), S3, S2, wave, lane);                                          // d x3 -> S2
+    pf_dgrad(W(A_M2_W), wave, lane, dM2);
+    lin_dgrad_r<false>(dH1, S3, S2, wave, lane);                                          // d x3 -> S2
     MAT_SYNC();
     tile_ln_bwd(S2, kMHS, kMD, aN3, rstd(8), W(A_LN3_G), S4, G(A_LN3_G), G(A_LN3_B), tid);     // d r3 -> S4 (= d x2 residual = d mlp out)
     tile_gelu(aZM, S0, tid);                                                                  // mlp hidden activation
     MAT_SYNC();
     lin_wgrad(S4, S0, G(A_M2_W), G(A_M2_B), wave, lane, tid);
-    lin_dgrad<false>(W(A_M2_W), S4, S3, wave, lane);
+    pf_dgrad(W(A_M1_W), wave, lane, dM1);
+    lin_dgrad_r<false>(dM2, S4, S3, wave, lane);
     MAT_SYNC();
     tile_gelu_bwd(S3, aZM, tid);                                                              // d aZM
     tile_affine(aN2, W(A_LN2_G), W(A_LN2_B), S0, tid);                                        // x2
     MAT_SYNC();
     lin_wgrad(S3, S0, G(A_M1_W), G(A_M1_B), wave, lane, tid);
-    lin_dgrad<true>(W(A_M1_W), S3, S4, wave, lane);                                           // d x2 total in S4
+    pf_dgrad(W(A_P2_W), wave, lane, dP2);
+    lin_dgrad_r<true>(dM1, S3, S4, wave, lane);                                           // d x2 total in S4
     MAT_SYNC();
     tile_ln_bwd(S4, kMHS, kMD, aN2, rstd(7), W(A_LN2_G), DENC, G(A_LN2_G), G(A_LN2_B), tid);   // d r2 -> DENC (rep_enc share) = d proj2 out
     MAT_SYNC();
     lin_wgrad(DENC, aY2, G(A_P2_W), G(A_P2_B), wave, lane, tid);
-    lin_dgrad<false>(W(A_P2_W), DENC, S2, wave, lane);                                        // d Y2 -> S2
+    pf_dgrad(W(A_Q2_W), wave, lane, dQ2); pf_dgrad(W(A_K2_W), wave, lane, dK2); pf_dgrad(W(A_V2_W), wave, lane, dV2);
+    lin_dgrad_r<false>(dP2, DENC, S2, wave, lane);                                        // d Y2 -> S2
     MAT_SYNC();
     MAT_STAMP(6);
     att_bwd(aQ2, aK2, aV2, sP2, S2, S0, S3, S4, sS, wave, lane);                              // dQ2 -> S0, dK2 -> S3, dV2 -> S4
     MAT_SYNC();
     MAT_STAMP(7);
+    MatFr eH1, eM2, eM1, eP, eQ, eK, eV;
     lin_wgrad(S0, cENC, G(A_Q2_W), G(A_Q2_B), wave, lane, tid);
-    lin_dgrad<true>(W(A_Q2_W), S0, DENC, wave, lane);                                         // rep_enc gradient from the query path
+    lin_dgrad_r<true>(dQ2, S0, DENC, wave, lane);                                         // rep_enc gradient from the query path
     tile_affine(aN1, W(A_LN1_G), W(A_LN1_B), S1, tid);                                        // x1
     MAT_SYNC();
     lin_wgrad(S3, S1, G(A_K2_W), G(A_K2_B), wave, lane, tid);
     lin_wgrad(S4, S1, G(A_V2_W), G(A_V2_B), wave, lane, tid);
-    lin_dgrad<false>(W(A_K2_W), S3, S2, wave, lane);
+    pf_dgrad(W(A_P1_W), wave, lane, dP1);
+    lin_dgrad_r<false>(dK2, S3, S2, wave, lane);
     MAT_SYNC();
-    lin_dgrad<true>(W(A_V2_W), S4, S2, wave, lane);                                           // d x1 -> S2
+    lin_dgrad_r<true>(dV2, S4, S2, wave, lane);                                           // d x1 -> S2
     MAT_SYNC();
     tile_ln_bwd(S2, kMHS, kMD, aN1, rstd(6), W(A_LN1_G), S0, G(A_LN1_G), G(A_LN1_B), tid);     // d r1 -> S0 (= d x0 residual = d proj1 out)
     MAT_SYNC();
     lin_wgrad(S0, aY1, G(A_P1_W), G(A_P1_B), wave, lane, tid);
-    lin_dgrad<false>(W(A_P1_W), S0, S2, wave, lane);                                          // d Y1 -> S2
+    pf_dgrad(W(A_Q1_W), wave, lane, dQ1); pf_dgrad(W(A_K1_W), wave, lane, dK1); pf_dgrad(W(A_V1_W), wave, lane, dV1);
+    lin_dgrad_r<false>(dP1, S0, S2, wave, lane);                                          // d Y1 -> S2
     MAT_SYNC();
     att_bwd(aQ1, aK1, aV1, sP1, S2, S1, S3, S4, sS, wave, lane);                              // dQ1 -> S1, dK1 -> S3, dV1 -> S4
     MAT_SYNC();                                                                               // dY (S2) fully consumed
@@ -773,9 +850,10 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     lin_wgrad(S1, S2, G(A_Q1_W), G(A_Q1_B), wave, lane, tid);
     lin_wgrad(S3, S2, G(A_K1_W), G(A_K1_B), wave, lane, tid);
     lin_wgrad(S4, S2, G(A_V1_W), G(A_V1_B), wave, lane, tid);
-    lin_dgrad<true>(W(A_Q1_W), S1, S0, wave, lane);
-    lin_dgrad<true>(W(A_K1_W), S3, S0, wave, lane);
-    lin_dgrad<true>(W(A_V1_W), S4, S0, wave, lane);                                           // d x0 total in S0
+    pf_dgrad(W(C_H1_W), wave, lane, eH1);
+    lin_dgrad_r<true>(dQ1, S1, S0, wave, lane);
+    lin_dgrad_r<true>(dK1, S3, S0, wave, lane);
+    lin_dgrad_r<true>(dV1, S4, S0, wave, lane);                                           // d x0 total in S0
     MAT_SYNC();
     tile_ln_bwd(S0, kMHS, kMD, aN0, rstd(5), W(A_LN_G), S1, G(A_LN_G), G(A_LN_B), tid);        // d gelu out -> S1
     tile_gelu_bwd(S1, aZ, tid);
@@ -792,24 +870,28 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     tile_gelu_bwd(S3, cZH, tid);
     MAT_SYNC();
     lin_wgrad(S3, cENC, G(C_H1_W), G(C_H1_B), wave, lane, tid);
-    lin_dgrad<true>(W(C_H1_W), S3, DENC, wave, lane);                                         // total d rep_enc
+    pf_dgrad(W(C_M2_W), wave, lane, eM2);
+    lin_dgrad_r<true>(eH1, S3, DENC, wave, lane);                                         // total d rep_enc
     MAT_SYNC();
     tile_ln_bwd(DENC, kMHS, kMD, cN2, rstd(3), W(C_LN2_G), S4, G(C_LN2_G), G(C_LN2_B), tid);   // d r2 -> S4
     tile_gelu(cZM, S0, tid);
     MAT_SYNC();
     lin_wgrad(S4, S0, G(C_M2_W), G(C_M2_B), wave, lane, tid);
-    lin_dgrad<false>(W(C_M2_W), S4, S3, wave, lane);
+    pf_dgrad(W(C_M1_W), wave, lane, eM1);
+    lin_dgrad_r<false>(eM2, S4, S3, wave, lane);
     MAT_SYNC();
     tile_gelu_bwd(S3, cZM, tid);
     tile_affine(cN1, W(C_LN1_G), W(C_LN1_B), S0, tid);                                        // H1
     MAT_SYNC();
     lin_wgrad(S3, S0, G(C_M1_W), G(C_M1_B), wave, lane, tid);
-    lin_dgrad<true>(W(C_M1_W), S3, S4, wave, lane);                                           // d H1 total
+    pf_dgrad(W(C_P_W), wave, lane, eP);
+    lin_dgrad_r<true>(eM1, S3, S4, wave, lane);                                           // d H1 total
     MAT_SYNC();
     tile_ln_bwd(S4, kMHS, kMD, cN1, rstd(2), W(C_LN1_G), S0, G(C_LN1_G), G(C_LN1_B), tid);     // d r1 -> S0
     MAT_SYNC();
     lin_wgrad(S0, cY, G(C_P_W), G(C_P_B), wave, lane, tid);
-    lin_dgrad<false>(W(C_P_W), S0, S2, wave, lane);                                           // d Y
+    pf_dgrad(W(C_Q_W), wave, lane, eQ); pf_dgrad(W(C_K_W), wave, lane, eK); pf_dgrad(W(C_V_W), wave, lane, eV);
+    lin_dgrad_r<false>(eP, S0, S2, wave, lane);                                           // d Y
     MAT_SYNC();
     att_bwd(cQ, cK, cV, sP0, S2, S1, S3, S4, sS, wave, lane);                                 // dQ -> S1, dK -> S3, dV -> S4
     MAT_SYNC();
@@ -818,9 +900,9 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     lin_wgrad(S1, S2, G(C_Q_W), G(C_Q_B), wave, lane, tid);
     lin_wgrad(S3, S2, G(C_K_W), G(C_K_B), wave, lane, tid);
     lin_wgrad(S4, S2, G(C_V_W), G(C_V_B), wave, lane, tid);
-    lin_dgrad<true>(W(C_Q_W), S1, S0, wave, lane);
-    lin_dgrad<true>(W(C_K_W), S3, S0, wave, lane);
-    lin_dgrad<true>(W(C_V_W), S4, S0, wave, lane);                                            // d H0 total
+    lin_dgrad_r<true>(eQ, S1, S0, wave, lane);
+    lin_dgrad_r<true>(eK, S3, S0, wave, lane);
+    lin_dgrad_r<true>(eV, S4, S0, wave, lane);                                            // d H0 total
     MAT_SYNC();
     tile_ln_bwd(S0, kMHS, kMD, cN0, rstd(1), W(C_LN_G), S1, G(C_LN_G), G(C_LN_B), tid);
     tile_gelu_bwd(S1, cZ1, tid);
@@ -893,7 +975,7 @@ __global__ __launch_bounds__(kMT) void mat_policy_step_kernel(MatStepDev u) {
     }
     if (tid < n_rows && tid % L == 0) sXA[tid * kMXS] = 1.0f;     // start token of agent 0 (mat_policy.py:325-333)
     MAT_SYNC();
-    mat_encoder_forward(c, tid, wave, lane);
+    mat_encoder_forward<false>(c, tid, wave, lane);
     MAT_SYNC();
     if (tid < n_rows) {
         float v = sOutC[tid * 8];
@@ -901,7 +983,7 @@ __global__ __launch_bounds__(kMT) void mat_policy_step_kernel(MatStepDev u) {
         u.value_out[tok0 + tid] = v;
     }
     for (int i = 0; i < L; ++i) {
-        mat_decoder_forward(c, tid, wave, lane);                  // ends with a barrier
+        mat_decoder_forward<false>(c, tid, wave, lane);           // ends with a barrier
         if (tid < n_rows && tid % L == i) {
             float p[8];
             float m = -INFINITY;
@@ -1057,6 +1139,8 @@ static int make_mat(const ppoaf_mat_update_args_t* a, MatDev& u) {
     u.huber_delta = a->huber_delta; u.loss_partials = a->loss_partials; u.totals = a->totals;
     PPOAF_REQUIRE(!a->fuse_norm || (a->norm_scratch && a->step_count), "mat_update: fuse_norm needs norm_scratch and step_count");
     u.norm_scratch = a->norm_scratch; u.step_count = a->step_count; u.fuse_norm = a->fuse_norm != 0;
+    static const int warm = [] { const char* e = getenv("PPOAF_MAT_L2_WARMUP"); return e && e[0] == '1' ? 1 : 0; }();
+    u.l2_warmup = warm;
     return PPOAF_OK;
 }
 
