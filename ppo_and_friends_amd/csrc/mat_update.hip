@@ -698,96 +698,91 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     pf_dgrad(W(A_H1_W), wave, lane, dH1);
 
     // =========================================== heads: distribution + losses (K6 + K3) =============================
+    // wave 0: the categorical head of the 16 token rows, 4 lanes per row (lane (s4, q) owns classes q and q + 4: the
+    // transcendental chain is 2 values long instead of 8, class reductions are quad permutes -- as K12's head);
+    // wave 1: the value loss of the rows, at the same time.
     if (wave == 0) {
+        const int s4 = lane >> 2, q = lane & 3;
+        const bool live4 = s4 < n_rows && sRow[s4] >= 0;
+        float av4 = 0.f, lpo4 = 0.f;
+        if (live4) {
+            av4 = sRowF[s4]; lpo4 = sRowF[16 + s4];
+            if (u.normalize_adv) av4 = (av4 - sMisc[0]) / (sMisc[1] + 1e-8f);
+        }
+        const int k0 = q, k1 = q + 4;
+        const bool v0 = k0 < NA, v1 = k1 < NA;
+        const float z0 = v0 ? sOutA[s4 * 8 + k0] : -INFINITY, z1 = v1 ? sOutA[s4 * 8 + k1] : -INFINITY;
+        const float m = group4_max(fmaxf(z0, z1));
+        float p0 = v0 ? expf(z0 - m) : 0.f, p1 = v1 ? expf(z1 - m) : 0.f;
+        const float inv = 1.0f / group4_sum(p0 + p1);
+        p0 *= inv; p1 *= inv;
+        const float s2 = group4_sum(p0 + p1);
+        const int a = sAct[s4];
+        const float n0 = p0 / s2, n1 = p1 / s2;                                   // Categorical's renormalisation
+        const float l0 = v0 ? logf(clamp_prob_u(n0)) : 0.f, l1 = v1 ? logf(clamp_prob_u(n1)) : 0.f;
+        const float ent4 = -group4_sum((v0 ? n0 * l0 : 0.f) + (v1 ? n1 * l1 : 0.f));
+        const float logp4 = group4_sum((k0 == a ? l0 : 0.f) + (k1 == a ? l1 : 0.f));
+        const float ratio = expf(logp4 - lpo4);
+        const float bad4 = (isnan(ratio) || isinf(ratio)) ? 1.f : 0.f;
+        const float lo = 1.0f - u.surr_clip, hi = 1.0f + u.surr_clip;
+        const float surr1 = ratio * av4, surr2 = fminf(fmaxf(ratio, lo), hi) * av4;
+        float glp;
+        if (surr1 <= surr2) glp = -av4 * ratio;
+        else glp = (ratio >= lo && ratio <= hi) ? -av4 * ratio : 0.f;
+        glp *= inv_n;
+        const float gH = (u.entropy_weight != 0.0f) ? -u.entropy_weight * inv_n : 0.f;
+        auto gk_of = [&](bool valid, int k, float nk, float lg) {               // chain: z -softmax-> p -(/sum)-> n -clamp,log-> l
+            if (!valid) return 0.f;
+            const float ck = clamp_prob_u(nk);
+            const float in_range = (nk >= FLT_EPSILON && nk <= 1.0f - FLT_EPSILON) ? 1.f : 0.f;
+            float gk = gH * (-lg - nk * in_range / ck);
+            if (k == a) gk += glp * in_range / ck;
+            return gk;
+        };
+        float g0 = gk_of(v0, k0, n0, l0), g1 = gk_of(v1, k1, n1, l1);
+        const float dot = group4_sum(g0 * n0 + g1 * n1);
+        g0 = (g0 - dot) / s2; g1 = (g1 - dot) / s2;
+        const float dot2 = group4_sum(g0 * p0 + g1 * p1);
+        sDOutA[s4 * 8 + k0] = live4 ? p0 * (g0 - dot2) : 0.f;
+        sDOutA[s4 * 8 + k1] = live4 ? p1 * (g1 - dot2) : 0.f;
+        // row results -> lane s (= row s) for the partial sums of the tile
+        const int src = (lane & 15) * 4;
+        const float r_live = __shfl(live4 ? 1.f : 0.f, src, 64);
+        const float r_surr = __shfl(-fminf(surr1, surr2), src, 64), r_ent = __shfl(ent4, src, 64);
+        const float r_kl = __shfl(lpo4 - logp4, src, 64), r_bad = __shfl(bad4, src, 64);
+        const bool row_live = lane < kRows && r_live != 0.f;
+        const float t0 = group16_sum(row_live ? r_surr : 0.f), t3 = group16_sum(row_live ? r_ent : 0.f);
+        const float t4 = group16_sum(row_live ? r_kl : 0.f), t7 = group16_sum(row_live ? r_bad : 0.f);
+        if (lane == 0) {
+            float* lp = u.loss_partials + (long)g * 8;
+            lp[0] = t0; lp[1] = 0.f; lp[3] = t3; lp[4] = t4; lp[7] = t7;
+            lp[5] = g == 0 ? sMisc[0] : 0.f; lp[6] = g == 0 ? sMisc[1] : 0.f;
+        }
+    } else if (wave == 1) {
         const int s = lane;
         const bool live = s < n_rows && sRow[s] >= 0;
-        float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float l = 0.f;
         if (live) {
-            float av = sRowF[s];
-            const float lpo = sRowF[16 + s];
-            if (u.normalize_adv) av = (av - sMisc[0]) / (sMisc[1] + 1e-8f);
-            float p[8];
-            float m = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) if (k < NA) m = fmaxf(m, sOutA[s * 8 + k]);
-            float ssum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { p[k] = k < NA ? expf(sOutA[s * 8 + k] - m) : 0.f; ssum += p[k]; }
-            const float inv = 1.0f / ssum;
-            float s2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { p[k] *= inv; s2 += p[k]; }
-            const int a = sAct[s];
-            float nk8[8], lg8[8], logp = 0.f, ent = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                nk8[k] = p[k] / s2;
-                lg8[k] = k < NA ? logf(clamp_prob_u(nk8[k])) : 0.f;
-                if (k < NA) ent -= nk8[k] * lg8[k];
-                if (k == a) logp = lg8[k];
-            }
-            const float ratio = expf(logp - lpo);
-            if (isnan(ratio) || isinf(ratio)) part[7] = 1.f;
-            const float lo = 1.0f - u.surr_clip, hi = 1.0f + u.surr_clip;
-            const float surr1 = ratio * av, surr2 = fminf(fmaxf(ratio, lo), hi) * av;
-            part[0] = -fminf(surr1, surr2);
-            part[3] = ent;
-            part[4] = lpo - logp;
-            float glp;
-            if (surr1 <= surr2) glp = -av * ratio;
-            else glp = (ratio >= lo && ratio <= hi) ? -av * ratio : 0.f;
-            glp *= inv_n;
-            const float gH = (u.entropy_weight != 0.0f) ? -u.entropy_weight * inv_n : 0.f;
-            float gn[8], dot = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float gk = 0.f;
-                if (k < NA) {
-                    const float nk = nk8[k], ck = clamp_prob_u(nk);
-                    const float in_range = (nk >= FLT_EPSILON && nk <= 1.0f - FLT_EPSILON) ? 1.f : 0.f;
-                    gk = gH * (-lg8[k] - nk * in_range / ck);
-                    if (k == a) gk += glp * in_range / ck;
-                    dot += gk * nk;
-                }
-                gn[k] = gk;
-            }
-            float dot2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { gn[k] = (gn[k] - dot) / s2; dot2 += gn[k] * p[k]; }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sDOutA[s * 8 + k] = p[k] * (gn[k] - dot2);
-            // value loss
             const float v = sOutC[s * 8];
             float rt = sRowF[32 + s];
             if (u.normalize_values) rt = (rt - sMisc[2]) / sqrtf(sMisc[3] + 1e-8f);
             const float diff = v - rt;
-            float l, dl;
+            float dl;
             if (u.use_huber) {
                 const float ad = fabsf(diff);
                 if (ad < u.huber_delta) { l = 0.5f * diff * diff; dl = diff; }
                 else { l = u.huber_delta * (ad - 0.5f * u.huber_delta); dl = diff > 0.f ? u.huber_delta : -u.huber_delta; }
             } else { l = diff * diff; dl = 2.0f * diff; }
-            part[2] = l;
             sDOutC[s * 8] = dl * inv_n;
             u.values[(long)sRow[s] * L + (s % L)] = v;                                          // ppo.py:2340
         } else if (s < kRows) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { sDOutA[s * 8 + k] = 0.f; sDOutC[s * 8 + k] = 0.f; }
+            for (int k = 0; k < 8; ++k) sDOutC[s * 8 + k] = 0.f;
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float v = (lane < kRows) ? part[k] : 0.f;
-            part[k] = group16_sum(v);
-        }
-        if (lane == 0) {
-            if (g == 0) { part[5] = sMisc[0]; part[6] = sMisc[1]; }
-            float* lp = u.loss_partials + (long)g * 8;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) lp[k] = part[k];
-        }
+        const float t2 = group16_sum((lane < kRows && live) ? l : 0.f);
+        if (lane == 0) u.loss_partials[(long)g * 8 + 2] = t2;
     }
     MAT_SYNC();
-
     MAT_STAMP(5);
     // =========================================== actor backward ===========================================
     // S1 still holds the head LayerNorm output
@@ -1059,14 +1054,16 @@ __global__ __launch_bounds__(kMatRedThreads) void mat_update_reduce_kernel(MatDe
     const long idx = (long)blockIdx.x * kMatRedThreads + threadIdx.x;
     const float4* sl = reinterpret_cast<const float4*>(u.slabs);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // 52 slabs at C5: 16 loads of a column in flight at a time (the slabs were written by other XCDs a moment ago: every
+    // batch is one cold round trip, so the launch lasts ceil(slabs / 16) of them), added in slab order
     if (idx < n4)
-    for (int g0 = 0; g0 < u.nT; g0 += 8) {
-        float4 v[8];
+    for (int g0 = 0; g0 < u.nT; g0 += 16) {
+        float4 v[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < 16; ++k)
             v[k] = (g0 + k < u.nT) ? sl[(long)(g0 + k) * n4 + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+        for (int k = 0; k < 16; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
     }
     if (idx < n4) reinterpret_cast<float4*>(u.grads)[idx] = acc;
     if (u.fuse_norm) {                                        // uniform per launch: every thread reaches the barriers
