@@ -679,7 +679,11 @@ typedef struct {
      * 1024) per-workgroup partials of ||grads||^2 in norm_scratch[2 ..] (float64[2 + that many], at least
      * PPOAF_NORM_SCRATCH_DOUBLES) and advances step_count, so the caller follows with ppoaf_adam_step_prenormed
      * (n_norm_partials = that count) instead of ppoaf_clip_adam_step */
-    double* norm_scratch; int64_t* step_count; int32_t fuse_norm, _pad;
+    double* norm_scratch; int64_t* step_count; int32_t fuse_norm;
+    /* 1: critic_obs / raw_actions / advantages / old_log_probs / rewards_to_go are per-epoch tables already in shuffled
+     * order (entry i belongs to perm[i]): a mini-batch reads [k * batch_stride, +B) directly, its loads depend on the cursor
+     * only; `values` is still written through perm / row_map.  0: they are the rollout buffer's rows. */
+    int32_t inputs_in_batch_order;
 } ppoaf_mat_update_args_t;
 
 int ppoaf_mat_update_fwd_bwd(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream);

@@ -113,7 +113,8 @@ class MatUpdateArgs(C.Structure):
                 ("surr_clip", C.c_float), ("entropy_weight", C.c_float), ("kl_loss_weight", C.c_float),
                 ("huber_delta", C.c_float),
                 ("loss_partials", C.c_void_p), ("totals", C.c_void_p),
-                ("norm_scratch", C.c_void_p), ("step_count", C.c_void_p), ("fuse_norm", C.c_int32), ("_pad", C.c_int32)]
+                ("norm_scratch", C.c_void_p), ("step_count", C.c_void_p), ("fuse_norm", C.c_int32),
+                ("inputs_in_batch_order", C.c_int32)]
 
 
 class MatStepArgs(C.Structure):

@@ -54,6 +54,7 @@ struct MatDev {
     float surr_clip, entropy_weight, kl_loss_weight, huber_delta;
     float* loss_partials; double* totals;
     double* norm_scratch; int64_t* step_count; int fuse_norm;
+    int pregathered;     // obs / actions / adv / old_lp / rtg are per-epoch tables in shuffled order (entry i belongs to perm[i])
     int l2_warmup;       // diagnostic (PPOAF_MAT_L2_WARMUP=1): touch every line of the bucket at kernel start, as rounds 1-2 did
 };
 
@@ -621,8 +622,20 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
         float av = 0.f, lpo = 0.f, rt = 0.f;
         if (tid < n_rows) {
             const int s = tid / L, a = tid - s * L;
-            const long p = u.perm[mb * u.batch_stride + seq0 + s];
-            if (p >= 0 && p < u.n_rows) {
+            const long pos = mb * u.batch_stride + seq0 + s;
+            const long p = u.perm[pos];
+            if (u.pregathered) {
+                // per-epoch tables in shuffled order: entry `pos` belongs to perm[pos], so these loads depend on the cursor
+                // only and go out together with the perm load (instead of behind perm -> row_map: two cold round trips)
+                const long tok = pos * L + a;
+                const int a_raw = (int)u.actions[tok];
+                const float av_ = u.adv[tok], lpo_ = u.old_lp[tok], rt_ = u.rtg[tok];
+                if (p >= 0 && p < u.n_rows) {
+                    row = u.row_map ? u.row_map[p] : (int)p;
+                    act = a_raw < 0 ? 0 : (a_raw >= NA ? NA - 1 : a_raw);
+                    av = av_; lpo = lpo_; rt = rt_;
+                }
+            } else if (p >= 0 && p < u.n_rows) {
                 row = u.row_map ? u.row_map[p] : (int)p;
                 const long tok = (long)row * L + a;
                 act = (int)u.actions[tok];
@@ -679,7 +692,8 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     for (int idx = tid; idx < n_rows * O; idx += kMT) {
         const int s = idx / O, i = idx - s * O;
         const int row = sRow[s];
-        if (row >= 0) sYO[s * OS + i] = u.obs[((long)row * L + (s % L)) * O + i];
+        const long orow = u.pregathered ? mb * u.batch_stride + seq0 + s / L : (long)row;
+        if (row >= 0) sYO[s * OS + i] = u.obs[(orow * L + (s % L)) * O + i];
     }
     if (tid < n_rows && sRow[tid] >= 0) {
         const int a = tid % L;
@@ -1136,6 +1150,7 @@ static int make_mat(const ppoaf_mat_update_args_t* a, MatDev& u) {
     u.huber_delta = a->huber_delta; u.loss_partials = a->loss_partials; u.totals = a->totals;
     PPOAF_REQUIRE(!a->fuse_norm || (a->norm_scratch && a->step_count), "mat_update: fuse_norm needs norm_scratch and step_count");
     u.norm_scratch = a->norm_scratch; u.step_count = a->step_count; u.fuse_norm = a->fuse_norm != 0;
+    u.pregathered = a->inputs_in_batch_order != 0;
     static const int warm = [] { const char* e = getenv("PPOAF_MAT_L2_WARMUP"); return e && e[0] == '1' ? 1 : 0; }();
     u.l2_warmup = warm;
     return PPOAF_OK;

@@ -1022,9 +1022,11 @@ class FusedMatUpdate(FusedPolicyUpdate):
         a.bucket_total = t["bucket_total"]
         ac = pol.actor_critic
         a.params, a.grads, a.slabs = ac.flat_params.data_ptr(), ac.flat_grads.data_ptr(), self.slabs.data_ptr()
-        a.critic_obs, a.raw_actions = buf.critic_observations.data_ptr(), buf.raw_actions.data_ptr()
-        a.advantages, a.old_log_probs = buf.advantages.data_ptr(), buf.log_probs.data_ptr()
-        a.rewards_to_go, a.values = buf.rewards_to_go.data_ptr(), buf.values.data_ptr()
+        t = self.tables                        # per-epoch inputs in shuffled order (begin_epoch): no index -> data dependent load
+        a.critic_obs, a.raw_actions = t["critic_obs"].data_ptr(), t["raw_actions"].data_ptr()
+        a.advantages, a.old_log_probs = t["advantages"].data_ptr(), t["log_probs"].data_ptr()
+        a.rewards_to_go, a.values = t["rewards_to_go"].data_ptr(), buf.values.data_ptr()
+        a.inputs_in_batch_order = 1
         a.perm, a.row_map, a.n_rows = self.perm.data_ptr(), buf.row_map.data_ptr(), buf.num_transitions
         a.cursor, a.B, a.batch_stride = self.cursor.data_ptr(), B, self.B
         a.normalize_values, a.n_ranks = int(bool(ppo.normalize_values)), self.world
@@ -1076,6 +1078,16 @@ class FusedMatUpdate(FusedPolicyUpdate):
             self._graphs.clear()
         self.perm.copy_(perm)
         nb = (N + self.B - 1) // self.B
+        # K4 over the whole epoch: every input field of the update in shuffled order (one launch)
+        flat = lambda x: x.view((buf.num_transitions,) + tuple(x.shape[2:]))
+        fields = dict(critic_obs=buf.critic_observations, raw_actions=buf.raw_actions, advantages=buf.advantages,
+                      log_probs=buf.log_probs, rewards_to_go=buf.rewards_to_go)
+        t = getattr(self, "tables", None)
+        if t is None or t["advantages"].shape[0] != N:
+            t = self.tables = {k: torch.empty((N,) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device) for k, v in fields.items()}
+            self._graphs.clear()
+            self._args = {}
+        K.minibatch_gather([(flat(v), t[k]) for k, v in fields.items()], self.perm, buf.row_map)
 
         def keep(name, rec):
             cur = getattr(self, name)
@@ -1094,7 +1106,7 @@ class FusedMatUpdate(FusedPolicyUpdate):
                                                    gather=False)[0].contiguous())
         self.cursor.zero_()
         self.totals.zero_()
-        sig = (buf.critic_observations.data_ptr(), buf.num_transitions, self.perm.data_ptr(),
+        sig = (buf.critic_observations.data_ptr(), self.tables["critic_obs"].data_ptr(), buf.num_transitions, self.perm.data_ptr(),
                None if self.records is None else self.records.data_ptr(),
                None if self.adv_records is None else self.adv_records.data_ptr(),
                float(pol.entropy_weight()), float(pol.surr_clip), float(pol.kl_loss_weight),
