@@ -236,6 +236,9 @@ def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
     pol.train()
     N = pol.buffer.num_transitions
     fused.begin_epoch(torch.randperm(N, device=pol.device))
+    # a policy with an ICM runs its PPO epoch beside the ICM epoch on a second stream, where the persistent kernel is not
+    # used (ppo.py: _train_with_icm): probe the kernel the timed region ran, not the one a lone epoch would pick
+    fused.ws_allowed = not getattr(pol, "enable_icm", False)
     args = fused._args_for(B)
     ref = C.byref(args)
     lin = lambda net: sum(2 * m.weight.numel() for m in net.modules() if isinstance(m, torch.nn.Linear))
@@ -296,8 +299,12 @@ def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
         fwd = lin(pol.actor) + lin(pol.critic)
         ha, hc = args.actor.hidden // 16, args.critic.hidden // 16
         kernel, desc = f"ppo_update_fwd_bwd_kernel<{ha}, {hc}>", "3 x 2 x sum(Linear weights of actor + critic) x B"
+        passes = 3
         if fused.split:
-            desc += " (the chain's FLOPs; the hidden layers' wgrad third runs in ppo_update_wgrad_kernel)"
+            # split-wgrad chain: this kernel runs the forward and the input-gradient pass; the weight-gradient third is
+            # ppo_update_wgrad_kernel's (the output layer's few wgrad FLOPs stay here and are not counted)
+            passes = 2
+            desc = "2 x 2 x sum(Linear weights of actor + critic) x B (forward + dgrad; the wgrad third runs in ppo_update_wgrad_kernel)"
         if fused.split:
             kernel = kernel.replace(">", ", true>")                  # the split-wgrad instantiation of the same kernel
         for _ in range(launches):
@@ -306,9 +313,10 @@ def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
             _lib.check(lib.ppoaf_ppo_update_adam(ref, 3 if fused.split else 0, st), "adam")
             evs.append(ev)
     torch.cuda.synchronize()
+    fused.ws_allowed = True
     us = sorted(K.event_elapsed_ms(a, b) * 1e3 for a, b in evs)
     avg = sum(us) / len(us)
-    flop = 3 * fwd * B
+    flop = (passes if not pol.agent_grouping else 3) * fwd * B
     tf = flop / (avg * 1e-6) / 1e12
     pmc = update_pmc_traffic(config, kernel)
     return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
