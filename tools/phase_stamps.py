@@ -1,7 +1,7 @@
 import sys, os, ctypes as C; sys.path.insert(0,'.')
 import numpy as np, torch
 from ppo_and_friends_amd import _lib
-_lib.LIB_PATH=os.path.abspath('tools/libppoaf_hip_stamps.so')
+_lib.LIB_PATH=os.path.abspath(os.environ.get('PPOAF_LIB','tools/libppoaf_hip_stamps.so'))
 from ppo_and_friends_amd.ppo import PPO, PermutationLoader
 from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
 from ppo_and_friends_amd.spaces import Box, Discrete
