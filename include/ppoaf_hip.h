@@ -37,7 +37,7 @@ typedef void* ppoaf_stream_t;            /* hipStream_t */
 #define PPOAF_E_INVALID    -1            /* bad argument / unsupported shape   */
 #define PPOAF_E_LAUNCH     -2            /* hipLaunch / runtime error          */
 
-#define PPOAF_ABI_VERSION 3
+#define PPOAF_ABI_VERSION 4
 
 int         ppoaf_abi_version(void);
 const char* ppoaf_last_error(void);
@@ -684,12 +684,25 @@ typedef struct {
      * order (entry i belongs to perm[i]): a mini-batch reads [k * batch_stride, +B) directly, its loads depend on the cursor
      * only; `values` is still written through perm / row_map.  0: they are the rollout buffer's rows. */
     int32_t inputs_in_batch_order;
+    /* split-wgrad chain (NULL: every workgroup writes a slab of the whole bucket).  With a workspace of
+     * ppoaf_mat_update_split_workspace_bytes() bytes (256-byte aligned) fwd_bwd forms NO weight gradient of the 18
+     * 64 x 64 linears -- a third of its MFMA work, all on the one CU that owns a token tile -- and publishes each
+     * linear's input and dLoss/dz tile there instead; ppoaf_mat_update_reduce then forms dW = dz^T x once per mini-batch
+     * over all tokens (K = every token row, f32 MFMA, one workgroup per 16 x 16 tile), the biases as column sums of dz,
+     * and reduces the (now 13 KB) slabs of the small tensors.  Same call sequence, same outputs; sums run in MFMA K order
+     * (float32-rounding-level differences from the slab form, bitwise reproducible).  With fuse_norm the launch leaves
+     * ppoaf_mat_update_norm_partials(args) partials in norm_scratch[2 ..]. */
+    void* split_workspace; int64_t split_workspace_bytes;
 } ppoaf_mat_update_args_t;
 
 int ppoaf_mat_update_fwd_bwd(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream);
 int ppoaf_mat_update_fwd_bwd_timed(const ppoaf_mat_update_args_t* args, void* start_event, void* stop_event,
                                    ppoaf_stream_t stream);
 int ppoaf_mat_update_reduce(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream);
+int ppoaf_mat_update_split_workspace_bytes(const ppoaf_mat_update_args_t* args, int64_t* bytes_out);
+/* number of squared-norm partials a fuse_norm reduce launch leaves (n_norm_partials of ppoaf_adam_step_prenormed;
+ * norm_scratch must hold 2 + that many doubles); -1 on invalid args */
+int ppoaf_mat_update_norm_partials(const ppoaf_mat_update_args_t* args);
 
 /* ------------------------------------------------------------------------ *
  * K16  one rollout step of a MATPolicy for all E envs of the rank in one launch

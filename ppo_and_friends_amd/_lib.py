@@ -60,7 +60,7 @@ class PpoUpdateArgs(C.Structure):
                 ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64)]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class PolicyStepArgs(C.Structure):
@@ -114,7 +114,8 @@ class MatUpdateArgs(C.Structure):
                 ("huber_delta", C.c_float),
                 ("loss_partials", C.c_void_p), ("totals", C.c_void_p),
                 ("norm_scratch", C.c_void_p), ("step_count", C.c_void_p), ("fuse_norm", C.c_int32),
-                ("inputs_in_batch_order", C.c_int32)]
+                ("inputs_in_batch_order", C.c_int32),
+                ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64)]
 
 
 class MatStepArgs(C.Structure):
@@ -216,6 +217,8 @@ SIGNATURES = {
     "ppoaf_mat_update_fwd_bwd": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
     "ppoaf_mat_update_fwd_bwd_timed": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr, _ptr, _ptr]),
     "ppoaf_mat_update_reduce": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
+    "ppoaf_mat_update_split_workspace_bytes": (C.c_int, [C.POINTER(MatUpdateArgs), C.POINTER(C.c_int64)]),
+    "ppoaf_mat_update_norm_partials": (C.c_int, [C.POINTER(MatUpdateArgs)]),
     "ppoaf_mat_policy_step": (C.c_int, [C.POINTER(MatStepArgs), _ptr]),
     "ppoaf_peer_exchange_create": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
     "ppoaf_peer_exchange_export": (C.c_int, [_ptr, _ptr]),

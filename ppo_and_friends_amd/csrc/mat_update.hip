@@ -56,7 +56,33 @@ struct MatDev {
     double* norm_scratch; int64_t* step_count; int fuse_norm;
     int pregathered;     // obs / actions / adv / old_lp / rtg are per-epoch tables in shuffled order (entry i belongs to perm[i])
     int l2_warmup;       // diagnostic (PPOAF_MAT_L2_WARMUP=1): touch every line of the bucket at kernel start, as rounds 1-2 did
+    // split-wgrad chain (args->split_workspace): fwd_bwd computes NO weight gradient of the 18 64x64 linears; it publishes
+    // their inputs and dLoss/dz tiles into panels and the reduce launch becomes mat_update_wgrad_kernel
+    int split;
+    int R;               // rows of a panel = 16 * nT (tile g owns rows [16 g, +16), dead rows included: their dz is zero)
+    float* xpanel;       // [MAT_NUM_XPANELS][R][64] inputs of the linears
+    float* dpanel;       // [kMatLin][R][64]         dLoss / d(linear output)
+    int goff[64];        // where parameter k's partial sits inside a workgroup's slab (split: compact layout of the small
+                         // tensors, -1 for the 18 linears' W and b; else == off)
+    long slab_stride;    // floats per workgroup slab (split: n_small4 * 4; else total)
+    int n_small4;        // float4 columns of the compact slab
+    int n_seg, seg_start[4], seg_dst[4];   // runs of small tensors: compact float offset -> bucket float offset
 };
+
+// the 18 linears whose weight gradients the wgrad launch forms, in the order the backward meets them, and the panel that
+// holds each one's input (x1 feeds K2 / V2, x0 feeds Q1 / K1 / V1, H0 feeds Q / K / V, rep_enc feeds Q2 and the critic head)
+enum MatX { X_X3, X_GAM, X_X2, X_AY2, X_ENC, X_X1, X_AY1, X_X0, X_GCM, X_H1, X_CY, X_H0, MAT_NUM_XPANELS };
+constexpr int kMatLin = 18;
+#define PPOAF_MAT_LIN_W { A_H1_W, A_M2_W, A_M1_W, A_P2_W, A_Q2_W, A_K2_W, A_V2_W, A_P1_W, A_Q1_W, A_K1_W, A_V1_W, \
+                          C_H1_W, C_M2_W, C_M1_W, C_P_W, C_Q_W, C_K_W, C_V_W }
+#define PPOAF_MAT_LIN_X { X_X3, X_GAM, X_X2, X_AY2, X_ENC, X_X1, X_X1, X_AY1, X_X0, X_X0, X_X0, \
+                          X_ENC, X_GCM, X_H1, X_CY, X_H0, X_H0, X_H0 }
+static const int kMatLinW_host[kMatLin] = PPOAF_MAT_LIN_W;
+__constant__ int kMatLinW[kMatLin] = PPOAF_MAT_LIN_W;
+__constant__ int kMatLinX[kMatLin] = PPOAF_MAT_LIN_X;
+// indices into the tables above, named by the weight (call sites of the backward)
+enum MatLinId { L_A_H1, L_A_M2, L_A_M1, L_A_P2, L_A_Q2, L_A_K2, L_A_V2, L_A_P1, L_A_Q1, L_A_K1, L_A_V1,
+                L_C_H1, L_C_M2, L_C_M1, L_C_P, L_C_Q, L_C_K, L_C_V };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char mat_smem[];
 
@@ -210,6 +236,13 @@ __device__ __forceinline__ void lin_dgrad(const float* __restrict__ W, const flo
         const int idx = (4 * (lane >> 4) + r) * kMHS + wave * 16 + (lane & 15);
         out[idx] = ACCUM ? out[idx] + acc[r] : acc[r];
     }
+}
+
+// split-wgrad chain: a settled [16, 64] LDS tile -> rows [16 g, +16) of a [R][64] panel (one float4 per thread)
+__device__ __forceinline__ void publish_tile(const float* __restrict__ T, float* __restrict__ panel, int g, int tid) {
+    const int r = tid >> 4, c4 = tid & 15;
+    *reinterpret_cast<float4*>(panel + ((long)g * kRows + r) * kMD + 4 * c4) =
+        *reinterpret_cast<const float4*>(T + r * kMHS + 4 * c4);
 }
 
 // The same linears with their weight fragments REQUESTED AHEAD: a wave's share of a 64x64 linear is 4 float4 per lane (+ its
@@ -589,12 +622,28 @@ __device__ __forceinline__ void mat_decoder_forward(const MatCtx& c, int tid, in
 }
 
 
+// SPLIT: the weight gradients of the 18 64x64 linears are NOT formed here (a third of the kernel's MFMA work, on the
+// one CU that owns the tile: ablation 72 -> 59 us); the D and input tiles each of them needs go to the panels instead.
+#define MAT_WGRAD(lin, D, In, pub_x, Wk, Bk)                                                        \
+    do {                                                                                            \
+        if constexpr (SPLIT) {                                                                      \
+            publish_tile(D, u.dpanel + (long)(lin) * u.R * kMD, g, tid);                            \
+            if (pub_x) publish_tile(In, u.xpanel + (long)kMatLinX_of(lin) * u.R * kMD, g, tid);     \
+        } else {                                                                                    \
+            lin_wgrad(D, In, G(Wk), G(Bk), wave, lane, tid);                                        \
+        }                                                                                           \
+    } while (0)
+__device__ __forceinline__ constexpr int kMatLinX_of(int lin) {
+    constexpr int t[kMatLin] = PPOAF_MAT_LIN_X;
+    return t[lin];
+}
+template <bool SPLIT>
 __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x;
     const int NT0 = (u.O + 15) >> 4;
     const float* P = u.params;
-    float* slab = u.slabs + (long)g * u.total;
+    float* slab = u.slabs + (long)g * u.slab_stride;
     const long mb = u.cursor[0];
     const long seq0 = (long)g * u.per_tile;
     const long rem = u.B - seq0;
@@ -609,7 +658,7 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     MAT_TILES(c);
     int* sRow = c.sRow; int* sAct = c.sAct; float* sMisc = c.sMisc; float* sRowF = c.sRowF;
     float* sDOutC = c.sDOutC; float* sDOutA = c.sDOutA;
-    auto G = [&](int k) -> float* { return slab + u.off[k]; };
+    auto G = [&](int k) -> float* { return slab + u.goff[k]; };
 
     // L2 warm-up: the bucket was rewritten by the Adam kernel a moment ago, so this XCD's L2 holds none of it and
     // each of the ~50 dependent linears below would otherwise start with a cold miss.  One load per 128-byte
@@ -806,27 +855,27 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     tile_gelu_bwd(S3, aZH, tid);                                                              // d aZH
     tile_affine(aN3, W(A_LN3_G), W(A_LN3_B), S0, tid);                                        // x3
     MAT_SYNC();
-    lin_wgrad(S3, S0, G(A_H1_W), G(A_H1_B), wave, lane, tid);
+    MAT_WGRAD(L_A_H1, S3, S0, true, A_H1_W, A_H1_B);
     pf_dgrad(W(A_M2_W), wave, lane, dM2);
     lin_dgrad_r<false>(dH1, S3, S2, wave, lane);                                          // d x3 -> S2
     MAT_SYNC();
     tile_ln_bwd(S2, kMHS, kMD, aN3, rstd(8), W(A_LN3_G), S4, G(A_LN3_G), G(A_LN3_B), tid);     // d r3 -> S4 (= d x2 residual = d mlp out)
     tile_gelu(aZM, S0, tid);                                                                  // mlp hidden activation
     MAT_SYNC();
-    lin_wgrad(S4, S0, G(A_M2_W), G(A_M2_B), wave, lane, tid);
+    MAT_WGRAD(L_A_M2, S4, S0, true, A_M2_W, A_M2_B);
     pf_dgrad(W(A_M1_W), wave, lane, dM1);
     lin_dgrad_r<false>(dM2, S4, S3, wave, lane);
     MAT_SYNC();
     tile_gelu_bwd(S3, aZM, tid);                                                              // d aZM
     tile_affine(aN2, W(A_LN2_G), W(A_LN2_B), S0, tid);                                        // x2
     MAT_SYNC();
-    lin_wgrad(S3, S0, G(A_M1_W), G(A_M1_B), wave, lane, tid);
+    MAT_WGRAD(L_A_M1, S3, S0, true, A_M1_W, A_M1_B);
     pf_dgrad(W(A_P2_W), wave, lane, dP2);
     lin_dgrad_r<true>(dM1, S3, S4, wave, lane);                                           // d x2 total in S4
     MAT_SYNC();
     tile_ln_bwd(S4, kMHS, kMD, aN2, rstd(7), W(A_LN2_G), DENC, G(A_LN2_G), G(A_LN2_B), tid);   // d r2 -> DENC (rep_enc share) = d proj2 out
     MAT_SYNC();
-    lin_wgrad(DENC, aY2, G(A_P2_W), G(A_P2_B), wave, lane, tid);
+    MAT_WGRAD(L_A_P2, DENC, aY2, true, A_P2_W, A_P2_B);
     pf_dgrad(W(A_Q2_W), wave, lane, dQ2); pf_dgrad(W(A_K2_W), wave, lane, dK2); pf_dgrad(W(A_V2_W), wave, lane, dV2);
     lin_dgrad_r<false>(dP2, DENC, S2, wave, lane);                                        // d Y2 -> S2
     MAT_SYNC();
@@ -835,12 +884,12 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     MAT_SYNC();
     MAT_STAMP(7);
     MatFr eH1, eM2, eM1, eP, eQ, eK, eV;
-    lin_wgrad(S0, cENC, G(A_Q2_W), G(A_Q2_B), wave, lane, tid);
+    MAT_WGRAD(L_A_Q2, S0, cENC, true, A_Q2_W, A_Q2_B);
     lin_dgrad_r<true>(dQ2, S0, DENC, wave, lane);                                         // rep_enc gradient from the query path
     tile_affine(aN1, W(A_LN1_G), W(A_LN1_B), S1, tid);                                        // x1
     MAT_SYNC();
-    lin_wgrad(S3, S1, G(A_K2_W), G(A_K2_B), wave, lane, tid);
-    lin_wgrad(S4, S1, G(A_V2_W), G(A_V2_B), wave, lane, tid);
+    MAT_WGRAD(L_A_K2, S3, S1, true, A_K2_W, A_K2_B);
+    MAT_WGRAD(L_A_V2, S4, S1, false, A_V2_W, A_V2_B);
     pf_dgrad(W(A_P1_W), wave, lane, dP1);
     lin_dgrad_r<false>(dK2, S3, S2, wave, lane);
     MAT_SYNC();
@@ -848,7 +897,7 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     MAT_SYNC();
     tile_ln_bwd(S2, kMHS, kMD, aN1, rstd(6), W(A_LN1_G), S0, G(A_LN1_G), G(A_LN1_B), tid);     // d r1 -> S0 (= d x0 residual = d proj1 out)
     MAT_SYNC();
-    lin_wgrad(S0, aY1, G(A_P1_W), G(A_P1_B), wave, lane, tid);
+    MAT_WGRAD(L_A_P1, S0, aY1, true, A_P1_W, A_P1_B);
     pf_dgrad(W(A_Q1_W), wave, lane, dQ1); pf_dgrad(W(A_K1_W), wave, lane, dK1); pf_dgrad(W(A_V1_W), wave, lane, dV1);
     lin_dgrad_r<false>(dP1, S0, S2, wave, lane);                                          // d Y1 -> S2
     MAT_SYNC();
@@ -856,9 +905,9 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     MAT_SYNC();                                                                               // dY (S2) fully consumed
     tile_affine(aN0, W(A_LN_G), W(A_LN_B), S2, tid);                                          // x0
     MAT_SYNC();
-    lin_wgrad(S1, S2, G(A_Q1_W), G(A_Q1_B), wave, lane, tid);
-    lin_wgrad(S3, S2, G(A_K1_W), G(A_K1_B), wave, lane, tid);
-    lin_wgrad(S4, S2, G(A_V1_W), G(A_V1_B), wave, lane, tid);
+    MAT_WGRAD(L_A_Q1, S1, S2, true, A_Q1_W, A_Q1_B);
+    MAT_WGRAD(L_A_K1, S3, S2, false, A_K1_W, A_K1_B);
+    MAT_WGRAD(L_A_V1, S4, S2, false, A_V1_W, A_V1_B);
     pf_dgrad(W(C_H1_W), wave, lane, eH1);
     lin_dgrad_r<true>(dQ1, S1, S0, wave, lane);
     lin_dgrad_r<true>(dK1, S3, S0, wave, lane);
@@ -878,27 +927,27 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     tile_ln_bwd(S2, kMHS, kMD, cNH, rstd(4), W(C_HLN_G), S3, G(C_HLN_G), G(C_HLN_B), tid);
     tile_gelu_bwd(S3, cZH, tid);
     MAT_SYNC();
-    lin_wgrad(S3, cENC, G(C_H1_W), G(C_H1_B), wave, lane, tid);
+    MAT_WGRAD(L_C_H1, S3, cENC, false, C_H1_W, C_H1_B);
     pf_dgrad(W(C_M2_W), wave, lane, eM2);
     lin_dgrad_r<true>(eH1, S3, DENC, wave, lane);                                         // total d rep_enc
     MAT_SYNC();
     tile_ln_bwd(DENC, kMHS, kMD, cN2, rstd(3), W(C_LN2_G), S4, G(C_LN2_G), G(C_LN2_B), tid);   // d r2 -> S4
     tile_gelu(cZM, S0, tid);
     MAT_SYNC();
-    lin_wgrad(S4, S0, G(C_M2_W), G(C_M2_B), wave, lane, tid);
+    MAT_WGRAD(L_C_M2, S4, S0, true, C_M2_W, C_M2_B);
     pf_dgrad(W(C_M1_W), wave, lane, eM1);
     lin_dgrad_r<false>(eM2, S4, S3, wave, lane);
     MAT_SYNC();
     tile_gelu_bwd(S3, cZM, tid);
     tile_affine(cN1, W(C_LN1_G), W(C_LN1_B), S0, tid);                                        // H1
     MAT_SYNC();
-    lin_wgrad(S3, S0, G(C_M1_W), G(C_M1_B), wave, lane, tid);
+    MAT_WGRAD(L_C_M1, S3, S0, true, C_M1_W, C_M1_B);
     pf_dgrad(W(C_P_W), wave, lane, eP);
     lin_dgrad_r<true>(eM1, S3, S4, wave, lane);                                           // d H1 total
     MAT_SYNC();
     tile_ln_bwd(S4, kMHS, kMD, cN1, rstd(2), W(C_LN1_G), S0, G(C_LN1_G), G(C_LN1_B), tid);     // d r1 -> S0
     MAT_SYNC();
-    lin_wgrad(S0, cY, G(C_P_W), G(C_P_B), wave, lane, tid);
+    MAT_WGRAD(L_C_P, S0, cY, true, C_P_W, C_P_B);
     pf_dgrad(W(C_Q_W), wave, lane, eQ); pf_dgrad(W(C_K_W), wave, lane, eK); pf_dgrad(W(C_V_W), wave, lane, eV);
     lin_dgrad_r<false>(eP, S0, S2, wave, lane);                                           // d Y
     MAT_SYNC();
@@ -906,9 +955,9 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     MAT_SYNC();
     tile_affine(cN0, W(C_LN_G), W(C_LN_B), S2, tid);                                          // H0
     MAT_SYNC();
-    lin_wgrad(S1, S2, G(C_Q_W), G(C_Q_B), wave, lane, tid);
-    lin_wgrad(S3, S2, G(C_K_W), G(C_K_B), wave, lane, tid);
-    lin_wgrad(S4, S2, G(C_V_W), G(C_V_B), wave, lane, tid);
+    MAT_WGRAD(L_C_Q, S1, S2, true, C_Q_W, C_Q_B);
+    MAT_WGRAD(L_C_K, S3, S2, false, C_K_W, C_K_B);
+    MAT_WGRAD(L_C_V, S4, S2, false, C_V_W, C_V_B);
     lin_dgrad_r<true>(eQ, S1, S0, wave, lane);
     lin_dgrad_r<true>(eK, S3, S0, wave, lane);
     lin_dgrad_r<true>(eV, S4, S0, wave, lane);                                            // d H0 total
@@ -1037,8 +1086,8 @@ __global__ __launch_bounds__(kMT) void mat_policy_step_kernel(MatStepDev u) {
 // slabs -> gradient bucket in a fixed order (each thread owns a float4 column, 8 slab loads in flight at a
 // time, no LDS staging); the last workgroup folds the loss partials and advances the cursor
 constexpr int kMatRedThreads = 256;
-__global__ __launch_bounds__(kMatRedThreads) void mat_update_reduce_kernel(MatDev u) {
-    if (blockIdx.x == gridDim.x - 1) {
+__device__ __forceinline__ void mat_update_bookkeeping(const MatDev& u) {
+    {
         if (threadIdx.x >= 64) return;
         const int lane = threadIdx.x;
         float p0 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p7 = 0.f;
@@ -1061,8 +1110,10 @@ __global__ __launch_bounds__(kMatRedThreads) void mat_update_reduce_kernel(MatDe
             u.cursor[0] += 1;
             if (u.fuse_norm) u.step_count[0] += 1;
         }
-        return;
     }
+}
+__global__ __launch_bounds__(kMatRedThreads) void mat_update_reduce_kernel(MatDev u) {
+    if (blockIdx.x == gridDim.x - 1) { mat_update_bookkeeping(u); return; }
     __shared__ double red[17];
     const long n4 = u.total >> 2;
     const long idx = (long)blockIdx.x * kMatRedThreads + threadIdx.x;
@@ -1084,6 +1135,109 @@ __global__ __launch_bounds__(kMatRedThreads) void mat_update_reduce_kernel(MatDe
         double q = (double)acc.x * acc.x + (double)acc.y * acc.y + (double)acc.z * acc.z + (double)acc.w * acc.w;
         q = block_sum(q, red);
         if (threadIdx.x == 0) u.norm_scratch[2 + blockIdx.x] = q;      // partials: ppoaf_adam_step_prenormed adds them in a fixed order
+    }
+}
+
+// Split-wgrad chain: what ppoaf_mat_update_reduce launches when args->split_workspace is set.
+//   workgroups [0, 288): one 16 x 16 tile of dW_k = dz_k^T x_k over ALL R rows of the mini-batch (K = R on f32 MFMA, the
+//     four waves take every fourth 16-row chunk and are folded in wave order) for the 18 linears; the tile column 0 jobs
+//     also form db_k = column sums of dz_k.  Jobs are dealt so that the ~2 linears an XCD works on stay in its L2:
+//     workgroup b runs on XCD b % 8 (round-robin dispatch; placement only changes speed) and takes job (b % 8) * 36 + b / 8
+//     of the linear-major job list.
+//   then ceil(n_small4 / 256) workgroups: the compact slabs of the small tensors (LayerNorm gains, narrow layers, heads)
+//     -> gradient bucket, in slab order (as mat_update_reduce_kernel);
+//   last workgroup: loss partials -> totals, cursor, step counter.
+// fuse_norm: one squared-norm partial per workgroup in norm_scratch[2 + b].
+constexpr int kMatWgJobs = kMatLin * 16;
+__global__ __launch_bounds__(256) void mat_update_wgrad_kernel(MatDev u, int n_small_blocks) {
+    __shared__ double s_red[17];
+    __shared__ __attribute__((aligned(16))) float s_fold[3 * 256 + 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (b == kMatWgJobs + n_small_blocks) { mat_update_bookkeeping(u); return; }          // uniform per workgroup
+    double q = 0.0;
+    if (b < kMatWgJobs) {
+        constexpr int per_xcd = kMatWgJobs / 8;
+        const int job = (b & 7) * per_xcd + (b >> 3);
+        const int k = job >> 4, ot = (job >> 2) & 3, it = job & 3;
+        const int wk = kMatLinW[k];
+        const long plane = (long)u.R * kMD;
+        const float* Dp = u.dpanel + (long)k * plane + ot * 16 + (lane & 15);
+        const float* Xp = u.xpanel + (long)kMatLinX[k] * plane + it * 16 + (lane & 15);
+        const int nc = u.nT;                                   // 16-row chunks
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        float bsum = 0.f;
+        constexpr int MAXC = 8;
+        for (int c0 = wave; c0 < nc; c0 += 4 * MAXC) {         // wave-uniform trip count
+            float a[MAXC][4], x[MAXC][4];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int ch = c0 + 4 * c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long row = 16 * (long)ch + 4 * j + (lane >> 4);
+                    const bool ok = ch < nc;
+                    a[c][j] = ok ? Dp[row * kMD] : 0.f;
+                    x[c][j] = ok ? Xp[row * kMD] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                if (c0 + 4 * c < nc) {                         // wave-uniform
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (c & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x[c][j], acc1, 0, 0, 0);
+                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x[c][j], acc0, 0, 0, 0);
+                        bsum += a[c][j];
+                    }
+                }
+            }
+        }
+        f32x4 acc = acc0 + acc1;
+        if (wave > 0) *reinterpret_cast<f32x4*>(s_fold + ((wave - 1) * 64 + lane) * 4) = acc;
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 16) s_fold[768 + wave * 16 + lane] = bsum;
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) acc += *reinterpret_cast<const f32x4*>(s_fold + (w * 64 + lane) * 4);
+            float* GW = u.grads + u.off[wk];
+            const int i = it * 16 + (lane & 15);               // C layout: column = lane & 15, rows 4 (lane >> 4) + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = ot * 16 + 4 * (lane >> 4) + r;
+                GW[o * kMD + i] = acc[r];
+                q += (double)acc[r] * acc[r];
+            }
+            if (it == 0 && lane < 16) {
+                const float bg = s_fold[768 + lane] + s_fold[768 + 16 + lane] + s_fold[768 + 32 + lane] + s_fold[768 + 48 + lane];
+                u.grads[u.off[wk + 1] + ot * 16 + lane] = bg;
+                q += (double)bg * bg;
+            }
+        }
+    } else {
+        const int sidx = (b - kMatWgJobs) * 256 + tid;
+        if (sidx < u.n_small4) {
+            const float4* sl = reinterpret_cast<const float4*>(u.slabs);
+            const long n4 = u.slab_stride >> 2;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g0 = 0; g0 < u.nT; g0 += 16) {
+                float4 v[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk)
+                    v[kk] = (g0 + kk < u.nT) ? sl[(long)(g0 + kk) * n4 + sidx] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) { acc.x += v[kk].x; acc.y += v[kk].y; acc.z += v[kk].z; acc.w += v[kk].w; }
+            }
+            int seg = 0;
+            for (int j = 1; j < u.n_seg; ++j) if (4 * sidx >= u.seg_start[j]) seg = j;
+            *reinterpret_cast<float4*>(u.grads + u.seg_dst[seg] + (4 * sidx - u.seg_start[seg])) = acc;
+            q = (double)acc.x * acc.x + (double)acc.y * acc.y + (double)acc.z * acc.z + (double)acc.w * acc.w;
+        }
+    }
+    if (u.fuse_norm) {                                          // uniform per launch
+        q = block_sum(q, s_red);
+        if (tid == 0) u.norm_scratch[2 + b] = q;
     }
 }
 
@@ -1151,6 +1305,38 @@ static int make_mat(const ppoaf_mat_update_args_t* a, MatDev& u) {
     PPOAF_REQUIRE(!a->fuse_norm || (a->norm_scratch && a->step_count), "mat_update: fuse_norm needs norm_scratch and step_count");
     u.norm_scratch = a->norm_scratch; u.step_count = a->step_count; u.fuse_norm = a->fuse_norm != 0;
     u.pregathered = a->inputs_in_batch_order != 0;
+    // gradient-partial layout of a workgroup's slab; split-wgrad chain: panels + the compact layout of the small tensors
+    u.split = 0; u.R = 16 * u.nT; u.xpanel = nullptr; u.dpanel = nullptr;
+    u.n_small4 = 0; u.n_seg = 0;
+    for (int i = 0; i < 4; ++i) { u.seg_start[i] = 0; u.seg_dst[i] = 0; }
+    u.slab_stride = u.total;
+    for (int i = 0; i < 64; ++i) u.goff[i] = i < MAT_NUM_PARAMS ? (int)u.off[i] : 0;
+    if (a->split_workspace) {
+        PPOAF_REQUIRE((((uintptr_t)a->split_workspace) & 255) == 0, "mat_update: split_workspace must be 256-byte aligned");
+        const size_t plane = (size_t)u.R * kMD * 4;
+        const size_t need = (size_t)(MAT_NUM_XPANELS + kMatLin) * plane;
+        PPOAF_REQUIRE((size_t)a->split_workspace_bytes >= need, "mat_update: split_workspace of %ld B, %zu needed",
+                      (long)a->split_workspace_bytes, need);
+        u.split = 1;
+        u.xpanel = reinterpret_cast<float*>(a->split_workspace);
+        u.dpanel = u.xpanel + (size_t)MAT_NUM_XPANELS * u.R * kMD;
+        bool big[MAT_NUM_PARAMS] = {};
+        for (int k = 0; k < kMatLin; ++k) { big[kMatLinW_host[k]] = true; big[kMatLinW_host[k] + 1] = true; }
+        long compact = 0;
+        bool in_run = false;
+        for (int i = 0; i < MAT_NUM_PARAMS; ++i) {
+            if (big[i]) { u.goff[i] = -1; in_run = false; continue; }
+            if (!in_run) {
+                PPOAF_REQUIRE(u.n_seg < 4, "mat_update: internal segment table");
+                u.seg_start[u.n_seg] = (int)compact; u.seg_dst[u.n_seg] = (int)u.off[i]; ++u.n_seg;
+                in_run = true;
+            }
+            u.goff[i] = (int)compact;
+            compact += (i + 1 < MAT_NUM_PARAMS ? u.off[i + 1] : u.total) - u.off[i];
+        }
+        u.slab_stride = compact;
+        u.n_small4 = (int)(compact >> 2);
+    }
     static const int warm = [] { const char* e = getenv("PPOAF_MAT_L2_WARMUP"); return e && e[0] == '1' ? 1 : 0; }();
     u.l2_warmup = warm;
     return PPOAF_OK;
@@ -1174,15 +1360,23 @@ extern "C" int ppoaf_mat_update_fwd_bwd_timed(const ppoaf_mat_update_args_t* arg
     PPOAF_REQUIRE(lds <= 160 * 1024, "mat_update: needs %zu B of LDS (> 160 KiB)", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mat_update_fwd_bwd_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mat_update_fwd_bwd_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(mat_update_fwd_bwd_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
         attr_set = true;
     }
-    if (e0 || e1)
-        hipExtLaunchKernelGGL(mat_update_fwd_bwd_kernel, dim3((unsigned)u.nT), dim3(kMT), lds, (hipStream_t)stream, e0, e1, 0, u);
-    else
-        hipLaunchKernelGGL(mat_update_fwd_bwd_kernel, dim3((unsigned)u.nT), dim3(kMT), lds, (hipStream_t)stream, u);
+    const dim3 grid((unsigned)u.nT), block(kMT);
+    hipStream_t st = (hipStream_t)stream;
+    if (u.split) {
+        if (e0 || e1) hipExtLaunchKernelGGL(mat_update_fwd_bwd_kernel<true>, grid, block, lds, st, e0, e1, 0, u);
+        else hipLaunchKernelGGL(mat_update_fwd_bwd_kernel<true>, grid, block, lds, st, u);
+    } else {
+        if (e0 || e1) hipExtLaunchKernelGGL(mat_update_fwd_bwd_kernel<false>, grid, block, lds, st, e0, e1, 0, u);
+        else hipLaunchKernelGGL(mat_update_fwd_bwd_kernel<false>, grid, block, lds, st, u);
+    }
     return check_launch("mat_update_fwd_bwd");
 }
 
@@ -1190,10 +1384,33 @@ extern "C" int ppoaf_mat_update_reduce(const ppoaf_mat_update_args_t* args, ppoa
     MatDev u;
     const int rc = make_mat(args, u);
     if (rc) return rc;
+    if (u.split) {
+        const int nsb = (u.n_small4 + 255) / 256;
+        hipLaunchKernelGGL(mat_update_wgrad_kernel, dim3((unsigned)(kMatWgJobs + nsb + 1)), dim3(256), 0, (hipStream_t)stream, u, nsb);
+        return check_launch("mat_update_reduce (wgrad)");
+    }
     const long n4 = u.total >> 2;
     hipLaunchKernelGGL(mat_update_reduce_kernel, dim3((unsigned)((n4 + kMatRedThreads - 1) / kMatRedThreads) + 1u),
                        dim3(kMatRedThreads), 0, (hipStream_t)stream, u);
     return check_launch("mat_update_reduce");
+}
+
+extern "C" int ppoaf_mat_update_split_workspace_bytes(const ppoaf_mat_update_args_t* args, int64_t* bytes_out) {
+    PPOAF_REQUIRE(args && bytes_out, "mat_update_split_workspace_bytes: null argument");
+    ppoaf_mat_update_args_t a = *args;
+    a.split_workspace = nullptr; a.split_workspace_bytes = 0;
+    MatDev u;
+    const int rc = make_mat(&a, u);
+    if (rc) return rc;
+    *bytes_out = (int64_t)((size_t)(MAT_NUM_XPANELS + kMatLin) * u.R * kMD * 4);
+    return PPOAF_OK;
+}
+
+extern "C" int ppoaf_mat_update_norm_partials(const ppoaf_mat_update_args_t* args) {
+    MatDev u;
+    if (make_mat(args, u)) return -1;
+    if (u.split) return kMatWgJobs + (u.n_small4 + 255) / 256;
+    return (int)(((u.total >> 2) + kMatRedThreads - 1) / kMatRedThreads);
 }
 
 extern "C" int ppoaf_mat_policy_step(const ppoaf_mat_step_args_t* a, ppoaf_stream_t stream) {

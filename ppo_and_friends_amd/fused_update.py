@@ -12,6 +12,7 @@ One epoch of PPO._ppo_batch_train (ppo.py:2274-2485) for an MLP actor/critic:
                 host read of the epoch: the KL early stop needs it)
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -1011,6 +1012,15 @@ class FusedMatUpdate(FusedPolicyUpdate):
         self.records = self.adv_records = self.perm = None
         self._graphs, self._args = {}, {}
         self.xchg, self.xchg_reason = (peer_exchange.open_exchange(total, dev) if self.multi else (None, "single rank"))
+        # split-wgrad chain (csrc/mat_update.hip: mat_update_wgrad_kernel): PPOAF_MAT_SPLIT = 1 (default) | 0.  The reduce
+        # entry point keeps its contract (slabs / panels -> gradient bucket), so every path above it -- graphs, K17, the
+        # RCCL loops -- is the same with either form.
+        mode = os.environ.get("PPOAF_MAT_SPLIT", "1")
+        if mode not in ("0", "1"):
+            raise ValueError(f"PPOAF_MAT_SPLIT={mode!r}: expected 0 or 1")
+        self.split = mode == "1"
+        self._split_space = None
+        self._norm_partials = {}
 
     def _make_args(self, B):
         pol, ppo, buf = self.pol, self.ppo, self.pol.buffer
@@ -1042,13 +1052,29 @@ class FusedMatUpdate(FusedPolicyUpdate):
         # the reduce launch also advances the step count and yields the local ||g||^2 (replaced by K17's norm of the
         # summed gradient when ranks exchange); only the RCCL path runs the separate K11 norm pass
         a.fuse_norm = int(not self.multi or self.xchg is not None)
+        a.split_workspace, a.split_workspace_bytes = None, 0
+        if self.split:
+            if self._split_space is None:                # sized once, for the full batch size (a tail mini-batch needs less)
+                need = C.c_int64(0)
+                _lib.check(self._lib.ppoaf_mat_update_split_workspace_bytes(C.byref(a), C.byref(need)), "mat_update_split_workspace_bytes")
+                self._split_space = torch.zeros(int(need.value), dtype=torch.uint8, device=pol.device)
+            a.split_workspace, a.split_workspace_bytes = self._split_space.data_ptr(), self._split_space.numel()
+        n = int(self._lib.ppoaf_mat_update_norm_partials(C.byref(a)))
+        if n < 0:
+            _lib.check(n, "mat_update_norm_partials")
+        self._norm_partials[B] = n
+        if opt.norm_scratch.numel() < 2 + n:             # one squared-norm partial per workgroup of the reduce launch
+            opt.norm_scratch = torch.zeros(2 + n, dtype=torch.float64, device=pol.device)
+            a.norm_scratch = opt.norm_scratch.data_ptr()
         return a
 
     @property
     def norm_partials(self):
         """How ppoaf_adam_step_prenormed finds ||g||^2: the reduce launch's per-workgroup partials (single rank), or
         norm_scratch[0] as K17's exchange left it (0)."""
-        return 0 if self.xchg is not None else (self.topo["bucket_total"] // 4 + 255) // 256
+        if self.xchg is not None:
+            return 0
+        return self._norm_partials.get(self.B) or (self.topo["bucket_total"] // 4 + 255) // 256
 
     def _eager_multi_rank(self, args, n):
         """The RCCL fallback (no K17 exchange): fwd_bwd -> reduce -> all-reduce -> K11 clip + Adam per mini-batch, issued from

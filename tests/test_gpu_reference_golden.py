@@ -15,6 +15,7 @@ Both update paths (fused K12 / K14 kernels; torch-ROCm modules + K2..K11) are ch
 """
 import ctypes as C
 
+import os
 import numpy as np
 import pytest
 import torch
@@ -277,15 +278,19 @@ def test_product_reproduces_the_reference_ppo_iterations(golden, name, update_mo
     np.testing.assert_allclose([float(rs.mean_t), float(rs.var_t), float(rs.count_t)], g["value_stats"], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("update_mode", ["fused", "torch"])
+@pytest.mark.parametrize("update_mode", ["fused", "fused_slabs", "torch"])
 @pytest.mark.parametrize("name", ["g12_c5_mat", "g12_c5_b256"])
-def test_product_reproduces_the_reference_mat_iterations(golden, name, update_mode):
+def test_product_reproduces_the_reference_mat_iterations(golden, name, update_mode, monkeypatch):
     """
     C5 shapes: the reference's own PPO object with MATPolicy (3 agents, O=18, Discrete(5), embedding 64, 1 block, 1 head;
     fixtures g12_c5_mat: 16-env mini-batches = 4 K15 tiles; g12_c5_b256: batch_size 256 = 52 tiles).  Autoregressive
     rollout (K16 / torch path) with the recorded actions replayed, shared-episode dataset incl. quirk Q14, first
     mini-batch (K15 launch): losses + the full gradient bucket before any optimiser step, epochs, final weights.
+    `fused` = the split-wgrad chain (the default), `fused_slabs` = weight-gradient slabs + slab reduce (PPOAF_MAT_SPLIT=0).
     """
+    if update_mode == "fused_slabs":
+        monkeypatch.setenv("PPOAF_MAT_SPLIT", "0")
+        update_mode = "fused"
     from ppo_and_friends_amd import _lib
     from ppo_and_friends_amd import kernels as K
     from ppo_and_friends_amd.ppo import PPO
@@ -309,6 +314,8 @@ def test_product_reproduces_the_reference_mat_iterations(golden, name, update_mo
               epochs_per_iter=c["epochs"], max_ts_per_ep=c["max_ts_per_ep"], update_mode=update_mode, save_state=False)
     pol = ppo.policies["agent"]
     assert (ppo._fused_updater("agent", B) is not None) == (update_mode == "fused")
+    if update_mode == "fused":
+        assert ppo._fused_updater("agent", B).split == (os.environ.get("PPOAF_MAT_SPLIT", "1") == "1")
     sd0 = {"actor." + k[len("init_actor."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init_actor.")}
     sd0.update({"critic." + k[len("init_critic."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init_critic.")})
     missing, unexpected = pol.actor_critic.load_state_dict(sd0, strict=False)
