@@ -500,13 +500,21 @@ enum { cZ1_ = 0, cN0_, cQ_, cK_, cV_, cY_, cN1_, cZM_, cN2_, cENC_, cZH_, cNH_,
     auto W = [&](int k) -> const float* { return c.W(k); };                                                       \
     auto rstd = [&](int k) -> float* { return c.rstd(k); }
 
+// split-wgrad chain: the forward publishes every linear's input tile the moment it is settled (the backward then has
+// no reason to rebuild it from the saved normalised activations); K16 and the slab form publish nothing
+struct MatNoPub { __device__ __forceinline__ void operator()(int, const float*) const {} };
+struct MatPanelPub {
+    float* xpanel; long plane; int g, tid;
+    __device__ __forceinline__ void operator()(int xid, const float* T) const { publish_tile(T, xpanel + (long)xid * plane, g, tid); }
+};
+
 // critic (encoder): observations in sYO -> rep_enc in cENC, value in sOutC[:, 0]; ends WITHOUT a barrier
 // PF (K15): the fragments of linear `n` are requested one phase ahead -- MAT_NEXT(n) at the start of the phase before;
 // else (K16: its registers are spoken for) at the point of use
 #define MAT_LIN(r, Wk, Bk, A, out) do { if (!PF) pf_fwd(W(Wk), W(Bk), wave, lane, r); lin_fwd_r(r, A, out, wave, lane); } while (0)
 #define MAT_NEXT(r, Wk, Bk) do { if (PF) pf_fwd(W(Wk), W(Bk), wave, lane, r); } while (0)
-template <bool PF>
-__device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, int wave, int lane) {
+template <bool PF, typename Pub = MatNoPub>
+__device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, int wave, int lane, const Pub pub = Pub()) {
     MAT_TILES(c);
     MatFr rq, rk, rv, rp, rm1, rm2, rh1;
     MAT_NEXT(rq, C_Q_W, C_Q_B); MAT_NEXT(rk, C_K_W, C_K_B); MAT_NEXT(rv, C_V_W, C_V_B);       // two phases ahead of their use
@@ -520,6 +528,7 @@ __device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, in
     tile_ln_fwd(S0, kMHS, kMD, W(C_LN_G), W(C_LN_B), cN0, rstd(1), S1, tid);                  // critic.ln -> H0 in S1
     MAT_SYNC();
     MAT_STAMP(18);
+    pub(X_H0, S1);
     MAT_NEXT(rp, C_P_W, C_P_B);
     MAT_LIN(rq, C_Q_W, C_Q_B, S1, cQ);
     MAT_LIN(rk, C_K_W, C_K_B, S1, cK);
@@ -529,6 +538,7 @@ __device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, in
     att_fwd(cQ, cK, cV, cY, sP0, L, n_rows, false, wave, lane);
     MAT_SYNC();
     MAT_STAMP(20);
+    pub(X_CY, cY);
     MAT_NEXT(rm1, C_M1_W, C_M1_B);
     MAT_LIN(rp, C_P_W, C_P_B, cY, S2);
     MAT_SYNC();
@@ -537,6 +547,7 @@ __device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, in
     tile_ln_fwd(S2, kMHS, kMD, W(C_LN1_G), W(C_LN1_B), cN1, rstd(2), S0, tid);                // H1 in S0
     MAT_SYNC();
     MAT_STAMP(22);
+    pub(X_H1, S0);
     MAT_NEXT(rm2, C_M2_W, C_M2_B);
     MAT_LIN(rm1, C_M1_W, C_M1_B, S0, cZM);
     MAT_SYNC();
@@ -544,6 +555,7 @@ __device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, in
     tile_gelu(cZM, S2, tid);
     MAT_SYNC();
     MAT_STAMP(24);
+    pub(X_GCM, S2);
     MAT_NEXT(rh1, C_H1_W, C_H1_B);
     MAT_LIN(rm2, C_M2_W, C_M2_B, S2, S3);
     MAT_SYNC();
@@ -552,6 +564,7 @@ __device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, in
     tile_ln_fwd(S3, kMHS, kMD, W(C_LN2_G), W(C_LN2_B), cN2, rstd(3), cENC, tid);              // rep_enc
     MAT_SYNC();
     MAT_STAMP(26);
+    pub(X_ENC, cENC);
     MAT_LIN(rh1, C_H1_W, C_H1_B, cENC, cZH);
     MAT_SYNC();
     MAT_STAMP(27);
@@ -564,8 +577,8 @@ __device__ __forceinline__ void mat_encoder_forward(const MatCtx& c, int tid, in
 }
 
 // actor (decoder): token block in sXA + rep_enc in cENC -> logits in sOutA; starts and ends with the tiles settled
-template <bool PF>
-__device__ __forceinline__ void mat_decoder_forward(const MatCtx& c, int tid, int wave, int lane) {
+template <bool PF, typename Pub = MatNoPub>
+__device__ __forceinline__ void mat_decoder_forward(const MatCtx& c, int tid, int wave, int lane, const Pub pub = Pub()) {
     MAT_TILES(c);
     MatFr rk1, rq1, rv1, rp1, rk2, rv2, rq2, rp2, rm1, rm2, rh1;
     MAT_NEXT(rk1, A_K1_W, A_K1_B); MAT_NEXT(rq1, A_Q1_W, A_Q1_B); MAT_NEXT(rv1, A_V1_W, A_V1_B);
@@ -574,6 +587,7 @@ __device__ __forceinline__ void mat_decoder_forward(const MatCtx& c, int tid, in
     tile_gelu(aZ, S0, tid);
     tile_ln_fwd(S0, kMHS, kMD, W(A_LN_G), W(A_LN_B), aN0, rstd(5), S1, tid);                  // x0 in S1
     MAT_SYNC();
+    pub(X_X0, S1);
     MAT_NEXT(rp1, A_P1_W, A_P1_B);
     MAT_LIN(rk1, A_K1_W, A_K1_B, S1, aK1);
     MAT_LIN(rq1, A_Q1_W, A_Q1_B, S1, aQ1);
@@ -581,12 +595,14 @@ __device__ __forceinline__ void mat_decoder_forward(const MatCtx& c, int tid, in
     MAT_SYNC();
     att_fwd(aQ1, aK1, aV1, aY1, sP1, L, n_rows, true, wave, lane);
     MAT_SYNC();
+    pub(X_AY1, aY1);
     MAT_NEXT(rk2, A_K2_W, A_K2_B); MAT_NEXT(rv2, A_V2_W, A_V2_B); MAT_NEXT(rq2, A_Q2_W, A_Q2_B);
     MAT_LIN(rp1, A_P1_W, A_P1_B, aY1, S2);
     MAT_SYNC();
     tile_add(S1, S2, S2, tid);
     tile_ln_fwd(S2, kMHS, kMD, W(A_LN1_G), W(A_LN1_B), aN1, rstd(6), S0, tid);                // x1 in S0
     MAT_SYNC();
+    pub(X_X1, S0);
     MAT_NEXT(rp2, A_P2_W, A_P2_B);
     MAT_LIN(rk2, A_K2_W, A_K2_B, S0, aK2);                                       // key = value = x1
     MAT_LIN(rv2, A_V2_W, A_V2_B, S0, aV2);
@@ -594,23 +610,27 @@ __device__ __forceinline__ void mat_decoder_forward(const MatCtx& c, int tid, in
     MAT_SYNC();
     att_fwd(aQ2, aK2, aV2, aY2, sP2, L, n_rows, true, wave, lane);
     MAT_SYNC();
+    pub(X_AY2, aY2);
     MAT_NEXT(rm1, A_M1_W, A_M1_B);
     MAT_LIN(rp2, A_P2_W, A_P2_B, aY2, S2);
     MAT_SYNC();
     tile_add(cENC, S2, S2, tid);
     tile_ln_fwd(S2, kMHS, kMD, W(A_LN2_G), W(A_LN2_B), aN2, rstd(7), S1, tid);                // x2 in S1
     MAT_SYNC();
+    pub(X_X2, S1);
     MAT_NEXT(rm2, A_M2_W, A_M2_B);
     MAT_LIN(rm1, A_M1_W, A_M1_B, S1, aZM);
     MAT_SYNC();
     tile_gelu(aZM, S2, tid);
     MAT_SYNC();
+    pub(X_GAM, S2);
     MAT_NEXT(rh1, A_H1_W, A_H1_B);
     MAT_LIN(rm2, A_M2_W, A_M2_B, S2, S3);
     MAT_SYNC();
     tile_add(S1, S3, S3, tid);
     tile_ln_fwd(S3, kMHS, kMD, W(A_LN3_G), W(A_LN3_B), aN3, rstd(8), S0, tid);                // x3 in S0
     MAT_SYNC();
+    pub(X_X3, S0);
     MAT_LIN(rh1, A_H1_W, A_H1_B, S0, aZH);
     MAT_SYNC();
     tile_gelu(aZH, S2, tid);
@@ -624,19 +644,14 @@ __device__ __forceinline__ void mat_decoder_forward(const MatCtx& c, int tid, in
 
 // SPLIT: the weight gradients of the 18 64x64 linears are NOT formed here (a third of the kernel's MFMA work, on the
 // one CU that owns the tile: ablation 72 -> 59 us); the D and input tiles each of them needs go to the panels instead.
-#define MAT_WGRAD(lin, D, In, pub_x, Wk, Bk)                                                        \
+// (the inputs were published by the forward pass: MatPanelPub)
+#define MAT_WGRAD(lin, D, In, Wk, Bk)                                                               \
     do {                                                                                            \
-        if constexpr (SPLIT) {                                                                      \
-            publish_tile(D, u.dpanel + (long)(lin) * u.R * kMD, g, tid);                            \
-            if (pub_x) publish_tile(In, u.xpanel + (long)kMatLinX_of(lin) * u.R * kMD, g, tid);     \
-        } else {                                                                                    \
-            lin_wgrad(D, In, G(Wk), G(Bk), wave, lane, tid);                                        \
-        }                                                                                           \
+        if constexpr (SPLIT) publish_tile(D, u.dpanel + (long)(lin) * u.R * kMD, g, tid);           \
+        else lin_wgrad(D, In, G(Wk), G(Bk), wave, lane, tid);                                       \
     } while (0)
-__device__ __forceinline__ constexpr int kMatLinX_of(int lin) {
-    constexpr int t[kMatLin] = PPOAF_MAT_LIN_X;
-    return t[lin];
-}
+// slab form only: an input tile rebuilt for a weight gradient (and the barrier that settles it)
+#define MAT_SLAB_ONLY(stmt) do { if constexpr (!SPLIT) { stmt; } } while (0)
 template <bool SPLIT>
 __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -752,9 +767,16 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     MAT_SYNC();
     MAT_STAMP(2);
 
-    mat_encoder_forward<true>(c, tid, wave, lane);
-    MAT_STAMP(3);
-    mat_decoder_forward<true>(c, tid, wave, lane);
+    if constexpr (SPLIT) {
+        const MatPanelPub pub{u.xpanel, (long)u.R * kMD, g, tid};
+        mat_encoder_forward<true>(c, tid, wave, lane, pub);
+        MAT_STAMP(3);
+        mat_decoder_forward<true>(c, tid, wave, lane, pub);
+    } else {
+        mat_encoder_forward<true>(c, tid, wave, lane);
+        MAT_STAMP(3);
+        mat_decoder_forward<true>(c, tid, wave, lane);
+    }
     MAT_STAMP(4);
     // input-gradient (dgrad) fragment sets of the backward: each requested at the start of the phase before its use
     MatFr dH1, dM2, dM1, dP2, dQ2, dK2, dV2, dP1, dQ1, dK1, dV1;
@@ -853,29 +875,29 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     MAT_SYNC();
     tile_ln_bwd(S2, kMHS, kMD, aNH, rstd(9), W(A_HLN_G), S3, G(A_HLN_G), G(A_HLN_B), tid);     // -> d gelu out in S3
     tile_gelu_bwd(S3, aZH, tid);                                                              // d aZH
-    tile_affine(aN3, W(A_LN3_G), W(A_LN3_B), S0, tid);                                        // x3
+    MAT_SLAB_ONLY(tile_affine(aN3, W(A_LN3_G), W(A_LN3_B), S0, tid));                         // x3
     MAT_SYNC();
-    MAT_WGRAD(L_A_H1, S3, S0, true, A_H1_W, A_H1_B);
+    MAT_WGRAD(L_A_H1, S3, S0, A_H1_W, A_H1_B);
     pf_dgrad(W(A_M2_W), wave, lane, dM2);
     lin_dgrad_r<false>(dH1, S3, S2, wave, lane);                                          // d x3 -> S2
     MAT_SYNC();
     tile_ln_bwd(S2, kMHS, kMD, aN3, rstd(8), W(A_LN3_G), S4, G(A_LN3_G), G(A_LN3_B), tid);     // d r3 -> S4 (= d x2 residual = d mlp out)
-    tile_gelu(aZM, S0, tid);                                                                  // mlp hidden activation
+    MAT_SLAB_ONLY(tile_gelu(aZM, S0, tid));                                                   // mlp hidden activation
     MAT_SYNC();
-    MAT_WGRAD(L_A_M2, S4, S0, true, A_M2_W, A_M2_B);
+    MAT_WGRAD(L_A_M2, S4, S0, A_M2_W, A_M2_B);
     pf_dgrad(W(A_M1_W), wave, lane, dM1);
     lin_dgrad_r<false>(dM2, S4, S3, wave, lane);
     MAT_SYNC();
     tile_gelu_bwd(S3, aZM, tid);                                                              // d aZM
-    tile_affine(aN2, W(A_LN2_G), W(A_LN2_B), S0, tid);                                        // x2
+    MAT_SLAB_ONLY(tile_affine(aN2, W(A_LN2_G), W(A_LN2_B), S0, tid));                         // x2
     MAT_SYNC();
-    MAT_WGRAD(L_A_M1, S3, S0, true, A_M1_W, A_M1_B);
+    MAT_WGRAD(L_A_M1, S3, S0, A_M1_W, A_M1_B);
     pf_dgrad(W(A_P2_W), wave, lane, dP2);
     lin_dgrad_r<true>(dM1, S3, S4, wave, lane);                                           // d x2 total in S4
     MAT_SYNC();
     tile_ln_bwd(S4, kMHS, kMD, aN2, rstd(7), W(A_LN2_G), DENC, G(A_LN2_G), G(A_LN2_B), tid);   // d r2 -> DENC (rep_enc share) = d proj2 out
     MAT_SYNC();
-    MAT_WGRAD(L_A_P2, DENC, aY2, true, A_P2_W, A_P2_B);
+    MAT_WGRAD(L_A_P2, DENC, aY2, A_P2_W, A_P2_B);
     pf_dgrad(W(A_Q2_W), wave, lane, dQ2); pf_dgrad(W(A_K2_W), wave, lane, dK2); pf_dgrad(W(A_V2_W), wave, lane, dV2);
     lin_dgrad_r<false>(dP2, DENC, S2, wave, lane);                                        // d Y2 -> S2
     MAT_SYNC();
@@ -884,30 +906,28 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     MAT_SYNC();
     MAT_STAMP(7);
     MatFr eH1, eM2, eM1, eP, eQ, eK, eV;
-    MAT_WGRAD(L_A_Q2, S0, cENC, true, A_Q2_W, A_Q2_B);
+    MAT_WGRAD(L_A_Q2, S0, cENC, A_Q2_W, A_Q2_B);
     lin_dgrad_r<true>(dQ2, S0, DENC, wave, lane);                                         // rep_enc gradient from the query path
-    tile_affine(aN1, W(A_LN1_G), W(A_LN1_B), S1, tid);                                        // x1
-    MAT_SYNC();
-    MAT_WGRAD(L_A_K2, S3, S1, true, A_K2_W, A_K2_B);
-    MAT_WGRAD(L_A_V2, S4, S1, false, A_V2_W, A_V2_B);
+    MAT_SLAB_ONLY(tile_affine(aN1, W(A_LN1_G), W(A_LN1_B), S1, tid); MAT_SYNC());             // x1
+    MAT_WGRAD(L_A_K2, S3, S1, A_K2_W, A_K2_B);
+    MAT_WGRAD(L_A_V2, S4, S1, A_V2_W, A_V2_B);
     pf_dgrad(W(A_P1_W), wave, lane, dP1);
     lin_dgrad_r<false>(dK2, S3, S2, wave, lane);
-    MAT_SYNC();
+    MAT_SLAB_ONLY(MAT_SYNC());                       // (a thread accumulates into its own elements: no barrier needed)
     lin_dgrad_r<true>(dV2, S4, S2, wave, lane);                                           // d x1 -> S2
     MAT_SYNC();
     tile_ln_bwd(S2, kMHS, kMD, aN1, rstd(6), W(A_LN1_G), S0, G(A_LN1_G), G(A_LN1_B), tid);     // d r1 -> S0 (= d x0 residual = d proj1 out)
     MAT_SYNC();
-    MAT_WGRAD(L_A_P1, S0, aY1, true, A_P1_W, A_P1_B);
+    MAT_WGRAD(L_A_P1, S0, aY1, A_P1_W, A_P1_B);
     pf_dgrad(W(A_Q1_W), wave, lane, dQ1); pf_dgrad(W(A_K1_W), wave, lane, dK1); pf_dgrad(W(A_V1_W), wave, lane, dV1);
     lin_dgrad_r<false>(dP1, S0, S2, wave, lane);                                          // d Y1 -> S2
     MAT_SYNC();
     att_bwd(aQ1, aK1, aV1, sP1, S2, S1, S3, S4, sS, wave, lane);                              // dQ1 -> S1, dK1 -> S3, dV1 -> S4
     MAT_SYNC();                                                                               // dY (S2) fully consumed
-    tile_affine(aN0, W(A_LN_G), W(A_LN_B), S2, tid);                                          // x0
-    MAT_SYNC();
-    MAT_WGRAD(L_A_Q1, S1, S2, true, A_Q1_W, A_Q1_B);
-    MAT_WGRAD(L_A_K1, S3, S2, false, A_K1_W, A_K1_B);
-    MAT_WGRAD(L_A_V1, S4, S2, false, A_V1_W, A_V1_B);
+    MAT_SLAB_ONLY(tile_affine(aN0, W(A_LN_G), W(A_LN_B), S2, tid); MAT_SYNC());               // x0
+    MAT_WGRAD(L_A_Q1, S1, S2, A_Q1_W, A_Q1_B);
+    MAT_WGRAD(L_A_K1, S3, S2, A_K1_W, A_K1_B);
+    MAT_WGRAD(L_A_V1, S4, S2, A_V1_W, A_V1_B);
     pf_dgrad(W(C_H1_W), wave, lane, eH1);
     lin_dgrad_r<true>(dQ1, S1, S0, wave, lane);
     lin_dgrad_r<true>(dK1, S3, S0, wave, lane);
@@ -927,37 +947,36 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     tile_ln_bwd(S2, kMHS, kMD, cNH, rstd(4), W(C_HLN_G), S3, G(C_HLN_G), G(C_HLN_B), tid);
     tile_gelu_bwd(S3, cZH, tid);
     MAT_SYNC();
-    MAT_WGRAD(L_C_H1, S3, cENC, false, C_H1_W, C_H1_B);
+    MAT_WGRAD(L_C_H1, S3, cENC, C_H1_W, C_H1_B);
     pf_dgrad(W(C_M2_W), wave, lane, eM2);
     lin_dgrad_r<true>(eH1, S3, DENC, wave, lane);                                         // total d rep_enc
     MAT_SYNC();
     tile_ln_bwd(DENC, kMHS, kMD, cN2, rstd(3), W(C_LN2_G), S4, G(C_LN2_G), G(C_LN2_B), tid);   // d r2 -> S4
-    tile_gelu(cZM, S0, tid);
+    MAT_SLAB_ONLY(tile_gelu(cZM, S0, tid));
     MAT_SYNC();
-    MAT_WGRAD(L_C_M2, S4, S0, true, C_M2_W, C_M2_B);
+    MAT_WGRAD(L_C_M2, S4, S0, C_M2_W, C_M2_B);
     pf_dgrad(W(C_M1_W), wave, lane, eM1);
     lin_dgrad_r<false>(eM2, S4, S3, wave, lane);
     MAT_SYNC();
     tile_gelu_bwd(S3, cZM, tid);
-    tile_affine(cN1, W(C_LN1_G), W(C_LN1_B), S0, tid);                                        // H1
+    MAT_SLAB_ONLY(tile_affine(cN1, W(C_LN1_G), W(C_LN1_B), S0, tid));                         // H1
     MAT_SYNC();
-    MAT_WGRAD(L_C_M1, S3, S0, true, C_M1_W, C_M1_B);
+    MAT_WGRAD(L_C_M1, S3, S0, C_M1_W, C_M1_B);
     pf_dgrad(W(C_P_W), wave, lane, eP);
     lin_dgrad_r<true>(eM1, S3, S4, wave, lane);                                           // d H1 total
     MAT_SYNC();
     tile_ln_bwd(S4, kMHS, kMD, cN1, rstd(2), W(C_LN1_G), S0, G(C_LN1_G), G(C_LN1_B), tid);     // d r1 -> S0
     MAT_SYNC();
-    MAT_WGRAD(L_C_P, S0, cY, true, C_P_W, C_P_B);
+    MAT_WGRAD(L_C_P, S0, cY, C_P_W, C_P_B);
     pf_dgrad(W(C_Q_W), wave, lane, eQ); pf_dgrad(W(C_K_W), wave, lane, eK); pf_dgrad(W(C_V_W), wave, lane, eV);
     lin_dgrad_r<false>(eP, S0, S2, wave, lane);                                           // d Y
     MAT_SYNC();
     att_bwd(cQ, cK, cV, sP0, S2, S1, S3, S4, sS, wave, lane);                                 // dQ -> S1, dK -> S3, dV -> S4
     MAT_SYNC();
-    tile_affine(cN0, W(C_LN_G), W(C_LN_B), S2, tid);                                          // H0
-    MAT_SYNC();
-    MAT_WGRAD(L_C_Q, S1, S2, true, C_Q_W, C_Q_B);
-    MAT_WGRAD(L_C_K, S3, S2, false, C_K_W, C_K_B);
-    MAT_WGRAD(L_C_V, S4, S2, false, C_V_W, C_V_B);
+    MAT_SLAB_ONLY(tile_affine(cN0, W(C_LN_G), W(C_LN_B), S2, tid); MAT_SYNC());               // H0
+    MAT_WGRAD(L_C_Q, S1, S2, C_Q_W, C_Q_B);
+    MAT_WGRAD(L_C_K, S3, S2, C_K_W, C_K_B);
+    MAT_WGRAD(L_C_V, S4, S2, C_V_W, C_V_B);
     lin_dgrad_r<true>(eQ, S1, S0, wave, lane);
     lin_dgrad_r<true>(eK, S3, S0, wave, lane);
     lin_dgrad_r<true>(eV, S4, S0, wave, lane);                                            // d H0 total
