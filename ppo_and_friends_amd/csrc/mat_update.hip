@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(kMatRedThreads) void mat_update_reduce_kernel(MatDe
 //     also form db_k = column sums of dz_k.  Jobs are dealt so that the ~2 linears an XCD works on stay in its L2:
 //     workgroup b runs on XCD b % 8 (round-robin dispatch; placement only changes speed) and takes job (b % 8) * 36 + b / 8
 //     of the linear-major job list.
-//   then ceil(n_small4 / 256) workgroups: the compact slabs of the small tensors (LayerNorm gains, narrow layers, heads)
+//   then ceil(4 n_small4 / 256) workgroups: the compact slabs of the small tensors (LayerNorm gains, narrow layers, heads)
 //     -> gradient bucket, in slab order (as mat_update_reduce_kernel);
 //   last workgroup: loss partials -> totals, cursor, step counter.
 // fuse_norm: one squared-norm partial per workgroup in norm_scratch[2 + b].
@@ -1185,7 +1185,9 @@ __global__ __launch_bounds__(256) void mat_update_wgrad_kernel(MatDev u, int n_s
         const int nc = u.nT;                                   // 16-row chunks
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         float bsum = 0.f;
-        constexpr int MAXC = 8;
+        // every operand of the job is requested before the first MFMA (the panels were written by other XCDs a moment
+        // ago: each batch is one cold round trip, so there must be one batch at the BASELINE sizes: 52 chunks / 4 waves)
+        constexpr int MAXC = 16;
         for (int c0 = wave; c0 < nc; c0 += 4 * MAXC) {         // wave-uniform trip count
             float a[MAXC][4], x[MAXC][4];
 #pragma unroll
@@ -1235,23 +1237,24 @@ __global__ __launch_bounds__(256) void mat_update_wgrad_kernel(MatDev u, int n_s
             }
         }
     } else {
+        // one float per thread, every slab's value requested before the first add (one cold round trip for nT <= 64;
+        // float4 columns would need 256 registers for that and halve the job workgroups' occupancy)
         const int sidx = (b - kMatWgJobs) * 256 + tid;
-        if (sidx < u.n_small4) {
-            const float4* sl = reinterpret_cast<const float4*>(u.slabs);
-            const long n4 = u.slab_stride >> 2;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int g0 = 0; g0 < u.nT; g0 += 16) {
-                float4 v[16];
+        if (sidx < 4 * u.n_small4) {
+            const long stride = u.slab_stride;
+            float acc = 0.f;
+            constexpr int SB = 64;
+            for (int g0 = 0; g0 < u.nT; g0 += SB) {
+                float v[SB];
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk)
-                    v[kk] = (g0 + kk < u.nT) ? sl[(long)(g0 + kk) * n4 + sidx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int kk = 0; kk < SB; ++kk) v[kk] = (g0 + kk < u.nT) ? u.slabs[(long)(g0 + kk) * stride + sidx] : 0.f;
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) { acc.x += v[kk].x; acc.y += v[kk].y; acc.z += v[kk].z; acc.w += v[kk].w; }
+                for (int kk = 0; kk < SB; ++kk) acc += v[kk];
             }
             int seg = 0;
-            for (int j = 1; j < u.n_seg; ++j) if (4 * sidx >= u.seg_start[j]) seg = j;
-            *reinterpret_cast<float4*>(u.grads + u.seg_dst[seg] + (4 * sidx - u.seg_start[seg])) = acc;
-            q = (double)acc.x * acc.x + (double)acc.y * acc.y + (double)acc.z * acc.z + (double)acc.w * acc.w;
+            for (int j = 1; j < u.n_seg; ++j) if (sidx >= u.seg_start[j]) seg = j;
+            u.grads[u.seg_dst[seg] + (sidx - u.seg_start[seg])] = acc;
+            q = (double)acc * acc;
         }
     }
     if (u.fuse_norm) {                                          // uniform per launch
@@ -1404,7 +1407,7 @@ extern "C" int ppoaf_mat_update_reduce(const ppoaf_mat_update_args_t* args, ppoa
     const int rc = make_mat(args, u);
     if (rc) return rc;
     if (u.split) {
-        const int nsb = (u.n_small4 + 255) / 256;
+        const int nsb = (4 * u.n_small4 + 255) / 256;
         hipLaunchKernelGGL(mat_update_wgrad_kernel, dim3((unsigned)(kMatWgJobs + nsb + 1)), dim3(256), 0, (hipStream_t)stream, u, nsb);
         return check_launch("mat_update_reduce (wgrad)");
     }
@@ -1428,7 +1431,7 @@ extern "C" int ppoaf_mat_update_split_workspace_bytes(const ppoaf_mat_update_arg
 extern "C" int ppoaf_mat_update_norm_partials(const ppoaf_mat_update_args_t* args) {
     MatDev u;
     if (make_mat(args, u)) return -1;
-    if (u.split) return kMatWgJobs + (u.n_small4 + 255) / 256;
+    if (u.split) return kMatWgJobs + (4 * u.n_small4 + 255) / 256;
     return (int)(((u.total >> 2) + kMatRedThreads - 1) / kMatRedThreads);
 }
 
