@@ -693,6 +693,10 @@ typedef struct {
      * (float32-rounding-level differences from the slab form, bitwise reproducible).  With fuse_norm the launch leaves
      * ppoaf_mat_update_norm_partials(args) partials in norm_scratch[2 ..]. */
     void* split_workspace; int64_t split_workspace_bytes;
+    /* mini-batch index = *cursor + mb_offset; the reduce launch adds cursor_advance to *cursor (as K12: eager use (0, 1);
+     * a captured chain of n mini-batches bakes mb_offset = 0..n-1 into its nodes and advances the cursor once, by n, in
+     * the last one, so all but the first read of the cursor word hit the reader's L2) */
+    int64_t mb_offset, cursor_advance;
 } ppoaf_mat_update_args_t;
 
 int ppoaf_mat_update_fwd_bwd(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream);

@@ -115,7 +115,8 @@ class MatUpdateArgs(C.Structure):
                 ("loss_partials", C.c_void_p), ("totals", C.c_void_p),
                 ("norm_scratch", C.c_void_p), ("step_count", C.c_void_p), ("fuse_norm", C.c_int32),
                 ("inputs_in_batch_order", C.c_int32),
-                ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64)]
+                ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64),
+                ("mb_offset", C.c_int64), ("cursor_advance", C.c_int64)]
 
 
 class MatStepArgs(C.Structure):

@@ -48,7 +48,7 @@ struct MatDev {
     const float* params; float* grads; float* slabs;
     const float* obs; const int64_t* actions; const float* adv; const float* old_lp; const float* rtg; float* values;
     const int64_t* perm; const int32_t* row_map; long n_rows;
-    int64_t* cursor; long B, batch_stride;
+    int64_t* cursor; long B, batch_stride, mb_offset, cursor_advance;
     int normalize_values, n_ranks, normalize_adv, use_huber;
     float* vn_mean; float* vn_var; double* vn_count; const double* vn_records; const double* adv_records;
     float surr_clip, entropy_weight, kl_loss_weight, huber_delta;
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     const int NT0 = (u.O + 15) >> 4;
     const float* P = u.params;
     float* slab = u.slabs + (long)g * u.slab_stride;
-    const long mb = u.cursor[0];
+    const long mb = u.cursor[0] + u.mb_offset;
     const long seq0 = (long)g * u.per_tile;
     const long rem = u.B - seq0;
     const int n_seq = (int)(rem < u.per_tile ? (rem < 0 ? 0 : rem) : u.per_tile);
@@ -1126,7 +1126,7 @@ __device__ __forceinline__ void mat_update_bookkeeping(const MatDev& u) {
             u.totals[5] += (double)u.loss_partials[5]; u.totals[6] += (double)u.loss_partials[6];
             u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
             u.totals[8] += 1.0;
-            u.cursor[0] += 1;
+            if (u.cursor_advance) u.cursor[0] += u.cursor_advance;
             if (u.fuse_norm) u.step_count[0] += 1;
         }
     }
@@ -1319,6 +1319,8 @@ static int make_mat(const ppoaf_mat_update_args_t* a, MatDev& u) {
     u.obs = a->critic_obs; u.actions = a->raw_actions; u.adv = a->advantages; u.old_lp = a->old_log_probs;
     u.rtg = a->rewards_to_go; u.values = a->values; u.perm = a->perm; u.row_map = a->row_map; u.n_rows = a->n_rows;
     u.cursor = a->cursor; u.B = a->B; u.batch_stride = a->batch_stride;
+    PPOAF_REQUIRE(a->mb_offset >= 0 && a->cursor_advance >= 0, "mat_update: mb_offset=%ld cursor_advance=%ld", (long)a->mb_offset, (long)a->cursor_advance);
+    u.mb_offset = a->mb_offset; u.cursor_advance = a->cursor_advance;
     u.normalize_values = a->normalize_values; u.n_ranks = a->n_ranks; u.normalize_adv = a->normalize_adv;
     u.use_huber = a->use_huber; u.vn_mean = a->vn_mean; u.vn_var = a->vn_var; u.vn_count = a->vn_count;
     u.vn_records = a->vn_records; u.adv_records = a->adv_records;

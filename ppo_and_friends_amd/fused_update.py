@@ -1052,6 +1052,7 @@ class FusedMatUpdate(FusedPolicyUpdate):
         # the reduce launch also advances the step count and yields the local ||g||^2 (replaced by K17's norm of the
         # summed gradient when ranks exchange); only the RCCL path runs the separate K11 norm pass
         a.fuse_norm = int(not self.multi or self.xchg is not None)
+        a.mb_offset, a.cursor_advance = 0, 1
         a.split_workspace, a.split_workspace_bytes = None, 0
         if self.split:
             if self._split_space is None:                # sized once, for the full batch size (a tail mini-batch needs less)
