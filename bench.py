@@ -245,8 +245,17 @@ def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
     evs = []
     if pol.agent_grouping:                                              # K15: one row = one env = A tokens
         A = pol.num_agents
-        fwd = A * lin(pol.actor_critic) + 3 * 2 * 2 * A * A * 64        # linears per token + 3 attention cores (QK^T, PV)
+        lin_f, att_f = A * lin(pol.actor_critic), 3 * 2 * 2 * A * A * 64   # linears per token; 3 attention cores (QK^T, PV)
+        fwd = lin_f + att_f
         kernel, desc = "mat_update_fwd_bwd_kernel", f"3 x ({A} tokens x 2 x sum(Linear weights) + 3 attention cores) x B"
+        mat_flop = 3 * fwd * B
+        if getattr(fused, "split", False):
+            # split-wgrad chain: the linears' weight-gradient third runs in mat_update_wgrad_kernel (the narrow first layers'
+            # and the heads' few wgrad FLOPs stay here and are not counted)
+            kernel = "mat_update_fwd_bwd_kernel<true>"
+            desc = (f"(2 x {A} tokens x 2 x sum(Linear weights) + 3 x 3 attention cores) x B (forward + dgrad; the linears' "
+                    "wgrad third runs in mat_update_wgrad_kernel)")
+            mat_flop = (2 * lin_f + 3 * att_f) * B
         opt, ac = pol.actor_critic_optim, pol.actor_critic
         clip = pol.gradient_clip
         for _ in range(launches):
@@ -316,7 +325,7 @@ def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
     fused.ws_allowed = True
     us = sorted(K.event_elapsed_ms(a, b) * 1e3 for a, b in evs)
     avg = sum(us) / len(us)
-    flop = (passes if not pol.agent_grouping else 3) * fwd * B
+    flop = mat_flop if pol.agent_grouping else passes * fwd * B
     tf = flop / (avg * 1e-6) / 1e12
     pmc = update_pmc_traffic(config, kernel)
     return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -1158,30 +1158,33 @@ __global__ __launch_bounds__(kMatRedThreads) void mat_update_reduce_kernel(MatDe
 }
 
 // Split-wgrad chain: what ppoaf_mat_update_reduce launches when args->split_workspace is set.
-//   workgroups [0, 288): one 16 x 16 tile of dW_k = dz_k^T x_k over ALL R rows of the mini-batch (K = R on f32 MFMA, the
-//     four waves take every fourth 16-row chunk and are folded in wave order) for the 18 linears; the tile column 0 jobs
+//   workgroups [0, 144): 16 x 32 of dW_k = dz_k^T x_k over ALL R rows of the mini-batch (K = R on f32 MFMA, the four
+//     waves take every fourth 16-row chunk and are folded in wave order) for the 18 linears; the jobs of input half 0
 //     also form db_k = column sums of dz_k.  Jobs are dealt so that the ~2 linears an XCD works on stay in its L2:
-//     workgroup b runs on XCD b % 8 (round-robin dispatch; placement only changes speed) and takes job (b % 8) * 36 + b / 8
+//     workgroup b runs on XCD b % 8 (round-robin dispatch; placement only changes speed) and takes job (b % 8) * 18 + b / 8
 //     of the linear-major job list.
 //   then ceil(4 n_small4 / 256) workgroups: the compact slabs of the small tensors (LayerNorm gains, narrow layers, heads)
 //     -> gradient bucket, in slab order (as mat_update_reduce_kernel);
 //   last workgroup: loss partials -> totals, cursor, step counter.
 // fuse_norm: one squared-norm partial per workgroup in norm_scratch[2 + b].
-constexpr int kMatWgJobs = kMatLin * 16;
+constexpr int kMatWgJobs = kMatLin * 8;
 __global__ __launch_bounds__(256) void mat_update_wgrad_kernel(MatDev u, int n_small_blocks) {
     __shared__ double s_red[17];
-    __shared__ __attribute__((aligned(16))) float s_fold[3 * 256 + 64];
+    __shared__ __attribute__((aligned(16))) float s_fold[2 * 3 * 256 + 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (b == kMatWgJobs + n_small_blocks) { mat_update_bookkeeping(u); return; }          // uniform per workgroup
     double q = 0.0;
     if (b < kMatWgJobs) {
+        // a job = 16 output rows x 32 input columns of one linear's dW: the X operand then uses whole 128-byte lines and
+        // the dz operand is shared by the job's two MFMA tiles (counters of the 16 x 16 form: 66 MB of L2 requests per
+        // launch for 7 MB of panels -- every line half used and fetched by four jobs -- at 7.5 TB/s: L2-bandwidth bound)
         constexpr int per_xcd = kMatWgJobs / 8;
         const int job = (b & 7) * per_xcd + (b >> 3);
-        const int k = job >> 4, ot = (job >> 2) & 3, it = job & 3;
+        const int k = job >> 3, ot = (job >> 1) & 3, ih = job & 1;
         const int wk = kMatLinW[k];
         const long plane = (long)u.R * kMD;
         const float* Dp = u.dpanel + (long)k * plane + ot * 16 + (lane & 15);
-        const float* Xp = u.xpanel + (long)kMatLinX[k] * plane + it * 16 + (lane & 15);
+        const float* Xp = u.xpanel + (long)kMatLinX[k] * plane + ih * 32 + (lane & 15);
         const int nc = u.nT;                                   // 16-row chunks
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         float bsum = 0.f;
@@ -1189,7 +1192,7 @@ __global__ __launch_bounds__(256) void mat_update_wgrad_kernel(MatDev u, int n_s
         // ago: each batch is one cold round trip, so there must be one batch at the BASELINE sizes: 52 chunks / 4 waves)
         constexpr int MAXC = 16;
         for (int c0 = wave; c0 < nc; c0 += 4 * MAXC) {         // wave-uniform trip count
-            float a[MAXC][4], x[MAXC][4];
+            float a[MAXC][4], x0[MAXC][4], x1[MAXC][4];
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {
                 const int ch = c0 + 4 * c;
@@ -1198,7 +1201,8 @@ __global__ __launch_bounds__(256) void mat_update_wgrad_kernel(MatDev u, int n_s
                     const long row = 16 * (long)ch + 4 * j + (lane >> 4);
                     const bool ok = ch < nc;
                     a[c][j] = ok ? Dp[row * kMD] : 0.f;
-                    x[c][j] = ok ? Xp[row * kMD] : 0.f;
+                    x0[c][j] = ok ? Xp[row * kMD] : 0.f;
+                    x1[c][j] = ok ? Xp[row * kMD + 16] : 0.f;
                 }
             }
 #pragma unroll
@@ -1206,32 +1210,39 @@ __global__ __launch_bounds__(256) void mat_update_wgrad_kernel(MatDev u, int n_s
                 if (c0 + 4 * c < nc) {                         // wave-uniform
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (c & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x[c][j], acc1, 0, 0, 0);
-                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x[c][j], acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x0[c][j], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x1[c][j], acc1, 0, 0, 0);
                         bsum += a[c][j];
                     }
                 }
             }
         }
-        f32x4 acc = acc0 + acc1;
-        if (wave > 0) *reinterpret_cast<f32x4*>(s_fold + ((wave - 1) * 64 + lane) * 4) = acc;
+        // fold the four waves' partial tiles in wave order (waves 1..3 park theirs in LDS)
+        if (wave > 0) {
+            *reinterpret_cast<f32x4*>(s_fold + (((wave - 1) * 2 + 0) * 64 + lane) * 4) = acc0;
+            *reinterpret_cast<f32x4*>(s_fold + (((wave - 1) * 2 + 1) * 64 + lane) * 4) = acc1;
+        }
         bsum += __shfl_xor(bsum, 16, 64);
         bsum += __shfl_xor(bsum, 32, 64);
-        if (lane < 16) s_fold[768 + wave * 16 + lane] = bsum;
+        if (lane < 16) s_fold[1536 + wave * 16 + lane] = bsum;
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
-            for (int w = 0; w < 3; ++w) acc += *reinterpret_cast<const f32x4*>(s_fold + (w * 64 + lane) * 4);
+            for (int w = 0; w < 3; ++w) {
+                acc0 += *reinterpret_cast<const f32x4*>(s_fold + ((w * 2 + 0) * 64 + lane) * 4);
+                acc1 += *reinterpret_cast<const f32x4*>(s_fold + ((w * 2 + 1) * 64 + lane) * 4);
+            }
             float* GW = u.grads + u.off[wk];
-            const int i = it * 16 + (lane & 15);               // C layout: column = lane & 15, rows 4 (lane >> 4) + r
+            const int i = ih * 32 + (lane & 15);               // C layout: column = lane & 15, rows 4 (lane >> 4) + r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = ot * 16 + 4 * (lane >> 4) + r;
-                GW[o * kMD + i] = acc[r];
-                q += (double)acc[r] * acc[r];
+                GW[o * kMD + i] = acc0[r];
+                GW[o * kMD + i + 16] = acc1[r];
+                q += (double)acc0[r] * acc0[r] + (double)acc1[r] * acc1[r];
             }
-            if (it == 0 && lane < 16) {
-                const float bg = s_fold[768 + lane] + s_fold[768 + 16 + lane] + s_fold[768 + 32 + lane] + s_fold[768 + 48 + lane];
+            if (ih == 0 && lane < 16) {
+                const float bg = s_fold[1536 + lane] + s_fold[1536 + 16 + lane] + s_fold[1536 + 32 + lane] + s_fold[1536 + 48 + lane];
                 u.grads[u.off[wk + 1] + ot * 16 + lane] = bg;
                 q += (double)bg * bg;
             }
