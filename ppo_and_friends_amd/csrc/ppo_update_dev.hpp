@@ -46,13 +46,17 @@ inline long ws_seg_off(const NetDev& n) {
 }
 inline long ws_seg_len(const NetDev& n) { return n.size - ws_seg_off(n); }
 
-// split-wgrad launch: one 4-wave workgroup per 16 x 16 tile of every layer's weight gradient (layer 0: ceil(in_dim / 16)
-// column tiles) + one per network for the output layer's segment; the bookkeeping workgroup comes last
+// split-wgrad launch: one 4-wave workgroup per 16 x 32 piece of every layer's weight gradient (two MFMA tiles that share
+// the dz operand and read whole 128-byte lines of the input panel; layer 0: ceil(in_dim / 32) pieces per 16 output rows)
+// + one per network for the output layer's segment.  Jobs are dealt to workgroups in XCD-sized runs (workgroup b runs on
+// XCD b % 8 and takes job (b % 8) * per_xcd + b / 8), so that a layer's panels are fetched by one or two XCDs instead of
+// all eight; the bookkeeping workgroup comes last.
 inline int split_wgrad_jobs(const NetDev& n) {
-    const int t = n.H / 16;
-    return (n.depth - 1) * t * t + t * ((n.in_dim + 15) / 16) + 1;
+    const int t = n.H / 16, t2 = (t + 1) / 2, p0 = ((n.in_dim + 15) / 16 + 1) / 2;
+    return (n.depth - 1) * t * t2 + t * p0 + 1;
 }
-inline int split_wgrad_blocks(const UpdateDev& u) { return split_wgrad_jobs(u.net[0]) + split_wgrad_jobs(u.net[1]); }
+inline int split_wgrad_per_xcd(const UpdateDev& u) { return (split_wgrad_jobs(u.net[0]) + split_wgrad_jobs(u.net[1]) + 7) / 8; }
+inline int split_wgrad_blocks(const UpdateDev& u) { return 8 * split_wgrad_per_xcd(u); }      // some run no job (partials 0)
 
 // workspace layout: per network hbuf, dbuf ([depth][Bp][H] each), outpart ([ceil(B/16)][seg]) and xbuf ([Bp][64])
 inline size_t ws_layout(const UpdateDev& u, WsDev* ws, char* base) {

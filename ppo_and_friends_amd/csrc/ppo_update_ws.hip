@@ -1481,7 +1481,7 @@ __device__ __forceinline__ void ppo_update_bookkeeping_split(const UpdateDev& u)
 
 // MAXC = chunks of 16 rows a wave may own (B <= 512: 32 chunks over 4 waves)
 template <int H>
-__device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int which, const int job, float* sFold /* [3][256] + [4][16] */) {
+__device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int which, const int job, float* sFold /* [3][2][256] + [4][16] */) {
     constexpr int MAXC = 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const auto& nd = u.net[which];
@@ -1494,20 +1494,23 @@ __device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int 
         return l == 0 ? szW0 : offW(l) + (l < depth ? (long)H * H : (((long)out_dim * H + 3) & ~3L));
     };
     float* G = u.grads + nd.offset;
-    constexpr int t = H / 16;
-    const int n_hidden = (depth - 1) * t * t, n_it0 = (in_dim + 15) / 16, n_l0 = t * n_it0;
+    constexpr int t = H / 16, t2 = (t + 1) / 2;
+    const int n_it0 = (in_dim + 15) / 16, p0 = (n_it0 + 1) / 2;
+    const int n_hidden = (depth - 1) * t * t2, n_l0 = t * p0;
     const float sc = u.grad_scale;
     double q = 0.0;
     if (job < n_hidden + n_l0) {
-        int l, ot, itile;
-        if (job < n_hidden) { l = 1 + job / (t * t); const int jj = job % (t * t); ot = jj / t; itile = jj % t; }
-        else { l = 0; const int jj = job - n_hidden; ot = jj / n_it0; itile = jj % n_it0; }
+        // 16 output rows x 32 input columns: input tiles itile and itile + 1 (the second may not exist: odd tile counts)
+        int l, ot, itile, n_it;
+        if (job < n_hidden) { l = 1 + job / (t * t2); const int jj = job % (t * t2); ot = jj / t2; itile = 2 * (jj % t2); n_it = t; }
+        else { l = 0; const int jj = job - n_hidden; ot = jj / p0; itile = 2 * (jj % p0); n_it = n_it0; }
+        const bool two = itile + 1 < n_it;                    // uniform per workgroup
         const float* Dp = u.sp.dbuf[which] + (long)l * plane + ot * 16 + (lane & 15);
         const float* Xp = l >= 1 ? u.sp.hbuf[which] + (long)(l - 1) * plane + itile * 16 + (lane & 15)
                                  : u.sp.xbuf[which] + itile * 16 + (lane & 15);
         const long ldx = l >= 1 ? H : 64;
         const int nc = (B + 15) >> 4;                         // 16-row chunks of the mini-batch
-        float a[MAXC][4], x[MAXC][4];
+        float a[MAXC][4], x0[MAXC][4], x1[MAXC][4];
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int ch = wave + 4 * c;
@@ -1516,7 +1519,8 @@ __device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int 
                 const int row = 16 * ch + 4 * j + (lane >> 4);
                 const bool ok = ch < nc && row < B;
                 a[c][j] = ok ? Dp[(long)row * H] : 0.f;
-                x[c][j] = ok ? Xp[(long)row * ldx] : 0.f;
+                x0[c][j] = ok ? Xp[(long)row * ldx] : 0.f;
+                x1[c][j] = (ok && two) ? Xp[(long)row * ldx + 16] : 0.f;
             }
         }
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -1526,35 +1530,38 @@ __device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int 
             if (wave + 4 * c < nc) {                          // wave-uniform
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (c & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x[c][j], acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x[c][j], acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x0[c][j], acc0, 0, 0, 0);
+                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x1[c][j], acc1, 0, 0, 0);
                     bsum += a[c][j];
                 }
             }
         }
-        f32x4 acc = acc0 + acc1;
         // fold the four waves' partial tiles in wave order (waves 1..3 park theirs in LDS)
-        if (wave > 0) *reinterpret_cast<f32x4*>(sFold + ((wave - 1) * 64 + lane) * 4) = acc;
+        if (wave > 0) {
+            *reinterpret_cast<f32x4*>(sFold + (((wave - 1) * 2 + 0) * 64 + lane) * 4) = acc0;
+            *reinterpret_cast<f32x4*>(sFold + (((wave - 1) * 2 + 1) * 64 + lane) * 4) = acc1;
+        }
         // bias: column o = lane & 15 summed over this lane group's rows, then over the 4 lane groups, then over the waves
         bsum += __shfl_xor(bsum, 16, 64);
         bsum += __shfl_xor(bsum, 32, 64);
-        if (lane < 16) sFold[768 + wave * 16 + lane] = bsum;
+        if (lane < 16) sFold[1536 + wave * 16 + lane] = bsum;
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
-            for (int w = 0; w < 3; ++w) acc += *reinterpret_cast<const f32x4*>(sFold + (w * 64 + lane) * 4);
+            for (int w = 0; w < 3; ++w) {
+                acc0 += *reinterpret_cast<const f32x4*>(sFold + ((w * 2 + 0) * 64 + lane) * 4);
+                acc1 += *reinterpret_cast<const f32x4*>(sFold + ((w * 2 + 1) * 64 + lane) * 4);
+            }
             const long ldw = l >= 1 ? H : in_dim;
             const int i = itile * 16 + (lane & 15);           // C layout: column = lane & 15, rows 4 (lane >> 4) + r
-            if (i < ldw) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = ot * 16 + 4 * (lane >> 4) + r;
-                    G[offW(l) + (long)o * ldw + i] = acc[r];
-                    q += (double)(acc[r] * sc) * (acc[r] * sc);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int o = ot * 16 + 4 * (lane >> 4) + r;
+                if (i < ldw) { G[offW(l) + (long)o * ldw + i] = acc0[r]; q += (double)(acc0[r] * sc) * (acc0[r] * sc); }
+                if (two && i + 16 < ldw) { G[offW(l) + (long)o * ldw + i + 16] = acc1[r]; q += (double)(acc1[r] * sc) * (acc1[r] * sc); }
             }
             if (itile == 0 && lane < 16) {
-                const float bg = sFold[768 + lane] + sFold[768 + 16 + lane] + sFold[768 + 32 + lane] + sFold[768 + 48 + lane];
+                const float bg = sFold[1536 + lane] + sFold[1536 + 16 + lane] + sFold[1536 + 32 + lane] + sFold[1536 + 48 + lane];
                 G[offB(l) + ot * 16 + lane] = bg;
                 q += (double)(bg * sc) * (bg * sc);
             }
@@ -1581,24 +1588,27 @@ __device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int 
 }
 
 template <int HA, int HC>
-__global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_kernel(UpdateDev u, int jobs_a, int jobs_c) {
+__global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_kernel(UpdateDev u, int jobs_a, int jobs_c, int per_xcd) {
     __shared__ double s_red[17];
-    __shared__ __attribute__((aligned(16))) float s_fold[3 * 256 + 64];
+    __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
     const int b = blockIdx.x;
-    if (b == jobs_a + jobs_c) { ppo_update_bookkeeping_split(u); return; }      // uniform per workgroup
-    const int which = b < jobs_a ? 0 : 1;
-    double q = which == 0 ? split_wgrad_job<HA>(u, 0, b, s_fold) : split_wgrad_job<HC>(u, 1, b - jobs_a, s_fold);
+    if (b == 8 * per_xcd) { ppo_update_bookkeeping_split(u); return; }           // uniform per workgroup
+    const int job = (b & 7) * per_xcd + (b >> 3);             // XCD b % 8 works on one run of the layer-major job list
+    double q = 0.0;
+    if (job < jobs_a) q = split_wgrad_job<HA>(u, 0, job, s_fold);
+    else if (job < jobs_a + jobs_c) q = split_wgrad_job<HC>(u, 1, job - jobs_a, s_fold);
+    const bool actor = job < jobs_a;
     q = block_sum(q, s_red);
     if (threadIdx.x == 0) {
-        u.norm_scratch[6 + 2 * b] = which == 0 ? q : 0.0;
-        u.norm_scratch[7 + 2 * b] = which == 1 ? q : 0.0;
+        u.norm_scratch[6 + 2 * b] = actor ? q : 0.0;
+        u.norm_scratch[7 + 2 * b] = actor ? 0.0 : q;
     }
 }
 
 template <int HA, int HC>
 static int wgrad_launch(const UpdateDev& u, hipStream_t s) {
-    const int ja = split_wgrad_jobs(u.net[0]), jc = split_wgrad_jobs(u.net[1]);
-    hipLaunchKernelGGL((ppo_update_wgrad_kernel<HA, HC>), dim3((unsigned)(ja + jc + 1)), dim3(kWgradThreads), 0, s, u, ja, jc);
+    const int ja = split_wgrad_jobs(u.net[0]), jc = split_wgrad_jobs(u.net[1]), px = split_wgrad_per_xcd(u);
+    hipLaunchKernelGGL((ppo_update_wgrad_kernel<HA, HC>), dim3((unsigned)(8 * px + 1)), dim3(kWgradThreads), 0, s, u, ja, jc, px);
     return check_launch("ppo_update_wgrad");
 }
 
