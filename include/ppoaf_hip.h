@@ -630,10 +630,18 @@ typedef struct {
     /* 1: obs / next_obs / actions are per-epoch tables already in shuffled order (entry i belongs to
      * perm[i]); mini-batch k reads [k * batch_stride, +B) directly, perm / row_map are not consulted */
     int32_t inputs_in_batch_order, _pad;
+    /* split-wgrad chain (NULL: every workgroup writes weight-gradient slabs of the bucket).  With a workspace of
+     * ppoaf_icm_update_split_workspace_bytes() bytes (256-byte aligned) the three fwd_bwd kernels form NO weight
+     * gradient: they publish each layer's dLoss/dz rows (and the inputs the scratch does not hold already), and
+     * ppoaf_icm_update_reduce forms every dW = dz^T x once per mini-batch over all rows (both observation streams for the
+     * encoder) on f32 MFMA, biases as column sums of dz, [+ Adam on the spot with fused_adam].  Same call sequence and
+     * outputs; sums run in MFMA K order (float32-rounding-level differences from the slab form, bitwise reproducible). */
+    void* split_workspace; int64_t split_workspace_bytes;
 } ppoaf_icm_update_args_t;
 
 int ppoaf_icm_update_fwd_bwd(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream);
 int ppoaf_icm_update_reduce(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream);
+int ppoaf_icm_update_split_workspace_bytes(const ppoaf_icm_update_args_t* args, int64_t* bytes_out);
 /* Rollout-time intrinsic reward of a whole env batch (PPOPolicy.get_intrinsic_reward,
  * policies/ppo_policy.py:954-1007 -> ICM.forward icm.py:375-430 without the inverse model):
  * intr_out[i] = scale * sum_d (forward_model(enc(obs_i), action_i) - enc(next_obs_i))_d^2 with

@@ -93,7 +93,8 @@ class IcmUpdateArgs(C.Structure):
                 ("cursor", C.c_void_p), ("B", C.c_int64), ("batch_stride", C.c_int64),
                 ("icm_beta", C.c_float), ("fused_adam", C.c_int32),
                 ("act_scratch", C.c_void_p), ("denc_scratch", C.c_void_p), ("loss_partials", C.c_void_p),
-                ("totals", C.c_void_p), ("inputs_in_batch_order", C.c_int32), ("_pad", C.c_int32)]
+                ("totals", C.c_void_p), ("inputs_in_batch_order", C.c_int32), ("_pad", C.c_int32),
+                ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64)]
 
 
 class MatUpdateArgs(C.Structure):
@@ -212,6 +213,7 @@ SIGNATURES = {
     "ppoaf_minibatch_moments": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int64, _ptr, _ptr]),
     "ppoaf_icm_update_fwd_bwd": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
     "ppoaf_icm_update_reduce": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
+    "ppoaf_icm_update_split_workspace_bytes": (C.c_int, [C.POINTER(IcmUpdateArgs), C.POINTER(C.c_int64)]),
     "ppoaf_icm_intrinsic_reward": (C.c_int, [C.POINTER(IcmUpdateArgs), C.c_float, _ptr, _ptr]),
     "ppoaf_adam_step_prenormed": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr, _ptr, C.c_float, C.c_float,
                                             C.c_float, C.c_float, C.c_float, _ptr, C.c_int32, _ptr, _ptr]),

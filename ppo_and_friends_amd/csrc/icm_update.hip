@@ -29,7 +29,39 @@ struct IcmDev {
     float icm_beta; int fused_adam, pregathered;
     float* actE; float* dEnc; float* loss_partials; double* totals;
     int nT;
+    // split-wgrad chain (args->split_workspace): the three fwd_bwd kernels form NO weight gradient; they publish every
+    // layer's dLoss/dz (and the inputs that are not in scratch already) as [rows][width] panels and the reduce launch
+    // becomes icm_wgrad_kernel.  Panels (plane = Bpad * H floats):
+    int split;
+    float* xO;      // [2][Bpad][XO]   gathered observation rows of the two streams, zero padded to XO = 16 ceil(O / 16)
+    float* dE;      // [2][4][plane]   encoder dz, stream-major
+    float* hI;      // [d_inv][plane]  inverse model hidden activations     dI: [d_inv][plane] its dz
+    float* dI;
+    float* oI;      // [Bpad][16]      d(inverse model output), zero padded
+    float* hF;      // [d_fwd][plane]  forward model hidden activations     dF: [d_fwd + 1][plane] its dz (last: the output layer)
+    float* dF;
+    float* aF;      // [Bpad][16]      the forward model's action columns (one-hot / action values), zero padded
+    int XO;
 };
+
+// one [n_o x n_i] block of some weight matrix = D^T X over all rows (and both observation streams for the encoder)
+struct IcmBlk {
+    const float* D; const float* X;     // [rows][ldd] / [rows][ldx] panels; segment s adds s * seg_d / s * seg_x floats
+    long seg_d, seg_x, w, b;            // w: bucket offset of the block's first weight; b: of its bias (-1: none from this block)
+    int n_seg, ldd, ldx, n_o, n_i, ldw, job0, n_ip;
+};
+constexpr int kIcmMaxBlk = 16;
+struct IcmWg { IcmBlk blk[kIcmMaxBlk]; int n_blk, n_jobs; };
+
+// 16 rows x H floats of LDS (row stride HS) -> rows [16 g, +16) of a [Bpad][H] panel
+template <int H>
+__device__ __forceinline__ void icm_publish(const float* __restrict__ src, int HS, float* __restrict__ panel, int g, int tid) {
+    float* dst = panel + (long)g * kRows * H;
+    for (int i = tid; i < kRows * (H / 4); i += kThreadsU) {
+        const int r = i / (H / 4), c4 = i - r * (H / 4);
+        *reinterpret_cast<float4*>(dst + (long)r * H + 4 * c4) = *reinterpret_cast<const float4*>(src + r * HS + 4 * c4);
+    }
+}
 
 extern __shared__ __attribute__((aligned(16))) unsigned char icm_smem[];
 
@@ -87,6 +119,10 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_fwd_kernel(IcmDev u) {
         }
     }
     __syncthreads();
+    if (u.split) {          // the layer-0 wgrad's K-panel: this tile's rows, zero padded to XO columns
+        float* xo = u.xO + ((long)which * u.Bpad + (long)g * kRows) * u.XO;
+        for (int i = tid; i < kRows * u.XO; i += kThreadsU) { const int r = i / u.XO, c = i - r * u.XO; xo[i] = sX[r * INP + c]; }
+    }
     // layer 0: K = O padded to 16 (sX zero padded), weights read with a bound check
     for (int nt = wave; nt < HT; nt += kNW) {
         const int o = nt * 16 + (lane & 15);
@@ -207,6 +243,7 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
             __syncthreads();
         }
         const float* Hlast = sH + (long)(depth - 1) * kRows * HS;
+        if (u.split) for (int l = 0; l < depth; ++l) icm_publish<H>(sH + (long)l * kRows * HS, HS, u.hI + (long)l * u.Bpad * H, g, tid);
         // output layer (A <= 8): VALU from LDS + 16-lane reductions
         if (tid < 256) {
             const int s = tid >> 4, part = tid & 15;
@@ -278,7 +315,12 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
         }
         __syncthreads();
         // output layer backward
-        if (tid < H) {
+        if (u.split) {
+            if (tid < kRows * 16) {                             // d(out) rows, zero padded to 16 columns
+                const int s = tid >> 4, k = tid & 15;
+                u.oI[((long)g * kRows + s) * 16 + k] = k < 8 ? sDOut[s * kMaxOut + k] : 0.f;
+            }
+        } else if (tid < H) {
             const int i = tid;
             float h[kRows];
 #pragma unroll
@@ -290,7 +332,7 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
                 slab[offW(depth) + (long)k * H + i] = acc;
             }
         }
-        if (tid >= 256 && tid < 256 + 8) {
+        if (!u.split && tid >= 256 && tid < 256 + 8) {
             const int k = tid - 256;                           // the padded bias entries get zeros
             float acc = 0.f;
             if (k < A)
@@ -324,13 +366,17 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
         for (int l = depth - 1; l >= 1; --l) {
             const float* Hin = sH + (long)(l - 1) * kRows * HS;
             layer_dgrad<HT>(P + offW(l), H, Dc, Hin, act, Dn, nullptr, wave, lane);
-            layer_wgrad<HT>(Dc, Hin, HS, HT, H, slab + offW(l), H, slab + offB(l), wave, lane, tid);
+            if (u.split) icm_publish<H>(Dc, HS, u.dI + (long)l * u.Bpad * H, g, tid);
+            else layer_wgrad<HT>(Dc, Hin, HS, HT, H, slab + offW(l), H, slab + offB(l), wave, lane, tid);
             __syncthreads();
             float* t = Dc; Dc = Dn; Dn = t;
         }
         // layer 0: two K halves; the gradients of the encodings leave through scratch
-        layer_wgrad<HT>(Dc, sE1, HS, HT, H, slab + offW(0), 2 * H, slab + offB(0), wave, lane, tid);
-        layer_wgrad<HT>(Dc, sE2, HS, HT, H, slab + offW(0) + H, 2 * H, nullptr, wave, lane, tid);
+        if (u.split) icm_publish<H>(Dc, HS, u.dI, g, tid);
+        else {
+            layer_wgrad<HT>(Dc, sE1, HS, HT, H, slab + offW(0), 2 * H, slab + offB(0), wave, lane, tid);
+            layer_wgrad<HT>(Dc, sE2, HS, HT, H, slab + offW(0) + H, 2 * H, nullptr, wave, lane, tid);
+        }
         float* dE = u.dEnc + ((long)(0 * 2 + 0) * u.Bpad + (long)g * kRows) * H;
         layer_dgrad<HT>(P + offW(0), 2 * H, Dc, nullptr, act, nullptr, dE, wave, lane);
         dE = u.dEnc + ((long)(0 * 2 + 1) * u.Bpad + (long)g * kRows) * H;
@@ -367,6 +413,13 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
             __syncthreads();
         }
         const float* Hlast = sH + (long)(depth - 1) * kRows * HS;
+        if (u.split) {
+            for (int l = 0; l < depth; ++l) icm_publish<H>(sH + (long)l * kRows * HS, HS, u.hF + (long)l * u.Bpad * H, g, tid);
+            if (tid < kRows * 16) {                             // the action columns of layer 0's input
+                const int s = tid >> 4, k = tid & 15;
+                u.aF[((long)g * kRows + s) * 16 + k] = sXa[s * kXS + k];
+            }
+        }
         // output layer H -> H (linear): the prediction of enc_2, into sD0
         layer_fwd<HT, true>(P + offW(depth), H, P + offB(depth), Hlast, sD0, -1, wave, lane);
         __syncthreads();
@@ -397,12 +450,16 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
         for (int l = depth; l >= 1; --l) {
             const float* Hin = sH + (long)(l - 1) * kRows * HS;
             layer_dgrad<HT>(P + offW(l), H, Dc, Hin, act, Dn, nullptr, wave, lane);
-            layer_wgrad<HT>(Dc, Hin, HS, HT, H, slab + offW(l), H, slab + offB(l), wave, lane, tid);
+            if (u.split) icm_publish<H>(Dc, HS, u.dF + (long)l * u.Bpad * H, g, tid);
+            else layer_wgrad<HT>(Dc, Hin, HS, HT, H, slab + offW(l), H, slab + offB(l), wave, lane, tid);
             __syncthreads();
             float* t = Dc; Dc = Dn; Dn = t;
         }
-        layer_wgrad<HT>(Dc, sE1, HS, HT, H, slab + offW(0), (int)ld0, slab + offB(0), wave, lane, tid);
-        layer_wgrad<HT>(Dc, sXa, kXS, 1, Ain, slab + offW(0) + H, (int)ld0, nullptr, wave, lane, tid);
+        if (u.split) icm_publish<H>(Dc, HS, u.dF, g, tid);
+        else {
+            layer_wgrad<HT>(Dc, sE1, HS, HT, H, slab + offW(0), (int)ld0, slab + offB(0), wave, lane, tid);
+            layer_wgrad<HT>(Dc, sXa, kXS, 1, Ain, slab + offW(0) + H, (int)ld0, nullptr, wave, lane, tid);
+        }
         float* dE = u.dEnc + ((long)(1 * 2 + 0) * u.Bpad + (long)g * kRows) * H;
         layer_dgrad<HT>(P + offW(0), ld0, Dc, nullptr, act, nullptr, dE, wave, lane);
     }
@@ -526,7 +583,7 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_bwd_kernel(IcmDev u) {
         *reinterpret_cast<float4*>(sD0 + s * HS + 4 * c4) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     }
     __syncthreads();
-    {
+    if (!u.split) {                             // layer 0's wgrad input (split chain: published by the forward kernel)
         const float* src = which == 0 ? u.obs : u.next_obs;
         for (int idx = tid; idx < kRows * O; idx += kThreadsU) {
             const int s = idx / O, i = idx - s * O;
@@ -540,11 +597,13 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_bwd_kernel(IcmDev u) {
     for (int l = 3; l >= 1; --l) {
         const float* Hin = sH + (long)(l - 1) * kRows * HS;
         layer_dgrad<HT>(P + encW(l), H, Dc, Hin, u.act, Dn, nullptr, wave, lane);
-        layer_wgrad<HT>(Dc, Hin, HS, HT, H, slab + encW(l), H, slab + encB(l), wave, lane, tid);
+        if (u.split) icm_publish<H>(Dc, HS, u.dE + (long)(which * 4 + l) * u.Bpad * H, g, tid);
+        else layer_wgrad<HT>(Dc, Hin, HS, HT, H, slab + encW(l), H, slab + encB(l), wave, lane, tid);
         __syncthreads();
         float* t = Dc; Dc = Dn; Dn = t;
     }
-    layer_wgrad<HT>(Dc, sX, INP, NT0, O, slab + encW(0), O, slab + encB(0), wave, lane, tid);
+    if (u.split) icm_publish<H>(Dc, HS, u.dE + (long)(which * 4) * u.Bpad * H, g, tid);
+    else layer_wgrad<HT>(Dc, sX, INP, NT0, O, slab + encW(0), O, slab + encB(0), wave, lane, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -607,6 +666,171 @@ __global__ __launch_bounds__(kIcmRedThreads) void icm_reduce_kernel(IcmDev u) {
     }
 }
 
+// Split-wgrad chain: what ppoaf_icm_update_reduce launches when args->split_workspace is set.  Every weight gradient of
+// the ICM is dW = dz^T x over all rows of the mini-batch (both observation streams for the encoder), formed ONCE here
+// instead of per 16-row tile into 3 x B/16 slabs of the bucket (20 MB per mini-batch at C3): one 4-wave workgroup per 16
+// output rows x 32 input columns (two f32 MFMA tiles sharing the dz operand, K = all rows: the waves take every fourth
+// 16-row chunk and are folded in wave order), the biases as column sums of dz in the jobs of input piece 0.  With
+// fused_adam the job applies Adam to its elements right away (the ICM update does not clip: ppo.py:2559-2562).  Jobs are
+// dealt to XCDs in runs of the block-major list (workgroup b runs on XCD b % 8).  Last workgroup: loss -> totals, cursor.
+__device__ __forceinline__ void icm_adam1(const IcmDev& u, long idx, float g, float step_size, float bc2_sqrt) {
+    const float gi = g * u.grad_scale;
+    float* pp = const_cast<float*>(u.params);
+    const float m = u.beta1 * u.exp_avg[idx] + (1.0f - u.beta1) * gi;
+    const float v = u.beta2 * u.exp_avg_sq[idx] + (1.0f - u.beta2) * gi * gi;
+    pp[idx] = pp[idx] - step_size * (m / (sqrtf(v) / bc2_sqrt + u.adam_eps));
+    u.exp_avg[idx] = m;
+    u.exp_avg_sq[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void icm_wgrad_kernel(IcmDev u, IcmWg w, int per_xcd) {
+    __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (b == 8 * per_xcd) {                                   // bookkeeping workgroup: loss -> totals, cursor++
+        if (tid >= 64) return;
+        float inv = 0.f, fl = 0.f;
+        for (int g = lane; g < u.nT; g += 64) { inv += u.loss_partials[g * 2]; fl += u.loss_partials[g * 2 + 1]; }
+        inv = wave_sum(inv); fl = wave_sum(fl);
+        if (lane == 0) {
+            const float n = (float)u.B;
+            inv = u.discrete ? inv / n : inv / (n * (float)u.A);
+            fl = fl / (n * (float)u.H);
+            u.totals[0] += (double)((1.0f - u.icm_beta) * fl + u.icm_beta * inv);
+            u.totals[1] += 1.0;
+            u.cursor[0] += 1;
+        }
+        return;
+    }
+    const int job = (b & 7) * per_xcd + (b >> 3);
+    if (job >= w.n_jobs) return;                              // uniform per workgroup
+    int bi = 0;
+    for (int i = 1; i < w.n_blk; ++i) if (job >= w.blk[i].job0) bi = i;
+    const IcmBlk& k = w.blk[bi];
+    const int jj = job - k.job0, ot = jj / k.n_ip, ip = jj - ot * k.n_ip;
+    const int oc = ot * 16 + (lane & 15), ic = ip * 32 + (lane & 15);
+    const bool vo = oc < k.n_o, v0 = ic < k.n_i, v1 = ic + 16 < k.n_i;
+    const float* Dp = k.D + oc;
+    const float* Xp = k.X + ic;
+    const int nc = u.nT, ncs = nc * k.n_seg;                  // 16-row chunks, over all segments
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    constexpr int MAXC = 8;                                   // B = 256, two streams: 32 chunks over 4 waves in one batch
+    for (int c0 = wave; c0 < ncs; c0 += 4 * MAXC) {           // wave-uniform trip count
+        float a[MAXC][4], x0[MAXC][4], x1[MAXC][4];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ci = c0 + 4 * c;
+            const int sg = ci / nc, ch = ci - sg * nc;
+            const bool ok = ci < ncs;
+            const float* dp = Dp + sg * k.seg_d;
+            const float* xp = Xp + sg * k.seg_x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long row = 16 * (long)ch + 4 * j + (lane >> 4);
+                a[c][j] = (ok && vo) ? dp[row * k.ldd] : 0.f;
+                x0[c][j] = (ok && v0) ? xp[row * k.ldx] : 0.f;
+                x1[c][j] = (ok && v1) ? xp[row * k.ldx + 16] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c0 + 4 * c < ncs) {                           // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x0[c][j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x1[c][j], acc1, 0, 0, 0);
+                    bsum += a[c][j];
+                }
+            }
+        }
+    }
+    if (wave > 0) {
+        *reinterpret_cast<f32x4*>(s_fold + (((wave - 1) * 2 + 0) * 64 + lane) * 4) = acc0;
+        *reinterpret_cast<f32x4*>(s_fold + (((wave - 1) * 2 + 1) * 64 + lane) * 4) = acc1;
+    }
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lane < 16) s_fold[1536 + wave * 16 + lane] = bsum;
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int ww = 0; ww < 3; ++ww) {
+        acc0 += *reinterpret_cast<const f32x4*>(s_fold + ((ww * 2 + 0) * 64 + lane) * 4);
+        acc1 += *reinterpret_cast<const f32x4*>(s_fold + ((ww * 2 + 1) * 64 + lane) * 4);
+    }
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if (u.fused_adam) { step_size = u.loss_partials[2 * u.nT]; bc2_sqrt = u.loss_partials[2 * u.nT + 1]; }
+    const int i0 = ip * 32 + (lane & 15);                     // C layout: column = lane & 15, rows 4 (lane >> 4) + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = ot * 16 + 4 * (lane >> 4) + r;
+        if (o < k.n_o) {
+            const long base = k.w + (long)o * k.ldw;
+            if (i0 < k.n_i) { u.grads[base + i0] = acc0[r]; if (u.fused_adam) icm_adam1(u, base + i0, acc0[r], step_size, bc2_sqrt); }
+            if (i0 + 16 < k.n_i) { u.grads[base + i0 + 16] = acc1[r]; if (u.fused_adam) icm_adam1(u, base + i0 + 16, acc1[r], step_size, bc2_sqrt); }
+        }
+    }
+    if (ip == 0 && k.b >= 0 && lane < 16 && ot * 16 + lane < k.n_o) {
+        const float bg = s_fold[1536 + lane] + s_fold[1536 + 16 + lane] + s_fold[1536 + 32 + lane] + s_fold[1536 + 48 + lane];
+        const long idx = k.b + ot * 16 + lane;
+        u.grads[idx] = bg;
+        if (u.fused_adam) icm_adam1(u, idx, bg, step_size, bc2_sqrt);
+    }
+}
+
+// panel layout of the split workspace and the block table of the wgrad launch -> bytes
+static size_t icm_split_layout(IcmDev& u, char* base, IcmWg* w) {
+    const long H = u.H, plane = u.Bpad * H;
+    size_t off = 0;
+    auto take = [&](size_t floats) { float* p = reinterpret_cast<float*>(base + off); off += (floats * 4 + 255) & ~(size_t)255; return p; };
+    u.XO = 16 * ((u.O + 15) / 16);
+    u.xO = take((size_t)2 * u.Bpad * u.XO);
+    u.dE = take((size_t)8 * plane);
+    u.hI = take((size_t)u.d_inv * plane); u.dI = take((size_t)u.d_inv * plane); u.oI = take((size_t)u.Bpad * 16);
+    u.hF = take((size_t)u.d_fwd * plane); u.dF = take((size_t)(u.d_fwd + 1) * plane); u.aF = take((size_t)u.Bpad * 16);
+    if (!w) return off;
+    int n = 0, jobs = 0;
+    auto add = [&](const float* D, int ldd, long seg_d, const float* X, int ldx, long seg_x, int n_seg, int n_o, int n_i,
+                   long wo, int ldw, long bo) {
+        IcmBlk& k = w->blk[n++];
+        k.D = D; k.X = X; k.seg_d = seg_d; k.seg_x = seg_x; k.w = wo; k.b = bo;
+        k.n_seg = n_seg; k.ldd = ldd; k.ldx = ldx; k.n_o = n_o; k.n_i = n_i; k.ldw = ldw; k.job0 = jobs;
+        k.n_ip = (n_i + 31) / 32;
+        jobs += ((n_o + 15) / 16) * k.n_ip;
+    };
+    const int Hi = (int)H;
+    // encoder (both observation streams: two segments): layer 0 from the gathered rows, layers 1..3 from the scratch
+    long e = u.enc_off;
+    add(u.dE, Hi, 4 * plane, u.xO, u.XO, u.Bpad * u.XO, 2, Hi, u.O, e, u.O, e + H * u.O);
+    e += H * u.O + H;
+    for (int l = 1; l < 4; ++l) {
+        add(u.dE + l * plane, Hi, 4 * plane, u.actE + (l - 1) * plane, Hi, 4 * plane, 2, Hi, Hi, e, Hi, e + H * H);
+        e += H * H + H;
+    }
+    // inverse model: layer 0 over cat(enc_1, enc_2), hidden layers, output layer (A rows)
+    long q = u.inv_off;
+    add(u.dI, Hi, 0, u.actE + 3 * plane, Hi, 0, 1, Hi, Hi, q, 2 * Hi, q + 2 * H * H);
+    add(u.dI, Hi, 0, u.actE + 7 * plane, Hi, 0, 1, Hi, Hi, q + H, 2 * Hi, -1);
+    q += 2 * H * H + H;
+    for (int l = 1; l < u.d_inv; ++l) {
+        add(u.dI + l * plane, Hi, 0, u.hI + (l - 1) * plane, Hi, 0, 1, Hi, Hi, q, Hi, q + H * H);
+        q += H * H + H;
+    }
+    add(u.oI, 16, 0, u.hI + (u.d_inv - 1) * plane, Hi, 0, 1, u.A, Hi, q, Hi, q + (long)u.A * H);
+    // forward model: layer 0 over cat(enc_1, action), hidden layers, output layer (H rows)
+    long f = u.fwd_off;
+    const int ld0 = Hi + u.Ain;
+    add(u.dF, Hi, 0, u.actE + 3 * plane, Hi, 0, 1, Hi, Hi, f, ld0, f + H * ld0);
+    add(u.dF, Hi, 0, u.aF, 16, 0, 1, Hi, u.Ain, f + H, ld0, -1);
+    f += H * ld0 + H;
+    for (int l = 1; l <= u.d_fwd; ++l) {
+        add(u.dF + l * plane, Hi, 0, u.hF + (l - 1) * plane, Hi, 0, 1, Hi, Hi, f, Hi, f + H * H);
+        f += H * H + H;
+    }
+    w->n_blk = n; w->n_jobs = jobs;
+    return off;
+}
+
 static int make_icm(const ppoaf_icm_update_args_t* a, IcmDev& u, bool training = true) {
     PPOAF_REQUIRE(a, "icm_update: null args");
     PPOAF_REQUIRE(a->hidden == 64 || a->hidden == 128, "icm_update: hidden=%d is not an instantiated width (64, 128)", a->hidden);
@@ -653,6 +877,15 @@ static int make_icm(const ppoaf_icm_update_args_t* a, IcmDev& u, bool training =
     u.Bpad = (long)u.nT * kRows;
     u.icm_beta = a->icm_beta; u.fused_adam = a->fused_adam != 0; u.pregathered = a->inputs_in_batch_order != 0;
     u.actE = a->act_scratch; u.dEnc = a->denc_scratch; u.loss_partials = a->loss_partials; u.totals = a->totals;
+    u.split = 0; u.XO = 0;
+    u.xO = u.dE = u.hI = u.dI = u.oI = u.hF = u.dF = u.aF = nullptr;
+    if (training && a->split_workspace) {
+        PPOAF_REQUIRE((((uintptr_t)a->split_workspace) & 255) == 0, "icm_update: split_workspace must be 256-byte aligned");
+        const size_t need = icm_split_layout(u, reinterpret_cast<char*>(a->split_workspace), nullptr);
+        PPOAF_REQUIRE((size_t)a->split_workspace_bytes >= need, "icm_update: split_workspace of %ld B, %zu needed",
+                      (long)a->split_workspace_bytes, need);
+        u.split = 1;
+    }
     return PPOAF_OK;
 }
 
@@ -714,10 +947,28 @@ extern "C" int ppoaf_icm_update_reduce(const ppoaf_icm_update_args_t* args, ppoa
     IcmDev u;
     const int rc = make_icm(args, u);
     if (rc) return rc;
+    if (u.split) {
+        IcmWg w;
+        icm_split_layout(u, reinterpret_cast<char*>(args->split_workspace), &w);
+        const int per_xcd = (w.n_jobs + 7) / 8;
+        hipLaunchKernelGGL(icm_wgrad_kernel, dim3((unsigned)(8 * per_xcd + 1)), dim3(256), 0, (hipStream_t)stream, u, w, per_xcd);
+        return check_launch("icm_update_reduce (wgrad)");
+    }
     const long n4 = u.total >> 2;
     hipLaunchKernelGGL(icm_reduce_kernel, dim3((unsigned)((n4 + kIcmRedThreads - 1) / kIcmRedThreads) + 1u),
                        dim3(kIcmRedThreads), 0, (hipStream_t)stream, u);
     return check_launch("icm_reduce");
+}
+
+extern "C" int ppoaf_icm_update_split_workspace_bytes(const ppoaf_icm_update_args_t* args, int64_t* bytes_out) {
+    PPOAF_REQUIRE(args && bytes_out, "icm_update_split_workspace_bytes: null argument");
+    ppoaf_icm_update_args_t a = *args;
+    a.split_workspace = nullptr; a.split_workspace_bytes = 0;
+    IcmDev u;
+    const int rc = make_icm(&a, u);
+    if (rc) return rc;
+    *bytes_out = (int64_t)icm_split_layout(u, nullptr, nullptr);
+    return PPOAF_OK;
 }
 
 template <int HT>

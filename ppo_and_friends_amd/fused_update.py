@@ -794,6 +794,13 @@ class FusedIcmUpdate:
         self._graphs, self._args = {}, {}
         self.xchg, self.xchg_reason = (peer_exchange.open_exchange(pol.icm_model.flat_grads.numel(), dev)
                                        if self.multi else (None, "single rank"))
+        # split-wgrad chain (csrc/icm_update.hip: icm_wgrad_kernel): PPOAF_ICM_SPLIT = 1 (default) | 0.  The reduce entry
+        # point keeps its contract, so graphs, K17 and the RCCL loop are the same with either form.
+        mode = os.environ.get("PPOAF_ICM_SPLIT", "1")
+        if mode not in ("0", "1"):
+            raise ValueError(f"PPOAF_ICM_SPLIT={mode!r}: expected 0 or 1")
+        self.split = mode == "1"
+        self._split_space = None
 
     def _make_args(self, B):
         pol, buf, opt = self.pol, self.pol.buffer, self.pol.icm_optim
@@ -816,6 +823,13 @@ class FusedIcmUpdate:
         a.fused_adam = int(not self.multi)
         a.act_scratch, a.denc_scratch = self.act_scratch.data_ptr(), self.denc_scratch.data_ptr()
         a.loss_partials, a.totals = self.loss_partials.data_ptr(), self.totals.data_ptr()
+        a.split_workspace, a.split_workspace_bytes = None, 0
+        if self.split:
+            if self._split_space is None:                # sized once, for the full batch size (a tail mini-batch needs less)
+                need = C.c_int64(0)
+                _lib.check(self._lib.ppoaf_icm_update_split_workspace_bytes(C.byref(a), C.byref(need)), "icm_update_split_workspace_bytes")
+                self._split_space = torch.zeros(int(need.value), dtype=torch.uint8, device=pol.device)
+            a.split_workspace, a.split_workspace_bytes = self._split_space.data_ptr(), self._split_space.numel()
         return a
 
     def begin_epoch(self, perm):

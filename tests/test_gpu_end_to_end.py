@@ -617,11 +617,14 @@ def test_filter_stack_in_the_loop(update_mode):
     dict(kind="d", NA=5, O=18, H=64, E=8, T=12, B=32, d_inv=3, d_fwd=1),
     dict(kind="c", NA=2, O=3, H=64, E=16, T=64, B=16, graphs=True),          # 64 mini-batches: two graph chunks
 ])
-def test_fused_icm_update_matches_oracle(case):
+@pytest.mark.parametrize("form", ["split", "slabs"])
+def test_fused_icm_update_matches_oracle(case, form, monkeypatch):
     """
-    K14 (fused ICM mini-batch update: encoder x2, inverse + forward model, both losses, backward, slab
-    reduce, Adam) against the torch-CPU ICM of oracle/icm_oracle.py trained on the same mini-batches.
+    K14 (fused ICM mini-batch update: encoder x2, inverse + forward model, both losses, backward, weight
+    gradients, Adam) against the torch-CPU ICM of oracle/icm_oracle.py trained on the same mini-batches.
+    `split` = the split-wgrad chain (default: panels + icm_wgrad_kernel), `slabs` = per-tile slabs + slab reduce.
     """
+    monkeypatch.setenv("PPOAF_ICM_SPLIT", "1" if form == "split" else "0")
     from oracle import icm_oracle
     from ppo_and_friends_amd.ppo import PPO
     from ppo_and_friends_amd.fused_update import FusedIcmUpdate
