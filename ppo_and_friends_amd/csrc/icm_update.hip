@@ -14,6 +14,7 @@
 // (inverse, forward model) for the heads.  float32 MFMA (v_mfma_f32_16x16x4_f32) keeps fmaf
 // chains exact, weight gradients are written to private slabs and summed in a fixed order.
 #include "mlp_device.hpp"
+#include <algorithm>
 
 namespace ppoaf {
 
@@ -51,7 +52,7 @@ struct IcmBlk {
     int n_seg, ldd, ldx, n_o, n_i, ldw, job0, n_ip;
 };
 constexpr int kIcmMaxBlk = 16;
-struct IcmWg { IcmBlk blk[kIcmMaxBlk]; int n_blk, n_jobs; };
+struct IcmWg { IcmBlk blk[kIcmMaxBlk]; int n_blk, n_jobs; int xcd_job0[9]; };   // XCD x works on jobs [xcd_job0[x], xcd_job0[x + 1])
 
 // 16 rows x H floats of LDS (row stride HS) -> rows [16 g, +16) of a [Bpad][H] panel
 template <int H>
@@ -673,19 +674,27 @@ __global__ __launch_bounds__(kIcmRedThreads) void icm_reduce_kernel(IcmDev u) {
 // 16-row chunk and are folded in wave order), the biases as column sums of dz in the jobs of input piece 0.  With
 // fused_adam the job applies Adam to its elements right away (the ICM update does not clip: ppo.py:2559-2562).  Jobs are
 // dealt to XCDs in runs of the block-major list (workgroup b runs on XCD b % 8).  Last workgroup: loss -> totals, cursor.
-__device__ __forceinline__ void icm_adam1(const IcmDev& u, long idx, float g, float step_size, float bc2_sqrt) {
+// (p, m, v) of one element, requested at the start of the job -- beside the operand panels, not one cold round trip after
+// the MFMAs -- and the Adam step on it (icm_reduce_kernel's arithmetic)
+struct IcmPmv { float p, m, v; };
+__device__ __forceinline__ IcmPmv icm_pmv_load(const IcmDev& u, long idx, bool ok) {
+    IcmPmv r = {0.f, 0.f, 0.f};
+    if (ok) { r.p = u.params[idx]; r.m = u.exp_avg[idx]; r.v = u.exp_avg_sq[idx]; }
+    return r;
+}
+__device__ __forceinline__ void icm_adam1(const IcmDev& u, long idx, float g, const IcmPmv& s, float step_size, float bc2_sqrt) {
     const float gi = g * u.grad_scale;
-    float* pp = const_cast<float*>(u.params);
-    const float m = u.beta1 * u.exp_avg[idx] + (1.0f - u.beta1) * gi;
-    const float v = u.beta2 * u.exp_avg_sq[idx] + (1.0f - u.beta2) * gi * gi;
-    pp[idx] = pp[idx] - step_size * (m / (sqrtf(v) / bc2_sqrt + u.adam_eps));
+    const float m = u.beta1 * s.m + (1.0f - u.beta1) * gi;
+    const float v = u.beta2 * s.v + (1.0f - u.beta2) * gi * gi;
+    const_cast<float*>(u.params)[idx] = s.p - step_size * (m / (sqrtf(v) / bc2_sqrt + u.adam_eps));
     u.exp_avg[idx] = m;
     u.exp_avg_sq[idx] = v;
 }
 
 __global__ __launch_bounds__(256) void icm_wgrad_kernel(IcmDev u, IcmWg w, int per_xcd) {
     __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: chunk bases below stay in scalar registers
     if (b == 8 * per_xcd) {                                   // bookkeeping workgroup: loss -> totals, cursor++
         if (tid >= 64) return;
         float inv = 0.f, fl = 0.f;
@@ -701,35 +710,56 @@ __global__ __launch_bounds__(256) void icm_wgrad_kernel(IcmDev u, IcmWg w, int p
         }
         return;
     }
-    const int job = (b & 7) * per_xcd + (b >> 3);
-    if (job >= w.n_jobs) return;                              // uniform per workgroup
+    const int job = w.xcd_job0[b & 7] + (b >> 3);
+    if (job >= w.xcd_job0[(b & 7) + 1]) return;               // uniform per workgroup
     int bi = 0;
     for (int i = 1; i < w.n_blk; ++i) if (job >= w.blk[i].job0) bi = i;
     const IcmBlk& k = w.blk[bi];
     const int jj = job - k.job0, ot = jj / k.n_ip, ip = jj - ot * k.n_ip;
-    const int oc = ot * 16 + (lane & 15), ic = ip * 32 + (lane & 15);
-    const bool vo = oc < k.n_o, v0 = ic < k.n_i, v1 = ic + 16 < k.n_i;
-    const float* Dp = k.D + oc;
-    const float* Xp = k.X + ic;
+    // Operand addresses = uniform base (segment, 16-row chunk: scalar registers) + one 32-bit lane offset.  Lanes whose
+    // output row or input column lies outside the block read a clamped (valid) address instead of a zero: they only feed
+    // output elements that are never stored.
+    const int oc = min(ot * 16 + (lane & 15), k.n_o - 1);
+    const int ic0 = min(ip * 32 + (lane & 15), k.n_i - 1), ic1 = min(ip * 32 + 16 + (lane & 15), k.n_i - 1);
+    // buffer loads: resource = the panel's base, scalar offset = segment + chunk + row quad (scalar ALU), vector offset =
+    // the lane's constant byte offset -- no vector address arithmetic per load
+    const unsigned dl = 4u * (unsigned)((lane >> 4) * k.ldd + oc);
+    const unsigned xl0 = 4u * (unsigned)((lane >> 4) * k.ldx + ic0), xl1 = 4u * (unsigned)((lane >> 4) * k.ldx + ic1);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(k.D), 0, 0xFFFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(k.X), 0, 0xFFFFFFFF, 0x00020000);
+    // wave 0 owns the output (C layout: column = lane & 15, rows 4 (lane >> 4) + r): its elements' optimiser state first
+    const int i0 = ip * 32 + (lane & 15);
+    const bool adam = u.fused_adam && wave == 0;
+    IcmPmv s0[4], s1[4], sb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = ot * 16 + 4 * (lane >> 4) + r;
+        const long base = k.w + (long)o * k.ldw;
+        s0[r] = icm_pmv_load(u, base + i0, adam && o < k.n_o && i0 < k.n_i);
+        s1[r] = icm_pmv_load(u, base + i0 + 16, adam && o < k.n_o && i0 + 16 < k.n_i);
+    }
+    const bool has_b = ip == 0 && k.b >= 0 && lane < 16 && ot * 16 + lane < k.n_o;
+    sb = icm_pmv_load(u, k.b + ot * 16 + lane, adam && has_b);
     const int nc = u.nT, ncs = nc * k.n_seg;                  // 16-row chunks, over all segments
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     constexpr int MAXC = 8;                                   // B = 256, two streams: 32 chunks over 4 waves in one batch
+    const unsigned d16 = 16u * (unsigned)k.ldd, x16 = 16u * (unsigned)k.ldx;       // bytes per 4 rows
     for (int c0 = wave; c0 < ncs; c0 += 4 * MAXC) {           // wave-uniform trip count
         float a[MAXC][4], x0[MAXC][4], x1[MAXC][4];
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int ci = c0 + 4 * c;
-            const int sg = ci / nc, ch = ci - sg * nc;
-            const bool ok = ci < ncs;
-            const float* dp = Dp + sg * k.seg_d;
-            const float* xp = Xp + sg * k.seg_x;
+            if (ci < ncs) {                                   // wave-uniform
+                const int sg = ci / nc, ch = ci - sg * nc;
+                const unsigned sd = (unsigned)(4 * (sg * k.seg_d + (long)ch * 16 * k.ldd));
+                const unsigned sx = (unsigned)(4 * (sg * k.seg_x + (long)ch * 16 * k.ldx));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long row = 16 * (long)ch + 4 * j + (lane >> 4);
-                a[c][j] = (ok && vo) ? dp[row * k.ldd] : 0.f;
-                x0[c][j] = (ok && v0) ? xp[row * k.ldx] : 0.f;
-                x1[c][j] = (ok && v1) ? xp[row * k.ldx + 16] : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, sd + j * d16, 0));
+                    x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl0, sx + j * x16, 0));
+                    x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl1, sx + j * x16, 0));
+                }
             }
         }
 #pragma unroll
@@ -760,24 +790,24 @@ __global__ __launch_bounds__(256) void icm_wgrad_kernel(IcmDev u, IcmWg w, int p
     }
     float step_size = 0.f, bc2_sqrt = 1.f;
     if (u.fused_adam) { step_size = u.loss_partials[2 * u.nT]; bc2_sqrt = u.loss_partials[2 * u.nT + 1]; }
-    const int i0 = ip * 32 + (lane & 15);                     // C layout: column = lane & 15, rows 4 (lane >> 4) + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = ot * 16 + 4 * (lane >> 4) + r;
         if (o < k.n_o) {
             const long base = k.w + (long)o * k.ldw;
-            if (i0 < k.n_i) { u.grads[base + i0] = acc0[r]; if (u.fused_adam) icm_adam1(u, base + i0, acc0[r], step_size, bc2_sqrt); }
-            if (i0 + 16 < k.n_i) { u.grads[base + i0 + 16] = acc1[r]; if (u.fused_adam) icm_adam1(u, base + i0 + 16, acc1[r], step_size, bc2_sqrt); }
+            if (i0 < k.n_i) { u.grads[base + i0] = acc0[r]; if (u.fused_adam) icm_adam1(u, base + i0, acc0[r], s0[r], step_size, bc2_sqrt); }
+            if (i0 + 16 < k.n_i) { u.grads[base + i0 + 16] = acc1[r]; if (u.fused_adam) icm_adam1(u, base + i0 + 16, acc1[r], s1[r], step_size, bc2_sqrt); }
         }
     }
-    if (ip == 0 && k.b >= 0 && lane < 16 && ot * 16 + lane < k.n_o) {
+    if (has_b) {
         const float bg = s_fold[1536 + lane] + s_fold[1536 + 16 + lane] + s_fold[1536 + 32 + lane] + s_fold[1536 + 48 + lane];
         const long idx = k.b + ot * 16 + lane;
         u.grads[idx] = bg;
-        if (u.fused_adam) icm_adam1(u, idx, bg, step_size, bc2_sqrt);
+        if (u.fused_adam) icm_adam1(u, idx, bg, sb, step_size, bc2_sqrt);
     }
 }
 
+static int jobs_of(const IcmBlk* blk, int i, int n, int jobs) { return (i + 1 < n ? blk[i + 1].job0 : jobs) - blk[i].job0; }
 // panel layout of the split workspace and the block table of the wgrad launch -> bytes
 static size_t icm_split_layout(IcmDev& u, char* base, IcmWg* w) {
     const long H = u.H, plane = u.Bpad * H;
@@ -828,6 +858,21 @@ static size_t icm_split_layout(IcmDev& u, char* base, IcmWg* w) {
         f += H * H + H;
     }
     w->n_blk = n; w->n_jobs = jobs;
+    // deal the block-major job list to the 8 XCDs in runs of equal COST (a job's cost = its K: the encoder's jobs run over
+    // both observation streams), so that no XCD is left with twice the work of the others
+    long total = 0;
+    for (int i = 0; i < n; ++i) total += (long)(jobs_of(w->blk, i, n, jobs)) * w->blk[i].n_seg;
+    long acc = 0;
+    int x = 0;
+    w->xcd_job0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const int nj = jobs_of(w->blk, i, n, jobs);
+        for (int j = 0; j < nj; ++j) {
+            while (x < 7 && acc * 8 >= total * (x + 1)) w->xcd_job0[++x] = w->blk[i].job0 + j;
+            acc += w->blk[i].n_seg;
+        }
+    }
+    while (x < 8) w->xcd_job0[++x] = jobs;
     return off;
 }
 
@@ -950,7 +995,8 @@ extern "C" int ppoaf_icm_update_reduce(const ppoaf_icm_update_args_t* args, ppoa
     if (u.split) {
         IcmWg w;
         icm_split_layout(u, reinterpret_cast<char*>(args->split_workspace), &w);
-        const int per_xcd = (w.n_jobs + 7) / 8;
+        int per_xcd = 1;
+        for (int x = 0; x < 8; ++x) per_xcd = std::max(per_xcd, w.xcd_job0[x + 1] - w.xcd_job0[x]);
         hipLaunchKernelGGL(icm_wgrad_kernel, dim3((unsigned)(8 * per_xcd + 1)), dim3(256), 0, (hipStream_t)stream, u, w, per_xcd);
         return check_launch("icm_update_reduce (wgrad)");
     }
