@@ -1171,7 +1171,8 @@ constexpr int kMatWgJobs = kMatLin * 8;
 __global__ __launch_bounds__(256) void mat_update_wgrad_kernel(MatDev u, int n_small_blocks) {
     __shared__ double s_red[17];
     __shared__ __attribute__((aligned(16))) float s_fold[2 * 3 * 256 + 64];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: the chunk offsets below stay in scalar registers
     if (b == kMatWgJobs + n_small_blocks) { mat_update_bookkeeping(u); return; }          // uniform per workgroup
     double q = 0.0;
     if (b < kMatWgJobs) {
@@ -1183,8 +1184,13 @@ __global__ __launch_bounds__(256) void mat_update_wgrad_kernel(MatDev u, int n_s
         const int k = job >> 3, ot = (job >> 1) & 3, ih = job & 1;
         const int wk = kMatLinW[k];
         const long plane = (long)u.R * kMD;
-        const float* Dp = u.dpanel + (long)k * plane + ot * 16 + (lane & 15);
-        const float* Xp = u.xpanel + (long)kMatLinX[k] * plane + ih * 32 + (lane & 15);
+        // buffer loads: resource = the panel, scalar offset = chunk + row quad, vector offset = the lane's constant byte
+        // offset: no vector address arithmetic per load (the same launch with 64-bit addresses spent as many VALU
+        // instructions on addresses as on everything else)
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(u.dpanel + (long)k * plane, 0, 0xFFFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(u.xpanel + (long)kMatLinX[k] * plane, 0, 0xFFFFFFFF, 0x00020000);
+        const unsigned dl = 4u * (unsigned)((lane >> 4) * kMD + ot * 16 + (lane & 15));
+        const unsigned xl = 4u * (unsigned)((lane >> 4) * kMD + ih * 32 + (lane & 15));
         const int nc = u.nT;                                   // 16-row chunks
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         float bsum = 0.f;
@@ -1196,13 +1202,14 @@ __global__ __launch_bounds__(256) void mat_update_wgrad_kernel(MatDev u, int n_s
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {
                 const int ch = c0 + 4 * c;
+                if (ch < nc) {                                 // wave-uniform
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const long row = 16 * (long)ch + 4 * j + (lane >> 4);
-                    const bool ok = ch < nc;
-                    a[c][j] = ok ? Dp[row * kMD] : 0.f;
-                    x0[c][j] = ok ? Xp[row * kMD] : 0.f;
-                    x1[c][j] = ok ? Xp[row * kMD + 16] : 0.f;
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned so = 4u * (unsigned)((16 * ch + 4 * j) * kMD);
+                        a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, so, 0));
+                        x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl, so, 0));
+                        x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl + 64u, so, 0));
+                    }
                 }
             }
 #pragma unroll

@@ -1483,7 +1483,8 @@ __device__ __forceinline__ void ppo_update_bookkeeping_split(const UpdateDev& u)
 template <int H>
 __device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int which, const int job, float* sFold /* [3][2][256] + [4][16] */) {
     constexpr int MAXC = 8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: the chunk offsets below stay in scalar registers
     const auto& nd = u.net[which];
     const int in_dim = nd.in_dim, depth = nd.depth, out_dim = nd.out_dim;
     const int B = (int)u.B;
@@ -1505,22 +1506,30 @@ __device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int 
         if (job < n_hidden) { l = 1 + job / (t * t2); const int jj = job % (t * t2); ot = jj / t2; itile = 2 * (jj % t2); n_it = t; }
         else { l = 0; const int jj = job - n_hidden; ot = jj / p0; itile = 2 * (jj % p0); n_it = n_it0; }
         const bool two = itile + 1 < n_it;                    // uniform per workgroup
-        const float* Dp = u.sp.dbuf[which] + (long)l * plane + ot * 16 + (lane & 15);
-        const float* Xp = l >= 1 ? u.sp.hbuf[which] + (long)(l - 1) * plane + itile * 16 + (lane & 15)
-                                 : u.sp.xbuf[which] + itile * 16 + (lane & 15);
+        // buffer loads: resource = the layer's panel, scalar offset = chunk + row quad, vector offset = the lane's constant
+        // byte offset (no vector address arithmetic per load).  Rows of the last chunk beyond B are dead rows of their
+        // tile: their dz is zero and their activations finite, exactly as the slab form sums them.
         const long ldx = l >= 1 ? H : 64;
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(u.sp.dbuf[which] + (long)l * plane, 0, 0xFFFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            l >= 1 ? u.sp.hbuf[which] + (long)(l - 1) * plane : u.sp.xbuf[which], 0, 0xFFFFFFFF, 0x00020000);
+        const unsigned dl = 4u * (unsigned)((lane >> 4) * H + ot * 16 + (lane & 15));
+        const unsigned xl = 4u * (unsigned)((lane >> 4) * (int)ldx + itile * 16 + (lane & 15));
         const int nc = (B + 15) >> 4;                         // 16-row chunks of the mini-batch
         float a[MAXC][4], x0[MAXC][4], x1[MAXC][4];
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int ch = wave + 4 * c;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = 16 * ch + 4 * j + (lane >> 4);
-                const bool ok = ch < nc && row < B;
-                a[c][j] = ok ? Dp[(long)row * H] : 0.f;
-                x0[c][j] = ok ? Xp[(long)row * ldx] : 0.f;
-                x1[c][j] = (ok && two) ? Xp[(long)row * ldx + 16] : 0.f;
+            for (int j = 0; j < 4; ++j) { a[c][j] = 0.f; x0[c][j] = 0.f; x1[c][j] = 0.f; }
+            if (ch < nc) {                                    // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned sd = 4u * (unsigned)((16 * ch + 4 * j) * H), sx = 4u * (unsigned)((16 * ch + 4 * j) * (int)ldx);
+                    a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, sd, 0));
+                    x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl, sx, 0));
+                    if (two) x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl + 64u, sx, 0));
+                }
             }
         }
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
