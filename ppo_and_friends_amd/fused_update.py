@@ -163,13 +163,13 @@ class FusedPolicyUpdate:
         self.perm = None
         self._graphs = {}
         self._args = {}
-        self.split, self.split_reason = self._split_wanted()
         self._split_space = None
         # N > 1: the per-mini-batch gradient exchange.  K17 over peer mappings when every rank can (same
         # host, IPC + self-test passed: collective decision), else the RCCL all-reduce in an eager loop.
         self.xchg, self.xchg_reason = (peer_exchange.open_exchange(total, dev) if self.multi else (None, "single rank"))
         # the persistent two-XCD kernel of an N > 1 run carries the exchange inside the launch, with its own element ->
         # group map (one group per worker), hence its own slots and flag words; opened collectively, like the first
+        self.split, self.split_reason = self._split_wanted()
         self.xchg_ws = None
         if self.xchg is not None and self._ws_wanted():
             self.xchg_ws, why = peer_exchange.open_exchange(total, dev)
@@ -180,7 +180,9 @@ class FusedPolicyUpdate:
         """
         (bool, why): the split-wgrad chain (fwd_bwd publishes activation / dz panels, ppoaf_ppo_update_wgrad forms the complete
         weight gradients) instead of weight-gradient slabs + the slab reduce.  PPOAF_SPLIT_WGRAD = auto | 1 | 0; auto =
-        single rank (the N > 1 chain fuses the K17 exchange into the slab reduce launch) and shapes the panels cover.
+        shapes the panels cover and, on N > 1 ranks, a K17 exchange plus a 256-wide network: the exchange is then a launch
+        of its own between wgrad and Adam (four launches), which beats the slab chain's fused reduce + exchange launch only
+        where the split saves more than a launch costs (<8,16>: 46.5 + 6.9 against 59 us; <8,8>: 17.8 + 5.1 against 21.4).
         """
         import os
         mode = os.environ.get("PPOAF_SPLIT_WGRAD", "auto")
@@ -193,7 +195,10 @@ class FusedPolicyUpdate:
         if max(self.actor_desc.in_dim, self.critic_desc.in_dim) > 64 or self.B > 512:
             return False, "the panels cover in_dim <= 64 and batch sizes <= 512"
         if self.multi:
-            return False, "N > 1: the slab reduce launch carries the K17 exchange"
+            if self.xchg is None:
+                return False, "N > 1 without K17: the all-reduce loops run the slab chain"
+            if mode != "1" and max(self.actor_desc.hidden, self.critic_desc.hidden) < 256:
+                return False, "N > 1, no 256-wide network: the slab reduce launch carries the K17 exchange"
         return True, ""
 
     def gradient_only(self, args, timing_events=(None, None)):
@@ -353,8 +358,16 @@ class FusedPolicyUpdate:
         single = not self.multi
         rc = lib.ppoaf_ppo_update_fwd_bwd(ref, st)
         if rc == 0 and args.split_workspace:
-            # split-wgrad chain (single rank): complete weight gradients from the published panels, then clip + Adam
-            rc = lib.ppoaf_ppo_update_wgrad(ref, st) or lib.ppoaf_ppo_update_adam(ref, 3, st)
+            # split-wgrad chain: complete weight gradients from the published panels, then clip + Adam
+            rc = lib.ppoaf_ppo_update_wgrad(ref, st)
+            if rc == 0 and self.xchg is not None:
+                # N > 1: K17 sums the bucket over the ranks and leaves both clip norms of the sum
+                g = self.pol.policy_grads
+                self.xchg.allreduce(g, g, split_floats=self.actor_desc.size, norm_scale=args.grad_scale,
+                                    norm_out=self.pol.policy_norm_scratch, stream=st)
+                rc = lib.ppoaf_ppo_update_adam(ref, 2, st)
+            elif rc == 0:
+                rc = lib.ppoaf_ppo_update_adam(ref, 3, st)
             if rc != 0:
                 _lib.check(rc, "ppo_update")
             return

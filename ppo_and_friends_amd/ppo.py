@@ -870,19 +870,23 @@ class PPO:
         bucket, `values` and the value normaliser; the ICM pass reads observations / actions and writes the
         ICM bucket.  Both are latency-bound chains on ~32 workgroups each, so running them side by side
         nearly halves the pair's wall time; shuffles are drawn in the reference's order, results are
-        identical.  Single rank + both fused updaters only (collectives stay on one stream).
+        identical.  Both fused updaters only; on N > 1 ranks only when BOTH exchange their gradients through K17 (two
+        independent exchange objects, each a kernel launch on its own stream: every rank issues the same sequence per
+        object, nothing orders the two against each other) -- host-side collectives stay on one stream, so the RCCL /
+        gloo paths run the two epochs one after the other as the reference does.
         """
         pol = self.policies[policy_id]
-        if not pol.enable_icm or not getattr(self, "overlap_icm", True) or mpi_utils.distributed_path() \
-                or self.device.type != "cuda":
+        if not pol.enable_icm or not getattr(self, "overlap_icm", True) or self.device.type != "cuda":
             return False
         fused = self._fused_updater(policy_id, loader.batch_size)
         fused_icm = self._fused_icm_updater(policy_id)
         if fused is None or fused_icm is None:
             return False
+        if mpi_utils.distributed_path() and (fused.xchg is None or fused_icm.xchg is None
+                                             or os.environ.get("PPOAF_OVERLAP_ICM_MULTI", "1") == "0"):
+            return False
         fused.begin_epoch(loader.epoch_permutation())
         fused_icm.begin_epoch(loader.epoch_permutation())
-        import os
         # two concurrent kernel chains: the persistent two-XCD kernel would serialise them (experiment switch only)
         fused.ws_allowed = os.environ.get("PPOAF_WS_WITH_ICM", "0") == "1"
         main = torch.cuda.current_stream()
