@@ -498,7 +498,8 @@ enum { cZ1_ = 0, cN0_, cQ_, cK_, cV_, cY_, cN1_, cZM_, cN2_, cENC_, cZH_, cNH_,
     const int O = c.O, L = c.L, NA = c.NA, Ain = c.Ain, OS = c.OS, n_rows = c.n_rows;                              \
     (void)O; (void)L; (void)NA; (void)Ain; (void)OS; (void)n_rows;                                                \
     auto W = [&](int k) -> const float* { return c.W(k); };                                                       \
-    auto rstd = [&](int k) -> float* { return c.rstd(k); }
+    auto rstd = [&](int k) -> float* { return c.rstd(k); };                                                       \
+    (void)W; (void)rstd
 
 // split-wgrad chain: the forward publishes every linear's input tile the moment it is settled (the backward then has
 // no reason to rebuild it from the saved normalised activations); K16 and the slab form publish nothing

@@ -552,7 +552,6 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
         const long plane = (long)Bp * H;
         const float* xsrc = which == 0 ? u.obs : u.critic_obs;
         const long mb = cursor0 + it;
-        const long base = mb * u.batch_stride;
         double sumsq = 0.0;
 
         // ---- row table of a mini-batch: dataset row, where its inputs are read from, and the per-row scalars of the loss
