@@ -273,3 +273,87 @@ def test_full_size_split_wgrad_chain_matches_the_slab_chain(name, monkeypatch):
     np.testing.assert_allclose(epochs["1"][0][2][:5] / n_mb, epochs["0"][0][2][:5] / n_mb, rtol=2e-4, atol=1e-4)   # (means of cancelling O(1) terms)
     a, b = epochs["1"]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_c5_mat_split_wgrad_chain_matches_the_slab_form_at_full_size(monkeypatch):
+    """
+    K15 at C5 size (52 token tiles, 832 token rows): ONE mini-batch's gradient bucket of the split-wgrad chain (input / dz
+    panels + mat_update_wgrad_kernel over all token rows) within 1e-5 of its largest entry of the slab form's (per-tile
+    slabs + slab reduce), the same loss scalars; then an epoch of each: every mini-batch counted once, statistics to
+    2e-4, and the split chain bitwise equal to itself run to run (graph replay and eager launches).
+    """
+    import ctypes as C
+    from ppo_and_friends_amd import _lib
+    from ppo_and_friends_amd import kernels as K
+    grads, totals, epochs = {}, {}, {}
+    for split in ("0", "1", "1"):
+        monkeypatch.setenv("PPOAF_MAT_SPLIT", split)
+        ppo, E, T, A = _c_config("C5", use_graphs=len(epochs.get("1", [])) == 0)
+        ppo.rollout()
+        pol = ppo.policies["p"]
+        pol.train()
+        fused = ppo._fused_updater("p", 256)
+        assert fused.split == (split == "1")
+        perm = torch.randperm(len(pol.dataset), device=pol.device, generator=torch.Generator(device=pol.device).manual_seed(3))
+        fused.begin_epoch(perm)
+        opt = pol.actor_critic_optim
+        steps = opt.step_count.clone()
+        args, lib, st = fused._args_for(256), _lib.load(), K.stream()
+        _lib.check(lib.ppoaf_mat_update_fwd_bwd(C.byref(args), st), "mat fwd_bwd")
+        _lib.check(lib.ppoaf_mat_update_reduce(C.byref(args), st), "mat reduce")
+        torch.cuda.synchronize()
+        opt.step_count.copy_(steps)
+        grads.setdefault(split, pol.actor_critic.flat_grads.clone()); totals.setdefault(split, fused.totals.clone())
+        fused.begin_epoch(perm)
+        fused.run_epoch()
+        t = fused.end_epoch()
+        n_mb = E * T // 256
+        assert t[8] == n_mb and int(opt.step_count.item()) == n_mb
+        epochs.setdefault(split, []).append((pol.actor_critic.flat_params.clone(), opt.exp_avg_sq.clone(), t.copy()))
+    scale = float(grads["0"].abs().max())
+    d = float((grads["1"] - grads["0"]).abs().max())
+    assert d <= 1e-5 * scale, f"max |dg| {d:.3e} against max |g| {scale:.3e}"
+    np.testing.assert_allclose(totals["1"].cpu().numpy(), totals["0"].cpu().numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(epochs["1"][0][2][:5] / n_mb, epochs["0"][0][2][:5] / n_mb, rtol=2e-4, atol=1e-4)
+    a, b = epochs["1"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_c3_icm_split_wgrad_chain_matches_the_slab_form_at_full_size(monkeypatch):
+    """
+    K14 at C3 size (B = 256, H = 128, O = 17, Box(6)): ONE mini-batch's gradient bucket of the split-wgrad chain (dz /
+    input panels + icm_wgrad_kernel over all rows and both observation streams, Adam on the spot) within 1e-5 of its
+    largest entry of the slab form's, the weights after that one Adam step within 1e-6, the same loss; then an epoch of
+    each: every mini-batch counted once, the epoch's mean loss to 2e-4, and the split chain bitwise equal to itself run to
+    run (graph replay and eager launches).
+    """
+    from ppo_and_friends_amd.fused_update import FusedIcmUpdate
+    grads, weights, losses, epochs = {}, {}, {}, {}
+    for split in ("0", "1", "1"):
+        monkeypatch.setenv("PPOAF_ICM_SPLIT", split)
+        ppo, E, T, A = _c_config("C3", use_graphs=len(epochs.get("1", [])) == 0)
+        ppo.rollout()
+        pol = ppo.policies["p"]
+        pol.train()
+        fused = FusedIcmUpdate(ppo, "p")
+        assert fused.split == (split == "1")
+        perm = torch.randperm(len(pol.dataset), device=pol.device, generator=torch.Generator(device=pol.device).manual_seed(3))
+        fused.begin_epoch(perm)
+        fused._one(fused._args_for(256))
+        torch.cuda.synchronize()
+        grads.setdefault(split, pol.icm_model.flat_grads.clone()); weights.setdefault(split, pol.icm_model.flat_params.clone())
+        losses.setdefault(split, fused.totals.clone())
+        fused.begin_epoch(perm)
+        fused.run_epoch()
+        t = fused.end_epoch()
+        n_mb = E * T // 256
+        assert t[1] == n_mb and int(pol.icm_optim.step_count.item()) == n_mb + 1
+        epochs.setdefault(split, []).append((pol.icm_model.flat_params.clone(), pol.icm_optim.exp_avg_sq.clone(), np.array(t, dtype=np.float64)))
+    scale = float(grads["0"].abs().max())
+    d = float((grads["1"] - grads["0"]).abs().max())
+    assert d <= 1e-5 * scale, f"max |dg| {d:.3e} against max |g| {scale:.3e}"
+    assert float((weights["1"] - weights["0"]).abs().max()) <= 1e-6
+    np.testing.assert_allclose(losses["1"].cpu().numpy(), losses["0"].cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(epochs["1"][0][2][0] / n_mb, epochs["0"][0][2][0] / n_mb, rtol=2e-4)   # (measured 4.4e-5 after 1024 Adam steps)
+    a, b = epochs["1"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2])
