@@ -782,6 +782,15 @@ int ppoaf_ppo_update_reduce_exchange(const ppoaf_ppo_update_args_t* args, ppoaf_
                                      double wait_seconds, ppoaf_stream_t stream);
 int ppoaf_ppo_update_adam_exchanged(const ppoaf_ppo_update_args_t* args, ppoaf_peer_exchange_t* x,
                                     ppoaf_stream_t stream);
+/* Split-wgrad chain on N > 1 ranks of one node: ppoaf_ppo_update_wgrad with the K17 exchange inside (mpi_avg_gradients, utils/mpi_utils.py:65-86, at
+ * its call site ppo.py:2443-2448): every wgrad workgroup is one exchange group -- its sums go to this rank's slot, it
+ * publishes, waits for the same group of its peers (at most wait_seconds) and stores the rank-ordered sum into grads; the
+ * clip-norm partials of the SUM stay in the exchange object, so ppoaf_ppo_update_adam_exchanged follows.  The exchange
+ * object must be used by this entry point only (its element -> group map); at most 256 workgroups
+ * (ppoaf_ppo_update_split_blocks): wider shapes use ppoaf_ppo_update_wgrad -> ppoaf_peer_exchange_allreduce ->
+ * ppoaf_ppo_update_adam(args, 2, stream). */
+int ppoaf_ppo_update_wgrad_exchange(const ppoaf_ppo_update_args_t* args, ppoaf_peer_exchange_t* xchg, double wait_seconds,
+                                    ppoaf_stream_t stream);
 /* ppoaf_ppo_update_ws for N > 1 ranks: the same persistent launch with the K17 exchange as a phase of every mini-batch
  * (mpi_avg_gradients at ppo.py:2443-2448 without leaving the kernel).  Worker w of a network owns the same parameter
  * columns on every rank and is exchange group (network * 32 + w): a row-tiled network sends its folded column sums

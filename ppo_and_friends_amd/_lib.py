@@ -241,6 +241,7 @@ SIGNATURES = {
     "ppoaf_allgather_moments": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr, _ptr]),
     "ppoaf_comm_destroy": (C.c_int, [_ptr]),
     "ppoaf_ppo_update_reduce_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr]),
+    "ppoaf_ppo_update_wgrad_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr]),
     "ppoaf_ppo_update_adam_exchanged": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, _ptr]),
     "ppoaf_env_filter_moments": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),
                                            C.c_int32, C.c_int64, _ptr, _ptr]),

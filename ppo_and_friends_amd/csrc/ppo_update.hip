@@ -725,7 +725,9 @@ extern "C" int ppoaf_ppo_update_adam_exchanged(const ppoaf_ppo_update_args_t* ar
     const long n4 = u.bucket_total >> 2;
     PPOAF_REQUIRE(xchg->dev.n4 == n4, "ppo_update_adam_exchanged: exchange made for %ld float4, bucket has %ld",
                   xchg->dev.n4, n4);
-    const unsigned groups = (unsigned)((n4 + kRedThreads - 1) / kRedThreads);     // as ppoaf_ppo_update_reduce_exchange
+    // one pair of norm partials per exchange group: the workgroups of ppoaf_ppo_update_reduce_exchange, or (split-wgrad
+    // chain) of ppoaf_ppo_update_wgrad_exchange
+    const unsigned groups = u.split ? (unsigned)split_wgrad_blocks(u) : (unsigned)((n4 + kRedThreads - 1) / kRedThreads);
     PPOAF_REQUIRE(groups <= (unsigned)kXchgMaxGrid, "ppo_update_adam_exchanged: bucket too large for the fused exchange");
     hipLaunchKernelGGL(ppo_update_adam_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u,
                        (const double*)xchg->dev.norm_partials, groups);

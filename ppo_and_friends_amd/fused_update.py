@@ -88,7 +88,7 @@ def _reduce_totals(upd, totals):
     if not upd.multi:
         return t.cpu().numpy()
     broken = 0.0
-    for x in (upd.xchg, getattr(upd, "xchg_ws", None)):
+    for x in (upd.xchg, getattr(upd, "xchg_ws", None), getattr(upd, "xchg_sp", None)):
         if x is not None and x.status()[1] != 0:
             broken = 1.0
     ws_failure = upd._persistent_failure() if hasattr(upd, "_persistent_failure") else ""
@@ -169,12 +169,33 @@ class FusedPolicyUpdate:
         self.xchg, self.xchg_reason = (peer_exchange.open_exchange(total, dev) if self.multi else (None, "single rank"))
         # the persistent two-XCD kernel of an N > 1 run carries the exchange inside the launch, with its own element ->
         # group map (one group per worker), hence its own slots and flag words; opened collectively, like the first
+        # PPOAF_SPLIT_WGRAD=1 on N > 1 ranks: the split-wgrad chain with the exchange inside its wgrad launch (one exchange
+        # group per wgrad workgroup: its own object again; at most 256 workgroups).  Opt-in: measured SLOWER than the slab
+        # chain's fused reduce + exchange launch at C2 (one-rank rehearsal 7.12e5 against 7.66e5 env-steps/s: the split saves
+        # 3.4 us per mini-batch there, scalar stores into the uncached slots cost more); parity-tested
+        # (tests/test_gpu_two_ranks.py: peer_split).  Shapes with a 256-wide network exchange in a launch of their own.
+        self.xchg_sp = None
+        if self.xchg is not None and type(self) is FusedPolicyUpdate and os.environ.get("PPOAF_SPLIT_WGRAD", "auto") == "1" \
+                and self._split_blocks() <= 256 and max(self.actor_desc.in_dim, self.critic_desc.in_dim) <= 64 and self.B <= 512:
+            self.xchg_sp, why = peer_exchange.open_exchange(total, dev)
+            if self.xchg_sp is not None and self.xchg_sp.status()[2] == 3:      # (the same kind on every rank: a collective choice)
+                self.xchg_sp.close()
+                self.xchg_sp, why = None, "coarse-grained slots need fences, which the wgrad launch does not use"
+            if self.xchg_sp is None:
+                self.xchg_reason += f"; wgrad-launch exchange refused ({why})"
         self.split, self.split_reason = self._split_wanted()
         self.xchg_ws = None
         if self.xchg is not None and self._ws_wanted():
             self.xchg_ws, why = peer_exchange.open_exchange(total, dev)
             if self.xchg_ws is None:
                 self.xchg_reason += f"; persistent-kernel exchange refused ({why})"
+
+    def _split_blocks(self):
+        """Workgroups of ppoaf_ppo_update_wgrad for this policy's shapes (csrc/ppo_update_dev.hpp: split_wgrad_blocks)."""
+        def jobs(d):
+            t = d.hidden // 16
+            return (d.depth - 1) * t * ((t + 1) // 2) + t * (((d.in_dim + 15) // 16 + 1) // 2) + 1
+        return 8 * ((jobs(self.actor_desc) + jobs(self.critic_desc) + 7) // 8)
 
     def _split_wanted(self):
         """
@@ -197,8 +218,8 @@ class FusedPolicyUpdate:
         if self.multi:
             if self.xchg is None:
                 return False, "N > 1 without K17: the all-reduce loops run the slab chain"
-            if mode != "1" and max(self.actor_desc.hidden, self.critic_desc.hidden) < 256:
-                return False, "N > 1, no 256-wide network: the slab reduce launch carries the K17 exchange"
+            if self.xchg_sp is None and mode != "1" and max(self.actor_desc.hidden, self.critic_desc.hidden) < 256:
+                return False, "N > 1, no exchange for the wgrad launch and no 256-wide network: the slab reduce launch carries K17"
         return True, ""
 
     def gradient_only(self, args, timing_events=(None, None)):
@@ -359,6 +380,13 @@ class FusedPolicyUpdate:
         rc = lib.ppoaf_ppo_update_fwd_bwd(ref, st)
         if rc == 0 and args.split_workspace:
             # split-wgrad chain: complete weight gradients from the published panels, then clip + Adam
+            if self.xchg_sp is not None:
+                # N > 1, at most 256 wgrad workgroups: K17 inside the wgrad launch, the norms of the sum left for Adam
+                rc = lib.ppoaf_ppo_update_wgrad_exchange(ref, self.xchg_sp.handle, self.xchg_sp.wait_seconds, st) \
+                    or lib.ppoaf_ppo_update_adam_exchanged(ref, self.xchg_sp.handle, st)
+                if rc != 0:
+                    _lib.check(rc, "ppo_update")
+                return
             rc = lib.ppoaf_ppo_update_wgrad(ref, st)
             if rc == 0 and self.xchg is not None:
                 # N > 1: K17 sums the bucket over the ranks and leaves both clip norms of the sum

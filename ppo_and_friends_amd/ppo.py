@@ -856,9 +856,13 @@ class PPO:
         for f in active:
             f.xchg.close()
             f.xchg, f.xchg_reason = None, f"disabled: {why}"
-            if getattr(f, "xchg_ws", None) is not None:
-                f.xchg_ws.close()
-                f.xchg_ws = None
+            for name in ("xchg_ws", "xchg_sp"):
+                if getattr(f, name, None) is not None:
+                    getattr(f, name).close()
+                    setattr(f, name, None)
+            if type(f).__name__ == "FusedPolicyUpdate":
+                f.split, f.split_reason = f._split_wanted()     # the all-reduce loops run the slab chain
+                f._split_space = None
             f._graphs.clear()
             f._args = {}
         self.status_dict["global status"]["peer exchange disabled"] = True

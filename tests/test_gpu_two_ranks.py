@@ -25,6 +25,11 @@ def _free_port():
 
 def _rank(rank, world, port, out, mode):
     ws_mode = None
+    if mode == "peer_split":
+        # the split-wgrad chain with K17 inside the wgrad launch (ppoaf_ppo_update_wgrad_exchange): opt-in below 256 wide,
+        # where the default stays the slab chain with K17 fused into the slab reduce launch
+        mode = "peer"
+        os.environ["PPOAF_SPLIT_WGRAD"] = "1"
     if mode.startswith("peer_ws_"):
         # the persistent two-XCD kernel with the K17 exchange as a phase of every mini-batch (forced here: at these
         # widths `auto` keeps the chain); the ranks share one GPU, so each takes its own pair of XCDs
@@ -58,6 +63,7 @@ def _rank(rank, world, port, out, mode):
     from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
     out[rank] = dict(w0=w0, w=pol.policy_params.detach().cpu().clone(),
                      peer_exchange=[getattr(f, "xchg", None) is not None for f in fused],
+                     split=[bool(f.split) for f in fused], wgrad_exchange=[getattr(f, "xchg_sp", None) is not None for f in fused],
                      ws_exchange_launches=FusedPolicyUpdate.ws_exchange_launch_count,
                      exp_avg=pol.policy_exp_avg.detach().cpu().clone(),
                      actor_sd={k: v.detach().cpu().clone() for k, v in pol.actor.state_dict().items()},
@@ -70,10 +76,11 @@ def _rank(rank, world, port, out, mode):
     dist.destroy_process_group()
 
 
-# "peer": K17 exchange over IPC mappings inside hipGraph-replayed chains; "rccl": the eager loop with the
-# process group's all-reduce (gloo here, staged through the host); "peer_ws_*": K17 inside the persistent two-XCD
-# kernel (ppoaf_ppo_update_ws_exchange), both networks row-tiled / layered
-@pytest.fixture(scope="module", params=["peer", "rccl", "peer_ws_rowtile", "peer_ws_layered"])
+# "peer": K17 exchange over IPC mappings inside hipGraph-replayed chains (slab chain, K17 fused into the slab reduce
+# launch); "peer_split": the split-wgrad chain with K17 inside the wgrad launch (ppoaf_ppo_update_wgrad_exchange); "rccl":
+# the eager loop with the process group's all-reduce (gloo here, staged through the host); "peer_ws_*": K17 inside the
+# persistent two-XCD kernel (ppoaf_ppo_update_ws_exchange), both networks row-tiled / layered
+@pytest.fixture(scope="module", params=["peer", "peer_split", "rccl", "peer_ws_rowtile", "peer_ws_layered"])
 def run2(request):
     world = 2
     mgr = mp.Manager()
@@ -84,12 +91,14 @@ def run2(request):
         assert r["peer_exchange"] == [request.param.startswith("peer")], r["peer_exchange"]
         # 2 epochs = 2 persistent launches when the exchange runs inside the kernel, none otherwise
         assert r["ws_exchange_launches"] == (2 if request.param.startswith("peer_ws_") else 0), r["ws_exchange_launches"]
+        if request.param in ("peer", "peer_split"):
+            assert r["split"] == r["wgrad_exchange"] == [request.param == "peer_split"], (r["split"], r["wgrad_exchange"])
     res[0]["mode"] = request.param
     return res
 
 
 def test_rowtiled_persistent_kernel_with_exchange_is_bitwise_the_chain():
-    """K17 inside the persistent kernel (row-tiled networks) against K17 inside the graph-replayed three-launch chain:
+    """K17 inside the persistent kernel (row-tiled networks) against K17 inside the graph-replayed three-launch SLAB chain:
     the same arithmetic in the same order on both ranks -- bitwise equal parameters, moments and statistics."""
     runs = {}
     for mode in ("peer", "peer_ws_rowtile"):
