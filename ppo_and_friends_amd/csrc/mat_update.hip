@@ -280,21 +280,6 @@ __device__ __forceinline__ void lin_dgrad_r(const MatFr& r, const float* __restr
 // ------------------------------------------------------------------------------------------------
 // attention core on LDS tiles (K9's block-diagonal packing).  Q, K, V, Y, dY ... are [16, 64] tiles.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 att_xyT(const float* __restrict__ X, const float* __restrict__ Y, int lane) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* xr = X + (lane & 15) * kMHS + 4 * (lane >> 4);
-    const float* yr = Y + (lane & 15) * kMHS + 4 * (lane >> 4);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float4 a = *reinterpret_cast<const float4*>(xr + 16 * c);
-        const float4 b = *reinterpret_cast<const float4*>(yr + 16 * c);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
-    }
-    return acc;
-}
 // out[:, 16 nt ..] = A[16,16] . Z[:, 16 nt ..]; A from the 17-stride tile T, as is or transposed
 __device__ __forceinline__ void att_a_times(const float* __restrict__ T, bool transposed, const float* __restrict__ Z,
                                             float* __restrict__ out, int nt, int lane) {
@@ -309,40 +294,62 @@ __device__ __forceinline__ void att_a_times(const float* __restrict__ T, bool tr
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[(4 * slot + r) * kMHS + 16 * nt + i] = acc[r];
 }
-// forward: probabilities -> sP (kept for the backward), Y = P V.  Two barriers inside, none after.
+// One 16-wide K chunk of X Y^T (X, Y: [16, 64] tiles): the wave's share of a score tile
+__device__ __forceinline__ f32x4 att_xyT_chunk(const float* __restrict__ X, const float* __restrict__ Y, int chunk, int lane) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float4 a = *reinterpret_cast<const float4*>(X + (lane & 15) * kMHS + 16 * chunk + 4 * (lane >> 4));
+    const float4 b = *reinterpret_cast<const float4*>(Y + (lane & 15) * kMHS + 16 * chunk + 4 * (lane >> 4));
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    return acc;
+}
+// forward: probabilities -> sP (kept for the backward), Y = P V.  Three barriers inside, none after.
+// The 16 x 16 score tile is ONE MFMA output tile: instead of one wave running its 16 dependent MFMAs and the softmax of all
+// 16 rows while three waves wait (stamps: 3.6 k cycles per attention), every wave takes one 16-wide K chunk (4 MFMAs), the
+// four partial tiles meet in LDS (the Y tile is free until the last phase), and every wave runs the softmax of 4 rows, one
+// row per 16 lanes.
 __device__ __forceinline__ void att_fwd(const float* Q, const float* K, const float* V, float* Y, float* sP,
                                         int L, int n_rows, bool masked, int wave, int lane) {
-    if (wave == 0) {
-        const f32x4 s = att_xyT(Q, K, lane);
+    {
+        const f32x4 s = att_xyT_chunk(Q, K, wave, lane);
         const int col = lane & 15;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * (lane >> 4) + r;
-            bool ok = row < n_rows && col < n_rows && (row / L) == (col / L);
-            if (masked) ok = ok && (col % L) <= (row % L);
-            const float x = ok ? s[r] * 0.125f : -INFINITY;             // 1 / sqrt(64)
-            const float m = group16_max(x);
-            const float e = ok ? expf(x - m) : 0.f;
-            const float den = group16_sum(e);
-            sP[row * 17 + col] = den > 0.f ? e / den : 0.f;
-        }
+        for (int r = 0; r < 4; ++r) Y[wave * 272 + (4 * (lane >> 4) + r) * 17 + col] = s[r];
+    }
+    __syncthreads();
+    {
+        const int row = 4 * wave + (lane >> 4), col = lane & 15;
+        const float sc = (Y[row * 17 + col] + Y[272 + row * 17 + col]) + (Y[544 + row * 17 + col] + Y[816 + row * 17 + col]);
+        bool ok = row < n_rows && col < n_rows && (row / L) == (col / L);
+        if (masked) ok = ok && (col % L) <= (row % L);
+        const float x = ok ? sc * 0.125f : -INFINITY;                       // 1 / sqrt(64)
+        const float m = group16_max(x);
+        const float e = ok ? expf(x - m) : 0.f;
+        const float den = group16_sum(e);
+        sP[row * 17 + col] = den > 0.f ? e / den : 0.f;
     }
     __syncthreads();
     att_a_times(sP, false, V, Y, wave, lane);
 }
-// backward from dY: dQ, dK, dV (three distinct output tiles); sS is a 17-stride scratch tile
+// backward from dY: dQ, dK, dV (three distinct output tiles); sS is a 17-stride scratch tile; the partial tiles of
+// dP = dY V^T meet in the dQ tile (written only in the last phase)
 __device__ __forceinline__ void att_bwd(const float* Q, const float* K, const float* V, const float* sP, const float* dY,
                                         float* dQ, float* dK, float* dV, float* sS, int wave, int lane) {
-    if (wave == 0) {
-        const f32x4 dp = att_xyT(dY, V, lane);
+    {
+        const f32x4 dp = att_xyT_chunk(dY, V, wave, lane);
         const int col = lane & 15;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * (lane >> 4) + r;
-            const float p = sP[row * 17 + col];
-            const float dot = group16_sum(dp[r] * p);
-            sS[row * 17 + col] = p * (dp[r] - dot) * 0.125f;
-        }
+        for (int r = 0; r < 4; ++r) dQ[wave * 272 + (4 * (lane >> 4) + r) * 17 + col] = dp[r];
+    }
+    __syncthreads();
+    {
+        const int row = 4 * wave + (lane >> 4), col = lane & 15;
+        const float dp = (dQ[row * 17 + col] + dQ[272 + row * 17 + col]) + (dQ[544 + row * 17 + col] + dQ[816 + row * 17 + col]);
+        const float p = sP[row * 17 + col];
+        const float dot = group16_sum(dp * p);
+        sS[row * 17 + col] = p * (dp - dot) * 0.125f;
     }
     __syncthreads();
     att_a_times(sP, true, dY, dV, wave, lane);      // dV = P^T dY
