@@ -134,7 +134,13 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
         // The weights were rewritten by the Adam kernel a moment ago, so this XCD's L2 does not hold them:
         // the first touch of every 128-B line of the network is requested here, before anything else, so
         // the misses overlap the index / gather / first-layer phases instead of stalling the hidden layers.
-        if (!deep && !NT) for (long i = (long)tid * 32; i < nd.size; i += (long)kThreadsU * 32) l2_touch += P[i];
+        // Not for 256-wide networks: the touches pull the whole 786 KB network through the CU's 64 B/clk vector L1 a third
+        // time (after them the forward and the dgrad fragments), and every load of the prologue queues behind them (vmcnt
+        // retires in order): critic workgroup 103 k -> 93 k cycles without them (stamps), hidden forward unchanged.
+#ifndef PPOAF_L2_TOUCH_MAX_HT
+#define PPOAF_L2_TOUCH_MAX_HT 8
+#endif
+        if (!deep && !NT && HT <= PPOAF_L2_TOUCH_MAX_HT) for (long i = (long)tid * 32; i < nd.size; i += (long)kThreadsU * 32) l2_touch += P[i];
         if (copy_fits) {
 #pragma unroll
             for (int r = 0; r < kCopyRegs; ++r) {
