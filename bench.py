@@ -23,6 +23,7 @@ Rank 0 prints ONE JSON line:
                       Otherwise K12 / K15 fwd_bwd (kernel begin/end events on eager launches of the same chain right
                       after the timed region -- the in-region launches are hipGraph nodes, which cannot carry stamps)
   config.other_configs  short runs (2 steps) of the other BASELINE configs' shapes (C3, C4, C5) in the same process
+                      (N = 1; at N > 1 only with PPOAF_BENCH_OTHER_CONFIGS_MULTI=1)
   cpu_baseline        oracle/cpu_ppo_loop.py (a port with the reference's loop structure, pinned against fixtures
                       recorded from the reference) on a bounded sample: 1 process; cpu_baseline_mpi: R = 8 processes
                       in the reference's launch model (oracle/cpu_ddppo.py, gloo); cpu_baseline_c1: C1 exactly.
@@ -512,7 +513,11 @@ def main():
     main_res = run_measured(args.config, args.steps, args.warmup, True)
     update_note = notes.get(args.config)
     others = {}
-    if args.config == "C2" and not args.no_other_configs:
+    # N > 1: the line the driver's scaling run reads is C2's; the other shapes' N > 1 paths (K17 inside the persistent kernel,
+    # overlapped PPO / ICM epochs) are rehearsed by `PPOAF_REHEARSE_MULTI_RANK=1 bench.py --config <C>` and the two-process
+    # tests, and run here only on request -- a failure in one of them must not cost the headline measurement
+    others_wanted = world == 1 or os.environ.get("PPOAF_BENCH_OTHER_CONFIGS_MULTI", "0") == "1"
+    if args.config == "C2" and not args.no_other_configs and others_wanted:
         for name in CONFIGS:
             if name == "C2":
                 continue
