@@ -287,7 +287,8 @@ def test_bench_contract_under_the_drivers_two_rank_launch():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PPOAF_BACKEND="gloo", PPOAF_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, PPOAF_BACKEND="gloo", PPOAF_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PPOAF_BENCH_OTHER_CONFIGS_MULTI="1")     # the other shapes' N > 1 paths too (off by default at N > 1)
     env.pop("PPOAF_GRAD_EXCHANGE", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
