@@ -1,3 +1,7 @@
+"""In-kernel s_memtime stamps of K12's row-tiled fwd_bwd kernel (diagnostic build: bash tools/build_stamps.sh, or
+bash tools/build_variant.sh <name> -DPPOAF_STAMPS [-DPPOAF_STAMP_BLOCK=4 for a critic workgroup] and PPOAF_LIB=tools/libppoaf_hip_<name>.so):
+shader-clock cycles per phase of one workgroup.  CRITIC_H=256 gives the C3 / C4 critic shape.  Note: a stamp is a global
+store, and the backend drains vmcnt before the loads that follow it -- the phase after a stamp includes that drain."""
 import sys, os, ctypes as C; sys.path.insert(0,'.')
 import numpy as np, torch
 from ppo_and_friends_amd import _lib
