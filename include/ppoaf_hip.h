@@ -683,8 +683,9 @@ typedef struct {
     float surr_clip, entropy_weight, kl_loss_weight, huber_delta;
     float* loss_partials;            /* [n_workgroups, 8] */
     double* totals;                  /* [9] */
-    /* single-rank fusion of K11's norm pass: with fuse_norm the reduce launch also leaves the ceil(bucket_total /
-     * 1024) per-workgroup partials of ||grads||^2 in norm_scratch[2 ..] (float64[2 + that many], at least
+    /* single-rank fusion of K11's norm pass: with fuse_norm the reduce launch also leaves one partial of ||grads||^2
+     * per workgroup -- ppoaf_mat_update_norm_partials(args) of them: ceil(bucket_total / 1024) in the slab form, one per
+     * wgrad workgroup with split_workspace -- in norm_scratch[2 ..] (float64[2 + that many], at least
      * PPOAF_NORM_SCRATCH_DOUBLES) and advances step_count, so the caller follows with ppoaf_adam_step_prenormed
      * (n_norm_partials = that count) instead of ppoaf_clip_adam_step */
     double* norm_scratch; int64_t* step_count; int32_t fuse_norm;
