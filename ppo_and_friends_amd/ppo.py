@@ -880,7 +880,8 @@ class PPO:
         gloo paths run the two epochs one after the other as the reference does.
         """
         pol = self.policies[policy_id]
-        if not pol.enable_icm or not getattr(self, "overlap_icm", True) or self.device.type != "cuda":
+        if not pol.enable_icm or not getattr(self, "overlap_icm", True) or self.device.type != "cuda" \
+                or os.environ.get("PPOAF_OVERLAP_ICM", "1") == "0":            # (measurement switch: the two epochs in turn)
             return False
         fused = self._fused_updater(policy_id, loader.batch_size)
         fused_icm = self._fused_icm_updater(policy_id)
