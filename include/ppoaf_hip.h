@@ -389,6 +389,12 @@ typedef struct {
      * every workgroup publishes its 16 rows of the inputs, hidden activations and dLoss/dz of the mini-batch there, and
      * ppoaf_ppo_update_wgrad forms the complete gradients from those panels (then ppoaf_ppo_update_adam, compute_norms 3). */
     void* split_workspace; int64_t split_workspace_bytes;
+    /* 0: fwd_bwd's workgroups use every XCD (actor on 0-3, critic on 4-7; default).  1 / 2: they sit on XCDs 0-3 / 4-7 only
+     * (actor on the half's first two XCDs, critic on the other two; the launch is twice as wide and the workgroups
+     * dispatched to the other half return at once): when another update chain (K14: ppoaf_icm_update_args_t.xcd_half)
+     * runs on a second stream, each keeps its weights and panels in its own four L2s -- C3: +2 % env-steps/s; alone the
+     * confinement costs 1 % (C2).  Placement only changes speed. */
+    int32_t xcd_half, _pad2;
 } ppoaf_ppo_update_args_t;
 
 int ppoaf_ppo_update_fwd_bwd(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t stream);
@@ -637,6 +643,10 @@ typedef struct {
      * encoder) on f32 MFMA, biases as column sums of dz, [+ Adam on the spot with fused_adam].  Same call sequence and
      * outputs; sums run in MFMA K order (float32-rounding-level differences from the slab form, bitwise reproducible). */
     void* split_workspace; int64_t split_workspace_bytes;
+    /* 0: the fwd_bwd launches use every XCD (default).  1 / 2: their workgroups sit on XCDs 0-3 / 4-7 only (the launch is
+     * twice as wide and the workgroups dispatched to the other half return at once; workgroup b is dispatched to XCD b % 8):
+     * for the PPO update running on the other half at the same time (ppoaf_ppo_update_args_t.xcd_half). */
+    int32_t xcd_half, _pad2;
 } ppoaf_icm_update_args_t;
 
 int ppoaf_icm_update_fwd_bwd(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream);

@@ -57,7 +57,8 @@ class PpoUpdateArgs(C.Structure):
                 ("min_std", C.c_float), ("inputs_in_batch_order", C.c_int32),
                 ("loss_partials", C.c_void_p), ("totals", C.c_void_p),
                 ("mb_offset", C.c_int64), ("cursor_advance", C.c_int64),
-                ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64)]
+                ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64),
+                ("xcd_half", C.c_int32), ("_pad2", C.c_int32)]
 
 
 ABI_VERSION = 4
@@ -94,7 +95,8 @@ class IcmUpdateArgs(C.Structure):
                 ("icm_beta", C.c_float), ("fused_adam", C.c_int32),
                 ("act_scratch", C.c_void_p), ("denc_scratch", C.c_void_p), ("loss_partials", C.c_void_p),
                 ("totals", C.c_void_p), ("inputs_in_batch_order", C.c_int32), ("_pad", C.c_int32),
-                ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64)]
+                ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64),
+                ("xcd_half", C.c_int32), ("_pad2", C.c_int32)]
 
 
 class MatUpdateArgs(C.Structure):

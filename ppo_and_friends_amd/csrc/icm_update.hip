@@ -15,6 +15,7 @@
 // chains exact, weight gradients are written to private slabs and summed in a fixed order.
 #include "mlp_device.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace ppoaf {
 
@@ -29,7 +30,7 @@ struct IcmDev {
     int64_t* cursor; long B, batch_stride, Bpad;
     float icm_beta; int fused_adam, pregathered;
     float* actE; float* dEnc; float* loss_partials; double* totals;
-    int nT;
+    int nT, confine;
     // split-wgrad chain (args->split_workspace): the three fwd_bwd kernels form NO weight gradient; they publish every
     // layer's dLoss/dz (and the inputs that are not in scratch already) as [rows][width] panels and the reduce launch
     // becomes icm_wgrad_kernel.  Panels (plane = Bpad * H floats):
@@ -66,6 +67,15 @@ __device__ __forceinline__ void icm_publish(const float* __restrict__ src, int H
 
 extern __shared__ __attribute__((aligned(16))) unsigned char icm_smem[];
 
+// args->xcd_half = 1 / 2: the fwd_bwd kernels' workgroups on XCDs 0-3 / 4-7 only (workgroup b is dispatched to XCD b % 8;
+// the launch is twice as wide, the other half's workgroups return at once) -> the block index the kernel works on, or -1
+__device__ __forceinline__ int icm_block(const IcmDev& u) {
+    const int b = blockIdx.x;
+    if (!u.confine) return b;
+    const int x = b & 7;
+    return (x >> 2) != u.confine - 1 ? -1 : ((b >> 3) << 2) | (x & 3);
+}
+
 __device__ __forceinline__ void icm_rows(const IcmDev& u, int g, int tid, int* sRow) {
     if (tid < kRows) {
         const long s = (long)g * kRows + tid;
@@ -91,7 +101,9 @@ template <int HT>
 __global__ __launch_bounds__(kThreadsU) void icm_encoder_fwd_kernel(IcmDev u) {
     constexpr int H = 16 * HT, HS = H + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int which = blockIdx.x & 1, g = blockIdx.x >> 1;
+    const int vb = icm_block(u);
+    if (vb < 0 || vb >= 2 * u.nT) return;
+    const int which = vb & 1, g = vb >> 1;
     const int O = u.O, NT0 = (O + 15) >> 4, INP = 16 * NT0 + 4;
     const float* P = u.params + u.enc_off;
     auto encW = [&](int l) -> long { return l == 0 ? 0 : (long)H * O + H + (long)(l - 1) * (H * H + H); };
@@ -100,7 +112,7 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_fwd_kernel(IcmDev u) {
     int* sRow = reinterpret_cast<int*>(smem);
     float* sX = smem + 16;                      // [16, INP]
     float* sH = sX + kRows * INP;               // 4 x [16, HS]
-    if (blockIdx.x == 0 && tid == 0 && u.fused_adam) {
+    if (vb == 0 && tid == 0 && u.fused_adam) {
         // Adam step counter and the two bias-correction constants of this mini-batch, computed once (in
         // double, as torch.optim.Adam does) and parked behind the loss partials for the reduce kernel
         const int64_t t = u.step_count[0] + 1;
@@ -170,7 +182,9 @@ template <int HT>
 __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
     constexpr int H = 16 * HT, HS = H + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int which = blockIdx.x & 1, g = blockIdx.x >> 1;
+    const int vb = icm_block(u);
+    if (vb < 0 || vb >= 2 * u.nT) return;
+    const int which = vb & 1, g = vb >> 1;
     const int act = u.act, A = u.A, Ain = u.Ain;
     const int depth = which == 0 ? u.d_inv : u.d_fwd;
     const long B = u.B;
@@ -555,10 +569,12 @@ template <int HT>
 __global__ __launch_bounds__(kThreadsU) void icm_encoder_bwd_kernel(IcmDev u) {
     constexpr int H = 16 * HT, HS = H + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int which = blockIdx.x & 1, g = blockIdx.x >> 1;
+    const int vb = icm_block(u);
+    if (vb < 0 || vb >= 2 * u.nT) return;
+    const int which = vb & 1, g = vb >> 1;
     const int O = u.O, NT0 = (O + 15) >> 4, INP = 16 * NT0 + 4;
     const float* P = u.params + u.enc_off;
-    float* slab = u.slabs + (long)blockIdx.x * u.total + u.enc_off;
+    float* slab = u.slabs + (long)vb * u.total + u.enc_off;
     auto encW = [&](int l) -> long { return l == 0 ? 0 : (long)H * O + H + (long)(l - 1) * (H * H + H); };
     auto encB = [&](int l) -> long { return encW(l) + (l == 0 ? (long)H * O : (long)H * H); };
     float* smem = reinterpret_cast<float*>(icm_smem);
@@ -922,6 +938,8 @@ static int make_icm(const ppoaf_icm_update_args_t* a, IcmDev& u, bool training =
     u.Bpad = (long)u.nT * kRows;
     u.icm_beta = a->icm_beta; u.fused_adam = a->fused_adam != 0; u.pregathered = a->inputs_in_batch_order != 0;
     u.actE = a->act_scratch; u.dEnc = a->denc_scratch; u.loss_partials = a->loss_partials; u.totals = a->totals;
+    PPOAF_REQUIRE(a->xcd_half >= 0 && a->xcd_half <= 2, "icm_update: xcd_half=%d (0, 1 or 2)", a->xcd_half);
+    u.confine = training ? a->xcd_half : 0;
     u.split = 0; u.XO = 0;
     u.xO = u.dE = u.hI = u.dI = u.oI = u.hF = u.dF = u.aF = nullptr;
     if (training && a->split_workspace) {
@@ -965,7 +983,7 @@ static int launch_icm_fwd_bwd(const IcmDev& u, hipStream_t s) {
     if (!rc) rc = allow_large_lds(reinterpret_cast<const void*>(icm_heads_kernel<HT>), lds_heads, big_h, "icm_heads");
     if (!rc) rc = allow_large_lds(reinterpret_cast<const void*>(icm_encoder_bwd_kernel<HT>), lds_enc_b, big_b, "icm_encoder_bwd");
     if (rc) return rc;
-    const unsigned grid = 2u * (unsigned)u.nT;
+    const unsigned grid = u.confine ? 8u * (unsigned)((2 * u.nT + 3) / 4) : 2u * (unsigned)u.nT;
     hipLaunchKernelGGL(icm_encoder_fwd_kernel<HT>, dim3(grid), dim3(kThreadsU), lds_enc_f, s, u);
     rc = check_launch("icm_encoder_fwd");
     if (rc) return rc;

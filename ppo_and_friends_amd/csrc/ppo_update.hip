@@ -28,8 +28,14 @@ namespace ppoaf {
 template <int HTA, int HTC, bool SPLIT>
 __global__ __launch_bounds__(kThreadsU) void ppo_update_fwd_bwd_kernel(UpdateDev u) {
     const int b = blockIdx.x;
-    const int which = (b >> 2) & 1;                        // b % 8 in {0..3} -> actor, {4..7} -> critic
-    const int g = ((b >> 3) << 2) | (b & 3);
+    int which = (b >> 2) & 1;                              // b % 8 in {0..3} -> actor, {4..7} -> critic
+    int g = ((b >> 3) << 2) | (b & 3);
+    if (u.confine) {                                       // one half of the XCDs left to another chain (args->xcd_half)
+        const int x = b & 7;
+        if ((x >> 2) != u.confine - 1) return;
+        which = (x & 3) >> 1;                              // the half's first two XCDs: actor, the other two: critic
+        g = ((b >> 3) << 1) | (x & 1);
+    }
     if (g >= u.n_wg) return;                               // uniform per workgroup, before any barrier
     if (which == 0) ppo_update_fwd_bwd_body<HTA, false, UpdateDev, RowtileNoHook, SPLIT>(u, 0, g);
     else ppo_update_fwd_bwd_body<HTC, false, UpdateDev, RowtileNoHook, SPLIT>(u, 1, g);
@@ -522,6 +528,8 @@ int make_update_dev(const ppoaf_ppo_update_args_t* a, UpdateDev& u) {
     u.n_wg = (int)((a->B + kRows - 1) / kRows);
     // split-wgrad chain: the caller's workspace holds this mini-batch's activation / dz panels
     u.split = 0;
+    PPOAF_REQUIRE(a->xcd_half >= 0 && a->xcd_half <= 2, "ppo_update: xcd_half=%d (0, 1 or 2)", a->xcd_half);
+    u.confine = a->xcd_half;
     u.sp = WsDev();
     if (a->split_workspace) {
         PPOAF_REQUIRE((((uintptr_t)a->split_workspace) & 255) == 0, "ppo_update: split_workspace must be 256-byte aligned");
@@ -550,7 +558,7 @@ static int launch_fwd_bwd_as(const UpdateDev& u, size_t lds, hipStream_t s, hipE
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
         attr_set = true;
     }
-    const unsigned grid = 8u * (unsigned)((u.n_wg + 3) / 4);     // groups of 4 actor + 4 critic blocks
+    const unsigned grid = u.confine ? 8u * (unsigned)((u.n_wg + 1) / 2) : 8u * (unsigned)((u.n_wg + 3) / 4);     // groups of 4 actor + 4 critic blocks
     if (e0 || e1)        // the kernel's own begin / end stamped into the events (bench.py: roofline_update)
         hipExtLaunchKernelGGL((ppo_update_fwd_bwd_kernel<HTA, HTC, SPLIT>), dim3(grid), dim3(kThreadsU), lds, s, e0, e1, 0, u);
     else

@@ -35,6 +35,7 @@ struct UpdateDev {
     float surr_clip, entropy_weight, kl_loss_weight, huber_delta, min_std;
     float* loss_partials; double* totals;
     int n_wg;
+    int confine;         // args->xcd_half: 0 every XCD; 1 / 2: fwd_bwd's workgroups on XCDs 0-3 / 4-7 only (actor on two of them, critic on two)
     int split;           // 1: split-wgrad chain -- fwd_bwd publishes activation / dz panels (sp) instead of weight-gradient slabs
     WsDev sp;
 };

@@ -276,6 +276,7 @@ class FusedPolicyUpdate:
         a.min_std = float(getattr(pol.actor.distribution, "min_std", 0.01))
         a.loss_partials = self.loss_partials.data_ptr(); a.totals = self.totals.data_ptr()
         a.mb_offset, a.cursor_advance = 0, 1
+        a.xcd_half = getattr(self, "xcd_half", 0)        # 1 / 2: beside the ICM chain (ppo.py: _ppo_icm_epoch_overlapped)
         a.split_workspace, a.split_workspace_bytes = None, 0
         if self.split:
             if self._split_space is None:            # sized once for the full batch size; a tail mini-batch needs less
@@ -297,7 +298,7 @@ class FusedPolicyUpdate:
                 None if self.adv_records is None else self.adv_records.data_ptr(),
                 float(pol.entropy_weight()), float(pol.surr_clip), float(pol.kl_loss_weight),
                 bool(pol.use_huber_loss), pol.gradient_clip, bool(self.ppo.normalize_adv),
-                bool(self.ppo.normalize_values))
+                bool(self.ppo.normalize_values), getattr(self, "xcd_half", 0))
 
     # ----------------------------------------------------------------- epoch
     def begin_epoch(self, perm):
@@ -864,6 +865,7 @@ class FusedIcmUpdate:
         a.fused_adam = int(not self.multi)
         a.act_scratch, a.denc_scratch = self.act_scratch.data_ptr(), self.denc_scratch.data_ptr()
         a.loss_partials, a.totals = self.loss_partials.data_ptr(), self.totals.data_ptr()
+        a.xcd_half = getattr(self, "xcd_half", 0)
         a.split_workspace, a.split_workspace_bytes = None, 0
         if self.split:
             if self._split_space is None:                # sized once, for the full batch size (a tail mini-batch needs less)
@@ -892,7 +894,7 @@ class FusedIcmUpdate:
         self.cursor.zero_()
         self.totals.zero_()
         sig = (t["obs"].data_ptr(), buf.observations.data_ptr(), buf.next_observations.data_ptr(), buf.actions.data_ptr(),
-               buf.num_transitions, self.perm.data_ptr(), float(pol.icm_beta))
+               buf.num_transitions, self.perm.data_ptr(), float(pol.icm_beta), getattr(self, "xcd_half", 0))
         if self._args.get("sig") != sig:
             self._args = {"sig": sig}
             self._graphs.clear()

@@ -890,6 +890,10 @@ class PPO:
         if mpi_utils.distributed_path() and (fused.xchg is None or fused_icm.xchg is None
                                              or os.environ.get("PPOAF_OVERLAP_ICM_MULTI", "1") == "0"):
             return False
+        # each chain's fwd_bwd launches on its own half of the XCDs: weights and panels of one chain stay out of the other's
+        # four L2s (C3: +2 % env-steps/s; PPOAF_XCD_HALVES=0: both use every XCD)
+        halves = os.environ.get("PPOAF_XCD_HALVES", "1") != "0"
+        fused.xcd_half, fused_icm.xcd_half = (1, 2) if halves else (0, 0)
         fused.begin_epoch(loader.epoch_permutation())
         fused_icm.begin_epoch(loader.epoch_permutation())
         # two concurrent kernel chains: the persistent two-XCD kernel would serialise them (experiment switch only)

@@ -357,3 +357,37 @@ def test_c3_icm_split_wgrad_chain_matches_the_slab_form_at_full_size(monkeypatch
     np.testing.assert_allclose(epochs["1"][0][2][0] / n_mb, epochs["0"][0][2][0] / n_mb, rtol=2e-4)   # (measured 4.4e-5 after 1024 Adam steps)
     a, b = epochs["1"]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_c3_xcd_halves_change_placement_only():
+    """
+    args.xcd_half (K12 / K14 fwd_bwd launches confined to XCDs 0-3 / 4-7, as the overlapped PPO / ICM epochs run them) moves
+    workgroups, not arithmetic: one mini-batch's gradient buckets and loss totals are bitwise those of the unconfined
+    launches, for both halves.
+    """
+    from ppo_and_friends_amd.fused_update import FusedIcmUpdate
+    out = {}
+    for half in (0, 1, 2):
+        ppo, E, T, A = _c_config("C3", use_graphs=False)
+        ppo.rollout()
+        pol = ppo.policies["p"]
+        pol.train()
+        perm = torch.randperm(len(pol.dataset), device=pol.device, generator=torch.Generator(device=pol.device).manual_seed(3))
+        fused = ppo._fused_updater("p", 256)
+        fused.xcd_half = half
+        fused.begin_epoch(perm)
+        args = fused._args_for(256)
+        assert args.xcd_half == half
+        fused.gradient_only(args)
+        icm = FusedIcmUpdate(ppo, "p")
+        icm.xcd_half = half
+        icm.begin_epoch(perm)
+        iargs = icm._args_for(256)
+        assert iargs.xcd_half == half
+        icm._one(iargs)
+        torch.cuda.synchronize()
+        out[half] = (pol.policy_grads.clone(), fused.totals.clone(), pol.icm_model.flat_grads.clone(), pol.icm_model.flat_params.clone(),
+                     icm.totals.clone())
+    for half in (1, 2):
+        for a, b in zip(out[0], out[half]):
+            assert torch.equal(a, b), half
