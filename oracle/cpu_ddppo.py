@@ -24,20 +24,46 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+class GlooComm:
+    """The collective surface of oracle/cpu_ppo_loop.ThreadComm for R processes over torch.distributed/gloo (mpi4py is
+    absent from this image): all-gather of Python / numpy objects, sum all-reduce of an ndarray or a scalar, barrier.
+    For R = 2 gloo's sum is bitwise the rank-ordered fold (a + b == b + a)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist, self.rank, self.size = dist, dist.get_rank(), dist.get_world_size()
+
+    def allgather(self, x):
+        parts = [None] * self.size
+        self.dist.all_gather_object(parts, x)
+        return parts
+
+    def allreduce_sum(self, x):
+        import numpy as np
+        import torch
+        if isinstance(x, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(x).copy())
+            self.dist.all_reduce(t)
+            return t.numpy()
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t)
+        return type(x)(t.item())
+
+    def barrier(self):
+        self.dist.barrier()
+
+
 def _worker(args):
     import numpy as np
     import torch
     import torch.distributed as dist
-    import torch.nn as nn
-    from torch.distributions import Categorical
-    from torch.utils.data import DataLoader
     from oracle import cpu_ppo_loop
-    from oracle import ppo_loss_oracle as lo
 
     torch.set_num_threads(max(int(args.threads), 1))
     R, rank = args.world, args.rank
     if R > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{args.port}", rank=rank, world_size=R)
+    comm = GlooComm() if R > 1 else None
     E, T, O, NA = args.envs, args.ts, 4, 2
     rng = np.random.default_rng(1234 + rank)
     obs_table = rng.standard_normal((T + 1, E, O), dtype=np.float32)
@@ -54,39 +80,10 @@ def _worker(args):
     ppo.rollout(obs_table, rew_table)
     barrier()
     t1 = time.perf_counter()
-    for _ in range(args.epochs):
-        loader = DataLoader(ppo.dataset, batch_size=args.batch, shuffle=True, generator=ppo.loader_generator)
-        for batch in loader:
-            critic_obs, obs, _, raw_actions, _, advantages, log_probs, rewards_tg, _, _, _, _, idxs = batch
-            flat = rewards_tg.flatten().numpy()
-            if R > 1:                                          # stats.py:47-50: gather the raw data of all ranks
-                parts = [None] * R
-                dist.all_gather_object(parts, flat)
-                ppo.value_stats.update(None, gathered=parts)
-            else:
-                ppo.value_stats.update(flat)
-            mean = torch.tensor(ppo.value_stats.mean, dtype=torch.float32)
-            var = torch.tensor(ppo.value_stats.variance, dtype=torch.float32)
-            rewards_tg = (rewards_tg - mean) / torch.sqrt(var + torch.tensor([1e-8]))
-            values = ppo.critic(critic_obs).squeeze()
-            dist_ = Categorical(torch.softmax(ppo.actor(obs), dim=-1))
-            cur_lp = torch.unsqueeze(dist_.log_prob(raw_actions.flatten()), dim=-1)
-            ppo.dataset.values[idxs] = values.detach()
-            r = lo.ppo_minibatch_losses(cur_lp, log_probs, advantages, dist_.entropy(), values, rewards_tg,
-                                        True, ppo.surr_clip, ppo.entropy_weight)
-            for net, opt, loss in ((ppo.actor, ppo.actor_optim, r["actor_loss"]), (ppo.critic, ppo.critic_optim, r["critic_loss"])):
-                opt.zero_grad()
-                loss.backward()
-                if R > 1:                                      # mpi_utils.py:89-111: one all-reduce per parameter tensor
-                    for p in net.parameters():
-                        dist.all_reduce(p.grad)
-                        p.grad /= R
-                nn.utils.clip_grad_norm_(net.parameters(), ppo.gradient_clip)
-                opt.step()
-            barrier()                                          # ppo.py:2468
-        if R > 1:                                              # ppo.py:2471-2476: five scalar all-reduces per epoch
-            for _ in range(5):
-                dist.all_reduce(torch.zeros(1))
+    # the epoch loop itself is the pinned restatement (R = 2 reference fixtures, tests/test_oracle_update_golden.py):
+    # per mini-batch the all-gather inside the value normaliser, one averaged all-reduce PER PARAMETER TENSOR after each
+    # backward, a barrier; per epoch the scalar all-reduces of ppo.py:2471-2476
+    cpu_ppo_loop.train_on_rollout(ppo, args.epochs, comm=comm)
     barrier()
     t2 = time.perf_counter()
     if rank == 0:

@@ -116,6 +116,54 @@ class _ListDataset(Dataset):
                 self.empty[idx], idx)
 
 
+class ThreadComm:
+    """
+    The three collectives the reference's update path uses (mpi4py `comm.allgather`, `comm.allreduce(x, MPI.SUM)`,
+    `comm.barrier`) for R "ranks" that are threads of one process: every call is a rendezvous that hands each rank the
+    rank-ordered list of everybody's objects; sums fold that list in rank order (parts[0] + parts[1] + ...), as the
+    pickle-based collectives of mpi4py apply the Python `+`.  oracle/cpu_ddppo.GlooComm is the same surface for R
+    processes over torch.distributed/gloo.
+    """
+
+    class Shared:
+        def __init__(self, size):
+            import threading
+            self.size, self.slots, self.barrier = size, [None] * size, threading.Barrier(size)
+
+    def __init__(self, shared, rank):
+        self.shared, self.rank, self.size = shared, rank, shared.size
+
+    def allgather(self, x):
+        sh = self.shared
+        sh.slots[self.rank] = x
+        sh.barrier.wait()
+        out = list(sh.slots)
+        sh.barrier.wait()
+        return out
+
+    def allreduce_sum(self, x):
+        parts = self.allgather(x)
+        out = parts[0]
+        for p in parts[1:]:
+            out = out + p
+        return out
+
+    def barrier(self):
+        self.shared.barrier.wait()
+
+
+def avg_gradients(params, comm):
+    """mpi_avg_gradients (utils/mpi_utils.py:89-111): one all-reduce(SUM) / num_procs per parameter TENSOR, written back
+    in place; parameters without a gradient are skipped."""
+    if comm is None or comm.size == 1:
+        return
+    for p in params:
+        if p.grad is None:
+            continue
+        g = p.grad.numpy()                                   # CPU tensor: a view, as `.cpu().numpy()` is in the reference
+        g[...] = comm.allreduce_sum(g.copy()) / comm.size
+
+
 class CpuPPO:
     """One rank of the reference's PPO on CPU for a Discrete-action MLP policy and a table-driven env."""
 
@@ -161,8 +209,12 @@ class CpuPPO:
         var = torch.tensor(self.value_stats.variance, dtype=torch.float32)
         return mean + v * torch.sqrt(var + torch.tensor([1e-8]))
 
-    def _norm_update(self, x):
-        self.value_stats.update(x.detach().cpu().numpy())
+    def _norm_update(self, x, comm=None):
+        data = x.detach().cpu().numpy()
+        if comm is not None and comm.size > 1:               # utils/stats.py:47-50: the raw data of ALL ranks, concatenated
+            self.value_stats.update(None, gathered=comm.allgather(data))
+        else:
+            self.value_stats.update(data)
         mean = torch.tensor(self.value_stats.mean, dtype=torch.float32)
         var = torch.tensor(self.value_stats.variance, dtype=torch.float32)
         return (x - mean) / torch.sqrt(var + torch.tensor([1e-8]))
@@ -174,7 +226,7 @@ class CpuPPO:
 
     # ----- rollout (ppo.py:1646-1983) on pre-generated observation / reward tables
     def rollout(self, obs_table, reward_table, actions=None, term_table=None, max_ts_per_ep=None,
-                critic_obs_table=None):
+                critic_obs_table=None, comm=None):
         """
         obs_table [T+1,E,O], reward_table [T,E] numpy.  actions (optional [T,E])
         replays a recorded rollout instead of sampling.  term_table (optional bool
@@ -271,6 +323,8 @@ class CpuPPO:
             cur_total = total_episodes if total_episodes != 0 else 1.0
             avg_ep_len = combined / E if ts_before == 0 else ts_before / cur_total
             total_episodes += float((episode_lengths / avg_ep_len).sum())
+            if comm is not None and comm.size > 1:     # ppo.py:1991, 2076-2077: episodes and intrinsic rewards of every rank
+                total_episodes, total_intr = comm.allreduce_sum(total_episodes), comm.allreduce_sum(total_intr)
             self.intrinsic_score_avg = total_intr / (total_episodes / E)
         self.dataset = _ListDataset(finished, torch.float32 if self.continuous else torch.long)
         return self.dataset
@@ -281,8 +335,8 @@ class CpuPPO:
             return DataLoader(self.dataset, batch_size=self.batch_size, sampler=[int(i) for i in perm])
         return DataLoader(self.dataset, batch_size=self.batch_size, shuffle=True, generator=self.loader_generator)
 
-    def icm_train_epoch(self, perm=None):
-        """ppo.py:2487-2567."""
+    def icm_train_epoch(self, perm=None, comm=None):
+        """ppo.py:2487-2567; `comm` (R > 1): mpi_avg_gradients(icm_model) :2559, all-reduced totals :2565-2567."""
         loader = self._loader(perm)
         total, n = 0.0, 0
         for batch in loader:
@@ -294,18 +348,25 @@ class CpuPPO:
             total += icm_loss.item()
             self.icm_optim.zero_grad()
             icm_loss.backward()
+            avg_gradients(self.icm.parameters(), comm)
             self.icm_optim.step()
             n += 1
+        if comm is not None and comm.size > 1:
+            n, total = comm.allreduce_sum(n), comm.allreduce_sum(total)
         return total / max(n, 1)
 
     # ----- one epoch (ppo.py:2274-2485)
-    def train_epoch(self, perm=None):
+    def train_epoch(self, perm=None, comm=None):
+        """`comm` (R > 1 ranks, see ThreadComm): the reference's DD-PPO exchanges -- the value normaliser sees the
+        rewards-to-go of every rank's mini-batch (utils/stats.py:47-50), every parameter tensor's gradient is averaged
+        over the ranks after each backward (utils/mpi_utils.py:89-111, ppo_policy.py:1035,1048), a barrier per
+        mini-batch (ppo.py:2468), and the epoch's five totals are summed over the ranks (ppo.py:2471-2475)."""
         loader = self._loader(perm)
         tot = dict(actor=0.0, critic=0.0, entropy=0.0, kl=0.0, n=0)
         for batch in loader:
             critic_obs, obs, _, raw_actions, _, advantages, log_probs, rewards_tg, _, _, _, _, idxs = batch
             if self.normalize_values:
-                rewards_tg = self._norm_update(rewards_tg.flatten()).reshape(rewards_tg.shape)
+                rewards_tg = self._norm_update(rewards_tg.flatten(), comm).reshape(rewards_tg.shape)
             if obs.shape[0] == 1:
                 continue
             values = self.critic(critic_obs).squeeze()
@@ -330,76 +391,89 @@ class CpuPPO:
                                        critic_grad=torch.cat([x.reshape(-1) for x in gc]).numpy()))
             self.actor_optim.zero_grad()
             r["actor_loss"].backward()
+            avg_gradients(self.actor_params, comm)
+            if getattr(self, "trace", None) is not None and comm is not None:
+                self.trace[-1]["actor_avg_grad"] = torch.cat([p.grad.reshape(-1) for p in self.actor_params]).numpy().copy()
             nn.utils.clip_grad_norm_(self.actor_params, self.gradient_clip)
             self.actor_optim.step()
             self.critic_optim.zero_grad()
             r["critic_loss"].backward()
+            avg_gradients(self.critic.parameters(), comm)
+            if getattr(self, "trace", None) is not None and comm is not None:
+                self.trace[-1]["critic_avg_grad"] = torch.cat([p.grad.reshape(-1) for p in self.critic.parameters()]).numpy().copy()
             nn.utils.clip_grad_norm_(self.critic.parameters(), self.gradient_clip)
             self.critic_optim.step()
+            if comm is not None:
+                comm.barrier()                                   # ppo.py:2468
             tot["actor"] += r["surr"]; tot["critic"] += r["critic"]
             tot["entropy"] += r["entropy"]; tot["kl"] += r["kl"]; tot["n"] += 1
+        if comm is not None and comm.size > 1:                   # ppo.py:2471-2475
+            for k in ("n", "entropy", "actor", "critic", "kl"):
+                tot[k] = comm.allreduce_sum(tot[k])
         n = max(tot["n"], 1)
         return {"actor loss": tot["actor"] / n, "critic loss": tot["critic"] / n,
                 "weighted entropy": tot["entropy"] * self.entropy_weight / n, "kl avg": tot["kl"] / n}
 
 
-def ddppo_train_epoch(ranks):
+def train_on_rollout(cpu, epochs_per_iter, target_kl=100.0, perms=None, icm_perms=None, on_epoch=None, comm=None):
     """
-    One epoch of the reference's DD-PPO over R in-process "ranks" (list of CpuPPO with identical
-    weights, each with its own dataset and shuffle generator): per mini-batch every rank normalises
-    its rewards-to-go with stats updated from the data of ALL ranks (utils/stats.py:47-54), computes
-    its losses and gradients, the gradients are averaged tensor by tensor (utils/mpi_utils.py:89-111)
-    and every rank takes the same clip + Adam step (policies/ppo_policy.py:1032-1055).
-    Returns the rank-averaged epoch statistics (ppo.py:2471-2485).
+    The epoch loop of PPO.learn with its KL early stop (ppo.py:2201-2232): per epoch one `_ppo_batch_train` pass, then --
+    with ICM -- one `_icm_batch_train` pass (:2213-2214, BEFORE the test, so the stopping epoch still trains the ICM),
+    then `if status["kl avg"] > target_kl: break` (:2222-2232; strict `>`).  `perms` / `icm_perms` replay recorded
+    shuffles (one per epoch actually run).  With `comm` (R > 1 ranks) the statistics are the all-reduced ones, so every
+    rank takes the same decision (the `comm.barrier()` of :2221 carries no data).  Returns the list of per-epoch
+    statistics dicts (+ "icm loss").
     """
-    R = len(ranks)
-    loaders = [iter(DataLoader(r.dataset, batch_size=r.batch_size, shuffle=True, generator=r.loader_generator))
-               for r in ranks]
-    tot = dict(actor=0.0, critic=0.0, entropy=0.0, kl=0.0, n=0)
-    while True:
-        batches = []
-        for it in loaders:          # every rank's loader is driven to exhaustion (each draws from its own RNG)
-            try:
-                batches.append(next(it))
-            except StopIteration:
-                pass
-        if len(batches) < R:
+    out = []
+    for epoch_idx in range(epochs_per_iter):
+        kw = {} if comm is None else {"comm": comm}
+        stats = cpu.train_epoch(perm=None if perms is None else perms[epoch_idx], **kw)
+        if getattr(cpu, "enable_icm", False):
+            stats["icm loss"] = cpu.icm_train_epoch(perm=None if icm_perms is None else icm_perms[epoch_idx], **kw)
+        out.append(stats)
+        if on_epoch is not None:
+            on_epoch(epoch_idx, stats)
+        if stats["kl avg"] > target_kl:
             break
-        gathered = [b[7].flatten().numpy() for b in batches]          # rewards_to_go of every rank
-        outs = []
-        for r, batch in zip(ranks, batches):
-            critic_obs, obs, _, raw_actions, _, advantages, log_probs, rewards_tg, _, _, _, _, idxs = batch
-            if r.normalize_values:
-                r.value_stats.update(None, gathered=gathered)
-                mean = torch.tensor(r.value_stats.mean, dtype=torch.float32)
-                var = torch.tensor(r.value_stats.variance, dtype=torch.float32)
-                rewards_tg = (rewards_tg - mean) / torch.sqrt(var + torch.tensor([1e-8]))
-            values = r.critic(critic_obs).squeeze()
-            dist = Categorical(torch.softmax(r.actor(obs), dim=-1))
-            cur_lp = torch.unsqueeze(dist.log_prob(raw_actions.flatten()), dim=-1)
-            r.dataset.values[idxs] = values.detach()
-            o = lo.ppo_minibatch_losses(cur_lp, log_probs, advantages, dist.entropy(), values, rewards_tg,
-                                        r.normalize_adv, r.surr_clip, r.entropy_weight)
-            r.actor_optim.zero_grad(); r.critic_optim.zero_grad()
-            o["actor_loss"].backward(); o["critic_loss"].backward()
-            outs.append(o)
-        for nets in (lambda r: r.actor, lambda r: r.critic):
-            for ps in zip(*[list(nets(r).parameters()) for r in ranks]):
-                avg = sum(p.grad for p in ps) / R
-                for p in ps:
-                    p.grad = avg.clone()
-        for r in ranks:
-            nn.utils.clip_grad_norm_(r.actor.parameters(), r.gradient_clip)
-            r.actor_optim.step()
-            nn.utils.clip_grad_norm_(r.critic.parameters(), r.gradient_clip)
-            r.critic_optim.step()
-        for o in outs:
-            tot["actor"] += o["surr"]; tot["critic"] += o["critic"]
-            tot["entropy"] += o["entropy"]; tot["kl"] += o["kl"]; tot["n"] += 1
-    n = max(tot["n"], 1)
-    ew = ranks[0].entropy_weight
-    return {"actor loss": tot["actor"] / n, "critic loss": tot["critic"] / n,
-            "weighted entropy": tot["entropy"] * ew / n, "kl avg": tot["kl"] / n}
+    return out
+
+
+def run_ranks(fns):
+    """Run one callable per rank, each on its own thread with a ThreadComm; returns their results in rank order
+    (an exception on any rank is re-raised here)."""
+    import threading
+    shared = ThreadComm.Shared(len(fns))
+    out, err = [None] * len(fns), []
+
+    def body(r):
+        try:
+            out[r] = fns[r](ThreadComm(shared, r))
+        except BaseException as e:           # noqa: BLE001 -- release the other ranks, then re-raise below
+            err.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(len(fns))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if err:
+        first = [e for e in err if not isinstance(e, threading.BrokenBarrierError)] or err
+        raise first[0]
+    return out
+
+
+def ddppo_train_epoch(ranks, perms=None):
+    """
+    One epoch of the reference's DD-PPO over R in-process "ranks" (list of CpuPPO with identical weights, each with its
+    own dataset and shuffle generator): every rank runs CpuPPO.train_epoch on its own thread with a ThreadComm, i.e. the
+    exchanges of utils/stats.py:47-54, utils/mpi_utils.py:89-111 and ppo.py:2468-2475 at the points where the reference
+    makes them.  Pinned by the R = 2 reference fixtures (tests/test_oracle_update_golden.py).  Returns the all-reduced
+    epoch statistics (identical on every rank).
+    """
+    stats = run_ranks([(lambda comm, r=r, i=i: r.train_epoch(perm=None if perms is None else perms[i], comm=comm))
+                       for i, r in enumerate(ranks)])
+    return stats[0]
 
 
 def time_iteration(E, T, obs_dim=4, n_actions=2, epochs=10, batch_size=256, seed=1234, threads=None):

@@ -120,13 +120,15 @@ def _flat_state(module):
 
 def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term_prob=0.0, max_ts_per_ep=200,
                  batch_size=64, epochs=2, iterations=1, critic_view="local", policy_class=None, policy_args=None,
-                 ppo_args=None, obs_scale=1.0, obs_shift=0.0, ac_network=None):
+                 ppo_args=None, obs_scale=1.0, obs_shift=0.0, ac_network=None, rank=0):
+    """`rank`: this process's rank under the R-process mpi4py stand-in (ref_import.py): its own environment tables and
+    seed + rank for everything random, as `ppoaf train` seeds its ranks (ppoaf_cli.py:419)."""
     from ppo_and_friends.ppo import PPO
     from ppo_and_friends.networks.ppo_networks.feed_forward import FeedForwardNetwork
     from torch.utils.data import DataLoader
 
     TableEnv = table_env_class()
-    tables = make_tables(seed, T, E, A, O, reward, term_prob, obs_scale, obs_shift)
+    tables = make_tables(seed + 7919 * rank, T, E, A, O, reward, term_prob, obs_scale, obs_shift)
     counter = {"n": 0}
     instances = []
     pmap = lambda agent_id: "agent"
@@ -146,9 +148,9 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
     settings = {"agent": (policy_class, obs_space, cobs_space, action_space, pargs)}
 
     state_dir = tempfile.mkdtemp(prefix="ppoaf_golden_state_")
-    torch.manual_seed(seed)
-    np.random.seed(seed)
-    kw = dict(device="cpu", random_seed=seed, envs_per_proc=E, max_ts_per_ep=max_ts_per_ep, batch_size=batch_size,
+    torch.manual_seed(seed + rank)
+    np.random.seed(seed + rank)
+    kw = dict(device="cpu", random_seed=seed + rank, envs_per_proc=E, max_ts_per_ep=max_ts_per_ep, batch_size=batch_size,
               ts_per_rollout=T, epochs_per_iter=epochs, normalize_obs=False, normalize_rewards=False,
               state_path=state_dir, save_train_scores=False, save_ep_scores=False, save_avg_ep_len=False,
               save_running_time=False, save_bs_info=False, checkpoint_every=10 ** 9)
@@ -262,6 +264,21 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
 
     pol.update_weights = rec_update
 
+    # what mpi_avg_gradients (utils/mpi_utils.py:89-111) left in .grad on the first mini-batch: the rank-averaged gradient
+    import ppo_and_friends.policies.ppo_policy as ref_policy_module
+    import ppo_and_friends.ppo as ref_ppo_module
+    orig_avg = ref_policy_module.mpi_avg_gradients
+
+    def rec_avg(model):
+        orig_avg(model)
+        tag = "actor" if model is pol.actor else "critic" if model is pol.critic else "icm"
+        if tag not in rec.setdefault("avg_grads", {}):
+            rec["avg_grads"][tag] = np.concatenate([np.zeros(p.numel(), np.float32) if p.grad is None else
+                                                    p.grad.detach().numpy().reshape(-1).copy() for p in model.parameters()])
+
+    ref_policy_module.mpi_avg_gradients = rec_avg
+    ref_ppo_module.mpi_avg_gradients = rec_avg
+
     orig_train = ppo._ppo_batch_train
 
     def harvest_perm(data_loader):
@@ -275,7 +292,11 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
         perm = harvest_perm(data_loader)
         orig_train(data_loader, policy_id)
         sd = ppo.status_dict[policy_id]
-        rec["epochs"].append(dict(kind="ppo", perm=perm, stats=np.array(
+        vs = None
+        if ppo.normalize_values:
+            rs_ = ppo.value_normalizers[policy_id].running_stats
+            vs = np.array([rs_.mean, rs_.variance, rs_.count], dtype=np.float64)
+        rec["epochs"].append(dict(kind="ppo", perm=perm, value_stats=vs, stats=np.array(
             [sd["actor loss"], sd["critic loss"], sd["kl avg"], sd["weighted entropy"]], dtype=np.float64)))
 
     ppo._ppo_batch_train = rec_train
@@ -296,10 +317,15 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
     def rec_rollout():
         orig_rollout()
         status_after_rollout.append(copy.deepcopy(ppo.status_dict))
+        rec.setdefault("ppo_epochs_before_rollout", []).append(sum(e["kind"] == "ppo" for e in rec["epochs"]))
 
     ppo.rollout = rec_rollout
 
-    ppo.learn(E * T * iterations)
+    try:
+        ppo.learn(E * T * iterations * max(int(os.environ.get("PPOAF_FAKE_MPI_SIZE", "1")), 1))   # (timesteps count every rank's)
+    finally:
+        ref_policy_module.mpi_avg_gradients = orig_avg
+        ref_ppo_module.mpi_avg_gradients = orig_avg
 
     # ---- pack
     agents = [f"agent{a}" for a in range(A)]
@@ -321,6 +347,16 @@ def run_scenario(name, *, seed, E, T, A, O, action_space, reward="uniform", term
             out[f"it{i}_ds_{k}"] = v
     ppo_ep = [e for e in rec["epochs"] if e["kind"] == "ppo"]
     icm_ep = [e for e in rec["epochs"] if e["kind"] == "icm"]
+    # PPO epochs the reference actually ran in each iteration: fewer than `epochs` when the KL early stop of
+    # ppo.py:2221-2232 broke out of the epoch loop
+    if int(os.environ.get("PPOAF_FAKE_MPI_SIZE", "1")) > 1:   # (R-rank fixtures only: older fixtures regenerate unchanged)
+        for tag, v in rec.get("avg_grads", {}).items():
+            out[f"mb0_{tag}_avg_grad"] = v          # identical on every rank: the all-reduced mean of the ranks' gradients
+        out["epoch_value_stats"] = np.stack([e["value_stats"] for e in ppo_ep])       # after every PPO epoch
+    if "target_kl" in pargs:                  # (only the KL-stop scenarios carry these: older fixtures regenerate unchanged)
+        marks = rec["ppo_epochs_before_rollout"] + [len(ppo_ep)]
+        out["epochs_run"] = np.diff(np.array(marks, dtype=np.int64))
+        out["target_kl"] = np.array([float(pol.target_kl)], dtype=np.float64)
     out["epoch_perms"] = np.stack([e["perm"] for e in ppo_ep])
     out["epoch_stats"] = np.stack([e["stats"] for e in ppo_ep])         # actor loss, critic loss, kl avg, weighted entropy
     if icm_ep:
@@ -599,13 +635,78 @@ def scenarios():
     sc["g12_c5_b256"] = dict(seed=129, E=1, T=512, A=3, O=18, action_space=Discrete(5), reward="uniform", term_prob=0.0,
                              max_ts_per_ep=512, batch_size=256, epochs=2, iterations=1, critic_view="local", policy_class=MATPolicy,
                              ac_network=mat.MATActorCritic, policy_args=dict(mat_kw_args={"embedding size": 64}))
+    # ---- KL early stop (ppo.py:2221-2232): 4 epochs allowed, a learning rate / target_kl pair under which the reference
+    # leaves the epoch loop early (`epochs_run` records after how many epochs, per iteration); with ICM the ICM pass of
+    # the stopping epoch still runs before the break (ppo.py:2213-2214 precede the test)
+    sc["g12_c2_klstop"] = dict(seed=131, E=16, T=32, A=1, O=4, action_space=Discrete(2), reward="ones", term_prob=0.06,
+                               batch_size=64, epochs=4, iterations=2, policy_args=dict(target_kl=0.01, lr=1e-3))
+    sc["g12_c2_icm_klstop"] = dict(seed=131, E=16, T=32, A=1, O=4, action_space=Discrete(2), reward="ones", term_prob=0.06,
+                                   batch_size=64, epochs=4, iterations=2,
+                                   policy_args=dict(target_kl=0.005, lr=3e-3, enable_icm=True))
     sc["g12_lstm_cut"] = dict(seed=111, E=4, T=18, A=1, O=4, action_space=Discrete(3), reward="uniform", term_prob=0.0,
                               max_ts_per_ep=6, batch_size=16, epochs=2, iterations=1, ac_network=LSTMNetwork,
                               policy_args=dict(actor_kw_args=lstm_kw(3), critic_kw_args=lstm_kw(3)))
     return sc
 
 
+def rank_scenarios():
+    """R = 2 ranks of the unmodified reference under the two-process mpi4py stand-in (ref_import.py): what pins the DD-PPO
+    arithmetic -- mpi_avg_gradients (utils/mpi_utils.py:50-111), the value normaliser's per-mini-batch allgather of raw
+    data (utils/stats.py:47-50), the per-epoch all-reduced statistics that drive the KL early stop (ppo.py:2468-2475,
+    2221-2232), the rank-0 broadcast of the initial weights (ppo_policy.py:457-471).  One fixture holds both ranks
+    (keys r0.* / r1.*)."""
+    from gymnasium.spaces import Discrete
+    import torch.nn as nn
+    leaky = lambda: {"activation": nn.LeakyReLU(), "hidden_size": 128}
+    big = lambda: {"activation": nn.LeakyReLU(), "hidden_size": 256}
+    sc = {}
+    sc["g12_c2_r2"] = dict(seed=141, E=16, T=32, A=1, O=4, action_space=Discrete(2), reward="ones", term_prob=0.06,
+                           batch_size=256, epochs=2, iterations=2)
+    sc["g12_c4_r2"] = dict(seed=144, E=6, T=32, A=3, O=18, action_space=Discrete(5), reward="uniform", term_prob=0.05,
+                           batch_size=256, epochs=2, iterations=1, critic_view="policy",
+                           policy_args=dict(actor_kw_args=leaky(), critic_kw_args=big()))
+    # ICM (mpi_avg_gradients(icm_model), ppo.py:2559) + KL early stop decided on all-reduced totals, on two ranks
+    sc["g12_c2_icm_r2_klstop"] = dict(seed=148, E=16, T=32, A=1, O=4, action_space=Discrete(2), reward="ones", term_prob=0.06,
+                                      batch_size=64, epochs=4, iterations=2,
+                                      policy_args=dict(target_kl=RANK_KL_TARGET, lr=3e-3, enable_icm=True))
+    return sc
+
+
+RANK_KL_TARGET = float(os.environ.get("PPOAF_GOLDEN_KL_TARGET", "0.005"))
+RANKS = 2
+
+
+def run_rank_scenario(name):
+    """Parent: start RANKS children of this script (one reference process per rank), merge their arrays."""
+    import subprocess
+    tmp = tempfile.mkdtemp(prefix="ppoaf_golden_ranks_")
+    addr = os.path.join(tmp, "hub.sock")
+    procs = []
+    for r in range(RANKS):
+        env = dict(os.environ, PYTHONHASHSEED="0", PPOAF_FAKE_MPI_RANK=str(r), PPOAF_FAKE_MPI_SIZE=str(RANKS), PPOAF_FAKE_MPI_ADDR=addr)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank-child", name, os.path.join(tmp, f"rank{r}.npz")],
+                                      env=env, stdout=subprocess.DEVNULL))
+    for p_ in procs:
+        if p_.wait() != 0:
+            raise RuntimeError(f"{name}: a rank failed")
+    out = {"ranks": np.array([RANKS], dtype=np.int64)}
+    for r in range(RANKS):
+        with np.load(os.path.join(tmp, f"rank{r}.npz")) as g:
+            out.update({f"r{r}.{k}": g[k] for k in g.files})
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--rank-child":
+        scratch = ref_import.make_scratch()
+        try:
+            out = run_scenario(sys.argv[2], rank=int(os.environ["PPOAF_FAKE_MPI_RANK"]), **rank_scenarios()[sys.argv[2]])
+            np.savez_compressed(sys.argv[3], **out)
+        finally:
+            ref_import.drop_scratch(scratch)
+        return
     only = set(sys.argv[1:])
     scratch = ref_import.make_scratch()
     try:
@@ -620,6 +721,13 @@ def main():
             if only and name not in only:
                 continue
             out = run_scenario(name, **cfg)
+            path = os.path.join(HERE, name + ".npz")
+            np.savez_compressed(path, **out)
+            print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} B")
+        for name in rank_scenarios():
+            if only and name not in only:
+                continue
+            out = run_rank_scenario(name)
             path = os.path.join(HERE, name + ".npz")
             np.savez_compressed(path, **out)
             print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} B")

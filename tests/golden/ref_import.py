@@ -3,7 +3,10 @@ Import recipe for the *unmodified* reference (build container only; /root/refere
 
 A scratch directory under /tmp goes on sys.path holding
   (i)   a symlink  ppo_and_friends -> /root/reference        (mirrors setup.py:6-13)
-  (ii)  a single-rank stand-in for `mpi4py`                  (rank 0 of 1; collectives = identity)
+  (ii)  a stand-in for `mpi4py`: rank 0 of 1 (collectives = identity) by default; with PPOAF_FAKE_MPI_SIZE=R in the
+        environment a REAL R-process communicator over a unix socket (rank 0 is the hub): allgather / allreduce /
+        Bcast / barrier move the ranks' objects and fold them in rank order, so the reference's own
+        mpi_avg_gradients / RunningMeanStd.update(allgather) / per-epoch allreduces run as they do under mpirun
   (iii) metadata-only stand-ins for `gymnasium(.spaces)` and `gym(.spaces)`:
         Box / Discrete / MultiDiscrete / MultiBinary / Tuple / Dict carrying shape, dtype, n, nvec,
         low, high -- NO arithmetic any fixture depends on, so every recorded number comes from the
@@ -30,6 +33,62 @@ class _Comm:
     def bcast(self, x, root=0): return x
     def barrier(self): return None
     def Barrier(self): return None
+    def Abort(self, code=1): raise RuntimeError('MPI Abort')
+class MPI:
+    COMM_WORLD = _Comm()
+    SUM = 'sum'; MAX = 'max'; MIN = 'min'
+'''
+
+# R processes (make_golden_update.py starts them): PPOAF_FAKE_MPI_RANK / _SIZE / _ADDR (a unix socket path).
+# Every collective is one gather-to-rank-0 + scatter of the rank-ordered list; reductions fold that list in rank order
+# with the Python operator mpi4py's lowercase (pickle) collectives apply: SUM -> a + b, MAX -> max, MIN -> min.
+# (For R = 2 a floating-point sum does not depend on the order at all: a + b == b + a bit for bit.)
+_MPI4PY_MULTI = '''
+import os as _os, time as _time
+import numpy as _np
+from multiprocessing.connection import Listener as _Listener, Client as _Client
+_RANK = int(_os.environ["PPOAF_FAKE_MPI_RANK"]); _SIZE = int(_os.environ["PPOAF_FAKE_MPI_SIZE"])
+_ADDR = _os.environ["PPOAF_FAKE_MPI_ADDR"]
+class _Comm:
+    def __init__(self):
+        if _RANK == 0:
+            lst = _Listener(_ADDR, family="AF_UNIX")
+            self._peers = {}
+            for _ in range(_SIZE - 1):
+                c = lst.accept(); self._peers[c.recv()] = c
+        else:
+            for _ in range(600):
+                try:
+                    self._hub = _Client(_ADDR, family="AF_UNIX"); break
+                except (FileNotFoundError, ConnectionRefusedError):
+                    _time.sleep(0.1)
+            self._hub.send(_RANK)
+    def _everyone(self, x):
+        """-> [rank 0's x, rank 1's x, ...] on every rank."""
+        if _RANK == 0:
+            parts = [x] + [self._peers[r].recv() for r in range(1, _SIZE)]
+            for r in range(1, _SIZE):
+                self._peers[r].send(parts)
+            return parts
+        self._hub.send(x)
+        return self._hub.recv()
+    def Get_rank(self): return _RANK
+    def Get_size(self): return _SIZE
+    def allgather(self, x): return self._everyone(x)
+    def allreduce(self, x, op=None):
+        parts = self._everyone(x)
+        out = parts[0]
+        for p in parts[1:]:
+            out = (out + p) if op in (None, "sum") else (max(out, p) if op == "max" else min(out, p))
+        return out
+    def Allreduce(self, send, recv, op=None): _np.copyto(recv, self.allreduce(_np.asarray(send), op))
+    def Bcast(self, buf, root=0):
+        parts = self._everyone(_np.array(buf, copy=True) if _RANK == root else None)
+        if _RANK != root:
+            _np.copyto(buf, parts[root])
+    def bcast(self, x, root=0): return self._everyone(x if _RANK == root else None)[root]
+    def barrier(self): self._everyone(None)
+    def Barrier(self): self._everyone(None)
     def Abort(self, code=1): raise RuntimeError('MPI Abort')
 class MPI:
     COMM_WORLD = _Comm()
@@ -119,7 +178,8 @@ def make_scratch():
     sys.dont_write_bytecode = True
     scratch = tempfile.mkdtemp(prefix="ppoaf_golden_")
     os.symlink(REFERENCE, os.path.join(scratch, "ppo_and_friends"))
-    _write(os.path.join(scratch, "mpi4py", "__init__.py"), _MPI4PY)
+    multi = int(os.environ.get("PPOAF_FAKE_MPI_SIZE", "1")) > 1
+    _write(os.path.join(scratch, "mpi4py", "__init__.py"), _MPI4PY_MULTI if multi else _MPI4PY)
     _write(os.path.join(scratch, "gymnasium", "__init__.py"), _GYMNASIUM)
     _write(os.path.join(scratch, "gymnasium", "spaces", "__init__.py"), _GYMNASIUM_SPACES)
     _write(os.path.join(scratch, "gym", "__init__.py"), "from . import spaces\n")

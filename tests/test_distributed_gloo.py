@@ -186,3 +186,32 @@ def test_replica_checksum_sees_one_ulp():
     mp.spawn(_checksum_rank, args=(2, _free_port(), out), nprocs=2, join=True)
     for r in range(2):
         assert out[r] == (True, False, True)
+
+
+def _ddppo_rank(rank, world, port, name):
+    """One gloo process = one rank of the reference's R = 2 run, replayed through the CPU port with cpu_ddppo.GlooComm."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [here, os.path.dirname(here)]
+    import torch.distributed as dist
+    from oracle import cpu_ddppo
+    import test_oracle_update_golden as replay
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = np.load(os.path.join(here, "golden", name + ".npz"), allow_pickle=False)
+    replay.replay_fixture(replay.RankView(g, rank), replay.RANK_SCENARIOS[name], cpu_ddppo.GlooComm())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["g12_c2_r2", "g12_c2_icm_r2_klstop"])
+def test_cpu_ddppo_over_gloo_reproduces_two_ranks_of_the_reference(name):
+    """
+    oracle/cpu_ddppo.py -- the R-process CPU baseline bench.py times (`cpu_baseline_mpi`) -- on the collectives it really
+    uses (torch.distributed / gloo between processes), against fixtures recorded from TWO ranks of the unmodified
+    reference: per-tensor gradient averaging (utils/mpi_utils.py:89-111), the value normaliser's all-gather of raw data
+    (utils/stats.py:47-50), all-reduced epoch totals and the KL early stop both ranks take together (ppo.py:2468-2475,
+    2221-2232).  Every check is made inside the rank processes (test_oracle_update_golden.replay_fixture).
+    """
+    import torch.multiprocessing as mp
+    mp.spawn(_ddppo_rank, args=(2, _free_port(), name), nprocs=2, join=True)

@@ -38,6 +38,11 @@ FF_SCENARIOS = {
     "g12_c3_b256": (dict(leaky=True, lr=1e-4, enable_icm=True),
                     dict(normalize_obs=True, normalize_rewards=True, obs_clip=(-2.0, 2.0), reward_clip=(-1.5, 1.5))),
 }
+# KL early stop (ppo.py:2221-2232): run through PPO.train_on_rollout itself, see test_kl_early_stop_matches_the_reference
+KLSTOP_SCENARIOS = {
+    "g12_c2_klstop": (dict(lr=1e-3, target_kl=0.01), {}),
+    "g12_c2_icm_klstop": (dict(lr=3e-3, target_kl=0.005, enable_icm=True), {}),
+}
 B256 = ["g12_c2_b256", "g12_c3_b256", "g12_c4_b256"]
 
 
@@ -83,7 +88,7 @@ def make_product(g, name, update_mode, dev):
     from ppo_and_friends_amd.spaces import Box, Discrete
     c = _cfg(g)
     E, T, A, O = c["E"], c["T"], c["A"], c["O"]
-    pk, ppo_kw = FF_SCENARIOS[name]
+    pk, ppo_kw = {**FF_SCENARIOS, **KLSTOP_SCENARIOS, **RANK_SCENARIOS}[name]
     names = set(g.files)
     continuous = "init_actor.distribution.log_std" in names
     n_out = int(g["init_actor.sequential_net.3.weight"].shape[0])
@@ -115,7 +120,8 @@ def make_product(g, name, update_mode, dev):
     akw, ckw = dict(hidden_size=h_a), dict(hidden_size=h_c)
     if pk.get("leaky"):
         akw["activation"], ckw["activation"] = nn.LeakyReLU(), nn.LeakyReLU()
-    pargs = dict(actor_kw_args=akw, critic_kw_args=ckw, lr=pk.get("lr", 3e-4), enable_icm=pk.get("enable_icm", False))
+    pargs = dict(actor_kw_args=akw, critic_kw_args=ckw, lr=pk.get("lr", 3e-4), enable_icm=pk.get("enable_icm", False),
+                 target_kl=pk.get("target_kl", 100.))
     sp, csp = Box(-np.inf, np.inf, (O,), np.float32), Box(-np.inf, np.inf, (c_in,), np.float32)
     kw = dict(normalize_obs=False, normalize_rewards=False)
     kw.update(ppo_kw)
@@ -187,6 +193,58 @@ def first_minibatch_probe(ppo, pol, perm, B):
     return totals.cpu().numpy().copy(), pol.policy_grads.clone()
 
 
+def replay_rollout_and_check(ppo, pol, g, c, it, continuous, dev):
+    """One rollout of the product with the reference's recorded raw actions replayed: per-step quantities, the dataset and
+    the rollout statistics block against the fixture.  Returns pi (dataset row of the product for every reference row)."""
+    E, T, A = c["E"], c["T"], c["A"]
+    tol = dict(rtol=1e-5, atol=1e-5)                                   # north_star: within 1e-5 (fp32)
+    keys, rkeys, gkeys = (list(g[k]) for k in ("rollout_status_keys", "rollout_range_keys", "global_status_keys"))
+    sl = slice(it * T, (it + 1) * T)
+    raw = agent_major(g["step_raw_actions"][sl])
+    if not continuous:
+        raw = raw.reshape(T, A * E, 1)
+    ppo.replay_raw_actions = torch.from_numpy(raw).to(dev)
+    ds = ppo.rollout()
+    buf = pol.buffer
+    # ---- per-step quantities, rows agent-major
+    np.testing.assert_allclose(buf.observations.cpu().numpy(), agent_major(g["step_obs"][sl]).astype(np.float32), **tol)
+    np.testing.assert_allclose(buf.log_probs.cpu().numpy(), agent_major(g["step_log_probs"][sl])[..., 0], **tol)
+    per_step = [i for i, s in enumerate(g["values_calls_step"]) if it * T < s <= (it + 1) * T]
+    first = {}
+    for i in per_step:
+        first.setdefault(int(g["values_calls_step"][i]), i)        # a step's first value call = V(obs_t)
+    v_ref = agent_major(np.stack([g["values_calls"][first[s]] for s in range(it * T + 1, (it + 1) * T + 1)]))
+    np.testing.assert_allclose(buf.values.cpu().numpy(), v_ref, **tol)
+    got_act = buf.actions.cpu().numpy()
+    want_act = agent_major(g["step_actions"][sl])
+    np.testing.assert_allclose(got_act.reshape(want_act.shape), want_act, **tol)   # tanh + per-dimension rescale
+    np.testing.assert_allclose(buf.rewards.cpu().numpy(), agent_major(g["step_rewards"][sl]), **tol)
+    # ---- dataset
+    pre = f"it{it}_ds_"
+    assert len(ds) == len(g[pre + "advantages"])
+    got_obs = ds.observations.cpu().numpy()
+    if A == 1:                                                      # single agent: the order itself is the contract
+        pi = np.arange(len(ds))
+        np.testing.assert_allclose(got_obs, g[pre + "observations"], **tol)
+        np.testing.assert_array_equal(ds.ep_lens.cpu().numpy(), g[pre + "ep_lens"])
+    else:
+        pi = row_mapping(g[pre + "observations"], got_obs)
+    np.testing.assert_allclose(ds.critic_observations.cpu().numpy()[pi], g[pre + "critic_observations"], **tol)
+    np.testing.assert_allclose(ds.values[torch.arange(len(ds), device=dev)].cpu().numpy()[pi], g[pre + "values"], **tol)
+    np.testing.assert_allclose(ds.log_probs.cpu().numpy().reshape(-1)[pi], g[pre + "log_probs"], **tol)
+    np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy()[pi], g[pre + "rewards_to_go"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(ds.advantages.cpu().numpy()[pi], g[pre + "advantages"], rtol=1e-5, atol=2e-5)
+    # ---- the rollout statistics block of the status dict
+    sd, gs = ppo.status_dict["agent"], ppo.status_dict["global status"]
+    for k in keys:
+        np.testing.assert_allclose(sd[k], g["rollout_status"][it][keys.index(k)], rtol=1e-5, atol=1e-5, err_msg=f"{k} it {it}")
+    for k in rkeys:
+        np.testing.assert_allclose(sd[k], g["rollout_ranges"][it][rkeys.index(k)], rtol=1e-5, atol=1e-5, err_msg=f"{k} it {it}")
+    for k in gkeys:
+        np.testing.assert_allclose(gs[k], g["global_status"][it][gkeys.index(k)], rtol=1e-6, err_msg=f"{k} it {it}")
+    return pi
+
+
 @pytest.mark.parametrize("update_mode", ["fused", "torch"])
 @pytest.mark.parametrize("name", sorted(FF_SCENARIOS))
 def test_product_reproduces_the_reference_ppo_iterations(golden, name, update_mode):
@@ -199,49 +257,8 @@ def test_product_reproduces_the_reference_ppo_iterations(golden, name, update_mo
     keys, rkeys, gkeys = (list(g[k]) for k in ("rollout_status_keys", "rollout_range_keys", "global_status_keys"))
     ep = icm_ep = 0
     for it in range(c["iterations"]):
-        sl = slice(it * T, (it + 1) * T)
-        raw = agent_major(g["step_raw_actions"][sl])
-        if not continuous:
-            raw = raw.reshape(T, A * E, 1)
-        ppo.replay_raw_actions = torch.from_numpy(raw).to(dev)
-        ds = ppo.rollout()
-        buf = pol.buffer
-        # ---- per-step quantities, rows agent-major
-        np.testing.assert_allclose(buf.observations.cpu().numpy(), agent_major(g["step_obs"][sl]).astype(np.float32), **tol)
-        np.testing.assert_allclose(buf.log_probs.cpu().numpy(), agent_major(g["step_log_probs"][sl])[..., 0], **tol)
-        per_step = [i for i, s in enumerate(g["values_calls_step"]) if it * T < s <= (it + 1) * T]
-        first = {}
-        for i in per_step:
-            first.setdefault(int(g["values_calls_step"][i]), i)        # a step's first value call = V(obs_t)
-        v_ref = agent_major(np.stack([g["values_calls"][first[s]] for s in range(it * T + 1, (it + 1) * T + 1)]))
-        np.testing.assert_allclose(buf.values.cpu().numpy(), v_ref, **tol)
-        got_act = buf.actions.cpu().numpy()
-        want_act = agent_major(g["step_actions"][sl])
-        np.testing.assert_allclose(got_act.reshape(want_act.shape), want_act, **tol)   # tanh + per-dimension rescale
-        np.testing.assert_allclose(buf.rewards.cpu().numpy(), agent_major(g["step_rewards"][sl]), **tol)
-        # ---- dataset
-        pre = f"it{it}_ds_"
-        assert len(ds) == len(g[pre + "advantages"])
-        got_obs = ds.observations.cpu().numpy()
-        if A == 1:                                                      # single agent: the order itself is the contract
-            pi = np.arange(len(ds))
-            np.testing.assert_allclose(got_obs, g[pre + "observations"], **tol)
-            np.testing.assert_array_equal(ds.ep_lens.cpu().numpy(), g[pre + "ep_lens"])
-        else:
-            pi = row_mapping(g[pre + "observations"], got_obs)
-        np.testing.assert_allclose(ds.critic_observations.cpu().numpy()[pi], g[pre + "critic_observations"], **tol)
-        np.testing.assert_allclose(ds.values[torch.arange(len(ds), device=dev)].cpu().numpy()[pi], g[pre + "values"], **tol)
-        np.testing.assert_allclose(ds.log_probs.cpu().numpy().reshape(-1)[pi], g[pre + "log_probs"], **tol)
-        np.testing.assert_allclose(ds.rewards_to_go.cpu().numpy()[pi], g[pre + "rewards_to_go"], rtol=1e-5, atol=2e-5)
-        np.testing.assert_allclose(ds.advantages.cpu().numpy()[pi], g[pre + "advantages"], rtol=1e-5, atol=2e-5)
-        # ---- the rollout statistics block of the status dict
-        sd, gs = ppo.status_dict["agent"], ppo.status_dict["global status"]
-        for k in keys:
-            np.testing.assert_allclose(sd[k], g["rollout_status"][it][keys.index(k)], rtol=1e-5, atol=1e-5, err_msg=f"{k} it {it}")
-        for k in rkeys:
-            np.testing.assert_allclose(sd[k], g["rollout_ranges"][it][rkeys.index(k)], rtol=1e-5, atol=1e-5, err_msg=f"{k} it {it}")
-        for k in gkeys:
-            np.testing.assert_allclose(gs[k], g["global_status"][it][gkeys.index(k)], rtol=1e-6, err_msg=f"{k} it {it}")
+        pi = replay_rollout_and_check(ppo, pol, g, c, it, continuous, dev)
+        sd = ppo.status_dict["agent"]
         # ---- first mini-batch of the run: losses + raw gradients before any optimiser step
         pol.train()
         if it == 0:
@@ -276,6 +293,152 @@ def test_product_reproduces_the_reference_ppo_iterations(golden, name, update_mo
         assert d.max() < 2e-4 and np.mean(d > 2e-5) < 1e-2, f"{tag}: max |dw| {d.max():.2e}, share > 2e-5: {np.mean(d > 2e-5):.2e}"
     rs = ppo.value_normalizers["agent"].running_stats
     np.testing.assert_allclose([float(rs.mean_t), float(rs.var_t), float(rs.count_t)], g["value_stats"], rtol=1e-5, atol=1e-5)
+
+
+class RecordedShuffles:
+    """Stands in for ppo.PermutationLoader inside PPO.train_on_rollout: hands out the reference's recorded shuffles in the
+    order the reference drew them (PPO epoch, then -- with ICM -- the ICM pass of the same epoch) and refuses a draw the
+    reference never made, i.e. an epoch beyond the one its KL early stop broke out of."""
+    queue = []
+
+    def __init__(self, dataset, batch_size, generator=None, prefetch_cache=None):
+        self.dataset, self.batch_size = dataset, int(batch_size)
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def epoch_permutation(self):
+        assert RecordedShuffles.queue, "the product asked for a shuffle beyond the epochs the reference ran"
+        return torch.as_tensor(np.asarray(RecordedShuffles.queue.pop(0), dtype=np.int64), device=self.dataset.device)
+
+    def prefetch(self):
+        pass
+
+
+# R = 2 ranks of the reference (make_golden_update.py: rank_scenarios; rank r's arrays through RankView)
+RANK_SCENARIOS = {
+    "g12_c2_r2": (dict(), {}),
+    "g12_c4_r2": (dict(leaky=True), {}),
+    "g12_c2_icm_r2_klstop": (dict(lr=3e-3, target_kl=0.005, enable_icm=True), {}),
+}
+
+
+class RankView:
+    """Rank r's arrays of a fixture holding R ranks of the reference (keys `r<rank>.<key>`) under single-rank key names."""
+
+    def __init__(self, g, rank):
+        self._g, self._p = g, f"r{rank}."
+        self.files = [k[len(self._p):] for k in g.files if k.startswith(self._p)]
+
+    def __getitem__(self, k):
+        return self._g[self._p + k]
+
+
+def run_kl_stop_scenario(g, name, update_mode, dev, first_minibatch=None):
+    """The fixture's iterations through the product's OWN epoch loop (PPO.train_on_rollout: KL early stop, overlapped
+    PPO / ICM epochs, persistent launches, whatever the environment selected).  Checks, per iteration, that the loop
+    ran exactly the epochs the reference ran, each epoch's statistics (on N > 1 ranks: the all-reduced ones, and the
+    value normaliser fed by every rank's data), and the weights at the end.  `first_minibatch(ppo, pol, pi)`: a probe
+    run after the first rollout, before any optimiser step.  Returns (ppo, epochs run per iteration)."""
+    import ppo_and_friends_amd.ppo as ppo_module
+    ppo, pol, c, continuous = make_product(g, name, update_mode, dev)
+    B = c["batch_size"]
+    sd = ppo.status_dict["agent"]
+    ep, ran_all = 0, []
+    assert float(pol.target_kl) == (float(g["target_kl"][0]) if "target_kl" in g.files else 100.0)
+    keep_loader = ppo_module.PermutationLoader
+    ppo_module.PermutationLoader = RecordedShuffles
+    try:
+        for it in range(c["iterations"]):
+            pi = replay_rollout_and_check(ppo, pol, g, c, it, continuous, dev)
+            pol.train()
+            if it == 0 and first_minibatch is not None:
+                first_minibatch(ppo, pol, pi)
+            want = int(g["epochs_run"][it]) if "epochs_run" in g.files else c["epochs"]
+            RecordedShuffles.queue = []
+            for e in range(want):
+                RecordedShuffles.queue.append(pi[g["epoch_perms"][ep + e]])
+                if pol.enable_icm:
+                    RecordedShuffles.queue.append(pi[g["icm_epoch_perms"][ep + e]])
+            seen = []
+
+            def record():
+                rs_ = ppo.value_normalizers["agent"].running_stats
+                seen.append((np.array([sd["actor loss"], sd["critic loss"], sd["kl avg"], sd["weighted entropy"]]),
+                             sd.get("icm loss"), np.array([float(rs_.mean_t), float(rs_.var_t), float(rs_.count_t)])))
+
+            def wrap(fn, when):
+                def inner(loader, policy_id):
+                    r = fn(loader, policy_id)
+                    if when(r):
+                        record()
+                    return r
+                return inner
+
+            orig = (ppo._ppo_icm_epoch_overlapped, ppo._ppo_batch_train, ppo._icm_batch_train)
+            ppo._ppo_icm_epoch_overlapped = wrap(orig[0], lambda r: bool(r))
+            ppo._ppo_batch_train = wrap(orig[1], lambda r: not pol.enable_icm)
+            ppo._icm_batch_train = wrap(orig[2], lambda r: True)
+            try:
+                ppo.train_on_rollout()
+            finally:
+                ppo._ppo_icm_epoch_overlapped, ppo._ppo_batch_train, ppo._icm_batch_train = orig
+            assert len(seen) == want and not RecordedShuffles.queue, \
+                f"iteration {it}: the product ran {len(seen)} epochs, the reference {want} (target_kl {pol.target_kl})"
+            for e, (got, icm_loss, vstats) in enumerate(seen):
+                if "epoch_value_stats" in g.files:      # R > 1 fixtures: the normaliser saw every rank's mini-batch (stats.py:47-50)
+                    np.testing.assert_allclose(vstats, g["epoch_value_stats"][ep + e], rtol=1e-5, atol=1e-5, err_msg=f"value stats {it}/{e}")
+                np.testing.assert_allclose(got, g["epoch_stats"][ep + e], rtol=2e-5, atol=2e-6,
+                                           err_msg=f"iteration {it} epoch {e}: max dev {np.abs(got - g['epoch_stats'][ep + e]).max():.2e}")
+                if pol.enable_icm:
+                    np.testing.assert_allclose(icm_loss, g["icm_epoch_stats"][ep + e][0], rtol=2e-5, err_msg=f"icm loss {it}/{e}")
+                # the stop decision itself: strict `>` on the epoch's average, every epoch but the last one below the target
+                assert (got[2] > pol.target_kl) == (e == want - 1 and want < c["epochs"]), (it, e, got[2])
+            ep += want
+            ran_all.append(want)
+    finally:
+        ppo_module.PermutationLoader = keep_loader
+    for tag, net in (("actor", pol.actor), ("critic", pol.critic)) + ((("icm", pol.icm_model),) if pol.enable_icm else ()):
+        want_w = np.concatenate([g[f"final_{tag}.{k}"].reshape(-1) for k, _ in net.named_parameters()])
+        got_w = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu().numpy()
+        d = np.abs(got_w - want_w)
+        assert d.max() < 2e-4 and np.mean(d > 2e-5) < 1e-2, f"{tag}: max |dw| {d.max():.2e}, share > 2e-5: {np.mean(d > 2e-5):.2e}"
+    rs = ppo.value_normalizers["agent"].running_stats
+    np.testing.assert_allclose([float(rs.mean_t), float(rs.var_t), float(rs.count_t)], g["value_stats"], rtol=1e-5, atol=1e-5)
+    return ppo, ran_all
+
+
+# how the epoch loop is run: the graph-replayed launch chain (the default at these widths), the persistent two-XCD kernel
+# (one launch per epoch; the stop depends on the totals it hands back), the PPO / ICM epochs in turn instead of overlapped
+# on two streams, and the torch-ROCm module path
+KL_PATHS = {"chain": {}, "ws_rowtile": {"PPOAF_WS_MODE": "rowtile"}, "ws_layered": {"PPOAF_WS_MODE": "layered"},
+            "sequential": {"PPOAF_OVERLAP_ICM": "0"}, "torch": {}}
+
+
+@pytest.mark.parametrize("path", sorted(KL_PATHS))
+@pytest.mark.parametrize("name", sorted(KLSTOP_SCENARIOS))
+def test_kl_early_stop_matches_the_reference(golden, name, path, monkeypatch):
+    """
+    ppo.py:2201-2232: fixtures recorded with a target_kl the reference reaches -- it left the epoch loop after 2 of 4
+    epochs in iteration 0 (after 4 / 3 in iteration 1).  The product's own PPO.train_on_rollout must leave after the same
+    epoch on every update path (a wrong or stale per-epoch total would run on, or stop early), with the ICM pass of the
+    stopping epoch still run (ppo.py:2213-2214 precede the test), and end with the reference's weights.
+    """
+    from ppo_and_friends_amd import fused_update
+    if path == "sequential" and "icm" not in name:
+        pytest.skip("only the ICM scenario has a PPO / ICM epoch pair")
+    for k, v in KL_PATHS[path].items():
+        monkeypatch.setenv(k, v)
+    g = golden(name)
+    before = fused_update.FusedPolicyUpdate.ws_launch_count
+    ppo, ran = run_kl_stop_scenario(g, name, "torch" if path == "torch" else "fused", torch.device("cuda", 0))
+    assert ran == [int(x) for x in g["epochs_run"]] and ran[0] < _cfg(g)["epochs"]
+    fused = ppo._fused_updater("agent", _cfg(g)["batch_size"])
+    assert (fused is None) == (path == "torch")
+    if path.startswith("ws_") and "icm" not in name:
+        # the persistent kernel really was the path that ran: one launch per epoch the reference ran
+        assert fused.ws_reason() == "", fused.ws_reason()
+        assert fused_update.FusedPolicyUpdate.ws_launch_count - before == sum(ran)
 
 
 @pytest.mark.parametrize("update_mode", ["fused", "fused_slabs", "torch"])

@@ -165,6 +165,98 @@ def test_two_rank_update_matches_ddppo_oracle(run2):
 
 
 # ----------------------------------------------------------------------------------------------------
+# Two ranks against TWO RANKS OF THE REFERENCE (fixtures g12_*_r2*, recorded under the two-process mpi4py stand-in of
+# tests/golden/ref_import.py): no oracle in between.
+def _fixture_rank(rank, world, port, out, name, mode):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [here]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", PPOAF_GRAD_EXCHANGE=mode, PPOAF_SHARE_DEVICE="1")
+    import torch.distributed as dist
+    from ppo_and_friends_amd.utils import mpi_utils
+    mpi_utils.init_process_group_from_env(backend="gloo")
+    import test_gpu_reference_golden as G
+    from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
+    g = G.RankView(np.load(os.path.join(here, "golden", name + ".npz"), allow_pickle=False), rank)
+    dev = torch.device("cuda", 0)
+    probe = {}
+
+    def first_minibatch(ppo, pol, pi):
+        """ONE mini-batch through the selected N > 1 path with everything it advances put back afterwards: what the
+        exchange left in the gradient bucket is the SUM over the ranks (1/R is folded into the Adam kernel) =
+        R x what mpi_avg_gradients left in .grad on the reference's ranks (utils/mpi_utils.py:89-111)."""
+        c = G._cfg(g)
+        fused = ppo._fused_updater("agent", c["batch_size"])
+        perm = torch.as_tensor(np.asarray(pi[g["epoch_perms"][0]], dtype=np.int64), device=dev)
+        fused.begin_epoch(perm)
+        state = [pol.policy_params, pol.policy_exp_avg, pol.policy_exp_avg_sq, pol.policy_step_counts, pol.policy_norm_scratch,
+                 fused.vn_mean, fused.vn_var, fused.vn_count, fused.cursor, fused.totals, pol.buffer.values]
+        keep = [t.clone() for t in state]
+        n_full, tail, n_done = fused.n_full, fused.tail, fused.n_done
+        fused.n_full, fused.tail = 1, 0
+        try:
+            fused.run_epoch()
+            torch.cuda.synchronize()
+        finally:
+            fused.n_full, fused.tail, fused.n_done = n_full, tail, n_done
+        grads = pol.policy_grads.clone()
+        for t, k in zip(state, keep):
+            t.copy_(k)
+        for tag, net in (("actor", pol.actor), ("critic", pol.critic)):
+            got = G.params_in_bucket_order(pol, grads, net) / world
+            want = g[f"mb0_{tag}_avg_grad"]
+            scale = np.abs(want).max()
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale, err_msg=f"{tag}: rank-averaged gradient")
+        probe["done"] = True
+
+    # (the ICM scenario's PPO / ICM epoch pairs and the persistent kernel's own exchange object have no single-launch
+    # probe of this kind; their first mini-batch is covered by the epoch statistics)
+    want_probe = name == "g12_c2_r2" or (name == "g12_c4_r2" and mode == "rccl")
+    ppo, ran = G.run_kl_stop_scenario(g, name, "fused", dev, first_minibatch=first_minibatch if want_probe else None)
+    pol = ppo.policies["agent"]
+    fused = [f for f in getattr(ppo, "_fused", {}).values() if f is not None]
+    out[rank] = dict(ran=ran, probe=bool(probe), w=pol.policy_params.detach().cpu().clone(),
+                     w_icm=pol.icm_model.flat_params.detach().cpu().clone() if pol.enable_icm else None,
+                     peer_exchange=[getattr(f, "xchg", None) is not None for f in fused],
+                     ws_exchange_launches=FusedPolicyUpdate.ws_exchange_launch_count,
+                     kl=float(ppo.status_dict["agent"]["kl avg"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["peer", "rccl"])
+@pytest.mark.parametrize("name", ["g12_c2_r2", "g12_c4_r2", "g12_c2_icm_r2_klstop"])
+def test_two_ranks_reproduce_two_ranks_of_the_reference(name, mode):
+    """
+    Each process is one rank of the product holding that rank's tables, actions and shuffles of the reference's own
+    two-rank run (`mpirun -n 2` semantics through the mpi4py stand-in): rollout, dataset and the all-reduced status
+    block, the rank-averaged first-mini-batch gradient (mpi_avg_gradients, utils/mpi_utils.py:89-111), every epoch's
+    all-reduced statistics (ppo.py:2468-2475) and the value normaliser fed with both ranks' data (utils/stats.py:47-50),
+    the KL early stop taken by both ranks after the same epoch (ppo.py:2221-2232; g12_c2_icm_r2_klstop: after 3 of 4
+    epochs), final weights.  `peer`: the K17 exchange (inside graph-replayed chains; inside the persistent two-XCD kernel
+    for the 256-wide critic of g12_c4_r2; PPO and ICM epochs overlapped on two streams); `rccl`: the all-reduce loops.
+    All fixture checks run inside the rank processes (test_gpu_reference_golden.run_kl_stop_scenario).
+    """
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"), allow_pickle=False)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_fixture_rank, args=(2, _free_port(), out, name, mode), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    want = [int(x) for x in g["r0.epochs_run"]] if "r0.epochs_run" in g.files else None
+    for r in (r0, r1):
+        assert r["peer_exchange"] and all(x == (mode == "peer") for x in r["peer_exchange"]), r["peer_exchange"]
+        if want is not None:
+            assert r["ran"] == want and want[0] < 4, (r["ran"], want)      # both ranks left the epoch loop together, early
+    assert r0["ran"] == r1["ran"] and r0["kl"] == r1["kl"]
+    assert torch.equal(r0["w"], r1["w"]), "synchronous DD-PPO keeps replicas identical"
+    if r0["w_icm"] is not None:
+        assert torch.equal(r0["w_icm"], r1["w_icm"])
+    if name == "g12_c4_r2" and mode == "peer":
+        assert r0["ws_exchange_launches"] > 0, "256-wide critic at N > 1: the exchange runs inside the persistent kernel"
+
+
+# ----------------------------------------------------------------------------------------------------
 # ICM (K14) and MAT (K15) updates on two ranks: the K17 exchange inside hipGraph-replayed chains against
 # the eager loop with the process group's all-reduce -- same sums, so the same training.
 def _rank_kind(rank, world, port, out, mode, kind):

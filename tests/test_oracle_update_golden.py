@@ -112,12 +112,31 @@ SCENARIOS = {
     # batch_size = 256, the reference's default and the metric's mini-batch shape (ppo.py:134)
     "g12_c2_b256": {}, "g12_c4_b256": LEAKY,
     "g12_c3_b256": dict(lr=1e-4, filters=dict(obs_clip=(-2.0, 2.0), reward_clip=(-1.5, 1.5)), **LEAKY),
+    # KL early stop (ppo.py:2221-2232): the reference left the epoch loop after 2 of 4 epochs (and 4 / 3 in iteration 1)
+    "g12_c2_klstop": dict(lr=1e-3), "g12_c2_icm_klstop": dict(lr=3e-3),
 }
 
 
-@pytest.mark.parametrize("name", sorted(SCENARIOS))
-def test_cpu_port_reproduces_the_reference_ppo_iterations(golden, name):
-    g = golden(name)
+class RankView:
+    """Rank r's arrays of a fixture that holds R ranks of the reference (keys `r<rank>.<key>`, make_golden_update.py:
+    rank_scenarios) behind the key names of a single-rank fixture."""
+
+    def __init__(self, g, rank):
+        self._g, self._p = g, f"r{rank}."
+        self.files = [k[len(self._p):] for k in g.files if k.startswith(self._p)]
+
+    def __getitem__(self, k):
+        return self._g[self._p + k]
+
+
+def replay_fixture(g, name, comm=None):
+    """
+    One rank of a g12 fixture through the CPU port: the reference's tables, initial weights, recorded actions and shuffles
+    in; datasets, first-mini-batch losses + raw gradients, every epoch's statistics (and the decision to stop early),
+    final weights and normaliser states checked against what the reference produced.  `comm` (R > 1 fixtures): the
+    collective surface of cpu_ppo_loop.ThreadComm / cpu_ddppo.GlooComm; the statistics, averaged gradients and weights
+    recorded on this rank are then the all-reduced ones.
+    """
     c = _cfg(g)
     c["name"] = name
     E, T, B, A = c["E"], c["T"], c["batch_size"], c["A"]
@@ -146,7 +165,7 @@ def test_cpu_port_reproduces_the_reference_ppo_iterations(golden, name):
             np.testing.assert_allclose(obs_table[:T], agent_major(g["step_obs"][it * T:(it + 1) * T]), rtol=1e-6, atol=1e-6)
         acts = agent_major(g["step_raw_actions" if cpu.continuous else "step_actions"][it * T:(it + 1) * T])
         ds = cpu.rollout(obs_table, rew_table, actions=acts, term_table=term if term.any() else None,
-                         max_ts_per_ep=c["max_ts_per_ep"], critic_obs_table=cobs_table)
+                         max_ts_per_ep=c["max_ts_per_ep"], critic_obs_table=cobs_table, comm=comm)
         pre = f"it{it}_ds_"
         tol = dict(rtol=1e-6, atol=1e-6)
         if A == 1:                                                         # single agent: the order itself is the contract
@@ -170,23 +189,42 @@ def test_cpu_port_reproduces_the_reference_ppo_iterations(golden, name):
         if cpu.enable_icm:
             k = list(g["rollout_status_keys"]).index("intrinsic score avg")
             np.testing.assert_allclose(cpu.intrinsic_score_avg, g["rollout_status"][it][k], rtol=1e-6)
-        for e in range(c["epochs"]):
-            cpu.trace = [] if ep == 0 else None
-            r = cpu.train_epoch(perm=pi[g["epoch_perms"][ep]])
-            if ep == 0:      # the very first mini-batch, before any optimiser step: losses and raw gradients
+        # the epoch loop with its KL early stop (ppo.py:2201-2232) is the oracle's own decision: it must run exactly the
+        # epochs the reference ran (`epochs_run`; every epoch where no target_kl was set)
+        target_kl = float(g["target_kl"][0]) if "target_kl" in g.files else 100.0
+        want_epochs = int(g["epochs_run"][it]) if "epochs_run" in g.files else c["epochs"]
+        first_ep, first_icm = ep, icm_ep
+        cpu.trace = [] if ep == 0 else None
+
+        def check_epoch(e, r):
+            assert e < want_epochs, f"iteration {it}: the reference stopped after {want_epochs} epochs"
+            if first_ep + e == 0:  # the very first mini-batch, before any optimiser step: losses and raw gradients
                 m = cpu.trace[0]
                 # (the actor loss is a mean of B O(1) surrogate terms that nearly cancel: float32 noise is ~1e-7 absolute)
                 np.testing.assert_allclose([m["actor"], m["critic"]], g["mb0_losses"], rtol=1e-5, atol=1e-7)
                 np.testing.assert_allclose(m["actor_grad"], g["mb0_actor_grad"], rtol=1e-5, atol=1e-7)
                 np.testing.assert_allclose(m["critic_grad"], g["mb0_critic_grad"], rtol=1e-5, atol=1e-7)
+                if comm is not None:   # what mpi_avg_gradients left in .grad (utils/mpi_utils.py:89-111): the ranks' mean
+                    np.testing.assert_allclose(m["actor_avg_grad"], g["mb0_actor_avg_grad"], rtol=1e-5, atol=1e-7)
+                    np.testing.assert_allclose(m["critic_avg_grad"], g["mb0_critic_avg_grad"], rtol=1e-5, atol=1e-7)
+            cpu.trace = None
+            if comm is not None:       # the value normaliser after this epoch: fed with the raw data of every rank (stats.py:47-50)
+                vs_ = cpu.value_stats
+                np.testing.assert_allclose([vs_.mean, vs_.variance, vs_.count], g["epoch_value_stats"][first_ep + e], rtol=2e-6, atol=1e-6)
             got = np.array([r["actor loss"], r["critic loss"], r["kl avg"], r["weighted entropy"]])
             # (the surrogate loss and the KL are means of O(1) terms that cancel: absolute floor 1e-6)
-            np.testing.assert_allclose(got, g["epoch_stats"][ep], rtol=5e-6, atol=1e-6, err_msg=f"iteration {it} epoch {e}")
-            ep += 1
+            np.testing.assert_allclose(got, g["epoch_stats"][first_ep + e], rtol=5e-6, atol=1e-6, err_msg=f"iteration {it} epoch {e}")
             if cpu.enable_icm:                                             # ppo.py:2213-2214: the ICM pass follows each PPO epoch
-                loss = cpu.icm_train_epoch(perm=pi[g["icm_epoch_perms"][icm_ep]])
-                np.testing.assert_allclose(loss, g["icm_epoch_stats"][icm_ep][0], rtol=5e-6, err_msg=f"icm loss {it}/{e}")
-                icm_ep += 1
+                np.testing.assert_allclose(r["icm loss"], g["icm_epoch_stats"][first_icm + e][0], rtol=5e-6, err_msg=f"icm loss {it}/{e}")
+
+        pad = [None] * c["epochs"]             # (never reached: check_epoch stops a port that runs past the reference)
+        ran = cpu_ppo_loop.train_on_rollout(
+            cpu, c["epochs"], target_kl, on_epoch=check_epoch, comm=comm,
+            perms=[pi[p] for p in g["epoch_perms"][ep:ep + want_epochs]] + pad,
+            icm_perms=([pi[p] for p in g["icm_epoch_perms"][icm_ep:icm_ep + want_epochs]] + pad) if cpu.enable_icm else None)
+        assert len(ran) == want_epochs, f"iteration {it}: ran {len(ran)} epochs, the reference {want_epochs}"
+        ep += want_epochs
+        icm_ep += want_epochs if cpu.enable_icm else 0
     for tag in ("actor", "critic") + (("icm",) if cpu.enable_icm else ()):
         got, want = final_params(g, tag, cpu)
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7, err_msg=tag)
@@ -202,6 +240,36 @@ def test_cpu_port_reproduces_the_reference_ppo_iterations(golden, name):
         st = orc.rew_norm.stats[0]
         np.testing.assert_allclose([st.mean, st.variance, st.count], [g[pre + "mean"], g[pre + "var"], g[pre + "count"][0]], rtol=1e-6)
         np.testing.assert_allclose(orc.rew_norm.running_reward[0], g["filter_RewardNormalizer_running_reward_agent0"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_cpu_port_reproduces_the_reference_ppo_iterations(golden, name):
+    replay_fixture(golden(name), name)
+
+
+# R = 2 ranks of the reference under the two-process mpi4py stand-in (tests/golden/ref_import.py, make_golden_update.py:
+# rank_scenarios): pins the DD-PPO arithmetic of the port -- mpi_avg_gradients (utils/mpi_utils.py:50-111), the value
+# normaliser's all-gather of raw data (utils/stats.py:47-50), the all-reduced epoch totals (ppo.py:2468-2475) and the KL
+# early stop they drive on both ranks (ppo.py:2221-2232)
+RANK_SCENARIOS = {"g12_c2_r2": "g12_c2_b256", "g12_c4_r2": "g12_c4_b256", "g12_c2_icm_r2_klstop": "g12_c2_icm_klstop"}
+
+
+@pytest.mark.parametrize("name", sorted(RANK_SCENARIOS))
+def test_cpu_ddppo_port_reproduces_two_ranks_of_the_reference(golden, name):
+    g = golden(name)
+    R = int(g["ranks"][0])
+    assert R == 2
+    views = [RankView(g, r) for r in range(R)]
+    # the fixture itself: the rank-0 broadcast made the initial weights identical, the ranks saw different data and
+    # shuffles, and synchronous DD-PPO left them with identical weights and statistics
+    for k in views[0].files:
+        if k.startswith(("init_", "final_")) or k in ("epoch_stats", "epoch_value_stats", "value_stats", "mb0_actor_avg_grad", "mb0_critic_avg_grad"):
+            np.testing.assert_array_equal(views[0][k], views[1][k], err_msg=k)
+    assert not np.array_equal(views[0]["obs_table"], views[1]["obs_table"])
+    assert not np.array_equal(views[0]["epoch_perms"], views[1]["epoch_perms"])
+    np.testing.assert_array_equal(views[0]["mb0_actor_avg_grad"], (views[0]["mb0_actor_grad"] + views[1]["mb0_actor_grad"]) / 2)
+    # both ranks of the port, each on its own thread, meeting in the reference's collectives
+    cpu_ppo_loop.run_ranks([(lambda comm, v=v: replay_fixture(v, RANK_SCENARIOS[name], comm)) for v in views])
 
 
 @pytest.mark.parametrize("name", sorted(SCENARIOS))
