@@ -37,7 +37,7 @@ typedef void* ppoaf_stream_t;            /* hipStream_t */
 #define PPOAF_E_INVALID    -1            /* bad argument / unsupported shape   */
 #define PPOAF_E_LAUNCH     -2            /* hipLaunch / runtime error          */
 
-#define PPOAF_ABI_VERSION 4
+#define PPOAF_ABI_VERSION 5
 
 int         ppoaf_abi_version(void);
 const char* ppoaf_last_error(void);
@@ -413,6 +413,22 @@ int ppoaf_ppo_update_reduce(const ppoaf_ppo_update_args_t* args, int compute_nor
 int ppoaf_ppo_update_split_workspace_bytes(const ppoaf_ppo_update_args_t* args, int64_t* bytes_out);
 int ppoaf_ppo_update_split_blocks(const ppoaf_ppo_update_args_t* args);
 int ppoaf_ppo_update_wgrad(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t stream);
+/* Fused tail of the split-wgrad chain (ABI 5; csrc/ppo_update_tail.hip): fwd_bwd (args->split_workspace set) ->
+ * ppoaf_ppo_update_wgrad_adam -- TWO launches per mini-batch.  Everything from loss.backward()'s weight gradients to
+ * optimizer.step() (ppo.py:2443-2444, ppo_policy.py:1032-1055: backward, clip_grad_norm_, Adam, both networks) in one
+ * launch: a workgroup forms one 16 x 32 piece of a layer's dW over all B rows (ppoaf_ppo_update_wgrad's jobs, bit for bit),
+ * publishes its squared-norm partial as one tagged 16-byte record, waits for the records of all workgroups, and applies
+ * clip + Adam to exactly its elements (their optimiser state was requested beside the MFMA operands).  Parameters, moments,
+ * gradient bucket, totals, step counters and cursor end BITWISE as after ppoaf_ppo_update_wgrad + ppoaf_ppo_update_adam(3).
+ * ctl: ppoaf_ppo_update_tail_ctl_bytes(args) bytes of device memory, 64-byte aligned, zeroed ONCE by the caller and then
+ * kept across launches (it carries the launch tag); its third 32-bit word is non-zero after a launch in which a wait
+ * ran out of wait_seconds (the workgroups were not all resident: the results of that launch are then invalid and later
+ * launches do not wait again).  All 8 * per_xcd + 1 workgroups must fit on the device together (checked). */
+int64_t ppoaf_ppo_update_tail_ctl_bytes(const ppoaf_ppo_update_args_t* args);
+int ppoaf_ppo_update_wgrad_adam(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds, ppoaf_stream_t stream);
+/* same launch with the kernel's own begin / end stamped into two events */
+int ppoaf_ppo_update_wgrad_adam_timed(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
+                                      void* start_event, void* stop_event, ppoaf_stream_t stream);
 /* The same chain for n_minibatches consecutive mini-batches (cursor .. cursor + n - 1) in ONE launch that keeps all
  * 2 * ceil(B/16) <= 32 workgroups on one XCD (target_xcc, 0..7): parameters, moments and gradients stay in that XCD's
  * L2 between mini-batches and the chain's three grid-wide dependencies are flag barriers inside it (single rank;

@@ -61,7 +61,7 @@ class PpoUpdateArgs(C.Structure):
                 ("xcd_half", C.c_int32), ("_pad2", C.c_int32)]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class PolicyStepArgs(C.Structure):
@@ -205,6 +205,9 @@ SIGNATURES = {
     "ppoaf_ppo_update_split_workspace_bytes": (C.c_int, [C.POINTER(PpoUpdateArgs), C.POINTER(C.c_int64)]),
     "ppoaf_ppo_update_split_blocks": (C.c_int, [C.POINTER(PpoUpdateArgs)]),
     "ppoaf_ppo_update_wgrad": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr]),
+    "ppoaf_ppo_update_tail_ctl_bytes": (C.c_int64, [C.POINTER(PpoUpdateArgs)]),
+    "ppoaf_ppo_update_wgrad_adam": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr]),
+    "ppoaf_ppo_update_wgrad_adam_timed": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr, _ptr, _ptr]),
     "ppoaf_ppo_update_adam": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
     "ppoaf_icm_forward_loss_fwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, C.c_float, _ptr, _ptr, _ptr, _ptr]),
     "ppoaf_icm_forward_loss_bwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int32, _ptr, _ptr, _ptr, _ptr]),

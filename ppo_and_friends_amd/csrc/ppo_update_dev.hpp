@@ -80,6 +80,49 @@ inline size_t ws_layout(const UpdateDev& u, WsDev* ws, char* base) {
     return off;
 }
 
+constexpr int kWgradThreads = 256;
+
+// per-mini-batch bookkeeping of the split-wgrad chain, by ONE wave (threads 0..63 of a workgroup): loss partials -> totals
+__device__ __forceinline__ void ppo_update_bookkeeping_totals(const UpdateDev& u) {
+    const int lane = threadIdx.x;
+    float p0 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p7 = 0.f;
+    for (int g = lane; g < u.n_wg; g += 64) {
+        const float* a = u.loss_partials + (long)g * 8;
+        const float* cc = u.loss_partials + ((long)u.n_wg + g) * 8;
+        p0 += a[0]; p3 += a[3]; p4 += a[4]; p7 += a[7]; p2 += cc[2];
+    }
+    p0 = wave_sum(p0); p2 = wave_sum(p2); p3 = wave_sum(p3); p4 = wave_sum(p4); p7 = wave_sum(p7);
+    if (lane == 0) {
+        const float n = (float)u.B;
+        const float surr = p0 / n, ent = p3 / n, kl = p4 / n, crit = p2 / n;
+        float total = surr;
+        if (u.entropy_weight != 0.0f) total -= u.entropy_weight * ent;
+        if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
+        u.totals[0] += (double)surr; u.totals[1] += (double)total; u.totals[2] += (double)crit;
+        u.totals[3] += (double)ent; u.totals[4] += (double)kl;
+        u.totals[5] += (double)u.loss_partials[5]; u.totals[6] += (double)u.loss_partials[6];
+        u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
+        u.totals[8] += 1.0;
+    }
+}
+// ... and the step counters + Adam bias corrections of the step being taken
+__device__ __forceinline__ void ppo_update_bookkeeping_steps(const UpdateDev& u) {
+    const int lane = threadIdx.x;
+    if (lane < 2) {                                       // one lane per network: step counter + bias corrections
+        const int w = lane;
+        const int64_t t = u.step_counts[w] + 1;
+        u.step_counts[w] = t;
+        u.norm_scratch[2 + 2 * w] = 1.0 - pow((double)u.beta1, (double)t);
+        u.norm_scratch[3 + 2 * w] = sqrt(1.0 - pow((double)u.beta2, (double)t));
+    }
+}
+
+__device__ __forceinline__ void ppo_update_bookkeeping_split(const UpdateDev& u) {
+    if (threadIdx.x >= 64) return;
+    ppo_update_bookkeeping_totals(u);
+    ppo_update_bookkeeping_steps(u);
+}
+
 // host: validate ppoaf_ppo_update_args_t and fill the device view (ppo_update.hip)
 int make_update_dev(const ppoaf_ppo_update_args_t* a, UpdateDev& u);
 

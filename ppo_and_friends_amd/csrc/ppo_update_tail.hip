@@ -1,0 +1,407 @@
+// K12, fused tail of the split-wgrad chain (round 4): ONE launch after fwd_bwd<SPLIT> forms every weight gradient of
+// the mini-batch, the two clip norms, and applies clip + Adam (ppo_policy.py:1032-1055) -- what ppoaf_ppo_update_wgrad +
+// ppoaf_ppo_update_adam(compute_norms 3) did in two launches.  Per mini-batch at C2 those two launches were 10.1 us
+// (5.05 + 5.01) for ~1 us of arithmetic each: a launch ramp plus a cold round trip for inputs other XCDs had just written
+// (profiles/r03_update_pmc.csv: waves parked 64-72 %).  Here
+//
+//   * every workgroup owns one 16 x 32 piece of one layer's dW (or a network's output segment) END TO END: it requests
+//     the optimiser state (p, m, v) of its elements together with its MFMA operands (one cold round trip for both),
+//     forms the gradient over all B rows on MFMA (split_wgrad_job's arithmetic and fold order, bit for bit), and applies
+//     Adam to exactly those elements -- the gradient never goes through memory on its way to the optimiser;
+//   * the one thing every workgroup needs from every other one is the squared norm of the whole gradient (the clip
+//     coefficient): each publishes its partial as ONE 16-byte record of two {32 data bits, 32-bit launch tag} granules
+//     (one `sc1` store; MI355X_MICROARCH.md, data-tagged granules: no flag, no fence, no ordering needed), and one wave of
+//     each workgroup polls all records with `sc1` loads until every tag is this launch's, then adds them lane-strided +
+//     xor butterfly -- the association xchg_ordered_norms uses in the Adam launch, so the coefficient, and with it every
+//     parameter and moment, is BITWISE what the three-launch chain produces;
+//   * a bookkeeping workgroup folds the loss partials into the totals, waits for the same records, and only then
+//     advances what the other workgroups read at their start (step counters, the launch tag, the mini-batch cursor).
+//
+// All workgroups must be resident together (C2: 153 of 256 threads on 256 CUs; 256-wide critics: 369, two to three per
+// CU at this kernel's register count -- checked on the host against the occupancy the runtime reports); every wait is
+// bounded by a wall-clock budget and ends in the control block's error word instead of a hang (the host then restores
+// the epoch's starting state and runs the three-launch chain, fused_update.py).
+#include "ppo_update_dev.hpp"
+#include <hip/hip_ext.h>
+
+namespace ppoaf {
+
+typedef unsigned tail_u32x4 __attribute__((ext_vector_type(4)));
+typedef float tail_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTailRecOff = 64;               // byte offset of the records inside the control block
+constexpr int kTailMaxRounds = 8;             // a polling lane holds up to 8 records: <= 512 workgroups
+constexpr int kTailMaxE = 9;                  // output segment: up to 9 elements per thread (8 x 256 weights + bias + log_std)
+
+struct TailCtl {
+    unsigned long long seq;                   // launches completed; a launch tags its records with (seq mod 2^32 - 1) + 1
+    unsigned error;                           // a wait ran out of its budget: later launches do not wait again
+    unsigned pad[13];
+    tail_u32x4 rec[1];                        // [8 * per_xcd]: {q bits 0..31, tag, q bits 32..63, tag}
+};
+
+struct TailDev {
+    TailCtl* ctl;
+    long long budget;                         // wall_clock64 ticks (100 MHz)
+    int nblk, jobs_a, jobs_c, per_xcd;
+};
+
+struct TailCoef { float gs, step_size, bc2_sqrt; };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tail_rsrc(const TailDev& td) {
+    return __builtin_amdgcn_make_buffer_rsrc(td.ctl, 0, 0xFFFFFFFF, 0x00020000);
+}
+
+// one lane: this workgroup's squared-norm partial, visible to every XCD (`sc1`: written through, dropped from this L2)
+__device__ __forceinline__ void tail_publish(const TailDev& td, const unsigned tag, const int b, const double q) {
+    const unsigned long long qb = (unsigned long long)__double_as_longlong(q);
+    const tail_u32x4 r = {(unsigned)qb, tag, (unsigned)(qb >> 32), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(r, tail_rsrc(td), (unsigned)(kTailRecOff + 16 * b), 0, 16 /* sc1 */);
+}
+
+// one whole wave: wait until every workgroup's record carries this launch's tag, then the two squared norms in the
+// association of xchg_ordered_norms (lane-strided ascending per lane, xor butterfly; an idle or other-network record adds
+// +0.0).  Returns false when the wait ran out of its budget (error word set; the sums are then meaningless).
+__device__ __forceinline__ bool tail_gather(const TailDev& td, const unsigned tag, double& sq0, double& sq1) {
+    const int lane = threadIdx.x & 63;
+    const __amdgpu_buffer_rsrc_t rs = tail_rsrc(td);
+    tail_u32x4 r[kTailMaxRounds];
+    long long budget = td.budget;
+    if (__hip_atomic_load(&td.ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) budget = 0;     // broken before: no second wait
+    const long long t0 = (long long)wall_clock64();
+    bool ok = true;
+    while (true) {
+#pragma unroll
+        for (int k = 0; k < kTailMaxRounds; ++k) {
+            const int bb = lane + 64 * k;
+            r[k] = tail_u32x4{0u, tag, 0u, tag};
+            if (bb < td.nblk) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(kTailRecOff + 16 * bb), 0, 16 /* sc1 */);
+        }
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < kTailMaxRounds; ++k) all = all && r[k].y == tag && r[k].w == tag;
+        if (__all((int)all)) break;
+        if ((long long)wall_clock64() - t0 > budget) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kTailMaxRounds; ++k) {
+        const int bb = lane + 64 * k;
+        if (bb < td.nblk) {
+            const double q = __longlong_as_double((long long)(((unsigned long long)r[k].z << 32) | (unsigned long long)r[k].x));
+            const int job = (bb & 7) * td.per_xcd + (bb >> 3);
+            if (job < td.jobs_a) p0 += q; else p1 += q;
+        }
+    }
+    sq0 = wave_sum(p0);
+    sq1 = wave_sum(p1);
+    if (!ok && lane == 0) __hip_atomic_store(&td.ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ok;
+}
+
+// Every thread of the workgroup: its squared-norm contribution in, the step's clip / Adam coefficients out.
+// t_next = step_counts[which] + 1 and lr were read at the START of the workgroup (the bookkeeping workgroup advances the
+// counter only after every workgroup has published, i.e. after all those reads).
+__device__ __forceinline__ TailCoef tail_sync(const UpdateDev& u, const TailDev& td, const unsigned tag, const int b, const int which,
+                                              const long long t_next, const float lr, const double q_thread, double* s_red,
+                                              float* s_coef) {
+    const double q = block_sum(q_thread, s_red);
+    if (threadIdx.x < 64) {
+        if (threadIdx.x == 0) tail_publish(td, tag, b, q);
+        // the bias corrections of ppo_update_bookkeeping_steps, while the records travel
+        const double bc1 = 1.0 - pow((double)u.beta1, (double)t_next);
+        const double bc2s = sqrt(1.0 - pow((double)u.beta2, (double)t_next));
+        double sq0, sq1;
+        tail_gather(td, tag, sq0, sq1);
+        if (threadIdx.x == 0) {                                // ppo_update_adam_kernel's coefficients, expression for expression
+            const float total_norm = (float)sqrt(which ? sq1 : sq0);
+            float coef = 1.0f;
+            if (u.max_norm > 0.f) coef = fminf(u.max_norm / (total_norm + 1e-6f), 1.0f);
+            s_coef[0] = u.grad_scale * coef;
+            s_coef[1] = (float)((double)lr / bc1);
+            s_coef[2] = (float)bc2s;
+        }
+    }
+    __syncthreads();
+    return TailCoef{s_coef[0], s_coef[1], s_coef[2]};
+}
+
+struct TailPmv { float p, m, v; };
+__device__ __forceinline__ TailPmv tail_pmv_load(const UpdateDev& u, const long idx, const bool ok) {
+    TailPmv r = {0.f, 0.f, 0.f};
+    if (ok) { r.p = u.params[idx]; r.m = u.exp_avg[idx]; r.v = u.exp_avg_sq[idx]; }
+    return r;
+}
+// ppo_update_adam_kernel's step on one element (-ffp-contract=off: the same roundings)
+__device__ __forceinline__ void tail_adam1(const UpdateDev& u, const long idx, const float g, const TailPmv& s, const TailCoef& c) {
+    const float gi = g * c.gs;
+    const float m = u.beta1 * s.m + (1.0f - u.beta1) * gi;
+    const float v = u.beta2 * s.v + (1.0f - u.beta2) * gi * gi;
+    const_cast<float*>(u.params)[idx] = s.p - c.step_size * (m / (sqrtf(v) / c.bc2_sqrt + u.adam_eps));
+    u.exp_avg[idx] = m;
+    u.exp_avg_sq[idx] = v;
+}
+
+// One job of the split-wgrad job list (ppo_update_ws.hip: split_wgrad_job -- same tiles, same operand loads, same fold
+// and summation orders), carried through to the optimiser step.  Offsets of p / m / v / G are bucket offsets.
+template <int H>
+__device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, const unsigned tag, const int b, const int which,
+                                         const int job, float* sFold /* [3][2][256] + [4][16] */, double* s_red, float* s_coef) {
+    constexpr int MAXC = 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const auto& nd = u.net[which];
+    const int in_dim = nd.in_dim, depth = nd.depth, out_dim = nd.out_dim;
+    const int B = (int)u.B;
+    const long plane = (long)u.sp.Bp * H;
+    const long szW0 = ((long)H * in_dim + 3) & ~3L;
+    auto offW = [&](int l) -> long { return l == 0 ? 0 : szW0 + H + (long)(l - 1) * ((long)H * H + H); };
+    auto offB = [&](int l) -> long {
+        return l == 0 ? szW0 : offW(l) + (l < depth ? (long)H * H : (((long)out_dim * H + 3) & ~3L));
+    };
+    const long nb = nd.offset;                                 // this network's first float in the bucket
+    float* G = u.grads + nb;
+    // read BEFORE this workgroup publishes (see tail_sync)
+    const long long t_next = (long long)u.step_counts[which] + 1;
+    const float lr = u.lr[0];
+    constexpr int t = H / 16, t2 = (t + 1) / 2;
+    const int n_it0 = (in_dim + 15) / 16, p0 = (n_it0 + 1) / 2;
+    const int n_hidden = (depth - 1) * t * t2, n_l0 = t * p0;
+    const float sc = u.grad_scale;
+    double q = 0.0;
+    if (job < n_hidden + n_l0) {
+        int l, ot, itile, n_it;
+        if (job < n_hidden) { l = 1 + job / (t * t2); const int jj = job % (t * t2); ot = jj / t2; itile = 2 * (jj % t2); n_it = t; }
+        else { l = 0; const int jj = job - n_hidden; ot = jj / p0; itile = 2 * (jj % p0); n_it = n_it0; }
+        const bool two = itile + 1 < n_it;                    // uniform per workgroup
+        const long ldw = l >= 1 ? H : in_dim;
+        const int i = itile * 16 + (lane & 15);               // C layout: column = lane & 15, rows 4 (lane >> 4) + r
+        // wave 0 owns the output tile: its elements' optimiser state goes out first, beside the operand loads below
+        TailPmv s0[4], s1[4], sb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = ot * 16 + 4 * (lane >> 4) + r;
+            const long e = nb + offW(l) + (long)o * ldw + i;
+            s0[r] = tail_pmv_load(u, e, wave == 0 && i < ldw);
+            s1[r] = tail_pmv_load(u, e + 16, wave == 0 && two && i + 16 < ldw);
+        }
+        const bool has_b = wave == 0 && itile == 0 && lane < 16;
+        sb = tail_pmv_load(u, nb + offB(l) + ot * 16 + lane, has_b);
+        const long ldx = l >= 1 ? H : 64;
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(u.sp.dbuf[which] + (long)l * plane, 0, 0xFFFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            l >= 1 ? u.sp.hbuf[which] + (long)(l - 1) * plane : u.sp.xbuf[which], 0, 0xFFFFFFFF, 0x00020000);
+        const unsigned dl = 4u * (unsigned)((lane >> 4) * H + ot * 16 + (lane & 15));
+        const unsigned xl = 4u * (unsigned)((lane >> 4) * (int)ldx + itile * 16 + (lane & 15));
+        const int nc = (B + 15) >> 4;
+        float a[MAXC][4], x0[MAXC][4], x1[MAXC][4];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = wave + 4 * c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[c][j] = 0.f; x0[c][j] = 0.f; x1[c][j] = 0.f; }
+            if (ch < nc) {                                    // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned sd = 4u * (unsigned)((16 * ch + 4 * j) * H), sx = 4u * (unsigned)((16 * ch + 4 * j) * (int)ldx);
+                    a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, sd, 0));
+                    x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl, sx, 0));
+                    if (two) x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl + 64u, sx, 0));
+                }
+            }
+        }
+        tail_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        float bsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (wave + 4 * c < nc) {                          // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x0[c][j], acc0, 0, 0, 0);
+                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x1[c][j], acc1, 0, 0, 0);
+                    bsum += a[c][j];
+                }
+            }
+        }
+        if (wave > 0) {
+            *reinterpret_cast<tail_f32x4*>(sFold + (((wave - 1) * 2 + 0) * 64 + lane) * 4) = acc0;
+            *reinterpret_cast<tail_f32x4*>(sFold + (((wave - 1) * 2 + 1) * 64 + lane) * 4) = acc1;
+        }
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 16) sFold[1536 + wave * 16 + lane] = bsum;
+        __syncthreads();
+        float bg = 0.f;
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                acc0 += *reinterpret_cast<const tail_f32x4*>(sFold + ((w * 2 + 0) * 64 + lane) * 4);
+                acc1 += *reinterpret_cast<const tail_f32x4*>(sFold + ((w * 2 + 1) * 64 + lane) * 4);
+            }
+            if (itile == 0 && lane < 16)
+                bg = sFold[1536 + lane] + sFold[1536 + 16 + lane] + sFold[1536 + 32 + lane] + sFold[1536 + 48 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = ot * 16 + 4 * (lane >> 4) + r;
+                if (i < ldw) { G[offW(l) + (long)o * ldw + i] = acc0[r]; q += (double)(acc0[r] * sc) * (acc0[r] * sc); }
+                if (two && i + 16 < ldw) { G[offW(l) + (long)o * ldw + i + 16] = acc1[r]; q += (double)(acc1[r] * sc) * (acc1[r] * sc); }
+            }
+            if (itile == 0 && lane < 16) {
+                G[offB(l) + ot * 16 + lane] = bg;
+                q += (double)(bg * sc) * (bg * sc);
+            }
+        }
+        const TailCoef cf = tail_sync(u, td, tag, b, which, t_next, lr, q, s_red, s_coef);
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = ot * 16 + 4 * (lane >> 4) + r;
+                const long e = nb + offW(l) + (long)o * ldw + i;
+                if (i < ldw) tail_adam1(u, e, acc0[r], s0[r], cf);
+                if (two && i + 16 < ldw) tail_adam1(u, e + 16, acc1[r], s1[r], cf);
+            }
+            if (has_b) tail_adam1(u, nb + offB(l) + ot * 16 + lane, bg, sb, cf);
+        }
+    } else {
+        // output layer (+ log_std): row-block partials -> gradient in block order; a thread keeps its elements
+        const long seg_off = offW(depth), seg_len = nd.size - seg_off;
+        const float* outpart = u.sp.outpart[which];
+        const int n_hb = (B + 15) >> 4;
+        TailPmv se[kTailMaxE];
+        float ge[kTailMaxE];
+#pragma unroll
+        for (int k = 0; k < kTailMaxE; ++k) {
+            const long idx = tid + (long)kWgradThreads * k;
+            se[k] = tail_pmv_load(u, nb + seg_off + idx, idx < seg_len);
+            ge[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < kTailMaxE; ++k) {
+            const long idx = tid + (long)kWgradThreads * k;
+            if (idx < seg_len) {
+                float acc = 0.f;
+                for (int g0 = 0; g0 < n_hb; g0 += 8) {
+                    float pv[8];
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) pv[kk] = outpart[(long)(g0 + kk < n_hb ? g0 + kk : 0) * seg_len + idx];
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) if (g0 + kk < n_hb) acc += pv[kk];
+                }
+                G[seg_off + idx] = acc;
+                q += (double)(acc * sc) * (acc * sc);
+                ge[k] = acc;
+            }
+        }
+        const TailCoef cf = tail_sync(u, td, tag, b, which, t_next, lr, q, s_red, s_coef);
+#pragma unroll
+        for (int k = 0; k < kTailMaxE; ++k) {
+            const long idx = tid + (long)kWgradThreads * k;
+            if (idx < seg_len) tail_adam1(u, nb + seg_off + idx, ge[k], se[k], cf);
+        }
+    }
+}
+
+template <int HA, int HC>
+__global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(UpdateDev u, TailDev td) {
+    __shared__ double s_red[17];
+    __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
+    __shared__ float s_coef[4];
+    const int b = blockIdx.x;
+    const unsigned long long seq = __hip_atomic_load(&td.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned tag = (unsigned)(seq % 0xFFFFFFFFull) + 1u;            // never 0: a zero-initialised record is never current
+    if (b == td.nblk) {
+        // bookkeeping: the totals need nobody; what other workgroups read at their start moves only after all have published
+        if (threadIdx.x >= 64) return;
+        ppo_update_bookkeeping_totals(u);
+        double sq0, sq1;
+        tail_gather(td, tag, sq0, sq1);
+        ppo_update_bookkeeping_steps(u);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&td.ctl->seq, seq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (u.cursor_advance) u.cursor[0] += u.cursor_advance;
+        }
+        return;
+    }
+    const int job = (b & 7) * td.per_xcd + (b >> 3);          // XCD b % 8 works on one run of the layer-major job list
+    if (job < td.jobs_a) tail_job<HA>(u, td, tag, b, 0, job, s_fold, s_red, s_coef);
+    else if (job < td.jobs_a + td.jobs_c) tail_job<HC>(u, td, tag, b, 1, job - td.jobs_a, s_fold, s_red, s_coef);
+    else if (threadIdx.x == 0) tail_publish(td, tag, b, 0.0);
+}
+
+template <int HA, int HC>
+static int tail_launch(const UpdateDev& u, const TailDev& td, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    // every workgroup waits for every other one: all of them must fit on the device at once
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(ppo_update_wgrad_adam_kernel<HA, HC>),
+                                                                   kWgradThreads, 0);
+        if (e != hipSuccess) { set_error("ppo_update_wgrad_adam: occupancy query: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+        per_cu = n > 0 ? n : -1;
+    }
+    static int cus = 0;                        // (queried on the first, eager, launch: nothing but the launch inside a stream capture)
+    if (cus == 0) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    PPOAF_REQUIRE(per_cu > 0 && (long)(td.nblk + 1) <= (long)per_cu * cus,
+                  "ppo_update_wgrad_adam: %d workgroups cannot be resident together (%d per CU x %d CUs)", td.nblk + 1, per_cu, cus);
+    if (e0 || e1)
+        hipExtLaunchKernelGGL((ppo_update_wgrad_adam_kernel<HA, HC>), dim3((unsigned)(td.nblk + 1)), dim3(kWgradThreads), 0, s, e0, e1, 0, u, td);
+    else
+        hipLaunchKernelGGL((ppo_update_wgrad_adam_kernel<HA, HC>), dim3((unsigned)(td.nblk + 1)), dim3(kWgradThreads), 0, s, u, td);
+    return check_launch("ppo_update_wgrad_adam");
+}
+
+}  // namespace ppoaf
+
+using namespace ppoaf;
+
+extern "C" int64_t ppoaf_ppo_update_tail_ctl_bytes(const ppoaf_ppo_update_args_t* args) {
+    UpdateDev u;
+    ppoaf_ppo_update_args_t a;
+    if (!args) return -1;
+    a = *args;
+    a.split_workspace = nullptr;
+    if (make_update_dev(&a, u)) return -1;
+    return (int64_t)kTailRecOff + 16 * (int64_t)split_wgrad_blocks(u);
+}
+
+extern "C" int ppoaf_ppo_update_wgrad_adam_timed(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
+                                                 void* start_event, void* stop_event, ppoaf_stream_t stream) {
+    UpdateDev u;
+    int rc = make_update_dev(args, u);
+    if (rc) return rc;
+    PPOAF_REQUIRE(u.split, "ppo_update_wgrad_adam: args->split_workspace is not set (the tail of the split-wgrad chain)");
+    PPOAF_REQUIRE(ctl && (((uintptr_t)ctl) & 63) == 0, "ppo_update_wgrad_adam: control block missing or not 64-byte aligned");
+    PPOAF_REQUIRE(wait_seconds > 0.0 && wait_seconds <= 600.0, "ppo_update_wgrad_adam: wait_seconds=%g", wait_seconds);
+    TailDev td;
+    td.ctl = reinterpret_cast<TailCtl*>(ctl);
+    td.budget = (long long)(wait_seconds * 1.0e8);
+    td.jobs_a = split_wgrad_jobs(u.net[0]);
+    td.jobs_c = split_wgrad_jobs(u.net[1]);
+    td.per_xcd = split_wgrad_per_xcd(u);
+    td.nblk = split_wgrad_blocks(u);
+    PPOAF_REQUIRE(td.nblk <= 64 * kTailMaxRounds, "ppo_update_wgrad_adam: %d workgroups, a polling wave holds %d records", td.nblk,
+                  64 * kTailMaxRounds);
+    for (int w = 0; w < 2; ++w)
+        PPOAF_REQUIRE(ws_seg_len(u.net[w]) <= (long)kWgradThreads * kTailMaxE, "ppo_update_wgrad_adam: output segment of %ld floats (at most %d)",
+                      ws_seg_len(u.net[w]), kWgradThreads * kTailMaxE);
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;
+    const int ha = u.net[0].H, hc = u.net[1].H;
+    if (ha == 32 && hc == 32) return tail_launch<32, 32>(u, td, s, e0, e1);
+    if (ha == 64 && hc == 64) return tail_launch<64, 64>(u, td, s, e0, e1);
+    if (ha == 128 && hc == 128) return tail_launch<128, 128>(u, td, s, e0, e1);
+    if (ha == 256 && hc == 256) return tail_launch<256, 256>(u, td, s, e0, e1);
+    if (ha == 128 && hc == 256) return tail_launch<128, 256>(u, td, s, e0, e1);
+    if (ha == 64 && hc == 128) return tail_launch<64, 128>(u, td, s, e0, e1);
+    set_error("ppo_update_wgrad_adam: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
+    return PPOAF_E_INVALID;
+}
+
+extern "C" int ppoaf_ppo_update_wgrad_adam(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds, ppoaf_stream_t stream) {
+    return ppoaf_ppo_update_wgrad_adam_timed(args, ctl, wait_seconds, nullptr, nullptr, stream);
+}

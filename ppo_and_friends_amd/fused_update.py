@@ -232,6 +232,35 @@ class FusedPolicyUpdate:
         else:
             _lib.check(lib.ppoaf_ppo_update_reduce(ref, 1, st), "ppo_update_reduce")
 
+    # ---- fused tail of the split-wgrad chain: fwd_bwd -> wgrad + clip norms + Adam in one launch (two launches per mini-batch)
+    tail_wait_seconds = 2.0            # bound of the in-kernel wait for the other workgroups' norm records
+    tail_launches = 0                  # launches issued in this process (tests: the path really ran; graph replays not counted)
+
+    def tail_reason(self):
+        """'' when a mini-batch of the split-wgrad chain ends in ppoaf_ppo_update_wgrad_adam, else why it takes the
+        wgrad and Adam launches.  PPOAF_FUSED_TAIL = 1 (default) | 0."""
+        import os
+        if os.environ.get("PPOAF_FUSED_TAIL", "1") == "0":
+            return "off (PPOAF_FUSED_TAIL=0)"
+        if getattr(self, "_tail_disabled", ""):
+            return "disabled after a failed launch: " + self._tail_disabled
+        if not self.split:
+            return "the slab chain runs (" + self.split_reason + ")"
+        if self.multi:
+            return "N > 1: the gradient exchange sits between the weight gradients and the optimiser step"
+        return ""
+
+    def _tail_ctl_ptr(self, args):
+        ctl = getattr(self, "_tail_ctl", None)
+        if ctl is None:
+            n = int(self._lib.ppoaf_ppo_update_tail_ctl_bytes(C.byref(args)))
+            if n <= 0:
+                raise _lib.PpoafError("ppo_update_tail_ctl_bytes: " + self._lib.ppoaf_last_error().decode("utf-8", "replace"))
+            # zeroed once, then kept: the block carries the launch tag from one launch to the next
+            ctl = self._tail_ctl = torch.zeros((n + 63) // 64 * 16, dtype=torch.int32, device=self.pol.device)
+        FusedPolicyUpdate.tail_launches += 1
+        return ctl.data_ptr()
+
     def _ws_wanted(self):
         """Would `ws_reason` pick the persistent kernel for this policy's shapes (before any epoch table exists)?"""
         import os
@@ -387,6 +416,13 @@ class FusedPolicyUpdate:
                     or lib.ppoaf_ppo_update_adam_exchanged(ref, self.xchg_sp.handle, st)
                 if rc != 0:
                     _lib.check(rc, "ppo_update")
+                return
+            if single and self.tail_reason() == "":
+                # fused tail (csrc/ppo_update_tail.hip): weight gradients, clip norms and clip + Adam in ONE launch
+                rc = lib.ppoaf_ppo_update_wgrad_adam(ref, self._tail_ctl_ptr(args), self.tail_wait_seconds, st)
+                self._tail_used = True
+                if rc != 0:
+                    _lib.check(rc, "ppo_update_wgrad_adam")
                 return
             rc = lib.ppoaf_ppo_update_wgrad(ref, st)
             if rc == 0 and self.xchg is not None:
@@ -561,6 +597,15 @@ class FusedPolicyUpdate:
                 return (f"ppo_update_ws: the last launch did not complete (error word {words[2]}, networks finished {words[3]} of 2, "
                         f"worker tickets drawn {words[0]} / {words[1]}): a network did not get all of its workgroups onto its XCD "
                         "(another process on this GPU, or a partition mode that exposes a single XCD?)")
+        ctl = getattr(self, "_tail_ctl", None)
+        if ctl is not None and getattr(self, "_tail_used", False):
+            self._tail_used = False
+            if int(ctl[2].item()) != 0:                   # TailCtl.error
+                ctl[2:3].zero_()
+                self._tail_disabled = "a wait for the other workgroups' norm records ran out of time"
+                self._graphs.clear()                      # the captured chains end in the fused launch
+                return ("ppo_update_wgrad_adam: a wait ran out of time -- the launch's workgroups were not all resident at once "
+                        "(another process on this GPU?)")
         ctl = getattr(self, "_persist_ctl", None)
         if ctl is not None and getattr(self, "_persist_used", False):
             self._persist_used = False
@@ -652,7 +697,7 @@ class FusedPolicyUpdate:
         args = self._args_for(self.B)
         left = self.n_full
         self._ws_snapshot = None
-        if left > 0 and self.n_done == 0 and (self.ws_reason() == "" or self.persistent_reason() == ""):
+        if left > 0 and self.n_done == 0 and (self.ws_reason() == "" or self.persistent_reason() == "" or self.tail_reason() == ""):
             # what the epoch starts from (a few buckets of <= 1 MB: device-to-device copies), should the launch not complete
             self._ws_snapshot = [t.clone() for t in self._epoch_state()]
         if left > 0 and self.ws_reason() == "":
@@ -730,7 +775,7 @@ class FusedPolicyUpdate:
     def end_epoch(self):
         """-> numpy totals[9] (sums of the 8 loss scalars over mini-batches, mini-batch count)."""
         ppo = self.ppo
-        if not self.multi and (getattr(self, "_ws_used", False) or getattr(self, "_persist_used", False)):
+        if not self.multi and (getattr(self, "_ws_used", False) or getattr(self, "_persist_used", False) or getattr(self, "_tail_used", False)):
             torch.cuda.current_stream().synchronize()
             why = self._persistent_failure()
             if why:                                       # before anything of the failed epoch reaches the normaliser

@@ -275,6 +275,50 @@ def test_full_size_split_wgrad_chain_matches_the_slab_chain(name, monkeypatch):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2])
 
 
+@pytest.mark.parametrize("name", ["C2", "C3", "C4"])
+def test_full_size_fused_tail_is_bitwise_the_three_launch_chain(name, monkeypatch):
+    """
+    Round 4: fwd_bwd -> ppoaf_ppo_update_wgrad_adam (weight gradients, clip norms from tagged records every workgroup
+    waits for, clip + Adam on the workgroup's own elements: ONE launch) against fwd_bwd -> wgrad -> Adam at the BASELINE
+    shapes, a whole epoch each on the same rollout and shuffle (C2: 2048 mini-batches, 153 workgroups per launch; C3 / C4:
+    256-wide critic, 369 workgroups): the same jobs, folds and summation orders, so parameters, both Adam moments, the
+    gradient bucket of the last mini-batch, step counters, normaliser state and totals are BITWISE equal -- graph replay
+    and eager launches alike -- and no wait ran out of its budget.
+    """
+    from ppo_and_friends_amd import fused_update
+    monkeypatch.setenv("PPOAF_WS", "0")                     # (256-wide critics: the chain, not the persistent kernel)
+    monkeypatch.setenv("PPOAF_OVERLAP_ICM", "0")
+    outs = {}
+    for tail, graphs in (("0", True), ("1", True), ("1", False)):
+        monkeypatch.setenv("PPOAF_FUSED_TAIL", tail)
+        before = fused_update.FusedPolicyUpdate.tail_launches
+        ppo, E, T, A = _c_config(name, use_graphs=graphs)
+        ppo.rollout()
+        pol = ppo.policies["p"]
+        pol.train()
+        fused = ppo._fused_updater("p", 256)
+        assert fused.split and (fused.tail_reason() == "") == (tail == "1"), (fused.split_reason, fused.tail_reason())
+        perm = torch.randperm(len(pol.dataset), device=pol.device, generator=torch.Generator(device=pol.device).manual_seed(5))
+        fused.begin_epoch(perm)
+        fused.run_epoch()
+        t = fused.end_epoch()
+        n_mb = E * T * A // 256
+        assert t[8] == n_mb and int(pol.policy_step_counts[0].item()) == int(pol.policy_step_counts[1].item()) == n_mb
+        assert (fused_update.FusedPolicyUpdate.tail_launches > before) == (tail == "1")
+        assert fused.tail_reason() == ("" if tail == "1" else "off (PPOAF_FUSED_TAIL=0)")      # no launch failed
+        if tail == "1":
+            assert int(fused._tail_ctl[2].item()) == 0 and int(fused._tail_ctl[0].item()) == n_mb      # error word, launches completed
+        outs[(tail, graphs)] = (pol.policy_params.clone(), pol.policy_exp_avg.clone(), pol.policy_exp_avg_sq.clone(),
+                                pol.policy_grads.clone(), t.copy(), fused.vn_mean.clone(), fused.vn_var.clone(), int(fused.cursor.item()))
+    ref = outs[("0", True)]
+    for key in (("1", True), ("1", False)):
+        got = outs[key]
+        for i, what in enumerate(("parameters", "exp_avg", "exp_avg_sq", "gradient bucket of the last mini-batch")):
+            assert torch.equal(got[i], ref[i]), f"{key}: {what} differ, max |d| {float((got[i] - ref[i]).abs().max()):.3e}"
+        assert np.array_equal(got[4], ref[4]), (got[4], ref[4])
+        assert torch.equal(got[5], ref[5]) and torch.equal(got[6], ref[6]) and got[7] == ref[7]
+
+
 def test_c5_mat_split_wgrad_chain_matches_the_slab_form_at_full_size(monkeypatch):
     """
     K15 at C5 size (52 token tiles, 832 token rows): ONE mini-batch's gradient bucket of the split-wgrad chain (input / dz
