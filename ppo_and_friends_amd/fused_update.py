@@ -240,6 +240,8 @@ class FusedPolicyUpdate:
         """'' when a mini-batch of the split-wgrad chain ends in ppoaf_ppo_update_wgrad_adam, else why it takes the
         wgrad and Adam launches.  PPOAF_FUSED_TAIL = 1 (default) | 0."""
         import os
+        if type(self) is not FusedPolicyUpdate:
+            return "K12 (MLP policies) only"
         if os.environ.get("PPOAF_FUSED_TAIL", "1") == "0":
             return "off (PPOAF_FUSED_TAIL=0)"
         if getattr(self, "_tail_disabled", ""):
