@@ -23,13 +23,14 @@
 // the epoch's starting state and runs the three-launch chain, fused_update.py).
 #include "ppo_update_dev.hpp"
 #include <hip/hip_ext.h>
+#include <cstddef>
 
 namespace ppoaf {
 
 typedef unsigned tail_u32x4 __attribute__((ext_vector_type(4)));
 typedef float tail_f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTailRecOff = 64;               // byte offset of the records inside the control block
+constexpr int kTailRecOff = 256;              // byte offset of the records inside the control block
 constexpr int kTailMaxRounds = 8;             // a polling lane holds up to 8 records: <= 512 workgroups
 constexpr int kTailMaxE = 9;                  // output segment: up to 9 elements per thread (8 x 256 weights + bias + log_std)
 
@@ -37,8 +38,27 @@ struct TailCtl {
     unsigned long long seq;                   // launches completed; a launch tags its records with (seq mod 2^32 - 1) + 1
     unsigned error;                           // a wait ran out of its budget: later launches do not wait again
     unsigned pad[13];
+    unsigned long long stamps[24];            // diagnostic build (-DPPOAF_TAIL_STAMPS): s_memtime per phase of one workgroup
     tail_u32x4 rec[1];                        // [8 * per_xcd]: {q bits 0..31, tag, q bits 32..63, tag}
 };
+static_assert(offsetof(TailCtl, rec) == kTailRecOff, "record offset");
+
+// diagnostic layer (tools/tail_stamps.py): one macro, nothing in the shipped kernel
+#ifdef PPOAF_TAIL_STAMPS
+#ifndef PPOAF_TAIL_STAMP_BLOCK
+#define PPOAF_TAIL_STAMP_BLOCK 0
+#endif
+#define TAIL_STAMP(td, k)                                                                          \
+    do {                                                                                           \
+        if (blockIdx.x == PPOAF_TAIL_STAMP_BLOCK && threadIdx.x == 0) {                            \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            (td).ctl->stamps[k] = t_;                                                              \
+        }                                                                                          \
+    } while (0)
+#else
+#define TAIL_STAMP(td, k) do {} while (0)
+#endif
 
 struct TailDev {
     TailCtl* ctl;
@@ -59,34 +79,55 @@ __device__ __forceinline__ void tail_publish(const TailDev& td, const unsigned t
     __builtin_amdgcn_raw_buffer_store_b128(r, tail_rsrc(td), (unsigned)(kTailRecOff + 16 * b), 0, 16 /* sc1 */);
 }
 
+// wave_sum<double> in its own association (xor 32, 16, 8, 4, 2, 1 -- IEEE addition is commutative, so pairing lane i with
+// lane i ^ k is all that matters), with the last four steps on DPP row operations instead of ds_bpermute round trips: after
+// the xor-32 and xor-16 steps all four 16-lane rows hold the same vector, row_ror:8 is then xor 8 exactly, the result is
+// 8-periodic so row_ror:4 delivers what xor 4 would, and xor 2 / xor 1 are quad permutes (mlp_device.hpp: group16_sum).
+template <int CTRL> __device__ __forceinline__ double tail_dpp_d(const double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double tail_wave_sum(double v) {
+    v += __shfl_xor(v, 32, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += tail_dpp_d<kDppRor8>(v);
+    v += tail_dpp_d<kDppRor4>(v);
+    v += tail_dpp_d<kDppXor2>(v);
+    v += tail_dpp_d<kDppXor1>(v);
+    return v;
+}
+
 // one whole wave: wait until every workgroup's record carries this launch's tag, then the two squared norms in the
 // association of xchg_ordered_norms (lane-strided ascending per lane, xor butterfly; an idle or other-network record adds
 // +0.0).  Returns false when the wait ran out of its budget (error word set; the sums are then meaningless).
-__device__ __forceinline__ bool tail_gather(const TailDev& td, const unsigned tag, double& sq0, double& sq1) {
+template <int NR>
+__device__ __forceinline__ bool tail_gather_n(const TailDev& td, const unsigned tag, double& sq0, double& sq1) {
     const int lane = threadIdx.x & 63;
     const __amdgpu_buffer_rsrc_t rs = tail_rsrc(td);
-    tail_u32x4 r[kTailMaxRounds];
+    tail_u32x4 r[NR];
     long long budget = td.budget;
     if (__hip_atomic_load(&td.ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) budget = 0;     // broken before: no second wait
     const long long t0 = (long long)wall_clock64();
     bool ok = true;
-    while (true) {
+    for (unsigned polls = 1;; ++polls) {
 #pragma unroll
-        for (int k = 0; k < kTailMaxRounds; ++k) {
+        for (int k = 0; k < NR; ++k) {
             const int bb = lane + 64 * k;
             r[k] = tail_u32x4{0u, tag, 0u, tag};
             if (bb < td.nblk) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(kTailRecOff + 16 * bb), 0, 16 /* sc1 */);
         }
         bool all = true;
 #pragma unroll
-        for (int k = 0; k < kTailMaxRounds; ++k) all = all && r[k].y == tag && r[k].w == tag;
+        for (int k = 0; k < NR; ++k) all = all && r[k].y == tag && r[k].w == tag;
         if (__all((int)all)) break;
-        if ((long long)wall_clock64() - t0 > budget) { ok = false; break; }
+        if ((polls & 15u) == 0u && (long long)wall_clock64() - t0 > budget) { ok = false; break; }
         __builtin_amdgcn_s_sleep(1);
     }
     double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-    for (int k = 0; k < kTailMaxRounds; ++k) {
+    for (int k = 0; k < NR; ++k) {
         const int bb = lane + 64 * k;
         if (bb < td.nblk) {
             const double q = __longlong_as_double((long long)(((unsigned long long)r[k].z << 32) | (unsigned long long)r[k].x));
@@ -94,24 +135,27 @@ __device__ __forceinline__ bool tail_gather(const TailDev& td, const unsigned ta
             if (job < td.jobs_a) p0 += q; else p1 += q;
         }
     }
-    sq0 = wave_sum(p0);
-    sq1 = wave_sum(p1);
+    sq0 = tail_wave_sum(p0);
+    sq1 = tail_wave_sum(p1);
     if (!ok && lane == 0) __hip_atomic_store(&td.ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return ok;
 }
+__device__ __forceinline__ bool tail_gather(const TailDev& td, const unsigned tag, double& sq0, double& sq1) {
+    if (td.nblk <= 192) return tail_gather_n<3>(td, tag, sq0, sq1);          // uniform: a lane holds ceil(nblk / 64) records
+    return tail_gather_n<kTailMaxRounds>(td, tag, sq0, sq1);
+}
 
 // Every thread of the workgroup: its squared-norm contribution in, the step's clip / Adam coefficients out.
-// t_next = step_counts[which] + 1 and lr were read at the START of the workgroup (the bookkeeping workgroup advances the
-// counter only after every workgroup has published, i.e. after all those reads).
+// bc1 / bc2s: the bias corrections of the step being taken (ppo_update_bookkeeping_steps' expressions), computed by the
+// caller from step_counts[which] + 1 read at the START of the workgroup (the bookkeeping workgroup advances the counter
+// only after every workgroup has published, i.e. after all those reads) while its operand loads were in flight.
 __device__ __forceinline__ TailCoef tail_sync(const UpdateDev& u, const TailDev& td, const unsigned tag, const int b, const int which,
-                                              const long long t_next, const float lr, const double q_thread, double* s_red,
+                                              const double bc1, const double bc2s, const float lr, const double q_thread, double* s_red,
                                               float* s_coef) {
     const double q = block_sum(q_thread, s_red);
+    TAIL_STAMP(td, 4);
     if (threadIdx.x < 64) {
         if (threadIdx.x == 0) tail_publish(td, tag, b, q);
-        // the bias corrections of ppo_update_bookkeeping_steps, while the records travel
-        const double bc1 = 1.0 - pow((double)u.beta1, (double)t_next);
-        const double bc2s = sqrt(1.0 - pow((double)u.beta2, (double)t_next));
         double sq0, sq1;
         tail_gather(td, tag, sq0, sq1);
         if (threadIdx.x == 0) {                                // ppo_update_adam_kernel's coefficients, expression for expression
@@ -124,6 +168,7 @@ __device__ __forceinline__ TailCoef tail_sync(const UpdateDev& u, const TailDev&
         }
     }
     __syncthreads();
+    TAIL_STAMP(td, 5);
     return TailCoef{s_coef[0], s_coef[1], s_coef[2]};
 }
 
@@ -145,9 +190,13 @@ __device__ __forceinline__ void tail_adam1(const UpdateDev& u, const long idx, c
 
 // One job of the split-wgrad job list (ppo_update_ws.hip: split_wgrad_job -- same tiles, same operand loads, same fold
 // and summation orders), carried through to the optimiser step.  Offsets of p / m / v / G are bucket offsets.
+// The 16 x 32 output tile is formed by wave 0 (C layout) and handed to ALL 256 threads through LDS for the optimiser
+// step: thread t owns tile elements t and t + 256 (row e / 32, column e % 32: whole 128-byte lines of p / m / v), whose
+// state it requested at the start of the job, beside the MFMA operands.
 template <int H>
 __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, const unsigned tag, const int b, const int which,
-                                         const int job, float* sFold /* [3][2][256] + [4][16] */, double* s_red, float* s_coef) {
+                                         const int job, float* sFold /* [3][2][256] + [4][16] */, float* sTile /* [16][32] + [16] */,
+                                         double* s_red, float* s_coef) {
     constexpr int MAXC = 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,24 +219,29 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
     const int n_hidden = (depth - 1) * t * t2, n_l0 = t * p0;
     const float sc = u.grad_scale;
     double q = 0.0;
+    double bc1 = 1.0, bc2s = 1.0;
+    TAIL_STAMP(td, 0);
     if (job < n_hidden + n_l0) {
         int l, ot, itile, n_it;
         if (job < n_hidden) { l = 1 + job / (t * t2); const int jj = job % (t * t2); ot = jj / t2; itile = 2 * (jj % t2); n_it = t; }
         else { l = 0; const int jj = job - n_hidden; ot = jj / p0; itile = 2 * (jj % p0); n_it = n_it0; }
         const bool two = itile + 1 < n_it;                    // uniform per workgroup
         const long ldw = l >= 1 ? H : in_dim;
-        const int i = itile * 16 + (lane & 15);               // C layout: column = lane & 15, rows 4 (lane >> 4) + r
-        // wave 0 owns the output tile: its elements' optimiser state goes out first, beside the operand loads below
-        TailPmv s0[4], s1[4], sb;
+        // this thread's two tile elements (and, threads 64..79 of the jobs of input piece 0, one bias): optimiser state first
+        long eidx[2];
+        bool eok[2];
+        TailPmv se[2], sb;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = ot * 16 + 4 * (lane >> 4) + r;
-            const long e = nb + offW(l) + (long)o * ldw + i;
-            s0[r] = tail_pmv_load(u, e, wave == 0 && i < ldw);
-            s1[r] = tail_pmv_load(u, e + 16, wave == 0 && two && i + 16 < ldw);
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + 256 * k, row = e >> 5, col = e & 31;
+            const int i = itile * 16 + col;
+            eok[k] = (col < 16 || two) && i < ldw;
+            eidx[k] = nb + offW(l) + (long)(ot * 16 + row) * ldw + i;
+            se[k] = tail_pmv_load(u, eidx[k], eok[k]);
         }
-        const bool has_b = wave == 0 && itile == 0 && lane < 16;
-        sb = tail_pmv_load(u, nb + offB(l) + ot * 16 + lane, has_b);
+        const bool has_b = itile == 0 && tid >= 64 && tid < 80;
+        const long bidx = nb + offB(l) + ot * 16 + (tid - 64);
+        sb = tail_pmv_load(u, bidx, has_b);
         const long ldx = l >= 1 ? H : 64;
         const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(u.sp.dbuf[which] + (long)l * plane, 0, 0xFFFFFFFF, 0x00020000);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -211,6 +265,11 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
                 }
             }
         }
+        if (wave == 0) {                                      // while the loads are in flight (only thread 0 uses them)
+            bc1 = 1.0 - pow((double)u.beta1, (double)t_next);
+            bc2s = sqrt(1.0 - pow((double)u.beta2, (double)t_next));
+        }
+        TAIL_STAMP(td, 1);
         tail_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         float bsum = 0.f;
 #pragma unroll
@@ -224,6 +283,7 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
                 }
             }
         }
+        TAIL_STAMP(td, 2);
         if (wave > 0) {
             *reinterpret_cast<tail_f32x4*>(sFold + (((wave - 1) * 2 + 0) * 64 + lane) * 4) = acc0;
             *reinterpret_cast<tail_f32x4*>(sFold + (((wave - 1) * 2 + 1) * 64 + lane) * 4) = acc1;
@@ -232,37 +292,37 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
         bsum += __shfl_xor(bsum, 32, 64);
         if (lane < 16) sFold[1536 + wave * 16 + lane] = bsum;
         __syncthreads();
-        float bg = 0.f;
         if (wave == 0) {
+            const int i = itile * 16 + (lane & 15);           // C layout: column = lane & 15, rows 4 (lane >> 4) + r
 #pragma unroll
             for (int w = 0; w < 3; ++w) {
                 acc0 += *reinterpret_cast<const tail_f32x4*>(sFold + ((w * 2 + 0) * 64 + lane) * 4);
                 acc1 += *reinterpret_cast<const tail_f32x4*>(sFold + ((w * 2 + 1) * 64 + lane) * 4);
             }
+            float bg = 0.f;
             if (itile == 0 && lane < 16)
                 bg = sFold[1536 + lane] + sFold[1536 + 16 + lane] + sFold[1536 + 32 + lane] + sFold[1536 + 48 + lane];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = ot * 16 + 4 * (lane >> 4) + r;
+                const int row = 4 * (lane >> 4) + r, o = ot * 16 + row;
                 if (i < ldw) { G[offW(l) + (long)o * ldw + i] = acc0[r]; q += (double)(acc0[r] * sc) * (acc0[r] * sc); }
                 if (two && i + 16 < ldw) { G[offW(l) + (long)o * ldw + i + 16] = acc1[r]; q += (double)(acc1[r] * sc) * (acc1[r] * sc); }
+                sTile[row * 32 + (lane & 15)] = acc0[r];
+                sTile[row * 32 + 16 + (lane & 15)] = acc1[r];
             }
             if (itile == 0 && lane < 16) {
                 G[offB(l) + ot * 16 + lane] = bg;
                 q += (double)(bg * sc) * (bg * sc);
+                sTile[512 + lane] = bg;
             }
         }
-        const TailCoef cf = tail_sync(u, td, tag, b, which, t_next, lr, q, s_red, s_coef);
-        if (wave == 0) {
+        TAIL_STAMP(td, 3);
+        const TailCoef cf = tail_sync(u, td, tag, b, which, bc1, bc2s, lr, q, s_red, s_coef);     // (ends in a workgroup barrier: sTile is visible)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = ot * 16 + 4 * (lane >> 4) + r;
-                const long e = nb + offW(l) + (long)o * ldw + i;
-                if (i < ldw) tail_adam1(u, e, acc0[r], s0[r], cf);
-                if (two && i + 16 < ldw) tail_adam1(u, e + 16, acc1[r], s1[r], cf);
-            }
-            if (has_b) tail_adam1(u, nb + offB(l) + ot * 16 + lane, bg, sb, cf);
-        }
+        for (int k = 0; k < 2; ++k)
+            if (eok[k]) tail_adam1(u, eidx[k], sTile[tid + 256 * k], se[k], cf);
+        if (has_b) tail_adam1(u, bidx, sTile[512 + tid - 64], sb, cf);
+        TAIL_STAMP(td, 6);
     } else {
         // output layer (+ log_std): row-block partials -> gradient in block order; a thread keeps its elements
         const long seg_off = offW(depth), seg_len = nd.size - seg_off;
@@ -293,7 +353,11 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
                 ge[k] = acc;
             }
         }
-        const TailCoef cf = tail_sync(u, td, tag, b, which, t_next, lr, q, s_red, s_coef);
+        if (wave == 0) {
+            bc1 = 1.0 - pow((double)u.beta1, (double)t_next);
+            bc2s = sqrt(1.0 - pow((double)u.beta2, (double)t_next));
+        }
+        const TailCoef cf = tail_sync(u, td, tag, b, which, bc1, bc2s, lr, q, s_red, s_coef);
 #pragma unroll
         for (int k = 0; k < kTailMaxE; ++k) {
             const long idx = tid + (long)kWgradThreads * k;
@@ -306,6 +370,7 @@ template <int HA, int HC>
 __global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(UpdateDev u, TailDev td) {
     __shared__ double s_red[17];
     __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
+    __shared__ float s_tile[16 * 32 + 16];
     __shared__ float s_coef[4];
     const int b = blockIdx.x;
     const unsigned long long seq = __hip_atomic_load(&td.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -324,8 +389,8 @@ __global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(Up
         return;
     }
     const int job = (b & 7) * td.per_xcd + (b >> 3);          // XCD b % 8 works on one run of the layer-major job list
-    if (job < td.jobs_a) tail_job<HA>(u, td, tag, b, 0, job, s_fold, s_red, s_coef);
-    else if (job < td.jobs_a + td.jobs_c) tail_job<HC>(u, td, tag, b, 1, job - td.jobs_a, s_fold, s_red, s_coef);
+    if (job < td.jobs_a) tail_job<HA>(u, td, tag, b, 0, job, s_fold, s_tile, s_red, s_coef);
+    else if (job < td.jobs_a + td.jobs_c) tail_job<HC>(u, td, tag, b, 1, job - td.jobs_a, s_fold, s_tile, s_red, s_coef);
     else if (threadIdx.x == 0) tail_publish(td, tag, b, 0.0);
 }
 
@@ -343,8 +408,8 @@ static int tail_launch(const UpdateDev& u, const TailDev& td, hipStream_t s, hip
     static int cus = 0;                        // (queried on the first, eager, launch: nothing but the launch inside a stream capture)
     if (cus == 0) {
         int dev = 0;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     }
     PPOAF_REQUIRE(per_cu > 0 && (long)(td.nblk + 1) <= (long)per_cu * cus,
                   "ppo_update_wgrad_adam: %d workgroups cannot be resident together (%d per CU x %d CUs)", td.nblk + 1, per_cu, cus);
