@@ -35,9 +35,11 @@ constexpr int kTailMaxRounds = 8;             // a polling lane holds up to 8 re
 constexpr int kTailMaxE = 9;                  // output segment: up to 9 elements per thread (8 x 256 weights + bias + log_std)
 
 struct TailCtl {
-    unsigned long long seq;                   // launches completed; a launch tags its records with (seq mod 2^32 - 1) + 1
+    unsigned long long seq;                   // launches completed; a launch tags its records with (seq mod 2^31) + 1
     unsigned error;                           // a wait ran out of its budget: later launches do not wait again
-    unsigned pad[13];
+    unsigned pad;
+    long long bc_t[2];                        // the Adam step (per network) the corrections below were computed for
+    double bc[4];                             // [network][1 - beta1^t, sqrt(1 - beta2^t)]: left by the previous launch's bookkeeping
     unsigned long long stamps[24];            // diagnostic build (-DPPOAF_TAIL_STAMPS): s_memtime per phase of one workgroup
     tail_u32x4 rec[1];                        // [8 * per_xcd]: {q bits 0..31, tag, q bits 32..63, tag}
 };
@@ -145,31 +147,41 @@ __device__ __forceinline__ bool tail_gather(const TailDev& td, const unsigned ta
     return tail_gather_n<kTailMaxRounds>(td, tag, sq0, sq1);
 }
 
-// Every thread of the workgroup: its squared-norm contribution in, the step's clip / Adam coefficients out.
-// bc1 / bc2s: the bias corrections of the step being taken (ppo_update_bookkeeping_steps' expressions), computed by the
-// caller from step_counts[which] + 1 read at the START of the workgroup (the bookkeeping workgroup advances the counter
-// only after every workgroup has published, i.e. after all those reads) while its operand loads were in flight.
-__device__ __forceinline__ TailCoef tail_sync(const UpdateDev& u, const TailDev& td, const unsigned tag, const int b, const int which,
-                                              const double bc1, const double bc2s, const float lr, const double q_thread, double* s_red,
-                                              float* s_coef) {
-    const double q = block_sum(q_thread, s_red);
-    TAIL_STAMP(td, 4);
-    if (threadIdx.x < 64) {
-        if (threadIdx.x == 0) tail_publish(td, tag, b, q);
-        double sq0, sq1;
-        tail_gather(td, tag, sq0, sq1);
-        if (threadIdx.x == 0) {                                // ppo_update_adam_kernel's coefficients, expression for expression
-            const float total_norm = (float)sqrt(which ? sq1 : sq0);
-            float coef = 1.0f;
-            if (u.max_norm > 0.f) coef = fminf(u.max_norm / (total_norm + 1e-6f), 1.0f);
-            s_coef[0] = u.grad_scale * coef;
-            s_coef[1] = (float)((double)lr / bc1);
-            s_coef[2] = (float)bc2s;
-        }
+// The bias corrections of Adam step t of network `which` (ppo_update_bookkeeping_steps' expressions): the previous launch's
+// bookkeeping workgroup left them in the control block while it waited (two double pow: ~2 us of one wave); computed
+// here only when the block holds another step's (first launch, restored state).
+struct TailBc { long long t; double bc1, bc2s; };
+__device__ __forceinline__ TailBc tail_bc_load(const UpdateDev& u, const TailDev& td, const int which) {
+    // read at the START of the workgroup: the bookkeeping workgroup rewrites these words only after every workgroup has
+    // published its record, i.e. after all of these reads
+    TailBc r;
+    r.t = td.ctl->bc_t[which];
+    r.bc1 = td.ctl->bc[2 * which];
+    r.bc2s = td.ctl->bc[2 * which + 1];
+    return r;
+}
+
+// Wave 0 of the workgroup (all 64 lanes), q = the workgroup's squared-norm partial: publish, wait for everybody's, and
+// leave the step's clip / Adam coefficients (ppo_update_adam_kernel's, expression for expression) in s_coef.
+__device__ __forceinline__ void tail_sync_wave0(const UpdateDev& u, const TailDev& td, const unsigned tag, const int b, const int which,
+                                                const long long t_next, const TailBc& pre, const float lr, const double q,
+                                                float* s_coef) {
+    if (threadIdx.x == 0) tail_publish(td, tag, b, q);
+    double bc1 = pre.bc1, bc2s = pre.bc2s;
+    if (pre.t != t_next) {                                    // uniform
+        bc1 = 1.0 - pow((double)u.beta1, (double)t_next);
+        bc2s = sqrt(1.0 - pow((double)u.beta2, (double)t_next));
     }
-    __syncthreads();
-    TAIL_STAMP(td, 5);
-    return TailCoef{s_coef[0], s_coef[1], s_coef[2]};
+    double sq0, sq1;
+    tail_gather(td, tag, sq0, sq1);
+    if (threadIdx.x == 0) {
+        const float total_norm = (float)sqrt(which ? sq1 : sq0);
+        float coef = 1.0f;
+        if (u.max_norm > 0.f) coef = fminf(u.max_norm / (total_norm + 1e-6f), 1.0f);
+        s_coef[0] = u.grad_scale * coef;
+        s_coef[1] = (float)((double)lr / bc1);
+        s_coef[2] = (float)bc2s;
+    }
 }
 
 struct TailPmv { float p, m, v; };
@@ -211,15 +223,15 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
     };
     const long nb = nd.offset;                                 // this network's first float in the bucket
     float* G = u.grads + nb;
-    // read BEFORE this workgroup publishes (see tail_sync)
+    // read BEFORE this workgroup publishes (the bookkeeping workgroup rewrites them after everybody has)
     const long long t_next = (long long)u.step_counts[which] + 1;
     const float lr = u.lr[0];
+    const TailBc pre = tail_bc_load(u, td, which);
     constexpr int t = H / 16, t2 = (t + 1) / 2;
     const int n_it0 = (in_dim + 15) / 16, p0 = (n_it0 + 1) / 2;
     const int n_hidden = (depth - 1) * t * t2, n_l0 = t * p0;
     const float sc = u.grad_scale;
     double q = 0.0;
-    double bc1 = 1.0, bc2s = 1.0;
     TAIL_STAMP(td, 0);
     if (job < n_hidden + n_l0) {
         int l, ot, itile, n_it;
@@ -265,10 +277,6 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
                 }
             }
         }
-        if (wave == 0) {                                      // while the loads are in flight (only thread 0 uses them)
-            bc1 = 1.0 - pow((double)u.beta1, (double)t_next);
-            bc2s = sqrt(1.0 - pow((double)u.beta2, (double)t_next));
-        }
         TAIL_STAMP(td, 1);
         tail_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         float bsum = 0.f;
@@ -304,24 +312,34 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
                 bg = sFold[1536 + lane] + sFold[1536 + 16 + lane] + sFold[1536 + 32 + lane] + sFold[1536 + 48 + lane];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 4 * (lane >> 4) + r, o = ot * 16 + row;
-                if (i < ldw) { G[offW(l) + (long)o * ldw + i] = acc0[r]; q += (double)(acc0[r] * sc) * (acc0[r] * sc); }
-                if (two && i + 16 < ldw) { G[offW(l) + (long)o * ldw + i + 16] = acc1[r]; q += (double)(acc1[r] * sc) * (acc1[r] * sc); }
+                const int row = 4 * (lane >> 4) + r;
+                if (i < ldw) q += (double)(acc0[r] * sc) * (acc0[r] * sc);
+                if (two && i + 16 < ldw) q += (double)(acc1[r] * sc) * (acc1[r] * sc);
                 sTile[row * 32 + (lane & 15)] = acc0[r];
                 sTile[row * 32 + 16 + (lane & 15)] = acc1[r];
             }
             if (itile == 0 && lane < 16) {
-                G[offB(l) + ot * 16 + lane] = bg;
                 q += (double)(bg * sc) * (bg * sc);
                 sTile[512 + lane] = bg;
             }
+            TAIL_STAMP(td, 3);
+            // block_sum(q) of the chain's wgrad launch: only this wave contributes, and its wave sum + three zeros is exact
+            q = tail_wave_sum(q);
+            TAIL_STAMP(td, 4);
+            tail_sync_wave0(u, td, tag, b, which, t_next, pre, lr, q, s_coef);
         }
-        TAIL_STAMP(td, 3);
-        const TailCoef cf = tail_sync(u, td, tag, b, which, bc1, bc2s, lr, q, s_red, s_coef);     // (ends in a workgroup barrier: sTile is visible)
+        __syncthreads();                                      // s_coef and sTile are visible
+        TAIL_STAMP(td, 5);
+        const TailCoef cf = {s_coef[0], s_coef[1], s_coef[2]};
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             if (eok[k]) tail_adam1(u, eidx[k], sTile[tid + 256 * k], se[k], cf);
         if (has_b) tail_adam1(u, bidx, sTile[512 + tid - 64], sb, cf);
+        // the gradient bucket itself (nobody in this launch reads it): last, off the step's critical path
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (eok[k]) u.grads[eidx[k]] = sTile[tid + 256 * k];
+        if (has_b) u.grads[bidx] = sTile[512 + tid - 64];
         TAIL_STAMP(td, 6);
     } else {
         // output layer (+ log_std): row-block partials -> gradient in block order; a thread keeps its elements
@@ -353,11 +371,16 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
                 ge[k] = acc;
             }
         }
+        // block_sum(q) in its own association (wave sums, then the wave sum of the four of them)
+        q = tail_wave_sum(q);
+        if (lane == 0) s_red[wave] = q;
+        __syncthreads();
         if (wave == 0) {
-            bc1 = 1.0 - pow((double)u.beta1, (double)t_next);
-            bc2s = sqrt(1.0 - pow((double)u.beta2, (double)t_next));
+            q = tail_wave_sum(lane < 4 ? s_red[lane] : 0.0);
+            tail_sync_wave0(u, td, tag, b, which, t_next, pre, lr, q, s_coef);
         }
-        const TailCoef cf = tail_sync(u, td, tag, b, which, bc1, bc2s, lr, q, s_red, s_coef);
+        __syncthreads();
+        const TailCoef cf = {s_coef[0], s_coef[1], s_coef[2]};
 #pragma unroll
         for (int k = 0; k < kTailMaxE; ++k) {
             const long idx = tid + (long)kWgradThreads * k;
@@ -374,14 +397,32 @@ __global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(Up
     __shared__ float s_coef[4];
     const int b = blockIdx.x;
     const unsigned long long seq = __hip_atomic_load(&td.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned tag = (unsigned)(seq % 0xFFFFFFFFull) + 1u;            // never 0: a zero-initialised record is never current
+    const unsigned tag = ((unsigned)seq & 0x7fffffffu) + 1u;              // never 0: a zero-initialised record is never current
     if (b == td.nblk) {
         // bookkeeping: the totals need nobody; what other workgroups read at their start moves only after all have published
         if (threadIdx.x >= 64) return;
         ppo_update_bookkeeping_totals(u);
+        // while the others work: the bias corrections of the step being taken (norm_scratch, as ppo_update_bookkeeping_steps
+        // leaves them) and of the NEXT step (control block: the next launch's workgroups need not compute them)
+        const int w = threadIdx.x & 1;
+        const long long t_now = (long long)u.step_counts[w] + 1;
+        double c_now[2] = {0.0, 0.0}, c_next[2] = {0.0, 0.0};
+        if (threadIdx.x < 2) {
+            c_now[0] = 1.0 - pow((double)u.beta1, (double)t_now);
+            c_now[1] = sqrt(1.0 - pow((double)u.beta2, (double)t_now));
+            c_next[0] = 1.0 - pow((double)u.beta1, (double)(t_now + 1));
+            c_next[1] = sqrt(1.0 - pow((double)u.beta2, (double)(t_now + 1)));
+        }
         double sq0, sq1;
         tail_gather(td, tag, sq0, sq1);
-        ppo_update_bookkeeping_steps(u);
+        if (threadIdx.x < 2) {
+            u.step_counts[w] = t_now;
+            u.norm_scratch[2 + 2 * w] = c_now[0];
+            u.norm_scratch[3 + 2 * w] = c_now[1];
+            td.ctl->bc_t[w] = t_now + 1;
+            td.ctl->bc[2 * w] = c_next[0];
+            td.ctl->bc[2 * w + 1] = c_next[1];
+        }
         if (threadIdx.x == 0) {
             __hip_atomic_store(&td.ctl->seq, seq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (u.cursor_advance) u.cursor[0] += u.cursor_advance;

@@ -37,7 +37,7 @@ print("tail launch, begin -> end events: median %.2f us  min %.2f  max %.2f" % (
 ctl = f._tail_ctl.cpu().numpy()
 print("error word", ctl[2], "launches completed", ctl[0])
 stamps = ctl.view(np.int64)[8:8 + 24]
-names = ["start -> loads issued (+ bias corrections)", "loads landed + MFMA", "fold + tile to LDS (wave 0)", "block_sum of the norm partial",
+names = ["start -> loads issued", "loads landed + MFMA", "fold + tile to LDS (wave 0)", "wave sum of the norm partial",
          "publish + wait for all records + sums", "Adam on own elements (stores issued)"]
 print("workgroup", os.environ.get("PPOAF_TAIL_STAMP_BLOCK_SHOWN", "0"), "total cycles", stamps[6] - stamps[0])
 for n, d in zip(names, np.diff(stamps[:7])):
