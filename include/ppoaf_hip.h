@@ -420,11 +420,11 @@ int ppoaf_ppo_update_wgrad(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t s
  * publishes its squared-norm partial as one tagged 16-byte record, waits for the records of all workgroups, and applies
  * clip + Adam to exactly its elements (their optimiser state was requested beside the MFMA operands).  Parameters, moments,
  * gradient bucket, totals, step counters and cursor end BITWISE as after ppoaf_ppo_update_wgrad + ppoaf_ppo_update_adam(3).
- * ctl: ppoaf_ppo_update_tail_ctl_bytes(args) bytes of device memory, 64-byte aligned, zeroed ONCE by the caller and then
+ * ctl: ppoaf_ppo_update_tail_ctl_bytes() bytes of device memory, 64-byte aligned, zeroed ONCE by the caller and then
  * kept across launches (it carries the launch tag); its third 32-bit word is non-zero after a launch in which a wait
  * ran out of wait_seconds (the workgroups were not all resident: the results of that launch are then invalid and later
  * launches do not wait again).  All 8 * per_xcd + 1 workgroups must fit on the device together (checked). */
-int64_t ppoaf_ppo_update_tail_ctl_bytes(const ppoaf_ppo_update_args_t* args);
+int ppoaf_ppo_update_tail_ctl_bytes(const ppoaf_ppo_update_args_t* args, int64_t* bytes_out);
 int ppoaf_ppo_update_wgrad_adam(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds, ppoaf_stream_t stream);
 /* same launch with the kernel's own begin / end stamped into two events */
 int ppoaf_ppo_update_wgrad_adam_timed(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
@@ -809,15 +809,19 @@ int ppoaf_ppo_update_reduce_exchange(const ppoaf_ppo_update_args_t* args, ppoaf_
                                      double wait_seconds, ppoaf_stream_t stream);
 int ppoaf_ppo_update_adam_exchanged(const ppoaf_ppo_update_args_t* args, ppoaf_peer_exchange_t* x,
                                     ppoaf_stream_t stream);
-/* Split-wgrad chain on N > 1 ranks of one node: ppoaf_ppo_update_wgrad with the K17 exchange inside (mpi_avg_gradients, utils/mpi_utils.py:65-86, at
- * its call site ppo.py:2443-2448): every wgrad workgroup is one exchange group -- its sums go to this rank's slot, it
- * publishes, waits for the same group of its peers (at most wait_seconds) and stores the rank-ordered sum into grads; the
- * clip-norm partials of the SUM stay in the exchange object, so ppoaf_ppo_update_adam_exchanged follows.  The exchange
- * object must be used by this entry point only (its element -> group map); at most 256 workgroups
- * (ppoaf_ppo_update_split_blocks): wider shapes use ppoaf_ppo_update_wgrad -> ppoaf_peer_exchange_allreduce ->
- * ppoaf_ppo_update_adam(args, 2, stream). */
-int ppoaf_ppo_update_wgrad_exchange(const ppoaf_ppo_update_args_t* args, ppoaf_peer_exchange_t* xchg, double wait_seconds,
-                                    ppoaf_stream_t stream);
+/* The fused tail launch on N > 1 ranks of one node (ABI 5): ppoaf_ppo_update_wgrad_adam with the K17 exchange as a phase
+ * of every weight-gradient job (mpi_avg_gradients, utils/mpi_utils.py:89-111, at its call sites ppo_policy.py:1035,1048):
+ * workgroup b of every rank forms the same 16 x 32 piece, writes its sums into this rank's slot (16-byte system-scope
+ * stores, job-major tiles), flags its peers' group b, reads their tiles back and adds them IN RANK ORDER, then takes part in
+ * the launch-wide norm wait and applies clip + Adam (grad_scale = 1 / ranks) to its elements -- two launches per mini-batch,
+ * bitwise the same parameters on every rank.  xchg: created for ppoaf_ppo_update_tail_exchange_floats() floats and
+ * used by this entry point only (its slot layout is the job list's); not coarse-grained memory (no fences are used);
+ * at most 256 workgroups (ppoaf_ppo_update_split_blocks) -- wider shapes use ppoaf_ppo_update_wgrad ->
+ * ppoaf_peer_exchange_allreduce -> ppoaf_ppo_update_adam(args, 2, stream).  A peer that does not show up within
+ * xchg_wait_seconds sets the exchange's error word (ppoaf_peer_exchange_status) and the launch drains. */
+int ppoaf_ppo_update_tail_exchange_floats(const ppoaf_ppo_update_args_t* args, int64_t* floats_out);
+int ppoaf_ppo_update_wgrad_adam_exchange(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
+                                         ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds, ppoaf_stream_t stream);
 /* ppoaf_ppo_update_ws for N > 1 ranks: the same persistent launch with the K17 exchange as a phase of every mini-batch
  * (mpi_avg_gradients at ppo.py:2443-2448 without leaving the kernel).  Worker w of a network owns the same parameter
  * columns on every rank and is exchange group (network * 32 + w): a row-tiled network sends its folded column sums

@@ -205,7 +205,7 @@ SIGNATURES = {
     "ppoaf_ppo_update_split_workspace_bytes": (C.c_int, [C.POINTER(PpoUpdateArgs), C.POINTER(C.c_int64)]),
     "ppoaf_ppo_update_split_blocks": (C.c_int, [C.POINTER(PpoUpdateArgs)]),
     "ppoaf_ppo_update_wgrad": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr]),
-    "ppoaf_ppo_update_tail_ctl_bytes": (C.c_int64, [C.POINTER(PpoUpdateArgs)]),
+    "ppoaf_ppo_update_tail_ctl_bytes": (C.c_int, [C.POINTER(PpoUpdateArgs), C.POINTER(C.c_int64)]),
     "ppoaf_ppo_update_wgrad_adam": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr]),
     "ppoaf_ppo_update_wgrad_adam_timed": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr, _ptr, _ptr]),
     "ppoaf_ppo_update_adam": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
@@ -246,7 +246,8 @@ SIGNATURES = {
     "ppoaf_allgather_moments": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr, _ptr]),
     "ppoaf_comm_destroy": (C.c_int, [_ptr]),
     "ppoaf_ppo_update_reduce_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr]),
-    "ppoaf_ppo_update_wgrad_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr]),
+    "ppoaf_ppo_update_wgrad_adam_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr, C.c_double, _ptr]),
+    "ppoaf_ppo_update_tail_exchange_floats": (C.c_int, [C.POINTER(PpoUpdateArgs), C.POINTER(C.c_int64)]),
     "ppoaf_ppo_update_adam_exchanged": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, _ptr]),
     "ppoaf_env_filter_moments": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),
                                            C.c_int32, C.c_int64, _ptr, _ptr]),

@@ -22,6 +22,7 @@
 // bounded by a wall-clock budget and ends in the control block's error word instead of a hang (the host then restores
 // the epoch's starting state and runs the three-launch chain, fused_update.py).
 #include "ppo_update_dev.hpp"
+#include "peer_exchange_device.hpp"
 #include <hip/hip_ext.h>
 #include <cstddef>
 
@@ -184,6 +185,97 @@ __device__ __forceinline__ void tail_sync_wave0(const UpdateDev& u, const TailDe
     }
 }
 
+// ---- N > 1: the K17 gradient exchange as a phase of the job (mpi_avg_gradients, utils/mpi_utils.py:89-111, at its call
+// sites ppo_policy.py:1035,1048).  Workgroup b of every rank runs the same job, so exchange group b depends only on
+// group b of its peers: the job's 16 x 32 sums (+ 16 bias sums) go to THIS rank's slot as 16-byte system-scope stores
+// (slot layout = job-major tiles, private to this exchange object: [nblk][528] floats, then the two output segments),
+// one lane tells every peer's flag word for (b, this rank), the peers' tiles are read back with 16-byte system-scope
+// loads and added IN RANK ORDER (every rank forms the bitwise identical sum), and the job carries on with the summed
+// tile: norm partial, the launch-wide wait, clip + Adam.  No fences (a system-scope acquire would drop this XCD's L2
+// under the other jobs' operand panels): slot, flag and peer accesses are system-scope accesses that bypass the caches;
+// a workgroup's slot stores are acknowledged (vmcnt(0) + barrier) before its flags go out, and a consumer reads a peer's
+// tile only after it has seen that peer's flag.  Two slots alternate with the sequence number's parity.
+constexpr int kTailTileFloats = 528;          // 16 x 32 tile + 16 bias sums
+struct TailXchg { XchgDev x; long long seq, wait_ticks; long seg_base[2]; };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tail_slot_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ void tail_xchg_publish_wait(const TailXchg& c, const unsigned g) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const XchgDev& x = c.x;
+    if (threadIdx.x == 0) {
+#pragma unroll                                                // (static indices: the pointer table stays in scalar registers)
+        for (int p = 0; p < kMaxPeers; ++p)
+            if (p < x.n_ranks && p != x.rank)
+                __hip_atomic_store(&x.peer_flags[p][g * kMaxPeers + x.rank], c.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const int p = (int)threadIdx.x - 64;
+    if (p >= 0 && p < x.n_ranks && p != x.rank) {
+        long long budget = c.wait_ticks;
+        if (__hip_atomic_load(&x.words[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) budget = 0;      // broken for good
+        const long long* flag = &x.my_flags[g * kMaxPeers + p];
+        const long long t0 = (long long)wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < c.seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((long long)wall_clock64() - t0 > budget) {
+                __hip_atomic_store(&x.words[3], c.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+// float offset `off` (a multiple of 4) inside the slot of this launch's parity: own value out, rank-ordered sum back
+__device__ __forceinline__ void tail_xchg_store4(const TailXchg& c, const long off, const tail_f32x4 v) {
+    const long byte = ((c.seq & 1) * c.x.n4 * 4 + off) * 4;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tail_u32x4, v), tail_slot_rsrc(c.x.my_slots), (unsigned)byte, 0, 17 /* sc0 sc1 */);
+}
+__device__ __forceinline__ tail_f32x4 tail_xchg_sum4(const TailXchg& c, const long off, const tail_f32x4 own) {
+    const long byte = ((c.seq & 1) * c.x.n4 * 4 + off) * 4;
+    tail_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p0 = 0; p0 < kMaxPeers; p0 += 8) {
+        if (p0 >= c.x.n_ranks) break;
+        tail_f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = p0 + k;
+            if (p >= c.x.n_ranks) v[k] = tail_f32x4{0.f, 0.f, 0.f, 0.f};
+            else if (p == c.x.rank) v[k] = own;
+            else v[k] = __builtin_bit_cast(tail_f32x4, __builtin_amdgcn_raw_buffer_load_b128(tail_slot_rsrc(c.x.peer_slots[p]), (unsigned)byte, 0, 17));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (p0 + k < c.x.n_ranks) acc += v[k];
+    }
+    return acc;
+}
+__device__ __forceinline__ void tail_xchg_store1(const TailXchg& c, const long off, const float v) {
+    float* mine = reinterpret_cast<float*>(c.x.my_slots) + (c.seq & 1) * c.x.n4 * 4 + off;
+    __hip_atomic_store(reinterpret_cast<unsigned*>(mine), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float tail_xchg_sum1(const TailXchg& c, const long off, const float own) {
+    const long fo = (c.seq & 1) * c.x.n4 * 4 + off;
+    float acc = 0.f;
+#pragma unroll
+    for (int p0 = 0; p0 < kMaxPeers; p0 += 8) {
+        if (p0 >= c.x.n_ranks) break;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = p0 + k;
+            if (p >= c.x.n_ranks) v[k] = 0.f;
+            else if (p == c.x.rank) v[k] = own;
+            else v[k] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(reinterpret_cast<const float*>(c.x.peer_slots[p]) + fo),
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (p0 + k < c.x.n_ranks) acc += v[k];
+    }
+    return acc;
+}
+
 struct TailPmv { float p, m, v; };
 __device__ __forceinline__ TailPmv tail_pmv_load(const UpdateDev& u, const long idx, const bool ok) {
     TailPmv r = {0.f, 0.f, 0.f};
@@ -205,10 +297,10 @@ __device__ __forceinline__ void tail_adam1(const UpdateDev& u, const long idx, c
 // The 16 x 32 output tile is formed by wave 0 (C layout) and handed to ALL 256 threads through LDS for the optimiser
 // step: thread t owns tile elements t and t + 256 (row e / 32, column e % 32: whole 128-byte lines of p / m / v), whose
 // state it requested at the start of the job, beside the MFMA operands.
-template <int H>
+template <int H, bool XCHG>
 __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, const unsigned tag, const int b, const int which,
                                          const int job, float* sFold /* [3][2][256] + [4][16] */, float* sTile /* [16][32] + [16] */,
-                                         double* s_red, float* s_coef) {
+                                         double* s_red, float* s_coef, const TailXchg* xc) {
     constexpr int MAXC = 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -300,28 +392,54 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
         bsum += __shfl_xor(bsum, 32, 64);
         if (lane < 16) sFold[1536 + wave * 16 + lane] = bsum;
         __syncthreads();
+        const int i = itile * 16 + (lane & 15);               // C layout: column = lane & 15, rows 4 (lane >> 4) + r
+        float bg = 0.f;
         if (wave == 0) {
-            const int i = itile * 16 + (lane & 15);           // C layout: column = lane & 15, rows 4 (lane >> 4) + r
 #pragma unroll
             for (int w = 0; w < 3; ++w) {
                 acc0 += *reinterpret_cast<const tail_f32x4*>(sFold + ((w * 2 + 0) * 64 + lane) * 4);
                 acc1 += *reinterpret_cast<const tail_f32x4*>(sFold + ((w * 2 + 1) * 64 + lane) * 4);
             }
-            float bg = 0.f;
             if (itile == 0 && lane < 16)
                 bg = sFold[1536 + lane] + sFold[1536 + 16 + lane] + sFold[1536 + 32 + lane] + sFold[1536 + 48 + lane];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * (lane >> 4) + r;
-                if (i < ldw) q += (double)(acc0[r] * sc) * (acc0[r] * sc);
-                if (two && i + 16 < ldw) q += (double)(acc1[r] * sc) * (acc1[r] * sc);
                 sTile[row * 32 + (lane & 15)] = acc0[r];
                 sTile[row * 32 + 16 + (lane & 15)] = acc1[r];
             }
-            if (itile == 0 && lane < 16) {
-                q += (double)(bg * sc) * (bg * sc);
-                sTile[512 + lane] = bg;
+            if (lane < 16) sTile[512 + lane] = bg;
+        }
+        if (XCHG) {
+            // threads 0..127: one float4 of the tile each; 128..131: the bias sums (jobs of input piece 0)
+            __syncthreads();
+            const bool mine = tid < 128 || (itile == 0 && tid < 132);
+            const long off = (long)b * kTailTileFloats + 4 * tid;
+            tail_f32x4 own = {0.f, 0.f, 0.f, 0.f};
+            if (mine) {
+                own = *reinterpret_cast<const tail_f32x4*>(sTile + 4 * tid);
+                tail_xchg_store4(*xc, off, own);
             }
+            tail_xchg_publish_wait(*xc, (unsigned)b);
+            if (mine) *reinterpret_cast<tail_f32x4*>(sTile + 4 * tid) = tail_xchg_sum4(*xc, off, own);
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * (lane >> 4) + r;
+                    acc0[r] = sTile[row * 32 + (lane & 15)];
+                    acc1[r] = sTile[row * 32 + 16 + (lane & 15)];
+                }
+                if (lane < 16) bg = sTile[512 + lane];
+            }
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (i < ldw) q += (double)(acc0[r] * sc) * (acc0[r] * sc);
+                if (two && i + 16 < ldw) q += (double)(acc1[r] * sc) * (acc1[r] * sc);
+            }
+            if (itile == 0 && lane < 16) q += (double)(bg * sc) * (bg * sc);
             TAIL_STAMP(td, 3);
             // block_sum(q) of the chain's wgrad launch: only this wave contributes, and its wave sum + three zeros is exact
             q = tail_wave_sum(q);
@@ -366,9 +484,28 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) if (g0 + kk < n_hb) acc += pv[kk];
                 }
-                G[seg_off + idx] = acc;
-                q += (double)(acc * sc) * (acc * sc);
                 ge[k] = acc;
+            }
+        }
+        if (XCHG) {
+#pragma unroll
+            for (int k = 0; k < kTailMaxE; ++k) {
+                const long idx = tid + (long)kWgradThreads * k;
+                if (idx < seg_len) tail_xchg_store1(*xc, xc->seg_base[which] + idx, ge[k]);
+            }
+            tail_xchg_publish_wait(*xc, (unsigned)b);
+#pragma unroll
+            for (int k = 0; k < kTailMaxE; ++k) {
+                const long idx = tid + (long)kWgradThreads * k;
+                if (idx < seg_len) ge[k] = tail_xchg_sum1(*xc, xc->seg_base[which] + idx, ge[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kTailMaxE; ++k) {
+            const long idx = tid + (long)kWgradThreads * k;
+            if (idx < seg_len) {
+                G[seg_off + idx] = ge[k];
+                q += (double)(ge[k] * sc) * (ge[k] * sc);
             }
         }
         // block_sum(q) in its own association (wave sums, then the wave sum of the four of them)
@@ -389,8 +526,8 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
     }
 }
 
-template <int HA, int HC>
-__global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(UpdateDev u, TailDev td) {
+template <int HA, int HC, bool XCHG>
+__global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(UpdateDev u, TailDev td, TailXchg xc) {
     __shared__ double s_red[17];
     __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
     __shared__ float s_tile[16 * 32 + 16];
@@ -430,60 +567,59 @@ __global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(Up
         return;
     }
     const int job = (b & 7) * td.per_xcd + (b >> 3);          // XCD b % 8 works on one run of the layer-major job list
-    if (job < td.jobs_a) tail_job<HA>(u, td, tag, b, 0, job, s_fold, s_tile, s_red, s_coef);
-    else if (job < td.jobs_a + td.jobs_c) tail_job<HC>(u, td, tag, b, 1, job - td.jobs_a, s_fold, s_tile, s_red, s_coef);
+    const bool live = job < td.jobs_a + td.jobs_c;            // the same on every rank
+    if (XCHG && live) xc.seq = xchg_sequence(xc.x, (unsigned)b);
+    if (job < td.jobs_a) tail_job<HA, XCHG>(u, td, tag, b, 0, job, s_fold, s_tile, s_red, s_coef, &xc);
+    else if (live) tail_job<HC, XCHG>(u, td, tag, b, 1, job - td.jobs_a, s_fold, s_tile, s_red, s_coef, &xc);
     else if (threadIdx.x == 0) tail_publish(td, tag, b, 0.0);
+    if (XCHG && live) xchg_advance(xc.x, xc.seq, (unsigned)b);
 }
 
-template <int HA, int HC>
-static int tail_launch(const UpdateDev& u, const TailDev& td, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+template <int HA, int HC, bool XCHG>
+static int tail_launch_as(const UpdateDev& u, const TailDev& td, const TailXchg& xc, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     // every workgroup waits for every other one: all of them must fit on the device at once
-    static int per_cu = 0;
+    static int per_cu = 0, cus = 0;            // (queried on the first, eager, launch: nothing but the launch inside a stream capture)
     if (per_cu == 0) {
-        int n = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(ppo_update_wgrad_adam_kernel<HA, HC>),
+        int n = 0, dev = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(ppo_update_wgrad_adam_kernel<HA, HC, XCHG>),
                                                                    kWgradThreads, 0);
         if (e != hipSuccess) { set_error("ppo_update_wgrad_adam: occupancy query: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
         per_cu = n > 0 ? n : -1;
-    }
-    static int cus = 0;                        // (queried on the first, eager, launch: nothing but the launch inside a stream capture)
-    if (cus == 0) {
-        int dev = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     }
     PPOAF_REQUIRE(per_cu > 0 && (long)(td.nblk + 1) <= (long)per_cu * cus,
                   "ppo_update_wgrad_adam: %d workgroups cannot be resident together (%d per CU x %d CUs)", td.nblk + 1, per_cu, cus);
     if (e0 || e1)
-        hipExtLaunchKernelGGL((ppo_update_wgrad_adam_kernel<HA, HC>), dim3((unsigned)(td.nblk + 1)), dim3(kWgradThreads), 0, s, e0, e1, 0, u, td);
+        hipExtLaunchKernelGGL((ppo_update_wgrad_adam_kernel<HA, HC, XCHG>), dim3((unsigned)(td.nblk + 1)), dim3(kWgradThreads), 0, s, e0, e1, 0, u, td, xc);
     else
-        hipLaunchKernelGGL((ppo_update_wgrad_adam_kernel<HA, HC>), dim3((unsigned)(td.nblk + 1)), dim3(kWgradThreads), 0, s, u, td);
+        hipLaunchKernelGGL((ppo_update_wgrad_adam_kernel<HA, HC, XCHG>), dim3((unsigned)(td.nblk + 1)), dim3(kWgradThreads), 0, s, u, td, xc);
     return check_launch("ppo_update_wgrad_adam");
 }
-
-}  // namespace ppoaf
-
-using namespace ppoaf;
-
-extern "C" int64_t ppoaf_ppo_update_tail_ctl_bytes(const ppoaf_ppo_update_args_t* args) {
-    UpdateDev u;
-    ppoaf_ppo_update_args_t a;
-    if (!args) return -1;
-    a = *args;
-    a.split_workspace = nullptr;
-    if (make_update_dev(&a, u)) return -1;
-    return (int64_t)kTailRecOff + 16 * (int64_t)split_wgrad_blocks(u);
+template <int HA, int HC>
+static int tail_launch(const UpdateDev& u, const TailDev& td, const TailXchg* xc, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (xc) return tail_launch_as<HA, HC, true>(u, td, *xc, s, e0, e1);
+    return tail_launch_as<HA, HC, false>(u, td, TailXchg(), s, e0, e1);
 }
 
-extern "C" int ppoaf_ppo_update_wgrad_adam_timed(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
-                                                 void* start_event, void* stop_event, ppoaf_stream_t stream) {
-    UpdateDev u;
+static int tail_dispatch(const UpdateDev& u, const TailDev& td, const TailXchg* xc, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const int ha = u.net[0].H, hc = u.net[1].H;
+    if (ha == 32 && hc == 32) return tail_launch<32, 32>(u, td, xc, s, e0, e1);
+    if (ha == 64 && hc == 64) return tail_launch<64, 64>(u, td, xc, s, e0, e1);
+    if (ha == 128 && hc == 128) return tail_launch<128, 128>(u, td, xc, s, e0, e1);
+    if (ha == 256 && hc == 256) return tail_launch<256, 256>(u, td, xc, s, e0, e1);
+    if (ha == 128 && hc == 256) return tail_launch<128, 256>(u, td, xc, s, e0, e1);
+    if (ha == 64 && hc == 128) return tail_launch<64, 128>(u, td, xc, s, e0, e1);
+    set_error("ppo_update_wgrad_adam: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
+    return PPOAF_E_INVALID;
+}
+
+static int tail_prepare(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds, UpdateDev& u, TailDev& td) {
     int rc = make_update_dev(args, u);
     if (rc) return rc;
     PPOAF_REQUIRE(u.split, "ppo_update_wgrad_adam: args->split_workspace is not set (the tail of the split-wgrad chain)");
     PPOAF_REQUIRE(ctl && (((uintptr_t)ctl) & 63) == 0, "ppo_update_wgrad_adam: control block missing or not 64-byte aligned");
     PPOAF_REQUIRE(wait_seconds > 0.0 && wait_seconds <= 600.0, "ppo_update_wgrad_adam: wait_seconds=%g", wait_seconds);
-    TailDev td;
     td.ctl = reinterpret_cast<TailCtl*>(ctl);
     td.budget = (long long)(wait_seconds * 1.0e8);
     td.jobs_a = split_wgrad_jobs(u.net[0]);
@@ -495,19 +631,77 @@ extern "C" int ppoaf_ppo_update_wgrad_adam_timed(const ppoaf_ppo_update_args_t* 
     for (int w = 0; w < 2; ++w)
         PPOAF_REQUIRE(ws_seg_len(u.net[w]) <= (long)kWgradThreads * kTailMaxE, "ppo_update_wgrad_adam: output segment of %ld floats (at most %d)",
                       ws_seg_len(u.net[w]), kWgradThreads * kTailMaxE);
-    hipStream_t s = (hipStream_t)stream;
-    hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;
-    const int ha = u.net[0].H, hc = u.net[1].H;
-    if (ha == 32 && hc == 32) return tail_launch<32, 32>(u, td, s, e0, e1);
-    if (ha == 64 && hc == 64) return tail_launch<64, 64>(u, td, s, e0, e1);
-    if (ha == 128 && hc == 128) return tail_launch<128, 128>(u, td, s, e0, e1);
-    if (ha == 256 && hc == 256) return tail_launch<256, 256>(u, td, s, e0, e1);
-    if (ha == 128 && hc == 256) return tail_launch<128, 256>(u, td, s, e0, e1);
-    if (ha == 64 && hc == 128) return tail_launch<64, 128>(u, td, s, e0, e1);
-    set_error("ppo_update_wgrad_adam: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
-    return PPOAF_E_INVALID;
+    return PPOAF_OK;
+}
+
+// floats of one exchange slot for these shapes: job-major tiles, then the two output segments (each padded to 4)
+static long tail_exchange_floats(const UpdateDev& u, long* seg_base) {
+    long off = (long)split_wgrad_blocks(u) * kTailTileFloats;
+    for (int w = 0; w < 2; ++w) {
+        if (seg_base) seg_base[w] = off;
+        off += (ws_seg_len(u.net[w]) + 3) & ~3L;
+    }
+    return off;
+}
+
+}  // namespace ppoaf
+
+using namespace ppoaf;
+
+extern "C" int ppoaf_ppo_update_tail_ctl_bytes(const ppoaf_ppo_update_args_t* args, int64_t* bytes_out) {
+    UpdateDev u;
+    PPOAF_REQUIRE(args && bytes_out, "ppo_update_tail_ctl_bytes: null argument");
+    ppoaf_ppo_update_args_t a = *args;
+    a.split_workspace = nullptr;
+    const int rc = make_update_dev(&a, u);
+    if (rc) return rc;
+    *bytes_out = (int64_t)kTailRecOff + 16 * (int64_t)split_wgrad_blocks(u);
+    return PPOAF_OK;
+}
+
+extern "C" int ppoaf_ppo_update_tail_exchange_floats(const ppoaf_ppo_update_args_t* args, int64_t* floats_out) {
+    UpdateDev u;
+    PPOAF_REQUIRE(args && floats_out, "ppo_update_tail_exchange_floats: null argument");
+    ppoaf_ppo_update_args_t a = *args;
+    a.split_workspace = nullptr;
+    const int rc = make_update_dev(&a, u);
+    if (rc) return rc;
+    *floats_out = (int64_t)tail_exchange_floats(u, nullptr);
+    return PPOAF_OK;
+}
+
+extern "C" int ppoaf_ppo_update_wgrad_adam_timed(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
+                                                 void* start_event, void* stop_event, ppoaf_stream_t stream) {
+    UpdateDev u;
+    TailDev td;
+    int rc = tail_prepare(args, ctl, wait_seconds, u, td);
+    if (rc) return rc;
+    return tail_dispatch(u, td, nullptr, (hipStream_t)stream, (hipEvent_t)start_event, (hipEvent_t)stop_event);
 }
 
 extern "C" int ppoaf_ppo_update_wgrad_adam(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds, ppoaf_stream_t stream) {
     return ppoaf_ppo_update_wgrad_adam_timed(args, ctl, wait_seconds, nullptr, nullptr, stream);
+}
+
+extern "C" int ppoaf_ppo_update_wgrad_adam_exchange(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
+                                                    ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds, ppoaf_stream_t stream) {
+    UpdateDev u;
+    TailDev td;
+    int rc = tail_prepare(args, ctl, wait_seconds, u, td);
+    if (rc) return rc;
+    PPOAF_REQUIRE(xchg && xchg->connected, "ppo_update_wgrad_adam_exchange: exchange missing or not connected");
+    TailXchg xc;
+    xc.x = xchg->dev;
+    xc.seq = 0;
+    const long need = tail_exchange_floats(u, xc.seg_base);
+    PPOAF_REQUIRE(xchg->dev.n4 * 4 >= need, "ppo_update_wgrad_adam_exchange: exchange slots of %ld floats, %ld needed "
+                  "(ppoaf_ppo_update_tail_exchange_floats)", (long)xchg->dev.n4 * 4, need);
+    PPOAF_REQUIRE(td.nblk <= kXchgMaxGrid, "ppo_update_wgrad_adam_exchange: %d workgroups, one exchange holds %d groups", td.nblk, kXchgMaxGrid);
+    PPOAF_REQUIRE(xchg->dev.n_ranks == u.n_ranks || !u.normalize_values, "ppo_update_wgrad_adam_exchange: %d ranks in the exchange, %d in args",
+                  xchg->dev.n_ranks, u.n_ranks);
+    PPOAF_REQUIRE(xchg_wait_seconds > 0.0 && xchg_wait_seconds <= 600.0, "ppo_update_wgrad_adam_exchange: xchg_wait_seconds=%g", xchg_wait_seconds);
+    PPOAF_REQUIRE(xchg->memory_kind != 3, "ppo_update_wgrad_adam_exchange: coarse-grained exchange slots are coherent only through "
+                  "fences, which this launch does not use (create the exchange with memory_kind 0, 1 or 2)");
+    xc.wait_ticks = (long long)(xchg_wait_seconds * 1.0e8);
+    return tail_dispatch(u, td, &xc, (hipStream_t)stream, nullptr, nullptr);
 }

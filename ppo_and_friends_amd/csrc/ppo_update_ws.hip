@@ -1446,63 +1446,8 @@ static int ws_launch(const WsArgs& a, WsCtl* ctl, int n_mb, long long budget, si
 // fwd_bwd's dependent chain.
 // ------------------------------------------------------------------------------------------------------------
 // MAXC = chunks of 16 rows a wave may own (B <= 512: 32 chunks over 4 waves)
-// XCHG (N > 1, K17 inside this launch): a job's sums go to this rank's exchange slot first, the workgroup (= exchange
-// group xg) publishes, waits for the same group of its peers, and the bucket receives the rank-ordered sum -- the
-// protocol of ppo_update_reduce_exchange_kernel with one group per wgrad workgroup.
-// No fence anywhere (a system-scope acquire invalidates the XCD's L2 under the other jobs' operand panels: measured 33 ->
-// 42 us per mini-batch): slot, flag and peer accesses are relaxed SYSTEM-scope atomic stores / loads, which bypass the
-// caches, as in the persistent kernel's exchange (ws_xchg_*); a workgroup's slot stores are acknowledged (vmcnt(0) +
-// barrier) before its flag goes out, and a consumer reads data only after it has seen the flag.
-struct WgradXchg { XchgDev x; long long seq, wait_ticks; unsigned xg; };
-__device__ __forceinline__ void sp_store1(float* p, float v) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ float sp_load1(const float* p) {
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-}
-__device__ __forceinline__ void sp_publish_wait(const WgradXchg& c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const XchgDev& x = c.x;
-    if (threadIdx.x == 0)
-        for (int p = 0; p < x.n_ranks; ++p)
-            if (p != x.rank)
-                __hip_atomic_store(&x.peer_flags[p][c.xg * kMaxPeers + x.rank], c.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const int p = (int)threadIdx.x - 64;
-    if (p >= 0 && p < x.n_ranks && p != x.rank) {
-        long long budget = c.wait_ticks;
-        if (__hip_atomic_load(&x.words[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) budget = 0;      // broken for good
-        const long long* flag = &x.my_flags[c.xg * kMaxPeers + p];
-        const long long t0 = (long long)wall_clock64();
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < c.seq) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((long long)wall_clock64() - t0 > budget) {
-                __hip_atomic_store(&x.words[3], c.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ float xchg_sum1(const XchgDev& x, long slotf, long i, float own) {
-    float acc = 0.f;
-    for (int p0 = 0; p0 < x.n_ranks; p0 += 8) {
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int p = p0 + k;
-            if (p >= x.n_ranks) v[k] = 0.f;
-            else if (p == x.rank) v[k] = own;
-            else v[k] = sp_load1(reinterpret_cast<const float*>(x.peer_slots[p]) + slotf + i);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if (p0 + k < x.n_ranks) acc += v[k];
-    }
-    return acc;
-}
-template <int H, bool XCHG = false>
-__device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int which, const int job, float* sFold /* [3][2][256] + [4][16] */,
-                                                  const WgradXchg* xc = nullptr) {
+template <int H>
+__device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int which, const int job, float* sFold /* [3][2][256] + [4][16] */) {
     constexpr int MAXC = 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: the chunk offsets below stay in scalar registers
@@ -1516,9 +1461,6 @@ __device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int 
         return l == 0 ? szW0 : offW(l) + (l < depth ? (long)H * H : (((long)out_dim * H + 3) & ~3L));
     };
     float* G = u.grads + nd.offset;
-    // XCHG: this rank's slot (the launch's parity), addressed like the bucket
-    const long slotf = XCHG ? (long)(xc->seq & 1) * xc->x.n4 * 4 + nd.offset : 0;
-    float* mine = XCHG ? reinterpret_cast<float*>(xc->x.my_slots) + slotf : nullptr;
     constexpr int t = H / 16, t2 = (t + 1) / 2;
     const int n_it0 = (in_dim + 15) / 16, p0 = (n_it0 + 1) / 2;
     const int n_hidden = (depth - 1) * t * t2, n_l0 = t * p0;
@@ -1591,27 +1533,6 @@ __device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int 
         float bg = 0.f;
         if (wave == 0 && itile == 0 && lane < 16)
             bg = sFold[1536 + lane] + sFold[1536 + 16 + lane] + sFold[1536 + 32 + lane] + sFold[1536 + 48 + lane];
-        if (XCHG) {
-            if (wave == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = ot * 16 + 4 * (lane >> 4) + r;
-                    if (i < ldw) sp_store1(mine + offW(l) + (long)o * ldw + i, acc0[r]);
-                    if (two && i + 16 < ldw) sp_store1(mine + offW(l) + (long)o * ldw + i + 16, acc1[r]);
-                }
-                if (itile == 0 && lane < 16) sp_store1(mine + offB(l) + ot * 16 + lane, bg);
-            }
-            sp_publish_wait(*xc);
-            if (wave == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = ot * 16 + 4 * (lane >> 4) + r;
-                    if (i < ldw) acc0[r] = xchg_sum1(xc->x, slotf, offW(l) + (long)o * ldw + i, acc0[r]);
-                    if (two && i + 16 < ldw) acc1[r] = xchg_sum1(xc->x, slotf, offW(l) + (long)o * ldw + i + 16, acc1[r]);
-                }
-                if (itile == 0 && lane < 16) bg = xchg_sum1(xc->x, slotf, offB(l) + ot * 16 + lane, bg);
-            }
-        }
         if (wave == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1629,7 +1550,6 @@ __device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int 
         const long seg_off = offW(depth), seg_len = nd.size - seg_off;
         const float* outpart = u.sp.outpart[which];
         const int n_hb = (B + 15) >> 4;
-        float* dst = XCHG ? mine : G;
         for (long idx = tid; idx < seg_len; idx += kWgradThreads) {
             float acc = 0.f;
             for (int g0 = 0; g0 < n_hb; g0 += 8) {
@@ -1639,16 +1559,8 @@ __device__ __forceinline__ double split_wgrad_job(const UpdateDev& u, const int 
 #pragma unroll
                 for (int k = 0; k < 8; ++k) if (g0 + k < n_hb) acc += pv[k];
             }
-            if (XCHG) sp_store1(dst + seg_off + idx, acc);
-            else { dst[seg_off + idx] = acc; q += (double)(acc * sc) * (acc * sc); }
-        }
-        if (XCHG) {
-            sp_publish_wait(*xc);
-            for (long idx = tid; idx < seg_len; idx += kWgradThreads) {
-                const float acc = xchg_sum1(xc->x, slotf, seg_off + idx, sp_load1(mine + seg_off + idx));   // (own value: back from its slot)
-                G[seg_off + idx] = acc;
-                q += (double)(acc * sc) * (acc * sc);
-            }
+            G[seg_off + idx] = acc;
+            q += (double)(acc * sc) * (acc * sc);
         }
     }
     return q;
@@ -1670,37 +1582,6 @@ __global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_kernel(UpdateD
         u.norm_scratch[6 + 2 * b] = actor ? q : 0.0;
         u.norm_scratch[7 + 2 * b] = actor ? 0.0 : q;
     }
-}
-
-template <int HA, int HC>
-__global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_exchange_kernel(UpdateDev u, int jobs_a, int jobs_c, int per_xcd,
-                                                                                 XchgDev x, long long wait_ticks) {
-    __shared__ double s_red[17];
-    __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
-    const int b = blockIdx.x;
-    if (b == 8 * per_xcd) { ppo_update_bookkeeping_split(u); return; }           // uniform per workgroup
-    const int job = (b & 7) * per_xcd + (b >> 3);
-    double q = 0.0;
-    const bool live = job < jobs_a + jobs_c;                                      // the same on every rank
-    WgradXchg xc;
-    xc.x = x; xc.wait_ticks = wait_ticks; xc.xg = (unsigned)b;
-    xc.seq = live ? xchg_sequence(x, (unsigned)b) : 0;
-    if (job < jobs_a) q = split_wgrad_job<HA, true>(u, 0, job, s_fold, &xc);
-    else if (live) q = split_wgrad_job<HC, true>(u, 1, job - jobs_a, s_fold, &xc);
-    const bool actor = job < jobs_a;
-    q = block_sum(q, s_red);
-    if (threadIdx.x == 0) {
-        x.norm_partials[2 * b] = actor ? q : 0.0;
-        x.norm_partials[2 * b + 1] = actor ? 0.0 : q;
-    }
-    if (live) xchg_advance(x, xc.seq, (unsigned)b);
-}
-
-template <int HA, int HC>
-static int wgrad_exchange_launch(const UpdateDev& u, const XchgDev& x, long long ticks, hipStream_t s) {
-    const int ja = split_wgrad_jobs(u.net[0]), jc = split_wgrad_jobs(u.net[1]), px = split_wgrad_per_xcd(u);
-    hipLaunchKernelGGL((ppo_update_wgrad_exchange_kernel<HA, HC>), dim3((unsigned)(8 * px + 1)), dim3(kWgradThreads), 0, s, u, ja, jc, px, x, ticks);
-    return check_launch("ppo_update_wgrad_exchange");
 }
 
 template <int HA, int HC>
@@ -1853,27 +1734,3 @@ extern "C" int ppoaf_ppo_update_wgrad(const ppoaf_ppo_update_args_t* args, ppoaf
     return PPOAF_E_INVALID;
 }
 
-extern "C" int ppoaf_ppo_update_wgrad_exchange(const ppoaf_ppo_update_args_t* args, ppoaf_peer_exchange_t* xchg, double wait_seconds,
-                                               ppoaf_stream_t stream) {
-    UpdateDev u;
-    int rc = make_update_dev(args, u);
-    if (rc) return rc;
-    PPOAF_REQUIRE(u.split, "ppo_update_wgrad_exchange: args->split_workspace is not set");
-    PPOAF_REQUIRE(xchg && xchg->connected, "ppo_update_wgrad_exchange: exchange missing or not connected");
-    PPOAF_REQUIRE(xchg->dev.n4 == (u.bucket_total >> 2), "ppo_update_wgrad_exchange: exchange made for %ld float4, bucket has %ld",
-                  xchg->dev.n4, (long)(u.bucket_total >> 2));
-    PPOAF_REQUIRE(split_wgrad_blocks(u) <= kXchgMaxGrid, "ppo_update_wgrad_exchange: %d workgroups, one exchange holds %d groups "
-                  "(use ppoaf_ppo_update_wgrad + ppoaf_peer_exchange_allreduce)", split_wgrad_blocks(u), kXchgMaxGrid);
-    PPOAF_REQUIRE(wait_seconds > 0.0 && wait_seconds <= 600.0, "ppo_update_wgrad_exchange: wait_seconds=%g", wait_seconds);
-    PPOAF_REQUIRE(xchg->memory_kind != 3, "ppo_update_wgrad_exchange: coarse-grained exchange slots are coherent only through "
-                  "fences, which this launch does not use (create the exchange with memory_kind 0, 1 or 2)");
-    const long long ticks = (long long)(wait_seconds * 1.0e8);
-    hipStream_t s = (hipStream_t)stream;
-    const int ha = u.net[0].H, hc = u.net[1].H;
-    if (ha == 32 && hc == 32) return wgrad_exchange_launch<32, 32>(u, xchg->dev, ticks, s);
-    if (ha == 64 && hc == 64) return wgrad_exchange_launch<64, 64>(u, xchg->dev, ticks, s);
-    if (ha == 128 && hc == 128) return wgrad_exchange_launch<128, 128>(u, xchg->dev, ticks, s);
-    if (ha == 64 && hc == 128) return wgrad_exchange_launch<64, 128>(u, xchg->dev, ticks, s);
-    set_error("ppo_update_wgrad_exchange: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
-    return PPOAF_E_INVALID;
-}

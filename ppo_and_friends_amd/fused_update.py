@@ -169,20 +169,19 @@ class FusedPolicyUpdate:
         self.xchg, self.xchg_reason = (peer_exchange.open_exchange(total, dev) if self.multi else (None, "single rank"))
         # the persistent two-XCD kernel of an N > 1 run carries the exchange inside the launch, with its own element ->
         # group map (one group per worker), hence its own slots and flag words; opened collectively, like the first
-        # PPOAF_SPLIT_WGRAD=1 on N > 1 ranks: the split-wgrad chain with the exchange inside its wgrad launch (one exchange
-        # group per wgrad workgroup: its own object again; at most 256 workgroups).  Opt-in: measured SLOWER than the slab
-        # chain's fused reduce + exchange launch at C2 (one-rank rehearsal 7.12e5 against 7.66e5 env-steps/s: the split saves
-        # 3.4 us per mini-batch there, scalar stores into the uncached slots cost more); parity-tested
-        # (tests/test_gpu_two_ranks.py: peer_split).  Shapes with a 256-wide network exchange in a launch of their own.
+        # the fused tail launch of the split-wgrad chain (csrc/ppo_update_tail.hip) carries the exchange as a phase of
+        # every weight-gradient job (one exchange group per workgroup, job-major tiles in the slots: an object of its own
+        # again; at most 256 workgroups, i.e. no 256-wide network): two launches per mini-batch on N > 1 ranks as well.
         self.xchg_sp = None
-        if self.xchg is not None and type(self) is FusedPolicyUpdate and os.environ.get("PPOAF_SPLIT_WGRAD", "auto") == "1" \
-                and self._split_blocks() <= 256 and max(self.actor_desc.in_dim, self.critic_desc.in_dim) <= 64 and self.B <= 512:
-            self.xchg_sp, why = peer_exchange.open_exchange(total, dev)
+        if self.xchg is not None and type(self) is FusedPolicyUpdate and os.environ.get("PPOAF_FUSED_TAIL", "1") != "0" \
+                and os.environ.get("PPOAF_SPLIT_WGRAD", "auto") != "0" and self._split_blocks() <= 256 \
+                and max(self.actor_desc.in_dim, self.critic_desc.in_dim) <= 64 and self.B <= 512:
+            self.xchg_sp, why = peer_exchange.open_exchange(self._tail_exchange_floats(), dev)
             if self.xchg_sp is not None and self.xchg_sp.status()[2] == 3:      # (the same kind on every rank: a collective choice)
                 self.xchg_sp.close()
-                self.xchg_sp, why = None, "coarse-grained slots need fences, which the wgrad launch does not use"
+                self.xchg_sp, why = None, "coarse-grained slots need fences, which the fused tail launch does not use"
             if self.xchg_sp is None:
-                self.xchg_reason += f"; wgrad-launch exchange refused ({why})"
+                self.xchg_reason += f"; fused-tail exchange refused ({why})"
         self.split, self.split_reason = self._split_wanted()
         self.xchg_ws = None
         if self.xchg is not None and self._ws_wanted():
@@ -196,6 +195,14 @@ class FusedPolicyUpdate:
             t = d.hidden // 16
             return (d.depth - 1) * t * ((t + 1) // 2) + t * (((d.in_dim + 15) // 16 + 1) // 2) + 1
         return 8 * ((jobs(self.actor_desc) + jobs(self.critic_desc) + 7) // 8)
+
+    def _tail_exchange_floats(self):
+        """Floats of one slot of the fused tail's exchange (csrc/ppo_update_tail.hip: tail_exchange_floats): job-major
+        16 x 32 tiles + 16 bias sums per workgroup, then the two networks' output segments (each padded to 4)."""
+        def seg(d):
+            sz_w0 = (d.hidden * d.in_dim + 3) // 4 * 4
+            return d.size - (sz_w0 + d.hidden + (d.depth - 1) * (d.hidden * d.hidden + d.hidden))
+        return self._split_blocks() * 528 + sum((seg(d) + 3) // 4 * 4 for d in (self.actor_desc, self.critic_desc))
 
     def _split_wanted(self):
         """
@@ -218,7 +225,7 @@ class FusedPolicyUpdate:
         if self.multi:
             if self.xchg is None:
                 return False, "N > 1 without K17: the all-reduce loops run the slab chain"
-            if self.xchg_sp is None and mode != "1" and max(self.actor_desc.hidden, self.critic_desc.hidden) < 256:
+            if self.xchg_sp is None and mode != "1" and max(self.actor_desc.hidden, self.critic_desc.hidden) < 256:   # (no fused-tail exchange)
                 return False, "N > 1, no exchange for the wgrad launch and no 256-wide network: the slab reduce launch carries K17"
         return True, ""
 
@@ -248,16 +255,19 @@ class FusedPolicyUpdate:
             return "disabled after a failed launch: " + self._tail_disabled
         if not self.split:
             return "the slab chain runs (" + self.split_reason + ")"
-        if self.multi:
-            return "N > 1: the gradient exchange sits between the weight gradients and the optimiser step"
+        if self.multi and self.xchg_sp is None:
+            return "N > 1 without an exchange for the fused tail launch (" + self.xchg_reason + ")"
         return ""
 
     def _tail_ctl_ptr(self, args):
         ctl = getattr(self, "_tail_ctl", None)
         if ctl is None:
-            n = int(self._lib.ppoaf_ppo_update_tail_ctl_bytes(C.byref(args)))
-            if n <= 0:
-                raise _lib.PpoafError("ppo_update_tail_ctl_bytes: " + self._lib.ppoaf_last_error().decode("utf-8", "replace"))
+            need = C.c_int64(0)
+            _lib.check(self._lib.ppoaf_ppo_update_tail_ctl_bytes(C.byref(args), C.byref(need)), "ppo_update_tail_ctl_bytes")
+            n = int(need.value)
+            if self.xchg_sp is not None:                  # the Python twin of the slot layout must be the library's
+                _lib.check(self._lib.ppoaf_ppo_update_tail_exchange_floats(C.byref(args), C.byref(need)), "ppo_update_tail_exchange_floats")
+                assert int(need.value) == self._tail_exchange_floats(), (int(need.value), self._tail_exchange_floats())
             # zeroed once, then kept: the block carries the launch tag from one launch to the next
             ctl = self._tail_ctl = torch.zeros((n + 63) // 64 * 16, dtype=torch.int32, device=self.pol.device)
         FusedPolicyUpdate.tail_launches += 1
@@ -412,16 +422,14 @@ class FusedPolicyUpdate:
         rc = lib.ppoaf_ppo_update_fwd_bwd(ref, st)
         if rc == 0 and args.split_workspace:
             # split-wgrad chain: complete weight gradients from the published panels, then clip + Adam
-            if self.xchg_sp is not None:
-                # N > 1, at most 256 wgrad workgroups: K17 inside the wgrad launch, the norms of the sum left for Adam
-                rc = lib.ppoaf_ppo_update_wgrad_exchange(ref, self.xchg_sp.handle, self.xchg_sp.wait_seconds, st) \
-                    or lib.ppoaf_ppo_update_adam_exchanged(ref, self.xchg_sp.handle, st)
-                if rc != 0:
-                    _lib.check(rc, "ppo_update")
-                return
-            if single and self.tail_reason() == "":
-                # fused tail (csrc/ppo_update_tail.hip): weight gradients, clip norms and clip + Adam in ONE launch
-                rc = lib.ppoaf_ppo_update_wgrad_adam(ref, self._tail_ctl_ptr(args), self.tail_wait_seconds, st)
+            if self.tail_reason() == "":
+                # fused tail (csrc/ppo_update_tail.hip): weight gradients, [N > 1: the K17 exchange of every job's sums,]
+                # clip norms and clip + Adam in ONE launch
+                if single:
+                    rc = lib.ppoaf_ppo_update_wgrad_adam(ref, self._tail_ctl_ptr(args), self.tail_wait_seconds, st)
+                else:
+                    rc = lib.ppoaf_ppo_update_wgrad_adam_exchange(ref, self._tail_ctl_ptr(args), self.tail_wait_seconds,
+                                                                 self.xchg_sp.handle, self.xchg_sp.wait_seconds, st)
                 self._tail_used = True
                 if rc != 0:
                     _lib.check(rc, "ppo_update_wgrad_adam")

@@ -25,11 +25,11 @@ def _free_port():
 
 def _rank(rank, world, port, out, mode):
     ws_mode = None
-    if mode == "peer_split":
-        # the split-wgrad chain with K17 inside the wgrad launch (ppoaf_ppo_update_wgrad_exchange): opt-in below 256 wide,
-        # where the default stays the slab chain with K17 fused into the slab reduce launch
+    if mode == "peer_slabs":
+        # the slab chain with K17 fused into the slab reduce launch: what N > 1 ranks ran before the fused tail launch
+        # (and still run where the tail's exchange cannot be opened)
         mode = "peer"
-        os.environ["PPOAF_SPLIT_WGRAD"] = "1"
+        os.environ["PPOAF_FUSED_TAIL"] = "0"
     if mode.startswith("peer_ws_"):
         # the persistent two-XCD kernel with the K17 exchange as a phase of every mini-batch (forced here: at these
         # widths `auto` keeps the chain); the ranks share one GPU, so each takes its own pair of XCDs
@@ -76,11 +76,12 @@ def _rank(rank, world, port, out, mode):
     dist.destroy_process_group()
 
 
-# "peer": K17 exchange over IPC mappings inside hipGraph-replayed chains (slab chain, K17 fused into the slab reduce
-# launch); "peer_split": the split-wgrad chain with K17 inside the wgrad launch (ppoaf_ppo_update_wgrad_exchange); "rccl":
+# "peer": K17 exchange over IPC mappings inside hipGraph-replayed chains: the split-wgrad chain whose fused tail launch
+# carries the exchange inside every weight-gradient job (ppoaf_ppo_update_wgrad_adam_exchange: two launches per
+# mini-batch); "peer_slabs": the slab chain, K17 fused into the slab reduce launch (PPOAF_FUSED_TAIL=0); "rccl":
 # the eager loop with the process group's all-reduce (gloo here, staged through the host); "peer_ws_*": K17 inside the
 # persistent two-XCD kernel (ppoaf_ppo_update_ws_exchange), both networks row-tiled / layered
-@pytest.fixture(scope="module", params=["peer", "peer_split", "rccl", "peer_ws_rowtile", "peer_ws_layered"])
+@pytest.fixture(scope="module", params=["peer", "peer_slabs", "rccl", "peer_ws_rowtile", "peer_ws_layered"])
 def run2(request):
     world = 2
     mgr = mp.Manager()
@@ -91,8 +92,8 @@ def run2(request):
         assert r["peer_exchange"] == [request.param.startswith("peer")], r["peer_exchange"]
         # 2 epochs = 2 persistent launches when the exchange runs inside the kernel, none otherwise
         assert r["ws_exchange_launches"] == (2 if request.param.startswith("peer_ws_") else 0), r["ws_exchange_launches"]
-        if request.param in ("peer", "peer_split"):
-            assert r["split"] == r["wgrad_exchange"] == [request.param == "peer_split"], (r["split"], r["wgrad_exchange"])
+        if request.param in ("peer", "peer_slabs"):
+            assert r["split"] == r["wgrad_exchange"] == [request.param == "peer"], (r["split"], r["wgrad_exchange"])
     res[0]["mode"] = request.param
     return res
 
@@ -101,12 +102,12 @@ def test_rowtiled_persistent_kernel_with_exchange_is_bitwise_the_chain():
     """K17 inside the persistent kernel (row-tiled networks) against K17 inside the graph-replayed three-launch SLAB chain:
     the same arithmetic in the same order on both ranks -- bitwise equal parameters, moments and statistics."""
     runs = {}
-    for mode in ("peer", "peer_ws_rowtile"):
+    for mode in ("peer_slabs", "peer_ws_rowtile"):
         mgr = mp.Manager()
         out = mgr.dict()
         mp.spawn(_rank, args=(2, _free_port(), out, mode), nprocs=2, join=True)
         runs[mode] = [out[r] for r in range(2)]
-    a, b = runs["peer"], runs["peer_ws_rowtile"]
+    a, b = runs["peer_slabs"], runs["peer_ws_rowtile"]
     assert b[0]["ws_exchange_launches"] == 2 and a[0]["ws_exchange_launches"] == 0
     for r in range(2):
         assert torch.equal(a[r]["w"], b[r]["w"]) and torch.equal(a[r]["exp_avg"], b[r]["exp_avg"])
