@@ -53,7 +53,8 @@ def _cfg(g):
 # ---- tolerances of quantities that have passed through optimiser steps -----------------------------------------------
 # Single-mini-batch quantities (losses, gradients, returns, log-probs) are asserted at the north_star's 1e-5 throughout.
 # Per-epoch statistics and final weights sit behind up to a few hundred Adam steps; their bounds are the deviations
-# MEASURED on MI355X (tests/golden/measured_deviations.json, written by a run with PPOAF_RECORD_DEVIATIONS=<file>;
+# MEASURED on MI355X (tests/golden/measured_deviations.json = tests/golden/merge_deviations.py over a run of the GPU
+# suite with PPOAF_RECORD_DEVIATIONS=<directory>;
 # the kernels are bitwise reproducible, so a rerun measures the same numbers) times MARGIN -- not round numbers.
 #   stat_dev   = max over the epoch's statistics of |got - want| / (0.1 + |want|)   (losses are O(1), KL / entropy O(1e-2))
 #   weight_max = max |dw| over a network's weights after all steps; weight_share = share of weights with |dw| > 2e-5
@@ -72,11 +73,12 @@ def _bound(case, key, value, floor):
     """Assert `value` within MARGIN x the deviation measured for (case, key) -- at least `floor`, the resolution below
     which float32 noise of a different summation order lives -- and record it when asked to."""
     rec = os.environ.get("PPOAF_RECORD_DEVIATIONS")
-    if rec:
+    if rec:                                    # a directory: one file per process (the two-rank tests record from their ranks)
         slot = _RECORDED.setdefault(case, {})
         slot[key] = max(float(value), slot.get(key, 0.0))
-        with open(rec, "w") as fh:
-            _json.dump({**MEASURED, **{c: {**MEASURED.get(c, {}), **v} for c, v in _RECORDED.items()}}, fh, indent=1, sort_keys=True)
+        os.makedirs(rec, exist_ok=True)
+        with open(os.path.join(rec, f"{os.getpid()}.json"), "w") as fh:
+            _json.dump(_RECORDED, fh)
         return
     assert case in MEASURED and key in MEASURED[case], f"no measured deviation for {case} / {key}: record with PPOAF_RECORD_DEVIATIONS"
     limit = max(MARGIN * MEASURED[case][key], floor)
