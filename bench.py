@@ -45,6 +45,17 @@ GAE_BYTES_PER_TRANSITION = 16  # read r, V; write adv, rtg
 STREAM_KERNEL = "void ppoaf::gae_rtg_stream_kernel<4, 1, 1024, false, 1>"   # the large-E form of K1 (csrc/gae.hip)
 
 
+def device_clocks():
+    """What the driver reports for the GPU's clocks right after the measurement (rocm-smi, read-only; None if unavailable)."""
+    import subprocess
+    try:
+        p = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(p.stdout).values()))
+        return {k.split(" clock")[0]: v for k, v in card.items() if "clock level" in k or "clock" in k.lower()}
+    except Exception:                                       # noqa: BLE001 -- a report field, never a reason to fail the bench
+        return None
+
+
 def pmc_traffic():
     """
     HBM bytes per launch of the GAE kernels from the committed PMC passes (profiles/*_gae_pmc.csv,
@@ -411,6 +422,9 @@ def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": pmc.get("ppoaf::gae_rtg_chunked_kernel"), "traffic_source": pmc.get("_source"),
             "bytes_per_launch": gae_bytes, "avg_launch_us": round(gae_avg_s * 1e6, 3), "launches": len(gae_ms),
+            "median_launch_us": round(sorted(gae_ms)[len(gae_ms) // 2] * 1e3, 3) if gae_ms else None,
+            "min_launch_us": round(min(gae_ms) * 1e3, 3) if gae_ms else None,
+            "max_launch_us": round(max(gae_ms) * 1e3, 3) if gae_ms else None,
             "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on the launch stream, timed region",
             "note": "config size (8.4 MB, fits L2/MALL) is latency-bound; see roofline_saturating"}
 
@@ -552,21 +566,29 @@ def main():
         r = torch.rand(T, Es, device=device); v = torch.randn(T, Es, device=device)
         b = torch.randn(Es, device=device)
         adv = torch.empty_like(r); rtg = torch.empty_like(r)
-        for _ in range(2):
+        for _ in range(3):
             K.gae_rtg_tmajor(r, v, b, b, None, adv_out=adv, rtg_out=rtg)
-        reps = 5
+        # protocol (round 4): 20 timed launches back to back after 3 warm-ups; `achieved` comes from the MEDIAN launch,
+        # min / max and the clocks the driver reports ride along -- five launches and a mean (rounds 1-3) moved +-9 %
+        # between boxes of the pool (5.17 and 5.91 TB/s on two driver runs of the same kernel)
+        reps = 20
         evs = [(K.event_create(), K.event_create()) for _ in range(reps)]
         for ev in evs:
             K.gae_rtg_tmajor(r, v, b, b, None, adv_out=adv, rtg_out=rtg, timing_events=ev)
         torch.cuda.synchronize()
-        sec = sum(K.event_elapsed_ms(a, c) for a, c in evs) * 1e-3 / reps
+        us = sorted(K.event_elapsed_ms(a, c) * 1e3 for a, c in evs)
+        med = 0.5 * (us[reps // 2 - 1] + us[reps // 2])
         bts = GAE_BYTES_PER_TRANSITION * T * Es
+        gbs = lambda t_us: round(bts / (t_us * 1e-6) / 1e9, 1)
         out["roofline_saturating"] = {"kernel": "gae_rtg_stream_kernel<4, 1, 1024>", "bound": "hbm",
-                                      "transitions": T * Es, "achieved": round(bts / sec / 1e9, 1),
+                                      "transitions": T * Es, "achieved": gbs(med),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(bts / sec / 1e9 / HBM_PEAK_GBS, 4),
-                                      "avg_launch_us": round(sec * 1e6, 1),
-                                      "traffic": pmc_traffic().get(STREAM_KERNEL)}
+                                      "frac": round(gbs(med) / HBM_PEAK_GBS, 4),
+                                      "avg_launch_us": round(sum(us) / reps, 1), "median_launch_us": round(med, 1),
+                                      "min_launch_us": round(us[0], 1), "max_launch_us": round(us[-1], 1), "launches": reps,
+                                      "achieved_best": gbs(us[0]), "achieved_worst": gbs(us[-1]),
+                                      "clocks": device_clocks(),
+                                      "traffic": pmc_traffic().get(STREAM_KERNEL), "traffic_source": pmc_traffic().get("_source")}
         del r, v, b, adv, rtg
 
     out.update(cpu)

@@ -255,6 +255,8 @@ class FusedPolicyUpdate:
             return "disabled after a failed launch: " + self._tail_disabled
         if not self.split:
             return "the slab chain runs (" + self.split_reason + ")"
+        if self._split_blocks() > 512:
+            return f"{self._split_blocks()} weight-gradient workgroups (a polling wave of the fused launch holds 512 records)"
         if self.multi and self.xchg_sp is None:
             return "N > 1 without an exchange for the fused tail launch (" + self.xchg_reason + ")"
         return ""
@@ -318,6 +320,8 @@ class FusedPolicyUpdate:
         a.loss_partials = self.loss_partials.data_ptr(); a.totals = self.totals.data_ptr()
         a.mb_offset, a.cursor_advance = 0, 1
         a.xcd_half = getattr(self, "xcd_half", 0)        # 1 / 2: beside the ICM chain (ppo.py: _ppo_icm_epoch_overlapped)
+        if a.xcd_half == 0 and os.environ.get("PPOAF_XCD_PER_NETWORK", "0") == "1":
+            a.xcd_half = 3                               # experiment: all row tiles of a network on ONE XCD (one L2 fetches its weights once)
         a.split_workspace, a.split_workspace_bytes = None, 0
         if self.split:
             if self._split_space is None:            # sized once for the full batch size; a tail mini-batch needs less

@@ -16,15 +16,17 @@ NAMES = {0: "U2 T1024 (shipped)", 1: "U4 T256", 2: "U8 T256 (round 1)", 4: "U8 T
          16: "U2 T1024 nt", 17: "U2 T1024 G2", 18: "U1 T1024 G2", 19: "U2 T512 G2", 20: "U1 T1024 G4", 21: "U3 T1024", 22: "U2 T768"}
 
 
-def run(r, v, b, adv, rtg, reps=4):
-    for _ in range(2):
+def run(r, v, b, adv, rtg, reps=20):
+    """bench.py's protocol (round 4): 3 warm-ups, 20 timed launches -> (best, median, worst) GB/s."""
+    for _ in range(3):
         K.gae_rtg_tmajor(r, v, b, b, None, adv_out=adv, rtg_out=rtg)
     evs = [(K.event_create(), K.event_create()) for _ in range(reps)]
     for ev in evs:
         K.gae_rtg_tmajor(r, v, b, b, None, adv_out=adv, rtg_out=rtg, timing_events=ev)
     torch.cuda.synchronize()
     s = sorted(K.event_elapsed_ms(a, c) for a, c in evs)
-    return 16.0 * T * Es / (s[0] * 1e-3) / 1e9, 16.0 * T * Es / (sum(s) / len(s) * 1e-3) / 1e9
+    g = lambda ms: 16.0 * T * Es / (ms * 1e-3) / 1e9
+    return g(s[0]), g(0.5 * (s[reps // 2 - 1] + s[reps // 2])), g(s[-1])
 
 
 n = T * Es
@@ -36,8 +38,8 @@ for skew in [int(x) for x in os.environ.get("SKEWS", "0,64,1088,16640").split(",
     views[0].uniform_(); views[1].normal_()
     for var in [int(x) for x in os.environ.get("VARIANTS", "0,1,13,14").split(",")]:
         os.environ["PPOAF_GAE_VARIANT"] = str(var)
-        best, avg = run(views[0], views[1], b, views[2], views[3])
-        print(f"skew {skew:6d}  variant {var:2d} {NAMES[var]:18s} best {best:7.1f} GB/s  avg {avg:7.1f} GB/s", flush=True)
+        best, med, worst = run(views[0], views[1], b, views[2], views[3])
+        print(f"skew {skew:6d}  variant {var:2d} {NAMES[var]:18s} best {best:7.1f}  median {med:7.1f}  worst {worst:7.1f} GB/s", flush=True)
 # copy reference: float4 copy of the same volume (read 2 arrays, write 2)
 x = big[:2 * n]; y = big[2 * (n + pad):2 * (n + pad) + 2 * n]
 for _ in range(2):
