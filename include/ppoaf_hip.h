@@ -429,15 +429,6 @@ int ppoaf_ppo_update_wgrad_adam(const ppoaf_ppo_update_args_t* args, void* ctl, 
 /* same launch with the kernel's own begin / end stamped into two events */
 int ppoaf_ppo_update_wgrad_adam_timed(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
                                       void* start_event, void* stop_event, ppoaf_stream_t stream);
-/* The same chain for n_minibatches consecutive mini-batches (cursor .. cursor + n - 1) in ONE launch that keeps all
- * 2 * ceil(B/16) <= 32 workgroups on one XCD (target_xcc, 0..7): parameters, moments and gradients stay in that XCD's
- * L2 between mini-batches and the chain's three grid-wide dependencies are flag barriers inside it (single rank;
- * see csrc/ppo_update.hip).  ctl: ppoaf_ppo_update_persistent_ctl_bytes() of device memory, 16-byte aligned, owned by
- * the caller for the duration of the launch; its second 32-bit word is non-zero afterwards if a wait ran out of
- * wait_seconds (the workers were not all resident).  mb_offset must be 0; the cursor advances by n_minibatches. */
-int ppoaf_ppo_update_persistent_ctl_bytes(void);
-int ppoaf_ppo_update_persistent(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl,
-                                int32_t target_xcc, double wait_seconds, ppoaf_stream_t stream);
 int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int compute_norms, ppoaf_stream_t stream);
 /* Weight-stationary persistent form of the same update (csrc/ppo_update_ws.hip; single rank): n_minibatches
  * consecutive mini-batches in ONE launch, processed layer by layer over all B rows -- forward / dgrad as 64x32 output

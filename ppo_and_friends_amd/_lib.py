@@ -193,8 +193,6 @@ SIGNATURES = {
                                        _ptr, _ptr, _ptr]),
     "ppoaf_ppo_update_fwd_bwd": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr]),
     "ppoaf_ppo_update_fwd_bwd_timed": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, _ptr, _ptr]),
-    "ppoaf_ppo_update_persistent_ctl_bytes": (C.c_int, []),
-    "ppoaf_ppo_update_persistent": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int64, _ptr, C.c_int32, C.c_double, _ptr]),
     "ppoaf_ppo_update_ws_ctl_bytes": (C.c_int, []),
     "ppoaf_ppo_update_ws_workspace_bytes": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int32, C.POINTER(C.c_int64)]),
     "ppoaf_ppo_update_ws": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int64, _ptr, _ptr, C.c_int64, C.c_int32, C.c_int32, C.c_int32,

@@ -227,212 +227,6 @@ __global__ __launch_bounds__(256) void ppo_update_adam_kernel(UpdateDev u, const
     if (blockIdx.x == 0 && threadIdx.x == 0 && u.cursor_advance) u.cursor[0] += u.cursor_advance;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Single-XCD persistent form of the chain (single rank): ONE launch runs n_mb consecutive mini-batches,
-// fwd_bwd -> slab reduce -> clip + Adam each, on 2 * n_wg <= 32 workgroups that all sit on ONE XCD.
-//   * why one XCD: the whole per-mini-batch state (parameters, moments, gradient bucket: 4 x 271 KB at C2) then
-//     lives in that XCD's 4 MB L2 -- the weights Adam has just rewritten are L2 hits for the next forward instead
-//     of cold misses behind a kernel boundary -- and the three grid-wide dependencies of a mini-batch become
-//     flag barriers inside that L2 (~1 us each) instead of launch boundaries (~2.6 us each).
-//   * placement: 256 workgroups are launched (one per CU: the LDS footprint admits no second one); each reads
-//     HW_REG_XCC_ID, those of the target XCD draw a ticket, the first 2 * n_wg tickets are the workers, everyone
-//     else exits at once.  Every wait is bounded by a wall-clock budget: if the workers are not all resident the
-//     launch ends with the error word set (the host raises) instead of hanging.
-//   * visibility inside the launch (MI355X_MICROARCH.md, inter-workgroup visibility): producers finish their
-//     stores (s_waitcnt vmcnt(0): acknowledged by the L2 all workers share) before their flag store; consumers
-//     read cross-CU data with L1-bypassing loads (NT) -- plain stores keep the lines in the XCD's L2.
-// Arithmetic and summation orders are those of the three-launch chain (slabs in slab order, norm partials in
-// worker order), so both forms give the same weights.
-// ------------------------------------------------------------------------------------------------------------
-struct PersistCtl {
-    unsigned tickets, error, pad0[30];
-    unsigned flags[32];               // one word per worker: the barrier epoch it has reached
-    double norm_partials[64];         // [worker][2]: squared-norm partials of the two networks
-    unsigned long long phase_ticks[8];// diagnostic build (-DPPOAF_PERSIST_STAMPS): s_memtime sums per phase, worker 0
-};
-#ifdef PPOAF_PERSIST_STAMPS
-#define PPOAF_PSTAMP(k)                                                                   \
-    do {                                                                                  \
-        if (w == 0 && tid == 0) {                                                         \
-            unsigned long long t_;                                                        \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
-            ctl->phase_ticks[k] += t_ - t_prev;                                           \
-            t_prev = t_;                                                                  \
-        }                                                                                 \
-    } while (0)
-#else
-#define PPOAF_PSTAMP(k) do {} while (0)
-#endif
-
-// The fwd_bwd body inside the persistent kernel's mini-batch loop.  Inlined naively, LLVM hoists everything in the
-// body that does not change between mini-batches (kernel-argument loads, per-lane global and LDS addresses) out of
-// the loop, where all of it is live at once: 2 KB of scratch per lane at 256 VGPRs.  Three opaque values make the
-// body loop-variant instead (218 VGPRs, no scratch, <8,8>): the kernel arguments are read through the kernarg
-// segment pointer (constant address space: still scalar loads), which passes through an empty asm every iteration;
-// the lane id passes through one as well (with its range re-asserted); the LDS base gets an opaque zero.
-typedef const UpdateDev __attribute__((address_space(4))) KUpdateDev;
-
-// All workers arrive; returns false when the wait ran out of its budget (the error word is then set).
-__device__ __forceinline__ bool persist_barrier(PersistCtl* c, const int w, const int n_workers, const unsigned epoch,
-                                                const long long budget, int* s_ok) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's stores have reached the L2
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *(volatile unsigned*)&c->flags[w] = epoch;            // plain store: the line stays in this XCD's L2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (threadIdx.x < 64) {
-        const long long t0 = wall_clock64();
-        int ok = 1;
-        while (true) {
-            unsigned f = epoch;
-            if ((int)threadIdx.x < n_workers)
-                f = __hip_atomic_load(&c->flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: L2-served
-            if (__all((int)(f >= epoch))) break;
-            if (__hip_atomic_load(&c->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-                wall_clock64() - t0 > budget) { ok = 0; break; }
-        }
-        if (threadIdx.x == 0) {
-            if (!ok) *(volatile unsigned*)&c->error = 1u;
-            *s_ok = ok;
-        }
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-
-template <int HTA, int HTC>
-__global__ __launch_bounds__(kThreadsU) void ppo_update_persistent_kernel(UpdateDev u, PersistCtl* ctl, int n_mb,
-                                                                          int target_xcc, long long budget) {
-    __shared__ int s_ticket, s_ok;
-    __shared__ double s_red[17];
-    __shared__ double s_norm[2];
-    __shared__ float s_step[4];
-    const int tid = threadIdx.x;
-    KUpdateDev* ku0 = (KUpdateDev*)__builtin_amdgcn_kernarg_segment_ptr();  // `u` is the first kernel argument
-    if ((int)hw_xcc_id() != target_xcc) return;               // uniform per workgroup
-    if (tid == 0) s_ticket = (int)atomicAdd(&ctl->tickets, 1u);
-    __syncthreads();
-    const int n_workers = 2 * u.n_wg;
-    const int w = __builtin_amdgcn_readfirstlane(s_ticket);   // wave-uniform by construction: keep it in an SGPR
-    if (w >= n_workers) return;
-    const int which = w < u.n_wg ? 0 : 1, g = w < u.n_wg ? w : w - u.n_wg;
-    const long n4 = u.bucket_total >> 2;
-    const long stride = (long)n_workers * kThreadsU;
-    const float4* sl = reinterpret_cast<const float4*>(u.slabs);
-    unsigned epoch = 0;
-#ifdef PPOAF_PERSIST_STAMPS
-    unsigned long long t_prev = 0;
-    if (w == 0 && tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
-#endif
-    for (int i = 0; i < n_mb; ++i) {
-        // ---- phase 1: forward + backward of this worker's 16 rows of its network -> its slab, loss partials
-        KUpdateDev* ku = ku0;
-        asm volatile("" : "+s"(ku));
-        int tid_l = threadIdx.x;                  // per-iteration copy of the lane id: phases 2 / 3 index with it, so their
-        asm volatile("" : "+v"(tid_l));           // address arithmetic is not hoisted across the fwd_bwd body either
-        __builtin_assume(tid_l >= 0 && tid_l < kThreadsU);
-        const int tid = tid_l;
-        if (which == 0) ppo_update_fwd_bwd_body<HTA, true, KUpdateDev>(*ku, 0, g, i);
-        else ppo_update_fwd_bwd_body<HTC, true, KUpdateDev>(*ku, 1, g, i);
-        PPOAF_PSTAMP(0);
-        if (!persist_barrier(ctl, w, n_workers, ++epoch, budget, &s_ok)) return;
-        PPOAF_PSTAMP(1);
-
-        // ---- phase 2: slabs -> gradient bucket (slab order), squared-norm partials per worker; bookkeeping
-        double q0 = 0.0, q1 = 0.0;
-        for (long idx = (long)w * kThreadsU + tid; idx < n4; idx += stride) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int g0 = 0; g0 < u.n_wg; g0 += 8) {
-                float4 v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    v[k] = (g0 + k < u.n_wg) ? ld4<true>(reinterpret_cast<const float*>(sl + (long)(g0 + k) * n4 + idx))
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
-            }
-            reinterpret_cast<float4*>(u.grads)[idx] = acc;
-            const float sc = u.grad_scale;
-            const double q = (double)(acc.x * sc) * (acc.x * sc) + (double)(acc.y * sc) * (acc.y * sc) +
-                             (double)(acc.z * sc) * (acc.z * sc) + (double)(acc.w * sc) * (acc.w * sc);
-            if (idx * 4 < u.net[0].size) q0 += q; else q1 += q;
-        }
-        q0 = block_sum(q0, s_red);
-        q1 = block_sum(q1, s_red);
-        if (tid == 0) { ctl->norm_partials[2 * w] = q0; ctl->norm_partials[2 * w + 1] = q1; }
-        if (w == n_workers - 1 && tid < 64) {
-            // the bookkeeping of ppo_update_bookkeeping, on loss partials other CUs wrote a moment ago
-            const int lane = tid;
-            float p0 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p7 = 0.f;
-            for (int gg = lane; gg < u.n_wg; gg += 64) {
-                const float* a = u.loss_partials + (long)gg * 8;
-                const float* cc = u.loss_partials + ((long)u.n_wg + gg) * 8;
-                p0 += ld1<true>(a); p3 += ld1<true>(a + 3); p4 += ld1<true>(a + 4); p7 += ld1<true>(a + 7); p2 += ld1<true>(cc + 2);
-            }
-            p0 = wave_sum(p0); p2 = wave_sum(p2); p3 = wave_sum(p3); p4 = wave_sum(p4); p7 = wave_sum(p7);
-            if (lane == 0) {
-                const float n = (float)u.B;
-                const float surr = p0 / n, ent = p3 / n, kl = p4 / n, crit = p2 / n;
-                float total = surr;
-                if (u.entropy_weight != 0.0f) total -= u.entropy_weight * ent;
-                if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
-                u.totals[0] += (double)surr; u.totals[1] += (double)total; u.totals[2] += (double)crit;
-                u.totals[3] += (double)ent; u.totals[4] += (double)kl;
-                u.totals[5] += (double)ld1<true>(u.loss_partials + 5); u.totals[6] += (double)ld1<true>(u.loss_partials + 6);
-                u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
-                u.totals[8] += 1.0;
-            }
-            if (lane < 2) {
-                const int64_t t = u.step_counts[lane] + 1;        // only this lane ever touches the counters in the launch
-                u.step_counts[lane] = t;
-                u.norm_scratch[2 + 2 * lane] = 1.0 - pow((double)u.beta1, (double)t);
-                u.norm_scratch[3 + 2 * lane] = sqrt(1.0 - pow((double)u.beta2, (double)t));
-            }
-        }
-        PPOAF_PSTAMP(2);
-        if (!persist_barrier(ctl, w, n_workers, ++epoch, budget, &s_ok)) return;
-        PPOAF_PSTAMP(3);
-
-        // ---- phase 3: clip + Adam on the columns this worker reduced; norms = partials in worker order
-        if (tid < 2) {
-            double sq = 0.0;
-            for (int k = 0; k < n_workers; ++k) sq += ld1<true>(ctl->norm_partials + 2 * k + tid);
-            s_norm[tid] = sq;
-            s_step[2 * tid] = (float)((double)u.lr[0] / ld1<true>(u.norm_scratch + 2 + 2 * tid));
-            s_step[2 * tid + 1] = (float)ld1<true>(u.norm_scratch + 3 + 2 * tid);
-        }
-        __syncthreads();
-        for (long idx = (long)w * kThreadsU + tid; idx < n4; idx += stride) {
-            const int wh = (idx * 4 < u.net[0].size) ? 0 : 1;
-            float4 p = ld4<true>(u.params + 4 * idx);
-            const float4 gr = ld4<true>(u.grads + 4 * idx);
-            float4 m = ld4<true>(u.exp_avg + 4 * idx), v = ld4<true>(u.exp_avg_sq + 4 * idx);
-            const float total_norm = (float)sqrt(s_norm[wh]);
-            float coef = 1.0f;
-            if (u.max_norm > 0.f) coef = fminf(u.max_norm / (total_norm + 1e-6f), 1.0f);
-            const float gs = u.grad_scale * coef;
-            const float step_size = s_step[2 * wh], bc2_sqrt = s_step[2 * wh + 1];
-#define PPOAF_ADAM1(c)                                                   \
-            {                                                            \
-                const float gi = gr.c * gs;                              \
-                m.c = u.beta1 * m.c + (1.0f - u.beta1) * gi;             \
-                v.c = u.beta2 * v.c + (1.0f - u.beta2) * gi * gi;        \
-                p.c = p.c - step_size * (m.c / (sqrtf(v.c) / bc2_sqrt + u.adam_eps)); \
-            }
-            PPOAF_ADAM1(x) PPOAF_ADAM1(y) PPOAF_ADAM1(z) PPOAF_ADAM1(w)
-#undef PPOAF_ADAM1
-            reinterpret_cast<float4*>(const_cast<float*>(u.params))[idx] = p;
-            reinterpret_cast<float4*>(u.exp_avg)[idx] = m;
-            reinterpret_cast<float4*>(u.exp_avg_sq)[idx] = v;
-        }
-        PPOAF_PSTAMP(4);
-        if (!persist_barrier(ctl, w, n_workers, ++epoch, budget, &s_ok)) return;
-        PPOAF_PSTAMP(5);
-    }
-    if (w == 0 && tid == 0) u.cursor[0] += n_mb;
-}
-
 // (n, mean, M2) of every mini-batch's rewards-to-go: one workgroup per mini-batch
 __global__ __launch_bounds__(256) void minibatch_moments_kernel(const float* __restrict__ data,
                                                                 const int64_t* __restrict__ perm,
@@ -603,53 +397,6 @@ extern "C" int ppoaf_ppo_update_fwd_bwd_timed(const ppoaf_ppo_update_args_t* arg
     if (ha == 128 && hc == 256) return launch_fwd_bwd<8, 16>(u, lds, s, e0, e1);
     if (ha == 64 && hc == 128) return launch_fwd_bwd<4, 8>(u, lds, s, e0, e1);
     set_error("ppo_update_fwd_bwd: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
-    return PPOAF_E_INVALID;
-}
-
-template <int HTA, int HTC>
-static int launch_persistent(const UpdateDev& u, size_t lds, PersistCtl* ctl, int n_mb, int xcc, long long budget,
-                             hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_update_persistent_kernel<HTA, HTC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
-        attr_set = true;
-    }
-    // one workgroup per CU of the whole device: only those on the target XCD that draw a worker ticket stay
-    hipLaunchKernelGGL((ppo_update_persistent_kernel<HTA, HTC>), dim3(256), dim3(kThreadsU), lds, s, u, ctl, n_mb, xcc, budget);
-    return check_launch("ppo_update_persistent");
-}
-
-extern "C" int ppoaf_ppo_update_persistent_ctl_bytes(void) { return (int)sizeof(PersistCtl); }
-
-extern "C" int ppoaf_ppo_update_persistent(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl,
-                                           int32_t target_xcc, double wait_seconds, ppoaf_stream_t stream) {
-    UpdateDev u;
-    int rc = make_update_dev(args, u);
-    if (rc) return rc;
-    PPOAF_REQUIRE(ctl && (((uintptr_t)ctl) & 15) == 0, "ppo_update_persistent: control block missing or misaligned");
-    PPOAF_REQUIRE(n_minibatches >= 1 && n_minibatches <= (1 << 20), "ppo_update_persistent: n_minibatches=%ld", (long)n_minibatches);
-    PPOAF_REQUIRE(2 * u.n_wg <= 32, "ppo_update_persistent: %d workgroups needed, one XCD holds 32 (batch size <= 256)", 2 * u.n_wg);
-    PPOAF_REQUIRE(target_xcc >= 0 && target_xcc < 8, "ppo_update_persistent: target_xcc=%d", target_xcc);
-    PPOAF_REQUIRE(wait_seconds > 0.0 && wait_seconds <= 600.0, "ppo_update_persistent: wait_seconds=%g", wait_seconds);
-    PPOAF_REQUIRE(u.mb_offset == 0, "ppo_update_persistent: mb_offset must be 0 (the launch walks the cursor itself)");
-    // the persistent form needs a little static LDS beside the fwd_bwd carve
-    const size_t lds = fwd_bwd_lds_bytes(u);
-    PPOAF_REQUIRE(lds <= 159 * 1024, "ppo_update_persistent: needs %zu B of LDS", lds);
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(ctl, 0, sizeof(PersistCtl), s);       // tickets, error word, barrier epochs
-    if (e != hipSuccess) { set_error("ppo_update_persistent: memset: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
-    const long long budget = (long long)(wait_seconds * 1.0e8);          // wall_clock64 ticks at 100 MHz
-    PersistCtl* c = reinterpret_cast<PersistCtl*>(ctl);
-    const int ha = u.net[0].H, hc = u.net[1].H;
-    if (ha == 32 && hc == 32) return launch_persistent<2, 2>(u, lds, c, (int)n_minibatches, target_xcc, budget, s);
-    if (ha == 64 && hc == 64) return launch_persistent<4, 4>(u, lds, c, (int)n_minibatches, target_xcc, budget, s);
-    if (ha == 128 && hc == 128) return launch_persistent<8, 8>(u, lds, c, (int)n_minibatches, target_xcc, budget, s);
-    if (ha == 256 && hc == 256) return launch_persistent<16, 16>(u, lds, c, (int)n_minibatches, target_xcc, budget, s);
-    if (ha == 128 && hc == 256) return launch_persistent<8, 16>(u, lds, c, (int)n_minibatches, target_xcc, budget, s);
-    if (ha == 64 && hc == 128) return launch_persistent<4, 8>(u, lds, c, (int)n_minibatches, target_xcc, budget, s);
-    set_error("ppo_update_persistent: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
     return PPOAF_E_INVALID;
 }
 

@@ -278,7 +278,7 @@ class FusedPolicyUpdate:
     def _ws_wanted(self):
         """Would `ws_reason` pick the persistent kernel for this policy's shapes (before any epoch table exists)?"""
         import os
-        if os.environ.get("PPOAF_WS", "1") == "0" or os.environ.get("PPOAF_WS_MULTI", "1") == "0":
+        if os.environ.get("PPOAF_WS", "1") == "0":
             return False
         return self._ws_mask() >= 0 or max(self.actor_desc.hidden, self.critic_desc.hidden) >= 256
 
@@ -474,12 +474,13 @@ class FusedPolicyUpdate:
             _lib.check(rc, "ppo_update")
 
     _rccl_comm_cache = "unset"         # process-wide: libppoaf_hip's own RCCL communicator (or None)
+    rccl_loop = "c"                    # "python": the fallback's per-mini-batch loop from Python (tests compare the two)
 
     def _rccl_comm(self):
         """
         The communicator of the C-level fallback loops (`ppoaf_{ppo,icm,mat}_update_chain_allreduce`): a second RCCL
         communicator owned by libppoaf_hip.so, created once per process with the id travelling over torch.distributed.
-        None -- on EVERY rank -- when the backend is not RCCL, PPOAF_RCCL_LOOP=python asks for the Python loop, or any
+        None -- on EVERY rank -- when the backend is not RCCL, FusedPolicyUpdate.rccl_loop = "python" asks for the Python loop, or any
         rank cannot bind librccl: that is voted on BEFORE the collective init (ncclCommInitRank blocks until every rank
         has called it, so no rank may enter it alone); a second vote covers an init that returned an error.
         """
@@ -492,7 +493,7 @@ class FusedPolicyUpdate:
         comm = None
         dev = self.pol.device
         lib = self._lib
-        if dist.get_backend() == "nccl" and os.environ.get("PPOAF_RCCL_LOOP", "c") == "c":
+        if dist.get_backend() == "nccl" and cls.rccl_loop == "c":
             rank, world = mpi_utils.get_rank(), mpi_utils.get_num_procs()
 
             def vote(ok):
@@ -573,34 +574,6 @@ class FusedPolicyUpdate:
         finally:
             args.mb_offset, args.cursor_advance = 0, 1
 
-    # ---- single-XCD persistent form (csrc/ppo_update.hip: ppo_update_persistent_kernel)
-    persistent_chunk = 4096            # mini-batches per launch (one launch per epoch at the BASELINE sizes)
-    persistent_launch_count = 0        # launches of the single-XCD persistent kernel in this process (tests)
-
-    def _persistent_ctl(self):
-        ctl = getattr(self, "_persist_ctl", None)
-        if ctl is None:
-            n = int(self._lib.ppoaf_ppo_update_persistent_ctl_bytes())
-            ctl = self._persist_ctl = torch.zeros((n + 3) // 4, dtype=torch.int32, device=self.pol.device)
-        return ctl
-
-    def persistent_reason(self):
-        """'' when the epoch's full mini-batches can run as one persistent launch, else why not."""
-        import os
-        if type(self) is not FusedPolicyUpdate:
-            return "K12 (MLP policies) only"
-        # opt-in: measured SLOWER than the three-launch chain at every BASELINE shape (C2: 40.6 vs 34 us per mini-batch;
-        # DESIGN.md section 3, "single-XCD persistent chain") -- kept, parity-tested, as the base for the next step
-        if os.environ.get("PPOAF_PERSISTENT", "0") != "1":
-            return "off (set PPOAF_PERSISTENT=1 to run the single-XCD persistent chain)"
-        if getattr(self, "_ws_disabled", ""):
-            return "disabled after a failed launch: " + self._ws_disabled
-        if self.multi:
-            return "N > 1: the gradient exchange sits between the reduce and the Adam phase (three-launch chain)"
-        if 2 * self.n_wg > 32:
-            return f"batch size {self.B} needs {2 * self.n_wg} workgroups, one XCD holds 32"
-        return ""
-
     def _persistent_failure(self):
         """After a host synchronisation: '' or why the last persistent launch did not complete (its control block)."""
         ctl = getattr(self, "_ws_ctl", None)
@@ -620,19 +593,13 @@ class FusedPolicyUpdate:
                 self._graphs.clear()                      # the captured chains end in the fused launch
                 return ("ppo_update_wgrad_adam: a wait ran out of time -- the launch's workgroups were not all resident at once "
                         "(another process on this GPU?)")
-        ctl = getattr(self, "_persist_ctl", None)
-        if ctl is not None and getattr(self, "_persist_used", False):
-            self._persist_used = False
-            if int(ctl[1].item()) != 0:
-                return ("ppo_update_persistent: a barrier wait ran out of time -- the launch did not get all of its workgroups "
-                        "onto one XCD (another process on this GPU?)")
         return ""
 
     def _check_persistent(self):
         """Raising form (tests, probes that drive single launches)."""
         why = self._persistent_failure()
         if why:
-            raise _lib.PpoafError(why + ".  Set PPOAF_WS=0 / unset PPOAF_PERSISTENT to use the three-launch chain.")
+            raise _lib.PpoafError(why + ".  Set PPOAF_WS=0 to use the launch chain.")
 
     # ---- a persistent launch that cannot get its workers resident must not cost the run: the epoch is redone on the chain
     def _epoch_state(self):
@@ -656,6 +623,8 @@ class FusedPolicyUpdate:
 
     # ---- weight-stationary persistent form (csrc/ppo_update_ws.hip: ppo_update_ws_kernel)
     ws_chunk = 4096                    # mini-batches per launch
+    ws_workers = 32                    # workgroups per network: every CU of its XCD
+    ws_wait_seconds = 2.0              # bound of every in-kernel wait
     ws_launch_count = 0                # launches of the kernel in this process (tests: the path really ran)
     ws_exchange_launch_count = 0       # ... of which with the K17 exchange inside the launch (N > 1)
 
@@ -711,28 +680,27 @@ class FusedPolicyUpdate:
         args = self._args_for(self.B)
         left = self.n_full
         self._ws_snapshot = None
-        if left > 0 and self.n_done == 0 and (self.ws_reason() == "" or self.persistent_reason() == "" or self.tail_reason() == ""):
+        if left > 0 and self.n_done == 0 and (self.ws_reason() == "" or self.tail_reason() == ""):
             # what the epoch starts from (a few buckets of <= 1 MB: device-to-device copies), should the launch not complete
             self._ws_snapshot = [t.clone() for t in self._epoch_state()]
         if left > 0 and self.ws_reason() == "":
             import os
             ctl, wsb = self._ws_buffers()
-            workers = int(os.environ.get("PPOAF_WS_WORKERS", "32"))
+            workers = self.ws_workers
             # one GPU per rank: XCDs 0 / 1.  Ranks rehearsing on ONE device (PPOAF_SHARE_DEVICE=1, tests) take XCD pairs of
             # their own -- two worker groups cannot share a CU's LDS, and every rank's workers must be resident at once
             slot = mpi_utils.get_rank() % 4 if os.environ.get("PPOAF_SHARE_DEVICE", "0") == "1" else 0
-            xa = int(os.environ.get("PPOAF_WS_XCC_ACTOR", str(2 * slot))) % 8
-            xc = int(os.environ.get("PPOAF_WS_XCC_CRITIC", str(2 * slot + 1))) % 8
+            xa, xc = (2 * slot) % 8, (2 * slot + 1) % 8
             st = K.stream()
-            wait_s = float(os.environ.get("PPOAF_WS_WAIT_SECONDS", "2.0"))    # bound of every in-kernel wait
+            wait_s = self.ws_wait_seconds                  # bound of every in-kernel wait
             while left > 0:
                 n = min(left, self.ws_chunk)
                 ev = self.ws_timing_events.pop() if getattr(self, "ws_timing_events", None) else (None, None)
                 if self.xchg_ws is not None:
-                    # N > 1: K17 as a phase of every mini-batch inside the launch (PPOAF_WS_XCHG_FENCES=1: formal fences too)
+                    # N > 1: K17 as a phase of every mini-batch inside the launch (system-scope accesses, no fences)
                     _lib.check(self._lib.ppoaf_ppo_update_ws_exchange(
                         C.byref(args), n, ctl.data_ptr(), wsb.data_ptr(), wsb.numel(), workers, xa, xc, self._ws_mask(), wait_s,
-                        self.xchg_ws.handle, self.xchg_ws.wait_seconds, int(os.environ.get("PPOAF_WS_XCHG_FENCES", "0")),
+                        self.xchg_ws.handle, self.xchg_ws.wait_seconds, 0,
                         ev[0], ev[1], st), "ppo_update_ws_exchange")
                     FusedPolicyUpdate.ws_exchange_launch_count += 1
                 else:
@@ -740,19 +708,6 @@ class FusedPolicyUpdate:
                                                              xa, xc, self._ws_mask(), wait_s, ev[0], ev[1], st), "ppo_update_ws")
                 self._ws_used = True
                 FusedPolicyUpdate.ws_launch_count += 1
-                left -= n
-                self.n_done += n
-        if left > 0 and self.persistent_reason() == "":
-            import os
-            ctl = self._persistent_ctl()
-            xcc = int(os.environ.get("PPOAF_PERSISTENT_XCC", "0")) % 8
-            st = K.stream()
-            while left > 0:
-                n = min(left, self.persistent_chunk)
-                _lib.check(self._lib.ppoaf_ppo_update_persistent(C.byref(args), n, ctl.data_ptr(), xcc, 2.0, st),
-                           "ppo_update_persistent")
-                self._persist_used = True
-                FusedPolicyUpdate.persistent_launch_count += 1
                 left -= n
                 self.n_done += n
         use_graph = self.ppo.use_graphs and (not self.multi or self.xchg is not None)   # RCCL calls are not captured
@@ -789,7 +744,7 @@ class FusedPolicyUpdate:
     def end_epoch(self):
         """-> numpy totals[9] (sums of the 8 loss scalars over mini-batches, mini-batch count)."""
         ppo = self.ppo
-        if not self.multi and (getattr(self, "_ws_used", False) or getattr(self, "_persist_used", False) or getattr(self, "_tail_used", False)):
+        if not self.multi and (getattr(self, "_ws_used", False) or getattr(self, "_tail_used", False)):
             torch.cuda.current_stream().synchronize()
             why = self._persistent_failure()
             if why:                                       # before anything of the failed epoch reaches the normaliser
@@ -895,11 +850,9 @@ class FusedIcmUpdate:
         self._graphs, self._args = {}, {}
         self.xchg, self.xchg_reason = (peer_exchange.open_exchange(pol.icm_model.flat_grads.numel(), dev)
                                        if self.multi else (None, "single rank"))
-        # split-wgrad chain (csrc/icm_update.hip: icm_wgrad_kernel): PPOAF_ICM_SPLIT = 1 (default) | 0.  The reduce entry
+        # split-wgrad chain (csrc/icm_update.hip: icm_wgrad_kernel): PPOAF_SPLIT_WGRAD = auto | 1 (default) | 0.  The reduce entry
         # point keeps its contract, so graphs, K17 and the RCCL loop are the same with either form.
-        mode = os.environ.get("PPOAF_ICM_SPLIT", "1")
-        if mode not in ("0", "1"):
-            raise ValueError(f"PPOAF_ICM_SPLIT={mode!r}: expected 0 or 1")
+        mode = "0" if os.environ.get("PPOAF_SPLIT_WGRAD", "auto") == "0" else "1"
         self.split = mode == "1"
         self._split_space = None
 
@@ -981,7 +934,7 @@ class FusedIcmUpdate:
 
     def _c_loop(self, args, n):
         """The RCCL fallback (no K17 exchange) issued from C: ppoaf_icm_update_chain_allreduce, <= 256 mini-batches per call.
-        False when the library has no RCCL communicator of its own (gloo tests, PPOAF_RCCL_LOOP=python)."""
+        False when the library has no RCCL communicator of its own (gloo tests, rccl_loop = "python")."""
         g = self.pol.icm_model.flat_grads
         if not self.multi or self.xchg is not None or mpi_utils._needs_staging(g):
             return False
@@ -1128,12 +1081,10 @@ class FusedMatUpdate(FusedPolicyUpdate):
         self.records = self.adv_records = self.perm = None
         self._graphs, self._args = {}, {}
         self.xchg, self.xchg_reason = (peer_exchange.open_exchange(total, dev) if self.multi else (None, "single rank"))
-        # split-wgrad chain (csrc/mat_update.hip: mat_update_wgrad_kernel): PPOAF_MAT_SPLIT = 1 (default) | 0.  The reduce
+        # split-wgrad chain (csrc/mat_update.hip: mat_update_wgrad_kernel): PPOAF_SPLIT_WGRAD = auto | 1 (default) | 0.  The reduce
         # entry point keeps its contract (slabs / panels -> gradient bucket), so every path above it -- graphs, K17, the
         # RCCL loops -- is the same with either form.
-        mode = os.environ.get("PPOAF_MAT_SPLIT", "1")
-        if mode not in ("0", "1"):
-            raise ValueError(f"PPOAF_MAT_SPLIT={mode!r}: expected 0 or 1")
+        mode = "0" if os.environ.get("PPOAF_SPLIT_WGRAD", "auto") == "0" else "1"
         self.split = mode == "1"
         self._split_space = None
         self._norm_partials = {}

@@ -887,17 +887,16 @@ class PPO:
         fused_icm = self._fused_icm_updater(policy_id)
         if fused is None or fused_icm is None:
             return False
-        if mpi_utils.distributed_path() and (fused.xchg is None or fused_icm.xchg is None
-                                             or os.environ.get("PPOAF_OVERLAP_ICM_MULTI", "1") == "0"):
+        if mpi_utils.distributed_path() and (fused.xchg is None or fused_icm.xchg is None):
             return False
         # each chain's fwd_bwd launches on its own half of the XCDs: weights and panels of one chain stay out of the other's
-        # four L2s (C3: +2 % env-steps/s; PPOAF_XCD_HALVES=0: both use every XCD)
-        halves = os.environ.get("PPOAF_XCD_HALVES", "1") != "0"
+        # four L2s (C3: +2 % env-steps/s; PPO.xcd_halves = False: both use every XCD)
+        halves = getattr(self, "xcd_halves", True)
         fused.xcd_half, fused_icm.xcd_half = (1, 2) if halves else (0, 0)
         fused.begin_epoch(loader.epoch_permutation())
         fused_icm.begin_epoch(loader.epoch_permutation())
         # two concurrent kernel chains: the persistent two-XCD kernel would serialise them (experiment switch only)
-        fused.ws_allowed = os.environ.get("PPOAF_WS_WITH_ICM", "0") == "1"
+        fused.ws_allowed = False
         main = torch.cuda.current_stream()
         sa, sb = K.concurrent_stream_pair(self.device)         # two streams on different hardware queues
         sa.wait_stream(main); sb.wait_stream(main)

@@ -12,6 +12,8 @@ from ppo_and_friends_amd.spaces import Box, Discrete
 from ppo_and_friends_amd import fused_update
 
 kind = os.environ.get("PPOAF_FALLBACK_KIND", "ppo")
+# (test-side knob of this helper, not a switch of the package: which of the two fallback loops issues the launches)
+fused_update.FusedPolicyUpdate.rccl_loop = os.environ.get("PPOAF_TEST_RCCL_LOOP", "c")
 mpi_utils.init_process_group_from_env()
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)

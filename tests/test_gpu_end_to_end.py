@@ -624,7 +624,7 @@ def test_fused_icm_update_matches_oracle(case, form, monkeypatch):
     gradients, Adam) against the torch-CPU ICM of oracle/icm_oracle.py trained on the same mini-batches.
     `split` = the split-wgrad chain (default: panels + icm_wgrad_kernel), `slabs` = per-tile slabs + slab reduce.
     """
-    monkeypatch.setenv("PPOAF_ICM_SPLIT", "1" if form == "split" else "0")
+    monkeypatch.setenv("PPOAF_SPLIT_WGRAD", "1" if form == "split" else "0")
     from oracle import icm_oracle
     from ppo_and_friends_amd.ppo import PPO
     from ppo_and_friends_amd.fused_update import FusedIcmUpdate

@@ -331,7 +331,7 @@ def test_c5_mat_split_wgrad_chain_matches_the_slab_form_at_full_size(monkeypatch
     from ppo_and_friends_amd import kernels as K
     grads, totals, epochs = {}, {}, {}
     for split in ("0", "1", "1"):
-        monkeypatch.setenv("PPOAF_MAT_SPLIT", split)
+        monkeypatch.setenv("PPOAF_SPLIT_WGRAD", split)
         ppo, E, T, A = _c_config("C5", use_graphs=len(epochs.get("1", [])) == 0)
         ppo.rollout()
         pol = ppo.policies["p"]
@@ -374,7 +374,7 @@ def test_c3_icm_split_wgrad_chain_matches_the_slab_form_at_full_size(monkeypatch
     from ppo_and_friends_amd.fused_update import FusedIcmUpdate
     grads, weights, losses, epochs = {}, {}, {}, {}
     for split in ("0", "1", "1"):
-        monkeypatch.setenv("PPOAF_ICM_SPLIT", split)
+        monkeypatch.setenv("PPOAF_SPLIT_WGRAD", split)
         ppo, E, T, A = _c_config("C3", use_graphs=len(epochs.get("1", [])) == 0)
         ppo.rollout()
         pol = ppo.policies["p"]

@@ -88,7 +88,7 @@ def _bound(case, key, value, floor):
 def case_id(name, update_mode):
     """Fixture + everything that selects a kernel form (each form sums in its own order, so each has its own measured
     deviation): update mode and the path switches present in the environment."""
-    keys = ("PPOAF_WS", "PPOAF_WS_MODE", "PPOAF_PERSISTENT", "PPOAF_MAT_SPLIT", "PPOAF_OVERLAP_ICM", "PPOAF_GRAD_EXCHANGE",
+    keys = ("PPOAF_WS", "PPOAF_WS_MODE", "PPOAF_SPLIT_WGRAD", "PPOAF_OVERLAP_ICM", "PPOAF_GRAD_EXCHANGE",
             "PPOAF_FUSED_TAIL", "WORLD_SIZE")
     env = ",".join(f"{k[6:] if k.startswith('PPOAF_') else k}={os.environ[k]}" for k in keys if k in os.environ)
     return f"{name}/{update_mode}" + (f"[{env}]" if env else "")
@@ -214,7 +214,7 @@ def first_minibatch_probe(ppo, pol, perm, B):
     perm_t = torch.as_tensor(np.asarray(perm, dtype=np.int64), device=pol.device)
     if fused is not None:
         fused.begin_epoch(perm_t)
-        if fused.n_full >= 1 and (fused.ws_reason() == "" or fused.persistent_reason() == ""):
+        if fused.n_full >= 1 and fused.ws_reason() == "":
             state = [pol.policy_params, pol.policy_exp_avg, pol.policy_exp_avg_sq, pol.policy_step_counts, pol.policy_norm_scratch,
                      fused.vn_mean, fused.vn_var, fused.vn_count, fused.cursor, fused.totals, pol.buffer.values]
             keep = [t.clone() for t in state]
@@ -504,10 +504,10 @@ def test_product_reproduces_the_reference_mat_iterations(golden, name, update_mo
     fixtures g12_c5_mat: 16-env mini-batches = 4 K15 tiles; g12_c5_b256: batch_size 256 = 52 tiles).  Autoregressive
     rollout (K16 / torch path) with the recorded actions replayed, shared-episode dataset incl. quirk Q14, first
     mini-batch (K15 launch): losses + the full gradient bucket before any optimiser step, epochs, final weights.
-    `fused` = the split-wgrad chain (the default), `fused_slabs` = weight-gradient slabs + slab reduce (PPOAF_MAT_SPLIT=0).
+    `fused` = the split-wgrad chain (the default), `fused_slabs` = weight-gradient slabs + slab reduce (PPOAF_SPLIT_WGRAD=0).
     """
     if update_mode == "fused_slabs":
-        monkeypatch.setenv("PPOAF_MAT_SPLIT", "0")
+        monkeypatch.setenv("PPOAF_SPLIT_WGRAD", "0")
         update_mode = "fused"
     from ppo_and_friends_amd import _lib
     from ppo_and_friends_amd import kernels as K
@@ -534,7 +534,7 @@ def test_product_reproduces_the_reference_mat_iterations(golden, name, update_mo
     pol = ppo.policies["agent"]
     assert (ppo._fused_updater("agent", B) is not None) == (update_mode == "fused")
     if update_mode == "fused":
-        assert ppo._fused_updater("agent", B).split == (os.environ.get("PPOAF_MAT_SPLIT", "1") == "1")
+        assert ppo._fused_updater("agent", B).split == (os.environ.get("PPOAF_SPLIT_WGRAD", "1") == "1")
     sd0 = {"actor." + k[len("init_actor."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init_actor.")}
     sd0.update({"critic." + k[len("init_critic."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init_critic.")})
     missing, unexpected = pol.actor_critic.load_state_dict(sd0, strict=False)
@@ -658,24 +658,6 @@ def test_product_reproduces_the_reference_lstm_iterations(golden, name, S, n_act
     for tag, net in (("actor", pol.actor), ("critic", pol.critic)):
         check_final_weights(case, tag, np.concatenate([p.detach().cpu().numpy().reshape(-1) for k, p in net.named_parameters()]),
                             np.concatenate([g[f"final_{tag}.{k}"].reshape(-1) for k, p in net.named_parameters()]))
-
-
-@pytest.mark.parametrize("name", ["g12_c2_term", "g12_c3_gauss", "g12_c4_mappo"] + B256)
-def test_persistent_single_xcd_chain_reproduces_the_reference(golden, name, monkeypatch):
-    """
-    The opt-in single-XCD persistent form of K12 (one launch per epoch: fwd_bwd -> reduce -> Adam phases separated by
-    flag barriers inside one XCD's L2, PPOAF_PERSISTENT=1) against the same reference-recorded iterations.
-    """
-    from ppo_and_friends_amd import fused_update
-    monkeypatch.setenv("PPOAF_PERSISTENT", "1")
-    monkeypatch.setenv("PPOAF_WS", "0")                   # (a 256-wide critic would otherwise take the two-XCD kernel)
-    before = fused_update.FusedPolicyUpdate.persistent_launch_count
-    test_product_reproduces_the_reference_ppo_iterations(golden, name, "fused")
-    # and it really was the persistent launch that ran: the first-mini-batch probe + one launch per epoch
-    g = golden(name)
-    c = _cfg(g)
-    ran = fused_update.FusedPolicyUpdate.persistent_launch_count - before
-    assert ran == 1 + c["iterations"] * c["epochs"], f"single-XCD persistent launches: {ran}"
 
 
 @pytest.mark.parametrize("mode", ["auto", "layered", "rowtile"])

@@ -272,7 +272,7 @@ def _rank_kind(rank, world, port, out, mode, kind):
     from ppo_and_friends_amd.spaces import Box, Discrete
     dev = torch.device("cuda", 0)
     if kind == "wide_chain":                                 # the same shape on the launch chain (tail / ICM-overlapped epochs)
-        os.environ["PPOAF_WS_MULTI"] = "0"
+        os.environ["PPOAF_WS"] = "0"
     if kind in ("wide", "wide_chain"):
         # C4 shape: 3 agents share the policy, 128-wide actor, 256-wide critic on the concatenated observations
         # (bucket of ~180k floats: 176 exchange groups)
@@ -408,7 +408,7 @@ def test_rccl_fallback_loops_agree(kind):
     The N > 1 fallback when the K17 exchange is not available: fwd_bwd -> reduce -> RCCL all-reduce -> [norm +] Adam per
     mini-batch, for the PPO (K12), ICM (K14) and MAT (K15) updates.  Issued from C in one call per 256 mini-batches
     (`ppoaf_{ppo,icm,mat}_update_chain_allreduce`, the library's own RCCL communicator, id over torch.distributed) or
-    from the Python loop (PPOAF_RCCL_LOOP=python): the same kernels in the same order -- bitwise equal parameters and
+    from the Python loop (FusedPolicyUpdate.rccl_loop = "python"): the same kernels in the same order -- bitwise equal parameters and
     moments (the clip norms are fixed-order sums: no atomics).  One rank rehearsing the N > 1 path (a one-GPU box cannot
     host two RCCL ranks).
     """
@@ -418,7 +418,7 @@ def test_rccl_fallback_loops_agree(kind):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
     for loop in ("c", "python"):
-        env = dict(os.environ, PPOAF_REHEARSE_MULTI_RANK="1", PPOAF_GRAD_EXCHANGE="rccl", PPOAF_RCCL_LOOP=loop,
+        env = dict(os.environ, PPOAF_REHEARSE_MULTI_RANK="1", PPOAF_GRAD_EXCHANGE="rccl", PPOAF_TEST_RCCL_LOOP=loop,
                    PPOAF_FALLBACK_KIND=kind,
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PPOAF_BACKEND"):
