@@ -58,7 +58,7 @@ class PpoUpdateArgs(C.Structure):
                 ("loss_partials", C.c_void_p), ("totals", C.c_void_p),
                 ("mb_offset", C.c_int64), ("cursor_advance", C.c_int64),
                 ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64),
-                ("xcd_half", C.c_int32), ("_pad2", C.c_int32)]
+                ("xcd_half", C.c_int32), ("_pad2", C.c_int32), ("tail_ctl", C.c_void_p)]
 
 
 ABI_VERSION = 5

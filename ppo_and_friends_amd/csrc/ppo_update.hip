@@ -30,12 +30,7 @@ __global__ __launch_bounds__(kThreadsU) void ppo_update_fwd_bwd_kernel(UpdateDev
     const int b = blockIdx.x;
     int which = (b >> 2) & 1;                              // b % 8 in {0..3} -> actor, {4..7} -> critic
     int g = ((b >> 3) << 2) | (b & 3);
-    if (u.confine == 3) {                                  // experiment (args->xcd_half = 3): ONE XCD per network (0: actor, 4: critic)
-        const int x = b & 7;
-        if (x != 0 && x != 4) return;
-        which = x >> 2;
-        g = b >> 3;
-    } else if (u.confine) {                                // one half of the XCDs left to another chain (args->xcd_half)
+    if (u.confine) {                                // one half of the XCDs left to another chain (args->xcd_half)
         const int x = b & 7;
         if ((x >> 2) != u.confine - 1) return;
         which = (x & 3) >> 1;                              // the half's first two XCDs: actor, the other two: critic
@@ -327,7 +322,7 @@ int make_update_dev(const ppoaf_ppo_update_args_t* a, UpdateDev& u) {
     u.n_wg = (int)((a->B + kRows - 1) / kRows);
     // split-wgrad chain: the caller's workspace holds this mini-batch's activation / dz panels
     u.split = 0;
-    PPOAF_REQUIRE(a->xcd_half >= 0 && a->xcd_half <= 3, "ppo_update: xcd_half=%d (0, 1, 2 or 3)", a->xcd_half);
+    PPOAF_REQUIRE(a->xcd_half >= 0 && a->xcd_half <= 2, "ppo_update: xcd_half=%d (0, 1 or 2)", a->xcd_half);
     u.confine = a->xcd_half;
     u.sp = WsDev();
     if (a->split_workspace) {
@@ -339,6 +334,16 @@ int make_update_dev(const ppoaf_ppo_update_args_t* a, UpdateDev& u) {
         PPOAF_REQUIRE((size_t)a->split_workspace_bytes >= need, "ppo_update: split_workspace of %ld B, %zu needed",
                       (long)a->split_workspace_bytes, need);
         u.split = 1;
+    }
+    u.sig = nullptr;
+    u.sig_seq = nullptr;
+    if (a->tail_ctl) {
+        PPOAF_REQUIRE(u.split, "ppo_update: tail_ctl is for the split-wgrad chain (split_workspace not set)");
+        PPOAF_REQUIRE((((uintptr_t)a->tail_ctl) & 63) == 0, "ppo_update: tail_ctl must be 64-byte aligned");
+        PPOAF_REQUIRE(u.n_wg <= kTailFlagWgs && u.net[0].depth <= kTailFlagLayers && u.net[1].depth <= kTailFlagLayers,
+                      "ppo_update: tail_ctl holds ready words for %d workgroups x %d layers per network", kTailFlagWgs, kTailFlagLayers);
+        u.sig = reinterpret_cast<unsigned*>(static_cast<char*>(a->tail_ctl) + kTailFlagOff);
+        u.sig_seq = reinterpret_cast<const unsigned long long*>(a->tail_ctl);
     }
     return PPOAF_OK;
 }
@@ -357,8 +362,7 @@ static int launch_fwd_bwd_as(const UpdateDev& u, size_t lds, hipStream_t s, hipE
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
         attr_set = true;
     }
-    const unsigned grid = u.confine == 3 ? 8u * (unsigned)u.n_wg
-                          : u.confine ? 8u * (unsigned)((u.n_wg + 1) / 2) : 8u * (unsigned)((u.n_wg + 3) / 4);     // groups of 4 actor + 4 critic blocks
+    const unsigned grid = u.confine ? 8u * (unsigned)((u.n_wg + 1) / 2) : 8u * (unsigned)((u.n_wg + 3) / 4);     // groups of 4 actor + 4 critic blocks
     if (e0 || e1)        // the kernel's own begin / end stamped into the events (bench.py: roofline_update)
         hipExtLaunchKernelGGL((ppo_update_fwd_bwd_kernel<HTA, HTC, SPLIT>), dim3(grid), dim3(kThreadsU), lds, s, e0, e1, 0, u);
     else

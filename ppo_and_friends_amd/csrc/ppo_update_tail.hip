@@ -31,7 +31,7 @@ namespace ppoaf {
 typedef unsigned tail_u32x4 __attribute__((ext_vector_type(4)));
 typedef float tail_f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTailRecOff = 256;              // byte offset of the records inside the control block
+// (kTailFlagOff / kTailRecOff: ppo_update_dev.hpp -- fwd_bwd writes the ready words of the same block)
 constexpr int kTailMaxRounds = 8;             // a polling lane holds up to 8 records: <= 512 workgroups
 constexpr int kTailMaxE = 9;                  // output segment: up to 9 elements per thread (8 x 256 weights + bias + log_std)
 
@@ -42,9 +42,11 @@ struct TailCtl {
     long long bc_t[2];                        // the Adam step (per network) the corrections below were computed for
     double bc[4];                             // [network][1 - beta1^t, sqrt(1 - beta2^t)]: left by the previous launch's bookkeeping
     unsigned long long stamps[24];            // diagnostic build (-DPPOAF_TAIL_STAMPS): s_memtime per phase of one workgroup
+    unsigned ready[2 * kTailFlagLayers * kTailFlagWgs];   // fwd_bwd's ready words (args->tail_ctl): tag of the mini-batch whose
+                                                          // dz_l rows (network, layer l, workgroup g) are out
     tail_u32x4 rec[1];                        // [8 * per_xcd]: {q bits 0..31, tag, q bits 32..63, tag}
 };
-static_assert(offsetof(TailCtl, rec) == kTailRecOff, "record offset");
+static_assert(offsetof(TailCtl, ready) == kTailFlagOff && offsetof(TailCtl, rec) == kTailRecOff, "control block layout");
 
 // diagnostic layer (tools/tail_stamps.py): one macro, nothing in the shipped kernel
 #ifdef PPOAF_TAIL_STAMPS
@@ -67,6 +69,7 @@ struct TailDev {
     TailCtl* ctl;
     long long budget;                         // wall_clock64 ticks (100 MHz)
     int nblk, jobs_a, jobs_c, per_xcd;
+    int handoff;                              // 1: fwd_bwd of this mini-batch signals ready words (args->tail_ctl) and may still be running
 };
 
 struct TailCoef { float gs, step_size, bc2_sqrt; };
@@ -80,6 +83,31 @@ __device__ __forceinline__ void tail_publish(const TailDev& td, const unsigned t
     const unsigned long long qb = (unsigned long long)__double_as_longlong(q);
     const tail_u32x4 r = {(unsigned)qb, tag, (unsigned)(qb >> 32), tag};
     __builtin_amdgcn_raw_buffer_store_b128(r, tail_rsrc(td), (unsigned)(kTailRecOff + 16 * b), 0, 16 /* sc1 */);
+}
+
+// Hand-off from a fwd_bwd launch that may still be running (td.handoff): all threads of the workgroup; wave 0 polls the
+// ready words of (network, layer) for the n_wg row-tile workgroups until each carries this mini-batch's tag, the barrier
+// holds the others.  The panels, partials and loss scalars behind the words were written through (sc1) and are read with
+// sc1 loads.  A wait that runs out of its budget sets the error word (the launch drains; the host redoes the epoch).
+__device__ __forceinline__ void tail_wait_ready(const TailDev& td, const unsigned tag, const int which, const int l, const int n_wg) {
+    if (!td.handoff) return;                                  // uniform
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        long long budget = td.budget;
+        if (__hip_atomic_load(&td.ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) budget = 0;
+        const long long t0 = (long long)wall_clock64();
+        for (unsigned polls = 1;; ++polls) {
+            unsigned f = tag;
+            if (lane < n_wg) f = __hip_atomic_load(&td.ctl->ready[tail_flag_index(which, l, lane)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(f == tag))) break;
+            if ((polls & 15u) == 0u && (long long)wall_clock64() - t0 > budget) {
+                if (lane == 0) __hip_atomic_store(&td.ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
 }
 
 // wave_sum<double> in its own association (xor 32, 16, 8, 4, 2, 1 -- IEEE addition is commutative, so pairing lane i with
@@ -346,6 +374,8 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
         const bool has_b = itile == 0 && tid >= 64 && tid < 80;
         const long bidx = nb + offB(l) + ot * 16 + (tid - 64);
         sb = tail_pmv_load(u, bidx, has_b);
+        tail_wait_ready(td, tag, which, l, u.n_wg);           // (concurrent fwd_bwd: dz_l and its K-panel are out)
+        const int aux = td.handoff ? 16 /* sc1 */ : 0;
         const long ldx = l >= 1 ? H : 64;
         const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(u.sp.dbuf[which] + (long)l * plane, 0, 0xFFFFFFFF, 0x00020000);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -363,9 +393,15 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned sd = 4u * (unsigned)((16 * ch + 4 * j) * H), sx = 4u * (unsigned)((16 * ch + 4 * j) * (int)ldx);
-                    a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, sd, 0));
-                    x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl, sx, 0));
-                    if (two) x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl + 64u, sx, 0));
+                    if (aux) {                                // uniform (the cache policy is an immediate of the instruction)
+                        a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, sd, 16));
+                        x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl, sx, 16));
+                        if (two) x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl + 64u, sx, 16));
+                    } else {
+                        a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, sd, 0));
+                        x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl, sx, 0));
+                        if (two) x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl + 64u, sx, 0));
+                    }
                 }
             }
         }
@@ -472,6 +508,7 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
             se[k] = tail_pmv_load(u, nb + seg_off + idx, idx < seg_len);
             ge[k] = 0.f;
         }
+        tail_wait_ready(td, tag, which, depth - 1, u.n_wg);   // (the partials precede dz of the last hidden layer)
 #pragma unroll
         for (int k = 0; k < kTailMaxE; ++k) {
             const long idx = tid + (long)kWgradThreads * k;
@@ -480,7 +517,10 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
                 for (int g0 = 0; g0 < n_hb; g0 += 8) {
                     float pv[8];
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) pv[kk] = outpart[(long)(g0 + kk < n_hb ? g0 + kk : 0) * seg_len + idx];
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const float* src = outpart + (long)(g0 + kk < n_hb ? g0 + kk : 0) * seg_len + idx;
+                        pv[kk] = td.handoff ? ld1<true>(src) : *src;
+                    }
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) if (g0 + kk < n_hb) acc += pv[kk];
                 }
@@ -534,11 +574,16 @@ __global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(Up
     __shared__ float s_coef[4];
     const int b = blockIdx.x;
     const unsigned long long seq = __hip_atomic_load(&td.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned tag = ((unsigned)seq & 0x7fffffffu) + 1u;              // never 0: a zero-initialised record is never current
+    const unsigned tag = tail_tag_of(seq);                                // never 0: a zero-initialised record is never current
     if (b == td.nblk) {
         // bookkeeping: the totals need nobody; what other workgroups read at their start moves only after all have published
+        if (td.handoff) {                                     // the loss partials of both networks' row tiles are out
+            tail_wait_ready(td, tag, 0, u.net[0].depth - 1, u.n_wg);
+            tail_wait_ready(td, tag, 1, u.net[1].depth - 1, u.n_wg);
+        }
         if (threadIdx.x >= 64) return;
-        ppo_update_bookkeeping_totals(u);
+        if (td.handoff) ppo_update_bookkeeping_totals<true>(u);
+        else ppo_update_bookkeeping_totals<false>(u);
         // while the others work: the bias corrections of the step being taken (norm_scratch, as ppo_update_bookkeeping_steps
         // leaves them) and of the NEXT step (control block: the next launch's workgroups need not compute them)
         const int w = threadIdx.x & 1;
@@ -626,6 +671,8 @@ static int tail_prepare(const ppoaf_ppo_update_args_t* args, void* ctl, double w
     td.jobs_c = split_wgrad_jobs(u.net[1]);
     td.per_xcd = split_wgrad_per_xcd(u);
     td.nblk = split_wgrad_blocks(u);
+    td.handoff = u.sig != nullptr;
+    PPOAF_REQUIRE(!td.handoff || args->tail_ctl == ctl, "ppo_update_wgrad_adam: args->tail_ctl names another control block");
     PPOAF_REQUIRE(td.nblk <= 64 * kTailMaxRounds, "ppo_update_wgrad_adam: %d workgroups, a polling wave holds %d records", td.nblk,
                   64 * kTailMaxRounds);
     for (int w = 0; w < 2; ++w)
@@ -653,6 +700,7 @@ extern "C" int ppoaf_ppo_update_tail_ctl_bytes(const ppoaf_ppo_update_args_t* ar
     PPOAF_REQUIRE(args && bytes_out, "ppo_update_tail_ctl_bytes: null argument");
     ppoaf_ppo_update_args_t a = *args;
     a.split_workspace = nullptr;
+    a.tail_ctl = nullptr;
     const int rc = make_update_dev(&a, u);
     if (rc) return rc;
     *bytes_out = (int64_t)kTailRecOff + 16 * (int64_t)split_wgrad_blocks(u);
@@ -664,6 +712,7 @@ extern "C" int ppoaf_ppo_update_tail_exchange_floats(const ppoaf_ppo_update_args
     PPOAF_REQUIRE(args && floats_out, "ppo_update_tail_exchange_floats: null argument");
     ppoaf_ppo_update_args_t a = *args;
     a.split_workspace = nullptr;
+    a.tail_ctl = nullptr;
     const int rc = make_update_dev(&a, u);
     if (rc) return rc;
     *floats_out = (int64_t)tail_exchange_floats(u, nullptr);

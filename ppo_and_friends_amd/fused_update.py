@@ -233,7 +233,11 @@ class FusedPolicyUpdate:
         """fwd_bwd + the launch that completes the gradient bucket (wgrad / slab reduce) of ONE mini-batch, no optimiser step:
         what tests and bench probes compare.  The bookkeeping of that launch (totals, step counters) runs as usual."""
         lib, st, ref = self._lib, K.stream(), C.byref(args)
-        _lib.check(lib.ppoaf_ppo_update_fwd_bwd_timed(ref, timing_events[0], timing_events[1], st), "ppo_update_fwd_bwd")
+        keep, args.tail_ctl = args.tail_ctl, None            # no fused tail launch follows: nothing to hand over to
+        try:
+            _lib.check(lib.ppoaf_ppo_update_fwd_bwd_timed(ref, timing_events[0], timing_events[1], st), "ppo_update_fwd_bwd")
+        finally:
+            args.tail_ctl = keep
         if args.split_workspace:
             _lib.check(lib.ppoaf_ppo_update_wgrad(ref, st), "ppo_update_wgrad")
         else:
@@ -261,7 +265,30 @@ class FusedPolicyUpdate:
             return "N > 1 without an exchange for the fused tail launch (" + self.xchg_reason + ")"
         return ""
 
-    def _tail_ctl_ptr(self, args):
+    def tail_overlap_reason(self):
+        """'' when fwd_bwd and the fused tail launch of a mini-batch run CONCURRENTLY (two streams inside the captured chain;
+        fwd_bwd signals ready words per layer, the tail's jobs wait for theirs: the weight gradients of the upper layers are
+        formed while the backward pass still runs and the tail's start-up is off the critical path), else why they run one
+        after the other.  PPOAF_FUSED_TAIL = 2 (default where it applies) | 1 (sequential) | 0 (wgrad + Adam launches)."""
+        import os
+        why = self.tail_reason()
+        if why:
+            return why
+        if os.environ.get("PPOAF_FUSED_TAIL", "2") == "1":
+            return "sequential (PPOAF_FUSED_TAIL=1)"
+        if getattr(self, "_overlap_disabled", ""):
+            return "disabled after a failed launch: " + self._overlap_disabled
+        # both launches must be resident together: a waiting tail workgroup keeps its CU's registers, and a fwd_bwd workgroup
+        # (512 threads x 231 VGPRs) needs a CU to itself -- one CU per workgroup of either launch, with slack
+        if self._split_blocks() + 1 + 2 * self.n_wg > 224:
+            return f"{self._split_blocks() + 1} + {2 * self.n_wg} workgroups do not fit on the device side by side"
+        if getattr(self, "xcd_half", 0):
+            return "the epoch shares the GPU with the ICM update on a second stream"
+        if not self.ppo.use_graphs:
+            return "eager launches (host-bound): one stream"
+        return ""
+
+    def _tail_ctl_ptr(self, args, count=True):
         ctl = getattr(self, "_tail_ctl", None)
         if ctl is None:
             need = C.c_int64(0)
@@ -272,7 +299,8 @@ class FusedPolicyUpdate:
                 assert int(need.value) == self._tail_exchange_floats(), (int(need.value), self._tail_exchange_floats())
             # zeroed once, then kept: the block carries the launch tag from one launch to the next
             ctl = self._tail_ctl = torch.zeros((n + 63) // 64 * 16, dtype=torch.int32, device=self.pol.device)
-        FusedPolicyUpdate.tail_launches += 1
+        if count:
+            FusedPolicyUpdate.tail_launches += 1
         return ctl.data_ptr()
 
     def _ws_wanted(self):
@@ -320,8 +348,6 @@ class FusedPolicyUpdate:
         a.loss_partials = self.loss_partials.data_ptr(); a.totals = self.totals.data_ptr()
         a.mb_offset, a.cursor_advance = 0, 1
         a.xcd_half = getattr(self, "xcd_half", 0)        # 1 / 2: beside the ICM chain (ppo.py: _ppo_icm_epoch_overlapped)
-        if a.xcd_half == 0 and os.environ.get("PPOAF_XCD_PER_NETWORK", "0") == "1":
-            a.xcd_half = 3                               # experiment: all row tiles of a network on ONE XCD (one L2 fetches its weights once)
         a.split_workspace, a.split_workspace_bytes = None, 0
         if self.split:
             if self._split_space is None:            # sized once for the full batch size; a tail mini-batch needs less
@@ -423,6 +449,10 @@ class FusedPolicyUpdate:
         st = K.stream()
         ref = C.byref(args)
         single = not self.multi
+        if args.split_workspace and self.tail_reason() == "":
+            # (fwd_bwd publishes write-through + ready words whenever the two launches MAY overlap; launched one after the
+            # other, as here, the tail's waits are satisfied at once)
+            args.tail_ctl = self._tail_ctl_ptr(args, count=False) if self.tail_overlap_reason() == "" else None
         rc = lib.ppoaf_ppo_update_fwd_bwd(ref, st)
         if rc == 0 and args.split_workspace:
             # split-wgrad chain: complete weight gradients from the published panels, then clip + Adam
@@ -566,12 +596,54 @@ class FusedPolicyUpdate:
 
     def _chunk(self, args, n):
         """n consecutive mini-batches with their index baked in: one cursor update for the whole chain."""
+        if type(self) is FusedPolicyUpdate and args.split_workspace and self.tail_overlap_reason() == "":
+            return self._chunk_overlapped(args, n)
         try:
             for j in range(n):
                 args.mb_offset = j
                 args.cursor_advance = n if j == n - 1 else 0
                 self._one(args)
         finally:
+            args.mb_offset, args.cursor_advance = 0, 1
+
+    tail_overlap_chunks = 0            # chunks issued on two streams in this process (tests: the path really ran)
+
+    def _chunk_overlapped(self, args, n):
+        """
+        The same chain with fwd_bwd(j) on the current stream and the fused tail launch(j) on a side stream, both ordered
+        behind tail(j - 1) only: inside a captured hipGraph two branches that meet again after every mini-batch.  tail(j)
+        starts with fwd_bwd(j), requests the optimiser state of its elements, and its jobs wait for the ready words fwd_bwd
+        sets layer by layer (csrc/ppo_update_tail.hip: tail_wait_ready).  fwd_bwd is issued FIRST, so that a device that
+        runs the two branches one after the other runs them in the order that completes.
+        """
+        lib, ref = self._lib, C.byref(args)
+        main = torch.cuda.current_stream()
+        side = getattr(self, "_tail_stream", None)
+        if side is None:
+            side = self._tail_stream = torch.cuda.Stream(device=self.pol.device)
+        ctl = self._tail_ctl_ptr(args, count=False)
+        args.tail_ctl = ctl
+        single = not self.multi
+        side.wait_stream(main)
+        try:
+            for j in range(n):
+                args.mb_offset = j
+                args.cursor_advance = n if j == n - 1 else 0
+                main.wait_stream(side)                                   # fwd_bwd(j) reads what tail(j - 1) wrote
+                rc = lib.ppoaf_ppo_update_fwd_bwd(ref, main.cuda_stream)
+                if rc == 0:
+                    if single:
+                        rc = lib.ppoaf_ppo_update_wgrad_adam(ref, ctl, self.tail_wait_seconds, side.cuda_stream)
+                    else:
+                        rc = lib.ppoaf_ppo_update_wgrad_adam_exchange(ref, ctl, self.tail_wait_seconds, self.xchg_sp.handle,
+                                                                     self.xchg_sp.wait_seconds, side.cuda_stream)
+                    FusedPolicyUpdate.tail_launches += 1
+                if rc != 0:
+                    _lib.check(rc, "ppo_update (overlapped chain)")
+            self._tail_used = True
+            FusedPolicyUpdate.tail_overlap_chunks += 1
+        finally:
+            main.wait_stream(side)
             args.mb_offset, args.cursor_advance = 0, 1
 
     def _persistent_failure(self):
@@ -589,7 +661,10 @@ class FusedPolicyUpdate:
             self._tail_used = False
             if int(ctl[2].item()) != 0:                   # TailCtl.error
                 ctl[2:3].zero_()
-                self._tail_disabled = "a wait for the other workgroups' norm records ran out of time"
+                if self.tail_overlap_reason() == "":      # first suspect: the two launches did not run side by side
+                    self._overlap_disabled = "a wait ran out of time with fwd_bwd and the tail launch on two streams"
+                else:
+                    self._tail_disabled = "a wait for the other workgroups' norm records ran out of time"
                 self._graphs.clear()                      # the captured chains end in the fused launch
                 return ("ppo_update_wgrad_adam: a wait ran out of time -- the launch's workgroups were not all resident at once "
                         "(another process on this GPU?)")
