@@ -21,7 +21,7 @@
 // CU at this kernel's register count -- checked on the host against the occupancy the runtime reports); every wait is
 // bounded by a wall-clock budget and ends in the control block's error word instead of a hang (the host then restores
 // the epoch's starting state and runs the three-launch chain, fused_update.py).
-#include "ppo_update_dev.hpp"
+#include "ppo_update_rowtile.hpp"
 #include "peer_exchange_device.hpp"
 #include <hip/hip_ext.h>
 #include <cstddef>
@@ -566,13 +566,10 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
     }
 }
 
+// One workgroup (256 threads) of the tail: block b of 8 * per_xcd + 1 (the last one keeps the books).
 template <int HA, int HC, bool XCHG>
-__global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(UpdateDev u, TailDev td, TailXchg xc) {
-    __shared__ double s_red[17];
-    __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
-    __shared__ float s_tile[16 * 32 + 16];
-    __shared__ float s_coef[4];
-    const int b = blockIdx.x;
+__device__ __forceinline__ void tail_block(const UpdateDev& u, const TailDev& td, TailXchg& xc, const int b, double* s_red, float* s_fold,
+                                           float* s_tile, float* s_coef) {
     const unsigned long long seq = __hip_atomic_load(&td.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned tag = tail_tag_of(seq);                                // never 0: a zero-initialised record is never current
     if (b == td.nblk) {
@@ -621,6 +618,43 @@ __global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(Up
 }
 
 template <int HA, int HC, bool XCHG>
+__global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(UpdateDev u, TailDev td, TailXchg xc) {
+    __shared__ double s_red[17];
+    __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
+    __shared__ float s_tile[16 * 32 + 16];
+    __shared__ float s_coef[4];
+    tail_block<HA, HC, XCHG>(u, td, xc, (int)blockIdx.x, s_red, s_fold, s_tile, s_coef);
+}
+
+// ---- ONE launch per mini-batch: fwd_bwd's row-tile workgroups (blocks 0 .. n_fwd - 1, dispatched first) and the tail's
+// workgroups in the same grid.  The tail workgroups start with the launch -- launch tag, step counters, the optimiser state
+// of their elements -- and wait for the ready words the row tiles set layer by layer (args->tail_ctl, tail_wait_ready):
+// the weight gradients of the upper layers are formed while the backward pass is still running, and between the last
+// dz rows and the optimiser step lie one hand-off, the layer-0 jobs and the norm records -- no kernel boundary, no second
+// ramp.  (Two launches on two streams do the same on paper; inside a captured hipGraph the cross-stream dependencies cost
+// more than the overlap buys: 38 us per mini-batch against 25.6 at C2.)  A row-tile workgroup never waits for anybody, and
+// it comes first in dispatch order, so the waits of the others are always served; every workgroup needs a CU of its own
+// (the kernel's register count admits one 512-thread workgroup per CU), which the host checks.
+template <int HTA, int HTC, bool XCHG>
+__global__ __launch_bounds__(kThreadsU) void ppo_update_step_kernel(UpdateDev u, TailDev td, TailXchg xc, int n_fwd) {
+    __shared__ double s_red[17];
+    __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
+    __shared__ float s_tile[16 * 32 + 16];
+    __shared__ float s_coef[4];
+    const int b = blockIdx.x;
+    if (b < n_fwd) {                                          // ppo_update_fwd_bwd_kernel's placement: XCDs 0-3 actor, 4-7 critic
+        const int which = (b >> 2) & 1;
+        const int g = ((b >> 3) << 2) | (b & 3);
+        if (g >= u.n_wg) return;
+        if (which == 0) ppo_update_fwd_bwd_body<HTA, false, UpdateDev, RowtileNoHook, true>(u, 0, g);
+        else ppo_update_fwd_bwd_body<HTC, false, UpdateDev, RowtileNoHook, true>(u, 1, g);
+        return;
+    }
+    if (threadIdx.x >= kWgradThreads) return;                 // a tail workgroup is four waves (before any barrier)
+    tail_block<16 * HTA, 16 * HTC, XCHG>(u, td, xc, b - n_fwd, s_red, s_fold, s_tile, s_coef);
+}
+
+template <int HA, int HC, bool XCHG>
 static int tail_launch_as(const UpdateDev& u, const TailDev& td, const TailXchg& xc, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     // every workgroup waits for every other one: all of them must fit on the device at once
     static int per_cu = 0, cus = 0;            // (queried on the first, eager, launch: nothing but the launch inside a stream capture)
@@ -656,6 +690,51 @@ static int tail_dispatch(const UpdateDev& u, const TailDev& td, const TailXchg* 
     if (ha == 128 && hc == 256) return tail_launch<128, 256>(u, td, xc, s, e0, e1);
     if (ha == 64 && hc == 128) return tail_launch<64, 128>(u, td, xc, s, e0, e1);
     set_error("ppo_update_wgrad_adam: hidden widths (actor %d, critic %d) not instantiated", ha, hc);
+    return PPOAF_E_INVALID;
+}
+
+template <int HTA, int HTC, bool XCHG>
+static int step_launch_as(const UpdateDev& u, const TailDev& td, const TailXchg& xc, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    static int per_cu = 0, cus = 0;
+    if (per_cu == 0) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_update_step_kernel<HTA, HTC, XCHG>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+        }
+        int n = 0, dev = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(ppo_update_step_kernel<HTA, HTC, XCHG>),
+                                                                   kThreadsU, lds);
+        if (e != hipSuccess) { set_error("ppo_update_step: occupancy query: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+        per_cu = n > 0 ? n : -1;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    const int n_fwd = 8 * ((u.n_wg + 3) / 4);                 // groups of 4 actor + 4 critic row tiles (ppo_update_fwd_bwd_kernel's grid)
+    const long grid = (long)n_fwd + td.nblk + 1;
+    PPOAF_REQUIRE(per_cu > 0 && grid <= (long)per_cu * cus,
+                  "ppo_update_step: %ld workgroups cannot be resident together (%d per CU x %d CUs)", grid, per_cu, cus);
+    if (e0 || e1)
+        hipExtLaunchKernelGGL((ppo_update_step_kernel<HTA, HTC, XCHG>), dim3((unsigned)grid), dim3(kThreadsU), (unsigned)lds, s, e0, e1, 0, u, td, xc, n_fwd);
+    else
+        hipLaunchKernelGGL((ppo_update_step_kernel<HTA, HTC, XCHG>), dim3((unsigned)grid), dim3(kThreadsU), lds, s, u, td, xc, n_fwd);
+    return check_launch("ppo_update_step");
+}
+template <int HTA, int HTC>
+static int step_launch(const UpdateDev& u, const TailDev& td, const TailXchg* xc, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (xc) return step_launch_as<HTA, HTC, true>(u, td, *xc, lds, s, e0, e1);
+    return step_launch_as<HTA, HTC, false>(u, td, TailXchg(), lds, s, e0, e1);
+}
+static int step_dispatch(const UpdateDev& u, const TailDev& td, const TailXchg* xc, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const size_t a = rowtile_lds_floats(u.net[0]), c = rowtile_lds_floats(u.net[1]);
+    const size_t lds = ((a > c ? a : c) * 4 + 15) / 16 * 16;
+    PPOAF_REQUIRE(lds <= 150 * 1024, "ppo_update_step: needs %zu B of LDS beside the tail's 9 KB", lds);
+    const int ha = u.net[0].H, hc = u.net[1].H;
+    if (ha == 32 && hc == 32) return step_launch<2, 2>(u, td, xc, lds, s, e0, e1);
+    if (ha == 64 && hc == 64) return step_launch<4, 4>(u, td, xc, lds, s, e0, e1);
+    if (ha == 128 && hc == 128) return step_launch<8, 8>(u, td, xc, lds, s, e0, e1);
+    if (ha == 64 && hc == 128) return step_launch<4, 8>(u, td, xc, lds, s, e0, e1);
+    set_error("ppo_update_step: hidden widths (actor %d, critic %d) not instantiated (networks up to 128 wide)", ha, hc);
     return PPOAF_E_INVALID;
 }
 
@@ -732,14 +811,8 @@ extern "C" int ppoaf_ppo_update_wgrad_adam(const ppoaf_ppo_update_args_t* args, 
     return ppoaf_ppo_update_wgrad_adam_timed(args, ctl, wait_seconds, nullptr, nullptr, stream);
 }
 
-extern "C" int ppoaf_ppo_update_wgrad_adam_exchange(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
-                                                    ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds, ppoaf_stream_t stream) {
-    UpdateDev u;
-    TailDev td;
-    int rc = tail_prepare(args, ctl, wait_seconds, u, td);
-    if (rc) return rc;
+static int tail_exchange_prepare(const UpdateDev& u, const TailDev& td, ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds, TailXchg& xc) {
     PPOAF_REQUIRE(xchg && xchg->connected, "ppo_update_wgrad_adam_exchange: exchange missing or not connected");
-    TailXchg xc;
     xc.x = xchg->dev;
     xc.seq = 0;
     const long need = tail_exchange_floats(u, xc.seg_base);
@@ -752,5 +825,51 @@ extern "C" int ppoaf_ppo_update_wgrad_adam_exchange(const ppoaf_ppo_update_args_
     PPOAF_REQUIRE(xchg->memory_kind != 3, "ppo_update_wgrad_adam_exchange: coarse-grained exchange slots are coherent only through "
                   "fences, which this launch does not use (create the exchange with memory_kind 0, 1 or 2)");
     xc.wait_ticks = (long long)(xchg_wait_seconds * 1.0e8);
+    return PPOAF_OK;
+}
+
+extern "C" int ppoaf_ppo_update_wgrad_adam_exchange(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
+                                                    ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds, ppoaf_stream_t stream) {
+    UpdateDev u;
+    TailDev td;
+    int rc = tail_prepare(args, ctl, wait_seconds, u, td);
+    if (rc) return rc;
+    TailXchg xc;
+    rc = tail_exchange_prepare(u, td, xchg, xchg_wait_seconds, xc);
+    if (rc) return rc;
     return tail_dispatch(u, td, &xc, (hipStream_t)stream, nullptr, nullptr);
+}
+
+// ---- one launch per mini-batch (fwd_bwd + tail in one grid)
+static int step_prepare(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds, UpdateDev& u, TailDev& td) {
+    int rc = tail_prepare(args, ctl, wait_seconds, u, td);
+    if (rc) return rc;
+    PPOAF_REQUIRE(td.handoff, "ppo_update_step: args->tail_ctl must name the control block (the row tiles signal through it)");
+    PPOAF_REQUIRE(u.confine == 0, "ppo_update_step: xcd_half must be 0");
+    return PPOAF_OK;
+}
+
+extern "C" int ppoaf_ppo_update_step_timed(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
+                                           void* start_event, void* stop_event, ppoaf_stream_t stream) {
+    UpdateDev u;
+    TailDev td;
+    int rc = step_prepare(args, ctl, wait_seconds, u, td);
+    if (rc) return rc;
+    return step_dispatch(u, td, nullptr, (hipStream_t)stream, (hipEvent_t)start_event, (hipEvent_t)stop_event);
+}
+
+extern "C" int ppoaf_ppo_update_step(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds, ppoaf_stream_t stream) {
+    return ppoaf_ppo_update_step_timed(args, ctl, wait_seconds, nullptr, nullptr, stream);
+}
+
+extern "C" int ppoaf_ppo_update_step_exchange(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
+                                              ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds, ppoaf_stream_t stream) {
+    UpdateDev u;
+    TailDev td;
+    int rc = step_prepare(args, ctl, wait_seconds, u, td);
+    if (rc) return rc;
+    TailXchg xc;
+    rc = tail_exchange_prepare(u, td, xchg, xchg_wait_seconds, xc);
+    if (rc) return rc;
+    return step_dispatch(u, td, &xc, (hipStream_t)stream, nullptr, nullptr);
 }

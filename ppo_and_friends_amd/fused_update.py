@@ -266,26 +266,27 @@ class FusedPolicyUpdate:
         return ""
 
     def tail_overlap_reason(self):
-        """'' when fwd_bwd and the fused tail launch of a mini-batch run CONCURRENTLY (two streams inside the captured chain;
-        fwd_bwd signals ready words per layer, the tail's jobs wait for theirs: the weight gradients of the upper layers are
-        formed while the backward pass still runs and the tail's start-up is off the critical path), else why they run one
-        after the other.  PPOAF_FUSED_TAIL = 2 (default where it applies) | 1 (sequential) | 0 (wgrad + Adam launches)."""
+        """'' when a mini-batch is ONE launch (ppoaf_ppo_update_step: fwd_bwd's row tiles and the fused tail's workgroups in
+        one grid; the row tiles signal ready words per layer, the tail's jobs wait for theirs, so the weight gradients of the
+        upper layers are formed while the backward pass still runs and the tail's start-up is off the critical path), else
+        why fwd_bwd and the tail are two launches.  PPOAF_FUSED_TAIL = 2 (default where it applies) | 1 (two launches) |
+        0 (three: wgrad and Adam apart)."""
         import os
         why = self.tail_reason()
         if why:
             return why
         if os.environ.get("PPOAF_FUSED_TAIL", "2") == "1":
-            return "sequential (PPOAF_FUSED_TAIL=1)"
+            return "two launches (PPOAF_FUSED_TAIL=1)"
         if getattr(self, "_overlap_disabled", ""):
             return "disabled after a failed launch: " + self._overlap_disabled
-        # both launches must be resident together: a waiting tail workgroup keeps its CU's registers, and a fwd_bwd workgroup
-        # (512 threads x 231 VGPRs) needs a CU to itself -- one CU per workgroup of either launch, with slack
-        if self._split_blocks() + 1 + 2 * self.n_wg > 224:
-            return f"{self._split_blocks() + 1} + {2 * self.n_wg} workgroups do not fit on the device side by side"
+        if max(self.actor_desc.hidden, self.critic_desc.hidden) > 128:
+            return "a 256-wide network: its weight-gradient jobs alone outnumber the CUs"
+        # every workgroup of the launch waits for others: one CU each (512 threads at the row tiles' register count)
+        grid = 8 * ((self.n_wg + 3) // 4) + self._split_blocks() + 1
+        if grid > 256:
+            return f"{grid} workgroups, one per CU"
         if getattr(self, "xcd_half", 0):
             return "the epoch shares the GPU with the ICM update on a second stream"
-        if not self.ppo.use_graphs:
-            return "eager launches (host-bound): one stream"
         return ""
 
     def _tail_ctl_ptr(self, args, count=True):
@@ -450,9 +451,20 @@ class FusedPolicyUpdate:
         ref = C.byref(args)
         single = not self.multi
         if args.split_workspace and self.tail_reason() == "":
-            # (fwd_bwd publishes write-through + ready words whenever the two launches MAY overlap; launched one after the
-            # other, as here, the tail's waits are satisfied at once)
-            args.tail_ctl = self._tail_ctl_ptr(args, count=False) if self.tail_overlap_reason() == "" else None
+            args.tail_ctl = None
+            if self.tail_overlap_reason() == "":
+                # the whole mini-batch in ONE launch (csrc/ppo_update_tail.hip: ppo_update_step_kernel)
+                ctl = args.tail_ctl = self._tail_ctl_ptr(args)
+                if single:
+                    rc = lib.ppoaf_ppo_update_step(ref, ctl, self.tail_wait_seconds, st)
+                else:
+                    rc = lib.ppoaf_ppo_update_step_exchange(ref, ctl, self.tail_wait_seconds, self.xchg_sp.handle,
+                                                            self.xchg_sp.wait_seconds, st)
+                self._tail_used = True
+                FusedPolicyUpdate.step_launches += 1
+                if rc != 0:
+                    _lib.check(rc, "ppo_update_step")
+                return
         rc = lib.ppoaf_ppo_update_fwd_bwd(ref, st)
         if rc == 0 and args.split_workspace:
             # split-wgrad chain: complete weight gradients from the published panels, then clip + Adam
@@ -596,8 +608,6 @@ class FusedPolicyUpdate:
 
     def _chunk(self, args, n):
         """n consecutive mini-batches with their index baked in: one cursor update for the whole chain."""
-        if type(self) is FusedPolicyUpdate and args.split_workspace and self.tail_overlap_reason() == "":
-            return self._chunk_overlapped(args, n)
         try:
             for j in range(n):
                 args.mb_offset = j
@@ -606,45 +616,7 @@ class FusedPolicyUpdate:
         finally:
             args.mb_offset, args.cursor_advance = 0, 1
 
-    tail_overlap_chunks = 0            # chunks issued on two streams in this process (tests: the path really ran)
-
-    def _chunk_overlapped(self, args, n):
-        """
-        The same chain with fwd_bwd(j) on the current stream and the fused tail launch(j) on a side stream, both ordered
-        behind tail(j - 1) only: inside a captured hipGraph two branches that meet again after every mini-batch.  tail(j)
-        starts with fwd_bwd(j), requests the optimiser state of its elements, and its jobs wait for the ready words fwd_bwd
-        sets layer by layer (csrc/ppo_update_tail.hip: tail_wait_ready).  fwd_bwd is issued FIRST, so that a device that
-        runs the two branches one after the other runs them in the order that completes.
-        """
-        lib, ref = self._lib, C.byref(args)
-        main = torch.cuda.current_stream()
-        side = getattr(self, "_tail_stream", None)
-        if side is None:
-            side = self._tail_stream = torch.cuda.Stream(device=self.pol.device)
-        ctl = self._tail_ctl_ptr(args, count=False)
-        args.tail_ctl = ctl
-        single = not self.multi
-        side.wait_stream(main)
-        try:
-            for j in range(n):
-                args.mb_offset = j
-                args.cursor_advance = n if j == n - 1 else 0
-                main.wait_stream(side)                                   # fwd_bwd(j) reads what tail(j - 1) wrote
-                rc = lib.ppoaf_ppo_update_fwd_bwd(ref, main.cuda_stream)
-                if rc == 0:
-                    if single:
-                        rc = lib.ppoaf_ppo_update_wgrad_adam(ref, ctl, self.tail_wait_seconds, side.cuda_stream)
-                    else:
-                        rc = lib.ppoaf_ppo_update_wgrad_adam_exchange(ref, ctl, self.tail_wait_seconds, self.xchg_sp.handle,
-                                                                     self.xchg_sp.wait_seconds, side.cuda_stream)
-                    FusedPolicyUpdate.tail_launches += 1
-                if rc != 0:
-                    _lib.check(rc, "ppo_update (overlapped chain)")
-            self._tail_used = True
-            FusedPolicyUpdate.tail_overlap_chunks += 1
-        finally:
-            main.wait_stream(side)
-            args.mb_offset, args.cursor_advance = 0, 1
+    step_launches = 0                  # one-launch mini-batches issued in this process (tests: the path really ran)
 
     def _persistent_failure(self):
         """After a host synchronisation: '' or why the last persistent launch did not complete (its control block)."""
@@ -662,7 +634,7 @@ class FusedPolicyUpdate:
             if int(ctl[2].item()) != 0:                   # TailCtl.error
                 ctl[2:3].zero_()
                 if self.tail_overlap_reason() == "":      # first suspect: the two launches did not run side by side
-                    self._overlap_disabled = "a wait ran out of time with fwd_bwd and the tail launch on two streams"
+                    self._overlap_disabled = "a wait ran out of time inside the one-launch mini-batch"
                 else:
                     self._tail_disabled = "a wait for the other workgroups' norm records ran out of time"
                 self._graphs.clear()                      # the captured chains end in the fused launch

@@ -283,8 +283,8 @@ def test_full_size_fused_tail_is_bitwise_the_three_launch_chain(name, monkeypatc
     shapes, a whole epoch each on the same rollout and shuffle (C2: 2048 mini-batches, 153 workgroups per launch; C3 / C4:
     256-wide critic, 369 workgroups): the same jobs, folds and summation orders, so parameters, both Adam moments, the
     gradient bucket of the last mini-batch, step counters, normaliser state and totals are BITWISE equal -- the two launches
-    one after the other (PPOAF_FUSED_TAIL=1) or side by side on two streams with fwd_bwd handing its panels over layer by
-    layer through ready words (=2, the default; C2), graph replay and eager launches alike -- and no wait ran out of its budget.
+    as two launches (PPOAF_FUSED_TAIL=1) or as ONE (=2, the default; C2: fwd_bwd's row tiles hand their panels to the tail's
+    workgroups of the same grid layer by layer through ready words), graph replay and eager launches alike -- and no wait ran out of its budget.
     """
     from ppo_and_friends_amd import fused_update
     monkeypatch.setenv("PPOAF_WS", "0")                     # (256-wide critics: the chain, not the persistent kernel)
@@ -292,7 +292,7 @@ def test_full_size_fused_tail_is_bitwise_the_three_launch_chain(name, monkeypatc
     outs = {}
     for tail, graphs in (("0", True), ("1", True), ("2", True), ("2", False)):
         monkeypatch.setenv("PPOAF_FUSED_TAIL", tail)
-        before, before_ov = fused_update.FusedPolicyUpdate.tail_launches, fused_update.FusedPolicyUpdate.tail_overlap_chunks
+        before, before_ov = fused_update.FusedPolicyUpdate.tail_launches, fused_update.FusedPolicyUpdate.step_launches
         ppo, E, T, A = _c_config(name, use_graphs=graphs)
         ppo.rollout()
         pol = ppo.policies["p"]
@@ -306,9 +306,9 @@ def test_full_size_fused_tail_is_bitwise_the_three_launch_chain(name, monkeypatc
         n_mb = E * T * A // 256
         assert t[8] == n_mb and int(pol.policy_step_counts[0].item()) == int(pol.policy_step_counts[1].item()) == n_mb
         assert (fused_update.FusedPolicyUpdate.tail_launches > before) == (tail != "0")
-        # fwd_bwd and the tail launch side by side on two streams: where both fit on the device (C2), inside captured chains
-        overlapped = fused_update.FusedPolicyUpdate.tail_overlap_chunks > before_ov
-        assert overlapped == (tail == "2" and graphs and name == "C2"), (overlapped, fused.tail_overlap_reason())
+        # the whole mini-batch as ONE launch: where every workgroup gets a CU of its own and no network is 256 wide (C2)
+        overlapped = fused_update.FusedPolicyUpdate.step_launches > before_ov
+        assert overlapped == (tail == "2" and name == "C2"), (overlapped, fused.tail_overlap_reason())
         assert fused.tail_reason() == ("" if tail != "0" else "off (PPOAF_FUSED_TAIL=0)")      # no launch failed
         if tail != "0":
             assert int(fused._tail_ctl[2].item()) == 0 and int(fused._tail_ctl[0].item()) == n_mb      # error word, launches completed
