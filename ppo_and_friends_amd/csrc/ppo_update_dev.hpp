@@ -155,7 +155,7 @@ __device__ __forceinline__ unsigned hw_xcc_id() {
 // d / d log_std parked in sOut[.][8..]), the block's loss partials -> u.loss_partials, critic values written back.
 //   sRow16[16] dataset row of each block row (-1: dead), sRowF[3][16] adv / old log-prob / rewards-to-go,
 //   sMisc[4] adv mean / std, value-normaliser mean / var, sActF[16][8] raw actions, log_std_p the actor's log_std.
-template <bool NT, typename U>
+template <bool NT, typename U, bool SIG = false>
 __device__ __forceinline__ void ppo_head_loss(const U& u, const int which, const int g, const int out_dim,
                                               const float* __restrict__ log_std_p, const int* sRow,
                                               const float* sRowF, const float* sMisc, float* sActF, float* sOut,
@@ -319,7 +319,7 @@ __device__ __forceinline__ void ppo_head_loss(const U& u, const int which, const
     if (lane == 0) {
         if (which == 0 && g == 0) { part[5] = sMisc[0]; part[6] = sMisc[1]; }
         float* lp = u.loss_partials + ((long)which * u.n_wg + g) * 8;
-        if (u.sig) {                                     // read by a concurrent launch's bookkeeping workgroup
+        if (SIG) {                                       // read by the bookkeeping workgroup of the same launch
 #pragma unroll
             for (int k = 0; k < 8; ++k) st1_sc1(lp + k, part[k]);
         } else {

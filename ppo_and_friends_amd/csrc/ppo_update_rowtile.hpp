@@ -41,7 +41,10 @@ static __device__ unsigned long long g_ppo_update_stamps[2][16];
 // against a 135 KB slab) -- and the output layer's partials go to u.sp.outpart (folded in block order by that launch).
 struct RowtileNoHook { __device__ __forceinline__ bool operator()() const { return true; } };
 
-template <int HT, bool NT = false, typename U = UpdateDev, typename Hook = RowtileNoHook, bool SPLIT = false>
+// SIG = true (the one-launch mini-batch, ppo_update_tail.hip: ppo_update_step_kernel): what SPLIT publishes is handed to
+// workgroups of the SAME launch -- write-through (sc1) stores and one ready word per (network, layer, workgroup) in
+// u.sig, set once a layer's dLoss/dz rows are out.  A compile-time flavour: the plain body's code is untouched.
+template <int HT, bool NT = false, typename U = UpdateDev, typename Hook = RowtileNoHook, bool SPLIT = false, bool SIG = false>
 __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int which, const int g,
                                                         const long mb_extra = 0, Hook before_weights = Hook()) {
     constexpr int H = 16 * HT, HS = H + 4;                 // which: 0 actor, 1 critic; g: 16-row block
@@ -72,7 +75,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
                         : u.slabs + (long)g * u.bucket_total + nd.offset;
     // 16 rows x H floats of LDS (row stride HS) -> rows [16 g, +16) of a [Bp][H] panel: one float4 per thread at H = 128
     // (u.sig: a concurrent tail launch reads the panels -- 16-byte write-through stores; see the ready words below)
-    const bool sig = SPLIT && u.sig != nullptr;
+    constexpr bool sig = SPLIT && SIG;
     auto publish_rows = [&](const float* src, float* panel) {
         float* dst = panel + (long)g * kRows * H;
         if (sig) {
@@ -363,7 +366,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
 
     // ---- distribution head + loss terms for this workgroup's rows (K6 + K3)
     if (wave == 0) {
-        ppo_head_loss<NT>(u, which, g, out_dim, P + nd.log_std_off, sRow, sRowF, sMisc, sActF, sOut, sDOut, lane, B);
+        ppo_head_loss<NT, U, sig>(u, which, g, out_dim, P + nd.log_std_off, sRow, sRowF, sMisc, sActF, sOut, sDOut, lane, B);
     }
     __syncthreads();
     PPOAF_STAMP(6);

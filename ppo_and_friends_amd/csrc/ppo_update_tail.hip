@@ -646,8 +646,8 @@ __global__ __launch_bounds__(kThreadsU) void ppo_update_step_kernel(UpdateDev u,
         const int which = (b >> 2) & 1;
         const int g = ((b >> 3) << 2) | (b & 3);
         if (g >= u.n_wg) return;
-        if (which == 0) ppo_update_fwd_bwd_body<HTA, false, UpdateDev, RowtileNoHook, true>(u, 0, g);
-        else ppo_update_fwd_bwd_body<HTC, false, UpdateDev, RowtileNoHook, true>(u, 1, g);
+        if (which == 0) ppo_update_fwd_bwd_body<HTA, false, UpdateDev, RowtileNoHook, true, true>(u, 0, g);
+        else ppo_update_fwd_bwd_body<HTC, false, UpdateDev, RowtileNoHook, true, true>(u, 1, g);
         return;
     }
     if (threadIdx.x >= kWgradThreads) return;                 // a tail workgroup is four waves (before any barrier)
