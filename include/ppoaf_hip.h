@@ -395,12 +395,10 @@ typedef struct {
      * runs on a second stream, each keeps its weights and panels in its own four L2s -- C3: +2 % env-steps/s; alone the
      * confinement costs 1 % (C2).  Placement only changes speed. */
     int32_t xcd_half, _pad2;
-    /* NULL, or the control block of the fused tail launch that FOLLOWS this mini-batch's fwd_bwd (ppoaf_ppo_update_wgrad_adam*,
-     * same block): fwd_bwd then publishes its panels, output-layer partials and loss partials with write-through (sc1) stores
-     * and sets one ready word per (network, layer, workgroup) in the block as soon as a layer's dLoss/dz rows are out, so
-     * that the tail launch may run CONCURRENTLY on a second stream -- its jobs wait for the ready words of their layer
-     * instead of for the kernel boundary, and the weight gradients of the upper layers are formed while the backward pass
-     * is still running.  Launched one after the other on one stream the pair behaves as without the field. */
+    /* ppoaf_ppo_update_step* only (else NULL): the control block passed to that call -- the row-tile workgroups of the
+     * one-launch mini-batch publish their panels, output-layer partials and loss partials with write-through (sc1) stores
+     * and set one ready word per (network, layer, workgroup) in this block as soon as a layer's dLoss/dz rows are out; the
+     * tail workgroups of the same launch wait for the words of their layer. */
     void* tail_ctl;
 } ppoaf_ppo_update_args_t;
 

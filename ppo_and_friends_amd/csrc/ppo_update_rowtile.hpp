@@ -78,28 +78,24 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     constexpr bool sig = SPLIT && SIG;
     auto publish_rows = [&](const float* src, float* panel) {
         float* dst = panel + (long)g * kRows * H;
-        if (sig) {
+        if constexpr (sig) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0xFFFFFFFF, 0x00020000);
             for (int i = tid; i < kRows * (H / 4); i += kThreadsU) {
                 const int r = i / (H / 4), c4 = i - r * (H / 4);
                 const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * HS + 4 * c4);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ppoaf_u32x4, v), rs, (unsigned)(4 * (r * H + 4 * c4)), 0, 16 /* sc1 */);
             }
-            return;
-        }
-        for (int i = tid; i < kRows * (H / 4); i += kThreadsU) {
-            const int r = i / (H / 4), c4 = i - r * (H / 4);
-            *reinterpret_cast<float4*>(dst + (long)r * H + 4 * c4) = *reinterpret_cast<const float4*>(src + r * HS + 4 * c4);
+        } else {
+            for (int i = tid; i < kRows * (H / 4); i += kThreadsU) {
+                const int r = i / (H / 4), c4 = i - r * (H / 4);
+                *reinterpret_cast<float4*>(dst + (long)r * H + 4 * c4) = *reinterpret_cast<const float4*>(src + r * HS + 4 * c4);
+            }
         }
     };
     // ready word of (this network, layer l, this workgroup): dz_l and everything published before it is out.  Every
     // storing wave has waited for its stores (vmcnt(0)) ahead of the workgroup barrier the caller places before this.
-    const unsigned sig_tag = sig ? tail_tag_of(__hip_atomic_load(u.sig_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
-    auto signal_layer = [&](int l) {
-        if (sig && tid == 0)
-            __hip_atomic_store(u.sig + tail_flag_index(which, l, g), sig_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto put1 = [&](float* p_, float v) { if (sig) st1_sc1(p_, v); else *p_ = v; };
+    [[maybe_unused]] unsigned sig_tag = 0u;
+    if constexpr (sig) sig_tag = tail_tag_of(__hip_atomic_load(u.sig_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     const long sp_plane = SPLIT ? (long)u.sp.Bp * H : 0;
 
     PPOAF_STAMP(0);
@@ -288,7 +284,8 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
         float* xb = u.sp.xbuf[which] + (long)g * kRows * 64;
         for (int i = tid; i < kRows * 64; i += kThreadsU) {
             const int r = i >> 6, c = i & 63;
-            put1(xb + i, c < 16 * NT0 ? sX[r * INP + c] : 0.f);
+            if constexpr (sig) st1_sc1(xb + i, c < 16 * NT0 ? sX[r * INP + c] : 0.f);
+            else xb[i] = c < 16 * NT0 ? sX[r * INP + c] : 0.f;
         }
     }
 
@@ -386,7 +383,8 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
                 float acc = 0.f;
 #pragma unroll
                 for (int s = 0; s < kRows; ++s) acc = fmaf(d[s], h[s], acc);
-                put1(slab + offW(depth) + (long)k * H + i, acc);
+                if constexpr (sig) st1_sc1(slab + offW(depth) + (long)k * H + i, acc);
+                else slab[offW(depth) + (long)k * H + i] = acc;
             }
         }
         // (SPLIT: the padding slots of the segment are written too, as zeros -- the partials row lives in a workspace whose
@@ -399,7 +397,8 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
 #pragma unroll
                 for (int s = 0; s < kRows; ++s) acc += sDOut[s * kMaxOut + k];
             }
-            put1(slab + offB(depth) + k, acc);
+            if constexpr (sig) st1_sc1(slab + offB(depth) + k, acc);
+            else slab[offB(depth) + k] = acc;
         }
         if (which == 0 && u.head_kind == PPOAF_HEAD_GAUSSIAN && tid >= 320 && tid < 320 + out_pad) {
             const int d = tid - 320;
@@ -408,7 +407,8 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
 #pragma unroll
                 for (int s = 0; s < kRows; ++s) acc += sOut[s * kMaxOut + 8 + d];
             }
-            put1(slab + nd.log_std_off + d, acc);
+            if constexpr (sig) st1_sc1(slab + nd.log_std_off + d, acc);
+            else slab[nd.log_std_off + d] = acc;
         }
         // dz_last = (dOut . W_out) * act'(Hlast): waves 4..7 (the others store dW_out above)
         if (tid >= 256) {
@@ -473,9 +473,11 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
             }
         }
         if (l == depth - 1) PPOAF_STAMP(12);
-        if (sig) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's published rows have left the CU
+        if constexpr (sig) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's published rows have left the CU
         __syncthreads();
-        signal_layer(l);
+        if constexpr (sig) {
+            if (tid == 0) __hip_atomic_store(u.sig + tail_flag_index(which, l, g), sig_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (l == depth - 1) PPOAF_STAMP(13);
         float* t = Dc; Dc = Dn; Dn = t;
     }
@@ -484,10 +486,10 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     // ---- first layer backward: dW0[o][i] = sum_s dz0[s][o] * x[s][i] on MFMA against the padded sX
     if (SPLIT) {
         publish_rows(Dc, u.sp.dbuf[which]);                   // dz_0 (its K-panel is x, published after the gather)
-        if (sig) {
+        if constexpr (sig) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            signal_layer(0);
+            if (tid == 0) __hip_atomic_store(u.sig + tail_flag_index(which, 0, g), sig_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
         for (int mt = wave; mt < HT; mt += kNW)

@@ -89,8 +89,9 @@ __device__ __forceinline__ void tail_publish(const TailDev& td, const unsigned t
 // ready words of (network, layer) for the n_wg row-tile workgroups until each carries this mini-batch's tag, the barrier
 // holds the others.  The panels, partials and loss scalars behind the words were written through (sc1) and are read with
 // sc1 loads.  A wait that runs out of its budget sets the error word (the launch drains; the host redoes the epoch).
+template <bool HANDOFF>
 __device__ __forceinline__ void tail_wait_ready(const TailDev& td, const unsigned tag, const int which, const int l, const int n_wg) {
-    if (!td.handoff) return;                                  // uniform
+    if (!HANDOFF) return;
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         long long budget = td.budget;
@@ -325,7 +326,7 @@ __device__ __forceinline__ void tail_adam1(const UpdateDev& u, const long idx, c
 // The 16 x 32 output tile is formed by wave 0 (C layout) and handed to ALL 256 threads through LDS for the optimiser
 // step: thread t owns tile elements t and t + 256 (row e / 32, column e % 32: whole 128-byte lines of p / m / v), whose
 // state it requested at the start of the job, beside the MFMA operands.
-template <int H, bool XCHG>
+template <int H, bool XCHG, bool HANDOFF>
 __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, const unsigned tag, const int b, const int which,
                                          const int job, float* sFold /* [3][2][256] + [4][16] */, float* sTile /* [16][32] + [16] */,
                                          double* s_red, float* s_coef, const TailXchg* xc) {
@@ -374,8 +375,8 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
         const bool has_b = itile == 0 && tid >= 64 && tid < 80;
         const long bidx = nb + offB(l) + ot * 16 + (tid - 64);
         sb = tail_pmv_load(u, bidx, has_b);
-        tail_wait_ready(td, tag, which, l, u.n_wg);           // (concurrent fwd_bwd: dz_l and its K-panel are out)
-        const int aux = td.handoff ? 16 /* sc1 */ : 0;
+        tail_wait_ready<HANDOFF>(td, tag, which, l, u.n_wg);  // (row tiles of the same launch: dz_l and its K-panel are out)
+        constexpr int aux = HANDOFF ? 16 /* sc1 */ : 0;
         const long ldx = l >= 1 ? H : 64;
         const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(u.sp.dbuf[which] + (long)l * plane, 0, 0xFFFFFFFF, 0x00020000);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -393,15 +394,9 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned sd = 4u * (unsigned)((16 * ch + 4 * j) * H), sx = 4u * (unsigned)((16 * ch + 4 * j) * (int)ldx);
-                    if (aux) {                                // uniform (the cache policy is an immediate of the instruction)
-                        a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, sd, 16));
-                        x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl, sx, 16));
-                        if (two) x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl + 64u, sx, 16));
-                    } else {
-                        a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, sd, 0));
-                        x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl, sx, 0));
-                        if (two) x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl + 64u, sx, 0));
-                    }
+                    a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, sd, aux));
+                    x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl, sx, aux));
+                    if (two) x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl + 64u, sx, aux));
                 }
             }
         }
@@ -508,7 +503,7 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
             se[k] = tail_pmv_load(u, nb + seg_off + idx, idx < seg_len);
             ge[k] = 0.f;
         }
-        tail_wait_ready(td, tag, which, depth - 1, u.n_wg);   // (the partials precede dz of the last hidden layer)
+        tail_wait_ready<HANDOFF>(td, tag, which, depth - 1, u.n_wg);   // (the partials precede dz of the last hidden layer)
 #pragma unroll
         for (int k = 0; k < kTailMaxE; ++k) {
             const long idx = tid + (long)kWgradThreads * k;
@@ -519,7 +514,7 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
                         const float* src = outpart + (long)(g0 + kk < n_hb ? g0 + kk : 0) * seg_len + idx;
-                        pv[kk] = td.handoff ? ld1<true>(src) : *src;
+                        pv[kk] = ld1<HANDOFF>(src);
                     }
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) if (g0 + kk < n_hb) acc += pv[kk];
@@ -567,20 +562,17 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
 }
 
 // One workgroup (256 threads) of the tail: block b of 8 * per_xcd + 1 (the last one keeps the books).
-template <int HA, int HC, bool XCHG>
+template <int HA, int HC, bool XCHG, bool HANDOFF>
 __device__ __forceinline__ void tail_block(const UpdateDev& u, const TailDev& td, TailXchg& xc, const int b, double* s_red, float* s_fold,
                                            float* s_tile, float* s_coef) {
     const unsigned long long seq = __hip_atomic_load(&td.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned tag = tail_tag_of(seq);                                // never 0: a zero-initialised record is never current
     if (b == td.nblk) {
         // bookkeeping: the totals need nobody; what other workgroups read at their start moves only after all have published
-        if (td.handoff) {                                     // the loss partials of both networks' row tiles are out
-            tail_wait_ready(td, tag, 0, u.net[0].depth - 1, u.n_wg);
-            tail_wait_ready(td, tag, 1, u.net[1].depth - 1, u.n_wg);
-        }
+        tail_wait_ready<HANDOFF>(td, tag, 0, u.net[0].depth - 1, u.n_wg);   // the loss partials of both networks' row tiles are out
+        tail_wait_ready<HANDOFF>(td, tag, 1, u.net[1].depth - 1, u.n_wg);
         if (threadIdx.x >= 64) return;
-        if (td.handoff) ppo_update_bookkeeping_totals<true>(u);
-        else ppo_update_bookkeeping_totals<false>(u);
+        ppo_update_bookkeeping_totals<HANDOFF>(u);
         // while the others work: the bias corrections of the step being taken (norm_scratch, as ppo_update_bookkeeping_steps
         // leaves them) and of the NEXT step (control block: the next launch's workgroups need not compute them)
         const int w = threadIdx.x & 1;
@@ -611,8 +603,8 @@ __device__ __forceinline__ void tail_block(const UpdateDev& u, const TailDev& td
     const int job = (b & 7) * td.per_xcd + (b >> 3);          // XCD b % 8 works on one run of the layer-major job list
     const bool live = job < td.jobs_a + td.jobs_c;            // the same on every rank
     if (XCHG && live) xc.seq = xchg_sequence(xc.x, (unsigned)b);
-    if (job < td.jobs_a) tail_job<HA, XCHG>(u, td, tag, b, 0, job, s_fold, s_tile, s_red, s_coef, &xc);
-    else if (live) tail_job<HC, XCHG>(u, td, tag, b, 1, job - td.jobs_a, s_fold, s_tile, s_red, s_coef, &xc);
+    if (job < td.jobs_a) tail_job<HA, XCHG, HANDOFF>(u, td, tag, b, 0, job, s_fold, s_tile, s_red, s_coef, &xc);
+    else if (live) tail_job<HC, XCHG, HANDOFF>(u, td, tag, b, 1, job - td.jobs_a, s_fold, s_tile, s_red, s_coef, &xc);
     else if (threadIdx.x == 0) tail_publish(td, tag, b, 0.0);
     if (XCHG && live) xchg_advance(xc.x, xc.seq, (unsigned)b);
 }
@@ -623,7 +615,7 @@ __global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(Up
     __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
     __shared__ float s_tile[16 * 32 + 16];
     __shared__ float s_coef[4];
-    tail_block<HA, HC, XCHG>(u, td, xc, (int)blockIdx.x, s_red, s_fold, s_tile, s_coef);
+    tail_block<HA, HC, XCHG, false>(u, td, xc, (int)blockIdx.x, s_red, s_fold, s_tile, s_coef);
 }
 
 // ---- ONE launch per mini-batch: fwd_bwd's row-tile workgroups (blocks 0 .. n_fwd - 1, dispatched first) and the tail's
@@ -651,7 +643,7 @@ __global__ __launch_bounds__(kThreadsU) void ppo_update_step_kernel(UpdateDev u,
         return;
     }
     if (threadIdx.x >= kWgradThreads) return;                 // a tail workgroup is four waves (before any barrier)
-    tail_block<16 * HTA, 16 * HTC, XCHG>(u, td, xc, b - n_fwd, s_red, s_fold, s_tile, s_coef);
+    tail_block<16 * HTA, 16 * HTC, XCHG, true>(u, td, xc, b - n_fwd, s_red, s_fold, s_tile, s_coef);
 }
 
 template <int HA, int HC, bool XCHG>
@@ -750,7 +742,7 @@ static int tail_prepare(const ppoaf_ppo_update_args_t* args, void* ctl, double w
     td.jobs_c = split_wgrad_jobs(u.net[1]);
     td.per_xcd = split_wgrad_per_xcd(u);
     td.nblk = split_wgrad_blocks(u);
-    td.handoff = u.sig != nullptr;
+    td.handoff = u.sig != nullptr;          // (only the one-launch mini-batch hands over inside the launch: ppoaf_ppo_update_step)
     PPOAF_REQUIRE(!td.handoff || args->tail_ctl == ctl, "ppo_update_wgrad_adam: args->tail_ctl names another control block");
     PPOAF_REQUIRE(td.nblk <= 64 * kTailMaxRounds, "ppo_update_wgrad_adam: %d workgroups, a polling wave holds %d records", td.nblk,
                   64 * kTailMaxRounds);
