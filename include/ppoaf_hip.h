@@ -395,11 +395,6 @@ typedef struct {
      * runs on a second stream, each keeps its weights and panels in its own four L2s -- C3: +2 % env-steps/s; alone the
      * confinement costs 1 % (C2).  Placement only changes speed. */
     int32_t xcd_half, _pad2;
-    /* ppoaf_ppo_update_step* only (else NULL): the control block passed to that call -- the row-tile workgroups of the
-     * one-launch mini-batch publish their panels, output-layer partials and loss partials with write-through (sc1) stores
-     * and set one ready word per (network, layer, workgroup) in this block as soon as a layer's dLoss/dz rows are out; the
-     * tail workgroups of the same launch wait for the words of their layer. */
-    void* tail_ctl;
 } ppoaf_ppo_update_args_t;
 
 int ppoaf_ppo_update_fwd_bwd(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t stream);
@@ -805,20 +800,6 @@ int ppoaf_ppo_update_reduce_exchange(const ppoaf_ppo_update_args_t* args, ppoaf_
                                      double wait_seconds, ppoaf_stream_t stream);
 int ppoaf_ppo_update_adam_exchanged(const ppoaf_ppo_update_args_t* args, ppoaf_peer_exchange_t* x,
                                     ppoaf_stream_t stream);
-/* ONE launch per mini-batch (ABI 5; csrc/ppo_update_tail.hip: ppo_update_step_kernel): fwd_bwd's row-tile workgroups and
- * the fused tail's workgroups in one grid.  The tail workgroups start with the launch (launch tag, step counters, the
- * optimiser state of their elements) and wait for the ready words the row tiles set layer by layer (args->tail_ctl == ctl,
- * required), so the weight gradients of the upper layers are formed while the backward pass still runs; between the last
- * dLoss/dz rows and the optimiser step lie one hand-off, the layer-0 jobs and the norm records -- the whole body of one
- * `_ppo_batch_train` iteration (ppo.py:2292-2469) without a kernel boundary.  Results are bitwise those of
- * ppoaf_ppo_update_fwd_bwd + ppoaf_ppo_update_wgrad_adam.  Networks up to 128 wide; every workgroup needs a CU of its own
- * (8 * ceil(B / 64) + ppoaf_ppo_update_split_blocks + 1 workgroups, checked against the device).  _exchange: N > 1 ranks,
- * as ppoaf_ppo_update_wgrad_adam_exchange. */
-int ppoaf_ppo_update_step(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds, ppoaf_stream_t stream);
-int ppoaf_ppo_update_step_timed(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
-                                void* start_event, void* stop_event, ppoaf_stream_t stream);
-int ppoaf_ppo_update_step_exchange(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
-                                   ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds, ppoaf_stream_t stream);
 /* The fused tail launch on N > 1 ranks of one node (ABI 5): ppoaf_ppo_update_wgrad_adam with the K17 exchange as a phase
  * of every weight-gradient job (mpi_avg_gradients, utils/mpi_utils.py:89-111, at its call sites ppo_policy.py:1035,1048):
  * workgroup b of every rank forms the same 16 x 32 piece, writes its sums into this rank's slot (16-byte system-scope

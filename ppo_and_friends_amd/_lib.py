@@ -58,7 +58,7 @@ class PpoUpdateArgs(C.Structure):
                 ("loss_partials", C.c_void_p), ("totals", C.c_void_p),
                 ("mb_offset", C.c_int64), ("cursor_advance", C.c_int64),
                 ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64),
-                ("xcd_half", C.c_int32), ("_pad2", C.c_int32), ("tail_ctl", C.c_void_p)]
+                ("xcd_half", C.c_int32), ("_pad2", C.c_int32)]
 
 
 ABI_VERSION = 5
@@ -245,9 +245,6 @@ SIGNATURES = {
     "ppoaf_comm_destroy": (C.c_int, [_ptr]),
     "ppoaf_ppo_update_reduce_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr]),
     "ppoaf_ppo_update_wgrad_adam_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr, C.c_double, _ptr]),
-    "ppoaf_ppo_update_step": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr]),
-    "ppoaf_ppo_update_step_timed": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr, _ptr, _ptr]),
-    "ppoaf_ppo_update_step_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, C.c_double, _ptr, C.c_double, _ptr]),
     "ppoaf_ppo_update_tail_exchange_floats": (C.c_int, [C.POINTER(PpoUpdateArgs), C.POINTER(C.c_int64)]),
     "ppoaf_ppo_update_adam_exchanged": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, _ptr]),
     "ppoaf_env_filter_moments": (C.c_int, [C.POINTER(ObsFilter), C.POINTER(ObsFilter), C.POINTER(RewardFilter),

@@ -335,16 +335,6 @@ int make_update_dev(const ppoaf_ppo_update_args_t* a, UpdateDev& u) {
                       (long)a->split_workspace_bytes, need);
         u.split = 1;
     }
-    u.sig = nullptr;
-    u.sig_seq = nullptr;
-    if (a->tail_ctl) {
-        PPOAF_REQUIRE(u.split, "ppo_update: tail_ctl is for the split-wgrad chain (split_workspace not set)");
-        PPOAF_REQUIRE((((uintptr_t)a->tail_ctl) & 63) == 0, "ppo_update: tail_ctl must be 64-byte aligned");
-        PPOAF_REQUIRE(u.n_wg <= kTailFlagWgs && u.net[0].depth <= kTailFlagLayers && u.net[1].depth <= kTailFlagLayers,
-                      "ppo_update: tail_ctl holds ready words for %d workgroups x %d layers per network", kTailFlagWgs, kTailFlagLayers);
-        u.sig = reinterpret_cast<unsigned*>(static_cast<char*>(a->tail_ctl) + kTailFlagOff);
-        u.sig_seq = reinterpret_cast<const unsigned long long*>(a->tail_ctl);
-    }
     return PPOAF_OK;
 }
 

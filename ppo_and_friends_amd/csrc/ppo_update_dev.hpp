@@ -38,22 +38,7 @@ struct UpdateDev {
     int confine;         // args->xcd_half: 0 every XCD; 1 / 2: fwd_bwd's workgroups on XCDs 0-3 / 4-7 only (actor on two of them, critic on two)
     int split;           // 1: split-wgrad chain -- fwd_bwd publishes activation / dz panels (sp) instead of weight-gradient slabs
     WsDev sp;
-    // args->tail_ctl: fwd_bwd hands its panels to a CONCURRENTLY running fused tail launch (csrc/ppo_update_tail.hip) --
-    // write-through stores, one ready word per (network, layer, workgroup); null: plain stores, the kernel boundary hands over
-    unsigned* sig;                         // ready words [2][kTailFlagLayers][kTailFlagWgs] inside the tail's control block
-    const unsigned long long* sig_seq;     // the block's launch counter: this mini-batch's tag = (seq mod 2^31) + 1
 };
-
-// layout of the fused tail launch's control block (TailCtl, ppo_update_tail.hip): header, ready words, norm records
-constexpr int kTailFlagLayers = 8, kTailFlagWgs = 32;
-constexpr int kTailFlagOff = 256;                                              // bytes
-constexpr int kTailRecOff = kTailFlagOff + 2 * kTailFlagLayers * kTailFlagWgs * 4;
-__device__ __forceinline__ unsigned tail_tag_of(unsigned long long seq) { return ((unsigned)seq & 0x7fffffffu) + 1u; }   // never 0
-__device__ __forceinline__ int tail_flag_index(int which, int l, int g) { return (which * kTailFlagLayers + l) * kTailFlagWgs + g; }
-// stores another XCD's workgroups read inside the same (or a concurrent) launch: written through (sc1), agent scope
-__device__ __forceinline__ void st1_sc1(float* p, float v) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // offset of the output layer's segment (W_out, b_out, log_std) inside a network's bucket, and its length
 inline long ws_seg_off(const NetDev& n) {
@@ -98,15 +83,13 @@ inline size_t ws_layout(const UpdateDev& u, WsDev* ws, char* base) {
 constexpr int kWgradThreads = 256;
 
 // per-mini-batch bookkeeping of the split-wgrad chain, by ONE wave (threads 0..63 of a workgroup): loss partials -> totals
-// (NT: the partials were written by workgroups of a concurrent launch -- agent-scope loads)
-template <bool NT = false>
 __device__ __forceinline__ void ppo_update_bookkeeping_totals(const UpdateDev& u) {
     const int lane = threadIdx.x;
     float p0 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p7 = 0.f;
     for (int g = lane; g < u.n_wg; g += 64) {
         const float* a = u.loss_partials + (long)g * 8;
         const float* cc = u.loss_partials + ((long)u.n_wg + g) * 8;
-        p0 += ld1<NT>(a + 0); p3 += ld1<NT>(a + 3); p4 += ld1<NT>(a + 4); p7 += ld1<NT>(a + 7); p2 += ld1<NT>(cc + 2);
+        p0 += a[0]; p3 += a[3]; p4 += a[4]; p7 += a[7]; p2 += cc[2];
     }
     p0 = wave_sum(p0); p2 = wave_sum(p2); p3 = wave_sum(p3); p4 = wave_sum(p4); p7 = wave_sum(p7);
     if (lane == 0) {
@@ -117,7 +100,7 @@ __device__ __forceinline__ void ppo_update_bookkeeping_totals(const UpdateDev& u
         if (u.kl_loss_weight > 0.0f) total += u.kl_loss_weight * kl;
         u.totals[0] += (double)surr; u.totals[1] += (double)total; u.totals[2] += (double)crit;
         u.totals[3] += (double)ent; u.totals[4] += (double)kl;
-        u.totals[5] += (double)ld1<NT>(u.loss_partials + 5); u.totals[6] += (double)ld1<NT>(u.loss_partials + 6);
+        u.totals[5] += (double)u.loss_partials[5]; u.totals[6] += (double)u.loss_partials[6];
         u.totals[7] += p7 > 0.f ? 1.0 : 0.0;
         u.totals[8] += 1.0;
     }
@@ -155,7 +138,7 @@ __device__ __forceinline__ unsigned hw_xcc_id() {
 // d / d log_std parked in sOut[.][8..]), the block's loss partials -> u.loss_partials, critic values written back.
 //   sRow16[16] dataset row of each block row (-1: dead), sRowF[3][16] adv / old log-prob / rewards-to-go,
 //   sMisc[4] adv mean / std, value-normaliser mean / var, sActF[16][8] raw actions, log_std_p the actor's log_std.
-template <bool NT, typename U, bool SIG = false>
+template <bool NT, typename U>
 __device__ __forceinline__ void ppo_head_loss(const U& u, const int which, const int g, const int out_dim,
                                               const float* __restrict__ log_std_p, const int* sRow,
                                               const float* sRowF, const float* sMisc, float* sActF, float* sOut,
@@ -319,13 +302,8 @@ __device__ __forceinline__ void ppo_head_loss(const U& u, const int which, const
     if (lane == 0) {
         if (which == 0 && g == 0) { part[5] = sMisc[0]; part[6] = sMisc[1]; }
         float* lp = u.loss_partials + ((long)which * u.n_wg + g) * 8;
-        if (SIG) {                                       // read by the bookkeeping workgroup of the same launch
 #pragma unroll
-            for (int k = 0; k < 8; ++k) st1_sc1(lp + k, part[k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) lp[k] = part[k];
-        }
+        for (int k = 0; k < 8; ++k) lp[k] = part[k];
     }
 }
 

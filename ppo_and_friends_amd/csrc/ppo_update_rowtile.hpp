@@ -41,10 +41,7 @@ static __device__ unsigned long long g_ppo_update_stamps[2][16];
 // against a 135 KB slab) -- and the output layer's partials go to u.sp.outpart (folded in block order by that launch).
 struct RowtileNoHook { __device__ __forceinline__ bool operator()() const { return true; } };
 
-// SIG = true (the one-launch mini-batch, ppo_update_tail.hip: ppo_update_step_kernel): what SPLIT publishes is handed to
-// workgroups of the SAME launch -- write-through (sc1) stores and one ready word per (network, layer, workgroup) in
-// u.sig, set once a layer's dLoss/dz rows are out.  A compile-time flavour: the plain body's code is untouched.
-template <int HT, bool NT = false, typename U = UpdateDev, typename Hook = RowtileNoHook, bool SPLIT = false, bool SIG = false>
+template <int HT, bool NT = false, typename U = UpdateDev, typename Hook = RowtileNoHook, bool SPLIT = false>
 __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int which, const int g,
                                                         const long mb_extra = 0, Hook before_weights = Hook()) {
     constexpr int H = 16 * HT, HS = H + 4;                 // which: 0 actor, 1 critic; g: 16-row block
@@ -74,28 +71,13 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     float* slab = SPLIT ? u.sp.outpart[which] + (long)g * (nd.size - offW(depth)) - offW(depth)
                         : u.slabs + (long)g * u.bucket_total + nd.offset;
     // 16 rows x H floats of LDS (row stride HS) -> rows [16 g, +16) of a [Bp][H] panel: one float4 per thread at H = 128
-    // (u.sig: a concurrent tail launch reads the panels -- 16-byte write-through stores; see the ready words below)
-    constexpr bool sig = SPLIT && SIG;
     auto publish_rows = [&](const float* src, float* panel) {
         float* dst = panel + (long)g * kRows * H;
-        if constexpr (sig) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0xFFFFFFFF, 0x00020000);
-            for (int i = tid; i < kRows * (H / 4); i += kThreadsU) {
-                const int r = i / (H / 4), c4 = i - r * (H / 4);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * HS + 4 * c4);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ppoaf_u32x4, v), rs, (unsigned)(4 * (r * H + 4 * c4)), 0, 16 /* sc1 */);
-            }
-        } else {
-            for (int i = tid; i < kRows * (H / 4); i += kThreadsU) {
-                const int r = i / (H / 4), c4 = i - r * (H / 4);
-                *reinterpret_cast<float4*>(dst + (long)r * H + 4 * c4) = *reinterpret_cast<const float4*>(src + r * HS + 4 * c4);
-            }
+        for (int i = tid; i < kRows * (H / 4); i += kThreadsU) {
+            const int r = i / (H / 4), c4 = i - r * (H / 4);
+            *reinterpret_cast<float4*>(dst + (long)r * H + 4 * c4) = *reinterpret_cast<const float4*>(src + r * HS + 4 * c4);
         }
     };
-    // ready word of (this network, layer l, this workgroup): dz_l and everything published before it is out.  Every
-    // storing wave has waited for its stores (vmcnt(0)) ahead of the workgroup barrier the caller places before this.
-    [[maybe_unused]] unsigned sig_tag = 0u;
-    if constexpr (sig) sig_tag = tail_tag_of(__hip_atomic_load(u.sig_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     const long sp_plane = SPLIT ? (long)u.sp.Bp * H : 0;
 
     PPOAF_STAMP(0);
@@ -284,8 +266,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
         float* xb = u.sp.xbuf[which] + (long)g * kRows * 64;
         for (int i = tid; i < kRows * 64; i += kThreadsU) {
             const int r = i >> 6, c = i & 63;
-            if constexpr (sig) st1_sc1(xb + i, c < 16 * NT0 ? sX[r * INP + c] : 0.f);
-            else xb[i] = c < 16 * NT0 ? sX[r * INP + c] : 0.f;
+            xb[i] = c < 16 * NT0 ? sX[r * INP + c] : 0.f;
         }
     }
 
@@ -363,7 +344,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
 
     // ---- distribution head + loss terms for this workgroup's rows (K6 + K3)
     if (wave == 0) {
-        ppo_head_loss<NT, U, sig>(u, which, g, out_dim, P + nd.log_std_off, sRow, sRowF, sMisc, sActF, sOut, sDOut, lane, B);
+        ppo_head_loss<NT>(u, which, g, out_dim, P + nd.log_std_off, sRow, sRowF, sMisc, sActF, sOut, sDOut, lane, B);
     }
     __syncthreads();
     PPOAF_STAMP(6);
@@ -383,8 +364,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
                 float acc = 0.f;
 #pragma unroll
                 for (int s = 0; s < kRows; ++s) acc = fmaf(d[s], h[s], acc);
-                if constexpr (sig) st1_sc1(slab + offW(depth) + (long)k * H + i, acc);
-                else slab[offW(depth) + (long)k * H + i] = acc;
+                slab[offW(depth) + (long)k * H + i] = acc;
             }
         }
         // (SPLIT: the padding slots of the segment are written too, as zeros -- the partials row lives in a workspace whose
@@ -397,8 +377,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
 #pragma unroll
                 for (int s = 0; s < kRows; ++s) acc += sDOut[s * kMaxOut + k];
             }
-            if constexpr (sig) st1_sc1(slab + offB(depth) + k, acc);
-            else slab[offB(depth) + k] = acc;
+            slab[offB(depth) + k] = acc;
         }
         if (which == 0 && u.head_kind == PPOAF_HEAD_GAUSSIAN && tid >= 320 && tid < 320 + out_pad) {
             const int d = tid - 320;
@@ -407,8 +386,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
 #pragma unroll
                 for (int s = 0; s < kRows; ++s) acc += sOut[s * kMaxOut + 8 + d];
             }
-            if constexpr (sig) st1_sc1(slab + nd.log_std_off + d, acc);
-            else slab[nd.log_std_off + d] = acc;
+            slab[nd.log_std_off + d] = acc;
         }
         // dz_last = (dOut . W_out) * act'(Hlast): waves 4..7 (the others store dW_out above)
         if (tid >= 256) {
@@ -473,11 +451,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
             }
         }
         if (l == depth - 1) PPOAF_STAMP(12);
-        if constexpr (sig) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's published rows have left the CU
         __syncthreads();
-        if constexpr (sig) {
-            if (tid == 0) __hip_atomic_store(u.sig + tail_flag_index(which, l, g), sig_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         if (l == depth - 1) PPOAF_STAMP(13);
         float* t = Dc; Dc = Dn; Dn = t;
     }
@@ -486,11 +460,6 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     // ---- first layer backward: dW0[o][i] = sum_s dz0[s][o] * x[s][i] on MFMA against the padded sX
     if (SPLIT) {
         publish_rows(Dc, u.sp.dbuf[which]);                   // dz_0 (its K-panel is x, published after the gather)
-        if constexpr (sig) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(u.sig + tail_flag_index(which, 0, g), sig_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     } else {
         for (int mt = wave; mt < HT; mt += kNW)
             wgrad_mtile(Dc, HS, sX, INP, mt * 16, NT0, in_dim, lane, slab + offW(0), in_dim);

@@ -21,7 +21,7 @@
 // CU at this kernel's register count -- checked on the host against the occupancy the runtime reports); every wait is
 // bounded by a wall-clock budget and ends in the control block's error word instead of a hang (the host then restores
 // the epoch's starting state and runs the three-launch chain, fused_update.py).
-#include "ppo_update_rowtile.hpp"
+#include "ppo_update_dev.hpp"
 #include "peer_exchange_device.hpp"
 #include <hip/hip_ext.h>
 #include <cstddef>
@@ -31,7 +31,7 @@ namespace ppoaf {
 typedef unsigned tail_u32x4 __attribute__((ext_vector_type(4)));
 typedef float tail_f32x4 __attribute__((ext_vector_type(4)));
 
-// (kTailFlagOff / kTailRecOff: ppo_update_dev.hpp -- fwd_bwd writes the ready words of the same block)
+constexpr int kTailRecOff = 256;              // byte offset of the records inside the control block
 constexpr int kTailMaxRounds = 8;             // a polling lane holds up to 8 records: <= 512 workgroups
 constexpr int kTailMaxE = 9;                  // output segment: up to 9 elements per thread (8 x 256 weights + bias + log_std)
 
@@ -42,11 +42,9 @@ struct TailCtl {
     long long bc_t[2];                        // the Adam step (per network) the corrections below were computed for
     double bc[4];                             // [network][1 - beta1^t, sqrt(1 - beta2^t)]: left by the previous launch's bookkeeping
     unsigned long long stamps[24];            // diagnostic build (-DPPOAF_TAIL_STAMPS): s_memtime per phase of one workgroup
-    unsigned ready[2 * kTailFlagLayers * kTailFlagWgs];   // fwd_bwd's ready words (args->tail_ctl): tag of the mini-batch whose
-                                                          // dz_l rows (network, layer l, workgroup g) are out
     tail_u32x4 rec[1];                        // [8 * per_xcd]: {q bits 0..31, tag, q bits 32..63, tag}
 };
-static_assert(offsetof(TailCtl, ready) == kTailFlagOff && offsetof(TailCtl, rec) == kTailRecOff, "control block layout");
+static_assert(offsetof(TailCtl, rec) == kTailRecOff, "record offset");
 
 // diagnostic layer (tools/tail_stamps.py): one macro, nothing in the shipped kernel
 #ifdef PPOAF_TAIL_STAMPS
@@ -69,7 +67,6 @@ struct TailDev {
     TailCtl* ctl;
     long long budget;                         // wall_clock64 ticks (100 MHz)
     int nblk, jobs_a, jobs_c, per_xcd;
-    int handoff;                              // 1: fwd_bwd of this mini-batch signals ready words (args->tail_ctl) and may still be running
 };
 
 struct TailCoef { float gs, step_size, bc2_sqrt; };
@@ -83,32 +80,6 @@ __device__ __forceinline__ void tail_publish(const TailDev& td, const unsigned t
     const unsigned long long qb = (unsigned long long)__double_as_longlong(q);
     const tail_u32x4 r = {(unsigned)qb, tag, (unsigned)(qb >> 32), tag};
     __builtin_amdgcn_raw_buffer_store_b128(r, tail_rsrc(td), (unsigned)(kTailRecOff + 16 * b), 0, 16 /* sc1 */);
-}
-
-// Hand-off from a fwd_bwd launch that may still be running (td.handoff): all threads of the workgroup; wave 0 polls the
-// ready words of (network, layer) for the n_wg row-tile workgroups until each carries this mini-batch's tag, the barrier
-// holds the others.  The panels, partials and loss scalars behind the words were written through (sc1) and are read with
-// sc1 loads.  A wait that runs out of its budget sets the error word (the launch drains; the host redoes the epoch).
-template <bool HANDOFF>
-__device__ __forceinline__ void tail_wait_ready(const TailDev& td, const unsigned tag, const int which, const int l, const int n_wg) {
-    if (!HANDOFF) return;
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        long long budget = td.budget;
-        if (__hip_atomic_load(&td.ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) budget = 0;
-        const long long t0 = (long long)wall_clock64();
-        for (unsigned polls = 1;; ++polls) {
-            unsigned f = tag;
-            if (lane < n_wg) f = __hip_atomic_load(&td.ctl->ready[tail_flag_index(which, l, lane)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all((int)(f == tag))) break;
-            if ((polls & 15u) == 0u && (long long)wall_clock64() - t0 > budget) {
-                if (lane == 0) __hip_atomic_store(&td.ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __syncthreads();
 }
 
 // wave_sum<double> in its own association (xor 32, 16, 8, 4, 2, 1 -- IEEE addition is commutative, so pairing lane i with
@@ -326,7 +297,7 @@ __device__ __forceinline__ void tail_adam1(const UpdateDev& u, const long idx, c
 // The 16 x 32 output tile is formed by wave 0 (C layout) and handed to ALL 256 threads through LDS for the optimiser
 // step: thread t owns tile elements t and t + 256 (row e / 32, column e % 32: whole 128-byte lines of p / m / v), whose
 // state it requested at the start of the job, beside the MFMA operands.
-template <int H, bool XCHG, bool HANDOFF>
+template <int H, bool XCHG>
 __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, const unsigned tag, const int b, const int which,
                                          const int job, float* sFold /* [3][2][256] + [4][16] */, float* sTile /* [16][32] + [16] */,
                                          double* s_red, float* s_coef, const TailXchg* xc) {
@@ -375,8 +346,6 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
         const bool has_b = itile == 0 && tid >= 64 && tid < 80;
         const long bidx = nb + offB(l) + ot * 16 + (tid - 64);
         sb = tail_pmv_load(u, bidx, has_b);
-        tail_wait_ready<HANDOFF>(td, tag, which, l, u.n_wg);  // (row tiles of the same launch: dz_l and its K-panel are out)
-        constexpr int aux = HANDOFF ? 16 /* sc1 */ : 0;
         const long ldx = l >= 1 ? H : 64;
         const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(u.sp.dbuf[which] + (long)l * plane, 0, 0xFFFFFFFF, 0x00020000);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -394,9 +363,9 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned sd = 4u * (unsigned)((16 * ch + 4 * j) * H), sx = 4u * (unsigned)((16 * ch + 4 * j) * (int)ldx);
-                    a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, sd, aux));
-                    x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl, sx, aux));
-                    if (two) x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl + 64u, sx, aux));
+                    a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, sd, 0));
+                    x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl, sx, 0));
+                    if (two) x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl + 64u, sx, 0));
                 }
             }
         }
@@ -503,7 +472,6 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
             se[k] = tail_pmv_load(u, nb + seg_off + idx, idx < seg_len);
             ge[k] = 0.f;
         }
-        tail_wait_ready<HANDOFF>(td, tag, which, depth - 1, u.n_wg);   // (the partials precede dz of the last hidden layer)
 #pragma unroll
         for (int k = 0; k < kTailMaxE; ++k) {
             const long idx = tid + (long)kWgradThreads * k;
@@ -512,10 +480,7 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
                 for (int g0 = 0; g0 < n_hb; g0 += 8) {
                     float pv[8];
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        const float* src = outpart + (long)(g0 + kk < n_hb ? g0 + kk : 0) * seg_len + idx;
-                        pv[kk] = ld1<HANDOFF>(src);
-                    }
+                    for (int kk = 0; kk < 8; ++kk) pv[kk] = outpart[(long)(g0 + kk < n_hb ? g0 + kk : 0) * seg_len + idx];
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) if (g0 + kk < n_hb) acc += pv[kk];
                 }
@@ -561,18 +526,19 @@ __device__ __forceinline__ void tail_job(const UpdateDev& u, const TailDev& td, 
     }
 }
 
-// One workgroup (256 threads) of the tail: block b of 8 * per_xcd + 1 (the last one keeps the books).
-template <int HA, int HC, bool XCHG, bool HANDOFF>
-__device__ __forceinline__ void tail_block(const UpdateDev& u, const TailDev& td, TailXchg& xc, const int b, double* s_red, float* s_fold,
-                                           float* s_tile, float* s_coef) {
+template <int HA, int HC, bool XCHG>
+__global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(UpdateDev u, TailDev td, TailXchg xc) {
+    __shared__ double s_red[17];
+    __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
+    __shared__ float s_tile[16 * 32 + 16];
+    __shared__ float s_coef[4];
+    const int b = blockIdx.x;
     const unsigned long long seq = __hip_atomic_load(&td.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned tag = tail_tag_of(seq);                                // never 0: a zero-initialised record is never current
+    const unsigned tag = ((unsigned)seq & 0x7fffffffu) + 1u;              // never 0: a zero-initialised record is never current
     if (b == td.nblk) {
         // bookkeeping: the totals need nobody; what other workgroups read at their start moves only after all have published
-        tail_wait_ready<HANDOFF>(td, tag, 0, u.net[0].depth - 1, u.n_wg);   // the loss partials of both networks' row tiles are out
-        tail_wait_ready<HANDOFF>(td, tag, 1, u.net[1].depth - 1, u.n_wg);
         if (threadIdx.x >= 64) return;
-        ppo_update_bookkeeping_totals<HANDOFF>(u);
+        ppo_update_bookkeeping_totals(u);
         // while the others work: the bias corrections of the step being taken (norm_scratch, as ppo_update_bookkeeping_steps
         // leaves them) and of the NEXT step (control block: the next launch's workgroups need not compute them)
         const int w = threadIdx.x & 1;
@@ -603,47 +569,10 @@ __device__ __forceinline__ void tail_block(const UpdateDev& u, const TailDev& td
     const int job = (b & 7) * td.per_xcd + (b >> 3);          // XCD b % 8 works on one run of the layer-major job list
     const bool live = job < td.jobs_a + td.jobs_c;            // the same on every rank
     if (XCHG && live) xc.seq = xchg_sequence(xc.x, (unsigned)b);
-    if (job < td.jobs_a) tail_job<HA, XCHG, HANDOFF>(u, td, tag, b, 0, job, s_fold, s_tile, s_red, s_coef, &xc);
-    else if (live) tail_job<HC, XCHG, HANDOFF>(u, td, tag, b, 1, job - td.jobs_a, s_fold, s_tile, s_red, s_coef, &xc);
+    if (job < td.jobs_a) tail_job<HA, XCHG>(u, td, tag, b, 0, job, s_fold, s_tile, s_red, s_coef, &xc);
+    else if (live) tail_job<HC, XCHG>(u, td, tag, b, 1, job - td.jobs_a, s_fold, s_tile, s_red, s_coef, &xc);
     else if (threadIdx.x == 0) tail_publish(td, tag, b, 0.0);
     if (XCHG && live) xchg_advance(xc.x, xc.seq, (unsigned)b);
-}
-
-template <int HA, int HC, bool XCHG>
-__global__ __launch_bounds__(kWgradThreads) void ppo_update_wgrad_adam_kernel(UpdateDev u, TailDev td, TailXchg xc) {
-    __shared__ double s_red[17];
-    __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
-    __shared__ float s_tile[16 * 32 + 16];
-    __shared__ float s_coef[4];
-    tail_block<HA, HC, XCHG, false>(u, td, xc, (int)blockIdx.x, s_red, s_fold, s_tile, s_coef);
-}
-
-// ---- ONE launch per mini-batch: fwd_bwd's row-tile workgroups (blocks 0 .. n_fwd - 1, dispatched first) and the tail's
-// workgroups in the same grid.  The tail workgroups start with the launch -- launch tag, step counters, the optimiser state
-// of their elements -- and wait for the ready words the row tiles set layer by layer (args->tail_ctl, tail_wait_ready):
-// the weight gradients of the upper layers are formed while the backward pass is still running, and between the last
-// dz rows and the optimiser step lie one hand-off, the layer-0 jobs and the norm records -- no kernel boundary, no second
-// ramp.  (Two launches on two streams do the same on paper; inside a captured hipGraph the cross-stream dependencies cost
-// more than the overlap buys: 38 us per mini-batch against 25.6 at C2.)  A row-tile workgroup never waits for anybody, and
-// it comes first in dispatch order, so the waits of the others are always served; every workgroup needs a CU of its own
-// (the kernel's register count admits one 512-thread workgroup per CU), which the host checks.
-template <int HTA, int HTC, bool XCHG>
-__global__ __launch_bounds__(kThreadsU) void ppo_update_step_kernel(UpdateDev u, TailDev td, TailXchg xc, int n_fwd) {
-    __shared__ double s_red[17];
-    __shared__ __attribute__((aligned(16))) float s_fold[6 * 256 + 64];
-    __shared__ float s_tile[16 * 32 + 16];
-    __shared__ float s_coef[4];
-    const int b = blockIdx.x;
-    if (b < n_fwd) {                                          // ppo_update_fwd_bwd_kernel's placement: XCDs 0-3 actor, 4-7 critic
-        const int which = (b >> 2) & 1;
-        const int g = ((b >> 3) << 2) | (b & 3);
-        if (g >= u.n_wg) return;
-        if (which == 0) ppo_update_fwd_bwd_body<HTA, false, UpdateDev, RowtileNoHook, true, true>(u, 0, g);
-        else ppo_update_fwd_bwd_body<HTC, false, UpdateDev, RowtileNoHook, true, true>(u, 1, g);
-        return;
-    }
-    if (threadIdx.x >= kWgradThreads) return;                 // a tail workgroup is four waves (before any barrier)
-    tail_block<16 * HTA, 16 * HTC, XCHG, true>(u, td, xc, b - n_fwd, s_red, s_fold, s_tile, s_coef);
 }
 
 template <int HA, int HC, bool XCHG>
@@ -685,51 +614,6 @@ static int tail_dispatch(const UpdateDev& u, const TailDev& td, const TailXchg* 
     return PPOAF_E_INVALID;
 }
 
-template <int HTA, int HTC, bool XCHG>
-static int step_launch_as(const UpdateDev& u, const TailDev& td, const TailXchg& xc, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    static int per_cu = 0, cus = 0;
-    if (per_cu == 0) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_update_step_kernel<HTA, HTC, XCHG>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
-        }
-        int n = 0, dev = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(ppo_update_step_kernel<HTA, HTC, XCHG>),
-                                                                   kThreadsU, lds);
-        if (e != hipSuccess) { set_error("ppo_update_step: occupancy query: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
-        per_cu = n > 0 ? n : -1;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    }
-    const int n_fwd = 8 * ((u.n_wg + 3) / 4);                 // groups of 4 actor + 4 critic row tiles (ppo_update_fwd_bwd_kernel's grid)
-    const long grid = (long)n_fwd + td.nblk + 1;
-    PPOAF_REQUIRE(per_cu > 0 && grid <= (long)per_cu * cus,
-                  "ppo_update_step: %ld workgroups cannot be resident together (%d per CU x %d CUs)", grid, per_cu, cus);
-    if (e0 || e1)
-        hipExtLaunchKernelGGL((ppo_update_step_kernel<HTA, HTC, XCHG>), dim3((unsigned)grid), dim3(kThreadsU), (unsigned)lds, s, e0, e1, 0, u, td, xc, n_fwd);
-    else
-        hipLaunchKernelGGL((ppo_update_step_kernel<HTA, HTC, XCHG>), dim3((unsigned)grid), dim3(kThreadsU), lds, s, u, td, xc, n_fwd);
-    return check_launch("ppo_update_step");
-}
-template <int HTA, int HTC>
-static int step_launch(const UpdateDev& u, const TailDev& td, const TailXchg* xc, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    if (xc) return step_launch_as<HTA, HTC, true>(u, td, *xc, lds, s, e0, e1);
-    return step_launch_as<HTA, HTC, false>(u, td, TailXchg(), lds, s, e0, e1);
-}
-static int step_dispatch(const UpdateDev& u, const TailDev& td, const TailXchg* xc, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    const size_t a = rowtile_lds_floats(u.net[0]), c = rowtile_lds_floats(u.net[1]);
-    const size_t lds = ((a > c ? a : c) * 4 + 15) / 16 * 16;
-    PPOAF_REQUIRE(lds <= 150 * 1024, "ppo_update_step: needs %zu B of LDS beside the tail's 9 KB", lds);
-    const int ha = u.net[0].H, hc = u.net[1].H;
-    if (ha == 32 && hc == 32) return step_launch<2, 2>(u, td, xc, lds, s, e0, e1);
-    if (ha == 64 && hc == 64) return step_launch<4, 4>(u, td, xc, lds, s, e0, e1);
-    if (ha == 128 && hc == 128) return step_launch<8, 8>(u, td, xc, lds, s, e0, e1);
-    if (ha == 64 && hc == 128) return step_launch<4, 8>(u, td, xc, lds, s, e0, e1);
-    set_error("ppo_update_step: hidden widths (actor %d, critic %d) not instantiated (networks up to 128 wide)", ha, hc);
-    return PPOAF_E_INVALID;
-}
-
 static int tail_prepare(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds, UpdateDev& u, TailDev& td) {
     int rc = make_update_dev(args, u);
     if (rc) return rc;
@@ -742,8 +626,6 @@ static int tail_prepare(const ppoaf_ppo_update_args_t* args, void* ctl, double w
     td.jobs_c = split_wgrad_jobs(u.net[1]);
     td.per_xcd = split_wgrad_per_xcd(u);
     td.nblk = split_wgrad_blocks(u);
-    td.handoff = u.sig != nullptr;          // (only the one-launch mini-batch hands over inside the launch: ppoaf_ppo_update_step)
-    PPOAF_REQUIRE(!td.handoff || args->tail_ctl == ctl, "ppo_update_wgrad_adam: args->tail_ctl names another control block");
     PPOAF_REQUIRE(td.nblk <= 64 * kTailMaxRounds, "ppo_update_wgrad_adam: %d workgroups, a polling wave holds %d records", td.nblk,
                   64 * kTailMaxRounds);
     for (int w = 0; w < 2; ++w)
@@ -771,7 +653,6 @@ extern "C" int ppoaf_ppo_update_tail_ctl_bytes(const ppoaf_ppo_update_args_t* ar
     PPOAF_REQUIRE(args && bytes_out, "ppo_update_tail_ctl_bytes: null argument");
     ppoaf_ppo_update_args_t a = *args;
     a.split_workspace = nullptr;
-    a.tail_ctl = nullptr;
     const int rc = make_update_dev(&a, u);
     if (rc) return rc;
     *bytes_out = (int64_t)kTailRecOff + 16 * (int64_t)split_wgrad_blocks(u);
@@ -783,7 +664,6 @@ extern "C" int ppoaf_ppo_update_tail_exchange_floats(const ppoaf_ppo_update_args
     PPOAF_REQUIRE(args && floats_out, "ppo_update_tail_exchange_floats: null argument");
     ppoaf_ppo_update_args_t a = *args;
     a.split_workspace = nullptr;
-    a.tail_ctl = nullptr;
     const int rc = make_update_dev(&a, u);
     if (rc) return rc;
     *floats_out = (int64_t)tail_exchange_floats(u, nullptr);
@@ -803,8 +683,14 @@ extern "C" int ppoaf_ppo_update_wgrad_adam(const ppoaf_ppo_update_args_t* args, 
     return ppoaf_ppo_update_wgrad_adam_timed(args, ctl, wait_seconds, nullptr, nullptr, stream);
 }
 
-static int tail_exchange_prepare(const UpdateDev& u, const TailDev& td, ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds, TailXchg& xc) {
+extern "C" int ppoaf_ppo_update_wgrad_adam_exchange(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
+                                                    ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds, ppoaf_stream_t stream) {
+    UpdateDev u;
+    TailDev td;
+    int rc = tail_prepare(args, ctl, wait_seconds, u, td);
+    if (rc) return rc;
     PPOAF_REQUIRE(xchg && xchg->connected, "ppo_update_wgrad_adam_exchange: exchange missing or not connected");
+    TailXchg xc;
     xc.x = xchg->dev;
     xc.seq = 0;
     const long need = tail_exchange_floats(u, xc.seg_base);
@@ -817,51 +703,5 @@ static int tail_exchange_prepare(const UpdateDev& u, const TailDev& td, ppoaf_pe
     PPOAF_REQUIRE(xchg->memory_kind != 3, "ppo_update_wgrad_adam_exchange: coarse-grained exchange slots are coherent only through "
                   "fences, which this launch does not use (create the exchange with memory_kind 0, 1 or 2)");
     xc.wait_ticks = (long long)(xchg_wait_seconds * 1.0e8);
-    return PPOAF_OK;
-}
-
-extern "C" int ppoaf_ppo_update_wgrad_adam_exchange(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
-                                                    ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds, ppoaf_stream_t stream) {
-    UpdateDev u;
-    TailDev td;
-    int rc = tail_prepare(args, ctl, wait_seconds, u, td);
-    if (rc) return rc;
-    TailXchg xc;
-    rc = tail_exchange_prepare(u, td, xchg, xchg_wait_seconds, xc);
-    if (rc) return rc;
     return tail_dispatch(u, td, &xc, (hipStream_t)stream, nullptr, nullptr);
-}
-
-// ---- one launch per mini-batch (fwd_bwd + tail in one grid)
-static int step_prepare(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds, UpdateDev& u, TailDev& td) {
-    int rc = tail_prepare(args, ctl, wait_seconds, u, td);
-    if (rc) return rc;
-    PPOAF_REQUIRE(td.handoff, "ppo_update_step: args->tail_ctl must name the control block (the row tiles signal through it)");
-    PPOAF_REQUIRE(u.confine == 0, "ppo_update_step: xcd_half must be 0");
-    return PPOAF_OK;
-}
-
-extern "C" int ppoaf_ppo_update_step_timed(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
-                                           void* start_event, void* stop_event, ppoaf_stream_t stream) {
-    UpdateDev u;
-    TailDev td;
-    int rc = step_prepare(args, ctl, wait_seconds, u, td);
-    if (rc) return rc;
-    return step_dispatch(u, td, nullptr, (hipStream_t)stream, (hipEvent_t)start_event, (hipEvent_t)stop_event);
-}
-
-extern "C" int ppoaf_ppo_update_step(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds, ppoaf_stream_t stream) {
-    return ppoaf_ppo_update_step_timed(args, ctl, wait_seconds, nullptr, nullptr, stream);
-}
-
-extern "C" int ppoaf_ppo_update_step_exchange(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
-                                              ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds, ppoaf_stream_t stream) {
-    UpdateDev u;
-    TailDev td;
-    int rc = step_prepare(args, ctl, wait_seconds, u, td);
-    if (rc) return rc;
-    TailXchg xc;
-    rc = tail_exchange_prepare(u, td, xchg, xchg_wait_seconds, xc);
-    if (rc) return rc;
-    return step_dispatch(u, td, &xc, (hipStream_t)stream, nullptr, nullptr);
 }

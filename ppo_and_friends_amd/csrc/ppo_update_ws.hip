@@ -1697,7 +1697,6 @@ extern "C" int ppoaf_ppo_update_split_workspace_bytes(const ppoaf_ppo_update_arg
     PPOAF_REQUIRE(args && bytes_out, "ppo_update_split_workspace_bytes: null argument");
     ppoaf_ppo_update_args_t a = *args;
     a.split_workspace = nullptr;
-    a.tail_ctl = nullptr;
     UpdateDev u;
     int rc = make_update_dev(&a, u);
     if (rc) return rc;
@@ -1714,7 +1713,6 @@ extern "C" int ppoaf_ppo_update_split_blocks(const ppoaf_ppo_update_args_t* args
     if (!args) return -1;
     a = *args;
     a.split_workspace = nullptr;
-    a.tail_ctl = nullptr;
     if (make_update_dev(&a, u)) return -1;
     return split_wgrad_blocks(u);
 }

@@ -233,11 +233,7 @@ class FusedPolicyUpdate:
         """fwd_bwd + the launch that completes the gradient bucket (wgrad / slab reduce) of ONE mini-batch, no optimiser step:
         what tests and bench probes compare.  The bookkeeping of that launch (totals, step counters) runs as usual."""
         lib, st, ref = self._lib, K.stream(), C.byref(args)
-        keep, args.tail_ctl = args.tail_ctl, None            # no fused tail launch follows: nothing to hand over to
-        try:
-            _lib.check(lib.ppoaf_ppo_update_fwd_bwd_timed(ref, timing_events[0], timing_events[1], st), "ppo_update_fwd_bwd")
-        finally:
-            args.tail_ctl = keep
+        _lib.check(lib.ppoaf_ppo_update_fwd_bwd_timed(ref, timing_events[0], timing_events[1], st), "ppo_update_fwd_bwd")
         if args.split_workspace:
             _lib.check(lib.ppoaf_ppo_update_wgrad(ref, st), "ppo_update_wgrad")
         else:
@@ -265,31 +261,7 @@ class FusedPolicyUpdate:
             return "N > 1 without an exchange for the fused tail launch (" + self.xchg_reason + ")"
         return ""
 
-    def tail_overlap_reason(self):
-        """'' when a mini-batch is ONE launch (ppoaf_ppo_update_step: fwd_bwd's row tiles and the fused tail's workgroups in
-        one grid; the row tiles signal ready words per layer, the tail's jobs wait for theirs, so the weight gradients of the
-        upper layers are formed while the backward pass still runs and the tail's start-up is off the critical path), else
-        why fwd_bwd and the tail are two launches.  PPOAF_FUSED_TAIL = 2 (default where it applies) | 1 (two launches) |
-        0 (three: wgrad and Adam apart)."""
-        import os
-        why = self.tail_reason()
-        if why:
-            return why
-        if os.environ.get("PPOAF_FUSED_TAIL", "2") == "1":
-            return "two launches (PPOAF_FUSED_TAIL=1)"
-        if getattr(self, "_overlap_disabled", ""):
-            return "disabled after a failed launch: " + self._overlap_disabled
-        if max(self.actor_desc.hidden, self.critic_desc.hidden) > 128:
-            return "a 256-wide network: its weight-gradient jobs alone outnumber the CUs"
-        # every workgroup of the launch waits for others: one CU each (512 threads at the row tiles' register count)
-        grid = 8 * ((self.n_wg + 3) // 4) + self._split_blocks() + 1
-        if grid > 256:
-            return f"{grid} workgroups, one per CU"
-        if getattr(self, "xcd_half", 0):
-            return "the epoch shares the GPU with the ICM update on a second stream"
-        return ""
-
-    def _tail_ctl_ptr(self, args, count=True):
+    def _tail_ctl_ptr(self, args):
         ctl = getattr(self, "_tail_ctl", None)
         if ctl is None:
             need = C.c_int64(0)
@@ -300,8 +272,7 @@ class FusedPolicyUpdate:
                 assert int(need.value) == self._tail_exchange_floats(), (int(need.value), self._tail_exchange_floats())
             # zeroed once, then kept: the block carries the launch tag from one launch to the next
             ctl = self._tail_ctl = torch.zeros((n + 63) // 64 * 16, dtype=torch.int32, device=self.pol.device)
-        if count:
-            FusedPolicyUpdate.tail_launches += 1
+        FusedPolicyUpdate.tail_launches += 1
         return ctl.data_ptr()
 
     def _ws_wanted(self):
@@ -450,21 +421,6 @@ class FusedPolicyUpdate:
         st = K.stream()
         ref = C.byref(args)
         single = not self.multi
-        if args.split_workspace and self.tail_reason() == "":
-            args.tail_ctl = None
-            if self.tail_overlap_reason() == "":
-                # the whole mini-batch in ONE launch (csrc/ppo_update_tail.hip: ppo_update_step_kernel)
-                ctl = args.tail_ctl = self._tail_ctl_ptr(args)
-                if single:
-                    rc = lib.ppoaf_ppo_update_step(ref, ctl, self.tail_wait_seconds, st)
-                else:
-                    rc = lib.ppoaf_ppo_update_step_exchange(ref, ctl, self.tail_wait_seconds, self.xchg_sp.handle,
-                                                            self.xchg_sp.wait_seconds, st)
-                self._tail_used = True
-                FusedPolicyUpdate.step_launches += 1
-                if rc != 0:
-                    _lib.check(rc, "ppo_update_step")
-                return
         rc = lib.ppoaf_ppo_update_fwd_bwd(ref, st)
         if rc == 0 and args.split_workspace:
             # split-wgrad chain: complete weight gradients from the published panels, then clip + Adam
@@ -616,8 +572,6 @@ class FusedPolicyUpdate:
         finally:
             args.mb_offset, args.cursor_advance = 0, 1
 
-    step_launches = 0                  # one-launch mini-batches issued in this process (tests: the path really ran)
-
     def _persistent_failure(self):
         """After a host synchronisation: '' or why the last persistent launch did not complete (its control block)."""
         ctl = getattr(self, "_ws_ctl", None)
@@ -633,10 +587,7 @@ class FusedPolicyUpdate:
             self._tail_used = False
             if int(ctl[2].item()) != 0:                   # TailCtl.error
                 ctl[2:3].zero_()
-                if self.tail_overlap_reason() == "":      # first suspect: the two launches did not run side by side
-                    self._overlap_disabled = "a wait ran out of time inside the one-launch mini-batch"
-                else:
-                    self._tail_disabled = "a wait for the other workgroups' norm records ran out of time"
+                self._tail_disabled = "a wait for the other workgroups' norm records ran out of time"
                 self._graphs.clear()                      # the captured chains end in the fused launch
                 return ("ppo_update_wgrad_adam: a wait ran out of time -- the launch's workgroups were not all resident at once "
                         "(another process on this GPU?)")
