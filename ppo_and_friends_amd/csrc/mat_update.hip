@@ -16,6 +16,7 @@
 // A mini-batch of 256 envs is 52 workgroups; the ~80 dependent phases are barrier + LDS latency
 // bound, not MFMA bound -- the point is that they replace ~270 separate kernel launches.
 #include "mlp_device.hpp"
+#include "tail_sync.hpp"
 #include <hip/hip_ext.h>
 #include <cstdlib>
 
@@ -1289,6 +1290,216 @@ __global__ __launch_bounds__(256) void mat_update_wgrad_kernel(MatDev u, int n_s
     }
 }
 
+// ---- fused tail of K15's split-wgrad chain (round 4; single rank): mat_update_wgrad_kernel's jobs carried through to the
+// optimiser step -- every workgroup requests the optimiser state of its elements beside its operands, forms its piece of
+// the gradient (same tiles, folds and orders), publishes its squared-norm partial as a tagged record (tail_sync.hpp),
+// waits for all records, and applies clip + Adam (ppoaf_adam_step_prenormed's arithmetic: mat_policy.py:677-699, ONE
+// optimiser over actor + critic) to exactly those elements.  mat_update_wgrad_kernel + clip_adam_kernel (7.6 + 5.1 us at
+// C5) become one launch.  Parameters, moments and the gradient bucket end bitwise as after the two launches.
+struct MatAdam { float* exp_avg; float* exp_avg_sq; const float* lr; float beta1, beta2, eps, grad_scale, max_norm; float* grad_norm_out; };
+struct MatPmv { float p, m, v; };
+__device__ __forceinline__ MatPmv mat_pmv_load(const MatDev& u, const MatAdam& ad, const long idx, const bool ok) {
+    MatPmv r = {0.f, 0.f, 0.f};
+    if (ok) { r.p = u.params[idx]; r.m = ad.exp_avg[idx]; r.v = ad.exp_avg_sq[idx]; }
+    return r;
+}
+__device__ __forceinline__ void mat_adam1(const MatDev& u, const MatAdam& ad, const long idx, const float g, const MatPmv& s,
+                                          const float gs, const float step_size, const float bc2_sqrt) {
+    const float gi = g * gs;                                   // clip_adam_kernel, expression for expression
+    const float mi = ad.beta1 * s.m + (1.0f - ad.beta1) * gi;
+    const float vi = ad.beta2 * s.v + (1.0f - ad.beta2) * gi * gi;
+    ad.exp_avg[idx] = mi;
+    ad.exp_avg_sq[idx] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + ad.eps;
+    const_cast<float*>(u.params)[idx] = s.p - step_size * (mi / denom);
+}
+// wave 0 of a workgroup: publish q, wait for everybody's, coefficients into s_coef (t = the step being taken)
+__device__ __forceinline__ void mat_tail_sync_wave0(const MatAdam& ad, const TailDev& td, const unsigned tag, const int b, const long long t_next,
+                                                    const long long pre_t, double bc1, double bc2s, const float lr, const double q, float* s_coef) {
+    if (threadIdx.x == 0) tail_publish(td, tag, b, q);
+    if (pre_t != t_next) {                                     // uniform: first launch / restored state
+        bc1 = 1.0 - pow((double)ad.beta1, (double)t_next);
+        bc2s = sqrt(1.0 - pow((double)ad.beta2, (double)t_next));
+    }
+    double sq, unused;
+    tail_gather(td, tag, sq, unused);
+    if (threadIdx.x == 0) {
+        const float total_norm = (float)sqrt(sq);
+        float coef = 1.0f;
+        if (ad.max_norm > 0.f) coef = fminf(ad.max_norm / (total_norm + 1e-6f), 1.0f);
+        s_coef[0] = ad.grad_scale * coef;
+        s_coef[1] = (float)((double)lr / bc1);
+        s_coef[2] = (float)bc2s;
+        if (b == 0 && ad.grad_norm_out) ad.grad_norm_out[0] = total_norm;
+    }
+}
+
+__global__ __launch_bounds__(256) void mat_update_wgrad_adam_kernel(MatDev u, int n_small_blocks, MatAdam ad, TailDev td) {
+    __shared__ double s_red[17];
+    __shared__ __attribute__((aligned(16))) float s_fold[2 * 3 * 256 + 64];
+    __shared__ float s_tile[16 * 32 + 16];
+    __shared__ float s_coef[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long seq = __hip_atomic_load(&td.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned tag = ((unsigned)seq & 0x7fffffffu) + 1u;
+    // read BEFORE this workgroup publishes: the bookkeeping workgroup rewrites them only after everybody has
+    const long long t_next = (long long)u.step_count[0] + 1;
+    const float lr = ad.lr[0];
+    const long long pre_t = td.ctl->bc_t[0];
+    const double pre_bc1 = td.ctl->bc[0], pre_bc2s = td.ctl->bc[1];
+    if (b == td.nblk) {
+        // bookkeeping: totals and cursor need nobody; the step counter and the launch tag move after all have published
+        if (tid >= 64) return;
+        const int keep_fuse = u.fuse_norm;
+        MatDev ub = u;
+        ub.fuse_norm = 0;                                      // (the step counter is advanced below, after the wait)
+        mat_update_bookkeeping(ub);
+        (void)keep_fuse;
+        double c_next[2] = {0.0, 0.0};
+        if (tid == 0) {
+            c_next[0] = 1.0 - pow((double)ad.beta1, (double)(t_next + 1));
+            c_next[1] = sqrt(1.0 - pow((double)ad.beta2, (double)(t_next + 1)));
+        }
+        double sq, unused;
+        tail_gather(td, tag, sq, unused);
+        if (tid == 0) {
+            u.step_count[0] = t_next;
+            u.norm_scratch[0] = sq;
+            td.ctl->bc_t[0] = t_next + 1;
+            td.ctl->bc[0] = c_next[0];
+            td.ctl->bc[1] = c_next[1];
+            __hip_atomic_store(&td.ctl->seq, seq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    double q = 0.0;
+    if (b < kMatWgJobs) {
+        constexpr int per_xcd = kMatWgJobs / 8;
+        const int job = (b & 7) * per_xcd + (b >> 3);
+        const int k = job >> 3, ot = (job >> 1) & 3, ih = job & 1;
+        const int wk = kMatLinW[k];
+        const long plane = (long)u.R * kMD;
+        // this thread's two elements of the 16 x 32 piece (row e / 32, column e % 32) and, threads 64..79 of the jobs of
+        // input half 0, one bias: optimiser state first
+        long eidx[2];
+        MatPmv se[2], sb;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int e = tid + 256 * kk, row = e >> 5, col = e & 31;
+            eidx[kk] = u.off[wk] + (long)(ot * 16 + row) * kMD + ih * 32 + col;
+            se[kk] = mat_pmv_load(u, ad, eidx[kk], true);
+        }
+        const bool has_b = ih == 0 && tid >= 64 && tid < 80;
+        const long bidx = u.off[wk + 1] + ot * 16 + (tid - 64);
+        sb = mat_pmv_load(u, ad, bidx, has_b);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(u.dpanel + (long)k * plane, 0, 0xFFFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(u.xpanel + (long)kMatLinX[k] * plane, 0, 0xFFFFFFFF, 0x00020000);
+        const unsigned dl = 4u * (unsigned)((lane >> 4) * kMD + ot * 16 + (lane & 15));
+        const unsigned xl = 4u * (unsigned)((lane >> 4) * kMD + ih * 32 + (lane & 15));
+        const int nc = u.nT;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        float bsum = 0.f;
+        constexpr int MAXC = 16;
+        for (int c0 = wave; c0 < nc; c0 += 4 * MAXC) {         // wave-uniform trip count
+            float a[MAXC][4], x0[MAXC][4], x1[MAXC][4];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int ch = c0 + 4 * c;
+                if (ch < nc) {                                 // wave-uniform
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned so = 4u * (unsigned)((16 * ch + 4 * j) * kMD);
+                        a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dl, so, 0));
+                        x0[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl, so, 0));
+                        x1[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xl + 64u, so, 0));
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                if (c0 + 4 * c < nc) {                         // wave-uniform
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x0[c][j], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], x1[c][j], acc1, 0, 0, 0);
+                        bsum += a[c][j];
+                    }
+                }
+            }
+        }
+        if (wave > 0) {
+            *reinterpret_cast<f32x4*>(s_fold + (((wave - 1) * 2 + 0) * 64 + lane) * 4) = acc0;
+            *reinterpret_cast<f32x4*>(s_fold + (((wave - 1) * 2 + 1) * 64 + lane) * 4) = acc1;
+        }
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 16) s_fold[1536 + wave * 16 + lane] = bsum;
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                acc0 += *reinterpret_cast<const f32x4*>(s_fold + ((w * 2 + 0) * 64 + lane) * 4);
+                acc1 += *reinterpret_cast<const f32x4*>(s_fold + ((w * 2 + 1) * 64 + lane) * 4);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (lane >> 4) + r;
+                s_tile[row * 32 + (lane & 15)] = acc0[r];
+                s_tile[row * 32 + 16 + (lane & 15)] = acc1[r];
+                q += (double)acc0[r] * acc0[r] + (double)acc1[r] * acc1[r];
+            }
+            if (ih == 0 && lane < 16) {
+                const float bg = s_fold[1536 + lane] + s_fold[1536 + 16 + lane] + s_fold[1536 + 32 + lane] + s_fold[1536 + 48 + lane];
+                s_tile[512 + lane] = bg;
+                q += (double)bg * bg;
+            }
+            q = tail_wave_sum(q);                              // block_sum of the wgrad launch: this wave's sum + three exact zeros
+            mat_tail_sync_wave0(ad, td, tag, b, t_next, pre_t, pre_bc1, pre_bc2s, lr, q, s_coef);
+        }
+        __syncthreads();
+        const float gs = s_coef[0], step_size = s_coef[1], bc2_sqrt = s_coef[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) mat_adam1(u, ad, eidx[kk], s_tile[tid + 256 * kk], se[kk], gs, step_size, bc2_sqrt);
+        if (has_b) mat_adam1(u, ad, bidx, s_tile[512 + tid - 64], sb, gs, step_size, bc2_sqrt);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) u.grads[eidx[kk]] = s_tile[tid + 256 * kk];
+        if (has_b) u.grads[bidx] = s_tile[512 + tid - 64];
+    } else {
+        // compact slabs of the small tensors: one float per thread (mat_update_wgrad_kernel's fold), then its Adam step
+        const int sidx = (b - kMatWgJobs) * 256 + tid;
+        const bool live = sidx < 4 * u.n_small4;
+        int seg = 0;
+        for (int j = 1; j < u.n_seg; ++j) if (sidx >= u.seg_start[j]) seg = j;
+        const long gidx = live ? (long)u.seg_dst[seg] + (sidx - u.seg_start[seg]) : 0;
+        const MatPmv st = mat_pmv_load(u, ad, gidx, live);
+        float acc = 0.f;
+        if (live) {
+            const long stride = u.slab_stride;
+            constexpr int SB = 64;
+            for (int g0 = 0; g0 < u.nT; g0 += SB) {
+                float v[SB];
+#pragma unroll
+                for (int kk = 0; kk < SB; ++kk) v[kk] = (g0 + kk < u.nT) ? u.slabs[(long)(g0 + kk) * stride + sidx] : 0.f;
+#pragma unroll
+                for (int kk = 0; kk < SB; ++kk) acc += v[kk];
+            }
+            u.grads[gidx] = acc;
+            q = (double)acc * acc;
+        }
+        // block_sum(q) in its own association: wave sums, then the wave sum of the four of them
+        q = tail_wave_sum(q);
+        if (lane == 0) s_red[wave] = q;
+        __syncthreads();
+        if (wave == 0) {
+            q = tail_wave_sum(lane < 4 ? s_red[lane] : 0.0);
+            mat_tail_sync_wave0(ad, td, tag, b, t_next, pre_t, pre_bc1, pre_bc2s, lr, q, s_coef);
+        }
+        __syncthreads();
+        if (live) mat_adam1(u, ad, gidx, acc, st, s_coef[0], s_coef[1], s_coef[2]);
+    }
+}
+
 static size_t mat_lds_bytes(int O) {
     const size_t OS = 16 * ((O + 15) / 16) + 4;
     return (256 + 4 * 128 + 4 * 272 + kRows * kMXS + 2 * kRows * OS + 34 * (size_t)kMTile) * 4;
@@ -1443,6 +1654,51 @@ extern "C" int ppoaf_mat_update_reduce(const ppoaf_mat_update_args_t* args, ppoa
     hipLaunchKernelGGL(mat_update_reduce_kernel, dim3((unsigned)((n4 + kMatRedThreads - 1) / kMatRedThreads) + 1u),
                        dim3(kMatRedThreads), 0, (hipStream_t)stream, u);
     return check_launch("mat_update_reduce");
+}
+
+extern "C" int ppoaf_mat_update_tail_ctl_bytes(const ppoaf_mat_update_args_t* args, int64_t* bytes_out) {
+    PPOAF_REQUIRE(args && bytes_out, "mat_update_tail_ctl_bytes: null argument");
+    MatDev u;
+    const int rc = make_mat(args, u);
+    if (rc) return rc;
+    PPOAF_REQUIRE(u.split, "mat_update_tail_ctl_bytes: args->split_workspace is not set");
+    *bytes_out = (int64_t)kTailRecOff + 16 * (int64_t)(kMatWgJobs + (4 * u.n_small4 + 255) / 256);
+    return PPOAF_OK;
+}
+
+extern "C" int ppoaf_mat_update_wgrad_adam(const ppoaf_mat_update_args_t* args, void* ctl, float* exp_avg, float* exp_avg_sq,
+                                           const float* lr, float beta1, float beta2, float eps, float grad_scale, float max_norm,
+                                           float* grad_norm_out, double wait_seconds, ppoaf_stream_t stream) {
+    MatDev u;
+    const int rc = make_mat(args, u);
+    if (rc) return rc;
+    PPOAF_REQUIRE(u.split, "mat_update_wgrad_adam: args->split_workspace is not set (the tail of the split-wgrad chain)");
+    PPOAF_REQUIRE(u.fuse_norm, "mat_update_wgrad_adam: args->fuse_norm must be set (the launch owns the step counter)");
+    PPOAF_REQUIRE(ctl && (((uintptr_t)ctl) & 63) == 0, "mat_update_wgrad_adam: control block missing or not 64-byte aligned");
+    PPOAF_REQUIRE(exp_avg && exp_avg_sq && lr, "mat_update_wgrad_adam: null optimiser state");
+    PPOAF_REQUIRE(wait_seconds > 0.0 && wait_seconds <= 600.0, "mat_update_wgrad_adam: wait_seconds=%g", wait_seconds);
+    const int nsb = (4 * u.n_small4 + 255) / 256;
+    TailDev td;
+    td.ctl = reinterpret_cast<TailCtl*>(ctl);
+    td.budget = (long long)(wait_seconds * 1.0e8);
+    td.nblk = kMatWgJobs + nsb;
+    td.jobs_a = 1 << 30; td.jobs_c = 0; td.per_xcd = 1;       // one optimiser: every record belongs to the one norm
+    PPOAF_REQUIRE(td.nblk <= 64 * kTailMaxRounds, "mat_update_wgrad_adam: %d workgroups, a polling wave holds %d records", td.nblk,
+                  64 * kTailMaxRounds);
+    static int per_cu = 0, cus = 0;            // all workgroups wait for each other: they must fit on the device together
+    if (per_cu == 0) {
+        int n = 0, dev = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(mat_update_wgrad_adam_kernel), 256, 0);
+        if (e != hipSuccess) { set_error("mat_update_wgrad_adam: occupancy query: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+        per_cu = n > 0 ? n : -1;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    PPOAF_REQUIRE(per_cu > 0 && (long)(td.nblk + 1) <= (long)per_cu * cus,
+                  "mat_update_wgrad_adam: %d workgroups cannot be resident together (%d per CU x %d CUs)", td.nblk + 1, per_cu, cus);
+    MatAdam ad{exp_avg, exp_avg_sq, lr, beta1, beta2, eps, grad_scale, max_norm, grad_norm_out};
+    hipLaunchKernelGGL(mat_update_wgrad_adam_kernel, dim3((unsigned)(td.nblk + 1)), dim3(256), 0, (hipStream_t)stream, u, nsb, ad, td);
+    return check_launch("mat_update_wgrad_adam");
 }
 
 extern "C" int ppoaf_mat_update_split_workspace_bytes(const ppoaf_mat_update_args_t* args, int64_t* bytes_out) {
