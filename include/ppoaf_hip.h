@@ -730,6 +730,18 @@ int ppoaf_mat_update_fwd_bwd_timed(const ppoaf_mat_update_args_t* args, void* st
                                    ppoaf_stream_t stream);
 int ppoaf_mat_update_reduce(const ppoaf_mat_update_args_t* args, ppoaf_stream_t stream);
 int ppoaf_mat_update_split_workspace_bytes(const ppoaf_mat_update_args_t* args, int64_t* bytes_out);
+/* Fused tail of K15's split-wgrad chain (ABI 5; single rank): ppoaf_mat_update_fwd_bwd -> ppoaf_mat_update_wgrad_adam -- TWO
+ * launches per mini-batch.  The weight gradients of the 18 linears and the small tensors (ppoaf_mat_update_reduce's jobs, bit
+ * for bit), the clip norm from tagged per-workgroup records every workgroup waits for, and clip + Adam on the workgroup's
+ * own elements (mat_policy.py:677-699: one optimiser over actor + critic; ppoaf_adam_step_prenormed's arithmetic) in one
+ * launch.  args->fuse_norm must be set (the launch advances step_count); exp_avg / exp_avg_sq / lr / betas / eps / max_norm /
+ * grad_norm_out as for ppoaf_adam_step_prenormed.  ctl: ppoaf_mat_update_tail_ctl_bytes() bytes of device memory, 64-byte
+ * aligned, zeroed once and kept across launches; its third 32-bit word is non-zero after a launch in which a wait ran out
+ * of wait_seconds (results invalid).  All workgroups must be resident together (checked). */
+int ppoaf_mat_update_tail_ctl_bytes(const ppoaf_mat_update_args_t* args, int64_t* bytes_out);
+int ppoaf_mat_update_wgrad_adam(const ppoaf_mat_update_args_t* args, void* ctl, float* exp_avg, float* exp_avg_sq,
+                                const float* lr, float beta1, float beta2, float eps, float grad_scale, float max_norm,
+                                float* grad_norm_out, double wait_seconds, ppoaf_stream_t stream);
 /* number of squared-norm partials a fuse_norm reduce launch leaves (n_norm_partials of ppoaf_adam_step_prenormed;
  * norm_scratch must hold 2 + that many doubles); -1 on invalid args */
 int ppoaf_mat_update_norm_partials(const ppoaf_mat_update_args_t* args);

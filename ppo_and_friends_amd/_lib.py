@@ -223,6 +223,9 @@ SIGNATURES = {
     "ppoaf_mat_update_fwd_bwd": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
     "ppoaf_mat_update_fwd_bwd_timed": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr, _ptr, _ptr]),
     "ppoaf_mat_update_reduce": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr]),
+    "ppoaf_mat_update_tail_ctl_bytes": (C.c_int, [C.POINTER(MatUpdateArgs), C.POINTER(C.c_int64)]),
+    "ppoaf_mat_update_wgrad_adam": (C.c_int, [C.POINTER(MatUpdateArgs), _ptr, _ptr, _ptr, _ptr, C.c_float, C.c_float, C.c_float,
+                                              C.c_float, C.c_float, _ptr, C.c_double, _ptr]),
     "ppoaf_mat_update_split_workspace_bytes": (C.c_int, [C.POINTER(MatUpdateArgs), C.POINTER(C.c_int64)]),
     "ppoaf_mat_update_norm_partials": (C.c_int, [C.POINTER(MatUpdateArgs)]),
     "ppoaf_mat_policy_step": (C.c_int, [C.POINTER(MatStepArgs), _ptr]),

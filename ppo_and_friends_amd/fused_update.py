@@ -1209,9 +1209,47 @@ class FusedMatUpdate(FusedPolicyUpdate):
         self.n_full, self.tail = N // self.B, N % self.B
         self.n_done = 0
 
+    # ---- fused tail of K15's split-wgrad chain (csrc/mat_update.hip: mat_update_wgrad_adam_kernel): weight gradients, the
+    # clip norm from tagged records and clip + Adam in ONE launch (single rank) -- two launches per mini-batch
+    def tail_reason(self):
+        import os
+        if os.environ.get("PPOAF_FUSED_TAIL", "1") == "0":
+            return "off (PPOAF_FUSED_TAIL=0)"
+        if getattr(self, "_tail_disabled", ""):
+            return "disabled after a failed launch: " + self._tail_disabled
+        if not self.split:
+            return "the slab form runs (" + self.split_reason + ")"
+        if self.multi:
+            return "N > 1: the gradient exchange sits between the weight gradients and the optimiser step"
+        return ""
+
+    def _epoch_state(self):
+        pol = self.pol
+        opt, ac = pol.actor_critic_optim, pol.actor_critic
+        return [ac.flat_params, opt.exp_avg, opt.exp_avg_sq, opt.step_count, self.vn_mean, self.vn_var, self.vn_count, pol.buffer.values]
+
+    def _mat_tail_ctl(self, args):
+        ctl = getattr(self, "_tail_ctl", None)
+        if ctl is None:
+            need = C.c_int64(0)
+            _lib.check(self._lib.ppoaf_mat_update_tail_ctl_bytes(C.byref(args), C.byref(need)), "mat_update_tail_ctl_bytes")
+            ctl = self._tail_ctl = torch.zeros((int(need.value) + 63) // 64 * 16, dtype=torch.int32, device=self.pol.device)
+        FusedPolicyUpdate.tail_launches += 1
+        return ctl.data_ptr()
+
     def _one(self, args):
         lib, st, ref = self._lib, K.stream(), C.byref(args)
         rc = lib.ppoaf_mat_update_fwd_bwd(ref, st)
+        if rc == 0 and self.tail_reason() == "":
+            opt, clip = self.pol.actor_critic_optim, self.pol.gradient_clip
+            rc = lib.ppoaf_mat_update_wgrad_adam(
+                ref, self._mat_tail_ctl(args), opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr(), opt.lr.data_ptr(), opt.betas[0],
+                opt.betas[1], opt.eps, 1.0, float(clip) if clip is not None else 0.0, opt.grad_norm.data_ptr(),
+                self.tail_wait_seconds, st)
+            self._tail_used = True
+            if rc != 0:
+                _lib.check(rc, "mat_update_wgrad_adam")
+            return
         if rc == 0:
             rc = lib.ppoaf_mat_update_reduce(ref, st)
         if rc != 0:

@@ -363,6 +363,47 @@ def test_c5_mat_split_wgrad_chain_matches_the_slab_form_at_full_size(monkeypatch
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2])
 
 
+def test_c5_mat_fused_tail_is_bitwise_the_three_launch_chain(monkeypatch):
+    """
+    K15's fused tail (round 4: mat_update_wgrad_adam_kernel -- weight gradients of the 18 linears and the small tensors, the
+    clip norm from tagged records every workgroup waits for, clip + Adam on the workgroup's own elements, ONE launch) against
+    ppoaf_mat_update_reduce + ppoaf_adam_step_prenormed at C5 size, a whole epoch each on the same rollout and shuffle
+    (512 mini-batches, 146 workgroups per launch): parameters, both Adam moments, the gradient bucket of the last
+    mini-batch, step counter, normaliser state and totals BITWISE equal, graph replay and eager launches alike.
+    """
+    from ppo_and_friends_amd import fused_update
+    outs = {}
+    for tail, graphs in (("0", True), ("1", True), ("1", False)):
+        monkeypatch.setenv("PPOAF_FUSED_TAIL", tail)
+        before = fused_update.FusedPolicyUpdate.tail_launches
+        ppo, E, T, A = _c_config("C5", use_graphs=graphs)
+        ppo.rollout()
+        pol = ppo.policies["p"]
+        pol.train()
+        fused = ppo._fused_updater("p", 256)
+        assert fused.split and (fused.tail_reason() == "") == (tail == "1"), (fused.split_reason, fused.tail_reason())
+        perm = torch.randperm(len(pol.dataset), device=pol.device, generator=torch.Generator(device=pol.device).manual_seed(7))
+        fused.begin_epoch(perm)
+        fused.run_epoch()
+        t = fused.end_epoch()
+        opt = pol.actor_critic_optim
+        n_mb = E * T // 256
+        assert t[8] == n_mb and int(opt.step_count.item()) == n_mb
+        assert (fused_update.FusedPolicyUpdate.tail_launches > before) == (tail == "1")
+        if tail == "1":
+            assert fused.tail_reason() == "" and int(fused._tail_ctl[2].item()) == 0 and int(fused._tail_ctl[0].item()) == n_mb
+        outs[(tail, graphs)] = (pol.actor_critic.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
+                                pol.actor_critic.flat_grads.clone(), t.copy(), fused.vn_mean.clone(), fused.vn_var.clone(),
+                                float(opt.grad_norm.item()))
+    ref = outs[("0", True)]
+    for key in (("1", True), ("1", False)):
+        got = outs[key]
+        for i, what in enumerate(("parameters", "exp_avg", "exp_avg_sq", "gradient bucket of the last mini-batch")):
+            assert torch.equal(got[i], ref[i]), f"{key}: {what} differ, max |d| {float((got[i] - ref[i]).abs().max()):.3e}"
+        assert np.array_equal(got[4], ref[4]), (got[4], ref[4])
+        assert torch.equal(got[5], ref[5]) and torch.equal(got[6], ref[6]) and got[7] == ref[7]
+
+
 def test_c3_icm_split_wgrad_chain_matches_the_slab_form_at_full_size(monkeypatch):
     """
     K14 at C3 size (B = 256, H = 128, O = 17, Box(6)): ONE mini-batch's gradient bucket of the split-wgrad chain (dz /
