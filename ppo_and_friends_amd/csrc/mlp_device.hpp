@@ -66,11 +66,6 @@ __device__ __forceinline__ float softplus_u(float x) { return x > 20.f ? x : log
 //      same way on both operands (lane slot s carries k = 4s+j at step j), which leaves the sum intact.
 
 // B fragments of one forward tile: fr[c] = W[o][16c + 4*slot .. +3], o = n0 + (lane&15); W row-major [*, H]
-#ifdef PPOAF_STAMPS
-#define PPOAF_DBG(bit) (g_dbg & (bit))
-#else
-#define PPOAF_DBG(bit) false
-#endif
 // Loads of data that ANOTHER CU of the same launch may have rewritten (the persistent update kernels: weights after
 // the Adam phase, slabs, activations, the gradient bucket, statistics).  A CU's vector L1 is never refreshed by
 // another CU's stores, so these loads must not be served by it.  NT = true: AGENT-SCOPE loads (`sc1`), the form the
@@ -78,21 +73,9 @@ __device__ __forceinline__ float softplus_u(float x) { return x > 20.f ? x : log
 // values as two 8-byte ones (MI355X_MICROARCH.md, inter-workgroup visibility, "8-B agent atomics" / `sc1` loads): they
 // miss in the L1 by definition and are served by the L2 all workers of a network share (one XCD), whatever other loads
 // have touched the same lines before.  (Rounds 1-2 used non-temporal loads here: a cache-policy HINT that happened to
-// bypass the L1 as long as every access to those lines was non-temporal; -DPPOAF_XCU_LOADS_NT keeps that form for A/B
-// timing.)  The producers' side is `s_waitcnt vmcnt(0)` + workgroup barrier before the flag store: their write-through
+// bypass the L1 as long as every access to those lines was non-temporal; measured the same speed)  The producers' side is `s_waitcnt vmcnt(0)` + workgroup barrier before the flag store: their write-through
 // stores have been acknowledged by that same L2.  NT = false: plain loads (separate launches: the kernel boundary does
 // the invalidation).
-#ifdef PPOAF_XCU_LOADS_NT
-template <bool NT> __device__ __forceinline__ float ld1(const float* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
-template <bool NT> __device__ __forceinline__ double ld1(const double* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
-template <bool NT> __device__ __forceinline__ float4 ld4(const float* p) {
-    if (NT) {
-        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-        return make_float4(v[0], v[1], v[2], v[3]);
-    }
-    return *reinterpret_cast<const float4*>(p);
-}
-#else
 template <bool NT> __device__ __forceinline__ float ld1(const float* p) {
     if (NT) return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     return *p;
@@ -102,18 +85,6 @@ template <bool NT> __device__ __forceinline__ double ld1(const double* p) {
                                                                      __HIP_MEMORY_SCOPE_AGENT));
     return *p;
 }
-#ifdef PPOAF_XCU_LOADS_X2
-template <bool NT> __device__ __forceinline__ float4 ld4(const float* p) {
-    if (NT) {
-        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-        const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
-                           __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
-    }
-    return *reinterpret_cast<const float4*>(p);
-}
-#else
 // 16 bytes in ONE instruction: `buffer_load_dwordx4 ... sc1` (two 8-byte agent-scope loads measured 8-10 % slower per
 // mini-batch at C4).  A buffer resource needs a wave-uniform base: the first active lane's address minus 2 GiB, each lane
 // then carries its own 32-bit byte offset (the lanes of a wave read one array: far less than 2 GiB apart).  The compiler
@@ -130,32 +101,18 @@ template <bool NT> __device__ __forceinline__ float4 ld4(const float* p) {
     }
     return *reinterpret_cast<const float4*>(p);
 }
-#endif
-#endif
 
 template <int HT, bool NT = false>
-__device__ __forceinline__ void load_fwd_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT],
-                                               int g_dbg = 0) {
+__device__ __forceinline__ void load_fwd_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT]) {
     const float* w = W + (long)(n0 + (lane & 15)) * (16 * HT) + 4 * (lane >> 4);
-    if (PPOAF_DBG(1)) {
-#pragma unroll
-        for (int c = 0; c < HT; ++c) fr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
 #pragma unroll
     for (int c = 0; c < HT; ++c) fr[c] = ld4<NT>(w + 16 * c);
 }
 // B fragments of one dgrad tile: fr[c] = { W[16c+4*slot+j][n0 + (lane&15)] }_j
 template <int HT, bool NT = false>
-__device__ __forceinline__ void load_dgrad_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT],
-                                                 int g_dbg = 0) {
+__device__ __forceinline__ void load_dgrad_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT]) {
     constexpr int H = 16 * HT;
     const float* w = W + (long)(4 * (lane >> 4)) * H + n0 + (lane & 15);
-    if (PPOAF_DBG(1)) {
-#pragma unroll
-        for (int c = 0; c < HT; ++c) fr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
 #pragma unroll
     for (int c = 0; c < HT; ++c) {
         const float* wp = w + (long)(16 * c) * H;

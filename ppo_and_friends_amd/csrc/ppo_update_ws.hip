@@ -63,8 +63,13 @@ struct WsCtl {
 #ifndef PPOAF_WS_STAMP_WORKER
 #define PPOAF_WS_STAMP_WORKER 0
 #endif
+#define PPOAF_WSTAMP_BEGIN()                                                                          \
+    unsigned long long t_prev = 0;                                                                    \
+    if (which == PPOAF_WS_STAMP_NET && w == PPOAF_WS_STAMP_WORKER && threadIdx.x == 0)                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory")
 #else
 #define PPOAF_WSTAMP(k) do {} while (0)
+#define PPOAF_WSTAMP_BEGIN() do {} while (0)
 #endif
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ppo_update_ws_smem[];
@@ -512,11 +517,7 @@ __device__ __forceinline__ void ws_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
     unsigned epoch = 0;
     const unsigned xg = (unsigned)(which * kWsMaxWorkers + w);                // exchange group of this worker (N > 1)
     long long xseq = ka0->xchg_ranks > 0 ? ka0->x.group_seq[xg] : 0;
-#ifdef PPOAF_WS_STAMPS
-    unsigned long long t_prev = 0;
-    if (which == PPOAF_WS_STAMP_NET && w == PPOAF_WS_STAMP_WORKER && threadIdx.x == 0)
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
-#endif
+    PPOAF_WSTAMP_BEGIN();
 
     for (int it = 0; it < n_mb; ++it) {
         KWsArgs* ka = ka0;
@@ -1168,11 +1169,7 @@ __device__ __forceinline__ void rt_worker(KWsArgs* ka0, WsCtl* ctl, const int w,
     unsigned epoch = 0;
     const unsigned xg = (unsigned)(which * kWsMaxWorkers + w);                // exchange group of this worker (N > 1)
     long long xseq = ka0->xchg_ranks > 0 ? ka0->x.group_seq[xg] : 0;
-#ifdef PPOAF_WS_STAMPS
-    unsigned long long t_prev = 0;
-    if (which == PPOAF_WS_STAMP_NET && w == PPOAF_WS_STAMP_WORKER && threadIdx.x == 0)
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
-#endif
+    PPOAF_WSTAMP_BEGIN();
     for (int it = 0; it < n_mb; ++it) {
         KWsArgs* ka = ka0;
         asm volatile("" : "+s"(ka));

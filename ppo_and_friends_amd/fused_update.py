@@ -1218,7 +1218,7 @@ class FusedMatUpdate(FusedPolicyUpdate):
         if getattr(self, "_tail_disabled", ""):
             return "disabled after a failed launch: " + self._tail_disabled
         if not self.split:
-            return "the slab form runs (" + self.split_reason + ")"
+            return "the slab form runs (" + getattr(self, "split_reason", "PPOAF_SPLIT_WGRAD=0") + ")"
         if self.multi:
             return "N > 1: the gradient exchange sits between the weight gradients and the optimiser step"
         return ""

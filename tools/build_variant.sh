@@ -1,6 +1,6 @@
 #!/bin/bash
 # diagnostic build of the library with extra -D flags -> tools/libppoaf_hip_<name>.so (select it with PPOAF_LIB=<path>)
-#   bash tools/build_variant.sh nt -DPPOAF_XCU_LOADS_NT
+#   bash tools/build_variant.sh tailstamps -DPPOAF_TAIL_STAMPS
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../ppo_and_friends_amd/csrc"
