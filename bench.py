@@ -93,18 +93,17 @@ def update_pmc_traffic(config, kernel):
     """
     import glob, re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_update_pmc.csv")))
-    if not files:
-        return None
-    vals = {}
-    for line in open(files[-1]):
-        m = re.match(r"^(C\d),(.*),(FETCH_SIZE|WRITE_SIZE),dispatches=(\d+),avg=([0-9.]+)", line)
-        if m and m.group(1) == config and m.group(2).replace("ppoaf::", "").startswith(kernel.split("<")[0]):
-            vals[m.group(3)] = (float(m.group(5)), int(m.group(4)))
-    if len(vals) != 2:
-        return None
-    return {"bytes": int((2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024),
-            "fetch_kb_raw": vals["FETCH_SIZE"][0], "write_kb": vals["WRITE_SIZE"][0], "dispatches": vals["FETCH_SIZE"][1],
-            "source": os.path.relpath(files[-1], ROOT)}
+    for path in reversed(files):                    # the newest collection that holds this (config, kernel)
+        vals = {}
+        for line in open(path):
+            m = re.match(r"^(C\d),(.*),(FETCH_SIZE|WRITE_SIZE),dispatches=(\d+),avg=([0-9.]+)", line)
+            if m and m.group(1) == config and m.group(2).replace("ppoaf::", "").startswith(kernel.split("<")[0]):
+                vals[m.group(3)] = (float(m.group(5)), int(m.group(4)))
+        if len(vals) == 2:
+            return {"bytes": int((2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024),
+                    "fetch_kb_raw": vals["FETCH_SIZE"][0], "write_kb": vals["WRITE_SIZE"][0], "dispatches": vals["FETCH_SIZE"][1],
+                    "source": os.path.relpath(path, ROOT)}
+    return None
 
 
 def parse():
