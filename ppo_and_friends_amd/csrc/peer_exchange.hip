@@ -123,7 +123,7 @@ extern "C" int ppoaf_peer_exchange_create(int rank, int n_ranks, int64_t bucket_
         return PPOAF_E_LAUNCH;
     }
     void* local = nullptr;
-    const size_t local_bytes = (4 + kXchgMaxGrid) * sizeof(long long) + 2 * kXchgMaxGrid * sizeof(double);
+    const size_t local_bytes = (4 + kXchgMaxGroups) * sizeof(long long) + 2 * kXchgMaxGroups * sizeof(double);
     e = hipMalloc(&local, local_bytes);
     if (e == hipSuccess) e = hipMemset(local, 0, local_bytes);
     if (e == hipSuccess) e = hipMemset(x->base, 0, x->bytes);
@@ -137,7 +137,7 @@ extern "C" int ppoaf_peer_exchange_create(int rank, int n_ranks, int64_t bucket_
     }
     x->dev.words = static_cast<long long*>(local);
     x->dev.group_seq = x->dev.words + 4;
-    x->dev.norm_partials = reinterpret_cast<double*>(x->dev.group_seq + kXchgMaxGrid);
+    x->dev.norm_partials = reinterpret_cast<double*>(x->dev.group_seq + kXchgMaxGroups);
     x->dev.my_flags = static_cast<long long*>(x->base);
     x->dev.my_slots = reinterpret_cast<float4*>(static_cast<char*>(x->base) + kXchgHeaderBytes);
     for (int p = 0; p < kMaxPeers; ++p) { x->dev.peer_flags[p] = nullptr; x->dev.peer_slots[p] = nullptr; }

@@ -9,19 +9,21 @@ namespace ppoaf {
 
 constexpr int kMaxPeers = PPOAF_PEER_EXCHANGE_MAX_RANKS;
 constexpr int kXchgThreads = 256;
-constexpr int kXchgMaxGrid = 256;               // every workgroup of an exchange launch must be resident (256 CUs)
-constexpr size_t kXchgHeaderBytes = (size_t)kXchgMaxGrid * kMaxPeers * 8;   // flag words of one rank [group][peer]; slots follow
+constexpr int kXchgMaxGrid = 256;               // stand-alone / slab-reduce exchange launches: one workgroup per CU, all resident
+constexpr int kXchgMaxGroups = 512;             // exchange groups an object has flag words for (the fused tail launch of a
+                                                // 256-wide critic has 368 job workgroups, two to three per CU)
+constexpr size_t kXchgHeaderBytes = (size_t)kXchgMaxGroups * kMaxPeers * 8;   // flag words of one rank [group][peer]; slots follow
 
 struct XchgDev {
     int rank, n_ranks;
     long n4;                                        // float4 elements of one slot
     long long* words;                               // local: [0] exchanges completed, [2] finish count, [3] error
-    long long* group_seq;                           // local [kXchgMaxGrid]: sequence number each workgroup has completed
+    long long* group_seq;                           // local [kXchgMaxGroups]: sequence number each workgroup has completed
     long long* my_flags;                            // this rank's flag words [group][peer] (polled locally)
     long long* peer_flags[kMaxPeers];               // rank p's flag words (remote store target)
     const float4* peer_slots[kMaxPeers];            // rank p's two slots
     float4* my_slots;
-    double* norm_partials;                          // [kXchgMaxGrid][2]
+    double* norm_partials;                          // [kXchgMaxGroups][2]
 };
 
 // The exchange is organised per WORKGROUP: group g of every rank owns the same elements of the bucket, publishes

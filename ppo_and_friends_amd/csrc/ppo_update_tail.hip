@@ -579,7 +579,7 @@ extern "C" int ppoaf_ppo_update_wgrad_adam_exchange(const ppoaf_ppo_update_args_
     const long need = tail_exchange_floats(u, xc.seg_base);
     PPOAF_REQUIRE(xchg->dev.n4 * 4 >= need, "ppo_update_wgrad_adam_exchange: exchange slots of %ld floats, %ld needed "
                   "(ppoaf_ppo_update_tail_exchange_floats)", (long)xchg->dev.n4 * 4, need);
-    PPOAF_REQUIRE(td.nblk <= kXchgMaxGrid, "ppo_update_wgrad_adam_exchange: %d workgroups, one exchange holds %d groups", td.nblk, kXchgMaxGrid);
+    PPOAF_REQUIRE(td.nblk <= kXchgMaxGroups, "ppo_update_wgrad_adam_exchange: %d workgroups, one exchange holds %d groups", td.nblk, kXchgMaxGroups);
     PPOAF_REQUIRE(xchg->dev.n_ranks == u.n_ranks || !u.normalize_values, "ppo_update_wgrad_adam_exchange: %d ranks in the exchange, %d in args",
                   xchg->dev.n_ranks, u.n_ranks);
     PPOAF_REQUIRE(xchg_wait_seconds > 0.0 && xchg_wait_seconds <= 600.0, "ppo_update_wgrad_adam_exchange: xchg_wait_seconds=%g", xchg_wait_seconds);

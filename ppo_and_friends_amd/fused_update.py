@@ -171,10 +171,10 @@ class FusedPolicyUpdate:
         # group map (one group per worker), hence its own slots and flag words; opened collectively, like the first
         # the fused tail launch of the split-wgrad chain (csrc/ppo_update_tail.hip) carries the exchange as a phase of
         # every weight-gradient job (one exchange group per workgroup, job-major tiles in the slots: an object of its own
-        # again; at most 256 workgroups, i.e. no 256-wide network): two launches per mini-batch on N > 1 ranks as well.
+        # again; at most 512 workgroups = the flag words of one exchange object): two launches per mini-batch on N > 1 ranks too.
         self.xchg_sp = None
         if self.xchg is not None and type(self) is FusedPolicyUpdate and os.environ.get("PPOAF_FUSED_TAIL", "1") != "0" \
-                and os.environ.get("PPOAF_SPLIT_WGRAD", "auto") != "0" and self._split_blocks() <= 256 \
+                and os.environ.get("PPOAF_SPLIT_WGRAD", "auto") != "0" and self._split_blocks() <= 512 \
                 and max(self.actor_desc.in_dim, self.critic_desc.in_dim) <= 64 and self.B <= 512:
             self.xchg_sp, why = peer_exchange.open_exchange(self._tail_exchange_floats(), dev)
             if self.xchg_sp is not None and self.xchg_sp.status()[2] == 3:      # (the same kind on every rank: a collective choice)
