@@ -51,7 +51,7 @@ def device_clocks():
     try:
         p = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
         card = next(iter(json.loads(p.stdout).values()))
-        return {k.split(" clock")[0]: v for k, v in card.items() if "clock level" in k or "clock" in k.lower()}
+        return {k: v for k, v in card.items() if "clock" in k.lower()}            # the driver's own wording, untouched
     except Exception:                                       # noqa: BLE001 -- a report field, never a reason to fail the bench
         return None
 
@@ -324,7 +324,8 @@ def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
             # split-wgrad chain: this kernel runs the forward and the input-gradient pass; the weight-gradient third is
             # ppo_update_wgrad_kernel's (the output layer's few wgrad FLOPs stay here and are not counted)
             passes = 2
-            desc = "2 x 2 x sum(Linear weights of actor + critic) x B (forward + dgrad; the wgrad third runs in ppo_update_wgrad_kernel)"
+            desc = ("2 x 2 x sum(Linear weights of actor + critic) x B (forward + dgrad; the wgrad third runs in the tail "
+                    "launch, ppo_update_wgrad_adam_kernel)")
         if fused.split:
             kernel = kernel.replace(">", ", true>")                  # the split-wgrad instantiation of the same kernel
         for _ in range(launches):
@@ -343,9 +344,9 @@ def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
             "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 5), "flop_per_launch": int(flop), "flop_formula": desc,
             "avg_launch_us": round(avg, 2), "median_launch_us": round(us[len(us) // 2], 2), "launches": len(us),
             "launches_per_step": (N // B) * ppo.epochs_per_iter,
-            "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on eager launches of the fwd_bwd -> reduce -> Adam chain "
-                      "right after the timed region (in-region launches are hipGraph nodes); profiles/ holds the rocprofv3 "
-                      "summary of the same command",
+            "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on eager launches of the update chain right after the timed "
+                      "region (in-region launches are hipGraph nodes: 18.3 us for this kernel at C2 under replay, "
+                      "profiles/r04_C2_kernel_stats.csv); profiles/ holds the rocprofv3 summary of the same command",
             "traffic": None if pmc is None else pmc["bytes"],
             "traffic_source": None if pmc is None else f"{pmc['source']}: 2 x FETCH_SIZE + WRITE_SIZE per launch ({pmc['dispatches']} launches)"}
 
