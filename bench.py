@@ -76,7 +76,8 @@ def pmc_traffic():
             vals[(m.group(1), m.group(2))] = float(m.group(3))
     out = {}
     for name, mult in (("ppoaf::gae_rtg_chunked_kernel", 1.0), (STREAM_KERNEL, 2.0)):
-        f, w = vals.get((name, "FETCH_SIZE")), vals.get((name, "WRITE_SIZE"))
+        pick = lambda c: next((v for (k, cc), v in vals.items() if cc == c and k.startswith(name)), None)   # template arguments vary
+        f, w = pick("FETCH_SIZE"), pick("WRITE_SIZE")
         if f is not None and w is not None:
             out[name] = int((mult * f + w) * 1024)
     out["_source"] = os.path.relpath(files[-1], ROOT)
@@ -418,7 +419,7 @@ def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline
         achieved = gae_bytes / gae_avg_s / 1e9 if gae_avg_s > 0 else 0.0
         pmc = pmc_traffic() if (E, T) == (4096, 128) else {}
         res["roofline"] = {
-            "kernel": "gae_rtg_chunked_kernel" if E < (1 << 17) else "gae_rtg_stream_kernel", "bound": "hbm",
+            "kernel": ("gae_rtg_chunked_kernel<32, 8, 8>" if E >= 8192 else "gae_rtg_chunked_kernel<16, 8, 4>") if E < (1 << 17) else "gae_rtg_stream_kernel", "bound": "hbm",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": pmc.get("ppoaf::gae_rtg_chunked_kernel"), "traffic_source": pmc.get("_source"),
             "bytes_per_launch": gae_bytes, "avg_launch_us": round(gae_avg_s * 1e6, 3), "launches": len(gae_ms),

@@ -159,10 +159,8 @@ __global__ __launch_bounds__(TPB) void gae_rtg_stream_kernel(
 // recurrence (X_in -> B + M * X_in), the maps are composed (shuffles inside a wave, LDS across
 // waves), then each lane replays its chunk from the true carry with its inputs still in registers.
 // ---------------------------------------------------------------------------------------------
-constexpr int EW = 16;          // env columns per workgroup
-constexpr int TS = 64 / EW;     // time sub-chunks per wave
-constexpr int CW = 8;           // waves per workgroup
-constexpr int TC = 4;           // timesteps per lane chunk
+// EW env columns per workgroup, CW waves per workgroup, TC timesteps per lane chunk
+// (64 / EW time sub-chunks per wave; one tile = CW * TS * TC steps).
 
 struct Affine { double Ma, Ba, Mr, Br; };   // adv: X -> Ba + Ma X ; rtg: X -> Br + Mr X
 // apply `first` (later in time), then `second` (earlier in time)
@@ -179,11 +177,13 @@ __device__ __forceinline__ Affine shfl_affine(const Affine& a, int src_lane) {
     return o;
 }
 
+template <int EW, int CW, int TC>
 __global__ __launch_bounds__(64 * CW) void gae_rtg_chunked_kernel(
     const float* __restrict__ rewards, const float* __restrict__ values,
     const float* __restrict__ boot_value, const float* __restrict__ boot_reward,
     const int8_t* __restrict__ end_kind, int T, long E, GaeParams p,
     float* __restrict__ adv_out, float* __restrict__ rtg_out) {
+    constexpr int TS = 64 / EW;             // time sub-chunks per wave
     __shared__ Affine sWave[CW][EW];        // per-wave aggregate map
     __shared__ double sCarryA[EW], sCarryR[EW];
 
@@ -363,7 +363,7 @@ extern "C" int ppoaf_gae_rtg_tmajor_timed(const float* rewards, const float* val
                   "gae_rtg_tmajor: null pointer");
     PPOAF_REQUIRE(T >= 0 && E >= 0, "gae_rtg_tmajor: negative shape T=%d E=%ld", T, (long)E);
     if (T == 0 || E == 0) return PPOAF_OK;
-    PPOAF_REQUIRE((E + EW - 1) / EW <= 0x7fffffffL, "gae_rtg_tmajor: E too large");
+    PPOAF_REQUIRE((E + 15) / 16 <= 0x7fffffffL, "gae_rtg_tmajor: E too large");
     const GaeParams p = make_params(gamma, lambd, has_clip, clip_lo, clip_hi, use_gae);
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;
@@ -400,9 +400,31 @@ extern "C" int ppoaf_gae_rtg_tmajor_timed(const float* rewards, const float* val
                               s, e0, e1, 0, rewards, values, boot_value, boot_reward, end_kind, (int)T,
                               (long)E, p, adv_out, rtg_out);
     } else {
-        hipExtLaunchKernelGGL(gae_rtg_chunked_kernel, dim3((unsigned)((E + EW - 1) / EW)), dim3(64 * CW), 0,
-                              s, e0, e1, 0, rewards, values, boot_value, boot_reward, end_kind, (int)T,
-                              (long)E, p, adv_out, rtg_out);
+#ifdef PPOAF_GAE_SWEEP
+        int chunk = 0;
+        if (const char* ev = getenv("PPOAF_GAE_CHUNK")) chunk = atoi(ev);
+#define PPOAF_GAE_C(ID, EW_, CW_, TC_)                                                                                   \
+        if (chunk == ID) {                                                                                               \
+            hipExtLaunchKernelGGL((gae_rtg_chunked_kernel<EW_, CW_, TC_>), dim3((unsigned)((E + EW_ - 1) / EW_)),        \
+                                  dim3(64 * CW_), 0, s, e0, e1, 0, rewards, values, boot_value, boot_reward, end_kind,   \
+                                  (int)T, (long)E, p, adv_out, rtg_out);                                                 \
+            return check_launch("gae_rtg_tmajor(chunk variant)");                                                        \
+        }
+        PPOAF_GAE_C(1, 32, 8, 8) PPOAF_GAE_C(2, 32, 16, 4) PPOAF_GAE_C(3, 64, 8, 16) PPOAF_GAE_C(4, 64, 16, 8)
+        PPOAF_GAE_C(5, 16, 16, 2) PPOAF_GAE_C(6, 32, 4, 16) PPOAF_GAE_C(7, 16, 4, 8) PPOAF_GAE_C(8, 8, 8, 2)
+        PPOAF_GAE_C(9, 32, 8, 4) PPOAF_GAE_C(10, 16, 8, 2)
+#undef PPOAF_GAE_C
+#endif
+        // lane mapping by measurement (tools/gae_chunk_sweep.py, profiles/r04_gae_chunk_sweep.txt): 16 columns per
+        // workgroup while that still leaves at most ~3 workgroups per CU, 32 columns (128-B row segments) beyond
+        if (E >= 8192)
+            hipExtLaunchKernelGGL((gae_rtg_chunked_kernel<32, 8, 8>), dim3((unsigned)((E + 31) / 32)), dim3(512), 0,
+                                  s, e0, e1, 0, rewards, values, boot_value, boot_reward, end_kind, (int)T,
+                                  (long)E, p, adv_out, rtg_out);
+        else
+            hipExtLaunchKernelGGL((gae_rtg_chunked_kernel<16, 8, 4>), dim3((unsigned)((E + 15) / 16)), dim3(512), 0,
+                                  s, e0, e1, 0, rewards, values, boot_value, boot_reward, end_kind, (int)T,
+                                  (long)E, p, adv_out, rtg_out);
     }
     return check_launch("gae_rtg_tmajor");
 }
