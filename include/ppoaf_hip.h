@@ -37,7 +37,7 @@ typedef void* ppoaf_stream_t;            /* hipStream_t */
 #define PPOAF_E_INVALID    -1            /* bad argument / unsupported shape   */
 #define PPOAF_E_LAUNCH     -2            /* hipLaunch / runtime error          */
 
-#define PPOAF_ABI_VERSION 5
+#define PPOAF_ABI_VERSION 6
 
 int         ppoaf_abi_version(void);
 const char* ppoaf_last_error(void);
@@ -394,7 +394,15 @@ typedef struct {
      * dispatched to the other half return at once): when another update chain (K14: ppoaf_icm_update_args_t.xcd_half)
      * runs on a second stream, each keeps its weights and panels in its own four L2s -- C3: +2 % env-steps/s; alone the
      * confinement costs 1 % (C2).  Placement only changes speed. */
-    int32_t xcd_half, _pad2;
+    int32_t xcd_half;
+    /* ABI 6.  1 (split-wgrad chain only; ignored otherwise): the 16-row tiles of a 256-wide network of depth 2 .. 4 run on
+     * PAIRS of workgroups that split every hidden layer pass by output columns and exchange the halves through tagged
+     * records behind the panels of split_workspace (csrc/ppo_update_rowpair.hpp) -- ppoaf_ppo_update_split_workspace_bytes()
+     * then includes the record region.  Results are BITWISE those of row_pairs = 0.  The tag is the mini-batch index + 1:
+     * the caller zeroes split_workspace before the first launch and whenever mini-batch indices restart (every epoch).
+     * The region's first 32-bit word (byte offset ppoaf_ppo_update_row_pairs_error_offset()) is non-zero after a launch in
+     * which a partner did not answer within 2 s; that launch's results are invalid. */
+    int32_t row_pairs;
 } ppoaf_ppo_update_args_t;
 
 int ppoaf_ppo_update_fwd_bwd(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t stream);
@@ -412,6 +420,8 @@ int ppoaf_ppo_update_reduce(const ppoaf_ppo_update_args_t* args, int compute_nor
  * order: float32-rounding-level differences from the slab chain, bitwise reproducible run to run. */
 int ppoaf_ppo_update_split_workspace_bytes(const ppoaf_ppo_update_args_t* args, int64_t* bytes_out);
 int ppoaf_ppo_update_split_blocks(const ppoaf_ppo_update_args_t* args);
+/* byte offset of the row-pair error word inside split_workspace; -1 in *offset_out when args (row_pairs, shapes) select no pairs */
+int ppoaf_ppo_update_row_pairs_error_offset(const ppoaf_ppo_update_args_t* args, int64_t* offset_out);
 int ppoaf_ppo_update_wgrad(const ppoaf_ppo_update_args_t* args, ppoaf_stream_t stream);
 /* Fused tail of the split-wgrad chain (ABI 5; csrc/ppo_update_tail.hip): fwd_bwd (args->split_workspace set) ->
  * ppoaf_ppo_update_wgrad_adam -- TWO launches per mini-batch.  Everything from loss.backward()'s weight gradients to

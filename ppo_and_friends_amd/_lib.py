@@ -58,10 +58,10 @@ class PpoUpdateArgs(C.Structure):
                 ("loss_partials", C.c_void_p), ("totals", C.c_void_p),
                 ("mb_offset", C.c_int64), ("cursor_advance", C.c_int64),
                 ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64),
-                ("xcd_half", C.c_int32), ("_pad2", C.c_int32)]
+                ("xcd_half", C.c_int32), ("row_pairs", C.c_int32)]
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class PolicyStepArgs(C.Structure):
@@ -201,6 +201,7 @@ SIGNATURES = {
                                                C.c_int32, C.c_int32, C.c_double, _ptr, C.c_double, C.c_int32, _ptr, _ptr, _ptr]),
     "ppoaf_ppo_update_reduce": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
     "ppoaf_ppo_update_split_workspace_bytes": (C.c_int, [C.POINTER(PpoUpdateArgs), C.POINTER(C.c_int64)]),
+    "ppoaf_ppo_update_row_pairs_error_offset": (C.c_int, [C.POINTER(PpoUpdateArgs), C.POINTER(C.c_int64)]),
     "ppoaf_ppo_update_split_blocks": (C.c_int, [C.POINTER(PpoUpdateArgs)]),
     "ppoaf_ppo_update_wgrad": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr]),
     "ppoaf_ppo_update_tail_ctl_bytes": (C.c_int, [C.POINTER(PpoUpdateArgs), C.POINTER(C.c_int64)]),

@@ -105,8 +105,14 @@ template <bool NT> __device__ __forceinline__ float4 ld4(const float* p) {
 template <int HT, bool NT = false>
 __device__ __forceinline__ void load_fwd_frags(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT]) {
     const float* w = W + (long)(n0 + (lane & 15)) * (16 * HT) + 4 * (lane >> 4);
+    // chunks c and c + 1 lie in one 128-byte line of every row: even chunks first -- a load that asks for a line whose fill is
+    // still pending stalls the CU's L1 (round 4, stamps of the 256-wide row pairs: a 128 KB set arrived in 18 k cycles instead of
+    // 32 k; C2 +0.7 %)
 #pragma unroll
-    for (int c = 0; c < HT; ++c) fr[c] = ld4<NT>(w + 16 * c);
+    for (int c = 0; c < HT; c += 2) fr[c] = ld4<NT>(w + 16 * c);
+    __builtin_amdgcn_sched_barrier(0);                    // (the scheduler would sort the loads by offset again)
+#pragma unroll
+    for (int c = 1; c < HT; c += 2) fr[c] = ld4<NT>(w + 16 * c);
 }
 // B fragments of one dgrad tile: fr[c] = { W[16c+4*slot+j][n0 + (lane&15)] }_j
 template <int HT, bool NT = false>
@@ -119,6 +125,43 @@ __device__ __forceinline__ void load_dgrad_frags(const float* __restrict__ W, in
         fr[c] = make_float4(ld1<NT>(wp), ld1<NT>(wp + H), ld1<NT>(wp + 2 * H), ld1<NT>(wp + 3 * H));
     }
 }
+// The same fragments through a buffer resource on the (wave-uniform) weight matrix: every load of a set shares ONE
+// per-lane byte offset, the chunk / row displacement rides in the instruction's immediate or scalar offset -- no 64-bit
+// address pair per load (the 64 scalar loads of a 256-wide dgrad set cost 128 address VGPRs as global loads: with them
+// two sets cannot be in flight at once).  Forward chunks c and c + 1 share a 128-byte line of every row: even chunks
+// first -- a load that asks for a line whose fill is still pending stalls the CU's L1 (stamps: a 128 KB set arrived in
+// 18 k cycles instead of 32 k).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frag_rsrc(const float* W) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ float4 frag_u4(const ppoaf_u32x4 v) {
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+template <int HT>
+__device__ __forceinline__ void load_fwd_frags_buf(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT]) {
+    const __amdgpu_buffer_rsrc_t rs = frag_rsrc(W);
+    const unsigned off = (unsigned)(((n0 + (lane & 15)) * (16 * HT) + 4 * (lane >> 4)) * 4);
+#pragma unroll
+    for (int c = 0; c < HT; c += 2) fr[c] = frag_u4(__builtin_amdgcn_raw_buffer_load_b128(rs, off + 64u * c, 0, 0));
+    __builtin_amdgcn_sched_barrier(0);                    // (the scheduler would sort the loads by offset again)
+#pragma unroll
+    for (int c = 1; c < HT; c += 2) fr[c] = frag_u4(__builtin_amdgcn_raw_buffer_load_b128(rs, off + 64u * c, 0, 0));
+}
+template <int HT>
+__device__ __forceinline__ void load_dgrad_frags_buf(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT]) {
+    constexpr int H = 16 * HT;
+    const __amdgpu_buffer_rsrc_t rs = frag_rsrc(W);
+    const unsigned off = (unsigned)((4 * (lane >> 4) * H + n0 + (lane & 15)) * 4);
+#pragma unroll
+    for (int c = 0; c < HT; ++c) {
+        const int row = 16 * c * H * 4;
+        fr[c] = make_float4(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, row, 0)),
+                            __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, row + H * 4, 0)),
+                            __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, row + 2 * H * 4, 0)),
+                            __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, row + 3 * H * 4, 0)));
+    }
+}
+
 // acc[16 rows, 16 cols] = init + A[16, H] . frags ; A rows in LDS with stride HS.  Two accumulators
 // (even / odd chunks) keep the matrix pipe issuing back to back instead of waiting on its own result.
 template <int HT>
@@ -141,6 +184,61 @@ __device__ __forceinline__ f32x4 mfma_rows_x_frags(const float* __restrict__ A, 
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, fr[c].z, acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, fr[c].w, acc0, 0, 0, 0);
         }
+    }
+    return acc0 + acc1;
+}
+
+// ---- forward fragments as WHOLE LINES.  One CU's L1 delivers the fragment pattern above (an instruction = 16 rows x 64
+// bytes: sixteen half lines) at 14 B/clk whether the lines hit the L2 or not -- 128 KB in 9.1 k cycles -- and 8 rows x 128
+// bytes per instruction at 32 (L2 miss) to 45 B/clk (tools/probes/frag_stream_probe.hip: 4.0 k / 2.9 k cycles).  So a set
+// is REQUESTED line by line (raw[2 q + h] = 16 bytes of row n0 + 8 h + lane / 8, line q, block lane % 8) and turned into
+// fragment order when it is consumed: each line of the 16 rows goes through a wave-private LDS slot (rows 144 bytes apart:
+// conflict-free 16-byte reads), two slots so that line q + 1 is written while line q's MFMAs issue.  The MFMA operands and
+// their order are exactly mfma_rows_x_frags' -- bitwise the same sums.
+constexpr int kLineRow = 36;                              // floats between the rows of a slot (128 B + 16 B)
+constexpr int kLineSlot = 16 * kLineRow;                  // floats per slot; a wave owns two
+template <int HT>
+__device__ __forceinline__ void load_fwd_lines_buf(const float* __restrict__ W, int n0, int lane, float4 (&raw)[HT]) {
+    static_assert(HT % 2 == 0, "whole lines: H a multiple of 32");
+    const __amdgpu_buffer_rsrc_t rs = frag_rsrc(W);
+    const unsigned off = (unsigned)(((n0 + (lane >> 3)) * (16 * HT) + 4 * (lane & 7)) * 4);
+#pragma unroll
+    for (int q = 0; q < HT / 2; ++q) {
+        raw[2 * q] = frag_u4(__builtin_amdgcn_raw_buffer_load_b128(rs, off + 128u * q, 0, 0));
+        raw[2 * q + 1] = frag_u4(__builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)(8 * 16 * HT * 4) + 128u * q, 0, 0));
+    }
+}
+template <int HT>
+__device__ __forceinline__ f32x4 mfma_rows_x_lines(const float* __restrict__ A, int HS, int lane, const float4 (&raw)[HT],
+                                                   float init, float* __restrict__ scratch) {
+    const float* arow = A + (lane & 15) * HS + 4 * (lane >> 4);
+    float* wr = scratch + (lane >> 3) * kLineRow + 4 * (lane & 7);
+    const float* rd = scratch + (lane & 15) * kLineRow + 4 * (lane >> 4);
+    f32x4 acc0 = {init, init, init, init};
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<float4*>(wr) = raw[0];
+    *reinterpret_cast<float4*>(wr + 8 * kLineRow) = raw[1];
+#pragma unroll
+    for (int q = 0; q < HT / 2; ++q) {
+        const int slot = (q & 1) * kLineSlot;
+        __builtin_amdgcn_wave_barrier();                  // (LDS executes a wave's instructions in order: no wait between the lanes' write and read)
+        const float4 f0 = *reinterpret_cast<const float4*>(rd + slot);
+        const float4 f1 = *reinterpret_cast<const float4*>(rd + slot + 16);
+        __builtin_amdgcn_wave_barrier();
+        if (q + 1 < HT / 2) {
+            *reinterpret_cast<float4*>(wr + (kLineSlot - slot)) = raw[2 * q + 2];
+            *reinterpret_cast<float4*>(wr + (kLineSlot - slot) + 8 * kLineRow) = raw[2 * q + 3];
+        }
+        const float4 a0 = *reinterpret_cast<const float4*>(arow + 32 * q);
+        const float4 a1 = *reinterpret_cast<const float4*>(arow + 32 * q + 16);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, f0.x, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, f0.y, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, f0.z, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, f0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, f1.x, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, f1.y, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, f1.z, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, f1.w, acc1, 0, 0, 0);
     }
     return acc0 + acc1;
 }

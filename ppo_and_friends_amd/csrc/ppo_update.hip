@@ -12,7 +12,7 @@
 // writes its weight-gradient partial to a private slab with plain coalesced stores; the slabs
 // are summed in a fixed order by the reduce kernel, so results are bitwise reproducible (float
 // atomics would not be) and nothing needs zeroing.
-#include "ppo_update_rowtile.hpp"
+#include "ppo_update_rowpair.hpp"
 #include <hip/hip_ext.h>
 #include "peer_exchange_device.hpp"
 #include <cstdlib>
@@ -39,6 +39,32 @@ __global__ __launch_bounds__(kThreadsU) void ppo_update_fwd_bwd_kernel(UpdateDev
     if (g >= u.n_wg) return;                               // uniform per workgroup, before any barrier
     if (which == 0) ppo_update_fwd_bwd_body<HTA, false, UpdateDev, RowtileNoHook, SPLIT>(u, 0, g);
     else ppo_update_fwd_bwd_body<HTC, false, UpdateDev, RowtileNoHook, SPLIT>(u, 1, g);
+}
+
+// args->row_pairs (split-wgrad chain): a 256-wide network's row tiles on pairs of workgroups (ppo_update_rowpair.hpp); the
+// other network's tiles as above.  Workgroup b runs on XCD b % 8; slot j = b / 8 of an XCD holds tile pair member j & 1.
+template <int HTA, int HTC>
+__global__ __launch_bounds__(kThreadsU) void ppo_update_fwd_bwd_pair_kernel(UpdateDev u, PairDev pd) {
+    const int b = blockIdx.x, x = b & 7, j = b >> 3;
+    int which, g, hf = 0;
+    if (u.confine) {
+        if ((x >> 2) != u.confine - 1) return;
+        which = (x & 3) >> 1;
+        if (which == 0 ? HTA == 16 : HTC == 16) { hf = j & 1; g = ((j >> 1) << 1) | (x & 1); }
+        else g = (j << 1) | (x & 1);
+    } else {
+        which = x >> 2;
+        if (which == 0 ? HTA == 16 : HTC == 16) { hf = j & 1; g = ((j >> 1) << 2) | (x & 3); }
+        else g = (j << 2) | (x & 3);
+    }
+    if (g >= u.n_wg) return;                               // uniform per workgroup, before any barrier
+    if (which == 0) {
+        if constexpr (HTA == 16) ppo_update_fwd_bwd_pair_body<16>(u, 0, g, hf, pd);
+        else ppo_update_fwd_bwd_body<HTA, false, UpdateDev, RowtileNoHook, true>(u, 0, g);
+    } else {
+        if constexpr (HTC == 16) ppo_update_fwd_bwd_pair_body<16>(u, 1, g, hf, pd);
+        else ppo_update_fwd_bwd_body<HTC, false, UpdateDev, RowtileNoHook, true>(u, 1, g);
+    }
 }
 
 // slabs -> gradient bucket in a fixed order.  The slabs were just written by other CUs, so every
@@ -330,7 +356,9 @@ int make_update_dev(const ppoaf_ppo_update_args_t* a, UpdateDev& u) {
         PPOAF_REQUIRE(u.net[0].in_dim <= 64 && u.net[1].in_dim <= 64 && u.B <= 512,
                       "ppo_update: the split-wgrad chain covers in_dim <= 64 and B <= 512 (got %d / %d, %ld)", u.net[0].in_dim,
                       u.net[1].in_dim, u.B);
-        const size_t need = ws_layout(u, &u.sp, reinterpret_cast<char*>(a->split_workspace));
+        size_t need = ws_layout(u, &u.sp, reinterpret_cast<char*>(a->split_workspace));
+        PPOAF_REQUIRE(a->row_pairs == 0 || a->row_pairs == 1, "ppo_update: row_pairs=%d (0 or 1)", a->row_pairs);
+        if (a->row_pairs) need = pair_region_offset(u) + pair_region_layout(u, nullptr, nullptr);      // the record region comes last
         PPOAF_REQUIRE((size_t)a->split_workspace_bytes >= need, "ppo_update: split_workspace of %ld B, %zu needed",
                       (long)a->split_workspace_bytes, need);
         u.split = 1;
@@ -360,6 +388,26 @@ static int launch_fwd_bwd_as(const UpdateDev& u, size_t lds, hipStream_t s, hipE
     return check_launch("ppo_update_fwd_bwd");
 }
 
+// split-wgrad chain with args->row_pairs: the 256-wide networks' tiles on workgroup pairs
+template <int HTA, int HTC>
+static int launch_fwd_bwd_pairs(const UpdateDev& u, const PairDev& pd, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_update_fwd_bwd_pair_kernel<HTA, HTC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PPOAF_E_LAUNCH; }
+        attr_set = true;
+    }
+    // slots per XCD: two per tile of a paired network (both networks share the grid: the wider need decides)
+    const unsigned per_slot = u.confine ? 2u : 4u;
+    const unsigned grid = 8u * 2u * (unsigned)((u.n_wg + per_slot - 1) / per_slot);
+    if (e0 || e1)
+        hipExtLaunchKernelGGL((ppo_update_fwd_bwd_pair_kernel<HTA, HTC>), dim3(grid), dim3(kThreadsU), lds, s, e0, e1, 0, u, pd);
+    else
+        hipLaunchKernelGGL((ppo_update_fwd_bwd_pair_kernel<HTA, HTC>), dim3(grid), dim3(kThreadsU), lds, s, u, pd);
+    return check_launch("ppo_update_fwd_bwd(row pairs)");
+}
+
 template <int HTA, int HTC>
 static int launch_fwd_bwd(const UpdateDev& u, size_t lds, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     return u.split ? launch_fwd_bwd_as<HTA, HTC, true>(u, lds, s, e0, e1) : launch_fwd_bwd_as<HTA, HTC, false>(u, lds, s, e0, e1);
@@ -384,6 +432,15 @@ extern "C" int ppoaf_ppo_update_fwd_bwd_timed(const ppoaf_ppo_update_args_t* arg
     hipStream_t s = (hipStream_t)stream;
     // instantiated (actor width, critic width) pairs; the host falls back to the torch path otherwise
     const int ha = u.net[0].H, hc = u.net[1].H;
+    if (u.split && args->row_pairs && (pair_eligible(u.net[0]) || pair_eligible(u.net[1]))) {
+        PairDev pd;
+        const size_t lds_pairs = lds + (size_t)kNW * 2 * kLineSlot * 4;        // + every wave's two line slots
+        PPOAF_REQUIRE(lds_pairs <= 160 * 1024, "ppo_update_fwd_bwd: row pairs need %zu B of LDS (> 160 KiB)", lds_pairs);
+        pair_region_layout(u, &pd, reinterpret_cast<char*>(args->split_workspace) + pair_region_offset(u));
+        if (ha == 128 && hc == 256 && pd.net_off[1]) return launch_fwd_bwd_pairs<8, 16>(u, pd, lds_pairs, s, e0, e1);
+        if (ha == 256 && hc == 256 && pd.net_off[0] && pd.net_off[1]) return launch_fwd_bwd_pairs<16, 16>(u, pd, lds_pairs, s, e0, e1);
+        // other shapes (a 256-wide network of depth 1 or > 4, a 256-wide actor beside a narrower critic): one workgroup per tile
+    }
     if (ha == 32 && hc == 32) return launch_fwd_bwd<2, 2>(u, lds, s, e0, e1);
     if (ha == 64 && hc == 64) return launch_fwd_bwd<4, 4>(u, lds, s, e0, e1);
     if (ha == 128 && hc == 128) return launch_fwd_bwd<8, 8>(u, lds, s, e0, e1);

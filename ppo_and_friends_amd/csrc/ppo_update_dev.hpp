@@ -80,6 +80,37 @@ inline size_t ws_layout(const UpdateDev& u, WsDev* ws, char* base) {
     return off;
 }
 
+// ---- row tiles of 256-wide networks on workgroup pairs (args->row_pairs; ppo_update_rowpair.hpp): the record region
+constexpr int kPairHeaderBytes = 256;                 // word 0: error (a wait ran out of time)
+constexpr int kPairRecBytes = 16 * 1024;              // a half panel (16 rows x 128 floats) as 1024 records of 16 bytes
+constexpr int kPairMaxTiles = 32;                     // B <= 512 (split-wgrad chain)
+constexpr long long kPairWaitTicks = 200000000LL;     // 2 s of wall_clock64 (100 MHz)
+
+struct PairDev {
+    unsigned char* base;                              // header, then per network [phase][tile][half] record blocks
+    long net_off[2];                                  // byte offset of a network's blocks; 0: that network does not run in pairs
+};
+
+inline bool pair_eligible(const NetDev& n) { return n.H == 256 && n.depth >= 2 && n.depth <= 4; }
+inline int pair_phases(const NetDev& n) { return 2 * n.depth - 3; }
+// the region's place does not move with the mini-batch size (a tail mini-batch's panels are laid out differently, and
+// nothing but records may ever be stored where records are polled): behind the panels of the FULL batch size
+inline size_t pair_region_offset(const UpdateDev& u) {
+    UpdateDev f = u;
+    if (u.batch_stride > f.B) f.B = u.batch_stride;
+    return ws_layout(f, nullptr, nullptr);
+}
+inline size_t pair_region_layout(const UpdateDev& u, PairDev* p, char* region) {
+    size_t off = kPairHeaderBytes;
+    for (int w = 0; w < 2; ++w) {
+        const bool on = pair_eligible(u.net[w]);
+        if (p) p->net_off[w] = on ? (long)off : 0;
+        if (on) off += (size_t)pair_phases(u.net[w]) * kPairMaxTiles * 2 * kPairRecBytes;
+    }
+    if (p) p->base = reinterpret_cast<unsigned char*>(region);
+    return off;
+}
+
 constexpr int kWgradThreads = 256;
 
 // per-mini-batch bookkeeping of the split-wgrad chain, by ONE wave (threads 0..63 of a workgroup): loss partials -> totals

@@ -1700,7 +1700,23 @@ extern "C" int ppoaf_ppo_update_split_workspace_bytes(const ppoaf_ppo_update_arg
     PPOAF_REQUIRE(u.net[0].in_dim <= 64 && u.net[1].in_dim <= 64 && u.B <= 512,
                   "ppo_update_split_workspace_bytes: the split-wgrad chain covers in_dim <= 64 and B <= 512 (got %d / %d, %ld)",
                   u.net[0].in_dim, u.net[1].in_dim, u.B);
-    *bytes_out = (int64_t)ws_layout(u, nullptr, nullptr);
+    size_t need = ws_layout(u, nullptr, nullptr);
+    if (a.row_pairs) need = pair_region_offset(u) + pair_region_layout(u, nullptr, nullptr);
+    *bytes_out = (int64_t)need;
+    return PPOAF_OK;
+}
+
+extern "C" int ppoaf_ppo_update_row_pairs_error_offset(const ppoaf_ppo_update_args_t* args, int64_t* offset_out) {
+    PPOAF_REQUIRE(args && offset_out, "ppo_update_row_pairs_error_offset: null argument");
+    ppoaf_ppo_update_args_t a = *args;
+    a.split_workspace = nullptr;
+    UpdateDev u;
+    int rc = make_update_dev(&a, u);
+    if (rc) return rc;
+    const int ha = u.net[0].H, hc = u.net[1].H;
+    const bool pairs = a.row_pairs && ((ha == 128 && hc == 256 && pair_eligible(u.net[1])) ||
+                                       (ha == 256 && hc == 256 && pair_eligible(u.net[0]) && pair_eligible(u.net[1])));
+    *offset_out = pairs ? (int64_t)pair_region_offset(u) : -1;
     return PPOAF_OK;
 }
 

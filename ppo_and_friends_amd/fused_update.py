@@ -239,6 +239,26 @@ class FusedPolicyUpdate:
         else:
             _lib.check(lib.ppoaf_ppo_update_reduce(ref, 1, st), "ppo_update_reduce")
 
+    # ---- split-wgrad chain, 256-wide networks: a row tile on a PAIR of workgroups (csrc/ppo_update_rowpair.hpp)
+    row_pairs = True                   # False: one workgroup per 16-row tile (bitwise the same results; tests compare the two)
+    pair_launches = 0                  # fwd_bwd launches issued with row pairs in this process (graph replays not counted)
+
+    def pairs_reason(self):
+        """'' when fwd_bwd runs the 256-wide networks' row tiles on workgroup pairs, else why not."""
+        if type(self) is not FusedPolicyUpdate:
+            return "K12 (MLP policies) only"
+        if not self.row_pairs:
+            return "off (row_pairs = False)"
+        if getattr(self, "_pairs_disabled", ""):
+            return "disabled after a failed launch: " + self._pairs_disabled
+        if not self.split:
+            return "the slab chain runs (" + self.split_reason + ")"
+        a, c = self.actor_desc, self.critic_desc
+        ok = lambda d: d.hidden == 256 and 2 <= d.depth <= 4
+        if not ((a.hidden == 128 and ok(c)) or (ok(a) and ok(c))):
+            return "no 256-wide network of depth 2 .. 4 (beside a 128- or 256-wide actor)"
+        return ""
+
     # ---- fused tail of the split-wgrad chain: fwd_bwd -> wgrad + clip norms + Adam in one launch (two launches per mini-batch)
     tail_wait_seconds = 2.0            # bound of the in-kernel wait for the other workgroups' norm records
     tail_launches = 0                  # launches issued in this process (tests: the path really ran; graph replays not counted)
@@ -257,6 +277,10 @@ class FusedPolicyUpdate:
             return "the slab chain runs (" + self.split_reason + ")"
         if self._split_blocks() > 512:
             return f"{self._split_blocks()} weight-gradient workgroups (a polling wave of the fused launch holds 512 records)"
+        if self.multi and os.environ.get("PPOAF_SHARE_DEVICE", "0") == "1" and self._split_blocks() * self.world > 512:
+            # (tests: R ranks time-share ONE GPU.  Every rank's launch waits for the other ranks' records, so all R launches must
+            #  be resident together: 2 x 369 workgroups of a 256-wide critic are not)
+            return f"{self.world} ranks share one device: {self._split_blocks()} workgroups each cannot all be resident at once"
         if self.multi and self.xchg_sp is None:
             return "N > 1 without an exchange for the fused tail launch (" + self.xchg_reason + ")"
         return ""
@@ -321,11 +345,19 @@ class FusedPolicyUpdate:
         a.mb_offset, a.cursor_advance = 0, 1
         a.xcd_half = getattr(self, "xcd_half", 0)        # 1 / 2: beside the ICM chain (ppo.py: _ppo_icm_epoch_overlapped)
         a.split_workspace, a.split_workspace_bytes = None, 0
+        a.row_pairs = 0
         if self.split:
+            a.row_pairs = int(self.pairs_reason() == "")
             if self._split_space is None:            # sized once for the full batch size; a tail mini-batch needs less
                 need = C.c_int64(0)
+                a.row_pairs = int(self.row_pairs)    # (room for the pairs' records whether or not they stay switched on)
                 _lib.check(self._lib.ppoaf_ppo_update_split_workspace_bytes(C.byref(a), C.byref(need)), "split_workspace_bytes")
                 self._split_space = torch.zeros(int(need.value), dtype=torch.uint8, device=pol.device)
+                off = C.c_int64(-1)
+                _lib.check(self._lib.ppoaf_ppo_update_row_pairs_error_offset(C.byref(a), C.byref(off)), "row_pairs_error_offset")
+                self._pair_region = int(off.value)   # -1: these shapes run no pairs
+                assert self._pair_region >= 0 or self.pairs_reason() != "", "the library runs no pairs for shapes pairs_reason() accepts"
+                a.row_pairs = int(self.pairs_reason() == "")
                 blocks = int(self._lib.ppoaf_ppo_update_split_blocks(C.byref(a)))
                 if pol.policy_norm_scratch.numel() < 6 + 2 * blocks:      # one pair of norm partials per wgrad workgroup
                     pol.policy_norm_scratch = torch.zeros(6 + 2 * blocks, dtype=torch.float64, device=pol.device)
@@ -381,6 +413,9 @@ class FusedPolicyUpdate:
             K.minibatch_moments(buf.advantages.view(-1), self.perm, buf.row_map, self.B, out=self.adv_records)
         self.cursor.zero_()
         self.totals.zero_()
+        if self._split_space is not None and getattr(self, "_pair_region", -1) >= 0:
+            # the pairs' records are tagged with the mini-batch index, which restarts now
+            self._split_space[self._pair_region:].zero_()
         sig = self._signature()
         if self._args.get("sig") != sig:
             self._args = {"sig": sig}
@@ -422,6 +457,9 @@ class FusedPolicyUpdate:
         ref = C.byref(args)
         single = not self.multi
         rc = lib.ppoaf_ppo_update_fwd_bwd(ref, st)
+        if args.row_pairs:
+            self._pairs_used = True
+            FusedPolicyUpdate.pair_launches += 1
         if rc == 0 and args.split_workspace:
             # split-wgrad chain: complete weight gradients from the published panels, then clip + Adam
             if self.tail_reason() == "":
@@ -582,6 +620,16 @@ class FusedPolicyUpdate:
                 return (f"ppo_update_ws: the last launch did not complete (error word {words[2]}, networks finished {words[3]} of 2, "
                         f"worker tickets drawn {words[0]} / {words[1]}): a network did not get all of its workgroups onto its XCD "
                         "(another process on this GPU, or a partition mode that exposes a single XCD?)")
+        if getattr(self, "_pairs_used", False):
+            self._pairs_used = False
+            word = self._split_space[self._pair_region:self._pair_region + 4].view(torch.int32)
+            if int(word.item()) != 0:
+                word.zero_()
+                self._pairs_disabled = "a workgroup's partner did not answer in time"
+                self._graphs.clear()                      # the captured chains begin with the paired launch
+                self._args = {"sig": self._args.get("sig")}
+                return ("ppo_update_fwd_bwd (row pairs): a wait for the partner workgroup's half ran out of time "
+                        "(another process on this GPU?)")
         ctl = getattr(self, "_tail_ctl", None)
         if ctl is not None and getattr(self, "_tail_used", False):
             self._tail_used = False
@@ -640,6 +688,10 @@ class FusedPolicyUpdate:
         if self.multi and self.xchg_ws is None:
             return "N > 1 without a K17 exchange for the persistent kernel (three-launch chain)"
         mask = self._ws_mask()
+        if mask < 0 and self.pairs_reason() == "" and self.tail_reason() == "":
+            # round 4 (C4, one box): fwd_bwd with the 256-wide critic's row tiles on workgroup pairs + the fused tail
+            # 39 us per mini-batch, this kernel 52-54.  PPOAF_WS_MODE=layered|rowtile still selects it.
+            return "a 256-wide network on row pairs: the two-launch chain is faster"
         if mask < 0 and max(self.actor_desc.hidden, self.critic_desc.hidden) < 256:
             # measured (C2, after the host-side shuffle prefetch stopped stalling): graph-replayed chain 29.4 us per
             # mini-batch, persistent kernel with both networks row-tiled 32.4 us.  The persistent kernel wins where a
@@ -678,7 +730,7 @@ class FusedPolicyUpdate:
         args = self._args_for(self.B)
         left = self.n_full
         self._ws_snapshot = None
-        if left > 0 and self.n_done == 0 and (self.ws_reason() == "" or self.tail_reason() == ""):
+        if left > 0 and self.n_done == 0 and (self.ws_reason() == "" or self.tail_reason() == "" or self.pairs_reason() == ""):
             # what the epoch starts from (a few buckets of <= 1 MB: device-to-device copies), should the launch not complete
             self._ws_snapshot = [t.clone() for t in self._epoch_state()]
         if left > 0 and self.ws_reason() == "":
@@ -742,7 +794,7 @@ class FusedPolicyUpdate:
     def end_epoch(self):
         """-> numpy totals[9] (sums of the 8 loss scalars over mini-batches, mini-batch count)."""
         ppo = self.ppo
-        if not self.multi and (getattr(self, "_ws_used", False) or getattr(self, "_tail_used", False)):
+        if not self.multi and (getattr(self, "_ws_used", False) or getattr(self, "_tail_used", False) or getattr(self, "_pairs_used", False)):
             torch.cuda.current_stream().synchronize()
             why = self._persistent_failure()
             if why:                                       # before anything of the failed epoch reaches the normaliser

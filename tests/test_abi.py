@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = built_lib.load()
     for name in _declared():
         assert hasattr(lib, name), f"libppoaf_hip.so lacks {name}"
-    assert lib.ppoaf_abi_version() == 5
+    assert lib.ppoaf_abi_version() == 6
 
 
 def test_ctypes_table_matches_header(built_lib):

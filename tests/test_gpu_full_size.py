@@ -319,6 +319,50 @@ def test_full_size_fused_tail_is_bitwise_the_three_launch_chain(name, monkeypatc
         assert torch.equal(got[5], ref[5]) and torch.equal(got[6], ref[6]) and got[7] == ref[7]
 
 
+@pytest.mark.parametrize("name", ["C3", "C4"])
+def test_full_size_row_pairs_are_bitwise_the_one_workgroup_tiles(name, monkeypatch):
+    """
+    Round 4: the 256-wide critic's 16-row tiles on PAIRS of workgroups (ppo_update_rowpair.hpp: every hidden pass split by
+    output columns, the halves exchanged as tagged records, 2 depth - 3 = 3 exchanges per mini-batch) against one
+    workgroup per tile, a whole epoch each at the BASELINE shapes on the same rollout and shuffle.  Each output tile is
+    accumulated in the same K order in both forms, so parameters, both Adam moments, the last gradient bucket, the critic
+    values written back, totals and normaliser state are BITWISE equal -- graph replay and eager launches alike -- and
+    no partner ever failed to answer.
+    """
+    from ppo_and_friends_amd import fused_update
+    monkeypatch.setenv("PPOAF_WS", "0")
+    monkeypatch.setenv("PPOAF_OVERLAP_ICM", "0")
+    outs = {}
+    for pairs, graphs in ((False, True), (True, True), (True, False)):
+        monkeypatch.setattr(fused_update.FusedPolicyUpdate, "row_pairs", pairs)
+        before = fused_update.FusedPolicyUpdate.pair_launches
+        ppo, E, T, A = _c_config(name, use_graphs=graphs)
+        ppo.rollout()
+        pol = ppo.policies["p"]
+        pol.train()
+        fused = ppo._fused_updater("p", 256)
+        assert fused.split and (fused.pairs_reason() == "") == pairs, (fused.split_reason, fused.pairs_reason())
+        perm = torch.randperm(len(pol.dataset), device=pol.device, generator=torch.Generator(device=pol.device).manual_seed(9))
+        for _ in range(2):                                   # the second epoch restarts the record tags
+            fused.begin_epoch(perm)
+            fused.run_epoch()
+            t = fused.end_epoch()
+        n_mb = E * T * A // 256
+        assert t[8] == n_mb and int(pol.policy_step_counts[0].item()) == int(pol.policy_step_counts[1].item()) == 2 * n_mb
+        assert (fused_update.FusedPolicyUpdate.pair_launches > before) == pairs
+        assert fused.pairs_reason() == ("" if pairs else "off (row_pairs = False)")           # no launch failed
+        outs[(pairs, graphs)] = (pol.policy_params.clone(), pol.policy_exp_avg.clone(), pol.policy_exp_avg_sq.clone(),
+                                 pol.policy_grads.clone(), pol.buffer.values.clone(), t.copy(), fused.vn_mean.clone(),
+                                 fused.vn_var.clone(), int(fused.cursor.item()))
+    ref = outs[(False, True)]
+    for key in ((True, True), (True, False)):
+        got = outs[key]
+        for i, what in enumerate(("parameters", "exp_avg", "exp_avg_sq", "gradient bucket of the last mini-batch", "values")):
+            assert torch.equal(got[i], ref[i]), f"{key}: {what} differ, max |d| {float((got[i] - ref[i]).abs().max()):.3e}"
+        assert np.array_equal(got[5], ref[5]), (got[5], ref[5])
+        assert torch.equal(got[6], ref[6]) and torch.equal(got[7], ref[7]) and got[8] == ref[8]
+
+
 def test_c5_mat_split_wgrad_chain_matches_the_slab_form_at_full_size(monkeypatch):
     """
     K15 at C5 size (52 token tiles, 832 token rows): ONE mini-batch's gradient bucket of the split-wgrad chain (input / dz

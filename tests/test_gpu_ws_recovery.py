@@ -17,6 +17,7 @@ def _run(monkeypatch, fail_first_launch, ws):
     from ppo_and_friends_amd.spaces import Box, Discrete
     from ppo_and_friends_amd import fused_update
     monkeypatch.setenv("PPOAF_WS", "1" if ws else "0")
+    monkeypatch.setenv("PPOAF_WS_MODE", "2")                 # (round 4: "auto" prefers the chain with row pairs for a 256-wide critic)
     dev = torch.device("cuda", 0)
     E, T, B, O, A = 8, 40, 32, 18, 3
     env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(5), T, dev, reward="uniform", seed=83, num_agents=A, critic_view="policy")
@@ -58,3 +59,35 @@ def test_failed_persistent_launch_is_redone_on_the_chain(monkeypatch):
     assert rec["stats"] == chain["stats"] and rec["vn"] == chain["vn"] and rec["steps"] == chain["steps"]
     ok = _run(monkeypatch, False, ws=True)
     assert ok["launches"] == 4 and ok["disabled"] == ""                            # 2 iterations x 2 epochs on the persistent kernel
+
+
+def test_failed_row_pair_launch_is_redone_with_one_workgroup_per_tile(monkeypatch):
+    """
+    Round 4: a fwd_bwd launch in which a workgroup's partner did not answer in time (ppo_update_rowpair.hpp: the error word
+    of the record region) costs one epoch's work, not the run: the epoch's starting state comes back, the pairs are
+    switched off (with the reason) and the epoch runs again with one workgroup per tile -- bitwise what a run with
+    row_pairs = False produces, since the two forms are bitwise equal anyway.  Simulated by setting the error word
+    after the first epoch's launches.
+    """
+    from ppo_and_friends_amd import fused_update
+    monkeypatch.setattr(fused_update.FusedPolicyUpdate, "row_pairs", False)
+    tiles = _run(monkeypatch, False, ws=False)
+    monkeypatch.setattr(fused_update.FusedPolicyUpdate, "row_pairs", True)
+    before = fused_update.FusedPolicyUpdate.pair_launches
+    orig = fused_update.FusedPolicyUpdate.run_epoch
+    state = {"failed": False, "updater": None}
+
+    def run_epoch(self):
+        orig(self)
+        state["updater"] = self
+        if not state["failed"]:
+            assert self.pairs_reason() == "", self.pairs_reason()
+            state["failed"] = True
+            self._split_space[self._pair_region:self._pair_region + 4].view(torch.int32).fill_(1)
+
+    monkeypatch.setattr(fused_update.FusedPolicyUpdate, "run_epoch", run_epoch)
+    rec = _run(monkeypatch, False, ws=False)
+    assert state["failed"] and fused_update.FusedPolicyUpdate.pair_launches > before
+    assert "did not answer" in state["updater"].pairs_reason()
+    assert torch.equal(rec["w"], tiles["w"]) and torch.equal(rec["m"], tiles["m"])
+    assert rec["stats"] == tiles["stats"] and rec["vn"] == tiles["vn"] and rec["steps"] == tiles["steps"]
