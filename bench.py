@@ -329,6 +329,8 @@ def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
                     "launch, ppo_update_wgrad_adam_kernel)")
         if fused.split:
             kernel = kernel.replace(">", ", true>")                  # the split-wgrad instantiation of the same kernel
+        if getattr(args, "row_pairs", 0):
+            kernel = f"ppo_update_fwd_bwd_pair_kernel<{ha}, {hc}>"   # a 256-wide network's row tiles on workgroup pairs
         for _ in range(launches):
             ev = (K.event_create(), K.event_create())
             fused.gradient_only(args, ev)                          # fwd_bwd (timed) + wgrad launch / slab reduce

@@ -368,7 +368,7 @@ int make_update_dev(const ppoaf_ppo_update_args_t* a, UpdateDev& u) {
 
 static size_t fwd_bwd_lds_bytes(const UpdateDev& u) {
     const size_t a = rowtile_lds_floats(u.net[0]), c = rowtile_lds_floats(u.net[1]);
-    return ((a > c ? a : c) * 4 + 15) / 16 * 16;
+    return ((a > c ? a : c) * 4 + 15) / 16 * 16 + kRowtileLineFloats * 4;
 }
 
 template <int HTA, int HTC, bool SPLIT>
@@ -434,8 +434,7 @@ extern "C" int ppoaf_ppo_update_fwd_bwd_timed(const ppoaf_ppo_update_args_t* arg
     const int ha = u.net[0].H, hc = u.net[1].H;
     if (u.split && args->row_pairs && (pair_eligible(u.net[0]) || pair_eligible(u.net[1]))) {
         PairDev pd;
-        const size_t lds_pairs = lds + (size_t)kNW * 2 * kLineSlot * 4;        // + every wave's two line slots
-        PPOAF_REQUIRE(lds_pairs <= 160 * 1024, "ppo_update_fwd_bwd: row pairs need %zu B of LDS (> 160 KiB)", lds_pairs);
+        const size_t lds_pairs = lds;
         pair_region_layout(u, &pd, reinterpret_cast<char*>(args->split_workspace) + pair_region_offset(u));
         if (ha == 128 && hc == 256 && pd.net_off[1]) return launch_fwd_bwd_pairs<8, 16>(u, pd, lds_pairs, s, e0, e1);
         if (ha == 256 && hc == 256 && pd.net_off[0] && pd.net_off[1]) return launch_fwd_bwd_pairs<16, 16>(u, pd, lds_pairs, s, e0, e1);

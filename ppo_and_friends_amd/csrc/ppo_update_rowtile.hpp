@@ -41,6 +41,22 @@ static __device__ unsigned long long g_ppo_update_stamps[2][16];
 // against a 135 KB slab) -- and the output layer's partials go to u.sp.outpart (folded in block order by that launch).
 struct RowtileNoHook { __device__ __forceinline__ bool operator()() const { return true; } };
 
+// A forward weight set of one output tile.  Separate launches (NT = false): requested as whole lines and turned into
+// fragment order through the wave's LDS slots when consumed (mlp_device.hpp: mfma_rows_x_lines; one CU's L1 delivers
+// the fragment pattern itself at a third of that rate).  Persistent forms (NT = true): agent-scope 16-byte loads in
+// fragment order, as before.  Same MFMA operands in the same order either way.
+template <int HT, bool NT>
+__device__ __forceinline__ void load_fwd_set(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT]) {
+    if constexpr (NT) load_fwd_frags<HT, true>(W, n0, lane, fr);
+    else load_fwd_lines_buf<HT>(W, n0, lane, fr);
+}
+template <int HT, bool NT>
+__device__ __forceinline__ f32x4 mfma_fwd_set(const float* __restrict__ A, int HS, int lane, const float4 (&fr)[HT], float init,
+                                              float* __restrict__ scratch) {
+    if constexpr (NT) return mfma_rows_x_frags<HT>(A, HS, lane, fr, init);
+    else return mfma_rows_x_lines<HT>(A, HS, lane, fr, init, scratch);
+}
+
 template <int HT, bool NT = false, typename U = UpdateDev, typename Hook = RowtileNoHook, bool SPLIT = false>
 __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int which, const int g,
                                                         const long mb_extra = 0, Hook before_weights = Hook()) {
@@ -99,6 +115,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     float* sD1 = sD0 + kRows * HS;                            // [16, HS]
     float* sOut = sD1 + kRows * HS;                           // [16, 16]
     float* sDOut = sOut + kRows * kMaxOut;                    // [16, 16]
+    float* sScr = sDOut + kRows * kMaxOut + wave * 2 * kLineSlot;   // this wave's two line slots (separate launches only)
 
     if (!NT && g == 0 && which == 0 && tid == 0) { u.norm_scratch[0] = 0.0; u.norm_scratch[1] = 0.0; }
 
@@ -123,8 +140,8 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     const bool copy_fits = n_bias <= kCopyRegs * kThreadsU && n_wout <= kCopyRegs * kThreadsU;
     auto request_weights = [&]() {
         if (deep && has_tile) {
-            load_fwd_frags<HT, NT>(P + offW(1), wave * 16, lane, fr);
-            load_fwd_frags<HT, NT>(P + offW(2), wave * 16, lane, fr2);
+            load_fwd_set<HT, NT>(P + offW(1), wave * 16, lane, fr);
+            load_fwd_set<HT, NT>(P + offW(2), wave * 16, lane, fr2);
         }
         if (l0_pre) {
             const float* w = P + offW(0) + (long)(wave * 16 + (lane & 15)) * in_dim;
@@ -259,7 +276,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
         }
     }
     // prefetch: fragments of the first hidden-to-hidden layer (or nothing if depth == 1)
-    if (!deep && depth > 1 && has_tile) load_fwd_frags<HT, NT>(P + offW(1), wave * 16, lane, fr);
+    if (!deep && depth > 1 && has_tile) load_fwd_set<HT, NT>(P + offW(1), wave * 16, lane, fr);
     __syncthreads();
     PPOAF_STAMP(2);
     if (SPLIT) {            // the block's input rows, zero padded to 64 columns: the layer-0 wgrad's K-panel
@@ -304,17 +321,17 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
             f32x4 acc;
             if (deep) {
                 if (l == 1) {
-                    acc = mfma_rows_x_frags<HT>(Hp, HS, lane, fr, sBias[l * H + o]);
+                    acc = mfma_fwd_set<HT, NT>(Hp, HS, lane, fr, sBias[l * H + o], sScr);
                     load_dgrad_frags<HT, NT>(P + offW(2), wave * 16, lane, fr);  // first backward phase, two phases early
                 } else {
-                    acc = mfma_rows_x_frags<HT>(Hp, HS, lane, fr2, sBias[l * H + o]);
+                    acc = mfma_fwd_set<HT, NT>(Hp, HS, lane, fr2, sBias[l * H + o], sScr);
                     load_dgrad_frags<HT, NT>(P + offW(1), wave * 16, lane, fr2); // second backward phase
                 }
             } else {
-            if (nt != wave) load_fwd_frags<HT, NT>(P + offW(l), nt * 16, lane, fr);
-            acc = mfma_rows_x_frags<HT>(Hp, HS, lane, fr, sBias[l * H + o]);
+            if (nt != wave) load_fwd_set<HT, NT>(P + offW(l), nt * 16, lane, fr);
+            acc = mfma_fwd_set<HT, NT>(Hp, HS, lane, fr, sBias[l * H + o], sScr);
             if (nt + kNW >= HT) {                           // last tile of this wave in this layer
-                if (l + 1 < depth) load_fwd_frags<HT, NT>(P + offW(l + 1), wave * 16, lane, fr);
+                if (l + 1 < depth) load_fwd_set<HT, NT>(P + offW(l + 1), wave * 16, lane, fr);
                 else load_dgrad_frags<HT, NT>(P + offW(l), wave * 16, lane, fr);   // first backward phase
             }
             }
@@ -475,6 +492,7 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
 }
 
 // dynamic LDS the body needs for one network
+constexpr size_t kRowtileLineFloats = (size_t)kNW * 2 * kLineSlot;         // the waves' line slots, behind the carve below
 inline size_t rowtile_lds_floats(const NetDev& n) {
     const size_t HS = n.H + 4, INP = 16 * ((n.in_dim + 15) / 16) + 4;
     return 208 + (size_t)(n.depth + 1) * n.H + 8 * (size_t)n.H + kRows * INP + (size_t)n.depth * kRows * HS + 2 * kRows * HS +
