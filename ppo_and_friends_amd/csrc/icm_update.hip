@@ -112,6 +112,12 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_fwd_kernel(IcmDev u) {
     int* sRow = reinterpret_cast<int*>(smem);
     float* sX = smem + 16;                      // [16, INP]
     float* sH = sX + kRows * INP;               // 4 x [16, HS]
+    float* sScr = sH + 4L * kRows * HS + wave * 2 * kLineSlot;     // this wave's two line slots (mfma_rows_x_lines)
+    // every hidden layer's weight set is requested a phase ahead (the first one now): a set asked for when it is needed
+    // costs the phase a memory round trip, 14 of them per mini-batch in this chain's three kernels
+    const bool has_tile = wave < HT;
+    float4 cur[HT], nxt[HT];
+    if (has_tile) load_fwd_lines_ld<HT>(P + encW(1), H, wave * 16, lane, cur);
     if (vb == 0 && tid == 0 && u.fused_adam) {
         // Adam step counter and the two bias-correction constants of this mini-batch, computed once (in
         // double, as torch.optim.Adam does) and parked behind the loss partials for the reduce kernel
@@ -158,12 +164,24 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_fwd_kernel(IcmDev u) {
         for (int r = 0; r < 4; ++r) sH[(4 * (lane >> 4) + r) * HS + o] = act_fwd(acc[r], u.act);
     }
     __syncthreads();
-#pragma unroll 1
-    for (int l = 1; l < 4; ++l) {
-        layer_fwd<HT, true>(P + encW(l), H, P + encB(l), sH + (long)(l - 1) * kRows * HS, sH + (long)l * kRows * HS,
-                            l < 3 ? u.act : -1, wave, lane);
-        __syncthreads();
+    const int o_t = wave * 16 + (lane & 15);
+    if (has_tile) {
+        const float bv = P[encB(1) + o_t];
+        load_fwd_lines_ld<HT>(P + encW(2), H, wave * 16, lane, nxt);
+        fwd_tile_store<HT>(mfma_rows_x_lines<HT>(sH, HS, lane, cur, bv, sScr), sH + kRows * HS, u.act, wave, lane);
     }
+    __syncthreads();
+    if (has_tile) {
+        const float bv = P[encB(2) + o_t];
+        load_fwd_lines_ld<HT>(P + encW(3), H, wave * 16, lane, cur);
+        fwd_tile_store<HT>(mfma_rows_x_lines<HT>(sH + kRows * HS, HS, lane, nxt, bv, sScr), sH + 2L * kRows * HS, u.act, wave, lane);
+    }
+    __syncthreads();
+    if (has_tile) {
+        const float bv = P[encB(3) + o_t];
+        fwd_tile_store<HT>(mfma_rows_x_lines<HT>(sH + 2L * kRows * HS, HS, lane, cur, bv, sScr), sH + 3L * kRows * HS, -1, wave, lane);
+    }
+    __syncthreads();
     // activations of all four layers -> scratch [which][l][row][H]
     for (int idx = tid; idx < 4 * kRows * (H / 4); idx += kThreadsU) {
         const int l = idx / (kRows * (H / 4)), rem = idx - l * (kRows * (H / 4));
@@ -201,7 +219,21 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
     float* sD1 = sD0 + kRows * HS;
     float* sOut = sD1 + kRows * HS;                           // [16, 16]
     float* sDOut = sOut + kRows * kMaxOut;                    // [16, 16]
+    float* sScr = sDOut + kRows * kMaxOut + wave * 2 * kLineSlot;     // this wave's two line slots (mfma_rows_x_lines)
     __shared__ float red[17];
+    // Every weight set is requested a phase (or more) ahead of the MFMAs that consume it -- the first ones here, before
+    // anything else; forward sets as whole lines where the rows are whole lines, dgrad sets as buffer loads.
+    const bool has_tile = wave < HT;
+    const int n0 = wave * 16;
+    float4 sa[HT], sb[HT], sc[HT];
+    if (has_tile) {
+        if (which == 0) {
+            load_fwd_lines_ld<HT>(u.params + u.inv_off, 2 * H, n0, lane, sa);          // layer 0, K half of enc_1
+            load_fwd_lines_ld<HT>(u.params + u.inv_off + H, 2 * H, n0, lane, sb);      //          K half of enc_2
+        } else {
+            load_fwd_frags_ld<HT, false>(u.params + u.fwd_off, H + Ain, n0, lane, sa); // layer 0 (rows of H + Ain floats: not lines)
+        }
+    }
 
     icm_rows(u, g, tid, sRow);
     for (int i = tid; i < kRows * kXS; i += kThreadsU) sXa[i] = 0.f;
@@ -240,23 +272,30 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
         for (int i = tid; i < A * H; i += kThreadsU) sWout[i] = P[offW(depth) + i];
         if (tid < A) sBout[tid] = P[offB(depth) + tid];
         // layer 0 over the two K = H halves of cat(enc_1, enc_2)
-        for (int nt = wave; nt < HT; nt += kNW) {
-            float4 fa[HT], fb[HT];
-            load_fwd_frags_ld<HT, true>(P, 2 * H, nt * 16, lane, fa);
-            load_fwd_frags_ld<HT, true>(P + H, 2 * H, nt * 16, lane, fb);
-            const int o = nt * 16 + (lane & 15);
-            f32x4 acc = mfma_rows_x_frags<HT>(sE1, HS, lane, fa, P[offB(0) + o]);
-            acc += mfma_rows_x_frags<HT>(sE2, HS, lane, fb, 0.f);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sH[(4 * (lane >> 4) + r) * HS + o] = act_fwd(acc[r], act);
+        if (has_tile) {
+            const int o = n0 + (lane & 15);
+            const float bv = P[offB(0) + o];
+            if (depth > 1) load_fwd_lines_ld<HT>(P + offW(1), H, n0, lane, sc);
+            else load_dgrad_frags_buf_ld<HT>(P, 2 * H, n0, lane, sc);              // (no hidden layer: layer 0's first dgrad half)
+            f32x4 acc = mfma_rows_x_lines<HT>(sE1, HS, lane, sa, bv, sScr);
+            acc += mfma_rows_x_lines<HT>(sE2, HS, lane, sb, 0.f, sScr);
+            fwd_tile_store<HT>(acc, sH, act, wave, lane);
         }
         __syncthreads();
 #pragma unroll 1
-        for (int l = 1; l < depth; ++l) {
-            layer_fwd<HT, true>(P + offW(l), H, P + offB(l), sH + (long)(l - 1) * kRows * HS, sH + (long)l * kRows * HS,
-                                act, wave, lane);
+        for (int l = 1; l < depth; ++l) {                  // sc: this layer's set; sa: the next one
+            if (has_tile) {
+                const float bv = P[offB(l) + n0 + (lane & 15)];
+                if (l + 1 < depth) load_fwd_lines_ld<HT>(P + offW(l + 1), H, n0, lane, sa);
+                else load_dgrad_frags_buf_ld<HT>(P + offW(l), H, n0, lane, sa);   // the backward pass begins with this layer
+                fwd_tile_store<HT>(mfma_rows_x_lines<HT>(sH + (long)(l - 1) * kRows * HS, HS, lane, sc, bv, sScr),
+                                   sH + (long)l * kRows * HS, act, wave, lane);
+#pragma unroll
+                for (int c = 0; c < HT; ++c) sc[c] = sa[c];
+            }
             __syncthreads();
         }
+        // sc now holds the first dgrad set of the backward pass (layer depth - 1, or layer 0's first half)
         const float* Hlast = sH + (long)(depth - 1) * kRows * HS;
         if (u.split) for (int l = 0; l < depth; ++l) icm_publish<H>(sH + (long)l * kRows * HS, HS, u.hI + (long)l * u.Bpad * H, g, tid);
         // output layer (A <= 8): VALU from LDS + 16-lane reductions
@@ -378,24 +417,33 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
         float* Dc = sD0;
         float* Dn = sD1;
 #pragma unroll 1
-        for (int l = depth - 1; l >= 1; --l) {
+        for (int l = depth - 1; l >= 1; --l) {             // sc: this layer's dgrad set; sa: the next one
             const float* Hin = sH + (long)(l - 1) * kRows * HS;
-            layer_dgrad<HT>(P + offW(l), H, Dc, Hin, act, Dn, nullptr, wave, lane);
+            if (has_tile) {
+                if (l - 1 >= 1) load_dgrad_frags_buf_ld<HT>(P + offW(l - 1), H, n0, lane, sa);
+                else load_dgrad_frags_buf_ld<HT>(P, 2 * H, n0, lane, sa);             // layer 0's first half
+                dgrad_tile_store<HT>(mfma_rows_x_frags<HT>(Dc, HS, lane, sc, 0.f), Hin, act, Dn, nullptr, wave, lane);
+#pragma unroll
+                for (int c = 0; c < HT; ++c) sc[c] = sa[c];
+            }
             if (u.split) icm_publish<H>(Dc, HS, u.dI + (long)l * u.Bpad * H, g, tid);
             else layer_wgrad<HT>(Dc, Hin, HS, HT, H, slab + offW(l), H, slab + offB(l), wave, lane, tid);
             __syncthreads();
             float* t = Dc; Dc = Dn; Dn = t;
         }
         // layer 0: two K halves; the gradients of the encodings leave through scratch
+        if (has_tile) load_dgrad_frags_buf_ld<HT>(P + H, 2 * H, n0, lane, sa);
         if (u.split) icm_publish<H>(Dc, HS, u.dI, g, tid);
         else {
             layer_wgrad<HT>(Dc, sE1, HS, HT, H, slab + offW(0), 2 * H, slab + offB(0), wave, lane, tid);
             layer_wgrad<HT>(Dc, sE2, HS, HT, H, slab + offW(0) + H, 2 * H, nullptr, wave, lane, tid);
         }
-        float* dE = u.dEnc + ((long)(0 * 2 + 0) * u.Bpad + (long)g * kRows) * H;
-        layer_dgrad<HT>(P + offW(0), 2 * H, Dc, nullptr, act, nullptr, dE, wave, lane);
-        dE = u.dEnc + ((long)(0 * 2 + 1) * u.Bpad + (long)g * kRows) * H;
-        layer_dgrad<HT>(P + offW(0) + H, 2 * H, Dc, nullptr, act, nullptr, dE, wave, lane);
+        if (has_tile) {
+            float* dE = u.dEnc + ((long)(0 * 2 + 0) * u.Bpad + (long)g * kRows) * H;
+            dgrad_tile_store<HT>(mfma_rows_x_frags<HT>(Dc, HS, lane, sc, 0.f), nullptr, act, nullptr, dE, wave, lane);
+            dE = u.dEnc + ((long)(0 * 2 + 1) * u.Bpad + (long)g * kRows) * H;
+            dgrad_tile_store<HT>(mfma_rows_x_frags<HT>(Dc, HS, lane, sa, 0.f), nullptr, act, nullptr, dE, wave, lane);
+        }
     } else {
         // =================================== forward model ===================================
         const float* P = u.params + u.fwd_off;
@@ -404,27 +452,34 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
         auto offW = [&](int l) -> long { return l == 0 ? 0 : (long)H * ld0 + H + (long)(l - 1) * (H * H + H); };
         auto offB = [&](int l) -> long { return offW(l) + (l == 0 ? (long)H * ld0 : (long)H * H); };
         __syncthreads();                                        // sXa / sAct complete
-        for (int nt = wave; nt < HT; nt += kNW) {
-            float4 fa[HT];
-            load_fwd_frags_ld<HT, false>(P, ld0, nt * 16, lane, fa);
-            const int o = nt * 16 + (lane & 15);
-            f32x4 acc = mfma_rows_x_frags<HT>(sE1, HS, lane, fa, P[offB(0) + o]);
+        if (has_tile) {
+            const int o = n0 + (lane & 15);
+            const float bv = P[offB(0) + o];
             const float* wrow = P + (long)o * ld0 + H;
-            const float* arow = sXa + (lane & 15) * kXS;
+            float bq[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * j + (lane >> 4);
-                const float bq = k < Ain ? wrow[k] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k], bq, acc, 0, 0, 0);
+                bq[j] = k < Ain ? wrow[k] : 0.f;
             }
+            load_fwd_lines_ld<HT>(P + offW(1), H, n0, lane, sc);       // layer 1: a hidden layer, or the H -> H output layer
+            f32x4 acc = mfma_rows_x_frags<HT>(sE1, HS, lane, sa, bv);
+            const float* arow = sXa + (lane & 15) * kXS;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sH[(4 * (lane >> 4) + r) * HS + o] = act_fwd(acc[r], act);
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j + (lane >> 4)], bq[j], acc, 0, 0, 0);
+            fwd_tile_store<HT>(acc, sH, act, wave, lane);
         }
         __syncthreads();
 #pragma unroll 1
-        for (int l = 1; l < depth; ++l) {
-            layer_fwd<HT, true>(P + offW(l), H, P + offB(l), sH + (long)(l - 1) * kRows * HS, sH + (long)l * kRows * HS,
-                                act, wave, lane);
+        for (int l = 1; l < depth; ++l) {                  // sc: this layer's set; sa: the next one (l + 1 <= depth: the output layer)
+            if (has_tile) {
+                const float bv = P[offB(l) + n0 + (lane & 15)];
+                load_fwd_lines_ld<HT>(P + offW(l + 1), H, n0, lane, sa);
+                fwd_tile_store<HT>(mfma_rows_x_lines<HT>(sH + (long)(l - 1) * kRows * HS, HS, lane, sc, bv, sScr),
+                                   sH + (long)l * kRows * HS, act, wave, lane);
+#pragma unroll
+                for (int c = 0; c < HT; ++c) sc[c] = sa[c];
+            }
             __syncthreads();
         }
         const float* Hlast = sH + (long)(depth - 1) * kRows * HS;
@@ -435,8 +490,14 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
                 u.aF[((long)g * kRows + s) * 16 + k] = sXa[s * kXS + k];
             }
         }
-        // output layer H -> H (linear): the prediction of enc_2, into sD0
-        layer_fwd<HT, true>(P + offW(depth), H, P + offB(depth), Hlast, sD0, -1, wave, lane);
+        // output layer H -> H (linear): the prediction of enc_2, into sD0; its dgrad set is the backward pass's first
+        if (has_tile) {
+            const float bv = P[offB(depth) + n0 + (lane & 15)];
+            load_dgrad_frags_buf_ld<HT>(P + offW(depth), H, n0, lane, sa);
+            fwd_tile_store<HT>(mfma_rows_x_lines<HT>(Hlast, HS, lane, sc, bv, sScr), sD0, -1, wave, lane);
+#pragma unroll
+            for (int c = 0; c < HT; ++c) sc[c] = sa[c];
+        }
         __syncthreads();
         // K8: f_loss = 0.5 mean((pred - enc_2)^2); d pred = (1 - beta) (pred - enc_2) / (B H); d enc_2 = -d pred
         {
@@ -462,9 +523,15 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
         float* Dn = sD1;
         // output layer backward, then the hidden layers
 #pragma unroll 1
-        for (int l = depth; l >= 1; --l) {
+        for (int l = depth; l >= 1; --l) {                 // sc: this layer's dgrad set; sa: the next one
             const float* Hin = sH + (long)(l - 1) * kRows * HS;
-            layer_dgrad<HT>(P + offW(l), H, Dc, Hin, act, Dn, nullptr, wave, lane);
+            if (has_tile) {
+                if (l - 1 >= 1) load_dgrad_frags_buf_ld<HT>(P + offW(l - 1), H, n0, lane, sa);
+                else load_dgrad_frags_buf_ld<HT>(P, ld0, n0, lane, sa);               // layer 0 (the encoding columns)
+                dgrad_tile_store<HT>(mfma_rows_x_frags<HT>(Dc, HS, lane, sc, 0.f), Hin, act, Dn, nullptr, wave, lane);
+#pragma unroll
+                for (int c = 0; c < HT; ++c) sc[c] = sa[c];
+            }
             if (u.split) icm_publish<H>(Dc, HS, u.dF + (long)l * u.Bpad * H, g, tid);
             else layer_wgrad<HT>(Dc, Hin, HS, HT, H, slab + offW(l), H, slab + offB(l), wave, lane, tid);
             __syncthreads();
@@ -475,8 +542,10 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
             layer_wgrad<HT>(Dc, sE1, HS, HT, H, slab + offW(0), (int)ld0, slab + offB(0), wave, lane, tid);
             layer_wgrad<HT>(Dc, sXa, kXS, 1, Ain, slab + offW(0) + H, (int)ld0, nullptr, wave, lane, tid);
         }
-        float* dE = u.dEnc + ((long)(1 * 2 + 0) * u.Bpad + (long)g * kRows) * H;
-        layer_dgrad<HT>(P + offW(0), ld0, Dc, nullptr, act, nullptr, dE, wave, lane);
+        if (has_tile) {
+            float* dE = u.dEnc + ((long)(1 * 2 + 0) * u.Bpad + (long)g * kRows) * H;
+            dgrad_tile_store<HT>(mfma_rows_x_frags<HT>(Dc, HS, lane, sc, 0.f), nullptr, act, nullptr, dE, wave, lane);
+        }
     }
 }
 
@@ -583,6 +652,9 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_bwd_kernel(IcmDev u) {
     float* sH = sX + kRows * INP;               // 3 x [16, HS]
     float* sD0 = sH + 3L * kRows * HS;
     float* sD1 = sD0 + kRows * HS;
+    const bool has_tile = wave < HT;
+    float4 da[HT], db[HT];                      // dgrad sets, requested a phase ahead (layer 3's now)
+    if (has_tile) load_dgrad_frags_buf_ld<HT>(P + encW(3), H, wave * 16, lane, da);
     icm_rows(u, g, tid, sRow);
     for (int i = tid; i < kRows * INP; i += kThreadsU) sX[i] = 0.f;
     for (int idx = tid; idx < 3 * kRows * (H / 4); idx += kThreadsU) {
@@ -610,10 +682,15 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_bwd_kernel(IcmDev u) {
     }
     float* Dc = sD0;
     float* Dn = sD1;
-#pragma unroll 1
+#pragma unroll
     for (int l = 3; l >= 1; --l) {
         const float* Hin = sH + (long)(l - 1) * kRows * HS;
-        layer_dgrad<HT>(P + encW(l), H, Dc, Hin, u.act, Dn, nullptr, wave, lane);
+        if (has_tile) {
+            if (l == 3) load_dgrad_frags_buf_ld<HT>(P + encW(2), H, wave * 16, lane, db);
+            if (l == 2) load_dgrad_frags_buf_ld<HT>(P + encW(1), H, wave * 16, lane, da);
+            const f32x4 acc = l == 2 ? mfma_rows_x_frags<HT>(Dc, HS, lane, db, 0.f) : mfma_rows_x_frags<HT>(Dc, HS, lane, da, 0.f);
+            dgrad_tile_store<HT>(acc, Hin, u.act, Dn, nullptr, wave, lane);
+        }
         if (u.split) icm_publish<H>(Dc, HS, u.dE + (long)(which * 4 + l) * u.Bpad * H, g, tid);
         else layer_wgrad<HT>(Dc, Hin, HS, HT, H, slab + encW(l), H, slab + encB(l), wave, lane, tid);
         __syncthreads();
@@ -971,10 +1048,11 @@ template <int HT>
 static int launch_icm_fwd_bwd(const IcmDev& u, hipStream_t s) {
     const size_t HS = 16 * HT + 4, H = 16 * HT;
     const size_t INP = 16 * ((u.O + 15) / 16) + 4;
-    const size_t lds_enc_f = (16 + kRows * INP + 4 * kRows * HS) * 4;
+    const size_t lds_lines = (size_t)kNW * 2 * kLineSlot * 4;                  // every wave's two line slots
+    const size_t lds_enc_f = (16 + kRows * INP + 4 * kRows * HS) * 4 + lds_lines;
     const size_t lds_enc_b = (16 + kRows * INP + 5 * kRows * HS) * 4;
     const int dmax = u.d_inv > u.d_fwd ? u.d_inv : u.d_fwd;
-    const size_t lds_heads = (160 + 8 * H + kRows * kXS + (4 + dmax) * kRows * HS + 2 * kRows * kMaxOut) * 4;
+    const size_t lds_heads = (160 + 8 * H + kRows * kXS + (4 + dmax) * kRows * HS + 2 * kRows * kMaxOut) * 4 + lds_lines;
     PPOAF_REQUIRE(lds_enc_b <= 160 * 1024 && lds_heads <= 160 * 1024 && lds_enc_f <= 160 * 1024,
                   "icm_update: needs %zu / %zu B of LDS (> 160 KiB): obs_dim or depth too large",
                   lds_enc_b, lds_heads);
@@ -1039,7 +1117,7 @@ template <int HT>
 static int launch_icm_reward(const IcmDev& u, float scale, float* intr_out, hipStream_t s) {
     const size_t HS = 16 * HT + 4;
     const size_t INP = 16 * ((u.O + 15) / 16) + 4;
-    const size_t lds_enc_f = (16 + kRows * INP + 4 * kRows * HS) * 4;
+    const size_t lds_enc_f = (16 + kRows * INP + 4 * kRows * HS) * 4 + (size_t)kNW * 2 * kLineSlot * 4;
     const size_t lds_rew = (kRows * kXS + 4 * kRows * HS) * 4;
     PPOAF_REQUIRE(lds_enc_f <= 160 * 1024 && lds_rew <= 160 * 1024, "icm_intrinsic_reward: obs_dim too large");
     static bool big_f = false, big_r = false;

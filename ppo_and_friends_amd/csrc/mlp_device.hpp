@@ -211,23 +211,29 @@ __device__ __forceinline__ void load_fwd_lines_buf(const float* __restrict__ W, 
 template <int HT>
 __device__ __forceinline__ f32x4 mfma_rows_x_lines(const float* __restrict__ A, int HS, int lane, const float4 (&raw)[HT],
                                                    float init, float* __restrict__ scratch) {
+    constexpr int NL = HT / 2;                            // lines per row
     const float* arow = A + (lane & 15) * HS + 4 * (lane >> 4);
     float* wr = scratch + (lane >> 3) * kLineRow + 4 * (lane & 7);
     const float* rd = scratch + (lane & 15) * kLineRow + 4 * (lane >> 4);
     f32x4 acc0 = {init, init, init, init};
     f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+    // three stages in flight: line q + 2 being written, line q + 1 being read back, line q in the matrix pipe
     *reinterpret_cast<float4*>(wr) = raw[0];
     *reinterpret_cast<float4*>(wr + 8 * kLineRow) = raw[1];
+    if (NL > 1) {
+        *reinterpret_cast<float4*>(wr + kLineSlot) = raw[2];
+        *reinterpret_cast<float4*>(wr + kLineSlot + 8 * kLineRow) = raw[3];
+    }
+    __builtin_amdgcn_wave_barrier();                      // (LDS executes a wave's instructions in order: no wait between the lanes' write and read)
+    float4 f0 = *reinterpret_cast<const float4*>(rd);
+    float4 f1 = *reinterpret_cast<const float4*>(rd + 16);
 #pragma unroll
-    for (int q = 0; q < HT / 2; ++q) {
+    for (int q = 0; q < NL; ++q) {
         const int slot = (q & 1) * kLineSlot;
-        __builtin_amdgcn_wave_barrier();                  // (LDS executes a wave's instructions in order: no wait between the lanes' write and read)
-        const float4 f0 = *reinterpret_cast<const float4*>(rd + slot);
-        const float4 f1 = *reinterpret_cast<const float4*>(rd + slot + 16);
-        __builtin_amdgcn_wave_barrier();
-        if (q + 1 < HT / 2) {
-            *reinterpret_cast<float4*>(wr + (kLineSlot - slot)) = raw[2 * q + 2];
-            *reinterpret_cast<float4*>(wr + (kLineSlot - slot) + 8 * kLineRow) = raw[2 * q + 3];
+        float4 g0 = f0, g1 = f1;
+        if (q + 1 < NL) {
+            g0 = *reinterpret_cast<const float4*>(rd + (kLineSlot - slot));
+            g1 = *reinterpret_cast<const float4*>(rd + (kLineSlot - slot) + 16);
         }
         const float4 a0 = *reinterpret_cast<const float4*>(arow + 32 * q);
         const float4 a1 = *reinterpret_cast<const float4*>(arow + 32 * q + 16);
@@ -239,6 +245,12 @@ __device__ __forceinline__ f32x4 mfma_rows_x_lines(const float* __restrict__ A, 
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, f1.y, acc1, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, f1.z, acc1, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, f1.w, acc1, 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+        if (q + 2 < NL) {                                 // this line's slot is free: its fragments were read an iteration ago
+            *reinterpret_cast<float4*>(wr + slot) = raw[2 * q + 4];
+            *reinterpret_cast<float4*>(wr + slot + 8 * kLineRow) = raw[2 * q + 5];
+        }
+        f0 = g0; f1 = g1;
     }
     return acc0 + acc1;
 }
@@ -317,6 +329,57 @@ __device__ __forceinline__ void load_dgrad_frags_ld(const float* __restrict__ W,
     for (int c = 0; c < HT; ++c) {
         const float* wp = w + (long)(16 * c) * ldw;
         fr[c] = make_float4(wp[0], wp[ldw], wp[2 * ldw], wp[3 * ldw]);
+    }
+}
+
+// ---- one output tile per wave, REQUESTED a phase ahead of its use (K14's kernels: waves >= HT hold no tile).  Forward
+// sets travel as whole lines when the rows are whole lines (ldw a multiple of 32 floats), in fragment order otherwise;
+// dgrad sets as buffer loads that share one per-lane offset.  The consumers are mfma_rows_x_lines / mfma_rows_x_frags:
+// the sums of layer_fwd / layer_dgrad below, bit for bit.
+template <int HT>
+__device__ __forceinline__ void load_fwd_lines_ld(const float* __restrict__ W, long ldw, int n0, int lane, float4 (&raw)[HT]) {
+    static_assert(HT % 2 == 0, "whole lines: H a multiple of 32");
+    const __amdgpu_buffer_rsrc_t rs = frag_rsrc(W);
+    const unsigned off = (unsigned)(((long)(n0 + (lane >> 3)) * ldw + 4 * (lane & 7)) * 4);
+    const unsigned half = (unsigned)(8 * ldw * 4);
+#pragma unroll
+    for (int q = 0; q < HT / 2; ++q) {
+        raw[2 * q] = frag_u4(__builtin_amdgcn_raw_buffer_load_b128(rs, off + 128u * q, 0, 0));
+        raw[2 * q + 1] = frag_u4(__builtin_amdgcn_raw_buffer_load_b128(rs, off + half + 128u * q, 0, 0));
+    }
+}
+template <int HT>
+__device__ __forceinline__ void load_dgrad_frags_buf_ld(const float* __restrict__ W, long ldw, int n0, int lane, float4 (&fr)[HT]) {
+    const __amdgpu_buffer_rsrc_t rs = frag_rsrc(W);
+    const unsigned off = (unsigned)(((long)(4 * (lane >> 4)) * ldw + n0 + (lane & 15)) * 4);
+    const int row = (int)(ldw * 4);
+#pragma unroll
+    for (int c = 0; c < HT; ++c) {
+        fr[c] = make_float4(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, (16 * c) * row, 0)),
+                            __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, (16 * c + 1) * row, 0)),
+                            __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, (16 * c + 2) * row, 0)),
+                            __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, (16 * c + 3) * row, 0)));
+    }
+}
+// epilogues of layer_fwd / layer_dgrad for this wave's tile
+template <int HT>
+__device__ __forceinline__ void fwd_tile_store(const f32x4 acc, float* __restrict__ out, int act, int wave, int lane) {
+    constexpr int HS = 16 * HT + 4;
+    const int o = wave * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(4 * (lane >> 4) + r) * HS + o] = act >= 0 ? act_fwd(acc[r], act) : acc[r];
+}
+template <int HT>
+__device__ __forceinline__ void dgrad_tile_store(const f32x4 acc, const float* __restrict__ Hin, int act, float* __restrict__ dst_lds,
+                                                 float* __restrict__ dst_glob, int wave, int lane) {
+    constexpr int H = 16 * HT, HS = H + 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int s = 4 * (lane >> 4) + r, i = wave * 16 + (lane & 15);
+        float v = acc[r];
+        if (Hin) v *= act_bwd(Hin[s * HS + i], act);
+        if (dst_lds) dst_lds[s * HS + i] = v;
+        else dst_glob[(long)s * H + i] = v;
     }
 }
 
