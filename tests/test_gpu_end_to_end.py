@@ -254,7 +254,7 @@ def test_fused_update_fuzz_against_the_torch_path(k12_form, monkeypatch):
     monkeypatch.setenv("PPOAF_WS", "0" if k12_form == "chain" else "1")
     monkeypatch.setenv("PPOAF_WS_MODE", "auto" if k12_form == "chain" else k12_form)
 
-    @settings(max_examples=40 if k12_form in ("chain", "auto") else 25, deadline=None, derandomize=True,
+    @settings(max_examples=24 if k12_form in ("chain", "auto") else 15, deadline=None, derandomize=True,
               suppress_health_check=list(HealthCheck))
     @given(O=st.integers(1, 70), kind=st.sampled_from(["d", "c"]), n=st.integers(1, 8),
            hidden=st.sampled_from([32, 64, 128, 256]), depth=st.integers(1, 4), B=st.integers(2, 300),
@@ -1043,7 +1043,7 @@ def test_fused_mat_and_icm_paths_fuzz_against_the_torch_paths():
     from ppo_and_friends_amd.spaces import Box, Discrete
     dev = torch.device("cuda", 0)
 
-    @settings(max_examples=16, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=10, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(A=st.integers(2, 5), O=st.integers(1, 32), NA=st.integers(2, 8), E=st.integers(1, 9), T=st.integers(2, 14),
            B=st.integers(2, 40), seed=st.integers(0, 50))
     def mat(A, O, NA, E, T, B, seed):
@@ -1090,7 +1090,7 @@ def test_fused_mat_and_icm_paths_fuzz_against_the_torch_paths():
         np.testing.assert_allclose(s0, s1, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(w0, w1, rtol=2e-4, atol=3e-5)
 
-    @settings(max_examples=16, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=10, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(kind=st.sampled_from(["d", "c"]), NA=st.integers(2, 8), O=st.integers(1, 60), H=st.sampled_from([64, 128]),
            d_inv=st.integers(1, 3), d_fwd=st.integers(1, 3), E=st.integers(1, 10), T=st.integers(2, 20), B=st.integers(2, 70))
     def icm(kind, NA, O, H, d_inv, d_fwd, E, T, B):
@@ -1128,7 +1128,7 @@ def test_rollout_dataset_order_fuzz_against_the_cpu_port():
     """
     from hypothesis import given, settings, strategies as st, HealthCheck
 
-    @settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=20, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(E=st.integers(1, 20), T=st.integers(1, 40), term=st.sampled_from([0.0, 0.05, 0.3, 0.9]),
            max_ts=st.sampled_from([1, 2, 3, 7, 200]), fused=st.booleans())
     def run(E, T, term, max_ts, fused):
@@ -1511,7 +1511,7 @@ def test_full_pipeline_fuzz_fused_equals_torch():
     from ppo_and_friends_amd.spaces import Box, Discrete
     dev = torch.device("cuda", 0)
 
-    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=26, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(O=st.integers(1, 30), cont=st.booleans(), NA=st.integers(2, 6), E=st.integers(2, 10), T=st.integers(3, 18),
            B=st.integers(2, 48), norm_obs=st.booleans(), norm_rew=st.booleans(), clip=st.booleans(), icm=st.booleans(),
            term=st.sampled_from([0.0, 0.1]), overlap=st.booleans())
