@@ -663,12 +663,21 @@ typedef struct {
     /* 0: the fwd_bwd launches use every XCD (default).  1 / 2: their workgroups sit on XCDs 0-3 / 4-7 only (the launch is
      * twice as wide and the workgroups dispatched to the other half return at once; workgroup b is dispatched to XCD b % 8):
      * for the PPO update running on the other half at the same time (ppoaf_ppo_update_args_t.xcd_half). */
-    int32_t xcd_half, _pad2;
+    int32_t xcd_half;
+    /* ABI 6.  1 (with split_workspace, hidden 128; ignored otherwise): ppoaf_icm_update_fwd_bwd issues ONE launch instead of
+     * three -- workgroup (tile, stream) runs its stream's encoder, swaps encodings with its partner, runs one of the two
+     * models, swaps the encoding gradients and runs its encoder's backward pass; the exchanges are tagged records at the
+     * START of split_workspace (ppoaf_icm_update_split_workspace_bytes() includes them), tagged with *cursor + 1: zero the
+     * workspace before the first launch and whenever the cursor restarts.  Bitwise the three launches' results.  Word 0 of
+     * the workspace is non-zero after a launch in which a partner did not answer within 2 s (results invalid).
+     * ppoaf_icm_update_fuses_kernels(args): 1 when these arguments take the single launch. */
+    int32_t fuse_kernels;
 } ppoaf_icm_update_args_t;
 
 int ppoaf_icm_update_fwd_bwd(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream);
 int ppoaf_icm_update_reduce(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream);
 int ppoaf_icm_update_split_workspace_bytes(const ppoaf_icm_update_args_t* args, int64_t* bytes_out);
+int ppoaf_icm_update_fuses_kernels(const ppoaf_icm_update_args_t* args);
 /* Rollout-time intrinsic reward of a whole env batch (PPOPolicy.get_intrinsic_reward,
  * policies/ppo_policy.py:954-1007 -> ICM.forward icm.py:375-430 without the inverse model):
  * intr_out[i] = scale * sum_d (forward_model(enc(obs_i), action_i) - enc(next_obs_i))_d^2 with

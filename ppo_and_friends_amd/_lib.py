@@ -96,7 +96,7 @@ class IcmUpdateArgs(C.Structure):
                 ("act_scratch", C.c_void_p), ("denc_scratch", C.c_void_p), ("loss_partials", C.c_void_p),
                 ("totals", C.c_void_p), ("inputs_in_batch_order", C.c_int32), ("_pad", C.c_int32),
                 ("split_workspace", C.c_void_p), ("split_workspace_bytes", C.c_int64),
-                ("xcd_half", C.c_int32), ("_pad2", C.c_int32)]
+                ("xcd_half", C.c_int32), ("fuse_kernels", C.c_int32)]
 
 
 class MatUpdateArgs(C.Structure):
@@ -218,6 +218,7 @@ SIGNATURES = {
     "ppoaf_icm_update_fwd_bwd": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
     "ppoaf_icm_update_reduce": (C.c_int, [C.POINTER(IcmUpdateArgs), _ptr]),
     "ppoaf_icm_update_split_workspace_bytes": (C.c_int, [C.POINTER(IcmUpdateArgs), C.POINTER(C.c_int64)]),
+    "ppoaf_icm_update_fuses_kernels": (C.c_int, [C.POINTER(IcmUpdateArgs)]),
     "ppoaf_icm_intrinsic_reward": (C.c_int, [C.POINTER(IcmUpdateArgs), C.c_float, _ptr, _ptr]),
     "ppoaf_adam_step_prenormed": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr, _ptr, C.c_float, C.c_float,
                                             C.c_float, C.c_float, C.c_float, _ptr, C.c_int32, _ptr, _ptr]),

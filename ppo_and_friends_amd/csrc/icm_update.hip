@@ -13,7 +13,7 @@
 // and each phase runs on 2 * B/16 workgroups: (obs, next_obs) for the encoder phases,
 // (inverse, forward model) for the heads.  float32 MFMA (v_mfma_f32_16x16x4_f32) keeps fmaf
 // chains exact, weight gradients are written to private slabs and summed in a fixed order.
-#include "mlp_device.hpp"
+#include "ppo_update_rowpair.hpp"
 #include <algorithm>
 #include <cstdlib>
 
@@ -97,22 +97,21 @@ __device__ __forceinline__ void icm_rows(const IcmDev& u, int g, int tid, int* s
 // ------------------------------------------------------------------------------------------------
 // encoder forward: blockIdx.x = 2 * g + which (0: obs, 1: next_obs)
 // ------------------------------------------------------------------------------------------------
-template <int HT>
-__global__ __launch_bounds__(kThreadsU) void icm_encoder_fwd_kernel(IcmDev u) {
+// FUSED (icm_fused_kernel below): the same body as the first phase of a workgroup that goes on to run a model and the
+// encoder's backward pass; its activations stay in LDS (they are stored for the wgrad launch all the same).
+template <int HT, bool FUSED>
+__device__ __forceinline__ void icm_encoder_fwd_body(const IcmDev& u, const int which, const int g, float* smem, float* sLines) {
     constexpr int H = 16 * HT, HS = H + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int vb = icm_block(u);
-    if (vb < 0 || vb >= 2 * u.nT) return;
-    const int which = vb & 1, g = vb >> 1;
+    const int vb = 2 * g + which;
     const int O = u.O, NT0 = (O + 15) >> 4, INP = 16 * NT0 + 4;
     const float* P = u.params + u.enc_off;
     auto encW = [&](int l) -> long { return l == 0 ? 0 : (long)H * O + H + (long)(l - 1) * (H * H + H); };
     auto encB = [&](int l) -> long { return encW(l) + (l == 0 ? (long)H * O : (long)H * H); };
-    float* smem = reinterpret_cast<float*>(icm_smem);
     int* sRow = reinterpret_cast<int*>(smem);
     float* sX = smem + 16;                      // [16, INP]
     float* sH = sX + kRows * INP;               // 4 x [16, HS]
-    float* sScr = sH + 4L * kRows * HS + wave * 2 * kLineSlot;     // this wave's two line slots (mfma_rows_x_lines)
+    float* sScr = sLines + wave * 2 * kLineSlot;                    // this wave's two line slots (mfma_rows_x_lines)
     // every hidden layer's weight set is requested a phase ahead (the first one now): a set asked for when it is needed
     // costs the phase a memory round trip, 14 of them per mini-batch in this chain's three kernels
     const bool has_tile = wave < HT;
@@ -191,22 +190,40 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_fwd_kernel(IcmDev u) {
     }
 }
 
+template <int HT>
+__global__ __launch_bounds__(kThreadsU) void icm_encoder_fwd_kernel(IcmDev u) {
+    constexpr int HS = 16 * HT + 4;
+    const int vb = icm_block(u);
+    if (vb < 0 || vb >= 2 * u.nT) return;
+    float* smem = reinterpret_cast<float*>(icm_smem);
+    const int INP = 16 * ((u.O + 15) >> 4) + 4;
+    icm_encoder_fwd_body<HT, false>(u, vb & 1, vb >> 1, smem, smem + 16 + kRows * INP + 4L * kRows * HS);
+}
+
 // ------------------------------------------------------------------------------------------------
 // heads: blockIdx.x = 2 * g + which (0: inverse model, 1: forward model)
 // ------------------------------------------------------------------------------------------------
 constexpr int kXS = 20;      // row stride of the padded action tile [16, 16 + 4]
 
-template <int HT>
-__global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
+// One launch per mini-batch for the three kernels of this file (icm_fused_kernel): what a workgroup hands to its partner and
+// where it finds its own encoding.  Exchanges are rounds of data-tagged records (ppo_update_rowpair.hpp: pair_send / pair_recv).
+struct IcmFuse {
+    const float* enc_own;      // LDS: this workgroup's stream's encoding (the encoder phase's last plane)
+    float* recv;               // LDS [16][HS]: where the partner's encoding gradient lands
+    unsigned char* base;       // record region: header (word 0: error), then [phase][tile][half] blocks
+    unsigned tag;              // mini-batch index + 1
+    __device__ __forceinline__ unsigned char* block(int phase, int g, int half) const {
+        return base + kPairHeaderBytes + (((long)phase * kPairMaxTiles + g) * 2 + half) * (long)kPairRecBytes;
+    }
+};
+
+template <int HT, bool FUSED>
+__device__ __forceinline__ void icm_heads_body(const IcmDev& u, const int which, const int g, float* smem, float* sLines, const IcmFuse& fx) {
     constexpr int H = 16 * HT, HS = H + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int vb = icm_block(u);
-    if (vb < 0 || vb >= 2 * u.nT) return;
-    const int which = vb & 1, g = vb >> 1;
     const int act = u.act, A = u.A, Ain = u.Ain;
     const int depth = which == 0 ? u.d_inv : u.d_fwd;
     const long B = u.B;
-    float* smem = reinterpret_cast<float*>(icm_smem);
     int* sRow = reinterpret_cast<int*>(smem);                 // [16]
     float* sAct = smem + 16;                                  // [16][8] actions (float, or int bits)
     float* sBout = smem + 144;                                // [16]
@@ -219,7 +236,7 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
     float* sD1 = sD0 + kRows * HS;
     float* sOut = sD1 + kRows * HS;                           // [16, 16]
     float* sDOut = sOut + kRows * kMaxOut;                    // [16, 16]
-    float* sScr = sDOut + kRows * kMaxOut + wave * 2 * kLineSlot;     // this wave's two line slots (mfma_rows_x_lines)
+    float* sScr = sLines + wave * 2 * kLineSlot;               // this wave's two line slots (mfma_rows_x_lines)
     __shared__ float red[17];
     // Every weight set is requested a phase (or more) ahead of the MFMAs that consume it -- the first ones here, before
     // anything else; forward sets as whole lines where the rows are whole lines, dgrad sets as buffer loads.
@@ -237,6 +254,15 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
 
     icm_rows(u, g, tid, sRow);
     for (int i = tid; i < kRows * kXS; i += kThreadsU) sXa[i] = 0.f;
+    if constexpr (FUSED) {
+        // the two encodings of this tile: mine from the encoder phase (LDS), the other stream's from the partner
+        if constexpr (H == 128) pair_send(fx.block(0, g, which), fx.enc_own, HS, 0, fx.tag, tid);
+        for (int idx = tid; idx < kRows * (H / 4); idx += kThreadsU) {
+            const int s = idx / (H / 4), c4 = idx - s * (H / 4);
+            *reinterpret_cast<float4*>((which == 0 ? sE1 : sE2) + s * HS + 4 * c4) = *reinterpret_cast<const float4*>(fx.enc_own + s * HS + 4 * c4);
+        }
+        if constexpr (H == 128) pair_recv(fx.block(0, g, which ^ 1), which == 0 ? sE2 : sE1, HS, 0, fx.tag, tid, reinterpret_cast<unsigned*>(fx.base));
+    } else {
     // encodings of this tile (layer 3 of the encoder scratch)
     for (int idx = tid; idx < 2 * kRows * (H / 4); idx += kThreadsU) {
         const int e = idx / (kRows * (H / 4)), rem = idx - e * (kRows * (H / 4));
@@ -244,6 +270,7 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
         const float4 v = *reinterpret_cast<const float4*>(
             u.actE + (((long)(e * 4 + 3) * u.Bpad) + (long)g * kRows + s) * H + 4 * c4);
         *reinterpret_cast<float4*>((e == 0 ? sE1 : sE2) + s * HS + 4 * c4) = v;
+    }
     }
     __syncthreads();
     if (tid < kRows) {
@@ -439,10 +466,11 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
             layer_wgrad<HT>(Dc, sE2, HS, HT, H, slab + offW(0) + H, 2 * H, nullptr, wave, lane, tid);
         }
         if (has_tile) {
+            // FUSED: d enc_1 stays here (sE1: this workgroup runs the obs stream's encoder backward), d enc_2 goes to the partner (sE2)
             float* dE = u.dEnc + ((long)(0 * 2 + 0) * u.Bpad + (long)g * kRows) * H;
-            dgrad_tile_store<HT>(mfma_rows_x_frags<HT>(Dc, HS, lane, sc, 0.f), nullptr, act, nullptr, dE, wave, lane);
+            dgrad_tile_store<HT>(mfma_rows_x_frags<HT>(Dc, HS, lane, sc, 0.f), nullptr, act, FUSED ? sE1 : nullptr, dE, wave, lane);
             dE = u.dEnc + ((long)(0 * 2 + 1) * u.Bpad + (long)g * kRows) * H;
-            dgrad_tile_store<HT>(mfma_rows_x_frags<HT>(Dc, HS, lane, sa, 0.f), nullptr, act, nullptr, dE, wave, lane);
+            dgrad_tile_store<HT>(mfma_rows_x_frags<HT>(Dc, HS, lane, sa, 0.f), nullptr, act, FUSED ? sE2 : nullptr, dE, wave, lane);
         }
     } else {
         // =================================== forward model ===================================
@@ -513,7 +541,8 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
                     dv = sc * diff;
                 }
                 sD0[s * HS + i] = dv;
-                dE2[(long)s * H + i] = -dv;
+                if (FUSED) sE1[s * HS + i] = -dv;            // d enc_2 stays here: this workgroup runs the next_obs stream's encoder backward
+                else dE2[(long)s * H + i] = -dv;
             }
             part = block_sum(part, red);
             if (tid == 0) u.loss_partials[g * 2 + 1] = 0.5f * part;
@@ -544,9 +573,27 @@ __global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
         }
         if (has_tile) {
             float* dE = u.dEnc + ((long)(1 * 2 + 0) * u.Bpad + (long)g * kRows) * H;
-            dgrad_tile_store<HT>(mfma_rows_x_frags<HT>(Dc, HS, lane, sc, 0.f), nullptr, act, nullptr, dE, wave, lane);
+            dgrad_tile_store<HT>(mfma_rows_x_frags<HT>(Dc, HS, lane, sc, 0.f), nullptr, act, FUSED ? sE2 : nullptr, dE, wave, lane);   // FUSED: d enc_1 goes to the partner
         }
     }
+    if constexpr (FUSED && H == 128) {
+        // the encoding gradients change hands: sE2 holds what the partner's stream needs, fx.recv takes what mine needs;
+        // sE1 (this model's gradient of my stream's encoding) stays -- the caller adds the two in the chain's order
+        __syncthreads();
+        pair_send(fx.block(1, g, which), sE2, HS, 0, fx.tag, tid);
+        pair_recv(fx.block(1, g, which ^ 1), fx.recv, HS, 0, fx.tag, tid, reinterpret_cast<unsigned*>(fx.base));
+        __syncthreads();
+    }
+}
+
+template <int HT>
+__global__ __launch_bounds__(kThreadsU) void icm_heads_kernel(IcmDev u) {
+    constexpr int H = 16 * HT, HS = H + 4;
+    const int vb = icm_block(u);
+    if (vb < 0 || vb >= 2 * u.nT) return;
+    float* smem = reinterpret_cast<float*>(icm_smem);
+    const int dmax = u.d_inv > u.d_fwd ? u.d_inv : u.d_fwd;
+    icm_heads_body<HT, false>(u, vb & 1, vb >> 1, smem, smem + 160 + 8 * H + kRows * kXS + (4L + dmax) * kRows * HS + 2 * kRows * kMaxOut, IcmFuse());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -634,19 +681,20 @@ __global__ __launch_bounds__(kThreadsU) void icm_reward_kernel(IcmDev u, float s
 // ------------------------------------------------------------------------------------------------
 // encoder backward: blockIdx.x = 2 * g + which (0: obs, 1: next_obs); slab index 2 * g + which
 // ------------------------------------------------------------------------------------------------
-template <int HT>
-__global__ __launch_bounds__(kThreadsU) void icm_encoder_bwd_kernel(IcmDev u) {
+// FUSED: the third phase of icm_fused_kernel -- the activations are still in LDS (same carve as the forward body), the
+// encoding's gradient is the sum of `own` (this workgroup's model) and `recv` (the partner's), in the chain's order:
+// inverse model's part + forward model's part.
+template <int HT, bool FUSED>
+__device__ __forceinline__ void icm_encoder_bwd_body(const IcmDev& u, const int which, const int g, float* smem, const float* own,
+                                                     const float* recv) {
     constexpr int H = 16 * HT, HS = H + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int vb = icm_block(u);
-    if (vb < 0 || vb >= 2 * u.nT) return;
-    const int which = vb & 1, g = vb >> 1;
+    const int vb = 2 * g + which;
     const int O = u.O, NT0 = (O + 15) >> 4, INP = 16 * NT0 + 4;
     const float* P = u.params + u.enc_off;
     float* slab = u.slabs + (long)vb * u.total + u.enc_off;
     auto encW = [&](int l) -> long { return l == 0 ? 0 : (long)H * O + H + (long)(l - 1) * (H * H + H); };
     auto encB = [&](int l) -> long { return encW(l) + (l == 0 ? (long)H * O : (long)H * H); };
-    float* smem = reinterpret_cast<float*>(icm_smem);
     int* sRow = reinterpret_cast<int*>(smem);
     float* sX = smem + 16;                      // [16, INP]
     float* sH = sX + kRows * INP;               // 3 x [16, HS]
@@ -655,6 +703,16 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_bwd_kernel(IcmDev u) {
     const bool has_tile = wave < HT;
     float4 da[HT], db[HT];                      // dgrad sets, requested a phase ahead (layer 3's now)
     if (has_tile) load_dgrad_frags_buf_ld<HT>(P + encW(3), H, wave * 16, lane, da);
+    if constexpr (FUSED) {
+        const float* a = which == 0 ? own : recv;            // the inverse model's part first, as the separate launch adds them
+        const float* b = which == 0 ? recv : own;
+        for (int idx = tid; idx < kRows * (H / 4); idx += kThreadsU) {
+            const int s2 = idx / (H / 4), c4 = idx - s2 * (H / 4);
+            const float4 va = *reinterpret_cast<const float4*>(a + s2 * HS + 4 * c4);
+            const float4 vb4 = *reinterpret_cast<const float4*>(b + s2 * HS + 4 * c4);
+            *reinterpret_cast<float4*>(sD0 + s2 * HS + 4 * c4) = make_float4(va.x + vb4.x, va.y + vb4.y, va.z + vb4.z, va.w + vb4.w);
+        }
+    } else {
     icm_rows(u, g, tid, sRow);
     for (int i = tid; i < kRows * INP; i += kThreadsU) sX[i] = 0.f;
     for (int idx = tid; idx < 3 * kRows * (H / 4); idx += kThreadsU) {
@@ -671,8 +729,9 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_bwd_kernel(IcmDev u) {
         const float4 b = *reinterpret_cast<const float4*>(u.dEnc + o1);
         *reinterpret_cast<float4*>(sD0 + s * HS + 4 * c4) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     }
+    }
     __syncthreads();
-    if (!u.split) {                             // layer 0's wgrad input (split chain: published by the forward kernel)
+    if (!FUSED && !u.split) {                   // layer 0's wgrad input (split chain: published by the forward kernel)
         const float* src = which == 0 ? u.obs : u.next_obs;
         for (int idx = tid; idx < kRows * O; idx += kThreadsU) {
             const int s = idx / O, i = idx - s * O;
@@ -698,6 +757,53 @@ __global__ __launch_bounds__(kThreadsU) void icm_encoder_bwd_kernel(IcmDev u) {
     }
     if (u.split) icm_publish<H>(Dc, HS, u.dE + (long)(which * 4) * u.Bpad * H, g, tid);
     else layer_wgrad<HT>(Dc, sX, INP, NT0, O, slab + encW(0), O, slab + encB(0), wave, lane, tid);
+}
+
+template <int HT>
+__global__ __launch_bounds__(kThreadsU) void icm_encoder_bwd_kernel(IcmDev u) {
+    const int vb = icm_block(u);
+    if (vb < 0 || vb >= 2 * u.nT) return;
+    icm_encoder_bwd_body<HT, false>(u, vb & 1, vb >> 1, reinterpret_cast<float*>(icm_smem), nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The three kernels above as ONE launch (split-wgrad chain, H = 128; args->fuse_kernels): workgroup (g, s) runs the encoder of
+// stream s (obs | next_obs) for its 16 rows, swaps encodings with its partner (g, s ^ 1), runs model s (inverse | forward) --
+// forward, losses, backward --, swaps the encoding gradients, and runs its stream's encoder backward with the activations
+// still in LDS.  Two exchanges of data-tagged records (~2.5 k cycles each) instead of two launch boundaries and the
+// reloads behind them; every panel the wgrad launch reads is stored as before; arithmetic and orders are the three
+// kernels': bitwise the same gradients.  Partners sit on one XCD (workgroup b runs on XCD b % 8: slots 2 k and 2 k + 1).
+// ------------------------------------------------------------------------------------------------
+template <int HT>
+__global__ __launch_bounds__(kThreadsU) void icm_fused_kernel(IcmDev u, unsigned char* records) {
+    constexpr int H = 16 * HT, HS = H + 4;
+    const int b = blockIdx.x, x = b & 7, j = b >> 3;
+    int g;
+    if (u.confine) {
+        if ((x >> 2) != u.confine - 1) return;
+        g = ((j >> 1) << 2) | (x & 3);
+    } else {
+        g = ((j >> 1) << 3) | x;
+    }
+    const int s = j & 1;
+    if (g >= u.nT) return;
+    float* smem = reinterpret_cast<float*>(icm_smem);
+    const int INP = 16 * ((u.O + 15) >> 4) + 4;
+    const int dmax = u.d_inv > u.d_fwd ? u.d_inv : u.d_fwd;
+    float* regE = smem;                                                      // encoder carve: rows, inputs, 3 activation planes, dz x 2
+    float* regH = regE + 16 + kRows * INP + 5L * kRows * HS;                 // the model's carve
+    float* lines = regH + 160 + 8 * H + kRows * kXS + (4L + dmax) * kRows * HS + 2 * kRows * kMaxOut;
+    float* encH = regE + 16 + kRows * INP;
+    IcmFuse fx;
+    fx.enc_own = encH + 3L * kRows * HS;                                     // the encoder's last plane
+    fx.recv = encH + 4L * kRows * HS;                                        // (the backward phase's second dz plane: free until its first dgrad)
+    fx.base = records;
+    fx.tag = (unsigned)(u.cursor[0] + 1);
+    icm_encoder_fwd_body<HT, true>(u, s, g, regE, lines);
+    __syncthreads();
+    icm_heads_body<HT, true>(u, s, g, regH, lines, fx);
+    float* sE1 = regH + 160 + 8 * H + kRows * kXS;
+    icm_encoder_bwd_body<HT, true>(u, s, g, regE, sE1, fx.recv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -969,6 +1075,14 @@ static size_t icm_split_layout(IcmDev& u, char* base, IcmWg* w) {
     return off;
 }
 
+// args->fuse_kernels: the exchange records of icm_fused_kernel come FIRST in the split workspace (a fixed place, whatever the
+// mini-batch size), the panels behind them
+constexpr size_t kIcmRecBytes = kPairHeaderBytes + 2 * (size_t)kPairMaxTiles * 2 * kPairRecBytes;
+static_assert(kIcmRecBytes % 256 == 0, "panels stay 256-byte aligned");
+static char* icm_panels_base(const ppoaf_icm_update_args_t* a) {
+    return reinterpret_cast<char*>(a->split_workspace) + (a->fuse_kernels ? kIcmRecBytes : 0);
+}
+
 static int make_icm(const ppoaf_icm_update_args_t* a, IcmDev& u, bool training = true) {
     PPOAF_REQUIRE(a, "icm_update: null args");
     PPOAF_REQUIRE(a->hidden == 64 || a->hidden == 128, "icm_update: hidden=%d is not an instantiated width (64, 128)", a->hidden);
@@ -1021,7 +1135,8 @@ static int make_icm(const ppoaf_icm_update_args_t* a, IcmDev& u, bool training =
     u.xO = u.dE = u.hI = u.dI = u.oI = u.hF = u.dF = u.aF = nullptr;
     if (training && a->split_workspace) {
         PPOAF_REQUIRE((((uintptr_t)a->split_workspace) & 255) == 0, "icm_update: split_workspace must be 256-byte aligned");
-        const size_t need = icm_split_layout(u, reinterpret_cast<char*>(a->split_workspace), nullptr);
+        PPOAF_REQUIRE(a->fuse_kernels == 0 || a->fuse_kernels == 1, "icm_update: fuse_kernels=%d (0 or 1)", a->fuse_kernels);
+        const size_t need = icm_split_layout(u, icm_panels_base(a), nullptr) + (a->fuse_kernels ? kIcmRecBytes : 0);
         PPOAF_REQUIRE((size_t)a->split_workspace_bytes >= need, "icm_update: split_workspace of %ld B, %zu needed",
                       (long)a->split_workspace_bytes, need);
         u.split = 1;
@@ -1076,10 +1191,36 @@ static int launch_icm_fwd_bwd(const IcmDev& u, hipStream_t s) {
 
 using namespace ppoaf;
 
+// 1 when these arguments run the three kernels as one launch (args->fuse_kernels, the split-wgrad chain, H = 128, LDS room)
+static size_t icm_fused_lds(const IcmDev& u) {
+    const size_t H = (size_t)u.H, HS = H + 4, INP = 16 * ((u.O + 15) / 16) + 4;
+    const int dmax = u.d_inv > u.d_fwd ? u.d_inv : u.d_fwd;
+    return (16 + kRows * INP + 5 * kRows * HS + 160 + 8 * H + kRows * kXS + (4 + dmax) * kRows * HS + 2 * kRows * kMaxOut +
+            (size_t)kNW * 2 * kLineSlot) * 4;
+}
+static bool icm_fuses(const ppoaf_icm_update_args_t* a, const IcmDev& u) {
+    return a->fuse_kernels && u.split && u.H == 128 && u.nT <= kPairMaxTiles && icm_fused_lds(u) + 256 <= 160 * 1024;
+}
+extern "C" int ppoaf_icm_update_fuses_kernels(const ppoaf_icm_update_args_t* args) {
+    IcmDev u;
+    if (make_icm(args, u)) return -1;
+    return icm_fuses(args, u) ? 1 : 0;
+}
+
 extern "C" int ppoaf_icm_update_fwd_bwd(const ppoaf_icm_update_args_t* args, ppoaf_stream_t stream) {
     IcmDev u;
     const int rc = make_icm(args, u);
     if (rc) return rc;
+    if (icm_fuses(args, u)) {
+        const size_t lds = icm_fused_lds(u);
+        static bool big = false;
+        int rc2 = allow_large_lds(reinterpret_cast<const void*>(icm_fused_kernel<8>), lds, big, "icm_fused");
+        if (rc2) return rc2;
+        const unsigned slots = 2u * (unsigned)(u.confine ? (u.nT + 3) / 4 : (u.nT + 7) / 8);
+        hipLaunchKernelGGL(icm_fused_kernel<8>, dim3(8u * slots), dim3(kThreadsU), lds, (hipStream_t)stream, u,
+                           reinterpret_cast<unsigned char*>(args->split_workspace));
+        return check_launch("icm_fused");
+    }
     if (u.H == 64) return launch_icm_fwd_bwd<4>(u, (hipStream_t)stream);
     return launch_icm_fwd_bwd<8>(u, (hipStream_t)stream);
 }
@@ -1090,7 +1231,7 @@ extern "C" int ppoaf_icm_update_reduce(const ppoaf_icm_update_args_t* args, ppoa
     if (rc) return rc;
     if (u.split) {
         IcmWg w;
-        icm_split_layout(u, reinterpret_cast<char*>(args->split_workspace), &w);
+        icm_split_layout(u, icm_panels_base(args), &w);
         int per_xcd = 1;
         for (int x = 0; x < 8; ++x) per_xcd = std::max(per_xcd, w.xcd_job0[x + 1] - w.xcd_job0[x]);
         hipLaunchKernelGGL(icm_wgrad_kernel, dim3((unsigned)(8 * per_xcd + 1)), dim3(256), 0, (hipStream_t)stream, u, w, per_xcd);
@@ -1109,7 +1250,7 @@ extern "C" int ppoaf_icm_update_split_workspace_bytes(const ppoaf_icm_update_arg
     IcmDev u;
     const int rc = make_icm(&a, u);
     if (rc) return rc;
-    *bytes_out = (int64_t)icm_split_layout(u, nullptr, nullptr);
+    *bytes_out = (int64_t)(icm_split_layout(u, nullptr, nullptr) + (args->fuse_kernels ? kIcmRecBytes : 0));
     return PPOAF_OK;
 }
 

@@ -929,13 +929,36 @@ class FusedIcmUpdate:
         a.loss_partials, a.totals = self.loss_partials.data_ptr(), self.totals.data_ptr()
         a.xcd_half = getattr(self, "xcd_half", 0)
         a.split_workspace, a.split_workspace_bytes = None, 0
+        a.fuse_kernels = 0
         if self.split:
+            # one launch for the encoder / model / encoder-backward kernels (csrc/icm_update.hip: icm_fused_kernel); its exchange
+            # records sit at the start of the workspace, so the flag must not change once the workspace exists
+            a.fuse_kernels = int(self.fuse_kernels and not getattr(self, "_fuse_disabled", ""))
             if self._split_space is None:                # sized once, for the full batch size (a tail mini-batch needs less)
                 need = C.c_int64(0)
                 _lib.check(self._lib.ppoaf_icm_update_split_workspace_bytes(C.byref(a), C.byref(need)), "icm_update_split_workspace_bytes")
                 self._split_space = torch.zeros(int(need.value), dtype=torch.uint8, device=pol.device)
+                self._split_fused_layout = a.fuse_kernels
+            elif self._split_fused_layout != a.fuse_kernels:      # switched off after a failed launch: panels move to the front
+                self._split_fused_layout = a.fuse_kernels
             a.split_workspace, a.split_workspace_bytes = self._split_space.data_ptr(), self._split_space.numel()
+            self._fuses = a.fuse_kernels == 1 and self._lib.ppoaf_icm_update_fuses_kernels(C.byref(a)) == 1
         return a
+
+    fuse_kernels = True                # False: the three kernels as three launches (bitwise the same; tests compare the two)
+    fused_launches = 0                 # single launches issued in this process (graph replays not counted)
+    _REC_BYTES = 256 + 2 * 32 * 2 * 16384     # csrc/icm_update.hip: kIcmRecBytes
+
+    def fuse_reason(self):
+        """'' when a mini-batch's encoder / model / encoder-backward kernels run as one launch, else why not."""
+        if not self.fuse_kernels:
+            return "off (fuse_kernels = False)"
+        if getattr(self, "_fuse_disabled", ""):
+            return "disabled after a failed launch: " + self._fuse_disabled
+        if not self.split:
+            return "the slab chain runs (PPOAF_SPLIT_WGRAD=0)"
+        self._args_for(self.B)
+        return "" if getattr(self, "_fuses", False) else "hidden width other than 128, or no LDS room for the three phases"
 
     def begin_epoch(self, perm):
         pol, buf = self.pol, self.pol.buffer
@@ -955,6 +978,8 @@ class FusedIcmUpdate:
         K.minibatch_gather([(flat(v), t[k]) for k, v in fields.items()], self.perm, buf.row_map)   # one launch per epoch
         self.cursor.zero_()
         self.totals.zero_()
+        if self._split_space is not None and getattr(self, "_split_fused_layout", 0):
+            self._split_space[:self._REC_BYTES].zero_()         # the exchange records are tagged with the cursor, which restarts now
         sig = (t["obs"].data_ptr(), buf.observations.data_ptr(), buf.next_observations.data_ptr(), buf.actions.data_ptr(),
                buf.num_transitions, self.perm.data_ptr(), float(pol.icm_beta), getattr(self, "xcd_half", 0))
         if self._args.get("sig") != sig:
@@ -970,6 +995,9 @@ class FusedIcmUpdate:
     def _one(self, args):
         lib, st, ref = self._lib, K.stream(), C.byref(args)
         rc = lib.ppoaf_icm_update_fwd_bwd(ref, st)
+        if args.fuse_kernels and getattr(self, "_fuses", False):
+            self._fused_used = True
+            FusedIcmUpdate.fused_launches += 1
         if rc == 0:
             rc = lib.ppoaf_icm_update_reduce(ref, st)
         if rc != 0:
@@ -999,9 +1027,17 @@ class FusedIcmUpdate:
             n -= k
         return True
 
+    def _epoch_state(self):
+        opt, icm = self.pol.icm_optim, self.pol.icm_model
+        return [icm.flat_params, opt.exp_avg, opt.exp_avg_sq, opt.step_count]
+
     def run_epoch(self):
         args = self._args_for(self.B)
         left = self.n_full
+        self._fuse_snapshot = None
+        if args.fuse_kernels and getattr(self, "_fuses", False) and not self.multi:
+            # what the epoch starts from (620 KB at C3), should a partner workgroup not answer (end_epoch)
+            self._fuse_snapshot = [t.clone() for t in self._epoch_state()]
         use_graph = self.ppo.use_graphs and (not self.multi or self.xchg is not None)   # RCCL calls are not captured
         chunk = self.graph_chunk if self.n_full < 8 * self.graph_chunk else 4 * self.graph_chunk   # long epochs: fewer, longer graphs
         if left > 0 and self._c_loop(args, left):
@@ -1030,8 +1066,36 @@ class FusedIcmUpdate:
         if self.tail:
             self._one(self._args_for(self.tail))
 
+    def _fused_failure(self):
+        """After a host synchronisation: '' or why the epoch's single launches did not complete."""
+        if not getattr(self, "_fused_used", False):
+            return ""
+        self._fused_used = False
+        word = self._split_space[:4].view(torch.int32)
+        if int(word.item()) == 0:
+            return ""
+        word.zero_()
+        return "icm_fused_kernel: a wait for the partner workgroup's records ran out of time (another process on this GPU?)"
+
     def end_epoch(self):
         """-> numpy [sum of icm_loss over mini-batches, mini-batch count] (summed over ranks)."""
+        if getattr(self, "_fused_used", False):
+            torch.cuda.current_stream().synchronize()
+            why = self._fused_failure()
+            if why:
+                if self._fuse_snapshot is None:
+                    raise _lib.PpoafError(why + ".  Set FusedIcmUpdate.fuse_kernels = False to use three launches.")
+                import sys
+                print(f"[ppo_and_friends_amd] {why}; restoring the epoch's starting state and continuing with three launches per mini-batch",
+                      file=sys.stderr, flush=True)
+                self._fuse_disabled = why
+                for t, keep in zip(self._epoch_state(), self._fuse_snapshot):
+                    t.copy_(keep)
+                self.cursor.zero_()
+                self.totals.zero_()
+                self._args = {"sig": self._args.get("sig")}
+                self._graphs.clear()
+                self.run_epoch()
         return _reduce_totals(self, self.totals)
 
 

@@ -488,6 +488,53 @@ def test_c3_icm_split_wgrad_chain_matches_the_slab_form_at_full_size(monkeypatch
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2])
 
 
+def test_c3_icm_single_launch_is_bitwise_the_three_launches(monkeypatch):
+    """
+    Round 4: K14's encoder / model / encoder-backward kernels as ONE launch per mini-batch on workgroup pairs (icm_fused_kernel:
+    encodings and encoding gradients change hands as tagged records, activations stay in LDS) against the three launches, at
+    C3 size: first one mini-batch's gradient bucket and losses, then two epochs (the second restarts the record tags) --
+    parameters, both Adam moments and totals BITWISE equal, graph replay and eager launches, unconfined and on an XCD half.
+    """
+    from ppo_and_friends_amd.fused_update import FusedIcmUpdate
+    outs = {}
+    for fuse, graphs, half in ((False, True, 0), (True, True, 0), (True, False, 0), (True, True, 2), (False, True, 2)):
+        monkeypatch.setattr(FusedIcmUpdate, "fuse_kernels", fuse)
+        before = FusedIcmUpdate.fused_launches
+        ppo, E, T, A = _c_config("C3", use_graphs=graphs)
+        ppo.rollout()
+        pol = ppo.policies["p"]
+        pol.train()
+        fused = FusedIcmUpdate(ppo, "p")
+        fused.xcd_half = half
+        assert fused.split
+        perm = torch.randperm(len(pol.dataset), device=pol.device, generator=torch.Generator(device=pol.device).manual_seed(3))
+        fused.begin_epoch(perm)
+        assert (fused.fuse_reason() == "") == fuse, fused.fuse_reason()
+        steps = pol.icm_optim.step_count.clone()
+        keep = [t.clone() for t in fused._epoch_state()]
+        fused._one(fused._args_for(256))
+        torch.cuda.synchronize()
+        g1, l1 = pol.icm_model.flat_grads.clone(), fused.totals.clone()
+        for t, k in zip(fused._epoch_state(), keep):
+            t.copy_(k)
+        for _ in range(2):
+            fused.begin_epoch(perm)
+            fused.run_epoch()
+            t = fused.end_epoch()
+        n_mb = E * T // 256
+        assert t[1] == n_mb and int(pol.icm_optim.step_count.item()) == int(steps.item()) + 2 * n_mb
+        assert (FusedIcmUpdate.fused_launches > before) == fuse and fused.fuse_reason() == ("" if fuse else "off (fuse_kernels = False)")
+        outs[(fuse, graphs, half)] = (g1, l1, pol.icm_model.flat_params.clone(), pol.icm_optim.exp_avg.clone(),
+                                      pol.icm_optim.exp_avg_sq.clone(), np.array(t, dtype=np.float64))
+    for ref_key, keys in (((False, True, 0), [(True, True, 0), (True, False, 0)]), ((False, True, 2), [(True, True, 2)])):
+        ref = outs[ref_key]
+        for key in keys:
+            got = outs[key]
+            for i, what in enumerate(("first gradient bucket", "first losses", "parameters", "exp_avg", "exp_avg_sq")):
+                assert torch.equal(got[i], ref[i]), f"{key}: {what} differ, max |d| {float((got[i] - ref[i]).abs().max()):.3e}"
+            assert np.array_equal(got[5], ref[5]), (got[5], ref[5])
+
+
 def test_c3_xcd_halves_change_placement_only():
     """
     args.xcd_half (K12 / K14 fwd_bwd launches confined to XCDs 0-3 / 4-7, as the overlapped PPO / ICM epochs run them) moves
