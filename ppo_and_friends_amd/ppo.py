@@ -427,8 +427,7 @@ class PPO:
                     buf.boot_value[t].copy_(v_next)
                 buf.end_kind[t] = torch.where(terminated, 1, torch.where(boot, 2, 0)).to(torch.int8)
                 ep_ts = torch.where(terminated | boot, torch.zeros_like(ep_ts), ep_ts)
-                if not last:
-                    buf.fixed_length = False
+                buf.fixed_length = False        # (also at the last row: an env may TERMINATE there -- ts_per_rollout = 1 made it visible)
             obs, critic_obs = nxt_obs, nxt_cobs
         # bootstrap values: V(next obs).  For ends before the last row the next
         # observation's value is the value logged at t+1 (same critic, same
@@ -563,8 +562,7 @@ class PPO:
                 kind = torch.where(term_e, 1, torch.where(boot, 2, 0)).to(torch.int8)
                 for c in ctxs:
                     c["buf"].end_kind[t] = kind.repeat(c["n"])
-                    if not last:
-                        c["buf"].fixed_length = False
+                    c["buf"].fixed_length = False
                 ep_ts = torch.where(term_e | boot, torch.zeros_like(ep_ts), ep_ts)
             obs, critic_obs = nxt_obs, nxt_cobs
         self._obs = (obs, critic_obs)

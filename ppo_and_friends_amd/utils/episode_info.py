@@ -115,7 +115,7 @@ class RolloutBuffer:
         self.end_kind[t].index_copy_(0, col_idxs, kind.expand(col_idxs.numel()).contiguous())
         self.boot_value[t].index_copy_(0, col_idxs, self._as_tensor(ending_values, torch.float32).reshape(-1))
         self.boot_reward[t].index_copy_(0, col_idxs, self._as_tensor(ending_rewards, torch.float32).reshape(-1))
-        if t != self.T - 1:
+        if t != self.T - 1 or bool(terminal.any()):      # (a terminal end at the last row is not a bootstrapped one)
             self.fixed_length = False
 
     def compute_advantages(self, gamma, lambd, bootstrap_clip, use_gae, adv_only=False, timing_events=None):
