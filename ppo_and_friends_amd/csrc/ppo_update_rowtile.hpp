@@ -139,7 +139,10 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     const int n_bias = (depth + 1) * H, n_wout = out_dim * H;
     const bool copy_fits = n_bias <= kCopyRegs * kThreadsU && n_wout <= kCopyRegs * kThreadsU;
     auto request_weights = [&]() {
-        if (deep && has_tile) {
+        // separate launches: request order = arrival order (a wave's loads return in order) -- layer 0's operands, biases and
+        // output weights go out BEFORE the 2 x 8 KB per wave of hidden-layer sets, so the first layer starts after one
+        // memory round trip instead of behind the whole stream (round 4)
+        if (NT && deep && has_tile) {
             load_fwd_set<HT, NT>(P + offW(1), wave * 16, lane, fr);
             load_fwd_set<HT, NT>(P + offW(2), wave * 16, lane, fr2);
         }
@@ -167,9 +170,25 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
                 if (i < n_wout) wout_reg[r] = ld1<NT>(P + offW(depth) + i);
             }
         }
+        if (!NT && deep && has_tile) {
+            load_fwd_set<HT, NT>(P + offW(1), wave * 16, lane, fr);
+            load_fwd_set<HT, NT>(P + offW(2), wave * 16, lane, fr2);
+        }
     };
     // three-launch chain: the weights first (cold misses, nothing to wait for).  Persistent forms: the row loads
     // first, then the hook (the wait for the previous Adam phase), then the weights (L2 hits).
+    // per-epoch tables in shuffled order: an input row's address depends on the cursor only -- requested now (16 x in_dim <=
+    // 1024 values: two per thread), dropped below where the row turns out to be padding
+    const float* x_src = which == 0 ? u.obs : u.critic_obs;
+    const bool x_pre = !NT && u.pregathered && kRows * in_dim <= 2 * kThreadsU;
+    float xr[2] = {0.f, 0.f};
+    if (x_pre) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + q * kThreadsU;
+            if (idx < kRows * in_dim && (long)g * kRows + idx / in_dim < B) xr[q] = x_src[(base + (long)g * kRows) * in_dim + idx];
+        }
+    }
     if (!NT) request_weights();
 
     if (tid < kRows) {
@@ -266,8 +285,15 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
     PPOAF_STAMP(1);
 
     // ---- S1: gather the input rows (K4)
-    {
-        const float* src = which == 0 ? u.obs : u.critic_obs;
+    if (x_pre) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + q * kThreadsU;
+            const int s = idx / in_dim, i = idx - s * in_dim;
+            if (idx < kRows * in_dim && sRow[s] >= 0) sX[s * INP + i] = xr[q];
+        }
+    } else {
+        const float* src = x_src;
         for (int idx = tid; idx < kRows * in_dim; idx += kThreadsU) {
             const int s = idx / in_dim, i = idx - s * in_dim;
             const int row = sRow[s];
