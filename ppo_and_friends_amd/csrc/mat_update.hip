@@ -56,7 +56,6 @@ struct MatDev {
     float* loss_partials; double* totals;
     double* norm_scratch; int64_t* step_count; int fuse_norm;
     int pregathered;     // obs / actions / adv / old_lp / rtg are per-epoch tables in shuffled order (entry i belongs to perm[i])
-    int l2_warmup;       // diagnostic (PPOAF_MAT_L2_WARMUP=1): touch every line of the bucket at kernel start, as rounds 1-2 did
     // split-wgrad chain (args->split_workspace): fwd_bwd computes NO weight gradient of the 18 64x64 linears; it publishes
     // their inputs and dLoss/dz tiles into panels and the reduce launch becomes mat_update_wgrad_kernel
     int split;
@@ -684,11 +683,6 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     float* sDOutC = c.sDOutC; float* sDOutA = c.sDOutA;
     auto G = [&](int k) -> float* { return slab + u.goff[k]; };
 
-    // L2 warm-up: the bucket was rewritten by the Adam kernel a moment ago, so this XCD's L2 holds none of it and
-    // each of the ~50 dependent linears below would otherwise start with a cold miss.  One load per 128-byte
-    // line of the whole bucket is issued here; they complete during the gather / first phases.
-    float l2_touch = 0.f;
-    if (u.l2_warmup) for (long i = (long)tid * 32; i < u.total; i += (long)kMT * 32) l2_touch += P[i];
     // ---- rows, per-token scalars, mini-batch statistics
     if (tid < kRows) {
         int row = -1, act = 0;
@@ -997,7 +991,6 @@ __global__ __launch_bounds__(kMT) void mat_update_fwd_bwd_kernel(MatDev u) {
     narrow_dgrad(W(C_ENC_W), O, S1, S2, kMHS, wave, lane);                                     // d (obs LayerNorm output) in S2[:, :O]
     MAT_SYNC();
     MAT_STAMP(9);
-    if (l2_touch == 1.2345e38f) slab[0] = l2_touch;            // keeps the warm-up loads alive
     // observation LayerNorm: only its affine parameters receive gradient
     if (tid < 64) {
         if (tid < O) {
@@ -1598,8 +1591,6 @@ static int make_mat(const ppoaf_mat_update_args_t* a, MatDev& u) {
         u.slab_stride = compact;
         u.n_small4 = (int)(compact >> 2);
     }
-    static const int warm = [] { const char* e = getenv("PPOAF_MAT_L2_WARMUP"); return e && e[0] == '1' ? 1 : 0; }();
-    u.l2_warmup = warm;
     return PPOAF_OK;
 }
 

@@ -315,10 +315,15 @@ template <int HT, bool ALIGNED>
 __device__ __forceinline__ void load_fwd_frags_ld(const float* __restrict__ W, long ldw, int n0, int lane,
                                                   float4 (&fr)[HT]) {
     const float* w = W + (long)(n0 + (lane & 15)) * ldw + 4 * (lane >> 4);
+    if (ALIGNED) {       // even chunks first: chunks c and c + 1 share a 128-byte line of every row (see load_fwd_frags)
 #pragma unroll
-    for (int c = 0; c < HT; ++c) {
-        if (ALIGNED) fr[c] = *reinterpret_cast<const float4*>(w + 16 * c);
-        else fr[c] = make_float4(w[16 * c], w[16 * c + 1], w[16 * c + 2], w[16 * c + 3]);
+        for (int c = 0; c < HT; c += 2) fr[c] = *reinterpret_cast<const float4*>(w + 16 * c);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 1; c < HT; c += 2) fr[c] = *reinterpret_cast<const float4*>(w + 16 * c);
+    } else {
+#pragma unroll
+        for (int c = 0; c < HT; ++c) fr[c] = make_float4(w[16 * c], w[16 * c + 1], w[16 * c + 2], w[16 * c + 3]);
     }
 }
 template <int HT>
