@@ -535,6 +535,39 @@ def test_c3_icm_single_launch_is_bitwise_the_three_launches(monkeypatch):
             assert np.array_equal(got[5], ref[5]), (got[5], ref[5])
 
 
+def test_failed_icm_single_launch_is_redone_on_three_launches(monkeypatch):
+    """
+    An icm_fused_kernel launch in which a workgroup's partner did not answer (word 0 of the record region; simulated after the
+    first epoch's launches) costs that epoch's work, not the run: the epoch's starting state comes back, the single launch is
+    switched off with the reason, the epoch runs again on three launches -- bitwise what fuse_kernels = False produces.
+    """
+    from ppo_and_friends_amd.fused_update import FusedIcmUpdate
+    outs = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(FusedIcmUpdate, "fuse_kernels", fuse)
+        ppo, E, T, A = _c_config("C3")
+        ppo.rollout()
+        pol = ppo.policies["p"]
+        pol.train()
+        fused = FusedIcmUpdate(ppo, "p")
+        perm = torch.randperm(len(pol.dataset), device=pol.device, generator=torch.Generator(device=pol.device).manual_seed(4))
+        totals = []
+        for ep in range(2):
+            fused.begin_epoch(perm)
+            fused.run_epoch()
+            if fuse and ep == 0:
+                assert fused.fuse_reason() == ""
+                fused._split_space[:4].view(torch.int32).fill_(1)          # "a partner did not answer"
+            totals.append(np.array(fused.end_epoch(), dtype=np.float64))
+        if fuse:
+            assert "ran out of time" in fused.fuse_reason()
+        outs[fuse] = (pol.icm_model.flat_params.clone(), pol.icm_optim.exp_avg.clone(), pol.icm_optim.exp_avg_sq.clone(),
+                      int(pol.icm_optim.step_count.item()), totals)
+    a, b = outs[True], outs[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3]
+    assert all(np.array_equal(x, y) for x, y in zip(a[4], b[4]))
+
+
 def test_c3_xcd_halves_change_placement_only():
     """
     args.xcd_half (K12 / K14 fwd_bwd launches confined to XCDs 0-3 / 4-7, as the overlapped PPO / ICM epochs run them) moves
