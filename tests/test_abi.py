@@ -140,3 +140,52 @@ def test_no_memset_in_capturable_paths():
             for m in re.finditer(r"hipMemset(?:Async)?\(\s*([^,]+),", open(os.path.join(root, f)).read()):
                 found.add((f, m.group(1).strip()))
     assert found <= allowed, found - allowed
+
+
+def test_row_pair_and_split_workspace_layout_on_the_host(built_lib):
+    """
+    The host-side arithmetic of round 4's row pairs (no launch, no GPU): the split workspace grows by exactly the record
+    region (header + (2 depth - 3) exchanges x 32 tiles x 2 halves x 16 KB per 256-wide network), the error word sits where
+    the panels of the full batch size end, and shapes the pairs do not cover report -1.
+    """
+    import ctypes as C
+    lib = built_lib.load()
+
+    def desc(in_dim, hidden, depth, out_dim, offset):
+        size, pad4 = 0, lambda x: (x + 3) // 4 * 4
+        for l in range(depth + 1):
+            i = in_dim if l == 0 else hidden
+            o = out_dim if l == depth else hidden
+            size += pad4(i * o) + pad4(o)
+        return built_lib.MlpDesc(in_dim=in_dim, hidden=hidden, depth=depth, out_dim=out_dim, activation=0, offset=offset,
+                                 size=size, log_std_offset=-1)
+
+    def args(critic_hidden, critic_depth, pairs, B=256, stride=256):
+        a = built_lib.PpoUpdateArgs()
+        a.actor = desc(18, 128, 3, 5, 0)
+        a.critic = desc(54, critic_hidden, critic_depth, 1, a.actor.size)
+        a.bucket_total = a.actor.size + a.critic.size
+        for f in ("params", "grads", "exp_avg", "exp_avg_sq", "slabs", "step_counts", "lr", "norm_scratch", "obs", "critic_obs",
+                  "raw_actions", "advantages", "old_log_probs", "rewards_to_go", "values", "perm", "cursor", "vn_mean", "vn_var",
+                  "vn_count", "loss_partials", "totals"):
+            setattr(a, f, 0x10000)                       # never dereferenced by the layout entry points
+        a.head_kind, a.n_rows, a.B, a.batch_stride, a.n_ranks = 0, 4096, B, stride, 1
+        a.beta1, a.beta2, a.adam_eps, a.grad_scale = 0.9, 0.999, 1e-5, 1.0
+        a.row_pairs = pairs
+        return a
+
+    def ws_bytes(a):
+        n = C.c_int64(0)
+        assert lib.ppoaf_ppo_update_split_workspace_bytes(C.byref(a), C.byref(n)) == 0, lib.ppoaf_last_error()
+        return n.value
+
+    def err_off(a):
+        n = C.c_int64(7)
+        assert lib.ppoaf_ppo_update_row_pairs_error_offset(C.byref(a), C.byref(n)) == 0, lib.ppoaf_last_error()
+        return n.value
+
+    plain, paired = ws_bytes(args(256, 3, 0)), ws_bytes(args(256, 3, 1))
+    assert paired - plain == 256 + 3 * 32 * 2 * 16384
+    assert ws_bytes(args(256, 2, 1)) - ws_bytes(args(256, 2, 0)) == 256 + 1 * 32 * 2 * 16384
+    assert err_off(args(256, 3, 1)) == plain and err_off(args(256, 3, 1, B=64, stride=256)) == plain      # a tail mini-batch: same place
+    assert err_off(args(256, 3, 0)) == -1 and err_off(args(128, 3, 1)) == -1 and err_off(args(256, 5, 1)) == -1
