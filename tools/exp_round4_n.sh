@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B: the fused tail's input panels as whole lines against operand-order loads (tools/libppoaf_hip_oldtail.so)
+# (the "before" library: check out the parent of the change, `bash tools/build_variant.sh <name>`, come back -- variant libraries are not kept in the tree)
 set -o pipefail
 mkdir -p gpurun_out
 run() {  # label, env..., -- bench args

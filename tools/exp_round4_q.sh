@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B: arrival-order requests + input rows requested up front in the row-tiled body (tools/libppoaf_hip_oldrt.so = before)
+# (the "before" library: check out the parent of the change, `bash tools/build_variant.sh <name>`, come back -- variant libraries are not kept in the tree)
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_row_pairs.py -q -x > gpurun_out/t_fs.log 2>&1 || { tail -30 gpurun_out/t_fs.log; exit 1; }

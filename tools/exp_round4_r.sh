@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B at C5: K15 / K16 fragment loads in even / odd chunk order, the diagnostic warm-up switch gone (tools/libppoaf_hip_oldmat.so = before)
+# (the "before" library: check out the parent of the change, `bash tools/build_variant.sh <name>`, come back -- variant libraries are not kept in the tree)
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_end_to_end.py -q -x -k "mat or MAT or c5" > gpurun_out/t_mat.log 2>&1 || { tail -30 gpurun_out/t_mat.log; exit 1; }
