@@ -226,7 +226,6 @@ def build_config(name, args, device, rank):
     return ppo, ppo.policies["cartpole"], dict(E=E, T=T, A=A, O=O, workload=workload)
 
 
-PMC_WS_MINIBATCHES = 16          # tools/update_pmc_driver.py --minibatches (one persistent launch)
 
 
 def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
@@ -248,9 +247,6 @@ def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
     pol.train()
     N = pol.buffer.num_transitions
     fused.begin_epoch(torch.randperm(N, device=pol.device))
-    # a policy with an ICM runs its PPO epoch beside the ICM epoch on a second stream, where the persistent kernel is not
-    # used (ppo.py: _train_with_icm): probe the kernel the timed region ran, not the one a lone epoch would pick
-    fused.ws_allowed = not getattr(pol, "enable_icm", False)
     args = fused._args_for(B)
     ref = C.byref(args)
     lin = lambda net: sum(2 * m.weight.numel() for m in net.modules() if isinstance(m, torch.nn.Linear))
@@ -280,42 +276,6 @@ def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
                 1.0, float(clip) if clip is not None else 0.0, opt.norm_scratch.data_ptr(), fused.norm_partials,
                 opt.grad_norm.data_ptr(), st), "adam")
             evs.append(ev)
-    elif fused.ws_reason() == "":
-        # the two-XCD persistent kernel: ONE launch = every full mini-batch of an epoch; begin / end of each launch
-        # stamped into events by the launch itself
-        fwd = lin(pol.actor) + lin(pol.critic)
-        ha, hc = args.actor.hidden, args.critic.hidden
-        mask = fused._ws_mask()
-        mask = ((1 if ha >= 256 else 0) | (2 if hc >= 256 else 0)) if mask is None or mask < 0 else mask
-        mode = lambda bit: "true" if mask & bit else "false"
-        n_mb = N // B
-        kernel = f"ppo_update_ws_kernel<{ha}, {hc}, {mode(1)}, {mode(2)}>"
-        desc = "3 x 2 x sum(Linear weights of actor + critic) x B x mini-batches in the launch"
-        reps = 4
-        for _ in range(reps):
-            ev = (K.event_create(), K.event_create())
-            fused.begin_epoch(torch.randperm(N, device=pol.device))
-            fused.ws_timing_events = [ev]
-            fused.run_epoch()
-            fused.end_epoch()
-            evs.append(ev)
-        torch.cuda.synchronize()
-        us = sorted(K.event_elapsed_ms(a, b) * 1e3 for a, b in evs)
-        avg = sum(us) / len(us)
-        flop = 3 * fwd * B * n_mb
-        tf = flop / (avg * 1e-6) / 1e12
-        pmc = update_pmc_traffic(config, "ppo_update_ws_kernel")
-        per_mb = None if pmc is None else pmc["bytes"] // PMC_WS_MINIBATCHES       # the profiled launch ran that many mini-batches
-        return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 5), "flop_per_launch": int(flop), "flop_formula": desc,
-                "avg_launch_us": round(avg, 2), "median_launch_us": round(us[len(us) // 2], 2), "launches": len(us),
-                "minibatches_per_launch": n_mb, "us_per_minibatch": round(avg / n_mb, 3),
-                "launches_per_step": ppo.epochs_per_iter,
-                "timing": "kernel begin/end events (hipExtLaunchKernelGGL) on epoch launches right after the timed region; "
-                          "profiles/ holds the rocprofv3 summary of the same command",
-                "traffic": None if per_mb is None else per_mb * n_mb, "traffic_per_minibatch": per_mb,
-                "traffic_source": None if pmc is None else
-                f"{pmc['source']}: (2 x FETCH_SIZE + WRITE_SIZE) of a profiled {PMC_WS_MINIBATCHES}-mini-batch launch, scaled to this launch's mini-batches"}
     else:
         fwd = lin(pol.actor) + lin(pol.critic)
         ha, hc = args.actor.hidden // 16, args.critic.hidden // 16
@@ -337,7 +297,6 @@ def update_kernel_roofline(ppo, pol, B, launches=64, config="C2"):
             _lib.check(lib.ppoaf_ppo_update_adam(ref, 3 if fused.split else 0, st), "adam")
             evs.append(ev)
     torch.cuda.synchronize()
-    fused.ws_allowed = True
     us = sorted(K.event_elapsed_ms(a, b) * 1e3 for a, b in evs)
     avg = sum(us) / len(us)
     flop = mat_flop if pol.agent_grouping else passes * fwd * B
@@ -365,7 +324,6 @@ def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline
     ppo, pol, d = build_config(name, args, device, rank)
     E, T, A = d["E"], d["T"], d["A"]
     from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
-    ws_xchg_before = FusedPolicyUpdate.ws_exchange_launch_count
 
     def barrier():
         if mpi_utils.distributed_path():
@@ -435,10 +393,8 @@ def run_config(name, args, device, rank, world, steps, warmup, with_gae_roofline
     fused = [f for f in getattr(ppo, "_fused", {}).values() if f is not None]
     peer = bool(fused) and all(getattr(f, "xchg", None) is not None for f in fused)
     c_loop = FusedPolicyUpdate._rccl_comm_cache not in ("unset", None)
-    in_launch = FusedPolicyUpdate.ws_exchange_launch_count > ws_xchg_before
     exchange = None if not mpi_utils.distributed_path() else \
-        ("K17 peer mappings (xGMI) inside the persistent two-XCD update kernel (one launch per epoch; tail mini-batch: in-graph chain)"
-         if peer and in_launch else "K17 peer mappings (xGMI), in-graph" if peer else
+        ("K17 peer mappings (xGMI), in-graph" if peer else
          ("RCCL all-reduce, chain issued from C (ppoaf_ppo_update_chain_allreduce)" if c_loop else "RCCL all-reduce, eager loop"))
     if exchange is not None and fused:                       # why that path (self-test verdict / fallback reason)
         exchange += f" [{getattr(fused[0], 'xchg_reason', '')}]"
@@ -514,23 +470,12 @@ def main():
     notes = {}
 
     def run_measured(name, steps, warmup, with_gae):
-        """run_config; if the two-XCD persistent kernel (which needs the GPU to itself: all CUs of two XCDs for an
-        epoch) cannot complete its launch, say so in the line and measure the three-launch chain instead of nothing."""
-        try:
-            return run_config(name, args, device, rank, world, steps, warmup, with_gae)
-        except _lib.PpoafError as e:
-            if "ppo_update_ws" not in str(e) or os.environ.get("PPOAF_WS", "1") == "0":
-                raise
-            notes[name] = f"three-launch chain (the persistent kernel failed: {str(e)[:200]})"
-            print(f"[bench] {name}: {notes[name]}", file=sys.stderr, flush=True)
-            os.environ["PPOAF_WS"] = "0"
-            torch.cuda.synchronize()
-            return run_config(name, args, device, rank, world, steps, warmup, with_gae)
+        return run_config(name, args, device, rank, world, steps, warmup, with_gae)
 
     main_res = run_measured(args.config, args.steps, args.warmup, True)
     update_note = notes.get(args.config)
     others = {}
-    # N > 1: the line the driver's scaling run reads is C2's; the other shapes' N > 1 paths (K17 inside the persistent kernel,
+    # N > 1: the line the driver's scaling run reads is C2's; the other shapes' N > 1 paths (256-wide critics on row pairs,
     # overlapped PPO / ICM epochs) are rehearsed by `PPOAF_REHEARSE_MULTI_RANK=1 bench.py --config <C>` and the two-process
     # tests, and run here only on request -- a failure in one of them must not cost the headline measurement
     others_wanted = world == 1 or os.environ.get("PPOAF_BENCH_OTHER_CONFIGS_MULTI", "0") == "1"

@@ -37,7 +37,7 @@ typedef void* ppoaf_stream_t;            /* hipStream_t */
 #define PPOAF_E_INVALID    -1            /* bad argument / unsupported shape   */
 #define PPOAF_E_LAUNCH     -2            /* hipLaunch / runtime error          */
 
-#define PPOAF_ABI_VERSION 6
+#define PPOAF_ABI_VERSION 7
 
 int         ppoaf_abi_version(void);
 const char* ppoaf_last_error(void);
@@ -440,35 +440,6 @@ int ppoaf_ppo_update_wgrad_adam(const ppoaf_ppo_update_args_t* args, void* ctl, 
 int ppoaf_ppo_update_wgrad_adam_timed(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
                                       void* start_event, void* stop_event, ppoaf_stream_t stream);
 int ppoaf_ppo_update_adam(const ppoaf_ppo_update_args_t* args, int compute_norms, ppoaf_stream_t stream);
-/* Weight-stationary persistent form of the same update (csrc/ppo_update_ws.hip; single rank): n_minibatches
- * consecutive mini-batches in ONE launch, processed layer by layer over all B rows -- forward / dgrad as 64x32 output
- * tiles, weight gradients as complete 64x64 tiles (K = the B rows: no slabs, no reduce pass), clip + Adam by the owner
- * of each parameter column -- on `workers` (<= 32) workgroups per network, the actor's all on XCD xcc_actor and the
- * critic's on xcc_critic (two different XCDs, 0..7), phases separated by flag barriers inside the XCD's L2.
- * Replaces ppo.py:2292-2469 for a run of mini-batches exactly as fwd_bwd -> reduce -> adam does (same arguments, same
- * totals / value-normaliser / step-counter bookkeeping).  A row-tiled network (see layered_mask) runs the chain's own
- * arithmetic in the chain's own order: bitwise the chain's parameters; a layered network sums its weight gradients in
- * another association (float32 rounding apart).
- * ctl: ppoaf_ppo_update_ws_ctl_bytes() of device memory, 16-byte aligned, owned by the caller during the launch;
- * workspace: ppoaf_ppo_update_ws_workspace_bytes() of device memory, 256-byte aligned (activations, dLoss/dz and the
- * output-layer partials of one mini-batch).  The third 32-bit word of ctl is non-zero afterwards if a wait ran out of
- * wait_seconds.  Shapes: hidden width 32, 64, 128 or 256, out_dim <= 8, 16 <= B <= 512; anything else returns
- * PPOAF_E_INVALID (callers keep the three-launch chain for those).  mb_offset must be 0; the cursor advances by
- * n_minibatches once both networks have finished.
- * layered_mask selects each network's decomposition: bit 0 (actor) / bit 1 (critic) set = layered as described above
- * (in_dim <= 64); clear = ROW-TILED: phase 1 is the fwd_bwd body of the three-launch chain on ceil(B/16) of the
- * workers (slabs), phase 2 folds the slabs for the parameter columns each worker owns -- sums stay in registers next
- * to the prefetched parameter / moment values -- and phase 3 applies clip + Adam to them (three barriers per
- * mini-batch); -1 = automatic (layered for 256-wide networks, whose 16-row workgroups sit at their MFMA floor,
- * row-tiled below).  Measured on MI355X: with a 256-wide critic (C4 shapes) 52 us per mini-batch against 74 us for the
- * three-launch chain; with two 128-wide networks (C2) 30-33 us against 29 us for the hipGraph-replayed chain -- this
- * package's host therefore calls it only when a network is 256 wide.  start_event / stop_event (from ppoaf_event_create, or NULL) receive the kernel's begin / end. */
-int ppoaf_ppo_update_ws_ctl_bytes(void);
-int ppoaf_ppo_update_ws_workspace_bytes(const ppoaf_ppo_update_args_t* args, int32_t layered_mask, int64_t* bytes_out);
-int ppoaf_ppo_update_ws(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl, void* workspace,
-                        int64_t workspace_bytes, int32_t workers, int32_t xcc_actor, int32_t xcc_critic,
-                        int32_t layered_mask, double wait_seconds, void* start_event, void* stop_event,
-                        ppoaf_stream_t stream);
 
 
 /* ------------------------------------------------------------------------ *
@@ -844,22 +815,6 @@ int ppoaf_ppo_update_adam_exchanged(const ppoaf_ppo_update_args_t* args, ppoaf_p
 int ppoaf_ppo_update_tail_exchange_floats(const ppoaf_ppo_update_args_t* args, int64_t* floats_out);
 int ppoaf_ppo_update_wgrad_adam_exchange(const ppoaf_ppo_update_args_t* args, void* ctl, double wait_seconds,
                                          ppoaf_peer_exchange_t* xchg, double xchg_wait_seconds, ppoaf_stream_t stream);
-/* ppoaf_ppo_update_ws for N > 1 ranks: the same persistent launch with the K17 exchange as a phase of every mini-batch
- * (mpi_avg_gradients at ppo.py:2443-2448 without leaving the kernel).  Worker w of a network owns the same parameter
- * columns on every rank and is exchange group (network * 32 + w): a row-tiled network sends its folded column sums
- * from registers between its second and third barrier; a layered network gets one more phase (its owners' columns of
- * the complete gradient -> slot -> rank-ordered sum -> gradient bucket + the summed gradient's norm partial) before
- * clip + Adam.  Sums are added in rank order: every rank ends with bitwise the same parameters.  x must have been
- * created for args->bucket_total floats and must be used by these launches only (its element -> group map differs
- * from ppoaf_peer_exchange_allreduce's); every rank issues the same launches with the same `workers`.  Slot, flag and
- * peer accesses are system-scope atomic accesses (no cache invalidates inside the epoch-long launch); xchg_fences != 0
- * adds system-scope release / acquire fences around them (always on for coarse-grained slots).  A peer that does not
- * show up within xchg_wait_seconds sets the exchange's error word (ppoaf_peer_exchange_status) and the launch drains. */
-int ppoaf_ppo_update_ws_exchange(const ppoaf_ppo_update_args_t* args, int64_t n_minibatches, void* ctl, void* workspace,
-                                 int64_t workspace_bytes, int32_t workers, int32_t xcc_actor, int32_t xcc_critic,
-                                 int32_t layered_mask, double wait_seconds, ppoaf_peer_exchange_t* x,
-                                 double xchg_wait_seconds, int32_t xchg_fences, void* start_event, void* stop_event,
-                                 ppoaf_stream_t stream);
 int ppoaf_peer_exchange_destroy(ppoaf_peer_exchange_t* x);
 
 /* ------------------------------------------------------------------------ *

@@ -61,7 +61,7 @@ class PpoUpdateArgs(C.Structure):
                 ("xcd_half", C.c_int32), ("row_pairs", C.c_int32)]
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class PolicyStepArgs(C.Structure):
@@ -193,12 +193,6 @@ SIGNATURES = {
                                        _ptr, _ptr, _ptr]),
     "ppoaf_ppo_update_fwd_bwd": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr]),
     "ppoaf_ppo_update_fwd_bwd_timed": (C.c_int, [C.POINTER(PpoUpdateArgs), _ptr, _ptr, _ptr]),
-    "ppoaf_ppo_update_ws_ctl_bytes": (C.c_int, []),
-    "ppoaf_ppo_update_ws_workspace_bytes": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int32, C.POINTER(C.c_int64)]),
-    "ppoaf_ppo_update_ws": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int64, _ptr, _ptr, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
-                                      C.c_int32, C.c_double, _ptr, _ptr, _ptr]),
-    "ppoaf_ppo_update_ws_exchange": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int64, _ptr, _ptr, C.c_int64, C.c_int32, C.c_int32,
-                                               C.c_int32, C.c_int32, C.c_double, _ptr, C.c_double, C.c_int32, _ptr, _ptr, _ptr]),
     "ppoaf_ppo_update_reduce": (C.c_int, [C.POINTER(PpoUpdateArgs), C.c_int, _ptr]),
     "ppoaf_ppo_update_split_workspace_bytes": (C.c_int, [C.POINTER(PpoUpdateArgs), C.POINTER(C.c_int64)]),
     "ppoaf_ppo_update_row_pairs_error_offset": (C.c_int, [C.POINTER(PpoUpdateArgs), C.POINTER(C.c_int64)]),

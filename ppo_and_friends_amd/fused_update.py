@@ -88,13 +88,11 @@ def _reduce_totals(upd, totals):
     if not upd.multi:
         return t.cpu().numpy()
     broken = 0.0
-    for x in (upd.xchg, getattr(upd, "xchg_ws", None), getattr(upd, "xchg_sp", None)):
+    for x in (upd.xchg, getattr(upd, "xchg_sp", None)):
         if x is not None and x.status()[1] != 0:
             broken = 1.0
-    ws_failure = upd._persistent_failure() if hasattr(upd, "_persistent_failure") else ""
-    if ws_failure:                 # this rank's persistent launch did not complete: its peers' exchanges timed out on it
-        upd._ws_disabled = ws_failure
-        broken = 1.0
+    if hasattr(upd, "_persistent_failure") and upd._persistent_failure():
+        broken = 1.0               # a bounded in-kernel wait of this rank ran out: its peers' exchanges timed out on it
     t = torch.cat([t, torch.tensor([broken], dtype=t.dtype, device=t.device)])
     mpi_utils.allreduce_sum_(t)
     out = t.cpu().numpy()
@@ -167,8 +165,6 @@ class FusedPolicyUpdate:
         # N > 1: the per-mini-batch gradient exchange.  K17 over peer mappings when every rank can (same
         # host, IPC + self-test passed: collective decision), else the RCCL all-reduce in an eager loop.
         self.xchg, self.xchg_reason = (peer_exchange.open_exchange(total, dev) if self.multi else (None, "single rank"))
-        # the persistent two-XCD kernel of an N > 1 run carries the exchange inside the launch, with its own element ->
-        # group map (one group per worker), hence its own slots and flag words; opened collectively, like the first
         # the fused tail launch of the split-wgrad chain (csrc/ppo_update_tail.hip) carries the exchange as a phase of
         # every weight-gradient job (one exchange group per workgroup, job-major tiles in the slots: an object of its own
         # again; at most 512 workgroups = the flag words of one exchange object): two launches per mini-batch on N > 1 ranks too.
@@ -183,11 +179,6 @@ class FusedPolicyUpdate:
             if self.xchg_sp is None:
                 self.xchg_reason += f"; fused-tail exchange refused ({why})"
         self.split, self.split_reason = self._split_wanted()
-        self.xchg_ws = None
-        if self.xchg is not None and self._ws_wanted():
-            self.xchg_ws, why = peer_exchange.open_exchange(total, dev)
-            if self.xchg_ws is None:
-                self.xchg_reason += f"; persistent-kernel exchange refused ({why})"
 
     def _split_blocks(self):
         """Workgroups of ppoaf_ppo_update_wgrad for this policy's shapes (csrc/ppo_update_dev.hpp: split_wgrad_blocks)."""
@@ -298,13 +289,6 @@ class FusedPolicyUpdate:
             ctl = self._tail_ctl = torch.zeros((n + 63) // 64 * 16, dtype=torch.int32, device=self.pol.device)
         FusedPolicyUpdate.tail_launches += 1
         return ctl.data_ptr()
-
-    def _ws_wanted(self):
-        """Would `ws_reason` pick the persistent kernel for this policy's shapes (before any epoch table exists)?"""
-        import os
-        if os.environ.get("PPOAF_WS", "1") == "0":
-            return False
-        return self._ws_mask() >= 0 or max(self.actor_desc.hidden, self.critic_desc.hidden) >= 256
 
     # ------------------------------------------------------------------ args
     def _make_args(self, B):
@@ -611,15 +595,7 @@ class FusedPolicyUpdate:
             args.mb_offset, args.cursor_advance = 0, 1
 
     def _persistent_failure(self):
-        """After a host synchronisation: '' or why the last persistent launch did not complete (its control block)."""
-        ctl = getattr(self, "_ws_ctl", None)
-        if ctl is not None and getattr(self, "_ws_used", False):
-            self._ws_used = False
-            words = ctl[:4].tolist()                      # tickets[2], error, done
-            if words[2] != 0 or words[3] != 2:
-                return (f"ppo_update_ws: the last launch did not complete (error word {words[2]}, networks finished {words[3]} of 2, "
-                        f"worker tickets drawn {words[0]} / {words[1]}): a network did not get all of its workgroups onto its XCD "
-                        "(another process on this GPU, or a partition mode that exposes a single XCD?)")
+        """After a host synchronisation: '' or which bounded in-kernel wait of the epoch's launches ran out (row pairs, fused tail)."""
         if getattr(self, "_pairs_used", False):
             self._pairs_used = False
             word = self._split_space[self._pair_region:self._pair_region + 4].view(torch.int32)
@@ -645,121 +621,34 @@ class FusedPolicyUpdate:
         """Raising form (tests, probes that drive single launches)."""
         why = self._persistent_failure()
         if why:
-            raise _lib.PpoafError(why + ".  Set PPOAF_WS=0 to use the launch chain.")
+            raise _lib.PpoafError(why)
 
-    # ---- a persistent launch that cannot get its workers resident must not cost the run: the epoch is redone on the chain
+    # ---- a launch whose workgroups could not all be resident must not cost the run: the epoch is redone without that form
     def _epoch_state(self):
         pol = self.pol
         return [pol.policy_params, pol.policy_exp_avg, pol.policy_exp_avg_sq, pol.policy_step_counts, pol.policy_norm_scratch,
                 self.vn_mean, self.vn_var, self.vn_count, pol.buffer.values]
 
     def _recover_on_the_chain(self, why):
-        """Single rank: the state the epoch began with comes back, the persistent kernels are switched off for good (with
-        the reason) and the epoch's mini-batches run again through the three-launch chain."""
+        """Single rank: the state the epoch began with comes back, the form that failed stays switched off (with the reason:
+        _persistent_failure) and the epoch's mini-batches run again."""
         import sys
-        print(f"[ppo_and_friends_amd] {why}; restoring the epoch's starting state and continuing on the three-launch chain",
+        print(f"[ppo_and_friends_amd] {why}; restoring the epoch's starting state and running the epoch again without it",
               file=sys.stderr, flush=True)
-        self._ws_disabled = why
-        for t, keep in zip(self._epoch_state(), self._ws_snapshot):
+        for t, keep in zip(self._epoch_state(), self._epoch_snapshot):
             t.copy_(keep)
         self.cursor.zero_()
         self.totals.zero_()
         self.n_done = 0
         self.run_epoch()
 
-    # ---- weight-stationary persistent form (csrc/ppo_update_ws.hip: ppo_update_ws_kernel)
-    ws_chunk = 4096                    # mini-batches per launch
-    ws_workers = 32                    # workgroups per network: every CU of its XCD
-    ws_wait_seconds = 2.0              # bound of every in-kernel wait
-    ws_launch_count = 0                # launches of the kernel in this process (tests: the path really ran)
-    ws_exchange_launch_count = 0       # ... of which with the K17 exchange inside the launch (N > 1)
-
-    def ws_reason(self):
-        """'' when the epoch's full mini-batches can run through the weight-stationary persistent kernel, else why not."""
-        import os
-        if type(self) is not FusedPolicyUpdate:
-            return "K12 (MLP policies) only"
-        if os.environ.get("PPOAF_WS", "1") == "0":
-            return "off (PPOAF_WS=0)"
-        if getattr(self, "_ws_disabled", ""):
-            return "disabled after a failed launch: " + self._ws_disabled
-        if not getattr(self, "ws_allowed", True):
-            return "the epoch shares the GPU with the ICM update on a second stream (a persistent kernel would starve it)"
-        if self.multi and self.xchg_ws is None:
-            return "N > 1 without a K17 exchange for the persistent kernel (three-launch chain)"
-        mask = self._ws_mask()
-        if mask < 0 and self.pairs_reason() == "" and self.tail_reason() == "":
-            # round 4 (C4, one box): fwd_bwd with the 256-wide critic's row tiles on workgroup pairs + the fused tail
-            # 39 us per mini-batch, this kernel 52-54.  PPOAF_WS_MODE=layered|rowtile still selects it.
-            return "a 256-wide network on row pairs: the two-launch chain is faster"
-        if mask < 0 and max(self.actor_desc.hidden, self.critic_desc.hidden) < 256:
-            # measured (C2, after the host-side shuffle prefetch stopped stalling): graph-replayed chain 29.4 us per
-            # mini-batch, persistent kernel with both networks row-tiled 32.4 us.  The persistent kernel wins where a
-            # network is layered (256-wide: C4 52 vs 74 us); PPOAF_WS_MODE=rowtile|layered forces it.
-            return "both networks narrower than 256: the graph-replayed three-launch chain is faster"
-        cached = getattr(self, "_ws_shape_reason", None)
-        if cached is None or cached[0] != (self.B, mask):
-            need = C.c_int64(0)
-            rc = self._lib.ppoaf_ppo_update_ws_workspace_bytes(C.byref(self._args_for(self.B)), mask, C.byref(need))
-            cached = self._ws_shape_reason = ((self.B, mask), "" if rc == 0 else self._lib.ppoaf_last_error().decode("utf-8", "replace"), int(need.value))
-        return cached[1]
-
-    @staticmethod
-    def _ws_mask():
-        """PPOAF_WS_MODE: auto (layered for 256-wide networks, row-tiled below), layered, rowtile, or a bit mask."""
-        import os
-        m = os.environ.get("PPOAF_WS_MODE", "auto")
-        if m.lstrip("-").isdigit():
-            return int(m)
-        if m not in ("auto", "layered", "rowtile"):
-            raise ValueError(f"PPOAF_WS_MODE={m!r}: expected auto, layered, rowtile or a bit mask (bit 0 actor, bit 1 critic)")
-        return {"auto": -1, "layered": 3, "rowtile": 0}[m]
-
-    def _ws_buffers(self):
-        need = self._ws_shape_reason[2]
-        ctl = getattr(self, "_ws_ctl", None)
-        if ctl is None:
-            n = int(self._lib.ppoaf_ppo_update_ws_ctl_bytes())
-            ctl = self._ws_ctl = torch.zeros((n + 3) // 4, dtype=torch.int32, device=self.pol.device)
-        wsb = getattr(self, "_ws_space", None)
-        if wsb is None or wsb.numel() < need:
-            wsb = self._ws_space = torch.zeros(need, dtype=torch.uint8, device=self.pol.device)
-        return ctl, wsb
-
     def run_epoch(self):
         args = self._args_for(self.B)
         left = self.n_full
-        self._ws_snapshot = None
-        if left > 0 and self.n_done == 0 and (self.ws_reason() == "" or self.tail_reason() == "" or self.pairs_reason() == ""):
+        self._epoch_snapshot = None
+        if left > 0 and self.n_done == 0 and (self.tail_reason() == "" or self.pairs_reason() == ""):
             # what the epoch starts from (a few buckets of <= 1 MB: device-to-device copies), should the launch not complete
-            self._ws_snapshot = [t.clone() for t in self._epoch_state()]
-        if left > 0 and self.ws_reason() == "":
-            import os
-            ctl, wsb = self._ws_buffers()
-            workers = self.ws_workers
-            # one GPU per rank: XCDs 0 / 1.  Ranks rehearsing on ONE device (PPOAF_SHARE_DEVICE=1, tests) take XCD pairs of
-            # their own -- two worker groups cannot share a CU's LDS, and every rank's workers must be resident at once
-            slot = mpi_utils.get_rank() % 4 if os.environ.get("PPOAF_SHARE_DEVICE", "0") == "1" else 0
-            xa, xc = (2 * slot) % 8, (2 * slot + 1) % 8
-            st = K.stream()
-            wait_s = self.ws_wait_seconds                  # bound of every in-kernel wait
-            while left > 0:
-                n = min(left, self.ws_chunk)
-                ev = self.ws_timing_events.pop() if getattr(self, "ws_timing_events", None) else (None, None)
-                if self.xchg_ws is not None:
-                    # N > 1: K17 as a phase of every mini-batch inside the launch (system-scope accesses, no fences)
-                    _lib.check(self._lib.ppoaf_ppo_update_ws_exchange(
-                        C.byref(args), n, ctl.data_ptr(), wsb.data_ptr(), wsb.numel(), workers, xa, xc, self._ws_mask(), wait_s,
-                        self.xchg_ws.handle, self.xchg_ws.wait_seconds, 0,
-                        ev[0], ev[1], st), "ppo_update_ws_exchange")
-                    FusedPolicyUpdate.ws_exchange_launch_count += 1
-                else:
-                    _lib.check(self._lib.ppoaf_ppo_update_ws(C.byref(args), n, ctl.data_ptr(), wsb.data_ptr(), wsb.numel(), workers,
-                                                             xa, xc, self._ws_mask(), wait_s, ev[0], ev[1], st), "ppo_update_ws")
-                self._ws_used = True
-                FusedPolicyUpdate.ws_launch_count += 1
-                left -= n
-                self.n_done += n
+            self._epoch_snapshot = [t.clone() for t in self._epoch_state()]
         use_graph = self.ppo.use_graphs and (not self.multi or self.xchg is not None)   # RCCL calls are not captured
         chunk = self.graph_chunk if self.n_full < 8 * self.graph_chunk else 4 * self.graph_chunk   # long epochs: fewer, longer graphs
         while left > 0:
@@ -794,11 +683,11 @@ class FusedPolicyUpdate:
     def end_epoch(self):
         """-> numpy totals[9] (sums of the 8 loss scalars over mini-batches, mini-batch count)."""
         ppo = self.ppo
-        if not self.multi and (getattr(self, "_ws_used", False) or getattr(self, "_tail_used", False) or getattr(self, "_pairs_used", False)):
+        if not self.multi and (getattr(self, "_tail_used", False) or getattr(self, "_pairs_used", False)):
             torch.cuda.current_stream().synchronize()
             why = self._persistent_failure()
             if why:                                       # before anything of the failed epoch reaches the normaliser
-                if self._ws_snapshot is None:
+                if self._epoch_snapshot is None:
                     raise _lib.PpoafError(why)
                 self._recover_on_the_chain(why)
         if ppo.normalize_values:

@@ -854,7 +854,7 @@ class PPO:
         for f in active:
             f.xchg.close()
             f.xchg, f.xchg_reason = None, f"disabled: {why}"
-            for name in ("xchg_ws", "xchg_sp"):
+            for name in ("xchg_sp",):
                 if getattr(f, name, None) is not None:
                     getattr(f, name).close()
                     setattr(f, name, None)
@@ -893,18 +893,13 @@ class PPO:
         fused.xcd_half, fused_icm.xcd_half = (1, 2) if halves else (0, 0)
         fused.begin_epoch(loader.epoch_permutation())
         fused_icm.begin_epoch(loader.epoch_permutation())
-        # two concurrent kernel chains: the persistent two-XCD kernel would serialise them (experiment switch only)
-        fused.ws_allowed = False
         main = torch.cuda.current_stream()
         sa, sb = K.concurrent_stream_pair(self.device)         # two streams on different hardware queues
         sa.wait_stream(main); sb.wait_stream(main)
-        try:
-            with torch.cuda.stream(sa):
-                fused.run_epoch()
-            with torch.cuda.stream(sb):
-                fused_icm.run_epoch()
-        finally:
-            fused.ws_allowed = True                     # the restriction belongs to this overlapped epoch only
+        with torch.cuda.stream(sa):
+            fused.run_epoch()
+        with torch.cuda.stream(sb):
+            fused_icm.run_epoch()
         main.wait_stream(sa); main.wait_stream(sb)
         loader.prefetch()
         self._publish_epoch_stats(policy_id, fused.end_epoch())

@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = built_lib.load()
     for name in _declared():
         assert hasattr(lib, name), f"libppoaf_hip.so lacks {name}"
-    assert lib.ppoaf_abi_version() == 6
+    assert lib.ppoaf_abi_version() == 7
 
 
 def test_ctypes_table_matches_header(built_lib):
@@ -99,13 +99,12 @@ def test_every_entry_point_sits_under_a_reference_citation():
         assert needle in src, needle
 
 
-def test_two_xcd_kernel_completion_guard_reports_on_the_host():
+def test_bounded_wait_guard_reports_on_the_host():
     """
-    The persistent update kernel reports through its control block (tickets[2], error word, networks finished); the host
-    side must notice -- never train on -- when a wait ran out of its budget or a network's worker group never ran
-    (e.g. a partition mode that exposes one XCD): `_persistent_failure` names the reason (the epoch is then redone on the
-    three-launch chain, tests/test_gpu_ws_recovery.py), `_check_persistent` raises it.  Pure host logic: checked on
-    fabricated control blocks.
+    The launches with in-kernel hand-overs (row pairs, fused tail) report a wait that ran out of its budget through an error
+    word; the host side must notice -- never train on -- it: `_persistent_failure` names the reason and switches the form off
+    (the epoch is then redone without it, tests/test_gpu_recovery.py), `_check_persistent` raises it.  Pure host logic:
+    checked on fabricated control blocks.
     """
     import types
     import pytest
@@ -113,27 +112,30 @@ def test_two_xcd_kernel_completion_guard_reports_on_the_host():
     from ppo_and_friends_amd import _lib
     from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
 
-    def block(words):
-        ns = types.SimpleNamespace(_ws_ctl=torch.tensor(words + [0] * 12, dtype=torch.int32), _ws_used=True)
+    def block(tail_error, pair_error):
+        ns = types.SimpleNamespace(_tail_ctl=torch.tensor([5, 0, tail_error, 0] + [0] * 12, dtype=torch.int32), _tail_used=True,
+                                   _split_space=torch.zeros(64, dtype=torch.uint8), _pair_region=16, _pairs_used=True,
+                                   _graphs={"x": 1}, _args={"sig": 3, 256: object()})
+        ns._split_space[16:20].view(torch.int32).fill_(pair_error)
         ns._persistent_failure = lambda: FusedPolicyUpdate._persistent_failure(ns)
         return ns
 
-    ok = block([32, 32, 0, 2])
-    assert FusedPolicyUpdate._persistent_failure(ok) == ""        # complete launch: silent, flag consumed
-    assert ok._ws_used is False
-    for words in ([32, 32, 1, 1], [32, 0, 0, 1], [32, 32, 0, 0]):
-        assert "did not complete" in FusedPolicyUpdate._persistent_failure(block(words))
-        with pytest.raises(_lib.PpoafError, match="did not complete"):
-            FusedPolicyUpdate._check_persistent(block(words))
+    ok = block(0, 0)
+    assert FusedPolicyUpdate._persistent_failure(ok) == "" and ok._tail_used is False and ok._pairs_used is False
+    bad = block(1, 0)
+    assert "ran out of time" in FusedPolicyUpdate._persistent_failure(bad) and bad._tail_disabled and not bad._graphs
+    bad = block(0, 1)
+    assert "partner" in FusedPolicyUpdate._persistent_failure(bad) and bad._pairs_disabled and bad._args == {"sig": 3}
+    with pytest.raises(_lib.PpoafError, match="ran out of time"):
+        FusedPolicyUpdate._check_persistent(block(1, 0))
 
 
 def test_no_memset_in_capturable_paths():
-    """Source-level guard: hipMemsetAsync stays out of every entry point that may be captured into a hipGraph.  The three
-    allowed uses are never captured: the control blocks of the persistent launches (one launch per epoch, issued eagerly)
-    and the one-time clears of ppoaf_peer_exchange_create."""
+    """Source-level guard: hipMemsetAsync stays out of every entry point that may be captured into a hipGraph.  The
+    allowed uses are never captured: the one-time clears of ppoaf_peer_exchange_create."""
     import re
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ppo_and_friends_amd", "csrc")
-    allowed = {("ppo_update.hip", "ctl"), ("ppo_update_ws.hip", "ctl"), ("peer_exchange.hip", "local"), ("peer_exchange.hip", "x->base")}
+    allowed = {("peer_exchange.hip", "local"), ("peer_exchange.hip", "x->base")}
     found = set()
     for f in sorted(os.listdir(root)):
         if f.endswith((".hip", ".hpp")):

@@ -113,15 +113,10 @@ def test_c1_config_two_full_iterations_match_cpu_port(update_mode):
         assert d.max() < 5e-4 and np.mean(d > 3e-5) < 1e-2, (d.max(), np.mean(d > 3e-5))
 
 
-@pytest.mark.parametrize("update_mode,use_graphs", [("fused", True), ("fused", False), ("fused", None),
-                                                    ("torch", True), ("torch", False)])
+@pytest.mark.parametrize("update_mode,use_graphs", [("fused", True), ("fused", False), ("torch", True), ("torch", False)])
 def test_update_epochs_match_cpu_port(update_mode, use_graphs, monkeypatch):
     """Both product update paths (fused K12 kernels; torch-ROCm MLPs + K2..K11) against the CPU port.  The fused path
-    runs its three-launch chain (graph-replayed / eager) for use_graphs True / False and the two-XCD persistent kernel
-    when use_graphs is None."""
-    monkeypatch.setenv("PPOAF_WS", "0" if use_graphs is not None else "1")
-    monkeypatch.setenv("PPOAF_WS_MODE", "rowtile")      # (128-wide networks: "auto" would keep the chain)
-    use_graphs = bool(use_graphs)
+    runs its launch chain graph-replayed / eagerly for use_graphs True / False."""
     E, T, B, epochs = 16, 32, 64, 2
     ppo = _make(E, T, B, epochs, use_graphs=use_graphs, update_mode=update_mode)
     cpu = _oracle_like(ppo, B)
@@ -236,12 +231,15 @@ def test_fused_update_equals_torch_update(cfg):
     np.testing.assert_allclose(val0, val1, rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("k12_form", ["chain", "auto", "layered", "rowtile"])
+K12_FORMS = {"chain": {}, "three_launches": {"PPOAF_FUSED_TAIL": "0"}, "slabs": {"PPOAF_SPLIT_WGRAD": "0"}}
+
+
+@pytest.mark.parametrize("k12_form", sorted(K12_FORMS))
 def test_fused_update_fuzz_against_the_torch_path(k12_form, monkeypatch):
     """
-    k12_form: which form of K12 the fused path takes for the epoch's full mini-batches -- the three-launch chain, or
-    the two-XCD persistent kernel with its automatic / all-layered / all-row-tiled decomposition (shapes a form does
-    not cover fall back to the chain by themselves).
+    k12_form: which form of K12 the fused path takes -- the default chain (split-wgrad panels, fused tail launch; 256-wide
+    networks on workgroup pairs), the same with separate weight-gradient and Adam launches, or weight-gradient slabs +
+    the slab reduce (shapes a form does not cover fall back by themselves).
     Randomised shapes (hypothesis, derandomised) for K12 + K6/K7: observation widths that are not multiples of
     4 or 16, 1-8 actions of either kind, every instantiated width pair with equal actor / critic width, depth
     1-3, batch sizes with ragged last workgroups and epoch tails, terminations.  Fused kernels against the
@@ -251,10 +249,10 @@ def test_fused_update_fuzz_against_the_torch_path(k12_form, monkeypatch):
     from hypothesis import given, settings, strategies as st, HealthCheck
     from ppo_and_friends_amd.spaces import Box, Discrete
     from ppo_and_friends_amd.ppo import PermutationLoader
-    monkeypatch.setenv("PPOAF_WS", "0" if k12_form == "chain" else "1")
-    monkeypatch.setenv("PPOAF_WS_MODE", "auto" if k12_form == "chain" else k12_form)
+    for k, v in K12_FORMS[k12_form].items():
+        monkeypatch.setenv(k, v)
 
-    @settings(max_examples=24 if k12_form in ("chain", "auto") else 15, deadline=None, derandomize=True,
+    @settings(max_examples=24 if k12_form == "chain" else 15, deadline=None, derandomize=True,
               suppress_health_check=list(HealthCheck))
     @given(O=st.integers(1, 70), kind=st.sampled_from(["d", "c"]), n=st.integers(1, 8),
            hidden=st.sampled_from([32, 64, 128, 256]), depth=st.integers(1, 4), B=st.integers(2, 300),
@@ -1151,7 +1149,7 @@ def test_rollout_dataset_order_fuzz_against_the_cpu_port():
     run()
 
 
-@pytest.mark.parametrize("k12_form", ["chain", "auto", "layered"])
+@pytest.mark.parametrize("k12_form", ["chain", "slabs", "tiles"])
 def test_fused_update_fuzz_with_different_actor_and_critic_shapes(k12_form, monkeypatch):
     """
     K12 / K6+K7 with the MAPPO shape: several agents share the policy, the critic sees the
@@ -1163,8 +1161,11 @@ def test_fused_update_fuzz_with_different_actor_and_critic_shapes(k12_form, monk
     from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
     from ppo_and_friends_amd.spaces import Box, Discrete
     dev = torch.device("cuda", 0)
-    monkeypatch.setenv("PPOAF_WS", "0" if k12_form == "chain" else "1")
-    monkeypatch.setenv("PPOAF_WS_MODE", "auto" if k12_form == "chain" else k12_form)
+    from ppo_and_friends_amd import fused_update
+    if k12_form == "slabs":
+        monkeypatch.setenv("PPOAF_SPLIT_WGRAD", "0")
+    if k12_form == "tiles":                                  # one workgroup per 16-row tile of the 256-wide critic instead of a pair
+        monkeypatch.setattr(fused_update.FusedPolicyUpdate, "row_pairs", False)
 
     @settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(A=st.integers(2, 4), O=st.integers(1, 24), NA=st.integers(2, 8), widths=st.sampled_from([(128, 256), (64, 128)]),
@@ -1258,9 +1259,8 @@ def test_graph_chunking_fuzz_equals_eager_launches(monkeypatch):
     """
     hipGraph chunking of the fused chains (32-mini-batch chunks, eager remainder, epoch tail, a second epoch that
     replays the captured chunk): for random small batch sizes and dataset lengths the graph-replayed run and the
-    eager run of the same kernels must agree bitwise -- K12 (three-launch chain: PPOAF_WS=0), and K15 for a MATPolicy.
+    eager run of the same kernels must agree bitwise -- K12 (the launch chain), and K15 for a MATPolicy.
     """
-    monkeypatch.setenv("PPOAF_WS", "0")
     from hypothesis import given, settings, strategies as st, HealthCheck
     from ppo_and_friends_amd.ppo import PPO
     from ppo_and_friends_amd.policies.mat_policy import MATPolicy

@@ -68,9 +68,7 @@ def test_c3_filters_counts_and_moments_at_full_size():
 
 def test_c3_icm_update_makes_progress_and_overlap_is_exact(monkeypatch):
     """K14 + K12 at C3 size: a second epoch on the same rollout lowers the ICM loss; two-stream overlap == sequential,
-    bitwise (both on the three-launch chain: the sequential order would otherwise take the two-XCD persistent kernel,
-    whose sums associate differently)."""
-    monkeypatch.setenv("PPOAF_WS", "0")
+    bitwise (both on the launch chain)."""
     ppo, E, T, A = _c_config("C3")
     ppo.rollout()
     ppo.train_on_rollout()
@@ -117,12 +115,11 @@ def test_c5_mat_update_full_size_properties():
 @pytest.mark.parametrize("name", ["C2", "C4"])
 def test_k12_full_size_graph_replay_equals_eager_launches(name, monkeypatch):
     """
-    (three-launch chain: PPOAF_WS=0; the persistent kernel has its own full-size test below)
+    (the launch chain)
     K12 at the metric's own size (C2: 2048 mini-batches per epoch; C4: MAPPO shape, 3 agents, 256-wide critic):
     the hipGraph-replayed chain and the eager launches are two execution modes of the same kernels -- bitwise
     equal weights, optimiser state and statistics; every mini-batch counted once; value normaliser saw every row.
     """
-    monkeypatch.setenv("PPOAF_WS", "0")
     outs = []
     for graphs in (True, False):
         ppo, E, T, A = _c_config(name, use_graphs=graphs)
@@ -141,97 +138,6 @@ def test_k12_full_size_graph_replay_equals_eager_launches(name, monkeypatch):
     assert outs[0][2] == outs[1][2] and np.array_equal(outs[0][3], outs[1][3])
 
 
-@pytest.mark.parametrize("name", ["C2", "C4"])
-def test_k12_full_size_persistent_kernel_matches_the_chain_and_is_reproducible(name, monkeypatch):
-    """
-    The two-XCD persistent kernel (one launch per epoch) at the metric's own size against the three-launch chain on the
-    same rollout and shuffle.  Row-tiled networks (C2: both; C4: the actor) run the chain's own arithmetic in the
-    chain's own order: BITWISE equal parameters and optimiser state.  The layered 256-wide critic of C4 sums in another
-    association: statistics to tolerance -- its weights after 1536 Adam steps on unlearnable targets are as far from
-    the chain's as the chain's are from a run of itself with ONE critic weight moved by 1 ulp (max |dw| 0.04, 79 % of
-    the weights off by > 1e-4: `tools/probes/c4_chaos.py`), so they are not compared.  And bitwise equal to itself run
-    to run.
-    """
-    from ppo_and_friends_amd import fused_update
-    monkeypatch.setenv("PPOAF_WS_MODE", "rowtile" if name == "C2" else "auto")   # C2: "auto" would keep the chain
-    monkeypatch.setenv("PPOAF_SPLIT_WGRAD", "0")     # bitwise claim: against the SLAB chain, whose arithmetic the row-tiled workers repeat
-    outs = []
-    for ws in ("1", "1", "0"):
-        monkeypatch.setenv("PPOAF_WS", ws)
-        before = fused_update.FusedPolicyUpdate.ws_launch_count
-        ppo, E, T, A = _c_config(name)
-        ppo.rollout()
-        pol = ppo.policies["p"]
-        ppo.train_on_rollout()
-        assert (fused_update.FusedPolicyUpdate.ws_launch_count > before) == (ws == "1")
-        n_mb = E * T * A // 256
-        assert int(pol.policy_step_counts[0].item()) == int(pol.policy_step_counts[1].item()) == n_mb
-        vs = ppo.value_normalizers["p"].running_stats
-        assert abs(vs.count - (E * T * A + 1e-4)) < 1e-3
-        sd = ppo.status_dict["p"]
-        n_actor = int(ppo._fused_updater("p", 256).actor_desc.size)
-        outs.append((pol.policy_params.clone(), pol.policy_exp_avg_sq.clone(),
-                     np.array([sd[k] for k in ("actor loss", "critic loss", "kl avg", "weighted entropy")]), vs.mean.copy(), n_actor))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
-    np.testing.assert_allclose(outs[0][2], outs[2][2], rtol=2e-4, atol=2e-6)
-    np.testing.assert_allclose(outs[0][3], outs[2][3], rtol=1e-6)
-    n = outs[0][4] if name == "C4" else outs[0][0].numel()          # C4: the critic is layered
-    assert torch.equal(outs[0][0][:n], outs[2][0][:n]) and torch.equal(outs[0][1][:n], outs[2][1][:n])
-
-
-@pytest.mark.parametrize("name", ["C2", "C3", "C4"])
-def test_full_size_single_minibatch_gradient_persistent_kernel_vs_chain(name, monkeypatch):
-    """
-    ONE mini-batch of 256 rows at the BASELINE shapes, no optimiser step compared: the gradient bucket and the loss
-    scalars the two-XCD persistent kernel produces (C2: both networks row-tiled -> bitwise; C3 / C4: row-tiled actor ->
-    bitwise, layered 256-wide critic -> complete-K wgrad sums in another association, 1e-5 of the bucket's largest entry)
-    against the three-launch chain's fwd_bwd + slab reduce on the same rollout, weights and shuffle.  (What the
-    whole-epoch test above cannot compare for the layered critic, whose weights are chaotic after 1536 Adam steps.)
-    """
-    import ctypes as C
-    from ppo_and_friends_amd import _lib, fused_update
-    from ppo_and_friends_amd import kernels as K
-    monkeypatch.setenv("PPOAF_WS_MODE", "rowtile" if name == "C2" else "auto")
-    monkeypatch.setenv("PPOAF_WS", "1")
-    monkeypatch.setenv("PPOAF_SPLIT_WGRAD", "0")          # the slab arithmetic is what a row-tiled worker group repeats bitwise
-    ppo, E, T, A = _c_config(name)
-    ppo.rollout()
-    pol = ppo.policies["p"]
-    pol.train()
-    fused = ppo._fused_updater("p", 256)
-    perm = torch.randperm(len(pol.dataset), device=pol.device, generator=torch.Generator(device=pol.device).manual_seed(3))
-    state = lambda: [pol.policy_params, pol.policy_exp_avg, pol.policy_exp_avg_sq, pol.policy_step_counts, pol.policy_norm_scratch,
-                     fused.vn_mean, fused.vn_var, fused.vn_count, fused.cursor, fused.totals, pol.buffer.values]
-    # ---- the slab chain: fwd_bwd + slab reduce only
-    fused.begin_epoch(perm)
-    keep = [t.clone() for t in state()]
-    args = fused._args_for(256)
-    fused.gradient_only(args)
-    torch.cuda.synchronize()
-    g_chain, t_chain = pol.policy_grads.clone(), fused.totals.clone()
-    for t, k in zip(state(), keep):
-        t.copy_(k)
-    # ---- one mini-batch through the persistent kernel (its Adam phase runs too; the gradient bucket is what it reduced)
-    before = fused_update.FusedPolicyUpdate.ws_launch_count
-    fused.begin_epoch(perm)
-    assert fused.ws_reason() == "", fused.ws_reason()
-    fused.n_full, fused.tail = 1, 0
-    fused.run_epoch()
-    torch.cuda.synchronize()
-    fused._check_persistent()
-    assert fused_update.FusedPolicyUpdate.ws_launch_count == before + 1
-    g_ws, t_ws = pol.policy_grads.clone(), fused.totals.clone()
-    na = int(fused.actor_desc.size)
-    assert torch.equal(g_ws[:na], g_chain[:na]), "row-tiled actor: the chain's arithmetic in the chain's order"
-    scale = float(g_chain[na:].abs().max())
-    d = float((g_ws[na:] - g_chain[na:]).abs().max())
-    if name == "C2":
-        assert torch.equal(g_ws[na:], g_chain[na:])
-    else:
-        assert d <= 1e-5 * scale, f"layered critic gradient: max |dg| {d:.3e} against max |g| {scale:.3e}"
-    np.testing.assert_allclose(t_ws.cpu().numpy(), t_chain.cpu().numpy(), rtol=1e-6, atol=1e-9)
-
-
 @pytest.mark.parametrize("name", ["C2", "C3", "C4"])
 def test_full_size_split_wgrad_chain_matches_the_slab_chain(name, monkeypatch):
     """
@@ -241,7 +147,6 @@ def test_full_size_split_wgrad_chain_matches_the_slab_chain(name, monkeypatch):
     then a whole epoch of each: every mini-batch counted once, statistics to 2e-4, and the split chain bitwise equal to
     itself run to run (graph replay and eager alike).
     """
-    monkeypatch.setenv("PPOAF_WS", "0")
     grads, totals, epochs = {}, {}, {}
     for split in ("0", "1", "1"):
         monkeypatch.setenv("PPOAF_SPLIT_WGRAD", split)
@@ -286,7 +191,6 @@ def test_full_size_fused_tail_is_bitwise_the_three_launch_chain(name, monkeypatc
     and eager launches alike -- and no wait ran out of its budget.
     """
     from ppo_and_friends_amd import fused_update
-    monkeypatch.setenv("PPOAF_WS", "0")                     # (256-wide critics: the chain, not the persistent kernel)
     monkeypatch.setenv("PPOAF_OVERLAP_ICM", "0")
     outs = {}
     for tail, graphs in (("0", True), ("1", True), ("1", False)):
@@ -330,7 +234,6 @@ def test_full_size_row_pairs_are_bitwise_the_one_workgroup_tiles(name, monkeypat
     no partner ever failed to answer.
     """
     from ppo_and_friends_amd import fused_update
-    monkeypatch.setenv("PPOAF_WS", "0")
     monkeypatch.setenv("PPOAF_OVERLAP_ICM", "0")
     outs = {}
     for pairs, graphs in ((False, True), (True, True), (True, False)):

@@ -1,8 +1,7 @@
 """
--m gpu: a persistent update launch that does not complete (its workers could not all be resident: another process on
-the GPU, a partition mode exposing one XCD) must not cost the run.  The epoch's starting state is restored, the
-persistent kernels are switched off for the rest of the run (with the reason) and the epoch is redone on the
-three-launch chain: the result is bitwise what a run with PPOAF_WS=0 produces.
+-m gpu: a launch with in-kernel hand-overs that does not complete (a partner workgroup was not resident in time: another
+process on the GPU) must not cost the run.  The epoch's starting state is restored, the form that failed is switched off
+for the rest of the run (with the reason) and the epoch is redone without it: bitwise what a run without that form produces.
 """
 import numpy as np
 import pytest
@@ -11,13 +10,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(monkeypatch, fail_first_launch, ws):
+def _run(monkeypatch):
     from ppo_and_friends_amd.ppo import PPO
     from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
     from ppo_and_friends_amd.spaces import Box, Discrete
-    from ppo_and_friends_amd import fused_update
-    monkeypatch.setenv("PPOAF_WS", "1" if ws else "0")
-    monkeypatch.setenv("PPOAF_WS_MODE", "2")                 # (round 4: "auto" prefers the chain with row pairs for a 256-wide critic)
     dev = torch.device("cuda", 0)
     E, T, B, O, A = 8, 40, 32, 18, 3
     env_gen = lambda: SyntheticFixedLengthEnv(E, O, Discrete(5), T, dev, reward="uniform", seed=83, num_agents=A, critic_view="policy")
@@ -26,39 +22,13 @@ def _run(monkeypatch, fail_first_launch, ws):
     ppo = PPO(env_gen, settings, device=dev, random_seed=5, normalize_obs=False, normalize_rewards=False, envs_per_proc=E,
               ts_per_rollout=T, batch_size=B, epochs_per_iter=2, update_mode="fused", save_state=False)
     pol = ppo.policies["p"]
-    if fail_first_launch:
-        orig = fused_update.FusedPolicyUpdate._persistent_failure
-        state = {"failed": False}
-
-        def failing(self):
-            why = orig(self)                                    # consumes the launch's flag: the launch itself was fine ...
-            if not state["failed"] and fused_update.FusedPolicyUpdate.ws_launch_count > before:
-                state["failed"] = True                          # ... but is reported as one whose waits ran out of time
-                return "ppo_update_ws: the last launch did not complete (simulated)"
-            return why
-
-        monkeypatch.setattr(fused_update.FusedPolicyUpdate, "_persistent_failure", failing)
-    before = fused_update.FusedPolicyUpdate.ws_launch_count
     for _ in range(2):
         ppo.rollout()
         ppo.train_on_rollout()
-    fused = [f for f in ppo._fused.values() if f is not None][0]
     stats = {k: float(v) for k, v in ppo.status_dict["p"].items() if isinstance(v, (int, float)) and not isinstance(v, bool)}
     vs = ppo.value_normalizers["p"].running_stats
     return dict(w=pol.policy_params.detach().clone(), m=pol.policy_exp_avg.detach().clone(), stats=stats,
-                vn=(float(vs.mean_t), float(vs.var_t), float(vs.count_t)), steps=pol.policy_step_counts.tolist(),
-                launches=fused_update.FusedPolicyUpdate.ws_launch_count - before, disabled=getattr(fused, "_ws_disabled", ""))
-
-
-def test_failed_persistent_launch_is_redone_on_the_chain(monkeypatch):
-    chain = _run(monkeypatch, False, ws=False)
-    assert chain["launches"] == 0
-    rec = _run(monkeypatch, True, ws=True)
-    assert rec["launches"] == 1 and "did not complete" in rec["disabled"]          # one (failed) launch, then never again
-    assert torch.equal(rec["w"], chain["w"]) and torch.equal(rec["m"], chain["m"])
-    assert rec["stats"] == chain["stats"] and rec["vn"] == chain["vn"] and rec["steps"] == chain["steps"]
-    ok = _run(monkeypatch, False, ws=True)
-    assert ok["launches"] == 4 and ok["disabled"] == ""                            # 2 iterations x 2 epochs on the persistent kernel
+                vn=(float(vs.mean_t), float(vs.var_t), float(vs.count_t)), steps=pol.policy_step_counts.tolist())
 
 
 def test_failed_row_pair_launch_is_redone_with_one_workgroup_per_tile(monkeypatch):
@@ -71,7 +41,7 @@ def test_failed_row_pair_launch_is_redone_with_one_workgroup_per_tile(monkeypatc
     """
     from ppo_and_friends_amd import fused_update
     monkeypatch.setattr(fused_update.FusedPolicyUpdate, "row_pairs", False)
-    tiles = _run(monkeypatch, False, ws=False)
+    tiles = _run(monkeypatch)
     monkeypatch.setattr(fused_update.FusedPolicyUpdate, "row_pairs", True)
     before = fused_update.FusedPolicyUpdate.pair_launches
     orig = fused_update.FusedPolicyUpdate.run_epoch
@@ -86,7 +56,7 @@ def test_failed_row_pair_launch_is_redone_with_one_workgroup_per_tile(monkeypatc
             self._split_space[self._pair_region:self._pair_region + 4].view(torch.int32).fill_(1)
 
     monkeypatch.setattr(fused_update.FusedPolicyUpdate, "run_epoch", run_epoch)
-    rec = _run(monkeypatch, False, ws=False)
+    rec = _run(monkeypatch)
     assert state["failed"] and fused_update.FusedPolicyUpdate.pair_launches > before
     assert "did not answer" in state["updater"].pairs_reason()
     assert torch.equal(rec["w"], tiles["w"]) and torch.equal(rec["m"], tiles["m"])

@@ -88,7 +88,7 @@ def _bound(case, key, value, floor):
 def case_id(name, update_mode):
     """Fixture + everything that selects a kernel form (each form sums in its own order, so each has its own measured
     deviation): update mode and the path switches present in the environment."""
-    keys = ("PPOAF_WS", "PPOAF_WS_MODE", "PPOAF_SPLIT_WGRAD", "PPOAF_OVERLAP_ICM", "PPOAF_GRAD_EXCHANGE",
+    keys = ("PPOAF_SPLIT_WGRAD", "PPOAF_OVERLAP_ICM", "PPOAF_GRAD_EXCHANGE",
             "PPOAF_FUSED_TAIL", "WORLD_SIZE")
     env = ",".join(f"{k[6:] if k.startswith('PPOAF_') else k}={os.environ[k]}" for k in keys if k in os.environ)
     return f"{name}/{update_mode}" + (f"[{env}]" if env else "")
@@ -204,8 +204,7 @@ def params_in_bucket_order(pol, bucket, net):
 def first_minibatch_probe(ppo, pol, perm, B):
     """
     Losses + raw gradient bucket of the first mini-batch WITHOUT an optimiser step.
-    fused path: one K12 fwd_bwd + slab-reduce launch -- or, when a persistent form of K12 is selected (two-XCD kernel,
-    single-XCD chain), ONE mini-batch through that very kernel with every piece of state it advances put back afterwards;
+    fused path: one K12 fwd_bwd + the launch that completes the gradient bucket (complete-K wgrad | slab reduce);
     torch path: one _minibatch_step (value-normaliser state restored).
     """
     from ppo_and_friends_amd import _lib
@@ -214,22 +213,6 @@ def first_minibatch_probe(ppo, pol, perm, B):
     perm_t = torch.as_tensor(np.asarray(perm, dtype=np.int64), device=pol.device)
     if fused is not None:
         fused.begin_epoch(perm_t)
-        if fused.n_full >= 1 and fused.ws_reason() == "":
-            state = [pol.policy_params, pol.policy_exp_avg, pol.policy_exp_avg_sq, pol.policy_step_counts, pol.policy_norm_scratch,
-                     fused.vn_mean, fused.vn_var, fused.vn_count, fused.cursor, fused.totals, pol.buffer.values]
-            keep = [t.clone() for t in state]
-            n_full, tail, n_done = fused.n_full, fused.tail, fused.n_done
-            fused.n_full, fused.tail = 1, 0
-            try:
-                fused.run_epoch()                      # one mini-batch, the kernel's own gradient left in policy_grads
-                torch.cuda.synchronize()
-                fused._check_persistent()
-            finally:
-                fused.n_full, fused.tail, fused.n_done = n_full, tail, n_done
-            out = fused.totals.cpu().numpy().copy(), pol.policy_grads.clone()
-            for t, k in zip(state, keep):
-                t.copy_(k)
-            return out
         args = fused._args_for(B)
         steps = pol.policy_step_counts.clone()              # the gradient launch's bookkeeping advances Adam's step counters
         fused.gradient_only(args)                           # fwd_bwd + (complete-K wgrad launch | slab reduce)
@@ -392,7 +375,7 @@ class RankView:
 
 def run_kl_stop_scenario(g, name, update_mode, dev, first_minibatch=None):
     """The fixture's iterations through the product's OWN epoch loop (PPO.train_on_rollout: KL early stop, overlapped
-    PPO / ICM epochs, persistent launches, whatever the environment selected).  Checks, per iteration, that the loop
+    PPO / ICM epochs, whatever the environment selected).  Checks, per iteration, that the loop
     ran exactly the epochs the reference ran, each epoch's statistics (on N > 1 ranks: the all-reduced ones, and the
     value normaliser fed by every rank's data), and the weights at the end.  `first_minibatch(ppo, pol, pi)`: a probe
     run after the first rollout, before any optimiser step.  Returns (ppo, epochs run per iteration)."""
@@ -463,10 +446,9 @@ def run_kl_stop_scenario(g, name, update_mode, dev, first_minibatch=None):
     return ppo, ran_all
 
 
-# how the epoch loop is run: the graph-replayed launch chain (the default at these widths), the persistent two-XCD kernel
-# (one launch per epoch; the stop depends on the totals it hands back), the PPO / ICM epochs in turn instead of overlapped
-# on two streams, and the torch-ROCm module path
-KL_PATHS = {"chain": {}, "ws_rowtile": {"PPOAF_WS_MODE": "rowtile"}, "ws_layered": {"PPOAF_WS_MODE": "layered"},
+# how the epoch loop is run: the graph-replayed launch chain, its three-launch and slab forms, the PPO / ICM epochs in turn
+# instead of overlapped on two streams, and the torch-ROCm module path
+KL_PATHS = {"chain": {}, "three_launches": {"PPOAF_FUSED_TAIL": "0"}, "slabs": {"PPOAF_SPLIT_WGRAD": "0"},
             "sequential": {"PPOAF_OVERLAP_ICM": "0"}, "torch": {}}
 
 
@@ -485,15 +467,12 @@ def test_kl_early_stop_matches_the_reference(golden, name, path, monkeypatch):
     for k, v in KL_PATHS[path].items():
         monkeypatch.setenv(k, v)
     g = golden(name)
-    before = fused_update.FusedPolicyUpdate.ws_launch_count
     ppo, ran = run_kl_stop_scenario(g, name, "torch" if path == "torch" else "fused", torch.device("cuda", 0))
     assert ran == [int(x) for x in g["epochs_run"]] and ran[0] < _cfg(g)["epochs"]
     fused = ppo._fused_updater("agent", _cfg(g)["batch_size"])
     assert (fused is None) == (path == "torch")
-    if path.startswith("ws_") and "icm" not in name:
-        # the persistent kernel really was the path that ran: one launch per epoch the reference ran
-        assert fused.ws_reason() == "", fused.ws_reason()
-        assert fused_update.FusedPolicyUpdate.ws_launch_count - before == sum(ran)
+    if fused is not None:
+        assert fused.split == (path != "slabs") and (fused.tail_reason() == "") == (path not in ("slabs", "three_launches"))
 
 
 @pytest.mark.parametrize("update_mode", ["fused", "fused_slabs", "torch"])
@@ -658,26 +637,6 @@ def test_product_reproduces_the_reference_lstm_iterations(golden, name, S, n_act
     for tag, net in (("actor", pol.actor), ("critic", pol.critic)):
         check_final_weights(case, tag, np.concatenate([p.detach().cpu().numpy().reshape(-1) for k, p in net.named_parameters()]),
                             np.concatenate([g[f"final_{tag}.{k}"].reshape(-1) for k, p in net.named_parameters()]))
-
-
-@pytest.mark.parametrize("mode", ["auto", "layered", "rowtile"])
-@pytest.mark.parametrize("name", ["g12_c2_term", "g12_c2_cut", "g12_c3_gauss", "g12_c3_full", "g12_c4_mappo", "g12_gauss_bounds"] + B256)
-def test_weight_stationary_persistent_update_reproduces_the_reference(golden, name, mode, monkeypatch):
-    """
-    The weight-stationary persistent form of K12 (csrc/ppo_update_ws.hip: one launch per epoch, the mini-batch processed
-    layer by layer over all of its rows on two single-XCD worker groups, complete weight gradients, clip + Adam by the
-    column owners) against the same reference-recorded iterations: first-mini-batch losses and gradient bucket,
-    every epoch's statistics, final weights.
-    """
-    from ppo_and_friends_amd import fused_update
-    monkeypatch.setenv("PPOAF_WS", "1")
-    monkeypatch.setenv("PPOAF_WS_MODE", mode)
-    before = fused_update.FusedPolicyUpdate.ws_launch_count
-    test_product_reproduces_the_reference_ppo_iterations(golden, name, "fused")
-    # "auto" never takes the persistent kernel on one rank (round 4: a 256-wide critic runs the chain with row pairs, narrower
-    # networks the chain anyway); forced modes always
-    ran = fused_update.FusedPolicyUpdate.ws_launch_count > before
-    assert ran == (mode != "auto"), f"persistent kernel ran: {ran} (mode {mode})"
 
 
 # ---------------------------------------------------------------- unit fixtures g9 / g10 / g13 through the HIP kernels

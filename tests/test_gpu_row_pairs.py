@@ -55,7 +55,6 @@ def _run(case, pairs, monkeypatch, graphs):
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_row_pairs_are_bitwise_one_workgroup_per_tile(case, monkeypatch):
-    monkeypatch.setenv("PPOAF_WS", "0")
     ref = _run(case, False, monkeypatch, graphs=False)
     for graphs in (False, True):
         got = _run(case, True, monkeypatch, graphs=graphs)

@@ -24,17 +24,11 @@ def _free_port():
 
 
 def _rank(rank, world, port, out, mode):
-    ws_mode = None
     if mode == "peer_slabs":
         # the slab chain with K17 fused into the slab reduce launch: what N > 1 ranks ran before the fused tail launch
         # (and still run where the tail's exchange cannot be opened)
         mode = "peer"
         os.environ["PPOAF_FUSED_TAIL"] = "0"
-    if mode.startswith("peer_ws_"):
-        # the persistent two-XCD kernel with the K17 exchange as a phase of every mini-batch (forced here: at these
-        # widths `auto` keeps the chain); the ranks share one GPU, so each takes its own pair of XCDs
-        mode, ws_mode = "peer", mode[len("peer_ws_"):]
-        os.environ.update(PPOAF_WS_MODE=ws_mode, PPOAF_SHARE_DEVICE="1")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
                       PPOAF_GRAD_EXCHANGE=mode)
@@ -64,7 +58,6 @@ def _rank(rank, world, port, out, mode):
     out[rank] = dict(w0=w0, w=pol.policy_params.detach().cpu().clone(),
                      peer_exchange=[getattr(f, "xchg", None) is not None for f in fused],
                      split=[bool(f.split) for f in fused], wgrad_exchange=[getattr(f, "xchg_sp", None) is not None for f in fused],
-                     ws_exchange_launches=FusedPolicyUpdate.ws_exchange_launch_count,
                      exp_avg=pol.policy_exp_avg.detach().cpu().clone(),
                      actor_sd={k: v.detach().cpu().clone() for k, v in pol.actor.state_dict().items()},
                      critic_sd={k: v.detach().cpu().clone() for k, v in pol.critic.state_dict().items()},
@@ -79,9 +72,8 @@ def _rank(rank, world, port, out, mode):
 # "peer": K17 exchange over IPC mappings inside hipGraph-replayed chains: the split-wgrad chain whose fused tail launch
 # carries the exchange inside every weight-gradient job (ppoaf_ppo_update_wgrad_adam_exchange: two launches per
 # mini-batch); "peer_slabs": the slab chain, K17 fused into the slab reduce launch (PPOAF_FUSED_TAIL=0); "rccl":
-# the eager loop with the process group's all-reduce (gloo here, staged through the host); "peer_ws_*": K17 inside the
-# persistent two-XCD kernel (ppoaf_ppo_update_ws_exchange), both networks row-tiled / layered
-@pytest.fixture(scope="module", params=["peer", "peer_slabs", "rccl", "peer_ws_rowtile", "peer_ws_layered"])
+# the eager loop with the process group's all-reduce (gloo here, staged through the host)
+@pytest.fixture(scope="module", params=["peer", "peer_slabs", "rccl"])
 def run2(request):
     world = 2
     mgr = mp.Manager()
@@ -90,30 +82,10 @@ def run2(request):
     res = [out[r] for r in range(world)]
     for r in res:
         assert r["peer_exchange"] == [request.param.startswith("peer")], r["peer_exchange"]
-        # 2 epochs = 2 persistent launches when the exchange runs inside the kernel, none otherwise
-        assert r["ws_exchange_launches"] == (2 if request.param.startswith("peer_ws_") else 0), r["ws_exchange_launches"]
         if request.param in ("peer", "peer_slabs"):
             assert r["split"] == r["wgrad_exchange"] == [request.param == "peer"], (r["split"], r["wgrad_exchange"])
     res[0]["mode"] = request.param
     return res
-
-
-def test_rowtiled_persistent_kernel_with_exchange_is_bitwise_the_chain():
-    """K17 inside the persistent kernel (row-tiled networks) against K17 inside the graph-replayed three-launch SLAB chain:
-    the same arithmetic in the same order on both ranks -- bitwise equal parameters, moments and statistics."""
-    runs = {}
-    for mode in ("peer_slabs", "peer_ws_rowtile"):
-        mgr = mp.Manager()
-        out = mgr.dict()
-        mp.spawn(_rank, args=(2, _free_port(), out, mode), nprocs=2, join=True)
-        runs[mode] = [out[r] for r in range(2)]
-    a, b = runs["peer_slabs"], runs["peer_ws_rowtile"]
-    assert b[0]["ws_exchange_launches"] == 2 and a[0]["ws_exchange_launches"] == 0
-    for r in range(2):
-        assert torch.equal(a[r]["w"], b[r]["w"]) and torch.equal(a[r]["exp_avg"], b[r]["exp_avg"])
-        assert a[r]["stats"] == b[r]["stats"]
-        np.testing.assert_array_equal(a[r]["vn"], b[r]["vn"])
-    assert torch.equal(b[0]["w"], b[1]["w"])
 
 
 def test_ranks_start_and_stay_identical(run2):
@@ -211,8 +183,8 @@ def _fixture_rank(rank, world, port, out, name, mode):
             np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale, err_msg=f"{tag}: rank-averaged gradient")
         probe["done"] = True
 
-    # (the ICM scenario's PPO / ICM epoch pairs and the persistent kernel's own exchange object have no single-launch
-    # probe of this kind; their first mini-batch is covered by the epoch statistics)
+    # (the ICM scenario's PPO / ICM epoch pairs have no single-launch probe of this kind; their first mini-batch is covered by
+    # the epoch statistics)
     want_probe = name == "g12_c2_r2" or (name == "g12_c4_r2" and mode == "rccl")
     ppo, ran = G.run_kl_stop_scenario(g, name, "fused", dev, first_minibatch=first_minibatch if want_probe else None)
     pol = ppo.policies["agent"]
@@ -220,7 +192,6 @@ def _fixture_rank(rank, world, port, out, name, mode):
     out[rank] = dict(ran=ran, probe=bool(probe), w=pol.policy_params.detach().cpu().clone(),
                      w_icm=pol.icm_model.flat_params.detach().cpu().clone() if pol.enable_icm else None,
                      peer_exchange=[getattr(f, "xchg", None) is not None for f in fused],
-                     ws_exchange_launches=FusedPolicyUpdate.ws_exchange_launch_count,
                      kl=float(ppo.status_dict["agent"]["kl avg"]))
     dist.barrier()
     dist.destroy_process_group()
@@ -235,8 +206,8 @@ def test_two_ranks_reproduce_two_ranks_of_the_reference(name, mode):
     block, the rank-averaged first-mini-batch gradient (mpi_avg_gradients, utils/mpi_utils.py:89-111), every epoch's
     all-reduced statistics (ppo.py:2468-2475) and the value normaliser fed with both ranks' data (utils/stats.py:47-50),
     the KL early stop taken by both ranks after the same epoch (ppo.py:2221-2232; g12_c2_icm_r2_klstop: after 3 of 4
-    epochs), final weights.  `peer`: the K17 exchange (inside graph-replayed chains; inside the persistent two-XCD kernel
-    for the 256-wide critic of g12_c4_r2; PPO and ICM epochs overlapped on two streams); `rccl`: the all-reduce loops.
+    epochs), final weights.  `peer`: the K17 exchange inside graph-replayed chains (the 256-wide critic of g12_c4_r2 on
+    workgroup pairs; PPO and ICM epochs overlapped on two streams); `rccl`: the all-reduce loops.
     All fixture checks run inside the rank processes (test_gpu_reference_golden.run_kl_stop_scenario).
     """
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"), allow_pickle=False)
@@ -253,8 +224,6 @@ def test_two_ranks_reproduce_two_ranks_of_the_reference(name, mode):
     assert torch.equal(r0["w"], r1["w"]), "synchronous DD-PPO keeps replicas identical"
     if r0["w_icm"] is not None:
         assert torch.equal(r0["w_icm"], r1["w_icm"])
-    if name == "g12_c4_r2" and mode == "peer":
-        assert r0["ws_exchange_launches"] > 0, "256-wide critic at N > 1: the exchange runs inside the persistent kernel"
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -263,7 +232,7 @@ def test_two_ranks_reproduce_two_ranks_of_the_reference(name, mode):
 def _rank_kind(rank, world, port, out, mode, kind):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PPOAF_GRAD_EXCHANGE=mode,
-                      PPOAF_SHARE_DEVICE="1")          # one GPU for both ranks: each persistent kernel on its own XCD pair
+                      PPOAF_SHARE_DEVICE="1")          # one GPU for both ranks
     import torch.distributed as dist
     from ppo_and_friends_amd.utils import mpi_utils
     mpi_utils.init_process_group_from_env(backend="gloo")
@@ -271,9 +240,7 @@ def _rank_kind(rank, world, port, out, mode, kind):
     from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
     from ppo_and_friends_amd.spaces import Box, Discrete
     dev = torch.device("cuda", 0)
-    if kind == "wide_chain":                                 # the same shape on the launch chain (tail / ICM-overlapped epochs)
-        os.environ["PPOAF_WS"] = "0"
-    if kind in ("wide", "wide_chain"):
+    if kind == "wide":
         # C4 shape: 3 agents share the policy, 128-wide actor, 256-wide critic on the concatenated observations
         # (bucket of ~180k floats: 176 exchange groups)
         E_, T_, O_, NA_, B_, A_ = 8, 32, 18, 5, 32, 3
@@ -302,7 +269,6 @@ def _rank_kind(rank, world, port, out, mode, kind):
     fused = [f for f in getattr(ppo, "_fused", {}).values() if f is not None]
     from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
     res = dict(peer_exchange=[getattr(f, "xchg", None) is not None for f in fused],
-               ws_exchange_launches=FusedPolicyUpdate.ws_exchange_launch_count,
                split=[bool(getattr(f, "split", False)) for f in fused],
                stats={k: float(v) for k, v in ppo.status_dict["p"].items()
                       if isinstance(v, (int, float)) and not isinstance(v, bool)})
@@ -317,7 +283,7 @@ def _rank_kind(rank, world, port, out, mode, kind):
         ppo.rollout()
         ppo.train_on_rollout()                                       # continues on the all-reduce path
         res["w"] = pol.policy_params.detach().cpu().clone()
-    elif kind in ("wide", "wide_chain"):
+    elif kind == "wide":
         res["w"] = pol.policy_params.detach().cpu().clone()
     elif kind == "icm":
         res["w"] = pol.policy_params.detach().cpu().clone()
@@ -329,7 +295,7 @@ def _rank_kind(rank, world, port, out, mode, kind):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["icm", "mat", "wide", "wide_chain"])
+@pytest.mark.parametrize("kind", ["icm", "mat", "wide"])
 def test_peer_exchange_equals_allreduce_path(kind):
     runs = {}
     for mode in ("peer", "rccl"):
@@ -340,16 +306,14 @@ def test_peer_exchange_equals_allreduce_path(kind):
         r0, r1 = runs[mode]
         assert r0["peer_exchange"] and all(x == (mode == "peer") for x in r0["peer_exchange"]), r0["peer_exchange"]
         assert torch.equal(r0["w"], r1["w"]), f"{mode}: replicas identical"
-        # the 256-wide critic puts the update on the persistent two-XCD kernel: with ranks, the exchange runs inside it
-        assert r0["ws_exchange_launches"] == (2 if (kind, mode) == ("wide", "peer") else 0), r0["ws_exchange_launches"]
         if kind == "icm":
             assert torch.equal(r0["w_icm"], r1["w_icm"])
-        if kind == "wide_chain":
+        if kind == "wide":
             # with K17 the 256-wide critic's chain is the split-wgrad chain + an exchange launch; the all-reduce loop keeps slabs
             assert r0["split"] == [mode == "peer"], r0["split"]
     a, b = runs["peer"][0], runs["rccl"][0]
-    # (wide_chain compares the split-wgrad chain with the slab chain: the same sums in another association)
-    wtol = dict(rtol=1e-4, atol=2e-5) if kind == "wide_chain" else dict(rtol=1e-5, atol=1e-6)
+    # (wide compares the split-wgrad chain with the slab chain: the same sums in another association)
+    wtol = dict(rtol=1e-4, atol=2e-5) if kind == "wide" else dict(rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(a["w"], b["w"], **wtol)
     if kind == "icm":
         torch.testing.assert_close(a["w_icm"], b["w_icm"], rtol=1e-5, atol=1e-6)

@@ -9,7 +9,6 @@ from ppo_and_friends_amd import fused_update
 from ppo_and_friends_amd.ppo import PPO, PermutationLoader
 from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
 from ppo_and_friends_amd.spaces import Box, Discrete
-os.environ["PPOAF_WS"] = "0"
 pairs = os.environ.get("PAIRS", "1") == "1"
 fused_update.FusedPolicyUpdate.row_pairs = pairs
 dev = torch.device('cuda', 0); E, T, O = 1024, 128, 17

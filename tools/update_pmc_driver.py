@@ -29,25 +29,20 @@ N = pol.buffer.num_transitions if not pol.agent_grouping else len(pol.dataset)
 perm = torch.randperm(len(pol.dataset), device=dev)
 
 
-def eager(fused, n_mb, force_chain=False):
+def eager(fused, n_mb):
     fused.begin_epoch(perm)
     keep = (fused.n_full, fused.tail)
     fused.n_full, fused.tail = n_mb, 0
-    if force_chain:
-        os.environ["PPOAF_WS"] = "0"
     try:
         fused.run_epoch()
         torch.cuda.synchronize()
     finally:
-        os.environ.pop("PPOAF_WS", None)
         fused.n_full, fused.tail = keep
 
 
 fused = ppo._fused_updater("cartpole", B)
 assert fused is not None
 eager(fused, n)
-if a.config in ("C3", "C4"):                               # the three-launch chain of the same shapes (C3's overlapped epochs run it)
-    eager(fused, n, force_chain=True)
 if pol.enable_icm:
     icm = ppo._fused_icm_updater("cartpole")
     icm.begin_epoch(perm)
