@@ -37,8 +37,8 @@ __global__ __launch_bounds__(kThreadsU) void ppo_update_fwd_bwd_kernel(UpdateDev
         g = ((b >> 3) << 1) | (x & 1);
     }
     if (g >= u.n_wg) return;                               // uniform per workgroup, before any barrier
-    if (which == 0) ppo_update_fwd_bwd_body<HTA, false, UpdateDev, RowtileNoHook, SPLIT>(u, 0, g);
-    else ppo_update_fwd_bwd_body<HTC, false, UpdateDev, RowtileNoHook, SPLIT>(u, 1, g);
+    if (which == 0) ppo_update_fwd_bwd_body<HTA, SPLIT>(u, 0, g);
+    else ppo_update_fwd_bwd_body<HTC, SPLIT>(u, 1, g);
 }
 
 // args->row_pairs (split-wgrad chain): a 256-wide network's row tiles on pairs of workgroups (ppo_update_rowpair.hpp); the
@@ -60,10 +60,10 @@ __global__ __launch_bounds__(kThreadsU) void ppo_update_fwd_bwd_pair_kernel(Upda
     if (g >= u.n_wg) return;                               // uniform per workgroup, before any barrier
     if (which == 0) {
         if constexpr (HTA == 16) ppo_update_fwd_bwd_pair_body<16>(u, 0, g, hf, pd);
-        else ppo_update_fwd_bwd_body<HTA, false, UpdateDev, RowtileNoHook, true>(u, 0, g);
+        else ppo_update_fwd_bwd_body<HTA, true>(u, 0, g);
     } else {
         if constexpr (HTC == 16) ppo_update_fwd_bwd_pair_body<16>(u, 1, g, hf, pd);
-        else ppo_update_fwd_bwd_body<HTC, false, UpdateDev, RowtileNoHook, true>(u, 1, g);
+        else ppo_update_fwd_bwd_body<HTC, true>(u, 1, g);
     }
 }
 

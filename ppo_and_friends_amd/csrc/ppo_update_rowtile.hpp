@@ -1,6 +1,4 @@
-// The row-tiled forward + backward of one 16-row block of one network (K12's fwd_bwd kernel body), shared by the
-// three-launch chain / its single-XCD persistent form (ppo_update.hip) and the row-tiled mode of the two-XCD persistent
-// kernel (ppo_update_ws.hip).
+// The row-tiled forward + backward of one 16-row block of one network (K12's fwd_bwd kernel body; ppo_update.hip).
 #pragma once
 #include "ppo_update_dev.hpp"
 
@@ -28,23 +26,14 @@ static __device__ unsigned long long g_ppo_update_stamps[2][16];
 #endif
 
 
-// NT = true (single-XCD persistent kernel): everything another CU of the same launch rewrites between mini-batches --
-// the parameter bucket, the value-normaliser slots -- is read with L1-bypassing loads; mb_extra = the mini-batch's
-// position inside the launch's chunk.
-// `before_weights` (persistent forms only, NT = true): called once by every thread after the mini-batch's row / index /
-// statistics loads and BEFORE the first load of a parameter -- the two-XCD kernel waits there for the previous
-// mini-batch's Adam phase, so that barrier's latency overlaps the dependent index loads.  Returning false abandons the
-// body (a bounded wait ran out).
 // SPLIT = true (split-wgrad chain): the body keeps forward, losses and dgrad, but computes NO weight gradient of a hidden
 // layer.  It publishes what a complete-K wgrad launch needs instead -- its 16 rows of the input x, of every hidden
 // activation h_l and of every dLoss/dz_l (u.sp: hbuf / dbuf / xbuf planes, 16 KB per layer per workgroup at H = 128
 // against a 135 KB slab) -- and the output layer's partials go to u.sp.outpart (folded in block order by that launch).
-struct RowtileNoHook { __device__ __forceinline__ bool operator()() const { return true; } };
 
-// A forward weight set of one output tile.  Separate launches (NT = false): requested as whole lines and turned into
-// fragment order through the wave's LDS slots when consumed (mlp_device.hpp: mfma_rows_x_lines; one CU's L1 delivers
-// the fragment pattern itself at a third of that rate).  Persistent forms (NT = true): agent-scope 16-byte loads in
-// fragment order, as before.  Same MFMA operands in the same order either way.
+// A forward weight set of one output tile: requested as whole lines and turned into fragment order through the wave's LDS
+// slots when consumed (mlp_device.hpp: mfma_rows_x_lines; one CU's L1 delivers the fragment pattern itself at a third of
+// that rate).  (NT = true: agent-scope loads in fragment order -- the removed persistent forms.)
 template <int HT, bool NT>
 __device__ __forceinline__ void load_fwd_set(const float* __restrict__ W, int n0, int lane, float4 (&fr)[HT]) {
     if constexpr (NT) load_fwd_frags<HT, true>(W, n0, lane, fr);
@@ -57,9 +46,12 @@ __device__ __forceinline__ f32x4 mfma_fwd_set(const float* __restrict__ A, int H
     else return mfma_rows_x_lines<HT>(A, HS, lane, fr, init, scratch);
 }
 
-template <int HT, bool NT = false, typename U = UpdateDev, typename Hook = RowtileNoHook, bool SPLIT = false>
-__device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int which, const int g,
-                                                        const long mb_extra = 0, Hook before_weights = Hook()) {
+template <int HT, bool SPLIT = false>
+__device__ __forceinline__ void ppo_update_fwd_bwd_body(const UpdateDev& u, const int which, const int g) {
+    // (NT, mb_extra: what the persistent forms of rounds 2-3 set -- loads at agent scope, the mini-batch's position inside a
+    //  launch; the forms are gone, the constants keep the body's text as it was measured)
+    constexpr bool NT = false;
+    constexpr long mb_extra = 0;
     constexpr int H = 16 * HT, HS = H + 4;                 // which: 0 actor, 1 critic; g: 16-row block
     int tid_ = threadIdx.x;
     if (NT) {     // persistent form: nothing derived from the lane id may be hoisted out of the caller's mini-batch loop
@@ -260,10 +252,6 @@ __device__ __forceinline__ void ppo_update_fwd_bwd_body(const U& u, const int wh
             sMisc[2] = m; sMisc[3] = v;
             if (g == 0) { u.vn_mean[slot ^ 1] = m; u.vn_var[slot ^ 1] = v; u.vn_count[slot ^ 1] = cnt; }
         }
-    }
-    if (NT) {
-        if (!before_weights()) return;
-        request_weights();
     }
     if (copy_fits) {
 #pragma unroll
