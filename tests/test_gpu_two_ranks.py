@@ -240,15 +240,18 @@ def _rank_kind(rank, world, port, out, mode, kind):
     from ppo_and_friends_amd.environments.synthetic import SyntheticFixedLengthEnv
     from ppo_and_friends_amd.spaces import Box, Discrete
     dev = torch.device("cuda", 0)
-    if kind == "wide":
-        # C4 shape: 3 agents share the policy, 128-wide actor, 256-wide critic on the concatenated observations
-        # (bucket of ~180k floats: 176 exchange groups)
+    if kind in ("wide", "wide_tail"):
+        # C4 shape: 3 agents share the policy, 128-wide actor, 256-wide critic on the concatenated observations.  "wide": 369
+        # weight-gradient workgroups per rank -- two ranks on ONE GPU cannot keep 2 x 369 resident, so the chain ends in the wgrad
+        # launch + a K17 launch + Adam (on a node: the fused tail).  "wide_tail": shallower networks (170 workgroups per rank), so
+        # that the two ranks here DO run the path a node runs -- row pairs + the fused tail launch with the exchange inside
         E_, T_, O_, NA_, B_, A_ = 8, 32, 18, 5, 32, 3
         env_gen = lambda: SyntheticFixedLengthEnv(E_, O_, Discrete(NA_), T_, dev, reward="uniform", seed=79, rank=rank,
                                                   num_agents=A_, critic_view="policy")
         sp, csp = Box(-np.inf, np.inf, (O_,), np.float32), Box(-np.inf, np.inf, (A_ * O_,), np.float32)
-        settings = {"p": (None, sp, csp, Discrete(NA_), dict(actor_kw_args=dict(hidden_size=128),
-                                                             critic_kw_args=dict(hidden_size=256)))}
+        depths = (1, 2) if kind == "wide_tail" else (3, 3)
+        settings = {"p": (None, sp, csp, Discrete(NA_), dict(actor_kw_args=dict(hidden_size=128, hidden_depth=depths[0]),
+                                                             critic_kw_args=dict(hidden_size=256, hidden_depth=depths[1])))}
     elif kind in ("icm", "guard"):
         E_, T_, O_, NA_, B_ = 16, 64, 6, 3, 16                 # 64 mini-batches per epoch: two graph chunks
         env_gen = lambda: SyntheticFixedLengthEnv(E_, O_, Discrete(NA_), T_, dev, reward="uniform", seed=77, rank=rank)
@@ -270,6 +273,8 @@ def _rank_kind(rank, world, port, out, mode, kind):
     from ppo_and_friends_amd.fused_update import FusedPolicyUpdate
     res = dict(peer_exchange=[getattr(f, "xchg", None) is not None for f in fused],
                split=[bool(getattr(f, "split", False)) for f in fused],
+               tail=[f.tail_reason() == "" for f in fused if hasattr(f, "tail_reason")],
+               pairs=[f.pairs_reason() == "" for f in fused if hasattr(f, "pairs_reason")],
                stats={k: float(v) for k, v in ppo.status_dict["p"].items()
                       if isinstance(v, (int, float)) and not isinstance(v, bool)})
     if kind == "guard":
@@ -283,7 +288,7 @@ def _rank_kind(rank, world, port, out, mode, kind):
         ppo.rollout()
         ppo.train_on_rollout()                                       # continues on the all-reduce path
         res["w"] = pol.policy_params.detach().cpu().clone()
-    elif kind == "wide":
+    elif kind in ("wide", "wide_tail"):
         res["w"] = pol.policy_params.detach().cpu().clone()
     elif kind == "icm":
         res["w"] = pol.policy_params.detach().cpu().clone()
@@ -295,7 +300,7 @@ def _rank_kind(rank, world, port, out, mode, kind):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["icm", "mat", "wide"])
+@pytest.mark.parametrize("kind", ["icm", "mat", "wide", "wide_tail"])
 def test_peer_exchange_equals_allreduce_path(kind):
     runs = {}
     for mode in ("peer", "rccl"):
@@ -308,12 +313,14 @@ def test_peer_exchange_equals_allreduce_path(kind):
         assert torch.equal(r0["w"], r1["w"]), f"{mode}: replicas identical"
         if kind == "icm":
             assert torch.equal(r0["w_icm"], r1["w_icm"])
-        if kind == "wide":
-            # with K17 the 256-wide critic's chain is the split-wgrad chain + an exchange launch; the all-reduce loop keeps slabs
-            assert r0["split"] == [mode == "peer"], r0["split"]
+        if kind in ("wide", "wide_tail"):
+            # with K17 the 256-wide critic runs the split-wgrad chain on row pairs (+ an exchange launch, or the fused tail with the
+            # exchange inside where both ranks' launches fit the one GPU); the all-reduce loop keeps slabs
+            assert r0["split"] == [mode == "peer"] and r0["pairs"] == [mode == "peer"], (r0["split"], r0["pairs"])
+            assert r0["tail"] == [mode == "peer" and kind == "wide_tail"], r0["tail"]
     a, b = runs["peer"][0], runs["rccl"][0]
     # (wide compares the split-wgrad chain with the slab chain: the same sums in another association)
-    wtol = dict(rtol=1e-4, atol=2e-5) if kind == "wide" else dict(rtol=1e-5, atol=1e-6)
+    wtol = dict(rtol=1e-4, atol=2e-5) if kind in ("wide", "wide_tail") else dict(rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(a["w"], b["w"], **wtol)
     if kind == "icm":
         torch.testing.assert_close(a["w_icm"], b["w_icm"], rtol=1e-5, atol=1e-6)
